@@ -1,0 +1,156 @@
+/*
+ * include/kmc_hip.h — C-ABI of libkmc_hip.so: KMC stage-2 "bin sort & count" on MI355X (gfx950).
+ *
+ * This is the drop-in boundary. Plain C: pointers + sizes, no C++/torch types.
+ * Every entry point names the reference interface it replaces (paths relative to the KMC 3.2.4
+ * tree, /root/reference). The C++ worker that binds these inside kmc_core is
+ * kmc_amd/host/kb_sorter_plugin.h; INTEGRATION.md shows the maintainer-side change.
+ *
+ * Conventions
+ *   - return 0 on success, a negative KMC_HIP_E* code on failure; never throws, never aborts.
+ *     kmc_hip_last_error(ctx) gives the message (the worker forwards it to
+ *     CCriticalErrorHandler::HandleCriticalError, critical_error_handler.h:9-90).
+ *   - `dev` is an index into the device list given to kmc_hip_init (not a HIP ordinal).
+ *   - one host thread per `dev` may call concurrently (mirrors one CWKmerBinSorter thread per
+ *     sorter, kmc.h:1576-1584); calls on the same `dev` must be serialised by the caller.
+ *   - host buffers belong to the caller; device memory, streams and events belong to the library.
+ *   - records are CKmer<SIZE> PODs (kmer.h:22-67): `words` x uint64, word 0 least significant.
+ */
+#ifndef KMC_HIP_H
+#define KMC_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define KMC_HIP_ABI_VERSION 1
+
+enum {
+	KMC_HIP_OK = 0,
+	KMC_HIP_EINVAL = -1,   /* bad argument / unsupported parameter combination */
+	KMC_HIP_EDEVICE = -2,  /* HIP runtime error (message has the hipError string) */
+	KMC_HIP_ENOMEM = -3,   /* device or pinned-host allocation failed */
+	KMC_HIP_ECORRUPT = -4, /* super-k-mer stream is ragged or disagrees with n_rec / pack sizes */
+	KMC_HIP_ECAPACITY = -5,/* out_capacity too small for the counted k-mers */
+	KMC_HIP_EINTERNAL = -6 /* device-side watchdog tripped (look-back spin bound) */
+};
+
+typedef struct kmc_hip_ctx kmc_hip_ctx;
+
+/* Per-run constants the reference sorter copies out of CKMCParams (kb_sorter.h:165-200). */
+typedef struct kmc_hip_bin_params {
+	uint32_t kmer_len;       /* Params.kmer_len, 1..256 */
+	uint32_t both_strands;   /* Params.both_strands: 1 = canonical k-mers */
+	uint32_t cutoff_min;     /* Params.cutoff_min */
+	uint32_t without_output; /* Params.without_output: tallies only, out_bytes = 0, lut untouched */
+	uint64_t cutoff_max;     /* Params.cutoff_max (compared as uint32, kb_sorter.h:186) */
+	uint64_t counter_max;    /* Params.counter_max */
+	uint32_t lut_prefix_len; /* Params.lut_prefix_len (kmc.h:1434-1469); 0 for KFF */
+	uint32_t output_type;    /* 0 = OutputType::KMC, 1 = OutputType::KFF (kb_sorter.h:1043-1049) */
+} kmc_hip_bin_params;
+
+/* stats[] order == the four tallies of CKmerQueue::push (queues.h:826, kb_sorter.h:1273) */
+enum { KMC_HIP_STAT_UNIQUE = 0, KMC_HIP_STAT_CUTOFF_MIN = 1, KMC_HIP_STAT_CUTOFF_MAX = 2, KMC_HIP_STAT_TOTAL = 3 };
+
+/* ---- lifetime ----------------------------------------------------------------------------- */
+
+/* Create a context on `n_dev` HIP devices (ordinals in device_ids; NULL => {0..n_dev-1}).
+ * Replaces: construction of CWKmerBinSorter<SIZE> workers + pmm_radix_buf pool (kmc.h:1510,1576-1584). */
+int kmc_hip_init(const int *device_ids, int n_dev, kmc_hip_ctx **out);
+void kmc_hip_destroy(kmc_hip_ctx *ctx);
+const char *kmc_hip_last_error(kmc_hip_ctx *ctx); /* thread-local message of the calling thread's last failure */
+int kmc_hip_abi_version(void);
+int kmc_hip_num_devices(kmc_hip_ctx *ctx);
+
+/* Derived sizes, so callers size buffers exactly like kb_reader.h:141-165 does. */
+uint32_t kmc_hip_words(uint32_t kmer_len);                                   /* SIZE = ceil(k/32) */
+uint32_t kmc_hip_counter_size(uint64_t cutoff_max, uint64_t counter_max);    /* defs.h:154-159 */
+uint32_t kmc_hip_out_rec_bytes(const kmc_hip_bin_params *p);                 /* suffix bytes + counter bytes */
+uint64_t kmc_hip_lut_entries(const kmc_hip_bin_params *p);                   /* 4^p, 0 when p == 0 */
+
+/* ---- narrow boundary: the sort alone ------------------------------------------------------- */
+
+/* Ascending sort of n records of `words` uint64 by their low `key_bytes` bytes (higher bytes must be
+ * zero), result left IN `recs` (host memory).
+ * Replaces: SortFunction<CKmer<SIZE>> (raduls.h:19-20) = RadulsSort::RadixSortMSD_* (raduls_impl.h:769-776)
+ * / RadixSort::RadixSortMSD (radix.h:845-852) as called at kb_sorter.h:775; key_bytes = rec_len there.
+ * (The reference leaves the result in `tmp` when rec_len is odd; this entry always returns it in place.) */
+int kmc_hip_sort_records(kmc_hip_ctx *ctx, int dev, void *recs, uint64_t n, uint32_t words, uint32_t key_bytes);
+
+/* Same, on device-resident records (d_recs, d_tmp: n*words*8 bytes each, 256-B aligned). On return
+ * *d_result points at whichever of the two holds the sorted records. Stream-synchronous. */
+int kmc_hip_sort_records_device(kmc_hip_ctx *ctx, int dev, void *d_recs, void *d_tmp, uint64_t n, uint32_t words,
+                                uint32_t key_bytes, void **d_result);
+
+/* ---- full boundary: one bin, super-k-mer bytes in -> (suffix,count) records + LUT + tallies out --- */
+
+/* Replaces: one iteration of CKmerBinSorter<SIZE>::ProcessBins (kb_sorter.h:210-237) = Expand (:728-752)
+ * + Sort (:757-780) + Compact (:1287; CompactKmers :1128-1281 / CompactKxmers :937-1122), i.e. everything
+ * between sorters_manager->GetNext (queues.h:2087) and kq->push (queues.h:826).
+ *   superkmers/size : the bin image CKmerBinReader read (kb_reader.h:176-190); format kb_collector.cpp:57-71
+ *   n_rec           : CBinDesc n_rec of the bin (number of k-mers)
+ *   pack_bytes/n_packs : byte length of each expander pack, in order (CExpanderPackDesc::pop, queues.h:390;
+ *                     first member of each pair). n_packs == 0 => the library finds pack boundaries itself.
+ *   out_suffix/out_capacity : the bin's mba_suffix slot; capacity as kb_reader.h:141-150
+ *   out_bytes       : bytes written = the single data pack [0, out_bytes) pushed to kq
+ *   lut             : the bin's mba_lut slot, kmc_hip_lut_entries() uint64, per-bin COUNTS (the completer makes
+ *                     them cumulative, kb_completer.cpp:193-199); zero-filled by the callee
+ *   stats           : {n_unique, n_cutoff_min, n_cutoff_max, n_total}
+ * out_suffix / lut MAY alias superkmers (they do in the reference arena when rec_len is even,
+ * queues.h:1352-1369): all input is on the device before the first output byte is written.
+ * Empty bins (size == 0, n_rec == 0) are valid and produce zeros. */
+int kmc_hip_process_bin(kmc_hip_ctx *ctx, int dev, const kmc_hip_bin_params *params, const uint8_t *superkmers,
+                        uint64_t size, uint64_t n_rec, const uint64_t *pack_bytes, uint64_t n_packs,
+                        uint8_t *out_suffix, uint64_t out_capacity, uint64_t *out_bytes, uint64_t *lut,
+                        uint64_t stats[4]);
+
+/* Asynchronous pair for double buffering: _submit enqueues H2D + kernels + D2H on the device's stream slot
+ * `slot` (0 or 1) and returns; _wait blocks until that slot's bin is complete and fills out_bytes/stats.
+ * Host buffers must stay valid (and out must not alias in) until _wait returns. */
+int kmc_hip_process_bin_submit(kmc_hip_ctx *ctx, int dev, int slot, const kmc_hip_bin_params *params,
+                               const uint8_t *superkmers, uint64_t size, uint64_t n_rec, const uint64_t *pack_bytes,
+                               uint64_t n_packs, uint8_t *out_suffix, uint64_t out_capacity, uint64_t *lut);
+int kmc_hip_process_bin_wait(kmc_hip_ctx *ctx, int dev, int slot, uint64_t *out_bytes, uint64_t stats[4]);
+
+/* Device-resident variant (inputs already in HBM; used by bench.py so the timed region excludes PCIe, and by
+ * callers that produce bins on the GPU). All d_* pointers are device memory on `dev`:
+ *   d_superkmers[size (+16 B readable slack)], d_pack_start[n_packs+1] = byte offsets of pack starts, last = size
+ *   d_out[out_capacity], d_lut[kmc_hip_lut_entries()], d_stats[4] (uint64, written by the device)
+ *   d_out_bytes: 1 uint64 written by the device.
+ * Returns after enqueueing unless `sync` != 0. */
+int kmc_hip_process_bin_device(kmc_hip_ctx *ctx, int dev, const kmc_hip_bin_params *params,
+                               const uint8_t *d_superkmers, uint64_t size, uint64_t n_rec,
+                               const uint64_t *d_pack_start, uint64_t n_packs, uint8_t *d_out, uint64_t out_capacity,
+                               uint64_t *d_out_bytes, uint64_t *d_lut, uint64_t *d_stats, int sync);
+
+/* ---- end-of-run tallies ---------------------------------------------------------------------- */
+
+/* Sum stats[4] over the context's devices with one RCCL all-reduce (ncclUint64 x 4, ncclSum) over xGMI.
+ * in/out: per_dev_stats[n_dev][4] host array -> every row holds the sum. With one device this is a device
+ * round-trip through the same code path. Replaces: the completer's running sums n_unique.. (kb_completer.cpp:206-209)
+ * when bins are sharded over GPUs. */
+int kmc_hip_allreduce_stats(kmc_hip_ctx *ctx, uint64_t *per_dev_stats);
+
+/* ---- instrumentation --------------------------------------------------------------------------- */
+
+/* Per-phase device time of the last completed bin on (dev): ms[0]=index (pack scan), [1]=expand, [2]=histogram,
+ * [3]=radix scatter passes, [4]=compact, [5]=total enqueue->done; measured with hipEvents on the bin's stream.
+ * Replaces: USE_TIMERS / MEASURE_TIMES compile-time probes (raduls_impl.h:30,567-657). */
+int kmc_hip_last_timings(kmc_hip_ctx *ctx, int dev, float ms[6]);
+/* Number of radix scatter launches and their summed duration for the last bin (roofline input for bench.py). */
+int kmc_hip_last_scatter_stats(kmc_hip_ctx *ctx, int dev, uint32_t *n_launches, float *total_ms, uint64_t *keys_per_launch);
+/* Device memory helpers so non-HIP callers (ctypes tests, the C++ worker) need not link HIP themselves. */
+int kmc_hip_malloc(kmc_hip_ctx *ctx, int dev, uint64_t bytes, void **d_ptr);
+int kmc_hip_free(kmc_hip_ctx *ctx, int dev, void *d_ptr);
+int kmc_hip_memcpy_h2d(kmc_hip_ctx *ctx, int dev, void *d_dst, const void *src, uint64_t bytes);
+int kmc_hip_memcpy_d2h(kmc_hip_ctx *ctx, int dev, void *dst, const void *d_src, uint64_t bytes);
+int kmc_hip_host_register(kmc_hip_ctx *ctx, void *ptr, uint64_t bytes);   /* pin the caller's arena (CMemoryBins buffer) */
+int kmc_hip_host_unregister(kmc_hip_ctx *ctx, void *ptr);
+int kmc_hip_synchronize(kmc_hip_ctx *ctx, int dev);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* KMC_HIP_H */

@@ -1,0 +1,231 @@
+/*
+ * kmc_amd/host/kb_sorter_plugin.h — the stage-2 worker of kmc_core, re-implemented over a bin engine.
+ *
+ * Drop-in for the reference's kmc_core/kb_sorter.h: it defines the same class template
+ *     template <unsigned SIZE> class CWKmerBinSorter      (reference: kb_sorter.h:1298-1322)
+ * with the same constructor, operator()() and GetDebugStats(), so CKMC<SIZE>::ProcessStage2_impl
+ * (kmc.h:1576-1584, :1736-1741) builds against it unchanged. Instead of Expand/Sort/Compact on the CPU
+ * (kb_sorter.h:223-231) each bin is handed to a KmcBinEngine (bin_engine.h): the HIP engine behind
+ * include/kmc_hip.h, or — in the oracle-pinning build only — oracle/stage2_oracle.c.
+ *
+ * How it is compiled in (oracle/Makefile): kmc_runner.cpp, the one translation unit that
+ * instantiates CKMC<SIZE>, is compiled with
+ *     -D_KB_SORTER_H  -include kmc_amd/host/kb_sorter_plugin.h  -I <kmc_core>
+ * so the reference's own `#include "kb_sorter.h"` (kmc.h:30) is skipped by its include guard and this
+ * definition is the one seen. No reference source is modified or copied.
+ *
+ * Protocol obligations kept (SURVEY.md §8b "Full boundary"):
+ *   per bin : sorters_manager->GetNext (queues.h:2087) -> bd->read (queues.h:654) -> epd->pop (queues.h:390)
+ *             -> reserve mba_suffix / mba_lut -> engine -> free mba_input_file, mba_input_array, mba_tmp_array,
+ *             mba_kxmer_counters -> exactly one kq->push (queues.h:826), also for empty bins
+ *             -> sorters_manager->ReturnThreads (queues.h:2130)
+ *   per run : kq->mark_completed() once per worker (kb_sorter.h:236)
+ *   errors  : CCriticalErrorHandler::Inst().HandleCriticalError(msg) (critical_error_handler.h)
+ *   order   : bins are pushed in the order GetNext hands them out, so with one worker (-sr1) the
+ *             .kmc_pre/.kmc_suf bytes equal the reference's -sr1 bytes (SURVEY.md §4 determinism finding).
+ */
+#ifndef KMC_AMD_KB_SORTER_PLUGIN_H
+#define KMC_AMD_KB_SORTER_PLUGIN_H
+
+/* the headers kb_sorter.h would have pulled in for the rest of kmc.h (kb_sorter.h:16-34) */
+#include "defs.h"
+#include "params.h"
+#include "kmer.h"
+#include "raduls.h"
+#include "radix.h"
+#include "s_mapper.h"
+#include <string>
+#include <algorithm>
+#include <numeric>
+#include <array>
+#include <vector>
+#include <stdio.h>
+#include <functional>
+#include <cstddef>
+#include <set>
+#include <atomic>
+#include <memory>
+#include <sstream>
+#include "kxmer_set.h"
+#include "rev_byte.h"
+#include "critical_error_handler.h"
+
+#include "bin_engine.h"
+
+#ifdef KMC_PLUGIN_ENGINE_ORACLE
+#include "stage2_oracle.h"
+#include <cstdlib>
+#include <cstring>
+/* TEST-ONLY engine: the CPU restatement, optionally teeing every bin (input image + outputs) to
+ * $KMC_BIN_DUMP so tests/golden fixtures can be cut from real reference stage-1 bins. */
+struct KmcOracleEngine : KmcBinEngine {
+	std::string err;
+	int process_bin(const kmc_hip_bin_params &p, const uint8_t *sk, uint64_t size, uint64_t n_rec,
+	                const uint64_t *pack_bytes, uint64_t n_packs, uint8_t *out, uint64_t cap, uint64_t *out_bytes,
+	                uint64_t *lut, uint64_t stats[4]) override
+	{
+		oracle_params op;
+		op.kmer_len = p.kmer_len;
+		op.both_strands = p.both_strands;
+		op.cutoff_min = p.cutoff_min;
+		op.without_output = p.without_output;
+		op.cutoff_max = p.cutoff_max;
+		op.counter_max = p.counter_max;
+		op.lut_prefix_len = p.lut_prefix_len;
+		op.output_type = p.output_type;
+		const char *dump = getenv("KMC_BIN_DUMP");
+		std::vector<uint8_t> copy;
+		if (dump)
+			copy.assign(sk, sk + size); /* out may alias sk */
+		int rc = oracle_process_bin(&op, sk, size, n_rec, out, cap, out_bytes, lut, stats);
+		if (rc) {
+			err = "oracle_process_bin failed, code " + std::to_string(rc);
+			return rc;
+		}
+		if (dump) {
+			static std::mutex mtx;
+			std::lock_guard<std::mutex> lck(mtx);
+			FILE *f = fopen(dump, "ab");
+			if (f) {
+				uint64_t lut_n = p.lut_prefix_len ? 1ull << (2 * p.lut_prefix_len) : 0;
+				uint64_t hdr[8] = {0x4B4D4342494E3031ull /* "KMCBIN01" */, size, n_rec, n_packs, *out_bytes, lut_n, 0, 0};
+				fwrite(hdr, 8, 8, f);
+				fwrite(&p, sizeof p, 1, f);
+				fwrite(stats, 8, 4, f);
+				fwrite(pack_bytes, 8, n_packs, f);
+				fwrite(copy.data(), 1, size, f);
+				fwrite(out, 1, *out_bytes, f);
+				fwrite(lut, 8, lut_n, f);
+				fclose(f);
+			}
+		}
+		return 0;
+	}
+	std::string last_error() override { return err; }
+};
+inline KmcBinEngine *kmc_make_bin_engine(int, int) { return new KmcOracleEngine(); }
+#endif
+
+template <unsigned SIZE> class CWKmerBinSorter {
+	CBinDesc *bd;
+	CExpanderPackDesc *epd;
+	CKmerQueue *kq;
+	CMemoryBins *memory_bins;
+	CSortersManager *sorters_manager;
+
+	kmc_hip_bin_params bp;
+	uint32 max_x;
+	uint64 sum_n_rec = 0, sum_n_plus_x_rec = 0;
+	int worker_idx, n_workers;
+
+	static std::atomic<int> &worker_counter()
+	{
+		static std::atomic<int> c{0};
+		return c;
+	}
+
+public:
+	CWKmerBinSorter(CKMCParams &Params, CKMCQueues &Queues, SortFunction<CKmer<SIZE>> /*sort_func: CPU sorter, unused*/)
+	{
+		bd = Queues.bd.get();
+		epd = Queues.epd.get();
+		kq = Queues.kq.get();
+		memory_bins = Queues.memory_bins.get();
+		sorters_manager = Queues.sorters_manager.get();
+
+		bp.kmer_len = Params.kmer_len;
+		bp.both_strands = Params.both_strands ? 1 : 0;
+		bp.cutoff_min = Params.cutoff_min;
+		bp.without_output = Params.without_output ? 1 : 0;
+		bp.cutoff_max = (uint64)Params.cutoff_max;
+		bp.counter_max = (uint64)Params.counter_max;
+		bp.lut_prefix_len = Params.lut_prefix_len;
+		bp.output_type = Params.output_type == OutputType::KMC ? 0 : 1;
+		max_x = Params.max_x;
+		n_workers = Params.n_sorters;
+		worker_idx = worker_counter()++ % (n_workers > 0 ? n_workers : 1);
+	}
+
+	void GetDebugStats(uint64 &_sum_n_recs, uint64 &_sum_n_plus_x_recs)
+	{
+		_sum_n_recs = sum_n_rec;
+		_sum_n_plus_x_recs = sum_n_plus_x_rec;
+	}
+
+	void operator()()
+	{
+		std::unique_ptr<KmcBinEngine> engine(kmc_make_bin_engine(worker_idx, n_workers));
+		if (!engine)
+			CCriticalErrorHandler::Inst().HandleCriticalError("Error: cannot create the stage-2 bin engine");
+
+		int32 bin_id;
+		uchar *data;
+		uint64 size, n_rec;
+		int n_sorting_threads;
+		const uint64 lut_recs = bp.lut_prefix_len ? 1ull << (2 * bp.lut_prefix_len) : 0;
+		const uint64 out_rec_bytes = kmc_hip_out_rec_bytes_host(bp);
+		std::vector<uint64> pack_bytes;
+
+		while (sorters_manager->GetNext(bin_id, data, size, n_rec, n_sorting_threads)) {
+			CMemDiskFile *file;
+			string desc;
+			uint64 tmp_size, tmp_n_rec, n_plus_x_recs;
+			bd->read(bin_id, file, desc, tmp_size, tmp_n_rec, n_plus_x_recs);
+			sum_n_rec += n_rec;
+			sum_n_plus_x_rec += n_plus_x_recs;
+
+			list<pair<uint64, uint64>> packs;
+			epd->pop(bin_id, packs);
+			pack_bytes.clear();
+			for (auto &e : packs)
+				pack_bytes.push_back(e.first);
+
+			uchar *out_buffer = nullptr, *raw_lut = nullptr;
+			memory_bins->reserve(bin_id, out_buffer, CMemoryBins::mba_suffix);
+			memory_bins->reserve(bin_id, raw_lut, CMemoryBins::mba_lut);
+
+			/* capacity of mba_suffix exactly as the reader sized it (kb_reader.h:141-150) */
+			uint64 max_out_recs = (n_rec + 1) / max((uint32)bp.cutoff_min, 1u);
+			uint64 out_capacity = max_out_recs * out_rec_bytes;
+
+			uint64 out_bytes = 0;
+			uint64 stats[4] = {0, 0, 0, 0};
+			int rc = engine->process_bin(bp, data, tmp_size, n_rec, pack_bytes.data(), pack_bytes.size(), out_buffer,
+			                             out_capacity, &out_bytes, (uint64 *)raw_lut, stats);
+			if (rc != 0) {
+				std::ostringstream ostr;
+				ostr << "Error: stage-2 bin engine failed on bin " << bin_id << " (code " << rc << "): " << engine->last_error();
+				CCriticalErrorHandler::Inst().HandleCriticalError(ostr.str());
+			}
+
+			/* the CPU sorter's working slots are never used here, but the region only recycles once every
+			 * slot of the bin is released (queues.h:1556-1583) */
+			memory_bins->free(bin_id, CMemoryBins::mba_input_file);
+			memory_bins->free(bin_id, CMemoryBins::mba_input_array);
+			memory_bins->free(bin_id, CMemoryBins::mba_tmp_array);
+			if (max_x && n_plus_x_recs)
+				memory_bins->free(bin_id, CMemoryBins::mba_kxmer_counters);
+
+			/* data packs exactly as the reference emits them: one pack [0,out_bytes); none when output is off,
+			 * and none for an empty bin on the k+x-mer path (kb_sorter.h:967-968,1105-1106,1269-1271) */
+			list<pair<uint64, uint64>> data_packs;
+			if (!bp.without_output && !(max_x && n_plus_x_recs == 0))
+				data_packs.emplace_back(0, out_bytes);
+			kq->push(bin_id, out_buffer, data_packs, raw_lut, lut_recs * sizeof(uint64), stats[0], stats[1], stats[2],
+			         stats[3]);
+
+			sorters_manager->ReturnThreads(n_sorting_threads, bin_id);
+		}
+		kq->mark_completed();
+	}
+
+private:
+	static uint64 kmc_hip_out_rec_bytes_host(const kmc_hip_bin_params &p)
+	{
+		uint32 sym = p.kmer_len - p.lut_prefix_len;
+		uint64 kmer_bytes = p.lut_prefix_len ? sym / 4 : (sym + 3) / 4; /* kb_reader.h:146-149 */
+		return kmer_bytes + calc_counter_size((int64)p.cutoff_max, (int64)p.counter_max);
+	}
+};
+
+#endif
