@@ -150,6 +150,12 @@ int kmc_hip_host_register(kmc_hip_ctx *ctx, void *ptr, uint64_t bytes);   /* pin
 int kmc_hip_host_unregister(kmc_hip_ctx *ctx, void *ptr);
 int kmc_hip_synchronize(kmc_hip_ctx *ctx, int dev);
 
+/* ---- stage-isolating test hooks (not used by the worker): run only index+expand, or only compaction ---- */
+int kmc_hip_debug_expand(kmc_hip_ctx *ctx, int dev, const kmc_hip_bin_params *params, const uint8_t *superkmers, uint64_t size,
+                         uint64_t n_rec, const uint64_t *pack_bytes, uint64_t n_packs, uint64_t *out_recs /* n_rec*words */);
+int kmc_hip_debug_compact(kmc_hip_ctx *ctx, int dev, const kmc_hip_bin_params *params, const uint64_t *sorted_recs, uint64_t n,
+                          uint8_t *out_suffix, uint64_t out_capacity, uint64_t *out_bytes, uint64_t *lut, uint64_t stats[4]);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,285 @@
+"""ctypes binding of the C-ABI in include/kmc_hip.h (libkmc_hip.so).
+
+This is the only way Python code (tests, bench.py) reaches the product: through the same `extern "C"` entry points
+the C++ worker (kmc_amd/host/kb_sorter_plugin.h) binds. There is no CPU fallback: a missing library or a missing
+GPU raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import build as _build
+
+u8p = C.POINTER(C.c_uint8)
+u64p = C.POINTER(C.c_uint64)
+
+
+class KmcHipError(RuntimeError):
+    def __init__(self, code: int, msg: str):
+        super().__init__(f"kmc_hip error {code}: {msg}")
+        self.code = code
+
+
+class BinParams(C.Structure):
+    """struct kmc_hip_bin_params (mirrors the CKMCParams fields of kb_sorter.h:165-200)."""
+
+    _fields_ = [
+        ("kmer_len", C.c_uint32),
+        ("both_strands", C.c_uint32),
+        ("cutoff_min", C.c_uint32),
+        ("without_output", C.c_uint32),
+        ("cutoff_max", C.c_uint64),
+        ("counter_max", C.c_uint64),
+        ("lut_prefix_len", C.c_uint32),
+        ("output_type", C.c_uint32),
+    ]
+
+
+def make_params(k, both_strands=1, cutoff_min=2, cutoff_max=10**9, counter_max=255, lut_prefix_len=3, output_type=0,
+                without_output=0) -> BinParams:
+    return BinParams(k, both_strands, cutoff_min, without_output, cutoff_max, counter_max, lut_prefix_len, output_type)
+
+
+# every symbol include/kmc_hip.h declares (tests check the library exports them all)
+SYMBOLS = [
+    "kmc_hip_init", "kmc_hip_destroy", "kmc_hip_last_error", "kmc_hip_abi_version", "kmc_hip_num_devices",
+    "kmc_hip_words", "kmc_hip_counter_size", "kmc_hip_out_rec_bytes", "kmc_hip_lut_entries",
+    "kmc_hip_sort_records", "kmc_hip_sort_records_device",
+    "kmc_hip_process_bin", "kmc_hip_process_bin_submit", "kmc_hip_process_bin_wait", "kmc_hip_process_bin_device",
+    "kmc_hip_allreduce_stats", "kmc_hip_last_timings", "kmc_hip_last_scatter_stats",
+    "kmc_hip_malloc", "kmc_hip_free", "kmc_hip_memcpy_h2d", "kmc_hip_memcpy_d2h",
+    "kmc_hip_host_register", "kmc_hip_host_unregister", "kmc_hip_synchronize",
+    "kmc_hip_debug_expand", "kmc_hip_debug_compact",
+]
+
+_LIB = None
+
+
+def lib_path() -> str:
+    return _build.LIB_HIP
+
+
+def load():
+    """dlopen libkmc_hip.so (in-tree). Raises FileNotFoundError when it has not been built."""
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    p = lib_path()
+    if not os.path.exists(p):
+        raise FileNotFoundError(f"{p} is missing — run `python -c 'import __graft_entry__ as g; g.build()'` (needs hipcc)")
+    L = C.CDLL(p, mode=C.RTLD_GLOBAL)
+    vp = C.c_void_p
+    L.kmc_hip_init.argtypes = [C.POINTER(C.c_int), C.c_int, C.POINTER(vp)]
+    L.kmc_hip_destroy.argtypes = [vp]
+    L.kmc_hip_destroy.restype = None
+    L.kmc_hip_last_error.argtypes = [vp]
+    L.kmc_hip_last_error.restype = C.c_char_p
+    L.kmc_hip_num_devices.argtypes = [vp]
+    L.kmc_hip_words.argtypes = [C.c_uint32]
+    L.kmc_hip_words.restype = C.c_uint32
+    L.kmc_hip_counter_size.argtypes = [C.c_uint64, C.c_uint64]
+    L.kmc_hip_counter_size.restype = C.c_uint32
+    L.kmc_hip_out_rec_bytes.argtypes = [C.POINTER(BinParams)]
+    L.kmc_hip_out_rec_bytes.restype = C.c_uint32
+    L.kmc_hip_lut_entries.argtypes = [C.POINTER(BinParams)]
+    L.kmc_hip_lut_entries.restype = C.c_uint64
+    L.kmc_hip_sort_records.argtypes = [vp, C.c_int, vp, C.c_uint64, C.c_uint32, C.c_uint32]
+    L.kmc_hip_sort_records_device.argtypes = [vp, C.c_int, vp, vp, C.c_uint64, C.c_uint32, C.c_uint32, C.POINTER(vp)]
+    L.kmc_hip_process_bin.argtypes = [vp, C.c_int, C.POINTER(BinParams), vp, C.c_uint64, C.c_uint64, vp, C.c_uint64, vp, C.c_uint64,
+                                      u64p, vp, u64p]
+    L.kmc_hip_process_bin_submit.argtypes = [vp, C.c_int, C.c_int, C.POINTER(BinParams), vp, C.c_uint64, C.c_uint64, vp, C.c_uint64,
+                                             vp, C.c_uint64, vp]
+    L.kmc_hip_process_bin_wait.argtypes = [vp, C.c_int, C.c_int, u64p, u64p]
+    L.kmc_hip_process_bin_device.argtypes = [vp, C.c_int, C.POINTER(BinParams), vp, C.c_uint64, C.c_uint64, vp, C.c_uint64, vp,
+                                             C.c_uint64, vp, vp, vp, C.c_int]
+    L.kmc_hip_allreduce_stats.argtypes = [vp, u64p]
+    L.kmc_hip_last_timings.argtypes = [vp, C.c_int, C.POINTER(C.c_float)]
+    L.kmc_hip_last_scatter_stats.argtypes = [vp, C.c_int, C.POINTER(C.c_uint32), C.POINTER(C.c_float), u64p]
+    L.kmc_hip_malloc.argtypes = [vp, C.c_int, C.c_uint64, C.POINTER(vp)]
+    L.kmc_hip_free.argtypes = [vp, C.c_int, vp]
+    L.kmc_hip_memcpy_h2d.argtypes = [vp, C.c_int, vp, vp, C.c_uint64]
+    L.kmc_hip_memcpy_d2h.argtypes = [vp, C.c_int, vp, vp, C.c_uint64]
+    L.kmc_hip_host_register.argtypes = [vp, vp, C.c_uint64]
+    L.kmc_hip_host_unregister.argtypes = [vp, vp]
+    L.kmc_hip_synchronize.argtypes = [vp, C.c_int]
+    L.kmc_hip_debug_expand.argtypes = [vp, C.c_int, C.POINTER(BinParams), vp, C.c_uint64, C.c_uint64, vp, C.c_uint64, vp]
+    L.kmc_hip_debug_compact.argtypes = [vp, C.c_int, C.POINTER(BinParams), vp, C.c_uint64, vp, C.c_uint64, u64p, vp, u64p]
+    _LIB = L
+    return L
+
+
+def _vp(a: np.ndarray):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+class Context:
+    """kmc_hip_ctx: one per process, `devices` = HIP ordinals."""
+
+    def __init__(self, devices=(0,)):
+        self.L = load()
+        ids = (C.c_int * len(devices))(*devices)
+        h = C.c_void_p()
+        rc = self.L.kmc_hip_init(ids, len(devices), C.byref(h))
+        if rc:
+            raise KmcHipError(rc, self.L.kmc_hip_last_error(None).decode())
+        self.h = h
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.kmc_hip_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _chk(self, rc):
+        if rc:
+            raise KmcHipError(rc, self.L.kmc_hip_last_error(self.h).decode())
+
+    # ---- derived sizes
+    def out_rec_bytes(self, p: BinParams) -> int:
+        return self.L.kmc_hip_out_rec_bytes(C.byref(p))
+
+    def lut_entries(self, p: BinParams) -> int:
+        return self.L.kmc_hip_lut_entries(C.byref(p))
+
+    # ---- narrow boundary
+    def sort_records(self, recs: np.ndarray, key_bytes: int, dev: int = 0) -> np.ndarray:
+        """Sort (n, words) uint64 records ascending by their low key_bytes bytes; returns a sorted copy."""
+        r = np.ascontiguousarray(recs, dtype=np.uint64).copy()
+        if r.ndim == 1:
+            r = r.reshape(-1, 1)
+        self._chk(self.L.kmc_hip_sort_records(self.h, dev, _vp(r), r.shape[0], r.shape[1], key_bytes))
+        return r
+
+    # ---- full boundary
+    def process_bin(self, p: BinParams, image: np.ndarray, n_rec: int, pack_bytes=None, out_capacity=None, dev: int = 0):
+        """One bin through kmc_hip_process_bin. Returns (suffix_bytes ndarray, lut ndarray, stats ndarray[4])."""
+        image = np.ascontiguousarray(image, dtype=np.uint8)
+        rec = self.out_rec_bytes(p)
+        if out_capacity is None:
+            out_capacity = ((n_rec + 1) // max(p.cutoff_min, 1)) * rec  # kb_reader.h:141-150
+        out = np.zeros(max(out_capacity, 1), dtype=np.uint8)
+        nl = self.lut_entries(p)
+        lut = np.zeros(max(nl, 1), dtype=np.uint64)
+        stats = np.zeros(4, dtype=np.uint64)
+        ob = C.c_uint64()
+        if pack_bytes is None:
+            pb, npk = None, 0
+        else:
+            pack_bytes = np.ascontiguousarray(pack_bytes, dtype=np.uint64)
+            pb, npk = _vp(pack_bytes), pack_bytes.size
+        src = image if image.size else np.zeros(1, dtype=np.uint8)
+        self._chk(self.L.kmc_hip_process_bin(self.h, dev, C.byref(p), _vp(src), image.size, n_rec, pb, npk, _vp(out), out_capacity,
+                                             C.byref(ob), _vp(lut), stats.ctypes.data_as(u64p)))
+        return out[: ob.value].copy(), lut[:nl].copy(), stats
+
+    # ---- stage-isolating test hooks
+    def debug_expand(self, p: BinParams, image: np.ndarray, n_rec: int, pack_bytes: np.ndarray, dev: int = 0) -> np.ndarray:
+        words = (p.kmer_len + 31) // 32
+        out = np.zeros((n_rec, words), dtype=np.uint64)
+        pack_bytes = np.ascontiguousarray(pack_bytes, dtype=np.uint64)
+        self._chk(self.L.kmc_hip_debug_expand(self.h, dev, C.byref(p), _vp(image), image.size, n_rec, _vp(pack_bytes), pack_bytes.size, _vp(out)))
+        return out
+
+    def debug_compact(self, p: BinParams, sorted_recs: np.ndarray, out_capacity=None, dev: int = 0):
+        r = np.ascontiguousarray(sorted_recs, dtype=np.uint64)
+        n = r.shape[0]
+        rec = self.out_rec_bytes(p)
+        if out_capacity is None:
+            out_capacity = (n + 1) * rec
+        out = np.zeros(max(out_capacity, 1), dtype=np.uint8)
+        nl = self.lut_entries(p)
+        lut = np.zeros(max(nl, 1), dtype=np.uint64)
+        stats = np.zeros(4, dtype=np.uint64)
+        ob = C.c_uint64()
+        self._chk(self.L.kmc_hip_debug_compact(self.h, dev, C.byref(p), _vp(r), n, _vp(out), out_capacity, C.byref(ob), _vp(lut),
+                                               stats.ctypes.data_as(u64p)))
+        return out[: ob.value].copy(), lut[:nl].copy(), stats
+
+    # ---- device memory helpers
+    def malloc(self, nbytes: int, dev: int = 0) -> int:
+        p = C.c_void_p()
+        self._chk(self.L.kmc_hip_malloc(self.h, dev, nbytes, C.byref(p)))
+        return p.value
+
+    def free(self, dptr: int, dev: int = 0):
+        self._chk(self.L.kmc_hip_free(self.h, dev, C.c_void_p(dptr)))
+
+    def h2d(self, dptr: int, a: np.ndarray, dev: int = 0):
+        a = np.ascontiguousarray(a)
+        self._chk(self.L.kmc_hip_memcpy_h2d(self.h, dev, C.c_void_p(dptr), _vp(a), a.nbytes))
+
+    def d2h(self, a: np.ndarray, dptr: int, dev: int = 0):
+        self._chk(self.L.kmc_hip_memcpy_d2h(self.h, dev, _vp(a), C.c_void_p(dptr), a.nbytes))
+
+    def synchronize(self, dev: int = 0):
+        self._chk(self.L.kmc_hip_synchronize(self.h, dev))
+
+    def process_bin_device(self, p: BinParams, d_image: int, size: int, n_rec: int, d_pack_start: int, n_packs: int, d_out: int,
+                           out_capacity: int, d_out_bytes: int, d_lut: int, d_stats: int, sync: bool = True, dev: int = 0):
+        self._chk(self.L.kmc_hip_process_bin_device(self.h, dev, C.byref(p), C.c_void_p(d_image), size, n_rec, C.c_void_p(d_pack_start),
+                                                    n_packs, C.c_void_p(d_out), out_capacity, C.c_void_p(d_out_bytes),
+                                                    C.c_void_p(d_lut), C.c_void_p(d_stats), 1 if sync else 0))
+
+    def sort_records_device(self, d_recs: int, d_tmp: int, n: int, words: int, key_bytes: int, dev: int = 0) -> int:
+        res = C.c_void_p()
+        self._chk(self.L.kmc_hip_sort_records_device(self.h, dev, C.c_void_p(d_recs), C.c_void_p(d_tmp), n, words, key_bytes, C.byref(res)))
+        return res.value
+
+    def last_timings(self, dev: int = 0):
+        ms = (C.c_float * 6)()
+        self._chk(self.L.kmc_hip_last_timings(self.h, dev, ms))
+        return dict(zip(("index", "expand", "hist", "scatter", "compact", "total"), [float(x) for x in ms]))
+
+    def last_scatter_stats(self, dev: int = 0):
+        n, t, k = C.c_uint32(), C.c_float(), C.c_uint64()
+        self._chk(self.L.kmc_hip_last_scatter_stats(self.h, dev, C.byref(n), C.byref(t), C.byref(k)))
+        return n.value, t.value, k.value
+
+    def allreduce_stats(self, per_dev: np.ndarray) -> np.ndarray:
+        a = np.ascontiguousarray(per_dev, dtype=np.uint64).copy()
+        self._chk(self.L.kmc_hip_allreduce_stats(self.h, a.ctypes.data_as(u64p)))
+        return a
+
+
+# ---- synthetic stage-2 inputs (libkmc_synth.so)
+_SYN = None
+
+
+def synth_bins(seed: int, genome_len: int, n_reads: int, k: int, n_bins: int = 1, read_len: int = 150, err: float = 0.01,
+               sig_len: int = 9, n_threads: int = 0):
+    """Returns a list of (image uint8 ndarray, n_rec, pack_bytes uint64 ndarray, n_super) per bin."""
+    global _SYN
+    if _SYN is None:
+        p = _build.LIB_SYNTH
+        if not os.path.exists(p):
+            _build.build_synth()
+        _SYN = C.CDLL(p)
+        _SYN.kmc_synth_bins.restype = C.c_void_p
+        _SYN.kmc_synth_bins.argtypes = [C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint32, C.c_double, C.c_uint32, C.c_uint32, C.c_uint32,
+                                        C.c_int, C.POINTER(C.POINTER(u8p)), C.POINTER(u64p), C.POINTER(u64p),
+                                        C.POINTER(C.POINTER(u64p)), C.POINTER(u64p), C.POINTER(u64p)]
+        _SYN.kmc_synth_free.argtypes = [C.c_void_p]
+        _SYN.kmc_synth_free.restype = None
+    imgs, sizes, nrec, packs, npacks, nsup = C.POINTER(u8p)(), u64p(), u64p(), C.POINTER(u64p)(), u64p(), u64p()
+    h = _SYN.kmc_synth_bins(seed, genome_len, n_reads, read_len, err, k, sig_len, n_bins, n_threads, C.byref(imgs), C.byref(sizes),
+                            C.byref(nrec), C.byref(packs), C.byref(npacks), C.byref(nsup))
+    if not h:
+        raise ValueError("kmc_synth_bins: bad arguments or out of memory")
+    out = []
+    try:
+        for b in range(n_bins):
+            sz = sizes[b]
+            img = np.ctypeslib.as_array(imgs[b], shape=(sz,)).copy() if sz else np.zeros(0, dtype=np.uint8)
+            pk = np.ctypeslib.as_array(packs[b], shape=(npacks[b],)).copy() if npacks[b] else np.zeros(0, dtype=np.uint64)
+            out.append((img, int(nrec[b]), pk, int(nsup[b])))
+    finally:
+        _SYN.kmc_synth_free(h)
+    return out

@@ -1,0 +1,245 @@
+/*
+ * kmc_amd/csrc/synth_bins.cpp — deterministic synthetic stage-2 INPUT generator (libkmc_synth.so).
+ *
+ * Produces what KMC's stage 1 would hand to stage 2 — bin images of super-k-mers in the on-disk format
+ * (kmc_core/kb_collector.cpp:57-71) plus expander-pack byte lengths (kb_collector.cpp:36-42, <= 4096
+ * super-k-mers per pack) — directly from the read model of SURVEY.md §8d (uniform random genome, L-bp reads at
+ * uniform starts, per-base substitution probability `err`, random strand), without FASTQ text or the reference.
+ * Stage 1 itself is out of scope; this is workload plumbing for bench.py and the large-size
+ * property tests. Super-k-mers are cut where the minimizer (smallest canonical m-mer of the k-mer, m = sig_len)
+ * changes, as in kmc_core/splitter.cpp:557-672, without KMC's signature blacklist (irrelevant to stage 2);
+ * bin = mix(signature) % n_bins. Output is independent of the number of threads.
+ */
+#include <algorithm>
+#include <cstdint>
+#include <cstdlib>
+#include <cstring>
+#include <thread>
+#include <vector>
+
+namespace {
+
+inline uint64_t mix64(uint64_t x)
+{
+	x += 0x9E3779B97F4A7C15ull;
+	x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+	x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+	return x ^ (x >> 31);
+}
+struct Rng { /* counter-based: stream (seed, read) is independent of scheduling */
+	uint64_t key, ctr;
+	Rng(uint64_t seed, uint64_t stream) : key(mix64(seed ^ mix64(stream))), ctr(0) {}
+	uint64_t next() { return mix64(key + 0x632BE59BD9B4E019ull * ++ctr); }
+};
+
+struct BinBuf {
+	std::vector<uint8_t> bytes;
+	std::vector<uint64_t> packs;
+	uint64_t n_rec = 0, n_super = 0;
+	uint64_t cur_pack_bytes = 0;
+	uint32_t cur_pack_sk = 0;
+};
+
+struct Chunk {
+	std::vector<BinBuf> bins;
+};
+
+constexpr uint64_t READS_PER_CHUNK = 1 << 15;
+
+void put_superkmer(BinBuf &b, const uint8_t *sym, uint32_t n, uint32_t k)
+{
+	if (b.cur_pack_sk >= 4096) {
+		b.packs.push_back(b.cur_pack_bytes);
+		b.cur_pack_bytes = 0;
+		b.cur_pack_sk = 0;
+	}
+	const size_t at = b.bytes.size();
+	const uint32_t nb = 1 + (n + 3) / 4;
+	b.bytes.resize(at + nb, 0);
+	uint8_t *p = b.bytes.data() + at;
+	p[0] = (uint8_t)(n - k);
+	for (uint32_t i = 0; i < n; ++i)
+		p[1 + (i >> 2)] |= (uint8_t)(sym[i] << (6 - 2 * (i & 3)));
+	b.cur_pack_bytes += nb;
+	++b.cur_pack_sk;
+	++b.n_super;
+	b.n_rec += n - k + 1;
+}
+
+void gen_chunk(uint64_t seed, const std::vector<uint8_t> &genome, uint64_t r0, uint64_t r1, uint32_t L, double err, uint32_t k, uint32_t m,
+               uint32_t n_bins, Chunk &out)
+{
+	out.bins.assign(n_bins, BinBuf());
+	const uint64_t G = genome.size();
+	const uint64_t err_thr = (uint64_t)(err * 18446744073709551615.0);
+	std::vector<uint8_t> rd(L);
+	std::vector<uint32_t> mm(L), mn(L);
+	const uint32_t n_mm = L - m + 1, n_k = L - k + 1, w = k - m + 1;
+	const uint32_t mmask = (m < 16) ? ((1u << (2 * m)) - 1) : 0xFFFFFFFFu;
+	std::vector<uint32_t> dq(L);
+	for (uint64_t r = r0; r < r1; ++r) {
+		Rng g(seed, r);
+		const uint64_t st = g.next() % (G - L + 1);
+		const bool flip = g.next() & 1;
+		for (uint32_t i = 0; i < L; ++i) {
+			uint8_t s = genome[st + i];
+			if (g.next() < err_thr)
+				s = (uint8_t)((s + 1 + g.next() % 3) & 3);
+			rd[i] = s;
+		}
+		if (flip) {
+			std::reverse(rd.begin(), rd.end());
+			for (auto &s : rd)
+				s = 3 - s;
+		}
+		/* canonical m-mers */
+		uint32_t f = 0, rc = 0;
+		for (uint32_t i = 0; i < L; ++i) {
+			f = ((f << 2) | rd[i]) & mmask;
+			rc = (rc >> 2) | ((uint32_t)(3 - rd[i]) << (2 * (m - 1)));
+			if (i + 1 >= m)
+				mm[i + 1 - m] = f < rc ? f : rc;
+		}
+		/* sliding-window minimum over w consecutive m-mers: leftmost smallest value */
+		uint32_t head = 0, tail = 0;
+		for (uint32_t i = 0; i < n_mm; ++i) {
+			while (tail > head && mm[dq[tail - 1]] > mm[i])
+				--tail;
+			dq[tail++] = i;
+			if (i + 1 >= w) {
+				const uint32_t kpos = i + 1 - w;
+				while (dq[head] < kpos)
+					++head;
+				mn[kpos] = mm[dq[head]];
+			}
+		}
+		/* cut into super-k-mers of equal signature */
+		uint32_t start = 0;
+		for (uint32_t i = 1; i <= n_k; ++i) {
+			if (i == n_k || mn[i] != mn[start] || i - start >= 256) {
+				const uint32_t bin = (uint32_t)(mix64(mn[start]) % n_bins);
+				put_superkmer(out.bins[bin], rd.data() + start, (i - start) + k - 1, k);
+				start = i;
+			}
+		}
+	}
+	for (auto &b : out.bins)
+		if (b.cur_pack_bytes) {
+			b.packs.push_back(b.cur_pack_bytes);
+			b.cur_pack_bytes = 0;
+			b.cur_pack_sk = 0;
+		}
+}
+
+struct Result {
+	std::vector<uint8_t *> image;
+	std::vector<uint64_t> size, n_rec, n_super, n_packs;
+	std::vector<uint64_t *> packs;
+};
+
+} // namespace
+
+extern "C" {
+
+/* Generate `n_bins` bin images. Arrays of length n_bins are returned through the out_* pointers (malloc'ed; free
+ * everything with kmc_synth_free(handle)). Returns an opaque handle or NULL. */
+void *kmc_synth_bins(uint64_t seed, uint64_t genome_len, uint64_t n_reads, uint32_t read_len, double err, uint32_t k, uint32_t sig_len,
+                     uint32_t n_bins, int n_threads, uint8_t ***out_images, uint64_t **out_sizes, uint64_t **out_n_rec,
+                     uint64_t ***out_pack_bytes, uint64_t **out_n_packs, uint64_t **out_n_super)
+{
+	if (k < sig_len || sig_len < 1 || sig_len > 15 || read_len < k || genome_len < read_len || n_bins < 1 || k > 256)
+		return nullptr;
+	if (n_threads < 1)
+		n_threads = (int)std::max(1u, std::thread::hardware_concurrency());
+	std::vector<uint8_t> genome(genome_len);
+	{
+		std::vector<std::thread> th;
+		const uint64_t per = (genome_len + n_threads - 1) / n_threads;
+		for (int t = 0; t < n_threads; ++t)
+			th.emplace_back([&, t] {
+				const uint64_t a = t * per, b = std::min(genome_len, a + per);
+				for (uint64_t i = a; i < b; ++i)
+					genome[i] = (uint8_t)(mix64(seed * 0x100000001B3ull + i) & 3);
+			});
+		for (auto &x : th)
+			x.join();
+	}
+	const uint64_t n_chunks = (n_reads + READS_PER_CHUNK - 1) / READS_PER_CHUNK;
+	std::vector<Chunk> chunks(n_chunks);
+	{
+		std::vector<std::thread> th;
+		for (int t = 0; t < n_threads; ++t)
+			th.emplace_back([&, t] {
+				for (uint64_t c = t; c < n_chunks; c += n_threads)
+					gen_chunk(seed, genome, c * READS_PER_CHUNK, std::min(n_reads, (c + 1) * READS_PER_CHUNK), read_len, err, k, sig_len,
+					          n_bins, chunks[c]);
+			});
+		for (auto &x : th)
+			x.join();
+	}
+	Result *R = new Result();
+	R->image.assign(n_bins, nullptr);
+	R->packs.assign(n_bins, nullptr);
+	R->size.assign(n_bins, 0);
+	R->n_rec.assign(n_bins, 0);
+	R->n_super.assign(n_bins, 0);
+	R->n_packs.assign(n_bins, 0);
+	for (uint32_t b = 0; b < n_bins; ++b) {
+		uint64_t sz = 0, np = 0;
+		for (auto &c : chunks) {
+			sz += c.bins[b].bytes.size();
+			np += c.bins[b].packs.size();
+			R->n_rec[b] += c.bins[b].n_rec;
+			R->n_super[b] += c.bins[b].n_super;
+		}
+		R->size[b] = sz;
+		R->n_packs[b] = np;
+		R->image[b] = (uint8_t *)malloc(sz + 256);
+		R->packs[b] = (uint64_t *)malloc((np + 1) * 8);
+		if (!R->image[b] || !R->packs[b])
+			return nullptr;
+		memset(R->image[b] + sz, 0, 256);
+	}
+	{ /* concatenate chunk pieces in chunk order (parallel over bins x chunks by offset) */
+		std::vector<std::thread> th;
+		for (int t = 0; t < n_threads; ++t)
+			th.emplace_back([&, t] {
+				for (uint32_t b = t; b < n_bins; b += n_threads) {
+					uint64_t off = 0, po = 0;
+					for (auto &c : chunks) {
+						auto &bb = c.bins[b];
+						if (!bb.bytes.empty())
+							memcpy(R->image[b] + off, bb.bytes.data(), bb.bytes.size());
+						off += bb.bytes.size();
+						for (auto p : bb.packs)
+							R->packs[b][po++] = p;
+						std::vector<uint8_t>().swap(bb.bytes);
+					}
+				}
+			});
+		for (auto &x : th)
+			x.join();
+	}
+	*out_images = R->image.data();
+	*out_sizes = R->size.data();
+	*out_n_rec = R->n_rec.data();
+	*out_pack_bytes = R->packs.data();
+	*out_n_packs = R->n_packs.data();
+	if (out_n_super)
+		*out_n_super = R->n_super.data();
+	return R;
+}
+
+void kmc_synth_free(void *handle)
+{
+	Result *R = (Result *)handle;
+	if (!R)
+		return;
+	for (auto p : R->image)
+		free(p);
+	for (auto p : R->packs)
+		free(p);
+	delete R;
+}
+
+} /* extern "C" */

@@ -36,24 +36,30 @@ def make_reads(seed: int, genome_len: int, n_reads: int, read_len: int = 150, er
 
 
 def write_fastq(path: str, reads: np.ndarray) -> int:
-    """Write reads as 4-line FASTQ records; returns bytes written."""
+    """Write reads as 4-line FASTQ records ("@r<9 digits>", sequence, "+", quality 'I'); returns bytes written."""
     n, L = reads.shape
-    qual = b"I" * L
+    rec = 12 + L + 3 + L + 1
     total = 0
     with open(path, "wb") as f:
-        step = 1 << 14
+        step = 1 << 16
         for lo in range(0, n, step):
             hi = min(n, lo + step)
-            seqs = _ACGT[reads[lo:hi]]
-            chunk = bytearray()
-            for i in range(hi - lo):
-                chunk += b"@r%d\n" % (lo + i)
-                chunk += seqs[i].tobytes()
-                chunk += b"\n+\n"
-                chunk += qual
-                chunk += b"\n"
-            f.write(chunk)
-            total += len(chunk)
+            m = hi - lo
+            buf = np.empty((m, rec), dtype=np.uint8)
+            buf[:, 0] = ord("@")
+            buf[:, 1] = ord("r")
+            ids = np.arange(lo, hi, dtype=np.int64)
+            for d in range(9):
+                buf[:, 10 - d] = (ids // 10**d) % 10 + ord("0")
+            buf[:, 11] = ord("\n")
+            buf[:, 12 : 12 + L] = _ACGT[reads[lo:hi]]
+            buf[:, 12 + L] = ord("\n")
+            buf[:, 13 + L] = ord("+")
+            buf[:, 14 + L] = ord("\n")
+            buf[:, 15 + L : 15 + 2 * L] = ord("I")
+            buf[:, 15 + 2 * L] = ord("\n")
+            f.write(buf.tobytes())
+            total += buf.size
     return total
 
 

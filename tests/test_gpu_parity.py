@@ -1,0 +1,305 @@
+"""GPU suite (-m gpu): the HIP path, through the C-ABI (ctypes -> libkmc_hip.so), against the oracle and the
+committed reference golden vectors. Bit-exact everywhere: this is integer/byte work."""
+import ctypes as C
+import glob
+import hashlib
+import os
+import subprocess
+import zlib
+
+import numpy as np
+import pytest
+
+import binsynth
+import golden_io
+import oracle_py as O
+from kmc_amd import capi
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLDEN = sorted(glob.glob(os.path.join(ROOT, "tests", "golden", "*.bins")))
+
+
+def _first_diff(a, b):
+    a, b = np.asarray(a).ravel(), np.asarray(b).ravel()
+    if a.size != b.size:
+        return f"size {a.size} != {b.size}"
+    d = np.flatnonzero(a != b)
+    return "equal" if d.size == 0 else f"{d.size} diffs, first at {int(d[0])}: {a[d[0]]} != {b[d[0]]}"
+
+
+def hp(k, **kw):
+    return capi.make_params(k, **kw)
+
+
+def op(p):
+    return O.make_params(p.kmer_len, p.both_strands, p.cutoff_min, p.cutoff_max, p.counter_max, p.lut_prefix_len, p.output_type,
+                         p.without_output)
+
+
+# ------------------------------------------------------------------------------------------------ narrow boundary
+@pytest.mark.parametrize("words,key_bytes", [(1, 7), (1, 8), (1, 1), (2, 14), (2, 16), (3, 20), (4, 32), (8, 64)])
+@pytest.mark.parametrize("n", [0, 1, 2, 63, 64, 65, 4095, 4096, 4097, 100_003])
+def test_sort_records_matches_oracle(ctx, words, key_bytes, n):
+    rng = np.random.default_rng(1000 * words + key_bytes + n)
+    recs = rng.integers(0, 2**63, size=(n, words), dtype=np.uint64) * np.uint64(2) + rng.integers(0, 2, size=(n, words), dtype=np.uint64)
+    # zero everything above key_bytes (contract of SortFunction: higher bytes are zero, kb_sorter.h:761-775)
+    for w in range(words):
+        lo = 8 * w
+        if key_bytes <= lo:
+            recs[:, w] = 0
+        elif key_bytes - lo < 8:
+            recs[:, w] &= np.uint64((1 << (8 * (key_bytes - lo))) - 1)
+    got = ctx.sort_records(recs, key_bytes)
+    want = O.sort(recs) if n else recs
+    assert np.array_equal(got, want), _first_diff(got, want)
+
+
+@pytest.mark.parametrize("kind", ["all_equal", "two_values", "low_entropy", "sorted", "reversed", "one_hot_byte"])
+def test_sort_records_skewed_inputs(ctx, kind):
+    """digit skew is what low-complexity bins (poly-A) look like: one bucket takes everything."""
+    rng = np.random.default_rng(42)
+    n = 300_001
+    if kind == "all_equal":
+        a = np.full(n, 0x00123456789ABCDE, dtype=np.uint64)
+    elif kind == "two_values":
+        a = np.where(rng.random(n) < 0.5, np.uint64(5), np.uint64(0x0011223344556677))
+    elif kind == "low_entropy":
+        a = rng.integers(0, 7, size=n, dtype=np.uint64) << np.uint64(40)
+    elif kind == "sorted":
+        a = np.sort(rng.integers(0, 2**54, size=n, dtype=np.uint64))
+    elif kind == "reversed":
+        a = np.sort(rng.integers(0, 2**54, size=n, dtype=np.uint64))[::-1].copy()
+    else:
+        a = rng.integers(0, 256, size=n, dtype=np.uint64) << np.uint64(8 * int(rng.integers(0, 7)))
+    got = ctx.sort_records(a.reshape(-1, 1), 7)
+    assert np.array_equal(got[:, 0], np.sort(a)), _first_diff(got[:, 0], np.sort(a))
+
+
+def test_sort_records_large_is_a_sorted_permutation(ctx):
+    """size-independent properties at a size the oracle would not finish quickly: sortedness + multiset checksum."""
+    rng = np.random.default_rng(9)
+    n = 40_000_000
+    a = rng.integers(0, 2**54, size=n, dtype=np.uint64)
+    got = ctx.sort_records(a.reshape(-1, 1), 7)[:, 0]
+    assert np.all(got[:-1] <= got[1:])
+    assert int(np.bitwise_xor.reduce(a)) == int(np.bitwise_xor.reduce(got))
+    assert int(a.sum(dtype=np.uint64)) == int(got.sum(dtype=np.uint64))
+    sub = rng.integers(0, n, size=1000)
+    srt = np.sort(a)
+    assert np.array_equal(got[sub], srt[sub])
+
+
+# ------------------------------------------------------------------------------------------------ stage isolation
+@pytest.mark.parametrize("k", [14, 27, 28, 32, 33, 55, 64, 96, 127, 200, 256])
+@pytest.mark.parametrize("both", [1, 0])
+def test_expand_stage_matches_oracle(ctx, k, both):
+    rng = np.random.default_rng(k * 2 + both)
+    img, nk, packs = binsynth.random_bin(rng, k, 3000, max_extra=120, pack_size=257)
+    p = hp(k, both_strands=both, lut_prefix_len=0, output_type=1)
+    got = ctx.debug_expand(p, img, nk, packs)
+    want = O.expand(op(p), img)
+    assert np.array_equal(got, want), _first_diff(got, want)
+
+
+@pytest.mark.parametrize("k,pl", [(27, 3), (27, 7), (55, 3), (127, 3), (32, 4), (64, 0)])
+def test_compact_stage_matches_oracle(ctx, k, pl):
+    rng = np.random.default_rng(k + pl)
+    g = rng.integers(0, 4, size=20_000, dtype=np.uint8)
+    img, nk, _ = binsynth.random_bin(rng, k, 4000, max_extra=60, genome=g)
+    for kw in (dict(cutoff_min=2), dict(cutoff_min=1, counter_max=3), dict(cutoff_min=1, cutoff_max=4), dict(cutoff_min=3, counter_max=70000)):
+        p = hp(k, lut_prefix_len=pl, output_type=0 if pl else 1, **kw)
+        srt = O.sort(O.expand(op(p), img))
+        out, lut, st = ctx.debug_compact(p, srt)
+        w_out, w_lut, w_st = O.process_bin(op(p), img, nk)
+        assert np.array_equal(st, w_st), (kw, st, w_st)
+        assert np.array_equal(out, w_out), (kw, _first_diff(out, w_out))
+        assert np.array_equal(lut, w_lut), (kw, _first_diff(lut, w_lut))
+
+
+def test_compact_long_runs_cross_many_tiles(ctx):
+    """runs far longer than a compaction tile (poly-A style): exercises the wave-cooperative run-start search."""
+    reps = [1, 5000, 2, 70_000, 1, 1, 300_000, 3, 2049, 2048, 2047, 1]
+    vals = np.sort(np.random.default_rng(5).integers(0, 2**54, size=len(reps), dtype=np.uint64))
+    srt = np.repeat(vals, reps).reshape(-1, 1)
+    for kw in (dict(cutoff_min=2), dict(cutoff_min=1, counter_max=255), dict(cutoff_min=1, cutoff_max=2048, counter_max=10**6)):
+        p = hp(27, lut_prefix_len=3, **kw)
+        out, lut, st = ctx.debug_compact(p, srt)
+        obytes, olut, ostats = (np.zeros(srt.shape[0] * 8 + 8, dtype=np.uint8), np.zeros(64, dtype=np.uint64), np.zeros(4, dtype=np.uint64))
+        ob = C.c_uint64()
+        rc = O.lib().oracle_compact(C.byref(op(p)), srt.ctypes.data_as(C.POINTER(C.c_uint64)), srt.shape[0],
+                                    obytes.ctypes.data_as(C.POINTER(C.c_uint8)), obytes.size, C.byref(ob),
+                                    olut.ctypes.data_as(C.POINTER(C.c_uint64)), ostats.ctypes.data_as(C.POINTER(C.c_uint64)))
+        assert rc == 0
+        assert np.array_equal(st, ostats), (kw, st, ostats)
+        assert np.array_equal(out, obytes[: ob.value]), (kw, _first_diff(out, obytes[: ob.value]))
+        assert np.array_equal(lut, olut)
+
+
+# ------------------------------------------------------------------------------------------------ full boundary
+@pytest.mark.parametrize("path", GOLDEN, ids=[os.path.basename(p) for p in GOLDEN])
+def test_process_bin_reproduces_reference_golden_bins(ctx, path):
+    """Real stage-1 bins of the reference with the reference's own stage-2 outputs (tests/golden/make_golden.py)."""
+    for b in golden_io.read_bins(path):
+        k, both, cmin, wo, cmax, cs, pl, ot = b["params"]
+        p = hp(k, both_strands=both, cutoff_min=cmin, cutoff_max=cmax, counter_max=cs, lut_prefix_len=pl, output_type=ot, without_output=wo)
+        for packs in (b["pack_bytes"], None):  # with the caller's expander packs, and letting the library find them
+            out, lut, st = ctx.process_bin(p, b["image"], b["n_rec"], packs)
+            assert np.array_equal(st, b["stats"]), (st, b["stats"])
+            assert np.array_equal(out, b["out"]), _first_diff(out, b["out"])
+            assert np.array_equal(lut, b["lut"]), _first_diff(lut, b["lut"])
+
+
+CASES = [
+    dict(k=27), dict(k=27, both_strands=0), dict(k=27, cutoff_min=1, counter_max=1), dict(k=27, cutoff_min=1, cutoff_max=3),
+    dict(k=27, lut_prefix_len=7), dict(k=28, lut_prefix_len=4), dict(k=31, lut_prefix_len=3), dict(k=32, lut_prefix_len=4),
+    dict(k=33, lut_prefix_len=5), dict(k=55), dict(k=55, counter_max=100000, cutoff_min=1), dict(k=64, lut_prefix_len=4),
+    dict(k=96, lut_prefix_len=4), dict(k=127), dict(k=127, both_strands=0), dict(k=160, lut_prefix_len=4), dict(k=200, lut_prefix_len=4),
+    dict(k=256, lut_prefix_len=4), dict(k=27, lut_prefix_len=0, output_type=1), dict(k=55, lut_prefix_len=0, output_type=1, counter_max=1000),
+    dict(k=27, without_output=1), dict(k=14, lut_prefix_len=2, cutoff_min=1),
+]
+
+
+@pytest.mark.parametrize("kw", CASES, ids=lambda d: "-".join(f"{a}{b}" for a, b in d.items()))
+def test_process_bin_matches_oracle(ctx, kw):
+    rng = np.random.default_rng(zlib.crc32(repr(sorted(kw.items())).encode()))
+    k = kw["k"]
+    g = rng.integers(0, 4, size=30_000, dtype=np.uint8)
+    img, nk, packs = binsynth.random_bin(rng, k, 6000, max_extra=100, genome=g, pack_size=1000)
+    p = hp(**kw)
+    out, lut, st = ctx.process_bin(p, img, nk, packs)
+    w_out, w_lut, w_st = O.process_bin(op(p), img, nk)
+    assert np.array_equal(st, w_st), (st, w_st)
+    assert np.array_equal(out, w_out), _first_diff(out, w_out)
+    if p.lut_prefix_len and not p.output_type and not p.without_output:
+        assert np.array_equal(lut, w_lut), _first_diff(lut, w_lut)
+
+
+def test_process_bin_edges(ctx):
+    p = hp(27)
+    out, lut, st = ctx.process_bin(p, np.zeros(0, dtype=np.uint8), 0)  # empty bin: still a valid call (kb_reader.h:198-205)
+    assert out.size == 0 and int(lut.sum()) == 0 and st.tolist() == [0, 0, 0, 0]
+    rng = np.random.default_rng(3)
+    img, nk, packs = binsynth.random_bin(rng, 27, 1, max_extra=0)  # a single k-mer
+    out, lut, st = ctx.process_bin(hp(27, cutoff_min=1), img, nk, packs)
+    w = O.process_bin(op(hp(27, cutoff_min=1)), img, nk)
+    assert np.array_equal(out, w[0]) and np.array_equal(st, w[2])
+    img, nk, packs = binsynth.random_bin(rng, 27, 50, max_extra=255)  # maximum-length super-k-mers (e = 255, splitter.cpp:656)
+    out, lut, st = ctx.process_bin(hp(27, cutoff_min=1), img, nk, packs)
+    w = O.process_bin(op(hp(27, cutoff_min=1)), img, nk)
+    assert np.array_equal(out, w[0]) and np.array_equal(lut, w[1]) and np.array_equal(st, w[2])
+    # error behaviour: ragged stream / wrong n_rec / too-small output are reported, never silently wrong
+    with pytest.raises(capi.KmcHipError) as e:
+        ctx.process_bin(hp(27), img[:-3], nk, None)
+    assert e.value.code == -4
+    with pytest.raises(capi.KmcHipError) as e:
+        ctx.process_bin(hp(27), img, nk + 1, packs)
+    assert e.value.code == -4
+    with pytest.raises(capi.KmcHipError) as e:
+        ctx.process_bin(hp(27, cutoff_min=1), img, nk, packs, out_capacity=7 * 3)
+    assert e.value.code == -5
+    with pytest.raises(capi.KmcHipError) as e:
+        ctx.process_bin(hp(27, lut_prefix_len=2), img, nk, packs)  # (k-p) % 4 != 0 is not a KMC configuration
+    assert e.value.code == -1
+
+
+def test_process_bin_medium_synthetic_bin_matches_oracle(ctx):
+    """a realistic bin: ~12 M k-mers of 30x-coverage reads cut by minimizers (kmc_amd/csrc/synth_bins.cpp)."""
+    (img, nrec, packs, _), = capi.synth_bins(seed=11, genome_len=400_000, n_reads=100_000, k=27, n_bins=1)
+    p = hp(27)
+    out, lut, st = ctx.process_bin(p, img, nrec, packs)
+    w_out, w_lut, w_st = O.process_bin(op(p), img, nrec)
+    assert np.array_equal(st, w_st), (st, w_st)
+    assert np.array_equal(out, w_out), _first_diff(out, w_out)
+    assert np.array_equal(lut, w_lut)
+
+
+def test_process_bin_large_properties(ctx):
+    """~250 M k-mers (k=27): properties that need no oracle — tally identities, LUT total, output ordering."""
+    (img, nrec, packs, _), = capi.synth_bins(seed=12, genome_len=8_000_000, n_reads=2_000_000, k=27, n_bins=1)
+    p = hp(27)
+    out, lut, st = ctx.process_bin(p, img, nrec, packs)
+    rec = ctx.out_rec_bytes(p)
+    counted = out.size // rec
+    assert out.size % rec == 0 and int(st[3]) == nrec
+    assert int(st[0] - st[1] - st[2]) == counted == int(lut.sum())
+    r = out.reshape(-1, rec)
+    assert r[:, -1].min() >= 2  # cutoff_min respected, counter byte
+    # inside each LUT prefix group suffixes ascend strictly (the DB's binary-search invariant, kmc_api/kmc_file.cpp)
+    suf = np.zeros(counted, dtype=np.uint64)
+    for j in range(rec - 1):
+        suf = (suf << np.uint64(8)) | r[:, j].astype(np.uint64)
+    bounds = np.concatenate([[0], np.cumsum(lut).astype(np.int64)])
+    inc = suf[1:] > suf[:-1]
+    is_boundary = np.zeros(counted - 1, dtype=bool)
+    b = bounds[1:-1]
+    is_boundary[b[(b > 0) & (b < counted)] - 1] = True
+    assert np.all(inc | is_boundary)
+    # idempotence of the device path
+    out2, lut2, st2 = ctx.process_bin(p, img, nrec, None)
+    assert np.array_equal(out, out2) and np.array_equal(lut, lut2) and np.array_equal(st, st2)
+
+
+def test_submit_wait_double_buffering(ctx):
+    rng = np.random.default_rng(8)
+    L = ctx.L
+    bins = [binsynth.random_bin(rng, 27, 2000, genome=rng.integers(0, 4, size=9000, dtype=np.uint8)) for _ in range(4)]
+    p = hp(27)
+    outs = []
+    bufs = []
+    for i, (img, nk, packs) in enumerate(bins):
+        slot = i & 1
+        if i >= 2:
+            outs.append(_wait(ctx, slot, bufs[i - 2]))
+        cap = (nk + 1) // 2 * 7
+        out = np.zeros(cap, dtype=np.uint8)
+        lut = np.zeros(64, dtype=np.uint64)
+        bufs.append((out, lut, img, packs))
+        rc = L.kmc_hip_process_bin_submit(ctx.h, 0, slot, C.byref(p), img.ctypes.data_as(C.c_void_p), img.size, nk,
+                                          packs.ctypes.data_as(C.c_void_p), packs.size, out.ctypes.data_as(C.c_void_p), cap,
+                                          lut.ctypes.data_as(C.c_void_p))
+        assert rc == 0, L.kmc_hip_last_error(ctx.h)
+    outs.append(_wait(ctx, 0, bufs[2]))
+    outs.append(_wait(ctx, 1, bufs[3]))
+    for (img, nk, packs), (o, l, s) in zip(bins, outs):
+        w = O.process_bin(op(p), img, nk)
+        assert np.array_equal(o, w[0]) and np.array_equal(l, w[1]) and np.array_equal(s, w[2])
+
+
+def _wait(ctx, slot, buf):
+    ob = C.c_uint64()
+    st = np.zeros(4, dtype=np.uint64)
+    rc = ctx.L.kmc_hip_process_bin_wait(ctx.h, 0, slot, C.byref(ob), st.ctypes.data_as(C.POINTER(C.c_uint64)))
+    assert rc == 0, ctx.L.kmc_hip_last_error(ctx.h)
+    return buf[0][: ob.value].copy(), buf[1].copy(), st
+
+
+def test_allreduce_stats_single_device(ctx):
+    a = np.array([[1, 2, 3, 2**40]], dtype=np.uint64)
+    assert np.array_equal(ctx.allreduce_stats(a), a)
+
+
+# ------------------------------------------------------------------------------------------------ the drop-in, end to end
+def _md5(p):
+    return hashlib.md5(open(p, "rb").read()).hexdigest()
+
+
+@pytest.mark.parametrize("flags", [["-k27"], ["-k55"], ["-k127"], ["-k27", "-b", "-ci1", "-cs3"]], ids=lambda f: "".join(f))
+def test_kmc_with_hip_sorter_writes_the_reference_database(flags, ref_bins, tmp_path):
+    """oracle/_ref/kmc_hip = the reference's own pipeline (stage 1, bin reader, completer, CLI) with
+    CWKmerBinSorter swapped for the HIP worker (kb_sorter_plugin.h + libkmc_hip.so). Its .kmc_pre/.kmc_suf must be
+    byte-identical to the unmodified reference run with -sr1."""
+    if ref_bins is None:
+        pytest.skip("oracle/_ref binaries were not shipped")
+    from kmc_amd import synth
+
+    fq = str(tmp_path / "in.fq")
+    synth.make_fastq(fq, **synth.CONFIGS["C1"])
+    env = dict(os.environ, KMC_HIP_LIB=capi.lib_path())
+    for exe, out in (("kmc", "ref"), ("kmc_hip", "hip")):
+        tmp = tmp_path / ("tmp_" + out)
+        tmp.mkdir()
+        r = subprocess.run([ref_bins[exe], *flags, "-sr1", fq, str(tmp_path / out), str(tmp)], env=env, capture_output=True, text=True)
+        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    for ext in (".kmc_pre", ".kmc_suf"):
+        assert _md5(str(tmp_path / ("ref" + ext))) == _md5(str(tmp_path / ("hip" + ext))), ext

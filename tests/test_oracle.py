@@ -1,0 +1,160 @@
+"""CPU suite, part 1: the oracle against the reference's golden vectors, and the host logic against the oracle.
+Nothing here touches a GPU; nothing here is the product path."""
+import ctypes as C
+import glob
+import hashlib
+import os
+import re
+import subprocess
+
+import numpy as np
+import pytest
+
+import binsynth
+import golden_io
+import oracle_py as O
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLDEN = sorted(glob.glob(os.path.join(ROOT, "tests", "golden", "*.bins")))
+
+
+def params_from_tuple(t):
+    k, both, cmin, wo, cmax, cs, p, ot = t
+    return O.make_params(k, both, cmin, cmax, cs, p, ot, wo)
+
+
+@pytest.mark.parametrize("path", GOLDEN, ids=[os.path.basename(p) for p in GOLDEN])
+def test_oracle_reproduces_reference_bins(path):
+    """tests/golden/*.bins were dumped from runs whose database equals the unmodified reference's byte for byte
+    (tests/golden/make_golden.py); the oracle must reproduce every (image -> out, lut, tallies) triple."""
+    n = 0
+    for b in golden_io.read_bins(path):
+        p = params_from_tuple(b["params"])
+        out, lut, stats = O.process_bin(p, b["image"], b["n_rec"])
+        assert np.array_equal(out, b["out"])
+        assert np.array_equal(lut, b["lut"])
+        assert np.array_equal(stats, b["stats"])
+        n += 1
+    assert n >= 2
+
+
+def test_reference_single_read_total():
+    """.github/workflows/main.yml "KMC single read": k=28 -ci1 on single_read.fq -> 70 k-mers (40 unique)."""
+    bins = list(golden_io.read_bins(os.path.join(ROOT, "tests", "golden", "single_read_k28.bins")))
+    b = bins[0]
+    assert b["n_rec"] == 70 and int(b["stats"][3]) == 70 and int(b["stats"][0]) == 40
+
+
+def test_oracle_properties_and_edges():
+    rng = np.random.default_rng(7)
+    # empty bin
+    p = O.make_params(27)
+    out, lut, st = O.process_bin(p, np.zeros(0, dtype=np.uint8), 0)
+    assert out.size == 0 and lut.sum() == 0 and st.tolist() == [0, 0, 0, 0]
+    # ragged stream is rejected
+    img, nk, _ = binsynth.random_bin(rng, 27, 10)
+    with pytest.raises(ValueError):
+        O.scan(27, img[:-1])
+    # all-identical k-mers: one run, count clamps at counter_max, cutoffs compare before clamping
+    genome = np.zeros(400, dtype=np.uint8)
+    img, nk, _ = binsynth.random_bin(rng, 21, 30, max_extra=50, genome=genome)
+    p = O.make_params(21, cutoff_min=1, counter_max=255, lut_prefix_len=1)
+    out, lut, st = O.process_bin(p, img, nk)
+    assert st.tolist() == [1, 0, 0, nk] and out.size == 5 + 1 and out[-1] == min(nk, 255) and lut.sum() == 1
+    p = O.make_params(21, cutoff_min=1, cutoff_max=5, lut_prefix_len=1)
+    out, lut, st = O.process_bin(p, img, nk)
+    assert st.tolist() == [1, 0, 1, nk] and out.size == 0
+    # tallies are consistent for random data, output sorted within the bin
+    g = rng.integers(0, 4, size=3000, dtype=np.uint8)
+    for k, pl in ((27, 3), (55, 3), (127, 3), (32, 4), (14, 2)):
+        img, nk, _ = binsynth.random_bin(rng, k, 400, genome=g)
+        p = O.make_params(k, lut_prefix_len=pl, cutoff_min=2)
+        out, lut, st = O.process_bin(p, img, nk)
+        rec = O.lib().oracle_out_rec_bytes(C.byref(p))
+        counted = out.size // rec
+        assert int(st[3]) == nk and int(lut.sum()) == counted and int(st[0] - st[1] - st[2]) == counted
+        recs = O.sort(O.expand(p, img))
+        assert np.array_equal(recs, recs[np.lexsort(recs.T[::1])])  # sorted by word W-1 .. 0
+
+
+def test_kmer_ops_host_matches_oracle():
+    """kmc_amd/csrc/kmer_ops.h (the arithmetic every kernel uses) compiled for the host vs the oracle."""
+    so = os.path.join(ROOT, "tests", "host", "libkmer_ops_host.so")
+    src = os.path.join(ROOT, "tests", "host", "kmer_ops_host.cpp")
+    hdr = os.path.join(ROOT, "kmc_amd", "csrc", "kmer_ops.h")
+    if not os.path.exists(so) or os.path.getmtime(so) < max(os.path.getmtime(src), os.path.getmtime(hdr)):
+        subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-w", src, "-o", so])
+    H = C.CDLL(so)
+    H.kmer_ops_expand.restype = C.c_uint64
+    rng = np.random.default_rng(1)
+    for k in [1, 2, 3, 4, 5, 13, 14, 16, 27, 28, 31, 32, 33, 55, 63, 64, 65, 96, 97, 127, 128, 129, 200, 255, 256]:
+        for both in (0, 1):
+            img, nk, _ = binsynth.random_bin(rng, k, 40, max_extra=60)
+            p = O.make_params(k, both_strands=both)
+            ref = O.expand(p, img)
+            out = np.zeros((nk, O.words(k)), dtype=np.uint64)
+            n = H.kmer_ops_expand(k, both, img.ctypes.data_as(C.POINTER(C.c_uint8)), img.size, out.ctypes.data_as(C.POINTER(C.c_uint64)))
+            assert n == nk and np.array_equal(ref, out), (k, both)
+    # record emission + LUT prefix against oracle_compact on distinct sorted records
+    for k, pl, cs, kff in ((27, 3, 255, 0), (55, 3, 70000, 0), (127, 7, 255, 0), (31, 0, 255, 1), (64, 4, 1, 0)):
+        img, nk, _ = binsynth.random_bin(rng, k, 30, max_extra=20)
+        p = O.make_params(k, cutoff_min=1, counter_max=cs, lut_prefix_len=pl, output_type=kff)
+        recs = np.unique(O.sort(O.expand(p, img)), axis=0)
+        recs = O.sort(recs)
+        out, lut, st = O.process_bin(p, img, nk)  # counts are all >= 1
+        sb, cb = H.kmer_ops_suffix_bytes(k, pl), H.kmer_ops_counter_bytes(10**9, cs)
+        assert cb == O.lib().oracle_counter_size(10**9, cs)
+        ref_out = out.reshape(-1, sb + cb)
+        counts = np.zeros(recs.shape[0], dtype=np.uint32)
+        for i in range(recs.shape[0]):  # decode the oracle's counter bytes
+            cbts = ref_out[i, sb:]
+            counts[i] = int.from_bytes(bytes(cbts), "big" if kff else "little") if cb else 0
+        mine = np.zeros_like(ref_out)
+        pref = np.zeros(recs.shape[0], dtype=np.uint64)
+        H.kmer_ops_emit(k, pl, recs.ctypes.data_as(C.POINTER(C.c_uint64)), C.c_uint64(recs.shape[0]), counts.ctypes.data_as(C.POINTER(C.c_uint32)),
+                        sb, cb, kff, mine.ctypes.data_as(C.POINTER(C.c_uint8)), pref.ctypes.data_as(C.POINTER(C.c_uint64)))
+        assert np.array_equal(mine, ref_out), (k, pl)
+        if pl and not kff:
+            assert np.array_equal(np.bincount(pref.astype(np.int64), minlength=lut.size), lut.astype(np.int64))
+
+
+def test_cabi_library_exports_every_declared_symbol():
+    """libkmc_hip.so must load (no GPU needed for dlopen) and export everything include/kmc_hip.h declares."""
+    from kmc_amd import capi
+
+    hdr = open(os.path.join(ROOT, "include", "kmc_hip.h")).read()
+    declared = sorted(set(re.findall(r"\b(kmc_hip_\w+)\s*\(", hdr)))
+    assert len(declared) >= 25
+    assert sorted(capi.SYMBOLS) == declared, "kmc_amd/capi.py SYMBOLS out of sync with include/kmc_hip.h"
+    L = capi.load()
+    for name in declared:
+        assert hasattr(L, name), name
+    assert L.kmc_hip_abi_version() == 1
+    # pure host-side helpers agree with the oracle
+    for cx, cs in ((10**9, 255), (10**9, 1), (200, 70000), (10**9, 70000), (10**9, 2**24)):
+        assert L.kmc_hip_counter_size(cx, cs) == O.lib().oracle_counter_size(cx, cs)
+    assert L.kmc_hip_words(27) == 1 and L.kmc_hip_words(33) == 2 and L.kmc_hip_words(256) == 8
+
+
+def _md5(p):
+    return hashlib.md5(open(p, "rb").read()).hexdigest()
+
+
+@pytest.mark.parametrize("flags", [["-k27"], ["-k55", "-ci1"], ["-k127"], ["-k27", "-b", "-cs3", "-ci1"], ["-k32", "-cx5", "-ci1"]],
+                         ids=lambda f: "".join(f))
+def test_oracle_database_equals_reference(flags, ref_bins, tmp_path):
+    """End-to-end pin: reference pipeline + oracle sorter (kmc_oracle) writes .kmc_pre/.kmc_suf byte-identical
+    to the unmodified reference run with one sorter (-sr1, SURVEY.md §4 determinism finding)."""
+    if ref_bins is None:
+        pytest.skip("oracle/_ref not built (needs /root/reference; see oracle/Makefile)")
+    from kmc_amd import synth
+
+    fq = str(tmp_path / "in.fq")
+    synth.make_fastq(fq, seed=99, genome_len=60_000, n_reads=4000)
+    for exe, out in (("kmc", "ref"), ("kmc_oracle", "orc")):
+        tmp = tmp_path / ("tmp_" + out)
+        tmp.mkdir()
+        subprocess.check_call([ref_bins[exe], *flags, "-sr1", fq, str(tmp_path / out), str(tmp)], stdout=subprocess.DEVNULL,
+                              stderr=subprocess.DEVNULL)
+    for ext in (".kmc_pre", ".kmc_suf"):
+        assert _md5(str(tmp_path / ("ref" + ext))) == _md5(str(tmp_path / ("orc" + ext)))
