@@ -140,7 +140,7 @@ int kmc_hip_allreduce_stats(kmc_hip_ctx *ctx, uint64_t *per_dev_stats);
  * Replaces: USE_TIMERS / MEASURE_TIMES compile-time probes (raduls_impl.h:30,567-657). */
 int kmc_hip_last_timings(kmc_hip_ctx *ctx, int dev, float ms[6]);
 /* Number of radix scatter launches and their summed duration for the last bin (roofline input for bench.py). */
-int kmc_hip_last_scatter_stats(kmc_hip_ctx *ctx, int dev, uint32_t *n_launches, float *total_ms, uint64_t *keys_per_launch);
+int kmc_hip_last_scatter_stats(kmc_hip_ctx *ctx, int dev, uint32_t *n_launches, float *total_ms, uint64_t *keys_per_launch /* average records per launch */);
 /* Device memory helpers so non-HIP callers (ctypes tests, the C++ worker) need not link HIP themselves. */
 int kmc_hip_malloc(kmc_hip_ctx *ctx, int dev, uint64_t bytes, void **d_ptr);
 int kmc_hip_free(kmc_hip_ctx *ctx, int dev, void *d_ptr);

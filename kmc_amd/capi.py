@@ -59,7 +59,8 @@ _LIB = None
 
 
 def lib_path() -> str:
-    return _build.LIB_HIP
+    """In-tree libkmc_hip.so; $KMC_HIP_LIB overrides (tuning variants built by tools/build_variants.py)."""
+    return os.environ.get("KMC_HIP_LIB") or _build.LIB_HIP
 
 
 def load():

@@ -67,7 +67,8 @@ constexpr size_t SM_STATS = 16;      /* u64[4]                           */
 constexpr size_t SM_OUTBYTES = 48;   /* u64                              */
 constexpr size_t SM_ERR = 56;        /* u32                              */
 constexpr size_t SM_DBASE_WORK = 256; /* u64[2][256] per-portion digit bases (ping-pong) */
-constexpr size_t SM_COUNTERS = 256 + 2 * 256 * 8; /* u32[N_COUNTERS] ticket counters, one per launch */
+constexpr size_t SM_SHARDS = 256 + 2 * 256 * 8;   /* u64[CP_SHARDS][4] tally shards of the compaction */
+constexpr size_t SM_COUNTERS = SM_SHARDS + CP_SHARDS * 4 * 8; /* u32[N_COUNTERS] ticket counters, one per launch */
 constexpr size_t N_COUNTERS = 4096;
 constexpr size_t SM_BYTES = SM_COUNTERS + N_COUNTERS * 4;
 
@@ -191,6 +192,14 @@ int sort_device_t(Slot &s, u64 *d_recs, u64 *d_tmp, u64 n, u32 n_pass, u64 **d_r
 	u32 *counters = small_ptr<u32>(s, SM_COUNTERS);
 	u64 *work = small_ptr<u64>(s, SM_DBASE_WORK);
 
+	if (rs_lds_bytes<SIZE>() > 65536) {
+		static bool attr_done = false; /* per instantiation */
+		if (!attr_done) {
+			HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_onesweep<SIZE>), hipFuncAttributeMaxDynamicSharedMemorySize,
+			                           (int)rs_lds_bytes<SIZE>()));
+			attr_done = true;
+		}
+	}
 	HIPCHK(hipMemsetAsync(ghist, 0, (size_t)n_pass * 256 * 8, s.stream));
 	{
 		u64 blocks = (n + 255) / 256;
@@ -201,7 +210,6 @@ int sort_device_t(Slot &s, u64 *d_recs, u64 *d_tmp, u64 n, u32 n_pass, u64 **d_r
 	}
 	if (s.timed)
 		HIPCHK(hipEventRecord(s.ev[3], s.stream));
-	s.sc_keys = std::min(n, PORTION);
 	for (u32 pass = 0; pass < n_pass; ++pass) {
 		const u64 *base_in = dbase + (size_t)pass * 256;
 		int flip = 0;
@@ -220,11 +228,12 @@ int sort_device_t(Slot &s, u64 *d_recs, u64 *d_tmp, u64 n, u32 n_pass, u64 **d_r
 					return rc;
 				HIPCHK(hipEventRecord(e0, s.stream));
 			}
-			k_onesweep<SIZE><<<dim3(tiles), dim3(RS_BLOCK), 0, s.stream>>>(src + start * SIZE, dst, cnt, pass, base_in, base_out,
-			                                                                 status, counters + counter_idx, tiles, err);
+			k_onesweep<SIZE><<<dim3((tiles + RS_TPB - 1) / RS_TPB), dim3(RS_BLOCK), rs_lds_bytes<SIZE>(), s.stream>>>(
+			    src + start * SIZE, dst, cnt, pass, base_in, base_out, status, counters + counter_idx, tiles, err);
 			if (s.timed)
 				HIPCHK(hipEventRecord(e1, s.stream));
 			++counter_idx;
+			s.sc_keys += cnt;
 			base_in = base_out;
 			flip ^= 1;
 		}
@@ -289,6 +298,7 @@ int run_bin_device_t(Slot &s, const DevParams &P, const uint8_t *d_in, u64 size,
 	u32 *counters = small_ptr<u32>(s, SM_COUNTERS);
 	u32 counter_idx = 0;
 	s.sc_used = 0;
+	s.sc_keys = 0;
 
 	HIPCHK(hipMemsetAsync(s.small.p, 0, SM_BYTES, s.stream));
 	HIPCHK(hipMemsetAsync(d_stats, 0, 4 * 8, s.stream));
@@ -352,8 +362,10 @@ int run_bin_device_t(Slot &s, const DevParams &P, const uint8_t *d_in, u64 size,
 	if (counter_idx >= N_COUNTERS)
 		return fail(KMC_HIP_EINVAL, "too many launches for one bin");
 	HIPCHK(hipMemsetAsync(s.status.p, 0, c_tiles * 8, s.stream));
-	k_compact<SIZE><<<dim3((u32)c_tiles), dim3(CP_BLOCK), 0, s.stream>>>(sorted, n_rec, P, d_out, out_capacity, d_lut, d_stats, d_out_bytes,
-	                                                                        (u64 *)s.status.p, counters + counter_idx, (u32)c_tiles, err);
+	k_compact<SIZE><<<dim3((u32)((c_tiles + CP_TPB - 1) / CP_TPB)), dim3(CP_BLOCK), 0, s.stream>>>(
+	    sorted, n_rec, P, d_out, out_capacity, d_lut, small_ptr<u64>(s, SM_SHARDS), d_out_bytes, (u64 *)s.status.p, counters + counter_idx,
+	    (u32)c_tiles, err);
+	k_stats_reduce<<<dim3(1), dim3(64), 0, s.stream>>>(small_ptr<u64>(s, SM_SHARDS), d_stats, n_rec);
 	++counter_idx;
 	if (s.timed)
 		HIPCHK(hipEventRecord(s.ev[5], s.stream));
@@ -437,10 +449,10 @@ int debug_compact_t(Slot &s, const DevParams &P, u64 n, u64 out_capacity, u64 lu
 	HIPCHK(hipMemsetAsync(s.status.p, 0, c_tiles * 8, s.stream));
 	if (lut_entries)
 		HIPCHK(hipMemsetAsync(s.lut.p, 0, lut_entries * 8, s.stream));
-	k_compact<SIZE><<<dim3((u32)c_tiles), dim3(CP_BLOCK), 0, s.stream>>>((const u64 *)s.recA.p, n, P, (uint8_t *)s.out.p, out_capacity,
-	                                                                        (u64 *)s.lut.p, small_ptr<u64>(s, SM_STATS),
-	                                                                        small_ptr<u64>(s, SM_OUTBYTES), (u64 *)s.status.p, counters,
-	                                                                        (u32)c_tiles, err);
+	k_compact<SIZE><<<dim3((u32)((c_tiles + CP_TPB - 1) / CP_TPB)), dim3(CP_BLOCK), 0, s.stream>>>(
+	    (const u64 *)s.recA.p, n, P, (uint8_t *)s.out.p, out_capacity, (u64 *)s.lut.p, small_ptr<u64>(s, SM_SHARDS),
+	    small_ptr<u64>(s, SM_OUTBYTES), (u64 *)s.status.p, counters, (u32)c_tiles, err);
+	k_stats_reduce<<<dim3(1), dim3(64), 0, s.stream>>>(small_ptr<u64>(s, SM_SHARDS), small_ptr<u64>(s, SM_STATS), n);
 	HIPCHK(hipGetLastError());
 	return 0;
 }
@@ -579,6 +591,7 @@ int kmc_hip_sort_records_device(kmc_hip_ctx *ctx, int dev, void *d_recs, void *d
 	Slot &s = ctx->devs[dev].slot[0];
 	s.timed = true;
 	s.sc_used = 0;
+	s.sc_keys = 0;
 	HIPCHK(hipMemsetAsync(s.small.p, 0, SM_BYTES, s.stream));
 	u32 counter_idx = 0;
 	u64 *res = nullptr;
@@ -889,6 +902,25 @@ int kmc_hip_allreduce_stats(kmc_hip_ctx *ctx, uint64_t *per_dev_stats)
 	return 0;
 }
 
+#ifdef KMC_TRACE
+/* tuning builds only: copy the device trace buffer (see kernels.hip.h TRACE_STAMP) */
+int kmc_hip_debug_read_trace(kmc_hip_ctx *ctx, int dev, unsigned long long *dst, uint64_t n_words, int clear)
+{
+	if (int rc = set_dev(ctx, dev))
+		return rc;
+	HIPCHK(hipDeviceSynchronize());
+	if (n_words > (uint64_t)TRACE_SLOTS * 8)
+		n_words = (uint64_t)TRACE_SLOTS * 8;
+	HIPCHK(hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_trace), n_words * 8, 0, hipMemcpyDeviceToHost));
+	if (clear) {
+		void *p = nullptr;
+		HIPCHK(hipGetSymbolAddress(&p, HIP_SYMBOL(g_trace)));
+		HIPCHK(hipMemset(p, 0, (size_t)TRACE_SLOTS * 64));
+	}
+	return 0;
+}
+#endif
+
 /* ---- instrumentation ---- */
 int kmc_hip_last_timings(kmc_hip_ctx *ctx, int dev, float ms[6])
 {
@@ -919,7 +951,7 @@ int kmc_hip_last_scatter_stats(kmc_hip_ctx *ctx, int dev, uint32_t *n_launches, 
 	if (total_ms)
 		*total_ms = tot;
 	if (keys_per_launch)
-		*keys_per_launch = s.sc_keys;
+		*keys_per_launch = s.sc_used >= 2 ? s.sc_keys / (s.sc_used / 2) : 0; /* average records per launch */
 	return 0;
 }
 

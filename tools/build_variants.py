@@ -1,0 +1,32 @@
+#!/usr/bin/env python3
+"""Builds tuning variants of libkmc_hip.so into kmc_amd/variants/ (macro overrides of tile geometry) so one gpurun
+call can A/B them: `KMC_HIP_LIB=kmc_amd/variants/libkmc_hip_<name>.so python bench.py ...`."""
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+VARIANTS = {
+    "base": [],
+    "k16": ["-DRS_LOOKBACK_K=16"],
+    "k24": ["-DRS_LOOKBACK_K=24", "-DRS_MIN_WAVES=3"],
+    "k16trace": ["-DRS_LOOKBACK_K=16", "-DKMC_TRACE"],
+    "trace": ["-DKMC_TRACE"],
+}
+
+
+def main(names):
+    out = os.path.join(ROOT, "kmc_amd", "variants")
+    os.makedirs(out, exist_ok=True)
+    procs = []
+    for n in names or VARIANTS:
+        cmd = ["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wno-unused-function", *VARIANTS[n],
+               os.path.join(ROOT, "kmc_amd", "csrc", "kmc_hip.hip"), "-o", os.path.join(out, f"libkmc_hip_{n}.so"), "-lrccl"]
+        procs.append((n, subprocess.Popen(cmd)))
+    for n, p in procs:
+        assert p.wait() == 0, n
+        print("built", n)
+
+
+if __name__ == "__main__":
+    main(sys.argv[1:])
