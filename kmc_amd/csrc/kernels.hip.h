@@ -31,7 +31,6 @@ typedef kmc_u32 u32;
 enum : u32 { KERR_CORRUPT = 1u, KERR_NREC = 2u, KERR_CAPACITY = 4u, KERR_WATCHDOG = 8u };
 
 /* tile geometry */
-constexpr int EXP_BLOCK = 256, EXP_ITEMS = 4, EXP_TILE = EXP_BLOCK * EXP_ITEMS; /* k-mers per expand workgroup   */
 #ifndef RS_BLOCK_THREADS
 #define RS_BLOCK_THREADS 512 /* 8192-record tiles: 16 % faster than 256 x 16 (fewer tiles to look back over, 256-B runs) */
 #endif
@@ -196,144 +195,344 @@ template <int SIZE> __device__ __forceinline__ void store_rec(u64 *p, const u64 
 	}
 }
 
-/* ------------------------------------------------------------------------------------------------ index
- * The bin image is a chain of variable-length records; the only random-access entry points the caller has are
- * the expander-pack boundaries (CExpanderPackDesc, queues.h:376-396; <= 4096 super-k-mers each,
- * kb_collector.h:46). One LANE walks one pack (64 independent chains per wave, every pack of the bin in flight
- * at once), twice: first to count, then — after an exclusive scan over packs — to write the per-super-k-mer index. */
+/* 64-bit look-back words (one per tile/slice): [63:62] flag (0 empty, 1 aggregate, 2 inclusive prefix), [61:0] count */
+constexpr u64 ST64_AGG = 1ull << 62, ST64_PREFIX = 2ull << 62, ST64_MASK = (1ull << 62) - 1;
 
-__global__ void __launch_bounds__(64) k_pack_scan(const uint8_t *__restrict__ data, const u64 *__restrict__ pack_start, u32 n_packs,
-                                                   u32 k, u32 *__restrict__ pack_nsk, u64 *__restrict__ pack_nk, u32 *err)
+/* ------------------------------------------------------------------------------------------------ parse
+ * The bin image is a chain of variable-length records (one byte of length information per record); the only
+ * random-access entry points the caller has are the expander-pack boundaries (CExpanderPackDesc, queues.h:376-396;
+ * <= 4096 super-k-mers each, kb_collector.h:46). One workgroup per pack marks every record start in a global
+ * bitmap (1 bit per input byte). Inside a pack the chain is resolved in LDS, PARSE_CHUNK bytes at a time, speculatively:
+ * every byte position is treated as a possible record start (see the three levels in the kernel). History: v1 walked
+ * the chain with one lane per pack (4096 dependent global loads per pack, ~1 us each: 8 ms per bin however small);
+ * v2 used pointer doubling over all positions (log2 rounds of two LDS sweeps: 53 k cycles per chunk). */
+constexpr int PARSE_CHUNK = 4096, PARSE_SUB = 128, PARSE_NSUB = PARSE_CHUNK / PARSE_SUB;
+
+__global__ void __launch_bounds__(256) k_parse_packs(const uint8_t *__restrict__ data, const u64 *__restrict__ pack_start, u32 n_packs, u32 k,
+                                                      u32 *__restrict__ bitmap, u32 *err)
 {
-	const u32 p = blockIdx.x * 64 + threadIdx.x;
+	/* Three levels per PARSE_CHUNK bytes staged in LDS (the chain has <= chunk/Lmin hops; walking it serially costs one
+	 * dependent load per hop):
+	 *   L1  every byte position p, in parallel: X(p) = where the chain started at p leaves p's 128-byte sub-block
+	 *       (<= 128/Lmin hops, 16 independent chains per thread interleaved so the LDS latency pipelines)
+	 *   L2  one lane hops sub-block to sub-block from the chunk's entry offset: 32 dependent LDS reads instead of ~500
+	 *   L3  one lane per sub-block walks it from its now-known entry and builds the sub-block's 128 start bits */
+	__shared__ uint8_t s_b[PARSE_CHUNK];
+	__shared__ unsigned short s_X[PARSE_CHUNK];
+	__shared__ unsigned short s_ent[PARSE_NSUB]; /* entry position + 1 of each sub-block (0 = chain does not start here) */
+	__shared__ u32 s_vis[PARSE_CHUNK / 32];
+	__shared__ u32 s_exit;
+	const u32 tid = threadIdx.x;
+	const u32 p = blockIdx.x;
 	if (p >= n_packs)
 		return;
-	u64 pos = pack_start[p];
-	const u64 end = pack_start[p + 1];
-	u32 nsk = 0;
-	u64 nk = 0;
-	while (pos < end) {
-		const u32 e = data[pos];
-		pos += 1 + ((k + e + 3) >> 2);
-		++nsk;
-		nk += e + 1;
-	}
-	if (pos != end)
-		atomicOr(err, KERR_CORRUPT);
-	pack_nsk[p] = nsk;
-	pack_nk[p] = nk;
-}
-
-/* single workgroup: exclusive scans of pack_nsk / pack_nk; totals[0] = #super-k-mers, totals[1] = #k-mers */
-__global__ void __launch_bounds__(1024) k_pack_offsets(const u32 *__restrict__ pack_nsk, const u64 *__restrict__ pack_nk, u32 n_packs,
-                                                        u64 *__restrict__ pack_sk_off, u64 *__restrict__ pack_k_off, u64 *totals,
-                                                        u64 n_rec_expected, u32 *err)
-{
-	__shared__ u64 tmp[17];
-	u64 carry_s = 0, carry_k = 0;
-	for (u32 base = 0; base < n_packs; base += 1024) {
-		const u32 i = base + threadIdx.x;
-		const u64 a = i < n_packs ? (u64)pack_nsk[i] : 0;
-		const u64 b = i < n_packs ? pack_nk[i] : 0;
-		u64 ta, tb;
-		const u64 ea = block_excl_sum<16, u64>(a, tmp, ta);
-		const u64 eb = block_excl_sum<16, u64>(b, tmp, tb);
-		if (i < n_packs) {
-			pack_sk_off[i] = carry_s + ea;
-			pack_k_off[i] = carry_k + eb;
+	const u64 pos0 = pack_start[p], end = pack_start[p + 1];
+	u32 entry = 0; /* offset inside the current chunk of the first record start */
+	for (u64 c0 = pos0; c0 < end; c0 += PARSE_CHUNK) {
+		const u32 clen = (end - c0) < (u64)PARSE_CHUNK ? (u32)(end - c0) : (u32)PARSE_CHUNK;
+		if (entry >= clen) { /* only for a ragged image; the final check below reports it */
+			entry -= clen;
+			continue;
 		}
-		carry_s += ta;
-		carry_k += tb;
+		for (u32 i = tid; i < clen; i += 256)
+			s_b[i] = data[c0 + i];
+		if (tid < PARSE_NSUB)
+			s_ent[tid] = 0;
+		__syncthreads();
+		/* L1 */
+		{
+			u32 q[PARSE_CHUNK / 256];
+#pragma unroll
+			for (int i = 0; i < PARSE_CHUNK / 256; ++i)
+				q[i] = tid + 256 * i;
+			const u32 max_hops = PARSE_SUB / (1 + ((k + 3) >> 2)) + 1;
+			for (u32 h = 0; h < max_hops; ++h) {
+#pragma unroll
+				for (int i = 0; i < PARSE_CHUNK / 256; ++i) {
+					const u32 p0 = tid + 256 * i;
+					const u32 sb_end = (p0 / PARSE_SUB + 1) * PARSE_SUB;
+					if (q[i] < sb_end && q[i] < clen)
+						q[i] += 1 + ((k + s_b[q[i]] + 3) >> 2);
+				}
+			}
+#pragma unroll
+			for (int i = 0; i < PARSE_CHUNK / 256; ++i)
+				if (tid + 256 * i < clen)
+					s_X[tid + 256 * i] = (unsigned short)q[i]; /* < clen + 130 */
+		}
+		__syncthreads();
+		/* L2 */
+		if (tid == 0) {
+			u32 q = entry;
+			while (q < clen) {
+				s_ent[q / PARSE_SUB] = (unsigned short)(q + 1);
+				q = s_X[q];
+			}
+			s_exit = q;
+		}
+		__syncthreads();
+		/* L3 */
+		if (tid < PARSE_NSUB) {
+			u32 w[PARSE_SUB / 32] = {0, 0, 0, 0};
+			const u32 e1 = s_ent[tid];
+			if (e1) {
+				u32 q = e1 - 1;
+				const u32 sb0 = tid * PARSE_SUB, sb_end = sb0 + PARSE_SUB;
+				while (q < sb_end && q < clen) {
+					const u32 r = q - sb0;
+#pragma unroll
+					for (int j = 0; j < PARSE_SUB / 32; ++j)
+						if ((r >> 5) == (u32)j)
+							w[j] |= 1u << (r & 31);
+					q += 1 + ((k + s_b[q] + 3) >> 2);
+				}
+			}
+#pragma unroll
+			for (int j = 0; j < PARSE_SUB / 32; ++j)
+				s_vis[tid * (PARSE_SUB / 32) + j] = w[j];
+		}
+		__syncthreads();
+		const u32 next_entry = s_exit - clen;
+		/* publish the chunk's bits [c0, c0+clen) into the global bitmap (bit i of the bitmap = byte i of the image) */
+		{
+			const u32 sh = (u32)(c0 & 31);
+			const u64 gw0 = c0 >> 5;
+			const u32 n_gw = (u32)(((c0 + clen + 31) >> 5) - gw0);
+			for (u32 g = tid; g < n_gw; g += 256) {
+				/* global word g covers local bits [32g - sh, 32g - sh + 32) */
+				const int lw = (int)g - (sh ? 1 : 0);
+				const u32 lo = (lw >= 0 && lw < PARSE_CHUNK / 32) ? s_vis[lw] : 0;
+				const u32 hi = (sh && lw + 1 >= 0 && lw + 1 < PARSE_CHUNK / 32) ? s_vis[lw + 1] : 0;
+				const u32 word = sh ? ((lo >> (32 - sh)) | (hi << sh)) : lo;
+				if (word) {
+					if (g == 0 || g == n_gw - 1)
+						atomicOr(&bitmap[gw0 + g], word); /* boundary words are shared with the neighbouring chunk/pack */
+					else
+						bitmap[gw0 + g] = word;
+				}
+			}
+		}
+		entry = next_entry;
+		__syncthreads();
 	}
-	if (threadIdx.x == 0) {
-		totals[0] = carry_s;
-		totals[1] = carry_k;
-		if (carry_k != n_rec_expected)
-			atomicOr(err, KERR_NREC);
-	}
-}
-
-/* second walk: sk_pos[s] = byte offset of super-k-mer s (its `e` byte), sk_koff[s] = index of its first k-mer;
- * tile_first[m] = the super-k-mer that contains k-mer m*EXP_TILE (entry point of expand tile m). */
-__global__ void __launch_bounds__(64) k_pack_index(const uint8_t *__restrict__ data, const u64 *__restrict__ pack_start, u32 n_packs,
-                                                    u32 k, const u64 *__restrict__ pack_sk_off, const u64 *__restrict__ pack_k_off,
-                                                    u64 *__restrict__ sk_pos, u64 *__restrict__ sk_koff, u64 *__restrict__ tile_first,
-                                                    u64 n_tiles, u64 sk_capacity)
-{
-	const u32 p = blockIdx.x * 64 + threadIdx.x;
-	if (p >= n_packs)
-		return;
-	u64 pos = pack_start[p];
-	const u64 end = pack_start[p + 1];
-	u64 s = pack_sk_off[p], koff = pack_k_off[p];
-	while (pos < end && s < sk_capacity) {
-		const u32 e = data[pos];
-		sk_pos[s] = pos;
-		sk_koff[s] = koff;
-		const u64 m = (koff + EXP_TILE - 1) / EXP_TILE; /* first tile boundary at or after koff */
-		if (m * EXP_TILE < koff + e + 1 && m < n_tiles)
-			tile_first[m] = s;
-		pos += 1 + ((k + e + 3) >> 2);
-		koff += e + 1;
-		++s;
-	}
+	if (tid == 0 && entry != 0)
+		atomicOr(err, KERR_CORRUPT); /* the last record does not end on the pack boundary */
 }
 
 /* ------------------------------------------------------------------------------------------------ expand
- * One THREAD per k-mer. A workgroup owns k-mers [m*T, (m+1)*T): it stages the (position, first-k-mer) pairs of
- * the super-k-mers overlapping that range in LDS, each thread binary-searches its super-k-mer there, pulls the
- * <= ceil((2k+13)/8) bytes of its window (neighbouring threads read overlapping bytes: L1 hits), builds the
- * forward k-mer and its reverse complement with bit tricks (kmer_ops.h) and writes the smaller one:
- * consecutive threads write consecutive records (coalesced 8*SIZE B per lane). */
-template <int SIZE>
-__global__ void __launch_bounds__(EXP_BLOCK) k_expand(const uint8_t *__restrict__ data, const u64 *__restrict__ sk_pos,
-                                                       const u64 *__restrict__ sk_koff, const u64 *__restrict__ tile_first,
-                                                       const u64 *__restrict__ totals, u64 n_rec, u64 n_tiles, u32 k,
-                                                       u32 both_strands, u64 *__restrict__ out)
+ * Fully parallel over EXP_CHUNK-byte slices of the image (packs no longer matter): a workgroup reads its slice and
+ * the slice's start bits, lists the super-k-mers that START in it (position, first k-mer index) in LDS, gets the
+ * slice's k-mer offset by a 64-bit decoupled look-back over slices, and then runs one THREAD per k-mer: binary search
+ * of the super-k-mer in the LDS list, window extraction from the LDS copy of the bytes, reverse complement by bit
+ * tricks (kmer_ops.h), canonical = min; consecutive threads write consecutive records. The per-pass byte histograms
+ * of the radix sort are accumulated in LDS on the way (one global flush per persistent workgroup), which removes the
+ * separate 8 B/record histogram read of the first version. */
+#ifndef EXP_BLOCK_THREADS
+#define EXP_BLOCK_THREADS 512 /* measured on the 1.65 G k-mer bin: 256 thr 13.7 ms, 512 thr 9.2 ms, 1024 thr 12.1 ms */
+#endif
+constexpr int EXP_CHUNK = 8192, EXP_TAIL = 160, EXP_MAX_SK = EXP_CHUNK / 2, EXP_KWIN = 8192, EXP_BLOCK = EXP_BLOCK_THREADS;
+
+template <int SIZE, bool FUSE_HIST>
+__global__ void __launch_bounds__(EXP_BLOCK) k_expand(const uint8_t *__restrict__ data, u64 size, const u32 *__restrict__ bitmap, u32 k,
+                                                 u32 both_strands, u32 n_pass, u64 n_rec, u64 *__restrict__ out, u64 *__restrict__ ghist,
+                                                 u64 *status, u32 *ticket_ctr, u32 n_chunks, u32 *err)
 {
-	__shared__ u64 s_pos[EXP_TILE + 1];
-	__shared__ int s_rel[EXP_TILE + 1];
-	const u64 n_sk = totals[0];
-	if (n_sk == 0)
-		return; /* only with a corrupt image (error already flagged by the index kernels) */
-	const u64 m = blockIdx.x;
-	const u64 j0 = m * EXP_TILE;
-	u64 s_lo = tile_first[m];
-	u64 s_hi = (m + 1 < n_tiles) ? tile_first[m + 1] : (n_sk - 1);
-	if (s_lo > n_sk - 1) /* clamps matter only for corrupt images: never index outside the tables */
-		s_lo = n_sk - 1;
-	if (s_hi > n_sk - 1)
-		s_hi = n_sk - 1;
-	if (s_hi < s_lo)
-		s_hi = s_lo;
-	u32 cnt = (u32)(s_hi - s_lo + 1);
-	if (cnt > EXP_TILE + 1)
-		cnt = EXP_TILE + 1; /* cannot happen for a well-formed index (every super-k-mer holds >= 1 k-mer) */
-	for (u32 i = threadIdx.x; i < cnt; i += EXP_BLOCK) {
-		s_pos[i] = sk_pos[s_lo + i];
-		s_rel[i] = (int)((long long)sk_koff[s_lo + i] - (long long)j0);
+	extern __shared__ __attribute__((aligned(16))) unsigned char s_raw[];
+	u64 *s_base = reinterpret_cast<u64 *>(s_raw);                             /* [2] (16 bytes keeps s_b 16-B aligned) */
+	uint8_t *s_b = s_raw + 16;                                                /* [EXP_CHUNK + EXP_TAIL] */
+	u32 *s_skoff = reinterpret_cast<u32 *>(s_b + EXP_CHUNK + EXP_TAIL);       /* [EXP_MAX_SK + 1] first k-mer of each super-k-mer */
+	u32 *s_tmp = s_skoff + EXP_MAX_SK + 1;                                    /* [24] scan scratch */
+	u32 *s_ticket = s_tmp + 24;                                                /* [3] */
+	u32 *s_h = s_ticket + 3;                                                  /* [n_pass * 256] when FUSE_HIST */
+	unsigned short *s_skpos = reinterpret_cast<unsigned short *>(s_h + (FUSE_HIST ? n_pass * 256 : 0)); /* [EXP_MAX_SK] byte position */
+	unsigned short *s_kidx = s_skpos + EXP_MAX_SK;                            /* [EXP_KWIN] k-mer (window-relative) -> super-k-mer */
+
+	if (FUSE_HIST) {
+		for (u32 i = threadIdx.x; i < n_pass * 256; i += EXP_BLOCK)
+			s_h[i] = 0;
 	}
-	__syncthreads();
-#pragma unroll
-	for (int r = 0; r < EXP_ITEMS; ++r) {
-		const int idx = r * EXP_BLOCK + threadIdx.x;
-		const u64 j = j0 + idx;
-		if (j >= n_rec)
-			continue;
-		/* largest i with s_rel[i] <= idx (s_rel is strictly increasing, s_rel[0] <= 0) */
-		u32 lo = 0, hi = cnt;
-		while (hi - lo > 1) {
-			const u32 mid = (lo + hi) >> 1;
-			if (s_rel[mid] <= idx)
-				lo = mid;
-			else
-				hi = mid;
+	while (true) {
+		__syncthreads();
+		if (threadIdx.x == 0)
+			s_ticket[0] = atomicAdd(ticket_ctr, 1u);
+		__syncthreads();
+		const u32 c = s_ticket[0];
+		if (c >= n_chunks)
+			break;
+		u32 tid = threadIdx.x;
+		asm volatile("" : "+v"(tid));
+		const u32 lane = tid & 63, wave = tid >> 6;
+		const u64 c0 = (u64)c * EXP_CHUNK;
+		const u32 clen = (size - c0) < (u64)EXP_CHUNK ? (u32)(size - c0) : (u32)EXP_CHUNK;
+		const u32 avail = (size - c0) < (u64)(EXP_CHUNK + EXP_TAIL) ? (u32)(size - c0) : (u32)(EXP_CHUNK + EXP_TAIL);
+		/* stage the slice (+ tail for records that start in it and end in the next one): 16-byte loads */
+		{
+			const uint4 *g = reinterpret_cast<const uint4 *>(data + c0); /* c0 is a multiple of 8192; `data` is 16-B aligned */
+			uint4 *l = reinterpret_cast<uint4 *>(s_b);
+			for (u32 i = tid; i < (avail + 15) / 16; i += EXP_BLOCK)
+				l[i] = g[i]; /* the image has >= 256 readable bytes of slack after `size` */
 		}
-		const u32 off = (u32)(idx - s_rel[lo]);
-		u64 v[SIZE];
-		kmc_canonical_at<SIZE>(data + s_pos[lo] + 1, off, k, both_strands != 0, v);
-		store_rec<SIZE>(out + j * SIZE, v);
+		/* this thread's 32 positions = one bitmap word */
+		const u32 bits = (tid < 256 && tid * 32 < clen) ? bitmap[(c0 >> 5) + tid] : 0; /* threads 0..255 own the slice's 256 words */
+		__syncthreads();
+		u32 my_sk = (u32)__popc(bits), my_k = 0;
+		{
+			u32 bb = bits;
+			while (bb) {
+				const u32 bpos = (u32)__ffs((int)bb) - 1;
+				bb &= bb - 1;
+				my_k += (u32)s_b[tid * 32 + bpos] + 1;
+			}
+		}
+		u32 tot_sk, tot_k;
+		const u32 off_sk = block_excl_sum<EXP_BLOCK / 64, u32>(my_sk, s_tmp, tot_sk);
+		const u32 off_k = block_excl_sum<EXP_BLOCK / 64, u32>(my_k, s_tmp, tot_k);
+		{
+			u32 bb = bits, i = off_sk, ko = off_k;
+			while (bb) {
+				const u32 bpos = (u32)__ffs((int)bb) - 1;
+				bb &= bb - 1;
+				if (i < (u32)EXP_MAX_SK) {
+					s_skpos[i] = (unsigned short)(tid * 32 + bpos);
+					s_skoff[i] = ko;
+				}
+				ko += (u32)s_b[tid * 32 + bpos] + 1;
+				++i;
+			}
+		}
+		/* slice offset among k-mers: decoupled look-back, one 64-bit word per slice, 64 slices per round trip */
+		if (wave == 0) {
+			u64 excl = 0;
+			if (c == 0) {
+				if (lane == 0)
+					st_agent(&status[0], ST64_PREFIX | (u64)tot_k);
+			} else {
+				if (lane == 0)
+					st_agent(&status[c], ST64_AGG | (u64)tot_k);
+				long long tbase = (long long)c - 1;
+				u32 spins = 0;
+				while (true) {
+					const long long t = tbase - (long long)lane;
+					const u64 v = t >= 0 ? ld_agent(&status[t]) : ST64_PREFIX;
+					const u64 flag = v & ~ST64_MASK;
+					const u64 m_pref = __ballot(flag == ST64_PREFIX);
+					const u64 m_zero = __ballot(flag == 0);
+					const int pl = m_pref ? (__ffsll(m_pref) - 1) : 64;
+					const u64 need = pl < 63 ? ((2ull << pl) - 1) : ~0ull;
+					if (m_zero & need) {
+						if (++spins > SPIN_LIMIT || (spins % 1024 == 0 && ld_agent(err) & KERR_WATCHDOG)) {
+							if (lane == 0)
+								atomicOr(err, KERR_WATCHDOG);
+							break;
+						}
+						__builtin_amdgcn_s_sleep(1);
+						continue;
+					}
+					const u64 part = wave_sum<u64>((int)lane <= pl ? (v & ST64_MASK) : 0ull);
+					excl += part;
+					if (pl < 64)
+						break;
+					tbase -= 64;
+				}
+				if (lane == 0)
+					st_agent(&status[c], ST64_PREFIX | (excl + tot_k));
+			}
+			if (lane == 0) {
+				*s_base = excl;
+				if (c == n_chunks - 1 && excl + tot_k != n_rec)
+					atomicOr(err, KERR_NREC); /* CBinDesc n_rec must agree with the byte stream */
+			}
+		}
+		if (tid == 0)
+			s_skoff[tot_sk < (u32)EXP_MAX_SK ? tot_sk : (u32)EXP_MAX_SK] = tot_k; /* sentinel */
+		__syncthreads();
+		const u64 base = *s_base;
+		const u32 n_sk = tot_sk < (u32)EXP_MAX_SK ? tot_sk : (u32)EXP_MAX_SK;
+		/* k-mers of the slice in windows of EXP_KWIN (one window unless the super-k-mers are unusually long) */
+		for (u32 w0 = 0; n_sk && w0 < tot_k; w0 += EXP_KWIN) {
+			const u32 wn = (tot_k - w0) < (u32)EXP_KWIN ? (tot_k - w0) : (u32)EXP_KWIN;
+			/* k-mer -> super-k-mer map: mark each super-k-mer's first k-mer, then a max-scan in k-mer order */
+			for (u32 r = tid; r < wn; r += EXP_BLOCK)
+				s_kidx[r] = 0;
+			__syncthreads();
+			for (u32 i = tid; i < n_sk; i += EXP_BLOCK) {
+				const u32 o = s_skoff[i], o1 = s_skoff[i + 1]; /* [o, o1) = this super-k-mer's k-mers; sentinel at n_sk */
+				if (o >= w0 && o < w0 + wn)
+					s_kidx[o - w0] = (unsigned short)i;
+				else if (o < w0 && o1 > w0)
+					s_kidx[0] = (unsigned short)i; /* the super-k-mer that straddles the window start */
+			}
+			__syncthreads();
+			{
+				constexpr int PER = EXP_KWIN / EXP_BLOCK;
+				u32 m = 0;
+#pragma unroll 4
+				for (int q = 0; q < PER; ++q) {
+					const u32 r = tid * PER + q;
+					if (r < wn) {
+						const u32 x = s_kidx[r];
+						m = x > m ? x : m;
+					}
+				}
+				const u32 carry = block_excl_max<EXP_BLOCK / 64, u32>(m, s_tmp);
+				m = carry;
+#pragma unroll 4
+				for (int q = 0; q < PER; ++q) {
+					const u32 r = tid * PER + q;
+					if (r < wn) {
+						const u32 x = s_kidx[r];
+						m = x > m ? x : m;
+						s_kidx[r] = (unsigned short)m;
+					}
+				}
+			}
+			__syncthreads();
+			for (u32 r = tid; r < wn; r += EXP_BLOCK) {
+				const u32 j = w0 + r;
+				const u32 si = s_kidx[r];
+				const u64 gj = base + j;
+				if (gj < n_rec) {
+					u64 v[SIZE];
+					const u32 off = j - s_skoff[si];
+					if constexpr (SIZE == 1) {
+						/* k <= 32: the window is <= 70 bits: three aligned LDS dwords, byte-swapped into a bit stream */
+						const u32 a = 16u + (u32)s_skpos[si] + 1u + (off >> 2); /* byte offset inside s_raw (s_b = s_raw + 16) */
+						const u32 *wp = reinterpret_cast<const u32 *>(s_raw + (a & ~3u));
+						const u32 b0 = __builtin_bswap32(wp[0]), b1 = __builtin_bswap32(wp[1]), b2 = __builtin_bswap32(wp[2]);
+						const u32 skip = 8u * (a & 3u) + 2u * (off & 3u); /* <= 30 */
+						const u64 top = ((u64)b0 << 32) | b1;
+						const u64 x = skip ? ((top << skip) | ((u64)b2 >> (32 - skip))) : top;
+						u64 f = x >> (64 - 2 * k);
+						if (both_strands) {
+							u64 rc = ~kmc_rev2(f) >> (64 - 2 * k); /* complement + reverse, realigned to the low 2k bits */
+							f = rc < f ? rc : f;
+						}
+						v[0] = f;
+					} else {
+						kmc_canonical_at<SIZE>(s_b + s_skpos[si] + 1, off, k, both_strands != 0, v);
+					}
+					store_rec<SIZE>(out + gj * SIZE, v);
+					if (FUSE_HIST) {
+						for (u32 b = 0; b < n_pass; ++b)
+							atomicAdd(&s_h[b * 256 + kmc_get_byte<SIZE>(v, b)], 1u);
+					}
+				}
+			}
+			__syncthreads();
+		}
 	}
+	if (FUSE_HIST) {
+		__syncthreads();
+		for (u32 i = threadIdx.x; i < n_pass * 256; i += EXP_BLOCK) {
+			const u32 v = s_h[i];
+			if (v)
+				atomicAdd(&ghist[i], (u64)v);
+		}
+	}
+}
+template <bool FUSE_HIST> constexpr size_t exp_lds_bytes(u32 n_pass)
+{
+	return 16 + (size_t)EXP_CHUNK + EXP_TAIL + (EXP_MAX_SK + 1 + 24 + 3) * 4 + (FUSE_HIST ? (size_t)n_pass * 1024 : 0) + EXP_MAX_SK * 2 + EXP_KWIN * 2 + 16;
 }
 
 /* ------------------------------------------------------------------------------------------------ histogram
@@ -408,6 +607,14 @@ constexpr u32 ST_AGG = 1u << 30, ST_PREFIX = 2u << 30, ST_MASK = (1u << 30) - 1;
 #ifndef RS_TPB
 #define RS_TPB 1 /* tiles per ticket. Keep 1: a workgroup that owns consecutive tiles publishes the later ones late and every
                    * successor's look-back stalls on them (measured 150x slower at 2); larger tiles are the way to fewer tickets */
+#endif
+
+#ifdef KMC_EXP_ORACLE_PREFIX
+/* experiment only: what would the scatter cost with a free look-back? mode 1 records every tile's exclusive prefixes,
+ * mode 2 replays them instead of walking back (same input => same tiles). */
+__device__ u32 *g_saved_prefix;
+__device__ int g_oracle_mode;
+__device__ u32 g_launch_seq; /* tile-row base of the current launch, advanced by the host */
 #endif
 
 template <int SIZE>
@@ -545,7 +752,14 @@ __global__ void __launch_bounds__(RS_BLOCK, RS_MIN_WAVES) k_onesweep(const u64 *
 			s_doff[tid] = doff;
 
 			u32 excl = 0;
+#ifdef KMC_EXP_ORACLE_PREFIX
+			const bool replay = g_oracle_mode == 2;
+			if (replay)
+				excl = g_saved_prefix[((u64)g_launch_seq + tile) * 256 + tid];
+			if (tile > 0 && !replay) {
+#else
 			if (tile > 0) {
+#endif
 				/* walk back over earlier tiles, RS_LOOKBACK_K status words per round trip: tiles start ~25-40 per
 				 * microsecond while one dependent global load costs ~0.5-1 us, so a one-word-per-hop walk spends most
 				 * of the tile's life here (measured: 39 % of it) */
@@ -588,6 +802,10 @@ __global__ void __launch_bounds__(RS_BLOCK, RS_MIN_WAVES) k_onesweep(const u64 *
 				TRACE_VALUE(2, tile, 5, (u64)((int)tile - 1 - t));
 				st_agent(&status[(u64)tile * 256 + tid], ST_PREFIX | (excl + cnt));
 			}
+#ifdef KMC_EXP_ORACLE_PREFIX
+			if (g_oracle_mode == 1)
+				g_saved_prefix[((u64)g_launch_seq + tile) * 256 + tid] = excl;
+#endif
 			const u64 gbase = digit_base_in[tid] + excl;
 			s_goff[tid] = gbase - doff;
 			if (tile == num_tiles - 1)
@@ -642,7 +860,6 @@ template <int SIZE> constexpr size_t rs_lds_bytes()
  * k-mers comes from a 64-bit decoupled look-back (one word per tile). LUT updates are aggregated per tile: the
  * prefixes of the tile's counted k-mers are a sorted list in LDS, and each run of equal prefixes costs two global
  * atomics (+end, -begin) instead of one per k-mer. */
-constexpr u64 ST64_AGG = 1ull << 62, ST64_PREFIX = 2ull << 62, ST64_MASK = (1ull << 62) - 1;
 
 template <int SIZE>
 __device__ __forceinline__ u64 run_start_search(const u64 *__restrict__ S, u64 base, u32 lane)
@@ -695,8 +912,9 @@ constexpr int CP_SHARDS = 32; /* tally shards: same-address device atomics seria
 
 template <int SIZE>
 __global__ void __launch_bounds__(CP_BLOCK) k_compact(const u64 *__restrict__ S, u64 n, DevParams P, uint8_t *__restrict__ out,
-                                                       u64 out_capacity, u64 *__restrict__ lut, u64 *stat_shards /* [CP_SHARDS][4] */,
-                                                       u64 *out_bytes, u64 *status, u32 *tile_counter, u32 num_tiles, u32 *err)
+                                                       u64 out_capacity, u64 *__restrict__ lut_base, u32 lut_shards, u64 lut_stride,
+                                                       u64 *stat_shards /* [CP_SHARDS][4] */, u64 *out_bytes, u64 *status, u32 *tile_counter,
+                                                       u32 num_tiles, u32 *err)
 {
 	constexpr int ITEMS = CpCfg<SIZE>::ITEMS;
 	constexpr int TILE = CpCfg<SIZE>::TILE;
@@ -895,6 +1113,62 @@ __global__ void __launch_bounds__(CP_BLOCK) k_compact(const u64 *__restrict__ S,
 					if (counted_bits & (1u << i))
 						s_pref[j++] = (u32)kmc_remove_suffix<SIZE>(key[i], 2 * (P.k - P.lut_prefix_len));
 			}
+			if (rec_bytes <= 8) {
+				/* fast path (k <= ~36): a record is one 64-bit value in output byte order; records go to an LDS window,
+				 * then every thread composes aligned output dwords from it */
+				u64 *s_rec = reinterpret_cast<u64 *>(s_stage);
+				constexpr u32 WREC = CP_STAGE / 8;
+				for (u32 r0 = 0; fits && r0 < tile_counted; r0 += WREC) {
+					const u32 r1 = (tile_counted - r0) < WREC ? tile_counted : r0 + WREC;
+					u32 j = thread_off;
+#pragma unroll
+					for (int i = 0; i < ITEMS; ++i) {
+						if (counted_bits & (1u << i)) {
+							if (j >= r0 && j < r1) {
+								u64 rv = P.sbytes ? __builtin_bswap64(key[i][0] << (8 * (8 - P.sbytes))) : 0ull;
+								if (P.cbytes) {
+									const u32 cv = P.kff ? (__builtin_bswap32(count[i]) >> (8 * (4 - P.cbytes))) : count[i];
+									rv |= (u64)cv << (8 * P.sbytes);
+								}
+								s_rec[j - r0] = rv;
+							}
+							++j;
+						}
+					}
+					__syncthreads();
+					const u64 g0 = gbyte0 + (u64)r0 * rec_bytes;
+					const u32 len = (r1 - r0) * rec_bytes;
+					u32 head = (u32)((4 - ((uintptr_t)(out + g0) & 3)) & 3);
+					if (head > len)
+						head = len;
+					const u32 ndw = (len - head) >> 2;
+					const u32 tail0 = head + (ndw << 2);
+					if (tid < head)
+						out[g0 + tid] = (uint8_t)(s_rec[tid / rec_bytes] >> (8 * (tid % rec_bytes)));
+					if (tid >= 32 && tid - 32 < len - tail0) {
+						const u32 bi = tail0 + (tid - 32);
+						out[g0 + bi] = (uint8_t)(s_rec[bi / rec_bytes] >> (8 * (bi % rec_bytes)));
+					}
+					u32 *gd = reinterpret_cast<u32 *>(out + g0 + head);
+					for (u32 w = tid; w < ndw; w += CP_BLOCK) {
+						const u32 i0 = head + (w << 2);
+						u32 ri = i0 / rec_bytes, q = i0 - ri * rec_bytes;
+						u64 cur = s_rec[ri];
+						u32 word = 0;
+#pragma unroll
+						for (int t = 0; t < 4; ++t) {
+							word |= ((u32)(cur >> (8 * q)) & 0xFFu) << (8 * t);
+							if (++q == rec_bytes) {
+								q = 0;
+								++ri;
+								cur = s_rec[ri < WREC ? ri : WREC - 1];
+							}
+						}
+						gd[w] = word;
+					}
+					__syncthreads();
+				}
+			} else
 			for (u32 c0 = 0; fits && c0 < tile_bytes; c0 += CP_STAGE) {
 				const u32 c1 = (tile_bytes - c0) < (u32)CP_STAGE ? tile_bytes : c0 + CP_STAGE;
 				u32 j = thread_off;
@@ -943,6 +1217,9 @@ __global__ void __launch_bounds__(CP_BLOCK) k_compact(const u64 *__restrict__ S,
 		}
 		__syncthreads();
 		if (use_lut) {
+			/* small LUTs are sharded: in sorted order every tile in flight updates the same one or two entries, and
+			 * same-address device atomics serialise at ~11 ns each (that alone was 11 of this kernel's 12 ms) */
+			u64 *lut = lut_base + (size_t)(tile % lut_shards) * lut_stride;
 			for (u32 j = tid; j < tile_counted; j += CP_BLOCK) {
 				const u32 pf = s_pref[j];
 				if (j + 1 == tile_counted || s_pref[j + 1] != pf)
@@ -963,6 +1240,18 @@ __global__ void __launch_bounds__(CP_BLOCK) k_compact(const u64 *__restrict__ S,
 		if (acc_a)
 			atomicAdd(&sh[2], acc_a);
 	}
+}
+
+/* lut[i] = sum over shards */
+__global__ void __launch_bounds__(256) k_lut_reduce(const u64 *__restrict__ shards, u32 n_shards, u64 entries, u64 *__restrict__ lut)
+{
+	const u64 i = (u64)blockIdx.x * 256 + threadIdx.x;
+	if (i >= entries)
+		return;
+	u64 v = 0;
+	for (u32 sidx = 0; sidx < n_shards; ++sidx)
+		v += shards[(size_t)sidx * entries + i];
+	lut[i] = v;
 }
 
 /* stats[0..2] = sum of the shards; stats[3] = n_total = n_rec (kb_sorter.h:1166) */

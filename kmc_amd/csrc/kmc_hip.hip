@@ -84,8 +84,8 @@ struct HostRes {
 
 struct Slot {
 	hipStream_t stream = nullptr;
-	DBuf in, pack_start, pack_nsk, pack_nk, pack_sk_off, pack_k_off, sk_pos, sk_koff, tile_first;
-	DBuf recA, recB, ghist, dbase, status, out, lut, small;
+	DBuf in, pack_start, bitmap;
+	DBuf recA, recB, ghist, dbase, status, out, lut, lutsh, small;
 	HostRes *h_res = nullptr; /* pinned */
 	hipEvent_t ev[6] = {};
 	std::vector<hipEvent_t> sc_ev;
@@ -142,8 +142,7 @@ int slot_init(Slot &s)
 
 void slot_destroy(Slot &s)
 {
-	for (DBuf *b : {&s.in, &s.pack_start, &s.pack_nsk, &s.pack_nk, &s.pack_sk_off, &s.pack_k_off, &s.sk_pos, &s.sk_koff,
-	                &s.tile_first, &s.recA, &s.recB, &s.ghist, &s.dbase, &s.status, &s.out, &s.lut, &s.small})
+	for (DBuf *b : {&s.in, &s.pack_start, &s.bitmap, &s.recA, &s.recB, &s.ghist, &s.dbase, &s.status, &s.out, &s.lut, &s.lutsh, &s.small})
 		if (b->p)
 			(void)hipFree(b->p);
 	if (s.h_res)
@@ -172,7 +171,7 @@ int sc_event(Slot &s, hipEvent_t &e)
 
 /* ---- the sort: histogram of every digit + n_pass onesweep launches (per portion) --------------------------- */
 template <int SIZE>
-int sort_device_t(Slot &s, u64 *d_recs, u64 *d_tmp, u64 n, u32 n_pass, u64 **d_result, u32 &counter_idx)
+int sort_device_t(Slot &s, u64 *d_recs, u64 *d_tmp, u64 n, u32 n_pass, u64 **d_result, u32 &counter_idx, bool hist_done = false)
 {
 	u64 *src = d_recs, *dst = d_tmp;
 	if (n < 2 || n_pass == 0) {
@@ -200,14 +199,14 @@ int sort_device_t(Slot &s, u64 *d_recs, u64 *d_tmp, u64 n, u32 n_pass, u64 **d_r
 			attr_done = true;
 		}
 	}
-	HIPCHK(hipMemsetAsync(ghist, 0, (size_t)n_pass * 256 * 8, s.stream));
-	{
+	if (!hist_done) {
+		HIPCHK(hipMemsetAsync(ghist, 0, (size_t)n_pass * 256 * 8, s.stream));
 		u64 blocks = (n + 255) / 256;
 		if (blocks > 256 * 8)
 			blocks = 256 * 8; /* 8 workgroups per CU, grid-stride */
 		k_hist<SIZE><<<dim3((u32)blocks), dim3(256), (size_t)n_pass * 1024, s.stream>>>(src, n, n_pass, ghist);
-		k_hist_scan<<<dim3(n_pass), dim3(256), 0, s.stream>>>(ghist, dbase);
 	}
+	k_hist_scan<<<dim3(n_pass), dim3(256), 0, s.stream>>>(ghist, dbase);
 	if (s.timed)
 		HIPCHK(hipEventRecord(s.ev[3], s.stream));
 	for (u32 pass = 0; pass < n_pass; ++pass) {
@@ -228,6 +227,18 @@ int sort_device_t(Slot &s, u64 *d_recs, u64 *d_tmp, u64 n, u32 n_pass, u64 **d_r
 					return rc;
 				HIPCHK(hipEventRecord(e0, s.stream));
 			}
+#ifdef KMC_EXP_ORACLE_PREFIX
+			{
+				static u32 seq_host = 0;
+				static u64 sort_id = 0;
+				if (pass == 0 && start == 0)
+					seq_host = 0;
+				(void)sort_id;
+				HIPCHK(hipMemcpyToSymbolAsync(HIP_SYMBOL(g_launch_seq), &seq_host, 4, 0, hipMemcpyHostToDevice, s.stream));
+				HIPCHK(hipStreamSynchronize(s.stream));
+				seq_host += tiles;
+			}
+#endif
 			k_onesweep<SIZE><<<dim3((tiles + RS_TPB - 1) / RS_TPB), dim3(RS_BLOCK), rs_lds_bytes<SIZE>(), s.stream>>>(
 			    src + start * SIZE, dst, cnt, pass, base_in, base_out, status, counters + counter_idx, tiles, err);
 			if (s.timed)
@@ -286,6 +297,81 @@ int check_params(const kmc_hip_bin_params *p, DevParams &P)
 	return 0;
 }
 
+/* ---- front end: mark super-k-mer starts (per pack), then expand slice-parallel with the sort's histograms fused in ---- */
+template <int SIZE>
+int front_end(Slot &s, const DevParams &P, const uint8_t *d_in, u64 size, u64 n_rec, const u64 *d_pack_start, u64 n_packs, u32 n_pass,
+              u32 &counter_idx, bool &hist_done)
+{
+	u32 *err = small_ptr<u32>(s, SM_ERR);
+	u32 *counters = small_ptr<u32>(s, SM_COUNTERS);
+	const u64 bm_words = (size + 31) / 32 + 2;
+	const u64 n_chunks = (size + EXP_CHUNK - 1) / EXP_CHUNK;
+	if (n_chunks > 0x7FFFFFF0ull || n_packs > 0x7FFFFFF0ull)
+		return fail(KMC_HIP_EINVAL, "bin too large");
+	int rc = 0;
+	if ((rc = ensure(s.bitmap, bm_words * 4)) || (rc = ensure(s.status, n_chunks * 8)) || (rc = ensure(s.ghist, (size_t)n_pass * 256 * 8)))
+		return rc;
+	HIPCHK(hipMemsetAsync(s.bitmap.p, 0, bm_words * 4, s.stream));
+	HIPCHK(hipMemsetAsync(s.status.p, 0, n_chunks * 8, s.stream));
+	k_parse_packs<<<dim3((u32)n_packs), dim3(256), 0, s.stream>>>(d_in, d_pack_start, (u32)n_packs, P.k, (u32 *)s.bitmap.p, err);
+	if (s.timed)
+		HIPCHK(hipEventRecord(s.ev[1], s.stream));
+	const bool fuse = n_pass <= 16 && n_rec >= 2; /* LDS: 1 KB of counters per pass next to the 33 KB of slice state */
+	if (fuse)
+		HIPCHK(hipMemsetAsync(s.ghist.p, 0, (size_t)n_pass * 256 * 8, s.stream));
+	const u32 blocks = (u32)std::min<u64>(n_chunks, 256 * 2 * (1024 / EXP_BLOCK));
+	if (fuse)
+		k_expand<SIZE, true><<<dim3(blocks), dim3(EXP_BLOCK), exp_lds_bytes<true>(n_pass), s.stream>>>(
+		    d_in, size, (const u32 *)s.bitmap.p, P.k, P.both_strands, n_pass, n_rec, (u64 *)s.recA.p, (u64 *)s.ghist.p, (u64 *)s.status.p,
+		    counters + counter_idx, (u32)n_chunks, err);
+	else
+		k_expand<SIZE, false><<<dim3(blocks), dim3(EXP_BLOCK), exp_lds_bytes<false>(n_pass), s.stream>>>(
+		    d_in, size, (const u32 *)s.bitmap.p, P.k, P.both_strands, n_pass, n_rec, (u64 *)s.recA.p, (u64 *)s.ghist.p, (u64 *)s.status.p,
+		    counters + counter_idx, (u32)n_chunks, err);
+	++counter_idx;
+	hist_done = fuse;
+	if (s.timed)
+		HIPCHK(hipEventRecord(s.ev[2], s.stream));
+	HIPCHK(hipGetLastError());
+	return 0;
+}
+
+/* ---- compaction launch (+ tally / LUT shard reductions) ---- */
+template <int SIZE>
+int launch_compact(Slot &s, const u64 *sorted, u64 n, const DevParams &P, uint8_t *d_out, u64 out_capacity, u64 *d_lut, u64 lut_entries,
+                   u64 *d_stats, u64 *d_out_bytes, u32 &counter_idx)
+{
+	u32 *err = small_ptr<u32>(s, SM_ERR);
+	u32 *counters = small_ptr<u32>(s, SM_COUNTERS);
+	const u64 c_tiles = (n + CpCfg<SIZE>::TILE - 1) / CpCfg<SIZE>::TILE;
+	if (c_tiles > 0x7FFFFFFFull)
+		return fail(KMC_HIP_EINVAL, "bin too large");
+	if (counter_idx >= N_COUNTERS)
+		return fail(KMC_HIP_EINVAL, "too many launches for one bin");
+	int rc = 0;
+	if ((rc = ensure(s.status, c_tiles * 8)))
+		return rc;
+	const bool use_lut = lut_entries && !P.without_output && !P.kff;
+	const u32 n_sh = !use_lut ? 1u : (lut_entries <= 1024 ? 32u : (lut_entries <= 16384 ? 4u : 1u));
+	u64 *lut_base = d_lut;
+	if (use_lut && n_sh > 1) {
+		if ((rc = ensure(s.lutsh, (size_t)n_sh * lut_entries * 8)))
+			return rc;
+		HIPCHK(hipMemsetAsync(s.lutsh.p, 0, (size_t)n_sh * lut_entries * 8, s.stream));
+		lut_base = (u64 *)s.lutsh.p;
+	}
+	HIPCHK(hipMemsetAsync(s.status.p, 0, c_tiles * 8, s.stream));
+	k_compact<SIZE><<<dim3((u32)((c_tiles + CP_TPB - 1) / CP_TPB)), dim3(CP_BLOCK), 0, s.stream>>>(
+	    sorted, n, P, d_out, out_capacity, lut_base, n_sh, lut_entries, small_ptr<u64>(s, SM_SHARDS), d_out_bytes, (u64 *)s.status.p,
+	    counters + counter_idx, (u32)c_tiles, err);
+	++counter_idx;
+	k_stats_reduce<<<dim3(1), dim3(64), 0, s.stream>>>(small_ptr<u64>(s, SM_SHARDS), d_stats, n);
+	if (use_lut && n_sh > 1)
+		k_lut_reduce<<<dim3((u32)((lut_entries + 255) / 256)), dim3(256), 0, s.stream>>>((const u64 *)s.lutsh.p, n_sh, lut_entries, d_lut);
+	HIPCHK(hipGetLastError());
+	return 0;
+}
+
 /* ---- one bin, everything device resident --------------------------------------------------------------------- */
 template <int SIZE>
 int run_bin_device_t(Slot &s, const DevParams &P, const uint8_t *d_in, u64 size, u64 n_rec, const u64 *d_pack_start,
@@ -316,37 +402,15 @@ int run_bin_device_t(Slot &s, const DevParams &P, const uint8_t *d_in, u64 size,
 	if (n_packs == 0 || n_packs > 0xFFFFFFF0ull)
 		return fail(KMC_HIP_EINVAL, "n_packs out of range");
 
-	const u64 n_tiles = (n_rec + EXP_TILE - 1) / EXP_TILE;
-	const u64 sk_cap = size / (1 + (k + 3) / 4) + 1;
 	int rc = 0;
-	if ((rc = ensure(s.pack_nsk, n_packs * 4)) || (rc = ensure(s.pack_nk, n_packs * 8)) || (rc = ensure(s.pack_sk_off, n_packs * 8)) ||
-	    (rc = ensure(s.pack_k_off, n_packs * 8)) || (rc = ensure(s.sk_pos, sk_cap * 8)) || (rc = ensure(s.sk_koff, sk_cap * 8)) ||
-	    (rc = ensure(s.tile_first, (n_tiles + 1) * 8)) || (rc = ensure(s.recA, n_rec * SIZE * 8 + 256)) ||
-	    (rc = ensure(s.recB, n_rec * SIZE * 8 + 256)))
+	if ((rc = ensure(s.recA, n_rec * SIZE * 8 + 256)) || (rc = ensure(s.recB, n_rec * SIZE * 8 + 256)))
 		return rc;
-
-	/* index */
-	HIPCHK(hipMemsetAsync(s.tile_first.p, 0, (n_tiles + 1) * 8, s.stream));
-	const u32 pk_blocks = (u32)((n_packs + 63) / 64);
-	k_pack_scan<<<dim3(pk_blocks), dim3(64), 0, s.stream>>>(d_in, d_pack_start, (u32)n_packs, k, (u32 *)s.pack_nsk.p, (u64 *)s.pack_nk.p, err);
-	k_pack_offsets<<<dim3(1), dim3(1024), 0, s.stream>>>((const u32 *)s.pack_nsk.p, (const u64 *)s.pack_nk.p, (u32)n_packs,
-	                                                       (u64 *)s.pack_sk_off.p, (u64 *)s.pack_k_off.p, totals, n_rec, err);
-	k_pack_index<<<dim3(pk_blocks), dim3(64), 0, s.stream>>>(d_in, d_pack_start, (u32)n_packs, k, (const u64 *)s.pack_sk_off.p,
-	                                                           (const u64 *)s.pack_k_off.p, (u64 *)s.sk_pos.p, (u64 *)s.sk_koff.p,
-	                                                           (u64 *)s.tile_first.p, n_tiles, sk_cap);
-	if (s.timed)
-		HIPCHK(hipEventRecord(s.ev[1], s.stream));
-	/* expand */
-	if (n_tiles > 0x7FFFFFFFull)
-		return fail(KMC_HIP_EINVAL, "bin too large");
-	k_expand<SIZE><<<dim3((u32)n_tiles), dim3(EXP_BLOCK), 0, s.stream>>>(d_in, (const u64 *)s.sk_pos.p, (const u64 *)s.sk_koff.p,
-	                                                                       (const u64 *)s.tile_first.p, totals, n_rec, n_tiles, k,
-	                                                                       P.both_strands, (u64 *)s.recA.p);
-	if (s.timed)
-		HIPCHK(hipEventRecord(s.ev[2], s.stream));
+	bool hist_done = false;
+	if ((rc = front_end<SIZE>(s, P, d_in, size, n_rec, d_pack_start, n_packs, n_pass, counter_idx, hist_done)))
+		return rc;
 	/* sort */
 	u64 *sorted = nullptr;
-	if ((rc = sort_device_t<SIZE>(s, (u64 *)s.recA.p, (u64 *)s.recB.p, n_rec, n_pass, &sorted, counter_idx)))
+	if ((rc = sort_device_t<SIZE>(s, (u64 *)s.recA.p, (u64 *)s.recB.p, n_rec, n_pass, &sorted, counter_idx, hist_done)))
 		return rc;
 	if (s.timed) {
 		if (n_rec < 2)
@@ -354,19 +418,8 @@ int run_bin_device_t(Slot &s, const DevParams &P, const uint8_t *d_in, u64 size,
 		HIPCHK(hipEventRecord(s.ev[4], s.stream));
 	}
 	/* compact */
-	const u64 c_tiles = (n_rec + CpCfg<SIZE>::TILE - 1) / CpCfg<SIZE>::TILE;
-	if (c_tiles > 0x7FFFFFFFull)
-		return fail(KMC_HIP_EINVAL, "bin too large");
-	if ((rc = ensure(s.status, c_tiles * 8)))
+	if ((rc = launch_compact<SIZE>(s, sorted, n_rec, P, d_out, out_capacity, d_lut, lut_entries, d_stats, d_out_bytes, counter_idx)))
 		return rc;
-	if (counter_idx >= N_COUNTERS)
-		return fail(KMC_HIP_EINVAL, "too many launches for one bin");
-	HIPCHK(hipMemsetAsync(s.status.p, 0, c_tiles * 8, s.stream));
-	k_compact<SIZE><<<dim3((u32)((c_tiles + CP_TPB - 1) / CP_TPB)), dim3(CP_BLOCK), 0, s.stream>>>(
-	    sorted, n_rec, P, d_out, out_capacity, d_lut, small_ptr<u64>(s, SM_SHARDS), d_out_bytes, (u64 *)s.status.p, counters + counter_idx,
-	    (u32)c_tiles, err);
-	k_stats_reduce<<<dim3(1), dim3(64), 0, s.stream>>>(small_ptr<u64>(s, SM_SHARDS), d_stats, n_rec);
-	++counter_idx;
 	if (s.timed)
 		HIPCHK(hipEventRecord(s.ev[5], s.stream));
 	HIPCHK(hipGetLastError());
@@ -411,50 +464,23 @@ namespace {
 template <int SIZE>
 int debug_expand_t(Slot &s, const DevParams &P, u64 size, u64 n_rec, u64 np)
 {
-	const u32 k = P.k;
-	u32 *err = small_ptr<u32>(s, SM_ERR);
-	u64 *totals = small_ptr<u64>(s, SM_TOTALS);
-	const u64 n_tiles = (n_rec + EXP_TILE - 1) / EXP_TILE;
-	const u64 sk_cap = size / (1 + (k + 3) / 4) + 1;
 	int rc = 0;
-	if ((rc = ensure(s.pack_nsk, np * 4)) || (rc = ensure(s.pack_nk, np * 8)) || (rc = ensure(s.pack_sk_off, np * 8)) ||
-	    (rc = ensure(s.pack_k_off, np * 8)) || (rc = ensure(s.sk_pos, sk_cap * 8)) || (rc = ensure(s.sk_koff, sk_cap * 8)) ||
-	    (rc = ensure(s.tile_first, (n_tiles + 1) * 8)) || (rc = ensure(s.recA, n_rec * SIZE * 8 + 256)))
+	if ((rc = ensure(s.recA, n_rec * SIZE * 8 + 256)))
 		return rc;
 	HIPCHK(hipMemsetAsync(s.small.p, 0, SM_BYTES, s.stream));
-	HIPCHK(hipMemsetAsync(s.tile_first.p, 0, (n_tiles + 1) * 8, s.stream));
-	const u32 pk_blocks = (u32)((np + 63) / 64);
-	k_pack_scan<<<dim3(pk_blocks), dim3(64), 0, s.stream>>>((const uint8_t *)s.in.p, (const u64 *)s.pack_start.p, (u32)np, k,
-	                                                          (u32 *)s.pack_nsk.p, (u64 *)s.pack_nk.p, err);
-	k_pack_offsets<<<dim3(1), dim3(1024), 0, s.stream>>>((const u32 *)s.pack_nsk.p, (const u64 *)s.pack_nk.p, (u32)np, (u64 *)s.pack_sk_off.p,
-	                                                       (u64 *)s.pack_k_off.p, totals, n_rec, err);
-	k_pack_index<<<dim3(pk_blocks), dim3(64), 0, s.stream>>>((const uint8_t *)s.in.p, (const u64 *)s.pack_start.p, (u32)np, k,
-	                                                           (const u64 *)s.pack_sk_off.p, (const u64 *)s.pack_k_off.p, (u64 *)s.sk_pos.p,
-	                                                           (u64 *)s.sk_koff.p, (u64 *)s.tile_first.p, n_tiles, sk_cap);
-	k_expand<SIZE><<<dim3((u32)n_tiles), dim3(EXP_BLOCK), 0, s.stream>>>((const uint8_t *)s.in.p, (const u64 *)s.sk_pos.p,
-	                                                                       (const u64 *)s.sk_koff.p, (const u64 *)s.tile_first.p, totals,
-	                                                                       n_rec, n_tiles, k, P.both_strands, (u64 *)s.recA.p);
-	HIPCHK(hipGetLastError());
-	return 0;
+	u32 counter_idx = 0;
+	bool hist_done = false;
+	return front_end<SIZE>(s, P, (const uint8_t *)s.in.p, size, n_rec, (const u64 *)s.pack_start.p, np, (2 * P.k + 7) / 8, counter_idx, hist_done);
 }
 template <int SIZE>
 int debug_compact_t(Slot &s, const DevParams &P, u64 n, u64 out_capacity, u64 lut_entries)
 {
-	u32 *err = small_ptr<u32>(s, SM_ERR);
-	u32 *counters = small_ptr<u32>(s, SM_COUNTERS);
-	const u64 c_tiles = (n + CpCfg<SIZE>::TILE - 1) / CpCfg<SIZE>::TILE;
-	if (int rc = ensure(s.status, c_tiles * 8))
-		return rc;
 	HIPCHK(hipMemsetAsync(s.small.p, 0, SM_BYTES, s.stream));
-	HIPCHK(hipMemsetAsync(s.status.p, 0, c_tiles * 8, s.stream));
 	if (lut_entries)
 		HIPCHK(hipMemsetAsync(s.lut.p, 0, lut_entries * 8, s.stream));
-	k_compact<SIZE><<<dim3((u32)((c_tiles + CP_TPB - 1) / CP_TPB)), dim3(CP_BLOCK), 0, s.stream>>>(
-	    (const u64 *)s.recA.p, n, P, (uint8_t *)s.out.p, out_capacity, (u64 *)s.lut.p, small_ptr<u64>(s, SM_SHARDS),
-	    small_ptr<u64>(s, SM_OUTBYTES), (u64 *)s.status.p, counters, (u32)c_tiles, err);
-	k_stats_reduce<<<dim3(1), dim3(64), 0, s.stream>>>(small_ptr<u64>(s, SM_SHARDS), small_ptr<u64>(s, SM_STATS), n);
-	HIPCHK(hipGetLastError());
-	return 0;
+	u32 counter_idx = 0;
+	return launch_compact<SIZE>(s, (const u64 *)s.recA.p, n, P, (uint8_t *)s.out.p, out_capacity, (u64 *)s.lut.p, lut_entries,
+	                            small_ptr<u64>(s, SM_STATS), small_ptr<u64>(s, SM_OUTBYTES), counter_idx);
 }
 } // namespace
 
@@ -917,6 +943,21 @@ int kmc_hip_debug_read_trace(kmc_hip_ctx *ctx, int dev, unsigned long long *dst,
 		HIPCHK(hipGetSymbolAddress(&p, HIP_SYMBOL(g_trace)));
 		HIPCHK(hipMemset(p, 0, (size_t)TRACE_SLOTS * 64));
 	}
+	return 0;
+}
+#endif
+
+#ifdef KMC_EXP_ORACLE_PREFIX
+int kmc_hip_debug_oracle_prefix(kmc_hip_ctx *ctx, int dev, int mode, uint64_t total_tiles)
+{
+	if (int rc = set_dev(ctx, dev))
+		return rc;
+	static void *buf = nullptr;
+	if (!buf) {
+		HIPCHK(hipMalloc(&buf, total_tiles * 1024));
+		HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(g_saved_prefix), &buf, sizeof(buf)));
+	}
+	HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(g_oracle_mode), &mode, sizeof(int)));
 	return 0;
 }
 #endif

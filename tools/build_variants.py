@@ -8,9 +8,9 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 VARIANTS = {
     "base": [],
-    "k16": ["-DRS_LOOKBACK_K=16"],
-    "k24": ["-DRS_LOOKBACK_K=24", "-DRS_MIN_WAVES=3"],
-    "k16trace": ["-DRS_LOOKBACK_K=16", "-DKMC_TRACE"],
+    "cp512x8": ["-DCP_BLOCK_THREADS=512", "-DCP_WORDS_PER_THREAD=8"],
+    "cp256x8": ["-DCP_BLOCK_THREADS=256", "-DCP_WORDS_PER_THREAD=8"],
+    "cp1024x8": ["-DCP_BLOCK_THREADS=1024", "-DCP_WORDS_PER_THREAD=8"],
     "trace": ["-DKMC_TRACE"],
 }
 
