@@ -13,7 +13,10 @@
 #include <dlfcn.h>
 #include <unistd.h>
 
+#include <chrono>
+#include <cstdio>
 #include <cstdlib>
+#include <atomic>
 #include <mutex>
 #include <string>
 #include <vector>
@@ -28,8 +31,10 @@ struct Api {
 	void (*destroy)(kmc_hip_ctx *) = nullptr;
 	const char *(*last_error)(kmc_hip_ctx *) = nullptr;
 	int (*abi_version)(void) = nullptr;
-	int (*process_bin)(kmc_hip_ctx *, int, const kmc_hip_bin_params *, const uint8_t *, uint64_t, uint64_t, const uint64_t *, uint64_t,
-	                   uint8_t *, uint64_t, uint64_t *, uint64_t *, uint64_t *) = nullptr;
+	int (*submit)(kmc_hip_ctx *, int, int, const kmc_hip_bin_params *, const uint8_t *, uint64_t, uint64_t, const uint64_t *, uint64_t,
+	              uint8_t *, uint64_t, uint64_t *) = nullptr;
+	int (*wait)(kmc_hip_ctx *, int, int, uint64_t *, uint64_t *) = nullptr;
+	std::mutex slot_mtx[64][2]; /* the C-ABI wants calls on one (device, slot) serialised; workers may outnumber slots */
 	int (*host_register)(kmc_hip_ctx *, void *, uint64_t) = nullptr;
 	kmc_hip_ctx *ctx = nullptr;
 	int n_dev = 0;
@@ -38,6 +43,10 @@ struct Api {
 
 Api g_api;
 std::once_flag g_once;
+
+/* KMC_HIP_VERBOSE=1: where did the worker spend its time? (printed when the last engine is destroyed) */
+std::atomic<long long> g_ns_init{0}, g_ns_bins{0}, g_n_bins{0}, g_bytes_in{0}, g_bytes_out{0}, g_kmers{0}, g_engines{0};
+inline long long now_ns() { return std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 
 std::string exe_dir()
 {
@@ -61,7 +70,14 @@ template <typename F> bool sym(void *so, const char *name, F &f, std::string &er
 	return true;
 }
 
+void load_api_impl();
 void load_api()
+{
+	const long long t0 = now_ns();
+	load_api_impl();
+	g_ns_init += now_ns() - t0;
+}
+void load_api_impl()
 {
 	Api &a = g_api;
 	std::vector<std::string> cands;
@@ -79,7 +95,8 @@ void load_api()
 		return;
 	if (!sym(a.so, "kmc_hip_init", a.init, a.err) || !sym(a.so, "kmc_hip_destroy", a.destroy, a.err) ||
 	    !sym(a.so, "kmc_hip_last_error", a.last_error, a.err) || !sym(a.so, "kmc_hip_abi_version", a.abi_version, a.err) ||
-	    !sym(a.so, "kmc_hip_process_bin", a.process_bin, a.err) || !sym(a.so, "kmc_hip_host_register", a.host_register, a.err)) {
+	    !sym(a.so, "kmc_hip_process_bin_submit", a.submit, a.err) || !sym(a.so, "kmc_hip_process_bin_wait", a.wait, a.err) ||
+	    !sym(a.so, "kmc_hip_host_register", a.host_register, a.err)) {
 		a.so = nullptr;
 		return;
 	}
@@ -112,9 +129,16 @@ void load_api()
 }
 
 struct HipEngine : KmcBinEngine {
-	int dev;
+	int dev, slot;
 	std::string err;
-	explicit HipEngine(int dev) : dev(dev) {}
+	HipEngine(int dev, int slot) : dev(dev), slot(slot) { ++g_engines; }
+	~HipEngine() override
+	{
+		if (--g_engines == 0 && getenv("KMC_HIP_VERBOSE"))
+			fprintf(stderr, "[kmc_hip] init %.3f s; %lld bins, %.3f s inside the engine (sum over workers), %.1f MB in, %.1f MB out, %lld k-mers\n",
+			        g_ns_init.load() * 1e-9, g_n_bins.load(), g_ns_bins.load() * 1e-9, g_bytes_in.load() / 1e6, g_bytes_out.load() / 1e6,
+			        g_kmers.load());
+	}
 	int process_bin(const kmc_hip_bin_params &p, const uint8_t *sk, uint64_t size, uint64_t n_rec, const uint64_t *pack_bytes,
 	                uint64_t n_packs, uint8_t *out, uint64_t cap, uint64_t *out_bytes, uint64_t *lut, uint64_t stats[4]) override
 	{
@@ -122,9 +146,21 @@ struct HipEngine : KmcBinEngine {
 			err = g_api.err.empty() ? "HIP engine not initialised" : g_api.err;
 			return KMC_HIP_EDEVICE;
 		}
-		int rc = g_api.process_bin(g_api.ctx, dev, &p, sk, size, n_rec, pack_bytes, n_packs, out, cap, out_bytes, lut, stats);
+		/* Two stream slots per device: workers (one per stage-2 sorter thread, kmc.h:1576-1584) are spread over
+		 * (device, slot) pairs; a pair is used by one worker at a time, so the copies of one bin overlap the kernels
+		 * of another. */
+		std::lock_guard<std::mutex> lck(g_api.slot_mtx[dev & 63][slot]);
+		const long long t0 = now_ns();
+		int rc = g_api.submit(g_api.ctx, dev, slot, &p, sk, size, n_rec, pack_bytes, n_packs, out, cap, lut);
+		if (!rc)
+			rc = g_api.wait(g_api.ctx, dev, slot, out_bytes, stats);
 		if (rc)
 			err = g_api.last_error(g_api.ctx);
+		g_ns_bins += now_ns() - t0;
+		++g_n_bins;
+		g_bytes_in += (long long)size;
+		g_bytes_out += (long long)*out_bytes;
+		g_kmers += (long long)n_rec;
 		return rc;
 	}
 	std::string last_error() override { return err; }
@@ -141,5 +177,5 @@ KmcBinEngine *kmc_make_bin_engine(int worker_idx, int /*n_workers*/)
 {
 	std::call_once(g_once, load_api);
 	const int n = g_api.n_dev > 0 ? g_api.n_dev : 1;
-	return new HipEngine(worker_idx % n);
+	return new HipEngine(worker_idx % n, (worker_idx / n) & 1);
 }
