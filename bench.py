@@ -32,6 +32,19 @@ sys.path.insert(0, ROOT)
 from kmc_amd import capi, sharding  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
+PMC_PROFILE = os.path.join(ROOT, "profiles", "r01", "final", "pmc_hbm_traffic.json")  # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes
+
+
+def pmc_traffic(kernel: str, records_per_launch: float):
+    """HBM bytes per launch of `kernel` from the committed PMC profile of THIS workload (null for any other workload:
+    counters cannot be collected from inside the timed run)."""
+    try:
+        d = json.load(open(PMC_PROFILE))
+        if abs(d["k_onesweep_records_per_launch_avg"] - records_per_launch) > 0.01 * records_per_launch:
+            return None
+        return d["kernels"][kernel]["hbm_bytes_per_launch"]
+    except Exception:
+        return None
 
 
 def cpu_baseline(k: int, sample_reads: int, genome_len: int):
@@ -179,7 +192,9 @@ def main():
             "stage2_algorithmic_bytes_per_kmer": W * (2 * ((2 * k + 7) // 8) + 3),
             "stage2_algorithmic_GBs": W * (2 * ((2 * k + 7) // 8) + 3) * n_rec / (timings["total"] * 1e-3) / 1e9,
             "roofline": {"bound": "hbm", "kernel": "k_onesweep<%d>" % ((k + 31) // 32), "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None, "launches_per_step": n_launch, "avg_launch_ms": avg_ms,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic("k_onesweep<%d>" % ((k + 31) // 32), sc_keys),
+                         "traffic_unit": "HBM bytes per launch (PMC FETCH_SIZE x2 + WRITE_SIZE, profiles/r01/final/pmc_hbm_traffic.json)",
+                         "algorithmic_bytes_per_launch": 2 * W * sc_keys, "launches_per_step": n_launch, "avg_launch_ms": avg_ms,
                          "records_per_launch": sc_keys, "algorithmic_bytes_per_record_per_launch": 2 * W},
             "setup_s": {"generate": t_gen, "h2d": t_h2d, "h2d_GBs": img.size / max(t_h2d, 1e-9) / 1e9},
         }
