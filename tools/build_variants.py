@@ -8,9 +8,9 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 VARIANTS = {
     "base": [],
-    "cp512x8": ["-DCP_BLOCK_THREADS=512", "-DCP_WORDS_PER_THREAD=8"],
-    "cp256x8": ["-DCP_BLOCK_THREADS=256", "-DCP_WORDS_PER_THREAD=8"],
-    "cp1024x8": ["-DCP_BLOCK_THREADS=1024", "-DCP_WORDS_PER_THREAD=8"],
+    "nowide": ["-DRS_WIDE_LOOKBACK=0"],
+    "wide256": ["-DRS_BLOCK_THREADS=256"],
+    "wide512x12": ["-DRS_WORDS_PER_THREAD=12"],
     "trace": ["-DKMC_TRACE"],
 }
 
