@@ -21,8 +21,8 @@
  *             -> sorters_manager->ReturnThreads (queues.h:2130)
  *   per run : kq->mark_completed() once per worker (kb_sorter.h:236)
  *   errors  : CCriticalErrorHandler::Inst().HandleCriticalError(msg) (critical_error_handler.h)
- *   order   : bins are pushed in the order GetNext hands them out, so with one worker (-sr1) the
- *             .kmc_pre/.kmc_suf bytes equal the reference's -sr1 bytes (SURVEY.md §4 determinism finding).
+ *   order   : bins are pushed in the order GetNext hands them out (KmcOrderedEmit below), so the .kmc_pre/.kmc_suf
+ *             bytes equal the reference's -sr1 bytes for any number of workers (SURVEY.md §4 determinism finding).
  */
 #ifndef KMC_AMD_KB_SORTER_PLUGIN_H
 #define KMC_AMD_KB_SORTER_PLUGIN_H
@@ -43,6 +43,8 @@
 #include <functional>
 #include <cstddef>
 #include <set>
+#include <map>
+#include <mutex>
 #include <atomic>
 #include <memory>
 #include <sstream>
@@ -106,7 +108,31 @@ struct KmcOracleEngine : KmcBinEngine {
 inline KmcBinEngine *kmc_make_bin_engine(int, int) { return new KmcOracleEngine(); }
 #endif
 
+/* Ordered hand-off to the completer. The reference's database bytes depend on the order bins reach kq
+ * (kb_completer.cpp:131-221): with several CPU sorters that order is a race, which is why reference
+ * runs are only reproducible with -sr1. Here every bin gets a sequence number when it is handed out (GetNext is
+ * taken under a mutex, so numbers follow CBinDesc's sorted order) and is pushed to kq strictly in that sequence,
+ * however many workers / GPUs / stream slots finish out of order: the DB equals the reference's -sr1 bytes for ANY -sr. */
+struct KmcOrderedEmit {
+	std::mutex take_mtx, emit_mtx;
+	CThrowingOnCancelConditionVariable cv; /* cancelled by CCriticalErrorHandler like every other wait in kmc_core */
+	uint64 next_take = 0, next_emit = 0;
+	static std::shared_ptr<KmcOrderedEmit> for_queue(CKmerQueue *kq)
+	{
+		static std::mutex m;
+		static std::map<CKmerQueue *, std::weak_ptr<KmcOrderedEmit>> live;
+		std::lock_guard<std::mutex> lck(m);
+		auto sp = live[kq].lock();
+		if (!sp) {
+			sp = std::make_shared<KmcOrderedEmit>();
+			live[kq] = sp;
+		}
+		return sp;
+	}
+};
+
 template <unsigned SIZE> class CWKmerBinSorter {
+	std::shared_ptr<KmcOrderedEmit> order;
 	CBinDesc *bd;
 	CExpanderPackDesc *epd;
 	CKmerQueue *kq;
@@ -132,6 +158,7 @@ public:
 		kq = Queues.kq.get();
 		memory_bins = Queues.memory_bins.get();
 		sorters_manager = Queues.sorters_manager.get();
+		order = KmcOrderedEmit::for_queue(kq);
 
 		bp.kmer_len = Params.kmer_len;
 		bp.both_strands = Params.both_strands ? 1 : 0;
@@ -166,7 +193,14 @@ public:
 		const uint64 out_rec_bytes = kmc_hip_out_rec_bytes_host(bp);
 		std::vector<uint64> pack_bytes;
 
-		while (sorters_manager->GetNext(bin_id, data, size, n_rec, n_sorting_threads)) {
+		while (true) {
+			uint64 seq = 0;
+			{
+				std::lock_guard<std::mutex> lck(order->take_mtx);
+				if (!sorters_manager->GetNext(bin_id, data, size, n_rec, n_sorting_threads))
+					break;
+				seq = order->next_take++;
+			}
 			CMemDiskFile *file;
 			string desc;
 			uint64 tmp_size, tmp_n_rec, n_plus_x_recs;
@@ -211,8 +245,14 @@ public:
 			list<pair<uint64, uint64>> data_packs;
 			if (!bp.without_output && !(max_x && n_plus_x_recs == 0))
 				data_packs.emplace_back(0, out_bytes);
-			kq->push(bin_id, out_buffer, data_packs, raw_lut, lut_recs * sizeof(uint64), stats[0], stats[1], stats[2],
-			         stats[3]);
+			{
+				std::unique_lock<std::mutex> lck(order->emit_mtx);
+				order->cv.wait(lck, [&] { return order->next_emit == seq; });
+				kq->push(bin_id, out_buffer, data_packs, raw_lut, lut_recs * sizeof(uint64), stats[0], stats[1], stats[2],
+				         stats[3]);
+				++order->next_emit;
+			}
+			order->cv.notify_all();
 
 			sorters_manager->ReturnThreads(n_sorting_threads, bin_id);
 		}

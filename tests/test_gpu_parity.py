@@ -295,11 +295,15 @@ def test_kmc_with_hip_sorter_writes_the_reference_database(flags, ref_bins, tmp_
 
     fq = str(tmp_path / "in.fq")
     synth.make_fastq(fq, **synth.CONFIGS["C1"])
-    env = dict(os.environ, KMC_HIP_LIB=capi.lib_path())
-    for exe, out in (("kmc", "ref"), ("kmc_hip", "hip")):
+    # hip4: four workers sharing two stream slots of device 0 twice over (KMC_HIP_DEVICES=0,0 exercises the
+    # multi-device mapping on a 1-GPU box); ordered emission keeps the bytes equal to the reference's -sr1 run
+    runs = (("kmc", "ref", ["-sr1"], {}), ("kmc_hip", "hip", ["-sr1"], {}), ("kmc_hip", "hip4", ["-t8", "-sr4"], {"KMC_HIP_DEVICES": "0,0"}))
+    for exe, out, mode, extra in runs:
+        env = dict(os.environ, KMC_HIP_LIB=capi.lib_path(), **extra)
         tmp = tmp_path / ("tmp_" + out)
         tmp.mkdir()
-        r = subprocess.run([ref_bins[exe], *flags, "-sr1", fq, str(tmp_path / out), str(tmp)], env=env, capture_output=True, text=True)
+        r = subprocess.run([ref_bins[exe], *flags, *mode, fq, str(tmp_path / out), str(tmp)], env=env, capture_output=True, text=True)
         assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     for ext in (".kmc_pre", ".kmc_suf"):
         assert _md5(str(tmp_path / ("ref" + ext))) == _md5(str(tmp_path / ("hip" + ext))), ext
+        assert _md5(str(tmp_path / ("ref" + ext))) == _md5(str(tmp_path / ("hip4" + ext))), ext + " (4 workers, 2 devices)"
