@@ -8,9 +8,9 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 VARIANTS = {
     "base": [],
-    "st2": ["-DRS_STAGES=2", "-DRS_MIN_WAVES=6"],
-    "st2w4": ["-DRS_STAGES=2"],
-    "st4": ["-DRS_STAGES=4", "-DRS_MIN_WAVES=8"],
+    "nowide": ["-DRS_WIDE_LOOKBACK=0"],
+    "wide256": ["-DRS_BLOCK_THREADS=256"],
+    "wide512x12": ["-DRS_WORDS_PER_THREAD=12"],
     "trace": ["-DKMC_TRACE"],
 }
 
