@@ -32,7 +32,8 @@ enum : u32 { KERR_CORRUPT = 1u, KERR_NREC = 2u, KERR_CAPACITY = 4u, KERR_WATCHDO
 
 /* tile geometry */
 #ifndef RS_BLOCK_THREADS
-#define RS_BLOCK_THREADS 512 /* 8192-record tiles: 16 % faster than 256 x 16 (fewer tiles to look back over, 256-B runs) */
+#define RS_BLOCK_THREADS 1024 /* 8192-record tiles. Measured scatter time of the 1.65 G bin: 256 thr x 16 rec 70.9 ms, 512 x 16 58.5,
+                               * 1024 x 8 with the LDS staging in two halves 54.8 (64 VGPRs -> 32 waves/CU instead of 16) */
 #endif
 constexpr int RS_BLOCK = RS_BLOCK_THREADS, RS_WAVES = RS_BLOCK / 64;                           /* radix scatter workgroup       */
 #ifndef CP_BLOCK_THREADS
@@ -42,11 +43,16 @@ constexpr int CP_BLOCK = CP_BLOCK_THREADS;                                      
 constexpr u32 SPIN_LIMIT = 1u << 24;                                              /* look-back watchdog (polls)    */
 
 #ifndef RS_WORDS_PER_THREAD
-#define RS_WORDS_PER_THREAD 16 /* 8-byte words held per thread in a scatter tile */
+#define RS_WORDS_PER_THREAD 8 /* 8-byte words held per thread in a scatter tile */
 #endif
+#ifndef RS_STAGES
+#define RS_STAGES 2
+#endif
+#define RS_STAGES_REQ RS_STAGES
 template <int SIZE> struct RsCfg { /* records per thread in a scatter tile: RS_WORDS_PER_THREAD x 8 B per thread for every SIZE */
 	static constexpr int ITEMS = (RS_WORDS_PER_THREAD / SIZE) > 2 ? (RS_WORDS_PER_THREAD / SIZE) : 2;
 	static constexpr int TILE = RS_BLOCK * ITEMS;
+	static constexpr int STAGES = (ITEMS % RS_STAGES_REQ == 0) ? RS_STAGES_REQ : 1; /* LDS staging slices per tile */
 };
 #ifndef CP_WORDS_PER_THREAD
 #define CP_WORDS_PER_THREAD 16
@@ -596,7 +602,7 @@ __global__ void __launch_bounds__(256) k_hist_scan(const u64 *__restrict__ ghist
 constexpr u32 ST_AGG = 1u << 30, ST_PREFIX = 2u << 30, ST_MASK = (1u << 30) - 1;
 
 #ifndef RS_MIN_WAVES
-#define RS_MIN_WAVES 4 /* waves per SIMD the register allocator must leave room for (4 workgroups of 256 per CU) */
+#define RS_MIN_WAVES 8 /* waves per SIMD the register allocator must leave room for (2 workgroups of 1024 per CU) */
 #endif
 #ifndef RS_RANK_LDS
 #define RS_RANK_LDS 0 /* measured: ballots 58.8 ms vs LDS words 62.0 ms per 7 passes of 1.65 G records */
@@ -618,7 +624,7 @@ __device__ u32 g_launch_seq; /* tile-row base of the current launch, advanced by
 #endif
 
 template <int SIZE>
-__global__ void __launch_bounds__(RS_BLOCK, RS_MIN_WAVES) k_onesweep(const u64 *__restrict__ in, u64 *__restrict__ out, u32 n, u32 byte_idx,
+__global__ void __launch_bounds__(RS_BLOCK, (SIZE <= 4 ? RS_MIN_WAVES : RS_MIN_WAVES / 2)) k_onesweep(const u64 *__restrict__ in, u64 *__restrict__ out, u32 n, u32 byte_idx,
                                                         const u64 *__restrict__ digit_base_in, u64 *__restrict__ digit_base_next,
                                                         u32 *status, u32 *tile_counter, u32 num_tiles, u32 *err)
 {
@@ -627,7 +633,7 @@ __global__ void __launch_bounds__(RS_BLOCK, RS_MIN_WAVES) k_onesweep(const u64 *
 	extern __shared__ __attribute__((aligned(16))) unsigned char s_raw[];
 	u64 *s_goff = reinterpret_cast<u64 *>(s_raw);              /* [256]  global index of LDS slot 0 as seen by digit d */
 	u64 *s_keys = s_goff + 256;                                /* [SIZE*TILE] word-major: s_keys[w*TILE + slot]         */
-	u32 *s_whist = reinterpret_cast<u32 *>(s_keys + SIZE * TILE); /* [RS_WAVES*256] per-wave digit counters -> offsets    */
+	u32 *s_whist = reinterpret_cast<u32 *>(s_keys + SIZE * TILE / RsCfg<SIZE>::STAGES); /* [RS_WAVES*256] per-wave digit counters -> offsets    */
 	u32 *s_doff = s_whist + RS_WAVES * 256;                    /* [256]  first LDS slot of digit d                      */
 	u32 *s_wsum = s_doff + 256;                                /* [4]                                                    */
 	u32 *s_tile = s_wsum + 4;                                  /* [1]                                                    */
@@ -815,29 +821,47 @@ __global__ void __launch_bounds__(RS_BLOCK, RS_MIN_WAVES) k_onesweep(const u64 *
 		__syncthreads();
 		TRACE_STAMP(0, tile, 5);
 
+		/* The tile goes through LDS in RS_STAGES slices of STAGE_N slots (digit order): with 2 slices the staging area is
+		 * 32 KB instead of 64 KB, i.e. 3 workgroups per CU instead of 2 (the kernel is bound by how many tiles are in flight) */
+		constexpr int STAGES = RsCfg<SIZE>::STAGES;
+		constexpr int STAGE_N = TILE / STAGES;
 #pragma unroll
 		for (int r = 0; r < ITEMS; ++r) {
-			if ((wbase + r * 64) < tile_n) {
-				const u32 d = kmc_get_byte<SIZE>(key[r], byte_idx);
-				const u32 slot = s_doff[d] + s_whist[wave * 256 + d] + rank[r];
-#pragma unroll
-				for (int w = 0; w < SIZE; ++w)
-					s_keys[w * TILE + slot] = key[r][w];
-			}
+			const u32 d = kmc_get_byte<SIZE>(key[r], byte_idx);
+			rank[r] = ((wbase + r * 64) < tile_n) ? s_doff[d] + s_whist[wave * 256 + d] + rank[r] : 0xFFFFFFFFu; /* slot in the tile */
 		}
-		__syncthreads();
-		TRACE_STAMP(0, tile, 6);
+#pragma unroll 1
+		for (int h = 0; h < STAGES; ++h) {
+			const u32 lo = h * STAGE_N;
+			if (lo >= tile_n)
+				break;
 #pragma unroll
-		for (int i = 0; i < ITEMS; ++i) {
-			const u32 slot = i * RS_BLOCK + tid;
-			if (slot < tile_n) {
-				u64 x[SIZE];
+			for (int r = 0; r < ITEMS; ++r) {
+				const u32 rel = rank[r] - lo;
+				if (rel < (u32)STAGE_N) {
 #pragma unroll
-				for (int w = 0; w < SIZE; ++w)
-					x[w] = s_keys[w * TILE + slot];
-				const u32 d = kmc_get_byte<SIZE>(x, byte_idx);
-				store_rec<SIZE>(out + (s_goff[d] + slot) * SIZE, x);
+					for (int w = 0; w < SIZE; ++w)
+						s_keys[w * STAGE_N + rel] = key[r][w];
+				}
 			}
+			__syncthreads();
+			if (h == 0)
+				TRACE_STAMP(0, tile, 6);
+#pragma unroll
+			for (int i = 0; i < ITEMS / STAGES; ++i) {
+				const u32 rel = i * RS_BLOCK + tid;
+				const u32 slot = lo + rel;
+				if (slot < tile_n) {
+					u64 x[SIZE];
+#pragma unroll
+					for (int w = 0; w < SIZE; ++w)
+						x[w] = s_keys[w * STAGE_N + rel];
+					const u32 d = kmc_get_byte<SIZE>(x, byte_idx);
+					store_rec<SIZE>(out + (s_goff[d] + slot) * SIZE, x);
+				}
+			}
+			if (h + 1 < STAGES)
+				__syncthreads();
 		}
 		TRACE_STAMP(0, tile, 7);
 		__syncthreads(); /* LDS is reused by the next tile of this ticket */
@@ -846,7 +870,7 @@ __global__ void __launch_bounds__(RS_BLOCK, RS_MIN_WAVES) k_onesweep(const u64 *
 
 template <int SIZE> constexpr size_t rs_lds_bytes()
 {
-	return 256 * 8 + (size_t)SIZE * RsCfg<SIZE>::TILE * 8 + RS_WAVES * 256 * 4 + 256 * 4 + 4 * 4 + 16;
+	return 256 * 8 + (size_t)SIZE * RsCfg<SIZE>::TILE * 8 / RsCfg<SIZE>::STAGES + RS_WAVES * 256 * 4 + 256 * 4 + 4 * 4 + 16;
 }
 
 /* ------------------------------------------------------------------------------------------------ compaction

@@ -8,9 +8,9 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 VARIANTS = {
     "base": [],
-    "nowide": ["-DRS_WIDE_LOOKBACK=0"],
-    "wide256": ["-DRS_BLOCK_THREADS=256"],
-    "wide512x12": ["-DRS_WORDS_PER_THREAD=12"],
+    "t1024x8s2": ["-DRS_BLOCK_THREADS=1024", "-DRS_WORDS_PER_THREAD=8", "-DRS_STAGES=2", "-DRS_MIN_WAVES=8"],
+    "t1024x8s1": ["-DRS_BLOCK_THREADS=1024", "-DRS_WORDS_PER_THREAD=8", "-DRS_STAGES=1", "-DRS_MIN_WAVES=4"],
+    "t512x8s2": ["-DRS_BLOCK_THREADS=512", "-DRS_WORDS_PER_THREAD=8", "-DRS_STAGES=2", "-DRS_MIN_WAVES=8"],
     "trace": ["-DKMC_TRACE"],
 }
 
