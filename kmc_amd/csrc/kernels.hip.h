@@ -604,9 +604,6 @@ constexpr u32 ST_AGG = 1u << 30, ST_PREFIX = 2u << 30, ST_MASK = (1u << 30) - 1;
 #ifndef RS_MIN_WAVES
 #define RS_MIN_WAVES 8 /* waves per SIMD the register allocator must leave room for (2 workgroups of 1024 per CU) */
 #endif
-#ifndef RS_RANK_LDS
-#define RS_RANK_LDS 0 /* measured: ballots 58.8 ms vs LDS words 62.0 ms per 7 passes of 1.65 G records */
-#endif
 #ifndef RS_LOOKBACK_K
 #define RS_LOOKBACK_K 4
 #endif
@@ -677,28 +674,11 @@ __global__ void __launch_bounds__(RS_BLOCK, (SIZE <= 4 ? RS_MIN_WAVES : RS_MIN_W
 		/* ranking, phase 1: find the lanes of this wave-round that hold the same digit ("match-any"), lowest peer
 		 * lane adds the peer count to the wave's private counter with ONE returning LDS atomic. The counter atomics
 		 * of all rounds are in flight together (LDS executes a wave's operations in order, so round r+1 sees round
-		 * r's add). Two ways to get the peer mask:
-		 *   RS_RANK_LDS=1  every lane ORs its lane bit into a per-(wave,digit) 64-bit LDS word, then reads it back
-		 *                  (3 LDS ops per round instead of ~50 VALU/SALU; the words live in the not-yet-used key
-		 *                  staging area and are cleared by the lowest peer)
-		 *   RS_RANK_LDS=0  8 ballots, one per digit bit */
-#if RS_RANK_LDS
-		u64 *s_mask = s_keys + wave * 256; /* [256] per wave; s_keys is not touched before the LDS scatter phase */
-#pragma unroll
-		for (int i = 0; i < 4; ++i)
-			s_mask[i * 64 + lane] = 0;
-		const u64 lane_bit = 1ull << lane;
-#endif
+		 * r's add). (An alternative that ORs lane bits into per-(wave,digit) LDS words instead of 8 ballots was 5 % slower.) */
 #pragma unroll
 		for (int r = 0; r < ITEMS; ++r) {
 			const bool valid = (wbase + r * 64) < tile_n;
 			const u32 d = kmc_get_byte<SIZE>(key[r], byte_idx);
-#if RS_RANK_LDS
-			if (valid)
-				atomicOr(&s_mask[d], lane_bit);
-			const u64 pm = s_mask[d];
-			const u32 lo = valid ? (u32)pm : 0u, hi = valid ? (u32)(pm >> 32) : 0u;
-#else
 			const u64 vm = __ballot(valid);
 			u32 lo = (u32)vm, hi = (u32)(vm >> 32);
 #pragma unroll
@@ -708,14 +688,10 @@ __global__ void __launch_bounds__(RS_BLOCK, (SIZE <= 4 ? RS_MIN_WAVES : RS_MIN_W
 				lo &= ~((u32)m ^ (u32)sb);
 				hi &= ~((u32)(m >> 32) ^ (u32)sb);
 			}
-#endif
 			const u32 below = __builtin_amdgcn_mbcnt_hi(hi, __builtin_amdgcn_mbcnt_lo(lo, 0));
 			const u32 leader = lo ? (u32)(__ffs((int)lo) - 1) : (hi ? (u32)(31 + __ffs((int)hi)) : 0u);
 			u32 old = 0;
 			if (valid && below == 0) {
-#if RS_RANK_LDS
-				s_mask[d] = 0;
-#endif
 				old = atomicAdd(&s_whist[wave * 256 + d], (u32)(__popc(lo) + __popc(hi)));
 			}
 			rank[r] = (old << 16) | (below << 8) | leader; /* old: meaningful in the leader lane only, until phase 2 */

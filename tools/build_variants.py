@@ -8,9 +8,10 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 VARIANTS = {
     "base": [],
-    "t1024x8s2": ["-DRS_BLOCK_THREADS=1024", "-DRS_WORDS_PER_THREAD=8", "-DRS_STAGES=2", "-DRS_MIN_WAVES=8"],
-    "t1024x8s1": ["-DRS_BLOCK_THREADS=1024", "-DRS_WORDS_PER_THREAD=8", "-DRS_STAGES=1", "-DRS_MIN_WAVES=4"],
-    "t512x8s2": ["-DRS_BLOCK_THREADS=512", "-DRS_WORDS_PER_THREAD=8", "-DRS_STAGES=2", "-DRS_MIN_WAVES=8"],
+    "k2": ["-DRS_LOOKBACK_K=2"],
+    "k8": ["-DRS_LOOKBACK_K=8"],
+    "ranklds": ["-DRS_RANK_LDS=1"],
+    "st4": ["-DRS_STAGES=4"],
     "trace": ["-DKMC_TRACE"],
 }
 
