@@ -8,10 +8,10 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 VARIANTS = {
     "base": [],
-    "k2": ["-DRS_LOOKBACK_K=2"],
-    "k8": ["-DRS_LOOKBACK_K=8"],
-    "ranklds": ["-DRS_RANK_LDS=1"],
-    "st4": ["-DRS_STAGES=4"],
+    "cp1024x4": ["-DCP_BLOCK_THREADS=1024", "-DCP_WORDS_PER_THREAD=4"],
+    "cp512x4": ["-DCP_BLOCK_THREADS=512", "-DCP_WORDS_PER_THREAD=4"],
+    "cp512x8": ["-DCP_BLOCK_THREADS=512", "-DCP_WORDS_PER_THREAD=8"],
+    "cp256x4": ["-DCP_BLOCK_THREADS=256", "-DCP_WORDS_PER_THREAD=4"],
     "trace": ["-DKMC_TRACE"],
 }
 
