@@ -336,7 +336,13 @@ __global__ void __launch_bounds__(256) k_parse_packs(const uint8_t *__restrict__
 #ifndef EXP_BLOCK_THREADS
 #define EXP_BLOCK_THREADS 512 /* measured on the 1.65 G k-mer bin: 256 thr 13.7 ms, 512 thr 9.2 ms, 1024 thr 12.1 ms */
 #endif
-constexpr int EXP_CHUNK = 8192, EXP_TAIL = 160, EXP_MAX_SK = EXP_CHUNK / 2, EXP_KWIN = 8192, EXP_BLOCK = EXP_BLOCK_THREADS;
+#ifndef EXP_CHUNK_BYTES
+#define EXP_CHUNK_BYTES 8192
+#endif
+#ifndef EXP_KWIN_KMERS
+#define EXP_KWIN_KMERS 8192
+#endif
+constexpr int EXP_CHUNK = EXP_CHUNK_BYTES, EXP_TAIL = 160, EXP_MAX_SK = EXP_CHUNK / 2, EXP_KWIN = EXP_KWIN_KMERS, EXP_BLOCK = EXP_BLOCK_THREADS;
 
 template <int SIZE, bool FUSE_HIST>
 __global__ void __launch_bounds__(EXP_BLOCK) k_expand(const uint8_t *__restrict__ data, u64 size, const u32 *__restrict__ bitmap, u32 k,
@@ -373,13 +379,13 @@ __global__ void __launch_bounds__(EXP_BLOCK) k_expand(const uint8_t *__restrict_
 		const u32 avail = (size - c0) < (u64)(EXP_CHUNK + EXP_TAIL) ? (u32)(size - c0) : (u32)(EXP_CHUNK + EXP_TAIL);
 		/* stage the slice (+ tail for records that start in it and end in the next one): 16-byte loads */
 		{
-			const uint4 *g = reinterpret_cast<const uint4 *>(data + c0); /* c0 is a multiple of 8192; `data` is 16-B aligned */
+			const uint4 *g = reinterpret_cast<const uint4 *>(data + c0); /* c0 is a multiple of EXP_CHUNK; `data` is 16-B aligned */
 			uint4 *l = reinterpret_cast<uint4 *>(s_b);
 			for (u32 i = tid; i < (avail + 15) / 16; i += EXP_BLOCK)
 				l[i] = g[i]; /* the image has >= 256 readable bytes of slack after `size` */
 		}
 		/* this thread's 32 positions = one bitmap word */
-		const u32 bits = (tid < 256 && tid * 32 < clen) ? bitmap[(c0 >> 5) + tid] : 0; /* threads 0..255 own the slice's 256 words */
+		const u32 bits = (tid < (u32)EXP_CHUNK / 32 && tid * 32 < clen) ? bitmap[(c0 >> 5) + tid] : 0; /* one bitmap word (32 positions) per thread */
 		__syncthreads();
 		u32 my_sk = (u32)__popc(bits), my_k = 0;
 		{

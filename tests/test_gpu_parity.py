@@ -102,6 +102,29 @@ def test_expand_stage_matches_oracle(ctx, k, both):
     assert np.array_equal(got, want), _first_diff(got, want)
 
 
+@pytest.mark.parametrize("k,max_extra,pack_size,n_super", [
+    (27, 255, 1, 600),        # one super-k-mer per pack
+    (27, 40, 10**9, 30000),   # a single pack far beyond 4096 super-k-mers / many parse chunks
+    (27, 255, 37, 5000),      # long records straddling parse-chunk and expand-slice boundaries
+    (14, 255, 4096, 9000),    # smallest bin-path k: shortest records (5 bytes), most starts per slice
+    (256, 255, 500, 3000),    # longest records (up to 129 bytes)
+    (31, 0, 4096, 20000),     # e = 0 everywhere: one k-mer per super-k-mer
+])
+def test_parse_and_expand_pack_shapes(ctx, k, max_extra, pack_size, n_super):
+    """the parse kernel resolves the record chain speculatively per pack and per 4 KiB chunk; the expand kernel works on
+    8 KiB slices: exercise every boundary case against the oracle's sequential walk"""
+    rng = np.random.default_rng(k + max_extra + n_super)
+    img, nk, packs = binsynth.random_bin(rng, k, n_super, max_extra=max_extra, pack_size=pack_size)
+    p = hp(k, lut_prefix_len=0, output_type=1)
+    want = O.expand(op(p), img)
+    got = ctx.debug_expand(p, img, nk, packs)
+    assert np.array_equal(got, want), _first_diff(got, want)
+    # and with the library finding pack boundaries itself
+    out, lut, st = ctx.process_bin(hp(k, cutoff_min=1, lut_prefix_len=0, output_type=1), img, nk, None)
+    w = O.process_bin(op(hp(k, cutoff_min=1, lut_prefix_len=0, output_type=1)), img, nk)
+    assert np.array_equal(out, w[0]) and np.array_equal(st, w[2])
+
+
 @pytest.mark.parametrize("k,pl", [(27, 3), (27, 7), (55, 3), (127, 3), (32, 4), (64, 0)])
 def test_compact_stage_matches_oracle(ctx, k, pl):
     rng = np.random.default_rng(k + pl)
