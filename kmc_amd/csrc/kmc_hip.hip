@@ -72,6 +72,10 @@ constexpr size_t SM_COUNTERS = SM_SHARDS + CP_SHARDS * 4 * 8; /* u32[N_COUNTERS]
 constexpr size_t N_COUNTERS = 4096;
 constexpr size_t SM_BYTES = SM_COUNTERS + N_COUNTERS * 4;
 
+#ifndef KMC_N_SLOTS
+#define KMC_N_SLOTS 8 /* 512 bins of 3.2 M k-mers: 1 slot 237 ms, 2 slots 133, 4 slots 104, 8 slots 95 (then the host launch rate binds) */
+#endif
+constexpr int N_SLOTS = KMC_N_SLOTS;
 constexpr u64 PORTION = 1ull << 29; /* records per scatter launch (30-bit look-back counts) */
 
 struct HostRes {
@@ -103,7 +107,8 @@ struct Slot {
 
 struct Dev {
 	int ordinal = 0;
-	Slot slot[2];
+	u32 rr = 0; /* round-robin slot choice of asynchronous device-resident calls */
+	Slot slot[N_SLOTS]; /* [0],[1]: the submit/wait slots of the host-buffer API; all of them: round-robin for async device-resident calls */
 	DBuf rccl_buf;
 };
 
@@ -601,8 +606,11 @@ int kmc_hip_synchronize(kmc_hip_ctx *ctx, int dev)
 		return rc;
 	for (auto &s : ctx->devs[dev].slot)
 		HIPCHK(hipStreamSynchronize(s.stream));
-	u32 err = 0;
-	HIPCHK(hipMemcpy(&err, small_ptr<u32>(ctx->devs[dev].slot[0], SM_ERR), 4, hipMemcpyDeviceToHost));
+	u32 err = 0, e1 = 0;
+	for (auto &s : ctx->devs[dev].slot) {
+		HIPCHK(hipMemcpy(&e1, small_ptr<u32>(s, SM_ERR), 4, hipMemcpyDeviceToHost));
+		err |= e1;
+	}
 	return err_to_code(err);
 }
 
@@ -665,7 +673,9 @@ int kmc_hip_process_bin_device(kmc_hip_ctx *ctx, int dev, const kmc_hip_bin_para
 		return rc;
 	if (!d_out_bytes || !d_stats || (size && (!d_superkmers || !d_pack_start)))
 		return fail(KMC_HIP_EINVAL, "kmc_hip_process_bin_device: NULL device pointer");
-	Slot &s = ctx->devs[dev].slot[0];
+	/* asynchronous calls go round-robin over the device's stream slots, so the launch gaps and serial tails of one
+	 * (small) bin are filled by the kernels of the next ones; a synchronous call always uses slot 0 */
+	Slot &s = ctx->devs[dev].slot[sync ? 0 : (ctx->devs[dev].rr++ % N_SLOTS)];
 	s.timed = true;
 	const u64 lut_entries = kmc_hip_lut_entries(params);
 	if (int rc = run_bin_device(s, P, d_superkmers, size, n_rec, (const u64 *)d_pack_start, n_packs, d_out, out_capacity,

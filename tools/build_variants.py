@@ -8,10 +8,7 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 VARIANTS = {
     "base": [],
-    "cp1024x4": ["-DCP_BLOCK_THREADS=1024", "-DCP_WORDS_PER_THREAD=4"],
-    "cp512x4": ["-DCP_BLOCK_THREADS=512", "-DCP_WORDS_PER_THREAD=4"],
-    "cp512x8": ["-DCP_BLOCK_THREADS=512", "-DCP_WORDS_PER_THREAD=8"],
-    "cp256x4": ["-DCP_BLOCK_THREADS=256", "-DCP_WORDS_PER_THREAD=4"],
+    "slots8": ["-DKMC_N_SLOTS=8"],
     "trace": ["-DKMC_TRACE"],
 }
 
