@@ -11,8 +11,8 @@
  *     kmc_hip_last_error(ctx) gives the message (the worker forwards it to
  *     CCriticalErrorHandler::HandleCriticalError, critical_error_handler.h:9-90).
  *   - `dev` is an index into the device list given to kmc_hip_init (not a HIP ordinal).
- *   - one host thread per `dev` may call concurrently (mirrors one CWKmerBinSorter thread per
- *     sorter, kmc.h:1576-1584); calls on the same `dev` must be serialised by the caller.
+ *   - host threads may call concurrently as long as each uses its own (dev, slot) pair (mirrors one
+ *     CWKmerBinSorter thread per sorter, kmc.h:1576-1584); calls on one pair must be serialised by the caller.
  *   - host buffers belong to the caller; device memory, streams and events belong to the library.
  *   - records are CKmer<SIZE> PODs (kmer.h:22-67): `words` x uint64, word 0 least significant.
  */
@@ -63,6 +63,7 @@ void kmc_hip_destroy(kmc_hip_ctx *ctx);
 const char *kmc_hip_last_error(kmc_hip_ctx *ctx); /* thread-local message of the calling thread's last failure */
 int kmc_hip_abi_version(void);
 int kmc_hip_num_devices(kmc_hip_ctx *ctx);
+int kmc_hip_num_slots(void); /* stream slots per device usable with _submit/_wait (independent bins in flight) */
 
 /* Derived sizes, so callers size buffers exactly like kb_reader.h:141-165 does. */
 uint32_t kmc_hip_words(uint32_t kmer_len);                                   /* SIZE = ceil(k/32) */
@@ -107,7 +108,7 @@ int kmc_hip_process_bin(kmc_hip_ctx *ctx, int dev, const kmc_hip_bin_params *par
                         uint64_t stats[4]);
 
 /* Asynchronous pair for double buffering: _submit enqueues H2D + kernels + D2H on the device's stream slot
- * `slot` (0 or 1) and returns; _wait blocks until that slot's bin is complete and fills out_bytes/stats.
+ * `slot` (0 .. kmc_hip_num_slots()-1) and returns; _wait blocks until that slot's bin is complete and fills out_bytes/stats.
  * Host buffers must stay valid (and out must not alias in) until _wait returns. */
 int kmc_hip_process_bin_submit(kmc_hip_ctx *ctx, int dev, int slot, const kmc_hip_bin_params *params,
                                const uint8_t *superkmers, uint64_t size, uint64_t n_rec, const uint64_t *pack_bytes,

@@ -45,7 +45,7 @@ def make_params(k, both_strands=1, cutoff_min=2, cutoff_max=10**9, counter_max=2
 
 # every symbol include/kmc_hip.h declares (tests check the library exports them all)
 SYMBOLS = [
-    "kmc_hip_init", "kmc_hip_destroy", "kmc_hip_last_error", "kmc_hip_abi_version", "kmc_hip_num_devices",
+    "kmc_hip_init", "kmc_hip_destroy", "kmc_hip_last_error", "kmc_hip_abi_version", "kmc_hip_num_devices", "kmc_hip_num_slots",
     "kmc_hip_words", "kmc_hip_counter_size", "kmc_hip_out_rec_bytes", "kmc_hip_lut_entries",
     "kmc_hip_sort_records", "kmc_hip_sort_records_device",
     "kmc_hip_process_bin", "kmc_hip_process_bin_submit", "kmc_hip_process_bin_wait", "kmc_hip_process_bin_device",

@@ -555,6 +555,7 @@ void kmc_hip_destroy(kmc_hip_ctx *ctx)
 }
 
 int kmc_hip_num_devices(kmc_hip_ctx *ctx) { return ctx ? (int)ctx->devs.size() : 0; }
+int kmc_hip_num_slots(void) { return N_SLOTS; }
 
 int kmc_hip_malloc(kmc_hip_ctx *ctx, int dev, uint64_t bytes, void **d_ptr)
 {
@@ -695,8 +696,8 @@ int kmc_hip_process_bin_submit(kmc_hip_ctx *ctx, int dev, int slot, const kmc_hi
 {
 	if (int rc = set_dev(ctx, dev))
 		return rc;
-	if (slot < 0 || slot > 1)
-		return fail(KMC_HIP_EINVAL, "slot must be 0 or 1");
+	if (slot < 0 || slot >= N_SLOTS)
+		return fail(KMC_HIP_EINVAL, "slot out of range (see kmc_hip_num_slots)");
 	DevParams P;
 	if (int rc = check_params(params, P))
 		return rc;
@@ -769,8 +770,8 @@ int kmc_hip_process_bin_wait(kmc_hip_ctx *ctx, int dev, int slot, uint64_t *out_
 {
 	if (int rc = set_dev(ctx, dev))
 		return rc;
-	if (slot < 0 || slot > 1)
-		return fail(KMC_HIP_EINVAL, "slot must be 0 or 1");
+	if (slot < 0 || slot >= N_SLOTS)
+		return fail(KMC_HIP_EINVAL, "slot out of range (see kmc_hip_num_slots)");
 	Slot &s = ctx->devs[dev].slot[slot];
 	if (!s.pending)
 		return fail(KMC_HIP_EINVAL, "no bin in flight on this slot");

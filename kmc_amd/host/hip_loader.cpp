@@ -34,7 +34,9 @@ struct Api {
 	int (*submit)(kmc_hip_ctx *, int, int, const kmc_hip_bin_params *, const uint8_t *, uint64_t, uint64_t, const uint64_t *, uint64_t,
 	              uint8_t *, uint64_t, uint64_t *) = nullptr;
 	int (*wait)(kmc_hip_ctx *, int, int, uint64_t *, uint64_t *) = nullptr;
-	std::mutex slot_mtx[64][2]; /* the C-ABI wants calls on one (device, slot) serialised; workers may outnumber slots */
+	int (*num_slots)(void) = nullptr;
+	int n_slots = 1;
+	std::mutex slot_mtx[64][16]; /* the C-ABI wants calls on one (device, slot) serialised; workers may outnumber slots */
 	int (*host_register)(kmc_hip_ctx *, void *, uint64_t) = nullptr;
 	kmc_hip_ctx *ctx = nullptr;
 	int n_dev = 0;
@@ -96,7 +98,7 @@ void load_api_impl()
 	if (!sym(a.so, "kmc_hip_init", a.init, a.err) || !sym(a.so, "kmc_hip_destroy", a.destroy, a.err) ||
 	    !sym(a.so, "kmc_hip_last_error", a.last_error, a.err) || !sym(a.so, "kmc_hip_abi_version", a.abi_version, a.err) ||
 	    !sym(a.so, "kmc_hip_process_bin_submit", a.submit, a.err) || !sym(a.so, "kmc_hip_process_bin_wait", a.wait, a.err) ||
-	    !sym(a.so, "kmc_hip_host_register", a.host_register, a.err)) {
+	    !sym(a.so, "kmc_hip_host_register", a.host_register, a.err) || !sym(a.so, "kmc_hip_num_slots", a.num_slots, a.err)) {
 		a.so = nullptr;
 		return;
 	}
@@ -126,6 +128,11 @@ void load_api_impl()
 		return;
 	}
 	a.n_dev = (int)devs.size();
+	a.n_slots = a.num_slots();
+	if (a.n_slots > 16)
+		a.n_slots = 16;
+	if (a.n_slots < 1)
+		a.n_slots = 1;
 }
 
 struct HipEngine : KmcBinEngine {
@@ -146,7 +153,7 @@ struct HipEngine : KmcBinEngine {
 			err = g_api.err.empty() ? "HIP engine not initialised" : g_api.err;
 			return KMC_HIP_EDEVICE;
 		}
-		/* Two stream slots per device: workers (one per stage-2 sorter thread, kmc.h:1576-1584) are spread over
+		/* Several stream slots per device (kmc_hip_num_slots): workers (one per stage-2 sorter thread, kmc.h:1576-1584) are spread over
 		 * (device, slot) pairs; a pair is used by one worker at a time, so the copies of one bin overlap the kernels
 		 * of another. */
 		std::lock_guard<std::mutex> lck(g_api.slot_mtx[dev & 63][slot]);
@@ -177,5 +184,5 @@ KmcBinEngine *kmc_make_bin_engine(int worker_idx, int /*n_workers*/)
 {
 	std::call_once(g_once, load_api);
 	const int n = g_api.n_dev > 0 ? g_api.n_dev : 1;
-	return new HipEngine(worker_idx % n, (worker_idx / n) & 1);
+	return new HipEngine(worker_idx % n, (worker_idx / n) % g_api.n_slots);
 }
