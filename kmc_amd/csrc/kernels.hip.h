@@ -22,6 +22,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <type_traits>
 #include "kmer_ops.h"
 
 typedef kmc_u64 u64;
@@ -613,6 +614,9 @@ constexpr u32 ST_AGG = 1u << 30, ST_PREFIX = 2u << 30, ST_MASK = (1u << 30) - 1;
 #ifndef RS_LOOKBACK_K
 #define RS_LOOKBACK_K 4
 #endif
+#ifndef RS_LB_WIDE
+#define RS_LB_WIDE 16 /* status words per thread in the workgroup-wide look-back round (0 = the digit owners walk alone) */
+#endif
 #ifndef RS_TPB
 #define RS_TPB 1 /* tiles per ticket. Keep 1: a workgroup that owns consecutive tiles publishes the later ones late and every
                    * successor's look-back stalls on them (measured 150x slower at 2); larger tiles are the way to fewer tickets */
@@ -625,6 +629,133 @@ __device__ u32 *g_saved_prefix;
 __device__ int g_oracle_mode;
 __device__ u32 g_launch_seq; /* tile-row base of the current launch, advanced by the host */
 #endif
+
+#ifndef RS_PROPAGATOR
+#define RS_PROPAGATOR 1 /* 1: one extra workgroup turns aggregates into prefixes for everybody; 0: every tile looks back itself */
+#endif
+#ifndef RS_PROP_ROWS
+#define RS_PROP_ROWS 16 /* status rows one propagator thread has in flight */
+#endif
+#ifndef RS_PROP_BLOCKS
+#define RS_PROP_BLOCKS 2 /* propagator workgroups; each serves 256/RS_PROP_BLOCKS digits with RS_BLOCK*RS_PROP_BLOCKS/512 batches in flight */
+#endif
+
+/* The prefix propagators (the workgroups that drew the first tickets). With decoupled look-back every tile walks back
+ * over ~25 status rows (1 KB each, device-coherent loads that miss every cache) and the walk length feeds back on
+ * itself: a prefix appears only when its tile's own walk ends, so walks last c*(1 + tile rate / walk speed) ~ 10 us of
+ * a tile's ~19 us life, and walking faster only adds traffic. Here a few workgroups do the chain for all tiles; a tile
+ * then needs exactly one row, prefix_row[tile-1].
+ *   Workgroup `which` serves DP = 256/RS_PROP_BLOCKS digits. Its waves form G loader groups and G storer groups of DP
+ * lanes. Loader group g owns the batches b = g, g+G, ... of RS_PROP_ROWS consecutive tiles: it fetches the batch's
+ * aggregates (all rows in flight together; the missing ones again and again), waits for the running sum of batch b-1
+ * from its neighbour (LDS value + sequence flag, no barrier), hands run+batch total on at once, and leaves the batch's
+ * inclusive prefixes in LDS for storer group g, which writes them out. Loads and stores are issued by different waves
+ * on purpose: vmcnt retires in order on gfx9, so a wave that stored 16 device-scope words could not see its next
+ * aggregates before those stores were acknowledged, and that round trip would be the period of the chain. */
+__device__ __forceinline__ void rs_propagate(const u32 *status, u32 *prefix, u32 num_tiles, u32 *err, u32 *lds, u32 which)
+{
+	constexpr int DP = 256 / RS_PROP_BLOCKS;  /* digits of this workgroup (whole waves) */
+	constexpr int G = RS_BLOCK / DP / 2;      /* loader groups = storer groups = batches in flight per digit */
+	constexpr int R = RS_PROP_ROWS;           /* rows per batch */
+	static_assert(DP % 64 == 0 && RS_BLOCK % (2 * DP) == 0 && G >= 1, "propagator groups must be whole waves");
+	u32 *s_cval = lds;                 /* [G][DP] running sum handed to loader group g                      */
+	u32 *s_ready = s_cval + G * DP;    /* [G][DP] = b+1 when s_cval[g] is the carry-in of batch b            */
+	u32 *s_oflag = s_ready + G * DP;   /* [G][DP] = b+1 when s_out[g] holds the prefixes of batch b          */
+	u32 *s_oack = s_oflag + G * DP;    /* [G][DP] = b+1 when the storer is done with batch b                 */
+	u32 *s_out = s_oack + G * DP;      /* [G][R][DP]                                                          */
+	const u32 tid = threadIdx.x, dl = tid % DP, d = which * DP + dl;
+	const u32 slot = (u32)__builtin_amdgcn_readfirstlane((int)(tid / DP)); /* wave-uniform: row addresses stay in SGPRs */
+	const u32 rows = num_tiles - 1; /* the last tile's inclusive prefix is nobody's exclusive prefix */
+	if (slot < (u32)G) {
+		s_ready[tid] = slot == 0 ? 1u : 0u; /* batch 0 starts from 0 */
+		s_cval[tid] = 0;
+		s_oflag[tid] = 0;
+		s_oack[tid] = 0;
+	}
+	__syncthreads();
+	u32 spins = 0;
+	if (slot < (u32)G) { /* ---- loader */
+		const u32 g = slot;
+		for (u32 b = g; (u64)b * R < rows; b += G) {
+			const u32 row0 = b * R;
+			const u32 nrow = rows - row0 < (u32)R ? rows - row0 : (u32)R;
+			const u32 *srow = status + (u64)row0 * 256 + d;
+			u32 v[R];
+#pragma unroll
+			for (int i = 0; i < R; ++i)
+				v[i] = (u32)i < nrow ? ld_agent(srow + i * 256) : ST_AGG; /* rows past the end count as published zeros */
+			for (;;) {
+				bool all = true;
+#pragma unroll
+				for (int i = 0; i < R; ++i) {
+					if ((v[i] & ~ST_MASK) == 0) {
+						v[i] = ld_agent(srow + i * 256);
+						all = false;
+					}
+				}
+				const bool ready = __hip_atomic_load(&s_ready[g * DP + dl], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) == b + 1 &&
+				                   (b < (u32)G || __hip_atomic_load(&s_oack[g * DP + dl], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) == b - G + 1);
+				if (all && ready)
+					break;
+				if (++spins > SPIN_LIMIT || (spins % 1024 == 0 && ld_agent(err) & KERR_WATCHDOG)) {
+					atomicOr(err, KERR_WATCHDOG);
+					return;
+				}
+				__builtin_amdgcn_s_sleep(1);
+			}
+			u32 run = s_cval[g * DP + dl];
+			u32 tot = 0;
+#pragma unroll
+			for (int i = 0; i < R; ++i)
+				tot += v[i] & ST_MASK;
+			const u32 gn = (g + 1) % G;
+			s_cval[gn * DP + dl] = run + tot;
+			__hip_atomic_store(&s_ready[gn * DP + dl], b + 2, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+#pragma unroll
+			for (int i = 0; i < R; ++i) {
+				run += v[i] & ST_MASK;
+				s_out[(g * R + i) * DP + dl] = ST_PREFIX | run;
+			}
+			__hip_atomic_store(&s_oflag[g * DP + dl], b + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+		}
+	} else { /* ---- storer */
+		const u32 g = slot - G;
+		for (u32 b = g; (u64)b * R < rows; b += G) {
+			const u32 row0 = b * R;
+			const u32 nrow = rows - row0 < (u32)R ? rows - row0 : (u32)R;
+			u32 *prow = prefix + (u64)row0 * 256 + d;
+			while (__hip_atomic_load(&s_oflag[g * DP + dl], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) != b + 1) {
+				if (++spins > SPIN_LIMIT || (spins % 1024 == 0 && ld_agent(err) & KERR_WATCHDOG)) {
+					atomicOr(err, KERR_WATCHDOG);
+					return;
+				}
+				__builtin_amdgcn_s_sleep(1);
+			}
+			u32 o[R];
+#pragma unroll
+			for (int i = 0; i < R; ++i)
+				o[i] = s_out[(g * R + i) * DP + dl];
+			__hip_atomic_store(&s_oack[g * DP + dl], b + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP); /* the values are in registers */
+#pragma unroll
+			for (int i = 0; i < R; ++i)
+				if ((u32)i < nrow)
+					st_agent(prow + i * 256, o[i]);
+		}
+	}
+}
+
+/* radix digit of pass `byte_idx` (= kmc_get_byte) without a dynamically indexed register array (which the compiler
+ * parks in scratch once two copies of the tile body share the function's promote-alloca budget): byte_idx is
+ * wave-uniform, so the 32-bit half that holds the digit is picked by a chain of v_cndmask on scalar conditions. */
+template <int SIZE> __device__ __forceinline__ u32 rs_digit(const u64 (&x)[SIZE], u32 byte_idx)
+{
+	const u32 hw = byte_idx >> 2;
+	u32 half = (u32)x[0];
+#pragma unroll
+	for (int i = 1; i < 2 * SIZE; ++i)
+		half = (hw == (u32)i) ? (u32)(x[i >> 1] >> ((i & 1) * 32)) : half;
+	return __builtin_amdgcn_ubfe(half, (byte_idx & 3) * 8, 8);
+}
 
 template <int SIZE>
 __global__ void __launch_bounds__(RS_BLOCK, (SIZE <= 4 ? RS_MIN_WAVES : RS_MIN_WAVES / 2)) k_onesweep(const u64 *__restrict__ in, u64 *__restrict__ out, u32 n, u32 byte_idx,
@@ -644,7 +775,15 @@ __global__ void __launch_bounds__(RS_BLOCK, (SIZE <= 4 ? RS_MIN_WAVES : RS_MIN_W
 	if (threadIdx.x == 0)
 		*s_tile = atomicAdd(tile_counter, 1u);
 	__syncthreads();
-	const u32 ticket = *s_tile;
+	u32 ticket = (u32)__builtin_amdgcn_readfirstlane((int)*s_tile); /* scalar: tile-level addresses live in SGPRs */
+#if RS_PROPAGATOR
+	u32 *prefix_rows = status + (u64)num_tiles * 256;
+	if (ticket < RS_PROP_BLOCKS) { /* the first workgroups to run serve the others; they are resident before any tile can wait for them */
+		rs_propagate(status, prefix_rows, num_tiles, err, reinterpret_cast<u32 *>(s_raw), ticket);
+		return;
+	}
+	ticket -= RS_PROP_BLOCKS;
+#endif
 
 #pragma unroll 1
 	for (int it = 0; it < RS_TPB; ++it) {
@@ -661,15 +800,18 @@ __global__ void __launch_bounds__(RS_BLOCK, (SIZE <= 4 ? RS_MIN_WAVES : RS_MIN_W
 		const u64 tile_base = (u64)tile * TILE;
 		const u32 tile_n = (n - tile_base) < (u64)TILE ? (u32)(n - tile_base) : (u32)TILE;
 		TRACE_STAMP(0, tile, 0);
-		TRACE_STAMP(0, tile, 1);
 
+		/* the body is instantiated twice: all tiles but the last of a portion are full, and for them every bounds
+		 * check (a v_cmp + exec juggling per record in four places) folds away */
+		auto tile_body = [&](auto full_tag) __attribute__((always_inline)) {
+		constexpr bool FULL = decltype(full_tag)::value;
 		u64 key[ITEMS][SIZE];
 		u32 rank[ITEMS];
 		const u32 wbase = wave * (ITEMS * 64) + lane;
 #pragma unroll
 		for (int r = 0; r < ITEMS; ++r) {
 			const u32 idx = wbase + r * 64;
-			if (idx < tile_n)
+			if (FULL || idx < tile_n)
 				load_rec<SIZE>(in + (tile_base + idx) * SIZE, key[r]);
 			else {
 #pragma unroll
@@ -677,39 +819,53 @@ __global__ void __launch_bounds__(RS_BLOCK, (SIZE <= 4 ? RS_MIN_WAVES : RS_MIN_W
 					key[r][w] = 0;
 			}
 		}
-		/* ranking, phase 1: find the lanes of this wave-round that hold the same digit ("match-any"), lowest peer
-		 * lane adds the peer count to the wave's private counter with ONE returning LDS atomic. The counter atomics
-		 * of all rounds are in flight together (LDS executes a wave's operations in order, so round r+1 sees round
-		 * r's add). (An alternative that ORs lane bits into per-(wave,digit) LDS words instead of 8 ballots was 5 % slower.) */
+#ifdef KMC_TRACE
+		asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); /* tuning build only: separate the load latency from the ranking */
+#endif
+		TRACE_STAMP(0, tile, 1);
+		/* ranking: for each round the wave finds the lanes that hold the same digit ("match-any", 8 ballots); the
+		 * rank of a record among the wave's records = the wave's running counter of that digit (read by every peer:
+		 * a same-address LDS read is a broadcast) + the number of lower peer lanes; the lowest peer then adds the peer
+		 * count to the counter with a NON-returning LDS add. LDS executes one wave's operations in order, so the read
+		 * of round r+1 sees the add of round r, and nothing waits on LDS inside a round: the counter value read in
+		 * round r is consumed one round later. */
+		u32 below_prev = 0;
+		u32 dpack[(ITEMS + 3) / 4] = {}; /* the digits, 4 per register, for step 5 */
 #pragma unroll
 		for (int r = 0; r < ITEMS; ++r) {
-			const bool valid = (wbase + r * 64) < tile_n;
-			const u32 d = kmc_get_byte<SIZE>(key[r], byte_idx);
+			const bool valid = FULL || (wbase + r * 64) < tile_n;
+			const u32 d = rs_digit<SIZE>(key[r], byte_idx);
+			dpack[r >> 2] |= d << ((r & 3) * 8);
 			const u64 vm = __ballot(valid);
 			u32 lo = (u32)vm, hi = (u32)(vm >> 32);
 #pragma unroll
 			for (int b = 0; b < 8; ++b) {
-				const int sb = -(int)((d >> b) & 1); /* 0 or ~0 */
-				const u64 m = __ballot(sb != 0);
-				lo &= ~((u32)m ^ (u32)sb);
-				hi &= ~((u32)(m >> 32) ^ (u32)sb);
+				/* 4 VALU per bit: v_bfe_i32, v_cmp (= the ballot), 2 x v_bitop3 [src1 & ~(src0 ^ src2)]. (__ballot(pred)
+				 * costs two more: it materialises the predicate as 0/1 and compares again.) */
+				const u32 sb = (u32)__builtin_amdgcn_sbfe((int)d, b, 1); /* 0 or ~0 */
+				const u64 m = __builtin_amdgcn_uicmp(sb, 0u, 33 /* ICMP_NE */);
+				lo = __builtin_amdgcn_bitop3_b32(sb, lo, (u32)m, 0x84);
+				hi = __builtin_amdgcn_bitop3_b32(sb, hi, (u32)(m >> 32), 0x84);
 			}
 			const u32 below = __builtin_amdgcn_mbcnt_hi(hi, __builtin_amdgcn_mbcnt_lo(lo, 0));
-			const u32 leader = lo ? (u32)(__ffs((int)lo) - 1) : (hi ? (u32)(31 + __ffs((int)hi)) : 0u);
-			u32 old = 0;
-			if (valid && below == 0) {
-				old = atomicAdd(&s_whist[wave * 256 + d], (u32)(__popc(lo) + __popc(hi)));
-			}
-			rank[r] = (old << 16) | (below << 8) | leader; /* old: meaningful in the leader lane only, until phase 2 */
+			if (r > 0)
+				rank[r - 1] += below_prev;
+			u32 *cnt = &s_whist[wave * 256 + d];
+			rank[r] = __hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); /* other lanes add to it */
+			if (valid && below == 0)
+				(void)__hip_atomic_fetch_add(cnt, (u32)(__popc(lo) + __popc(hi)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+			below_prev = below;
 			__builtin_amdgcn_sched_barrier(0); /* keep rounds in order: interleaving them only inflates SGPR/VGPR live ranges */
 		}
-		/* phase 2: fetch the leader's counter value */
+		rank[ITEMS - 1] += below_prev;
+		/* The look-back below wants many status words in flight per thread on top of the records; the ranks (< 2^16)
+		 * wait it out in the idle LDS staging area, two per word, so that the kernel still fits 64 VGPRs (2 workgroups
+		 * of 1024 per CU). */
+		u32 *s_lb = reinterpret_cast<u32 *>(s_keys); /* [RS_BLOCK] partial walks of the workgroup-wide round */
+		u32 *s_park = s_lb + RS_BLOCK;               /* [(ITEMS+1)/2][RS_BLOCK] */
 #pragma unroll
-		for (int r = 0; r < ITEMS; ++r) {
-			const u32 meta = rank[r];
-			const u32 old = (u32)__shfl((int)(meta >> 16), (int)(meta & 0xFF));
-			rank[r] = old + ((meta >> 8) & 0xFF);
-		}
+		for (int i = 0; i < (ITEMS + 1) / 2; ++i)
+			s_park[i * RS_BLOCK + tid] = rank[2 * i] | ((2 * i + 1 < ITEMS ? rank[2 * i + 1] : 0u) << 16);
 		TRACE_STAMP(0, tile, 2);
 		__syncthreads();
 		TRACE_STAMP(0, tile, 3);
@@ -723,14 +879,52 @@ __global__ void __launch_bounds__(RS_BLOCK, (SIZE <= 4 ? RS_MIN_WAVES : RS_MIN_W
 				s_whist[w * 256 + tid] = cnt;
 				cnt += t;
 			}
+#if RS_PROPAGATOR
+			st_agent(&status[(u64)tile * 256 + tid], ST_AGG | cnt);
+#else
 			st_agent(&status[(u64)tile * 256 + tid], (tile == 0 ? ST_PREFIX : ST_AGG) | cnt);
+#endif
 			inc = wave_incl_sum<u32>(cnt, lane);
 			if (lane == 63)
 				s_wsum[wave] = inc;
 		}
-		TRACE_STAMP(2, tile, 6);
+		TRACE_VALUE(2, tile, 7, wall_clock64()); /* when the aggregate went out, on the clock all CUs share */
 		__syncthreads();
-		TRACE_STAMP(2, tile, 7);
+		/* ---- decoupled look-back. Every digit needs sum(counts of earlier tiles): it walks back over published
+		 * AGGREGATES until it meets an inclusive PREFIX. The nearest prefix is typically 25-50 tiles back (tiles start
+		 * every ~35 ns, a prefix appears 1-2 us after its aggregate) and one dependent status load costs ~1.1 us, so a
+		 * digit owner walking 4 tiles per round trip spent 45 % of the tile's life here. Instead the WHOLE workgroup
+		 * walks the first 4*RS_LB_WIDE tiles in one round trip: thread (g = tid/256, d = tid%256) fetches the
+		 * RS_LB_WIDE status words of digit d for tiles tile-1-g*RS_LB_WIDE-i (all rows in flight together), folds them
+		 * nearest-first and leaves {sum, outcome} in LDS; the digit owners combine the 4 partial walks and only go on
+		 * one-by-one if no prefix was reached or an unpublished tile was hit. */
+#if RS_LB_WIDE > 0 && !RS_PROPAGATOR
+		if (tile > 0) {
+			const u32 dg = tid & 255;
+			const int t0 = (int)tile - 1 - (int)(tid >> 8) * RS_LB_WIDE;
+			u32 v[RS_LB_WIDE];
+#pragma unroll
+			for (int i = 0; i < RS_LB_WIDE; ++i)
+				v[i] = (t0 - i >= 0) ? ld_agent(&status[(u64)(t0 - i) * 256 + dg]) : ST_PREFIX; /* virtual empty prefix before tile 0 */
+			u32 sum = 0, code = 0 /* 0: only aggregates, 1: reached a prefix, 2: unpublished tile at `pos` */, pos = 0;
+#pragma unroll
+			for (int i = 0; i < RS_LB_WIDE; ++i) {
+				const u32 flag = v[i] & ~ST_MASK;
+				if (code == 0) {
+					if (flag == 0) {
+						code = 2;
+						pos = i;
+					} else {
+						sum += v[i] & ST_MASK;
+						if (flag == ST_PREFIX)
+							code = 1;
+					}
+				}
+			}
+			s_lb[tid] = (code << 30) | (pos << 26) | sum; /* sum <= RS_LB_WIDE * TILE < 2^26 */
+		}
+		__syncthreads();
+#endif
 		if (tid < 256) {
 			u32 doff = inc - cnt;
 #pragma unroll
@@ -748,14 +942,49 @@ __global__ void __launch_bounds__(RS_BLOCK, (SIZE <= 4 ? RS_MIN_WAVES : RS_MIN_W
 #else
 			if (tile > 0) {
 #endif
-				/* walk back over earlier tiles, RS_LOOKBACK_K status words per round trip: tiles start ~25-40 per
-				 * microsecond while one dependent global load costs ~0.5-1 us, so a one-word-per-hop walk spends most
-				 * of the tile's life here (measured: 39 % of it) */
 				int t = (int)tile - 1;
 				u32 spins = 0;
 				bool done = false;
 				u32 rounds = 0;
 				TRACE_STAMP(2, tile, 1);
+#if RS_PROPAGATOR
+				/* the exclusive prefix of this tile = the inclusive prefix of tile-1, written by the propagator */
+				for (;;) {
+					++rounds;
+					const u32 v = ld_agent(&prefix_rows[(u64)t * 256 + tid]);
+					if ((v & ~ST_MASK) != 0) {
+						excl = v & ST_MASK;
+						break;
+					}
+					if (++spins > SPIN_LIMIT || (spins % 1024 == 0 && ld_agent(err) & KERR_WATCHDOG)) {
+						atomicOr(err, KERR_WATCHDOG);
+						break;
+					}
+					__builtin_amdgcn_s_sleep(2);
+				}
+				done = true;
+#elif RS_LB_WIDE > 0
+				{
+					bool stop = false;
+#pragma unroll
+					for (int g = 0; g < RS_BLOCK / 256; ++g) {
+						if (!done && !stop) {
+							const u32 e = s_lb[g * 256 + tid];
+							excl += e & ((1u << 26) - 1);
+							if ((e >> 30) == 1)
+								done = true;
+							else if ((e >> 30) == 2) {
+								stop = true;
+								t = (int)tile - 1 - g * RS_LB_WIDE - (int)((e >> 26) & 15);
+							} else
+								t = (int)tile - 1 - (g + 1) * RS_LB_WIDE;
+						}
+					}
+					TRACE_VALUE(2, tile, 6, (u64)((int)tile - 1 - t) | ((u64)done << 32) | ((u64)stop << 33));
+				}
+#endif
+				/* one-by-one walk (RS_LOOKBACK_K words per round trip) from tile t: the tail of the walk, or all of it when
+				 * the wide round is compiled out */
 				while (!done) {
 					++rounds;
 					u32 v[RS_LOOKBACK_K];
@@ -788,7 +1017,9 @@ __global__ void __launch_bounds__(RS_BLOCK, (SIZE <= 4 ? RS_MIN_WAVES : RS_MIN_W
 				TRACE_VALUE(2, tile, 3, rounds);
 				TRACE_VALUE(2, tile, 4, spins);
 				TRACE_VALUE(2, tile, 5, (u64)((int)tile - 1 - t));
+#if !RS_PROPAGATOR
 				st_agent(&status[(u64)tile * 256 + tid], ST_PREFIX | (excl + cnt));
+#endif
 			}
 #ifdef KMC_EXP_ORACLE_PREFIX
 			if (g_oracle_mode == 1)
@@ -798,6 +1029,14 @@ __global__ void __launch_bounds__(RS_BLOCK, (SIZE <= 4 ? RS_MIN_WAVES : RS_MIN_W
 			s_goff[tid] = gbase - doff;
 			if (tile == num_tiles - 1)
 				digit_base_next[tid] = gbase + cnt; /* where the next portion continues this digit */
+		}
+		/* the ranks come back from their parking place */
+#pragma unroll
+		for (int i = 0; i < (ITEMS + 1) / 2; ++i) {
+			const u32 pr = s_park[i * RS_BLOCK + tid];
+			rank[2 * i] = pr & 0xFFFF;
+			if (2 * i + 1 < ITEMS)
+				rank[2 * i + 1] = pr >> 16;
 		}
 		TRACE_STAMP(0, tile, 4);
 		__syncthreads();
@@ -809,8 +1048,8 @@ __global__ void __launch_bounds__(RS_BLOCK, (SIZE <= 4 ? RS_MIN_WAVES : RS_MIN_W
 		constexpr int STAGE_N = TILE / STAGES;
 #pragma unroll
 		for (int r = 0; r < ITEMS; ++r) {
-			const u32 d = kmc_get_byte<SIZE>(key[r], byte_idx);
-			rank[r] = ((wbase + r * 64) < tile_n) ? s_doff[d] + s_whist[wave * 256 + d] + rank[r] : 0xFFFFFFFFu; /* slot in the tile */
+			const u32 d = (dpack[r >> 2] >> ((r & 3) * 8)) & 0xFF;
+			rank[r] = (FULL || (wbase + r * 64) < tile_n) ? s_doff[d] + s_whist[wave * 256 + d] + rank[r] : 0xFFFFFFFFu; /* slot in the tile */
 		}
 #pragma unroll 1
 		for (int h = 0; h < STAGES; ++h) {
@@ -833,12 +1072,12 @@ __global__ void __launch_bounds__(RS_BLOCK, (SIZE <= 4 ? RS_MIN_WAVES : RS_MIN_W
 			for (int i = 0; i < ITEMS / STAGES; ++i) {
 				const u32 rel = i * RS_BLOCK + tid;
 				const u32 slot = lo + rel;
-				if (slot < tile_n) {
+				if (FULL || slot < tile_n) {
 					u64 x[SIZE];
 #pragma unroll
 					for (int w = 0; w < SIZE; ++w)
 						x[w] = s_keys[w * STAGE_N + rel];
-					const u32 d = kmc_get_byte<SIZE>(x, byte_idx);
+					const u32 d = rs_digit<SIZE>(x, byte_idx);
 					store_rec<SIZE>(out + (s_goff[d] + slot) * SIZE, x);
 				}
 			}
@@ -846,13 +1085,24 @@ __global__ void __launch_bounds__(RS_BLOCK, (SIZE <= 4 ? RS_MIN_WAVES : RS_MIN_W
 				__syncthreads();
 		}
 		TRACE_STAMP(0, tile, 7);
+		};
+		if (tile_n == (u32)TILE)
+			tile_body(std::true_type{});
+		else
+			tile_body(std::false_type{});
 		__syncthreads(); /* LDS is reused by the next tile of this ticket */
 	}
 }
 
 template <int SIZE> constexpr size_t rs_lds_bytes()
 {
-	return 256 * 8 + (size_t)SIZE * RsCfg<SIZE>::TILE * 8 / RsCfg<SIZE>::STAGES + RS_WAVES * 256 * 4 + 256 * 4 + 4 * 4 + 16;
+	constexpr size_t tile_bytes = 256 * 8 + (size_t)SIZE * RsCfg<SIZE>::TILE * 8 / RsCfg<SIZE>::STAGES + RS_WAVES * 256 * 4 + 256 * 4 + 4 * 4 + 16;
+#if RS_PROPAGATOR
+	constexpr size_t prop_bytes = (size_t)(RS_BLOCK / 2) * 4 * (4 + RS_PROP_ROWS); /* rs_propagate: 4 flag/carry arrays + R rows, G*DP = RS_BLOCK/2 lanes */
+	return tile_bytes > prop_bytes ? tile_bytes : prop_bytes;
+#else
+	return tile_bytes;
+#endif
 }
 
 /* ------------------------------------------------------------------------------------------------ compaction
@@ -935,7 +1185,7 @@ __global__ void __launch_bounds__(CP_BLOCK) k_compact(const u64 *__restrict__ S,
 	if (threadIdx.x == 0)
 		s_tile = atomicAdd(tile_counter, 1u);
 	__syncthreads();
-	const u32 ticket = s_tile;
+	const u32 ticket = (u32)__builtin_amdgcn_readfirstlane((int)s_tile);
 	u64 acc_u = 0, acc_b = 0, acc_a = 0; /* thread 0: tallies of this workgroup's tiles */
 	const u32 rec_bytes = P.sbytes + P.cbytes;
 	const bool use_lut = P.lut_prefix_len != 0 && !P.kff && !P.without_output;

@@ -10,6 +10,13 @@ VARIANTS = {
     "base": [],
     "slots8": ["-DKMC_N_SLOTS=8"],
     "trace": ["-DKMC_TRACE"],
+    "np1": ["-DRS_PROP_BLOCKS=1"],
+    "np2": ["-DRS_PROP_BLOCKS=2"],
+    "np4": ["-DRS_PROP_BLOCKS=4"],
+    "np2r24": ["-DRS_PROP_BLOCKS=2", "-DRS_PROP_ROWS=24"],
+    "np2r8": ["-DRS_PROP_BLOCKS=2", "-DRS_PROP_ROWS=8"],
+    "noprop": ["-DRS_PROPAGATOR=0", "-DRS_LB_WIDE=0"],
+    "noprop_w8": ["-DRS_PROPAGATOR=0", "-DRS_LB_WIDE=8"],
 }
 
 
