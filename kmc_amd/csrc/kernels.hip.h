@@ -595,15 +595,19 @@ __global__ void __launch_bounds__(256) k_hist_scan(const u64 *__restrict__ ghist
 /* ------------------------------------------------------------------------------------------------ radix scatter
  * One 8-bit LSD pass over a portion of <= 2^29 records ("onesweep": single read, single write per record).
  *
- *  1. tile id from an atomic ticket (so every lower-numbered tile is already running: look-back cannot deadlock)
+ *  1. tile id from an atomic ticket (so every lower-numbered tile is already running: waiting on it cannot deadlock)
  *  2. wave w loads ITEMS x 64 consecutive records (512*SIZE B per wave-instruction), in index order
- *  3. ranking: for each of the ITEMS rounds the wave finds, with 8 ballots, the lanes holding the same digit
- *     ("match-any"); rank = wave-private running count of that digit (plain LDS read-modify-write by the lowest
- *     peer lane — no atomics) + number of lower peer lanes. Index order is preserved => the pass is STABLE.
- *  4. digit d's tile count = sum over waves; published as AGGREGATE in status[tile][d]; threads then look back
- *     over earlier tiles (each thread owns one digit) until a PREFIX is met, publish their own PREFIX.
- *  5. records are placed in LDS in digit order, then streamed out: consecutive threads write consecutive
- *     addresses inside each digit run (TILE/256 = 16 records = 128 B per run on uniform digits).
+ *  3. counting: every record adds 1 to its wave's private LDS counter of its digit; digit d's tile count = sum over
+ *     waves is published at once as AGGREGATE in status[tile][d] — as early as possible, because what a tile waits
+ *     for later (step 5) is two trips through device memory away (aggregate -> propagator -> prefix, ~2.5 us each).
+ *     The same pass over the counters turns them into "first LDS slot of (wave, digit)".
+ *  4. ranking: for each of the ITEMS rounds the wave finds, with 8 ballots, the lanes holding the same digit
+ *     ("match-any"); slot = the wave's running slot counter of that digit + number of lower peer lanes; the lowest
+ *     peer advances the counter. Index order is preserved => the pass is STABLE. The slot is final (tile-relative).
+ *  5. the digit owners (thread d < 256) fetch the exclusive prefix of the tile: from the prefix propagators
+ *     (RS_PROPAGATOR, see rs_propagate) or by walking back over earlier tiles' status words themselves.
+ *  6. records are placed in LDS in digit order, then streamed out: consecutive threads write consecutive
+ *     addresses inside each digit run (TILE/256 = 32 records = 256 B per run on uniform digits).
  * status word: [31:30] flag (0 empty, 1 aggregate, 2 inclusive prefix), [29:0] count — one relaxed agent-scope
  * 32-bit word that is both data and flag (no fences needed; cdna_hip_programming.md Guideline 16, form R2). */
 constexpr u32 ST_AGG = 1u << 30, ST_PREFIX = 2u << 30, ST_MASK = (1u << 30) - 1;
@@ -612,26 +616,19 @@ constexpr u32 ST_AGG = 1u << 30, ST_PREFIX = 2u << 30, ST_MASK = (1u << 30) - 1;
 #define RS_MIN_WAVES 8 /* waves per SIMD the register allocator must leave room for (2 workgroups of 1024 per CU) */
 #endif
 #ifndef RS_LOOKBACK_K
-#define RS_LOOKBACK_K 4
+#define RS_LOOKBACK_K 4 /* status words per round trip when tiles look back themselves (RS_PROPAGATOR 0) */
 #endif
 #ifndef RS_LB_WIDE
-#define RS_LB_WIDE 16 /* status words per thread in the workgroup-wide look-back round (0 = the digit owners walk alone) */
+#define RS_LB_WIDE 0 /* status words per thread in a workgroup-wide first look-back round (0 = the digit owners walk alone; 8 measured no faster: the status loads are bandwidth-, not latency-bound) */
 #endif
 #ifndef RS_TPB
 #define RS_TPB 1 /* tiles per ticket. Keep 1: a workgroup that owns consecutive tiles publishes the later ones late and every
-                   * successor's look-back stalls on them (measured 150x slower at 2); larger tiles are the way to fewer tickets */
-#endif
-
-#ifdef KMC_EXP_ORACLE_PREFIX
-/* experiment only: what would the scatter cost with a free look-back? mode 1 records every tile's exclusive prefixes,
- * mode 2 replays them instead of walking back (same input => same tiles). */
-__device__ u32 *g_saved_prefix;
-__device__ int g_oracle_mode;
-__device__ u32 g_launch_seq; /* tile-row base of the current launch, advanced by the host */
+                   * successor stalls on them (measured 150x slower at 2); larger tiles are the way to fewer tickets */
 #endif
 
 #ifndef RS_PROPAGATOR
-#define RS_PROPAGATOR 1 /* 1: one extra workgroup turns aggregates into prefixes for everybody; 0: every tile looks back itself */
+#define RS_PROPAGATOR 0 /* 1: RS_PROP_BLOCKS extra workgroups turn aggregates into prefixes for everybody (measured slower: two
+                          * trips through device memory per prefix instead of one); 0: every tile looks back itself */
 #endif
 #ifndef RS_PROP_ROWS
 #define RS_PROP_ROWS 16 /* status rows one propagator thread has in flight */
@@ -766,11 +763,11 @@ __global__ void __launch_bounds__(RS_BLOCK, (SIZE <= 4 ? RS_MIN_WAVES : RS_MIN_W
 	constexpr int TILE = RsCfg<SIZE>::TILE;
 	extern __shared__ __attribute__((aligned(16))) unsigned char s_raw[];
 	u64 *s_goff = reinterpret_cast<u64 *>(s_raw);              /* [256]  global index of LDS slot 0 as seen by digit d */
-	u64 *s_keys = s_goff + 256;                                /* [SIZE*TILE] word-major: s_keys[w*TILE + slot]         */
-	u32 *s_whist = reinterpret_cast<u32 *>(s_keys + SIZE * TILE / RsCfg<SIZE>::STAGES); /* [RS_WAVES*256] per-wave digit counters -> offsets    */
-	u32 *s_doff = s_whist + RS_WAVES * 256;                    /* [256]  first LDS slot of digit d                      */
-	u32 *s_wsum = s_doff + 256;                                /* [4]                                                    */
+	u64 *s_keys = s_goff + 256;                                /* [SIZE*TILE/STAGES] word-major staging area            */
+	u32 *s_whist = reinterpret_cast<u32 *>(s_keys + SIZE * TILE / RsCfg<SIZE>::STAGES); /* [RS_WAVES*256] per-wave digit counters -> slots */
+	u32 *s_wsum = s_whist + RS_WAVES * 256;                    /* [4]                                                    */
 	u32 *s_tile = s_wsum + 4;                                  /* [1]                                                    */
+	u32 *s_lb = s_tile + 4;                                    /* [2*RS_BLOCK] partial walks of the wide look-back round */
 
 	if (threadIdx.x == 0)
 		*s_tile = atomicAdd(tile_counter, 1u);
@@ -820,22 +817,65 @@ __global__ void __launch_bounds__(RS_BLOCK, (SIZE <= 4 ? RS_MIN_WAVES : RS_MIN_W
 			}
 		}
 #ifdef KMC_TRACE
-		asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); /* tuning build only: separate the load latency from the ranking */
+		asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); /* tuning build only: separate the load latency from the rest */
 #endif
 		TRACE_STAMP(0, tile, 1);
-		/* ranking: for each round the wave finds the lanes that hold the same digit ("match-any", 8 ballots); the
-		 * rank of a record among the wave's records = the wave's running counter of that digit (read by every peer:
-		 * a same-address LDS read is a broadcast) + the number of lower peer lanes; the lowest peer then adds the peer
-		 * count to the counter with a NON-returning LDS add. LDS executes one wave's operations in order, so the read
-		 * of round r+1 sees the add of round r, and nothing waits on LDS inside a round: the counter value read in
-		 * round r is consumed one round later. */
+
+		/* ---- step 3: count. The digits are extracted once and kept, 4 per register. */
+		u32 dpack[(ITEMS + 3) / 4] = {};
+#pragma unroll
+		for (int r = 0; r < ITEMS; ++r) {
+			const u32 d = rs_digit<SIZE>(key[r], byte_idx);
+			dpack[r >> 2] |= d << ((r & 3) * 8);
+			if (FULL || (wbase + r * 64) < tile_n)
+				(void)__hip_atomic_fetch_add(&s_whist[wave * 256 + d], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+		}
+		__syncthreads();
+		TRACE_STAMP(0, tile, 2);
+
+		/* thread `tid` (< 256) owns digit `tid` from here to the end of step 5 */
+		u32 cnt = 0, inc = 0;
+		if (tid < 256) {
+#pragma unroll
+			for (int w = 0; w < RS_WAVES; ++w)
+				cnt += s_whist[w * 256 + tid];
+#if RS_PROPAGATOR
+			st_agent(&status[(u64)tile * 256 + tid], ST_AGG | cnt);
+#else
+			st_agent(&status[(u64)tile * 256 + tid], (tile == 0 ? ST_PREFIX : ST_AGG) | cnt);
+#endif
+			inc = wave_incl_sum<u32>(cnt, lane);
+			if (lane == 63)
+				s_wsum[wave] = inc;
+		}
+		TRACE_VALUE(2, tile, 7, wall_clock64()); /* when the aggregate went out, on the clock all CUs share */
+		__syncthreads();
+		u32 doff = 0;
+		if (tid < 256) {
+			doff = inc - cnt; /* first LDS slot of digit `tid` */
+#pragma unroll
+			for (int w = 0; w < 4; ++w)
+				if (w < (int)wave)
+					doff += s_wsum[w];
+			u32 run = doff;
+#pragma unroll
+			for (int w = 0; w < RS_WAVES; ++w) { /* count -> first slot of (wave, digit) */
+				const u32 t = s_whist[w * 256 + tid];
+				s_whist[w * 256 + tid] = run;
+				run += t;
+			}
+		}
+		__syncthreads();
+		TRACE_STAMP(0, tile, 3);
+
+		/* ---- step 4: ranking. The slot counter read in round r is consumed one round later, the lowest peer advances
+		 * it with a NON-returning LDS add: LDS executes one wave's operations in order, so the read of round r+1 sees
+		 * the add of round r and nothing waits on LDS inside a round. */
 		u32 below_prev = 0;
-		u32 dpack[(ITEMS + 3) / 4] = {}; /* the digits, 4 per register, for step 5 */
 #pragma unroll
 		for (int r = 0; r < ITEMS; ++r) {
 			const bool valid = FULL || (wbase + r * 64) < tile_n;
-			const u32 d = rs_digit<SIZE>(key[r], byte_idx);
-			dpack[r >> 2] |= d << ((r & 3) * 8);
+			const u32 d = (dpack[r >> 2] >> ((r & 3) * 8)) & 0xFF;
 			const u64 vm = __ballot(valid);
 			u32 lo = (u32)vm, hi = (u32)(vm >> 32);
 #pragma unroll
@@ -850,55 +890,30 @@ __global__ void __launch_bounds__(RS_BLOCK, (SIZE <= 4 ? RS_MIN_WAVES : RS_MIN_W
 			const u32 below = __builtin_amdgcn_mbcnt_hi(hi, __builtin_amdgcn_mbcnt_lo(lo, 0));
 			if (r > 0)
 				rank[r - 1] += below_prev;
-			u32 *cnt = &s_whist[wave * 256 + d];
-			rank[r] = __hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); /* other lanes add to it */
+			u32 *ctr = &s_whist[wave * 256 + d];
+			rank[r] = __hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); /* other lanes add to it */
 			if (valid && below == 0)
-				(void)__hip_atomic_fetch_add(cnt, (u32)(__popc(lo) + __popc(hi)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+				(void)__hip_atomic_fetch_add(ctr, (u32)(__popc(lo) + __popc(hi)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 			below_prev = below;
 			__builtin_amdgcn_sched_barrier(0); /* keep rounds in order: interleaving them only inflates SGPR/VGPR live ranges */
 		}
 		rank[ITEMS - 1] += below_prev;
-		/* The look-back below wants many status words in flight per thread on top of the records; the ranks (< 2^16)
-		 * wait it out in the idle LDS staging area, two per word, so that the kernel still fits 64 VGPRs (2 workgroups
-		 * of 1024 per CU). */
-		u32 *s_lb = reinterpret_cast<u32 *>(s_keys); /* [RS_BLOCK] partial walks of the workgroup-wide round */
-		u32 *s_park = s_lb + RS_BLOCK;               /* [(ITEMS+1)/2][RS_BLOCK] */
+		if (!FULL) {
 #pragma unroll
-		for (int i = 0; i < (ITEMS + 1) / 2; ++i)
-			s_park[i * RS_BLOCK + tid] = rank[2 * i] | ((2 * i + 1 < ITEMS ? rank[2 * i + 1] : 0u) << 16);
-		TRACE_STAMP(0, tile, 2);
-		__syncthreads();
-		TRACE_STAMP(0, tile, 3);
-
-		/* thread `tid` (< 256) owns digit `tid` from here to the end of the look-back */
-		u32 cnt = 0, inc = 0;
-		if (tid < 256) {
-#pragma unroll
-			for (int w = 0; w < RS_WAVES; ++w) {
-				const u32 t = s_whist[w * 256 + tid];
-				s_whist[w * 256 + tid] = cnt;
-				cnt += t;
-			}
-#if RS_PROPAGATOR
-			st_agent(&status[(u64)tile * 256 + tid], ST_AGG | cnt);
-#else
-			st_agent(&status[(u64)tile * 256 + tid], (tile == 0 ? ST_PREFIX : ST_AGG) | cnt);
-#endif
-			inc = wave_incl_sum<u32>(cnt, lane);
-			if (lane == 63)
-				s_wsum[wave] = inc;
+			for (int r = 0; r < ITEMS; ++r)
+				if ((wbase + r * 64) >= tile_n)
+					rank[r] = 0xFFFFFFFFu;
 		}
-		TRACE_VALUE(2, tile, 7, wall_clock64()); /* when the aggregate went out, on the clock all CUs share */
-		__syncthreads();
-		/* ---- decoupled look-back. Every digit needs sum(counts of earlier tiles): it walks back over published
-		 * AGGREGATES until it meets an inclusive PREFIX. The nearest prefix is typically 25-50 tiles back (tiles start
-		 * every ~35 ns, a prefix appears 1-2 us after its aggregate) and one dependent status load costs ~1.1 us, so a
-		 * digit owner walking 4 tiles per round trip spent 45 % of the tile's life here. Instead the WHOLE workgroup
-		 * walks the first 4*RS_LB_WIDE tiles in one round trip: thread (g = tid/256, d = tid%256) fetches the
-		 * RS_LB_WIDE status words of digit d for tiles tile-1-g*RS_LB_WIDE-i (all rows in flight together), folds them
-		 * nearest-first and leaves {sum, outcome} in LDS; the digit owners combine the 4 partial walks and only go on
-		 * one-by-one if no prefix was reached or an unpublished tile was hit. */
+		TRACE_STAMP(0, tile, 4);
+
+		/* ---- step 5: the exclusive prefix of the tile, digit by digit */
 #if RS_LB_WIDE > 0 && !RS_PROPAGATOR
+		/* First round of the look-back by the WHOLE workgroup: thread (g = tid/256, d = tid%256) fetches the RS_LB_WIDE
+		 * status words of digit d for tiles tile-1-g*RS_LB_WIDE-i (all 4*RS_LB_WIDE rows in flight together), folds them
+		 * nearest-first and leaves {sum, outcome} in LDS (not in the staging area: the other waves start step 6 while the
+		 * owners are still reading); the digit owners combine the 4 partial
+		 * walks. The nearest inclusive prefix is ~20 tiles back and every aggregate on the way has long been published
+		 * (step 3), so this one round trip normally ends the walk that took the owners ~6 dependent round trips. */
 		if (tile > 0) {
 			const u32 dg = tid & 255;
 			const int t0 = (int)tile - 1 - (int)(tid >> 8) * RS_LB_WIDE;
@@ -921,34 +936,19 @@ __global__ void __launch_bounds__(RS_BLOCK, (SIZE <= 4 ? RS_MIN_WAVES : RS_MIN_W
 					}
 				}
 			}
-			s_lb[tid] = (code << 30) | (pos << 26) | sum; /* sum <= RS_LB_WIDE * TILE < 2^26 */
+			s_lb[tid] = sum; /* may include a prefix: up to 2^29 + RS_LB_WIDE * TILE */
+			s_lb[RS_BLOCK + tid] = (code << 8) | pos;
 		}
 		__syncthreads();
 #endif
 		if (tid < 256) {
-			u32 doff = inc - cnt;
-#pragma unroll
-			for (int w = 0; w < 4; ++w)
-				if (w < (int)wave)
-					doff += s_wsum[w];
-			s_doff[tid] = doff;
-
 			u32 excl = 0;
-#ifdef KMC_EXP_ORACLE_PREFIX
-			const bool replay = g_oracle_mode == 2;
-			if (replay)
-				excl = g_saved_prefix[((u64)g_launch_seq + tile) * 256 + tid];
-			if (tile > 0 && !replay) {
-#else
 			if (tile > 0) {
-#endif
 				int t = (int)tile - 1;
-				u32 spins = 0;
-				bool done = false;
-				u32 rounds = 0;
+				u32 spins = 0, rounds = 0;
 				TRACE_STAMP(2, tile, 1);
 #if RS_PROPAGATOR
-				/* the exclusive prefix of this tile = the inclusive prefix of tile-1, written by the propagator */
+				/* = the inclusive prefix of tile-1, written by a propagator */
 				for (;;) {
 					++rounds;
 					const u32 v = ld_agent(&prefix_rows[(u64)t * 256 + tid]);
@@ -962,29 +962,29 @@ __global__ void __launch_bounds__(RS_BLOCK, (SIZE <= 4 ? RS_MIN_WAVES : RS_MIN_W
 					}
 					__builtin_amdgcn_s_sleep(2);
 				}
-				done = true;
-#elif RS_LB_WIDE > 0
+#else
+				/* decoupled look-back: walk back over earlier tiles, RS_LOOKBACK_K status words per round trip, until an
+				 * inclusive prefix is met; then publish this tile's */
+				bool done = false;
+#if RS_LB_WIDE > 0
 				{
 					bool stop = false;
 #pragma unroll
 					for (int g = 0; g < RS_BLOCK / 256; ++g) {
 						if (!done && !stop) {
-							const u32 e = s_lb[g * 256 + tid];
-							excl += e & ((1u << 26) - 1);
-							if ((e >> 30) == 1)
+							const u32 e = s_lb[RS_BLOCK + g * 256 + tid];
+							excl += s_lb[g * 256 + tid];
+							if ((e >> 8) == 1)
 								done = true;
-							else if ((e >> 30) == 2) {
+							else if ((e >> 8) == 2) {
 								stop = true;
-								t = (int)tile - 1 - g * RS_LB_WIDE - (int)((e >> 26) & 15);
+								t = (int)tile - 1 - g * RS_LB_WIDE - (int)(e & 0xFF);
 							} else
 								t = (int)tile - 1 - (g + 1) * RS_LB_WIDE;
 						}
 					}
-					TRACE_VALUE(2, tile, 6, (u64)((int)tile - 1 - t) | ((u64)done << 32) | ((u64)stop << 33));
 				}
 #endif
-				/* one-by-one walk (RS_LOOKBACK_K words per round trip) from tile t: the tail of the walk, or all of it when
-				 * the wide round is compiled out */
 				while (!done) {
 					++rounds;
 					u32 v[RS_LOOKBACK_K];
@@ -1013,44 +1013,25 @@ __global__ void __launch_bounds__(RS_BLOCK, (SIZE <= 4 ? RS_MIN_WAVES : RS_MIN_W
 						__builtin_amdgcn_s_sleep(1);
 					}
 				}
+				st_agent(&status[(u64)tile * 256 + tid], ST_PREFIX | (excl + cnt));
+#endif
 				TRACE_STAMP(2, tile, 2);
 				TRACE_VALUE(2, tile, 3, rounds);
 				TRACE_VALUE(2, tile, 4, spins);
 				TRACE_VALUE(2, tile, 5, (u64)((int)tile - 1 - t));
-#if !RS_PROPAGATOR
-				st_agent(&status[(u64)tile * 256 + tid], ST_PREFIX | (excl + cnt));
-#endif
 			}
-#ifdef KMC_EXP_ORACLE_PREFIX
-			if (g_oracle_mode == 1)
-				g_saved_prefix[((u64)g_launch_seq + tile) * 256 + tid] = excl;
-#endif
 			const u64 gbase = digit_base_in[tid] + excl;
 			s_goff[tid] = gbase - doff;
 			if (tile == num_tiles - 1)
 				digit_base_next[tid] = gbase + cnt; /* where the next portion continues this digit */
 		}
-		/* the ranks come back from their parking place */
-#pragma unroll
-		for (int i = 0; i < (ITEMS + 1) / 2; ++i) {
-			const u32 pr = s_park[i * RS_BLOCK + tid];
-			rank[2 * i] = pr & 0xFFFF;
-			if (2 * i + 1 < ITEMS)
-				rank[2 * i + 1] = pr >> 16;
-		}
-		TRACE_STAMP(0, tile, 4);
-		__syncthreads();
 		TRACE_STAMP(0, tile, 5);
 
-		/* The tile goes through LDS in RS_STAGES slices of STAGE_N slots (digit order): with 2 slices the staging area is
-		 * 32 KB instead of 64 KB, i.e. 3 workgroups per CU instead of 2 (the kernel is bound by how many tiles are in flight) */
+		/* ---- step 6. The tile goes through LDS in RS_STAGES slices of STAGE_N slots (digit order): with 2 slices the
+		 * staging area is 32 KB instead of 64 KB (the kernel is bound by how many tiles are in flight). The first
+		 * barrier below is also the one that makes s_goff visible. */
 		constexpr int STAGES = RsCfg<SIZE>::STAGES;
 		constexpr int STAGE_N = TILE / STAGES;
-#pragma unroll
-		for (int r = 0; r < ITEMS; ++r) {
-			const u32 d = (dpack[r >> 2] >> ((r & 3) * 8)) & 0xFF;
-			rank[r] = (FULL || (wbase + r * 64) < tile_n) ? s_doff[d] + s_whist[wave * 256 + d] + rank[r] : 0xFFFFFFFFu; /* slot in the tile */
-		}
 #pragma unroll 1
 		for (int h = 0; h < STAGES; ++h) {
 			const u32 lo = h * STAGE_N;
@@ -1096,7 +1077,7 @@ __global__ void __launch_bounds__(RS_BLOCK, (SIZE <= 4 ? RS_MIN_WAVES : RS_MIN_W
 
 template <int SIZE> constexpr size_t rs_lds_bytes()
 {
-	constexpr size_t tile_bytes = 256 * 8 + (size_t)SIZE * RsCfg<SIZE>::TILE * 8 / RsCfg<SIZE>::STAGES + RS_WAVES * 256 * 4 + 256 * 4 + 4 * 4 + 16;
+	constexpr size_t tile_bytes = 256 * 8 + (size_t)SIZE * RsCfg<SIZE>::TILE * 8 / RsCfg<SIZE>::STAGES + RS_WAVES * 256 * 4 + 4 * 4 + 16 + 2 * RS_BLOCK * 4;
 #if RS_PROPAGATOR
 	constexpr size_t prop_bytes = (size_t)(RS_BLOCK / 2) * 4 * (4 + RS_PROP_ROWS); /* rs_propagate: 4 flag/carry arrays + R rows, G*DP = RS_BLOCK/2 lanes */
 	return tile_bytes > prop_bytes ? tile_bytes : prop_bytes;

@@ -233,18 +233,6 @@ int sort_device_t(Slot &s, u64 *d_recs, u64 *d_tmp, u64 n, u32 n_pass, u64 **d_r
 					return rc;
 				HIPCHK(hipEventRecord(e0, s.stream));
 			}
-#ifdef KMC_EXP_ORACLE_PREFIX
-			{
-				static u32 seq_host = 0;
-				static u64 sort_id = 0;
-				if (pass == 0 && start == 0)
-					seq_host = 0;
-				(void)sort_id;
-				HIPCHK(hipMemcpyToSymbolAsync(HIP_SYMBOL(g_launch_seq), &seq_host, 4, 0, hipMemcpyHostToDevice, s.stream));
-				HIPCHK(hipStreamSynchronize(s.stream));
-				seq_host += tiles;
-			}
-#endif
 			k_onesweep<SIZE><<<dim3((tiles + RS_TPB - 1) / RS_TPB + (RS_PROPAGATOR ? RS_PROP_BLOCKS : 0)), dim3(RS_BLOCK), rs_lds_bytes<SIZE>(), s.stream>>>(
 			    src + start * SIZE, dst, cnt, pass, base_in, base_out, status, counters + counter_idx, tiles, err);
 			if (s.timed)
@@ -955,21 +943,6 @@ int kmc_hip_debug_read_trace(kmc_hip_ctx *ctx, int dev, unsigned long long *dst,
 		HIPCHK(hipGetSymbolAddress(&p, HIP_SYMBOL(g_trace)));
 		HIPCHK(hipMemset(p, 0, (size_t)TRACE_SLOTS * 64));
 	}
-	return 0;
-}
-#endif
-
-#ifdef KMC_EXP_ORACLE_PREFIX
-int kmc_hip_debug_oracle_prefix(kmc_hip_ctx *ctx, int dev, int mode, uint64_t total_tiles)
-{
-	if (int rc = set_dev(ctx, dev))
-		return rc;
-	static void *buf = nullptr;
-	if (!buf) {
-		HIPCHK(hipMalloc(&buf, total_tiles * 1024));
-		HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(g_saved_prefix), &buf, sizeof(buf)));
-	}
-	HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(g_oracle_mode), &mode, sizeof(int)));
 	return 0;
 }
 #endif

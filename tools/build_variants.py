@@ -10,13 +10,12 @@ VARIANTS = {
     "base": [],
     "slots8": ["-DKMC_N_SLOTS=8"],
     "trace": ["-DKMC_TRACE"],
-    "np1": ["-DRS_PROP_BLOCKS=1"],
-    "np2": ["-DRS_PROP_BLOCKS=2"],
-    "np4": ["-DRS_PROP_BLOCKS=4"],
-    "np2r24": ["-DRS_PROP_BLOCKS=2", "-DRS_PROP_ROWS=24"],
-    "np2r8": ["-DRS_PROP_BLOCKS=2", "-DRS_PROP_ROWS=8"],
-    "noprop": ["-DRS_PROPAGATOR=0", "-DRS_LB_WIDE=0"],
-    "noprop_w8": ["-DRS_PROPAGATOR=0", "-DRS_LB_WIDE=8"],
+    "prop2": ["-DRS_PROPAGATOR=1"],
+    "w0": ["-DRS_LB_WIDE=0"],
+    "w4": ["-DRS_LB_WIDE=4"],
+    "w6": ["-DRS_LB_WIDE=6"],
+    "w12": ["-DRS_LB_WIDE=12"],
+    "st1": ["-DRS_STAGES=1"],
 }
 
 
