@@ -12,8 +12,8 @@ Inputs are resident in HBM when the timed region starts (the PCIe-inclusive rate
 `roofline`: the dominant kernel is k_onesweep (one launch = one 8-bit pass over <= 2^29 records); achieved =
 algorithmic bytes of a pass (2*W = 16 B per record) / its average launch time measured with HIP
 events on the library's own stream; peak = 8 TB/s (MI355X_MICROARCH.md). `cpu_baseline`: the REAL reference
-(oracle/_ref/kmc, built from /root/reference by oracle/Makefile) timed on this box's host cores on a bounded
-sample of the same read model — a reported baseline only.
+(oracle/_ref/kmc, built from /root/reference by oracle/Makefile) timed on this box's host cores on the same
+workload (its stage 2 has ~1 s of fixed cost, so a smaller sample would under-report it) — a reported baseline only.
 """
 import argparse
 import json

@@ -598,14 +598,20 @@ __global__ void __launch_bounds__(256) k_hist_scan(const u64 *__restrict__ ghist
  *  1. tile id from an atomic ticket (so every lower-numbered tile is already running: waiting on it cannot deadlock)
  *  2. wave w loads ITEMS x 64 consecutive records (512*SIZE B per wave-instruction), in index order
  *  3. counting: every record adds 1 to its wave's private LDS counter of its digit; digit d's tile count = sum over
- *     waves is published at once as AGGREGATE in status[tile][d] — as early as possible, because what a tile waits
- *     for later (step 5) is two trips through device memory away (aggregate -> propagator -> prefix, ~2.5 us each).
- *     The same pass over the counters turns them into "first LDS slot of (wave, digit)".
+ *     waves is published at once as AGGREGATE in status[tile][d] — before the ranking, so that by the time the
+ *     successors look back (step 5) every aggregate they need has long been visible (a store needs ~1.5 us to be seen
+ *     by another CU, a dependent status load ~1 us): published after the ranking, the walk kept running into tiles
+ *     that had not published yet and took 10 of a tile's 19 us; now 5.6. The same pass over the counters turns them
+ *     into "first LDS slot of (wave, digit)".
  *  4. ranking: for each of the ITEMS rounds the wave finds, with 8 ballots, the lanes holding the same digit
  *     ("match-any"); slot = the wave's running slot counter of that digit + number of lower peer lanes; the lowest
  *     peer advances the counter. Index order is preserved => the pass is STABLE. The slot is final (tile-relative).
- *  5. the digit owners (thread d < 256) fetch the exclusive prefix of the tile: from the prefix propagators
- *     (RS_PROPAGATOR, see rs_propagate) or by walking back over earlier tiles' status words themselves.
+ *  5. decoupled look-back: the digit owners (thread d < 256) walk back over earlier tiles' status words until they
+ *     meet an inclusive PREFIX (~21 tiles back), then publish this tile's. The walk is bound by the BYTES of status
+ *     rows it reads (device-coherent loads that miss every cache, 1 KB per tile and hop), not by round trips:
+ *     reading more rows per round trip (K = 8..16), a workgroup-wide first round of 32-64 rows, or dedicated
+ *     "propagator" workgroups that turn aggregates into prefixes for everybody were all measured slower or equal
+ *     (the code is in the history at commit "count first and publish the tile aggregate ...").
  *  6. records are placed in LDS in digit order, then streamed out: consecutive threads write consecutive
  *     addresses inside each digit run (TILE/256 = 32 records = 256 B per run on uniform digits).
  * status word: [31:30] flag (0 empty, 1 aggregate, 2 inclusive prefix), [29:0] count — one relaxed agent-scope
@@ -616,130 +622,12 @@ constexpr u32 ST_AGG = 1u << 30, ST_PREFIX = 2u << 30, ST_MASK = (1u << 30) - 1;
 #define RS_MIN_WAVES 8 /* waves per SIMD the register allocator must leave room for (2 workgroups of 1024 per CU) */
 #endif
 #ifndef RS_LOOKBACK_K
-#define RS_LOOKBACK_K 4 /* status words per round trip when tiles look back themselves (RS_PROPAGATOR 0) */
-#endif
-#ifndef RS_LB_WIDE
-#define RS_LB_WIDE 0 /* status words per thread in a workgroup-wide first look-back round (0 = the digit owners walk alone; 8 measured no faster: the status loads are bandwidth-, not latency-bound) */
+#define RS_LOOKBACK_K 4 /* status words per look-back round trip */
 #endif
 #ifndef RS_TPB
 #define RS_TPB 1 /* tiles per ticket. Keep 1: a workgroup that owns consecutive tiles publishes the later ones late and every
                    * successor stalls on them (measured 150x slower at 2); larger tiles are the way to fewer tickets */
 #endif
-
-#ifndef RS_PROPAGATOR
-#define RS_PROPAGATOR 0 /* 1: RS_PROP_BLOCKS extra workgroups turn aggregates into prefixes for everybody (measured slower: two
-                          * trips through device memory per prefix instead of one); 0: every tile looks back itself */
-#endif
-#ifndef RS_PROP_ROWS
-#define RS_PROP_ROWS 16 /* status rows one propagator thread has in flight */
-#endif
-#ifndef RS_PROP_BLOCKS
-#define RS_PROP_BLOCKS 2 /* propagator workgroups; each serves 256/RS_PROP_BLOCKS digits with RS_BLOCK*RS_PROP_BLOCKS/512 batches in flight */
-#endif
-
-/* The prefix propagators (the workgroups that drew the first tickets). With decoupled look-back every tile walks back
- * over ~25 status rows (1 KB each, device-coherent loads that miss every cache) and the walk length feeds back on
- * itself: a prefix appears only when its tile's own walk ends, so walks last c*(1 + tile rate / walk speed) ~ 10 us of
- * a tile's ~19 us life, and walking faster only adds traffic. Here a few workgroups do the chain for all tiles; a tile
- * then needs exactly one row, prefix_row[tile-1].
- *   Workgroup `which` serves DP = 256/RS_PROP_BLOCKS digits. Its waves form G loader groups and G storer groups of DP
- * lanes. Loader group g owns the batches b = g, g+G, ... of RS_PROP_ROWS consecutive tiles: it fetches the batch's
- * aggregates (all rows in flight together; the missing ones again and again), waits for the running sum of batch b-1
- * from its neighbour (LDS value + sequence flag, no barrier), hands run+batch total on at once, and leaves the batch's
- * inclusive prefixes in LDS for storer group g, which writes them out. Loads and stores are issued by different waves
- * on purpose: vmcnt retires in order on gfx9, so a wave that stored 16 device-scope words could not see its next
- * aggregates before those stores were acknowledged, and that round trip would be the period of the chain. */
-__device__ __forceinline__ void rs_propagate(const u32 *status, u32 *prefix, u32 num_tiles, u32 *err, u32 *lds, u32 which)
-{
-	constexpr int DP = 256 / RS_PROP_BLOCKS;  /* digits of this workgroup (whole waves) */
-	constexpr int G = RS_BLOCK / DP / 2;      /* loader groups = storer groups = batches in flight per digit */
-	constexpr int R = RS_PROP_ROWS;           /* rows per batch */
-	static_assert(DP % 64 == 0 && RS_BLOCK % (2 * DP) == 0 && G >= 1, "propagator groups must be whole waves");
-	u32 *s_cval = lds;                 /* [G][DP] running sum handed to loader group g                      */
-	u32 *s_ready = s_cval + G * DP;    /* [G][DP] = b+1 when s_cval[g] is the carry-in of batch b            */
-	u32 *s_oflag = s_ready + G * DP;   /* [G][DP] = b+1 when s_out[g] holds the prefixes of batch b          */
-	u32 *s_oack = s_oflag + G * DP;    /* [G][DP] = b+1 when the storer is done with batch b                 */
-	u32 *s_out = s_oack + G * DP;      /* [G][R][DP]                                                          */
-	const u32 tid = threadIdx.x, dl = tid % DP, d = which * DP + dl;
-	const u32 slot = (u32)__builtin_amdgcn_readfirstlane((int)(tid / DP)); /* wave-uniform: row addresses stay in SGPRs */
-	const u32 rows = num_tiles - 1; /* the last tile's inclusive prefix is nobody's exclusive prefix */
-	if (slot < (u32)G) {
-		s_ready[tid] = slot == 0 ? 1u : 0u; /* batch 0 starts from 0 */
-		s_cval[tid] = 0;
-		s_oflag[tid] = 0;
-		s_oack[tid] = 0;
-	}
-	__syncthreads();
-	u32 spins = 0;
-	if (slot < (u32)G) { /* ---- loader */
-		const u32 g = slot;
-		for (u32 b = g; (u64)b * R < rows; b += G) {
-			const u32 row0 = b * R;
-			const u32 nrow = rows - row0 < (u32)R ? rows - row0 : (u32)R;
-			const u32 *srow = status + (u64)row0 * 256 + d;
-			u32 v[R];
-#pragma unroll
-			for (int i = 0; i < R; ++i)
-				v[i] = (u32)i < nrow ? ld_agent(srow + i * 256) : ST_AGG; /* rows past the end count as published zeros */
-			for (;;) {
-				bool all = true;
-#pragma unroll
-				for (int i = 0; i < R; ++i) {
-					if ((v[i] & ~ST_MASK) == 0) {
-						v[i] = ld_agent(srow + i * 256);
-						all = false;
-					}
-				}
-				const bool ready = __hip_atomic_load(&s_ready[g * DP + dl], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) == b + 1 &&
-				                   (b < (u32)G || __hip_atomic_load(&s_oack[g * DP + dl], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) == b - G + 1);
-				if (all && ready)
-					break;
-				if (++spins > SPIN_LIMIT || (spins % 1024 == 0 && ld_agent(err) & KERR_WATCHDOG)) {
-					atomicOr(err, KERR_WATCHDOG);
-					return;
-				}
-				__builtin_amdgcn_s_sleep(1);
-			}
-			u32 run = s_cval[g * DP + dl];
-			u32 tot = 0;
-#pragma unroll
-			for (int i = 0; i < R; ++i)
-				tot += v[i] & ST_MASK;
-			const u32 gn = (g + 1) % G;
-			s_cval[gn * DP + dl] = run + tot;
-			__hip_atomic_store(&s_ready[gn * DP + dl], b + 2, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
-#pragma unroll
-			for (int i = 0; i < R; ++i) {
-				run += v[i] & ST_MASK;
-				s_out[(g * R + i) * DP + dl] = ST_PREFIX | run;
-			}
-			__hip_atomic_store(&s_oflag[g * DP + dl], b + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
-		}
-	} else { /* ---- storer */
-		const u32 g = slot - G;
-		for (u32 b = g; (u64)b * R < rows; b += G) {
-			const u32 row0 = b * R;
-			const u32 nrow = rows - row0 < (u32)R ? rows - row0 : (u32)R;
-			u32 *prow = prefix + (u64)row0 * 256 + d;
-			while (__hip_atomic_load(&s_oflag[g * DP + dl], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) != b + 1) {
-				if (++spins > SPIN_LIMIT || (spins % 1024 == 0 && ld_agent(err) & KERR_WATCHDOG)) {
-					atomicOr(err, KERR_WATCHDOG);
-					return;
-				}
-				__builtin_amdgcn_s_sleep(1);
-			}
-			u32 o[R];
-#pragma unroll
-			for (int i = 0; i < R; ++i)
-				o[i] = s_out[(g * R + i) * DP + dl];
-			__hip_atomic_store(&s_oack[g * DP + dl], b + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP); /* the values are in registers */
-#pragma unroll
-			for (int i = 0; i < R; ++i)
-				if ((u32)i < nrow)
-					st_agent(prow + i * 256, o[i]);
-		}
-	}
-}
 
 /* radix digit of pass `byte_idx` (= kmc_get_byte) without a dynamically indexed register array (which the compiler
  * parks in scratch once two copies of the tile body share the function's promote-alloca budget): byte_idx is
@@ -767,20 +655,11 @@ __global__ void __launch_bounds__(RS_BLOCK, (SIZE <= 4 ? RS_MIN_WAVES : RS_MIN_W
 	u32 *s_whist = reinterpret_cast<u32 *>(s_keys + SIZE * TILE / RsCfg<SIZE>::STAGES); /* [RS_WAVES*256] per-wave digit counters -> slots */
 	u32 *s_wsum = s_whist + RS_WAVES * 256;                    /* [4]                                                    */
 	u32 *s_tile = s_wsum + 4;                                  /* [1]                                                    */
-	u32 *s_lb = s_tile + 4;                                    /* [2*RS_BLOCK] partial walks of the wide look-back round */
 
 	if (threadIdx.x == 0)
 		*s_tile = atomicAdd(tile_counter, 1u);
 	__syncthreads();
-	u32 ticket = (u32)__builtin_amdgcn_readfirstlane((int)*s_tile); /* scalar: tile-level addresses live in SGPRs */
-#if RS_PROPAGATOR
-	u32 *prefix_rows = status + (u64)num_tiles * 256;
-	if (ticket < RS_PROP_BLOCKS) { /* the first workgroups to run serve the others; they are resident before any tile can wait for them */
-		rs_propagate(status, prefix_rows, num_tiles, err, reinterpret_cast<u32 *>(s_raw), ticket);
-		return;
-	}
-	ticket -= RS_PROP_BLOCKS;
-#endif
+	const u32 ticket = (u32)__builtin_amdgcn_readfirstlane((int)*s_tile); /* scalar: tile-level addresses live in SGPRs */
 
 #pragma unroll 1
 	for (int it = 0; it < RS_TPB; ++it) {
@@ -839,11 +718,7 @@ __global__ void __launch_bounds__(RS_BLOCK, (SIZE <= 4 ? RS_MIN_WAVES : RS_MIN_W
 #pragma unroll
 			for (int w = 0; w < RS_WAVES; ++w)
 				cnt += s_whist[w * 256 + tid];
-#if RS_PROPAGATOR
-			st_agent(&status[(u64)tile * 256 + tid], ST_AGG | cnt);
-#else
 			st_agent(&status[(u64)tile * 256 + tid], (tile == 0 ? ST_PREFIX : ST_AGG) | cnt);
-#endif
 			inc = wave_incl_sum<u32>(cnt, lane);
 			if (lane == 63)
 				s_wsum[wave] = inc;
@@ -907,84 +782,15 @@ __global__ void __launch_bounds__(RS_BLOCK, (SIZE <= 4 ? RS_MIN_WAVES : RS_MIN_W
 		TRACE_STAMP(0, tile, 4);
 
 		/* ---- step 5: the exclusive prefix of the tile, digit by digit */
-#if RS_LB_WIDE > 0 && !RS_PROPAGATOR
-		/* First round of the look-back by the WHOLE workgroup: thread (g = tid/256, d = tid%256) fetches the RS_LB_WIDE
-		 * status words of digit d for tiles tile-1-g*RS_LB_WIDE-i (all 4*RS_LB_WIDE rows in flight together), folds them
-		 * nearest-first and leaves {sum, outcome} in LDS (not in the staging area: the other waves start step 6 while the
-		 * owners are still reading); the digit owners combine the 4 partial
-		 * walks. The nearest inclusive prefix is ~20 tiles back and every aggregate on the way has long been published
-		 * (step 3), so this one round trip normally ends the walk that took the owners ~6 dependent round trips. */
-		if (tile > 0) {
-			const u32 dg = tid & 255;
-			const int t0 = (int)tile - 1 - (int)(tid >> 8) * RS_LB_WIDE;
-			u32 v[RS_LB_WIDE];
-#pragma unroll
-			for (int i = 0; i < RS_LB_WIDE; ++i)
-				v[i] = (t0 - i >= 0) ? ld_agent(&status[(u64)(t0 - i) * 256 + dg]) : ST_PREFIX; /* virtual empty prefix before tile 0 */
-			u32 sum = 0, code = 0 /* 0: only aggregates, 1: reached a prefix, 2: unpublished tile at `pos` */, pos = 0;
-#pragma unroll
-			for (int i = 0; i < RS_LB_WIDE; ++i) {
-				const u32 flag = v[i] & ~ST_MASK;
-				if (code == 0) {
-					if (flag == 0) {
-						code = 2;
-						pos = i;
-					} else {
-						sum += v[i] & ST_MASK;
-						if (flag == ST_PREFIX)
-							code = 1;
-					}
-				}
-			}
-			s_lb[tid] = sum; /* may include a prefix: up to 2^29 + RS_LB_WIDE * TILE */
-			s_lb[RS_BLOCK + tid] = (code << 8) | pos;
-		}
-		__syncthreads();
-#endif
 		if (tid < 256) {
 			u32 excl = 0;
 			if (tile > 0) {
 				int t = (int)tile - 1;
 				u32 spins = 0, rounds = 0;
 				TRACE_STAMP(2, tile, 1);
-#if RS_PROPAGATOR
-				/* = the inclusive prefix of tile-1, written by a propagator */
-				for (;;) {
-					++rounds;
-					const u32 v = ld_agent(&prefix_rows[(u64)t * 256 + tid]);
-					if ((v & ~ST_MASK) != 0) {
-						excl = v & ST_MASK;
-						break;
-					}
-					if (++spins > SPIN_LIMIT || (spins % 1024 == 0 && ld_agent(err) & KERR_WATCHDOG)) {
-						atomicOr(err, KERR_WATCHDOG);
-						break;
-					}
-					__builtin_amdgcn_s_sleep(2);
-				}
-#else
 				/* decoupled look-back: walk back over earlier tiles, RS_LOOKBACK_K status words per round trip, until an
 				 * inclusive prefix is met; then publish this tile's */
 				bool done = false;
-#if RS_LB_WIDE > 0
-				{
-					bool stop = false;
-#pragma unroll
-					for (int g = 0; g < RS_BLOCK / 256; ++g) {
-						if (!done && !stop) {
-							const u32 e = s_lb[RS_BLOCK + g * 256 + tid];
-							excl += s_lb[g * 256 + tid];
-							if ((e >> 8) == 1)
-								done = true;
-							else if ((e >> 8) == 2) {
-								stop = true;
-								t = (int)tile - 1 - g * RS_LB_WIDE - (int)(e & 0xFF);
-							} else
-								t = (int)tile - 1 - (g + 1) * RS_LB_WIDE;
-						}
-					}
-				}
-#endif
 				while (!done) {
 					++rounds;
 					u32 v[RS_LOOKBACK_K];
@@ -1014,7 +820,6 @@ __global__ void __launch_bounds__(RS_BLOCK, (SIZE <= 4 ? RS_MIN_WAVES : RS_MIN_W
 					}
 				}
 				st_agent(&status[(u64)tile * 256 + tid], ST_PREFIX | (excl + cnt));
-#endif
 				TRACE_STAMP(2, tile, 2);
 				TRACE_VALUE(2, tile, 3, rounds);
 				TRACE_VALUE(2, tile, 4, spins);
@@ -1077,13 +882,7 @@ __global__ void __launch_bounds__(RS_BLOCK, (SIZE <= 4 ? RS_MIN_WAVES : RS_MIN_W
 
 template <int SIZE> constexpr size_t rs_lds_bytes()
 {
-	constexpr size_t tile_bytes = 256 * 8 + (size_t)SIZE * RsCfg<SIZE>::TILE * 8 / RsCfg<SIZE>::STAGES + RS_WAVES * 256 * 4 + 4 * 4 + 16 + 2 * RS_BLOCK * 4;
-#if RS_PROPAGATOR
-	constexpr size_t prop_bytes = (size_t)(RS_BLOCK / 2) * 4 * (4 + RS_PROP_ROWS); /* rs_propagate: 4 flag/carry arrays + R rows, G*DP = RS_BLOCK/2 lanes */
-	return tile_bytes > prop_bytes ? tile_bytes : prop_bytes;
-#else
-	return tile_bytes;
-#endif
+	return 256 * 8 + (size_t)SIZE * RsCfg<SIZE>::TILE * 8 / RsCfg<SIZE>::STAGES + RS_WAVES * 256 * 4 + 4 * 4 + 16;
 }
 
 /* ------------------------------------------------------------------------------------------------ compaction

@@ -188,8 +188,7 @@ int sort_device_t(Slot &s, u64 *d_recs, u64 *d_tmp, u64 n, u32 n_pass, u64 **d_r
 	if (int rc = ensure(s.dbase, (size_t)n_pass * 256 * 8))
 		return rc;
 	const u64 max_tiles = (std::min(n, PORTION) + RsCfg<SIZE>::TILE - 1) / RsCfg<SIZE>::TILE;
-	constexpr size_t ST_ROWS = RS_PROPAGATOR ? 2 : 1; /* aggregates (+ the propagator's prefix rows) */
-	if (int rc = ensure(s.status, (size_t)max_tiles * 256 * 4 * ST_ROWS))
+	if (int rc = ensure(s.status, (size_t)max_tiles * 256 * 4))
 		return rc;
 	u64 *ghist = (u64 *)s.ghist.p, *dbase = (u64 *)s.dbase.p;
 	u32 *status = (u32 *)s.status.p;
@@ -223,7 +222,7 @@ int sort_device_t(Slot &s, u64 *d_recs, u64 *d_tmp, u64 n, u32 n_pass, u64 **d_r
 			const u32 tiles = (cnt + RsCfg<SIZE>::TILE - 1) / RsCfg<SIZE>::TILE;
 			if (counter_idx >= N_COUNTERS)
 				return fail(KMC_HIP_EINVAL, "too many scatter launches for one bin");
-			HIPCHK(hipMemsetAsync(status, 0, (size_t)tiles * 256 * 4 * ST_ROWS, s.stream));
+			HIPCHK(hipMemsetAsync(status, 0, (size_t)tiles * 256 * 4, s.stream));
 			u64 *base_out = work + (size_t)flip * 256;
 			hipEvent_t e0 = nullptr, e1 = nullptr;
 			if (s.timed) {
@@ -233,7 +232,7 @@ int sort_device_t(Slot &s, u64 *d_recs, u64 *d_tmp, u64 n, u32 n_pass, u64 **d_r
 					return rc;
 				HIPCHK(hipEventRecord(e0, s.stream));
 			}
-			k_onesweep<SIZE><<<dim3((tiles + RS_TPB - 1) / RS_TPB + (RS_PROPAGATOR ? RS_PROP_BLOCKS : 0)), dim3(RS_BLOCK), rs_lds_bytes<SIZE>(), s.stream>>>(
+			k_onesweep<SIZE><<<dim3((tiles + RS_TPB - 1) / RS_TPB), dim3(RS_BLOCK), rs_lds_bytes<SIZE>(), s.stream>>>(
 			    src + start * SIZE, dst, cnt, pass, base_in, base_out, status, counters + counter_idx, tiles, err);
 			if (s.timed)
 				HIPCHK(hipEventRecord(e1, s.stream));

@@ -10,12 +10,8 @@ VARIANTS = {
     "base": [],
     "slots8": ["-DKMC_N_SLOTS=8"],
     "trace": ["-DKMC_TRACE"],
-    "prop2": ["-DRS_PROPAGATOR=1"],
-    "w0": ["-DRS_LB_WIDE=0"],
-    "w4": ["-DRS_LB_WIDE=4"],
-    "w6": ["-DRS_LB_WIDE=6"],
-    "w12": ["-DRS_LB_WIDE=12"],
-    "st1": ["-DRS_STAGES=1"],
+    "k2": ["-DRS_LOOKBACK_K=2"],
+    "k8": ["-DRS_LOOKBACK_K=8"],
 }
 
 
