@@ -7,6 +7,8 @@
  *   KMC_HIP_LIB      path of libkmc_hip.so (default: <dir of the executable>/../../kmc_amd/libkmc_hip.so, then
  *                    plain "libkmc_hip.so" through the loader path)
  *   KMC_HIP_DEVICES  comma-separated HIP ordinals (default "0"); worker i uses device i % n_devices
+ *   KMC_HIP_EAGER_INIT  "0": load the library at the first stage-2 worker instead of at program start
+ *   KMC_HIP_VERBOSE  "1": print where the worker spent its time when the last engine is destroyed
  * There is deliberately NO CPU fallback here: if the library or a GPU is missing the engine reports the error and
  * the worker raises it through CCriticalErrorHandler.
  */
@@ -19,6 +21,7 @@
 #include <atomic>
 #include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "bin_engine.h"
@@ -178,6 +181,27 @@ struct HipEngine : KmcBinEngine {
 	}
 };
 
+} // namespace
+
+/* HIP start-up (dlopen of the ROCm runtime, context and stream creation) costs 0.13-0.35 s — as much as the GPU needs for
+ * the whole stage 2 of a 2 Gbp input — and nothing in kmc_core runs before stage 2 that the worker could hook. So the
+ * library is loaded by a background thread started when the program is loaded, i.e. during stage 1; the first worker only
+ * waits for it (call_once). KMC_HIP_EAGER_INIT=0 restores the lazy behaviour (load at the first stage-2 worker). */
+namespace {
+struct EagerInit {
+	std::thread th;
+	EagerInit()
+	{
+		const char *e = getenv("KMC_HIP_EAGER_INIT");
+		if (!e || e[0] != '0')
+			th = std::thread([] { std::call_once(g_once, load_api); });
+	}
+	~EagerInit()
+	{
+		if (th.joinable())
+			th.join();
+	}
+} g_eager;
 } // namespace
 
 KmcBinEngine *kmc_make_bin_engine(int worker_idx, int /*n_workers*/)

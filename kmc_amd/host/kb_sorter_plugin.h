@@ -31,6 +31,32 @@
 #include "defs.h"
 #include "params.h"
 #include "kmer.h"
+
+/* small_sort.h is one of the replaced subsystems too. On non-Intel hosts ProcessStage2_impl calls
+ * CSmallSort<SIZE>::Adjust(384) (kmc.h:1559), which benchmarks six CPU small-array sorters for 1.0-1.4 s (small_sort.h:68-103,
+ * :154-172) — more than the whole GPU stage 2 of a 2 Gbp input — to tune a CPU radix sort the GPU worker never runs.
+ * Its include guard is taken here, with the same interface: Adjust is a no-op, Sort (still reachable from
+ * RadixSort::SmallSortDispatch, radix.h:37-41, if strict-memory mode sorts an oversized bin on the CPU) is std::sort
+ * on CKmer's operator< (kmer.h:271-278), i.e. the same order. Define KMC_PLUGIN_KEEP_SMALL_SORT to keep the original. */
+#if !defined(_SMALL_SORT_H) && !defined(KMC_PLUGIN_KEEP_SMALL_SORT)
+#define _SMALL_SORT_H
+#include <cstdint>
+#include <chrono>
+#include <stdlib.h>
+#include <random>
+#include <algorithm>
+#include <vector>
+#include <functional>
+#include <array>
+#include <string>
+using namespace std; /* small_sort.h:26 — later reference headers rely on it */
+template <unsigned SIZE> class CSmallSort {
+public:
+	static void Adjust(uint32 /*arr_size*/ = 384) {}
+	static void Sort(CKmer<SIZE> *ptr, uint32 size) { std::sort(ptr, ptr + size); }
+};
+#endif
+
 #include "raduls.h"
 #include "radix.h"
 #include "s_mapper.h"

@@ -161,3 +161,28 @@ def test_oracle_database_equals_reference(flags, ref_bins, tmp_path):
     for ext in (".kmc_pre", ".kmc_suf"):
         assert _md5(str(tmp_path / ("ref" + ext))) == _md5(str(tmp_path / ("orc" + ext)))
         assert _md5(str(tmp_path / ("ref" + ext))) == _md5(str(tmp_path / ("orc3" + ext)))
+
+
+def test_dropin_binary_fails_loudly_without_a_gpu(ref_bins, tmp_path):
+    """The product worker has no CPU fallback: on a box without a GPU `kmc_hip` must stop with the engine's error
+    (CCriticalErrorHandler), not count on the host. Covers the eager background initialisation of hip_loader.cpp too
+    (it must neither crash at start-up nor at exit when HIP cannot initialise)."""
+    if ref_bins is None or "kmc_hip" not in ref_bins or not os.path.exists(ref_bins["kmc_hip"]):
+        pytest.skip("oracle/_ref/kmc_hip not built")
+    if os.path.exists("/dev/kfd"):
+        pytest.skip("a GPU is present: the drop-in runs for real here (see the -m gpu suite)")
+    from kmc_amd import synth
+
+    fq = str(tmp_path / "in.fq")
+    synth.make_fastq(fq, seed=7, genome_len=20_000, n_reads=500)
+    for eager in ("1", "0"):
+        tmp = tmp_path / ("tmp" + eager)
+        tmp.mkdir()
+        env = dict(os.environ, KMC_HIP_LIB=os.path.join(ROOT, "kmc_amd", "libkmc_hip.so"), KMC_HIP_EAGER_INIT=eager)
+        r = subprocess.run([ref_bins["kmc_hip"], "-k27", "-t2", fq, str(tmp_path / ("out" + eager)), str(tmp)], env=env,
+                           capture_output=True, text=True, timeout=120)
+        assert r.returncode != 0, r.stdout + r.stderr
+        assert re.search(r"kmc_hip|HIP|hip", r.stdout + r.stderr), r.stdout + r.stderr
+    # usage / early exit paths must not trip over the background thread either
+    r = subprocess.run([ref_bins["kmc_hip"]], capture_output=True, text=True, timeout=60)
+    assert "Usage" in r.stdout + r.stderr
