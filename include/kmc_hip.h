@@ -121,8 +121,9 @@ int kmc_hip_process_bin_wait(kmc_hip_ctx *ctx, int dev, int slot, uint64_t *out_
  *   d_out[out_capacity], d_lut[kmc_hip_lut_entries()], d_stats[4] (uint64, written by the device)
  *   d_out_bytes: 1 uint64 written by the device.
  * Returns after enqueueing unless `sync` != 0. Asynchronous calls are spread round-robin over several internal streams
- * (bins are independent), so consecutive small bins overlap; kmc_hip_synchronize(dev) waits for all of them and reports
- * any deferred device error. Output buffers of calls in flight must be distinct. */
+ * (bins are independent), so consecutive small bins overlap (a bin with more than 2 GiB of record arrays always takes
+ * the first stream: it fills the GPU alone); kmc_hip_synchronize(dev) waits for all of them and reports any deferred
+ * device error. Output buffers of calls in flight must be distinct. */
 int kmc_hip_process_bin_device(kmc_hip_ctx *ctx, int dev, const kmc_hip_bin_params *params,
                                const uint8_t *d_superkmers, uint64_t size, uint64_t n_rec,
                                const uint64_t *d_pack_start, uint64_t n_packs, uint8_t *d_out, uint64_t out_capacity,

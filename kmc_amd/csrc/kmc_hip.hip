@@ -663,8 +663,12 @@ int kmc_hip_process_bin_device(kmc_hip_ctx *ctx, int dev, const kmc_hip_bin_para
 	if (!d_out_bytes || !d_stats || (size && (!d_superkmers || !d_pack_start)))
 		return fail(KMC_HIP_EINVAL, "kmc_hip_process_bin_device: NULL device pointer");
 	/* asynchronous calls go round-robin over the device's stream slots, so the launch gaps and serial tails of one
-	 * (small) bin are filled by the kernels of the next ones; a synchronous call always uses slot 0 */
-	Slot &s = ctx->devs[dev].slot[sync ? 0 : (ctx->devs[dev].rr++ % N_SLOTS)];
+	 * (small) bin are filled by the kernels of the next ones; a synchronous call always uses slot 0, and so does a bin
+	 * whose record arrays exceed ASYNC_BIG_BYTES: it fills the GPU on its own, and every slot it visited would keep
+	 * two arrays of that size (slot buffers only grow) */
+	constexpr u64 ASYNC_BIG_BYTES = 1ull << 31;
+	const bool big = n_rec * (u64)kmc_hip_words(P.k) * 8 * 2 > ASYNC_BIG_BYTES;
+	Slot &s = ctx->devs[dev].slot[(sync || big) ? 0 : (ctx->devs[dev].rr++ % N_SLOTS)];
 	s.timed = true;
 	const u64 lut_entries = kmc_hip_lut_entries(params);
 	if (int rc = run_bin_device(s, P, d_superkmers, size, n_rec, (const u64 *)d_pack_start, n_packs, d_out, out_capacity,
