@@ -946,8 +946,11 @@ __device__ __forceinline__ u64 run_start_search(const u64 *__restrict__ S, u64 b
 constexpr int CP_STAGE = 16384; /* bytes of output assembled in LDS per window */
 constexpr int CP_SHARDS = 32; /* tally shards: same-address device atomics serialise at ~11 ns each */
 
+#ifndef CP_MIN_WAVES
+#define CP_MIN_WAVES 4 /* waves per SIMD the register allocator must leave room for: 128 VGPRs (4 spilled dwords at SIZE 1) buy a 4th workgroup per CU, 12.0 -> 10.9 ms */
+#endif
 template <int SIZE>
-__global__ void __launch_bounds__(CP_BLOCK) k_compact(const u64 *__restrict__ S, u64 n, DevParams P, uint8_t *__restrict__ out,
+__global__ void __launch_bounds__(CP_BLOCK, CP_MIN_WAVES) k_compact(const u64 *__restrict__ S, u64 n, DevParams P, uint8_t *__restrict__ out,
                                                        u64 out_capacity, u64 *__restrict__ lut_base, u32 lut_shards, u64 lut_stride,
                                                        u64 *stat_shards /* [CP_SHARDS][4] */, u64 *out_bytes, u64 *status, u32 *tile_counter,
                                                        u32 num_tiles, u32 *err)

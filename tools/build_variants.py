@@ -12,6 +12,7 @@ VARIANTS = {
     "trace": ["-DKMC_TRACE"],
     "k2": ["-DRS_LOOKBACK_K=2"],
     "k8": ["-DRS_LOOKBACK_K=8"],
+    "cp4": ["-DCP_MIN_WAVES=4"],
 }
 
 
