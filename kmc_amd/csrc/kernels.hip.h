@@ -220,8 +220,9 @@ __global__ void __launch_bounds__(256) k_parse_packs(const uint8_t *__restrict__
 {
 	/* Three levels per PARSE_CHUNK bytes staged in LDS (the chain has <= chunk/Lmin hops; walking it serially costs one
 	 * dependent load per hop):
-	 *   L1  every byte position p, in parallel: X(p) = where the chain started at p leaves p's 128-byte sub-block
-	 *       (<= 128/Lmin hops, 16 independent chains per thread interleaved so the LDS latency pipelines)
+	 *   L1  every possible entry position p of every 128-byte sub-block, in parallel: X(p) = where the chain started at
+	 *       p leaves the sub-block (<= 128/Lmin hops, up to 16 independent chains per thread interleaved so the LDS
+	 *       latency pipelines)
 	 *   L2  one lane hops sub-block to sub-block from the chunk's entry offset: 32 dependent LDS reads instead of ~500
 	 *   L3  one lane per sub-block walks it from its now-known entry and builds the sub-block's 128 start bits */
 	__shared__ uint8_t s_b[PARSE_CHUNK];
@@ -246,26 +247,39 @@ __global__ void __launch_bounds__(256) k_parse_packs(const uint8_t *__restrict__
 		if (tid < PARSE_NSUB)
 			s_ent[tid] = 0;
 		__syncthreads();
-		/* L1 */
+		/* L1. Only the first `maxlen` positions of a sub-block can be where the chain enters it (the record before
+		 * starts below the sub-block and is at most maxlen bytes long), so only they need X: thread (sub = tid/8,
+		 * o = tid%8) runs the candidates sub*128 + o + 8i, i < ceil(min(maxlen,128)/8) — 9 of 16 at k=27 — and the hop
+		 * loop stops as soon as the wave has no chain left inside its sub-blocks. */
 		{
-			u32 q[PARSE_CHUNK / 256];
+			constexpr int NC = PARSE_SUB / 8;
+			static_assert(PARSE_NSUB * 8 == 256, "one sub-block per 8 threads");
+			const u32 maxlen = 1 + ((k + 255 + 3) >> 2); /* e <= 255 (splitter.cpp:656) */
+			const u32 ni = ((maxlen < (u32)PARSE_SUB ? maxlen : (u32)PARSE_SUB) + 7) >> 3;
+			const u32 sb0 = (tid >> 3) * PARSE_SUB, sb_end = sb0 + PARSE_SUB;
+			u32 q[NC];
 #pragma unroll
-			for (int i = 0; i < PARSE_CHUNK / 256; ++i)
-				q[i] = tid + 256 * i;
+			for (int i = 0; i < NC; ++i)
+				q[i] = sb0 + (tid & 7) + 8 * i;
 			const u32 max_hops = PARSE_SUB / (1 + ((k + 3) >> 2)) + 1;
 			for (u32 h = 0; h < max_hops; ++h) {
+				bool moved = false;
 #pragma unroll
-				for (int i = 0; i < PARSE_CHUNK / 256; ++i) {
-					const u32 p0 = tid + 256 * i;
-					const u32 sb_end = (p0 / PARSE_SUB + 1) * PARSE_SUB;
-					if (q[i] < sb_end && q[i] < clen)
+				for (int i = 0; i < NC; ++i) {
+					if ((u32)i < ni && q[i] < sb_end && q[i] < clen) {
 						q[i] += 1 + ((k + s_b[q[i]] + 3) >> 2);
+						moved = true;
+					}
 				}
+				if (!__any(moved))
+					break;
 			}
 #pragma unroll
-			for (int i = 0; i < PARSE_CHUNK / 256; ++i)
-				if (tid + 256 * i < clen)
-					s_X[tid + 256 * i] = (unsigned short)q[i]; /* < clen + 130 */
+			for (int i = 0; i < NC; ++i) {
+				const u32 p0 = sb0 + (tid & 7) + 8 * i;
+				if ((u32)i < ni && p0 < clen)
+					s_X[p0] = (unsigned short)q[i]; /* < clen + 130 */
+			}
 		}
 		__syncthreads();
 		/* L2 */
