@@ -186,3 +186,78 @@ def test_dropin_binary_fails_loudly_without_a_gpu(ref_bins, tmp_path):
     # usage / early exit paths must not trip over the background thread either
     r = subprocess.run([ref_bins["kmc_hip"]], capture_output=True, text=True, timeout=60)
     assert "Usage" in r.stdout + r.stderr
+
+
+def _bruteforce_bin(img: np.ndarray, k: int, both: bool, cutoff_min: int, cutoff_max: int, counter_max: int, pl: int, kff: bool):
+    """Stage 2 from first principles, on STRINGS of symbols (no bit tricks shared with the oracle or the kernels):
+    parse [e][packed k+e symbols], count canonical k-mers in a dict, apply the cutoffs before clamping, emit
+    (suffix big-endian, counter) records in ascending k-mer order + the per-prefix counts."""
+    from collections import Counter
+
+    pos, counts, total = 0, Counter(), 0
+    data = bytes(img)
+    while pos < len(data):
+        e = data[pos]
+        nsym = k + e
+        nbytes = (nsym + 3) // 4
+        syms = []
+        for b in data[pos + 1 : pos + 1 + nbytes]:
+            syms += [(b >> 6) & 3, (b >> 4) & 3, (b >> 2) & 3, b & 3]
+        syms = syms[:nsym]
+        pos += 1 + nbytes
+        for i in range(e + 1):
+            kmer = tuple(syms[i : i + k])
+            if both:
+                rc = tuple(3 - s for s in reversed(kmer))
+                kmer = min(kmer, rc)
+            counts[kmer] += 1
+            total += 1
+    assert pos == len(data)
+    sbytes = (k - pl) // 4 if pl else (k + 3) // 4
+    cb = O.lib().oracle_counter_size(cutoff_max, counter_max) if not kff else O.lib().oracle_counter_size(cutoff_max, counter_max)
+    out, lut = bytearray(), np.zeros(4**pl if pl else 0, dtype=np.uint64)
+    n_below = n_above = 0
+    for kmer in sorted(counts):
+        c = counts[kmer]
+        if c < cutoff_min:
+            n_below += 1
+            continue
+        if c > cutoff_max:
+            n_above += 1
+            continue
+        c = min(c, counter_max)
+        value = 0
+        for s in kmer:
+            value = (value << 2) | s
+        out += (value & ((1 << (8 * sbytes)) - 1)).to_bytes(sbytes, "big")
+        out += c.to_bytes(cb, "big" if kff else "little") if cb else b""
+        if pl:
+            lut[value >> (2 * (k - pl))] += 1
+    return np.frombuffer(bytes(out), dtype=np.uint8), lut, [len(counts), n_below, n_above, total]
+
+
+@pytest.mark.parametrize("k,pl,both,kw", [
+    (27, 3, True, dict(cutoff_min=2)),
+    (27, 3, False, dict(cutoff_min=1, counter_max=3)),
+    (14, 2, True, dict(cutoff_min=1, cutoff_max=4)),
+    (32, 4, True, dict(cutoff_min=2, counter_max=70000)),
+    (33, 1, True, dict(cutoff_min=1)),
+    (55, 3, True, dict(cutoff_min=1, counter_max=1)),
+    (64, 0, True, dict(cutoff_min=1, output_type=1)),
+    (127, 7, True, dict(cutoff_min=1)),
+    (5, 1, True, dict(cutoff_min=1)),   # palindromes: k-mer == reverse complement only for even k; odd k never ties
+    (6, 2, True, dict(cutoff_min=1)),   # even k: canonical ties (issue-180 shape)
+])
+def test_oracle_matches_a_bruteforce_string_model(k, pl, both, kw):
+    """Pins the oracle independently of the reference binaries AND of its own word-level arithmetic."""
+    rng = np.random.default_rng(1000 + k)
+    genome = rng.integers(0, 4, size=600 if k < 100 else 1200, dtype=np.uint8)
+    img, nk, _ = binsynth.random_bin(rng, k, 60, max_extra=30, genome=genome)
+    p = O.make_params(k, both_strands=int(both), lut_prefix_len=pl, **kw)
+    out, lut, st = O.process_bin(p, img, nk)
+    want_out, want_lut, want_st = _bruteforce_bin(img, k, both, p.cutoff_min, p.cutoff_max, p.counter_max, pl if not p.output_type else 0,
+                                                  bool(p.output_type))
+    assert st.tolist() == want_st
+    assert np.array_equal(out, want_out)
+    if pl and not p.output_type:
+        assert np.array_equal(lut, want_lut)
