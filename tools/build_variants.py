@@ -8,11 +8,11 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 VARIANTS = {
     "base": [],
-    "slots8": ["-DKMC_N_SLOTS=8"],
-    "trace": ["-DKMC_TRACE"],
+    "trace": ["-DKMC_TRACE"],  # per-tile phase stamps, read by tools/trace_run.py
     "k2": ["-DRS_LOOKBACK_K=2"],
     "k8": ["-DRS_LOOKBACK_K=8"],
-    "cp4": ["-DCP_MIN_WAVES=4"],
+    "cp3": ["-DCP_MIN_WAVES=3"],
+    "b512x16": ["-DRS_BLOCK_THREADS=512", "-DRS_WORDS_PER_THREAD=16", "-DRS_MIN_WAVES=6"],
 }
 
 
