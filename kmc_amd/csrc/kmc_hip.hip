@@ -12,6 +12,7 @@
 
 #include <algorithm>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <string>
@@ -76,7 +77,10 @@ constexpr size_t SM_BYTES = SM_COUNTERS + N_COUNTERS * 4;
 #define KMC_N_SLOTS 8 /* 512 bins of 3.2 M k-mers: 1 slot 237 ms, 2 slots 133, 4 slots 104, 8 slots 95 (then the host launch rate binds) */
 #endif
 constexpr int N_SLOTS = KMC_N_SLOTS;
-constexpr u64 PORTION = 1ull << 29; /* records per scatter launch (30-bit look-back counts) */
+constexpr u64 PORTION_MAX = 1ull << 29; /* records per scatter launch (30-bit look-back counts) */
+/* Tests shrink the portion ($KMC_HIP_DEBUG_PORTION_LOG2, 10..29, read at kmc_hip_init) so that a small, oracle-checkable sort
+ * crosses many portion boundaries (digit bases carried from launch to launch) — the path a bin of > 2^29 k-mers takes. */
+static u64 PORTION = PORTION_MAX;
 
 struct HostRes {
 	u64 totals[2];
@@ -500,6 +504,12 @@ int kmc_hip_init(const int *device_ids, int n_dev, kmc_hip_ctx **out)
 	HIPCHK(hipGetDeviceCount(&count));
 	if (count < 1)
 		return fail(KMC_HIP_EDEVICE, "no HIP device visible");
+	PORTION = PORTION_MAX;
+	if (const char *e = getenv("KMC_HIP_DEBUG_PORTION_LOG2")) {
+		const int lg = atoi(e);
+		if (lg >= 10 && lg <= 29)
+			PORTION = 1ull << lg;
+	}
 	kmc_hip_ctx *ctx = new kmc_hip_ctx();
 	ctx->devs.resize(n_dev);
 	for (int i = 0; i < n_dev; ++i) {

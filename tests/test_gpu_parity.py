@@ -330,3 +330,32 @@ def test_kmc_with_hip_sorter_writes_the_reference_database(flags, ref_bins, tmp_
     for ext in (".kmc_pre", ".kmc_suf"):
         assert _md5(str(tmp_path / ("ref" + ext))) == _md5(str(tmp_path / ("hip" + ext))), ext
         assert _md5(str(tmp_path / ("ref" + ext))) == _md5(str(tmp_path / ("hip4" + ext))), ext + " (4 workers, 2 devices)"
+
+
+def test_sort_and_bin_cross_portion_boundaries(monkeypatch):
+    """A bin of more than 2^29 k-mers is scattered in portions (one launch each, digit bases carried from portion to portion,
+    kmc_hip.hip sort_device_t). With the portion shrunk to 2^15 records ($KMC_HIP_DEBUG_PORTION_LOG2, read at init) a
+    small sort takes the same path and can be checked against the oracle bit for bit."""
+    monkeypatch.setenv("KMC_HIP_DEBUG_PORTION_LOG2", "15")
+    c2 = capi.Context((0,))
+    try:
+        rng = np.random.default_rng(2029)
+        for words, key_bytes, n in ((1, 7, 100_003), (1, 8, 32_768 * 3), (2, 14, 70_001), (4, 32, 40_000)):
+            recs = rng.integers(0, 2**62, size=(n, words), dtype=np.uint64)
+            for w in range(words):
+                lo = 8 * w
+                if key_bytes - lo < 8:
+                    recs[:, w] &= np.uint64((1 << (8 * max(key_bytes - lo, 0))) - 1)
+            got = c2.sort_records(recs, key_bytes)
+            assert np.array_equal(got, O.sort(recs)), (words, key_bytes, n)
+        for k in (27, 55):
+            img, nk, packs = binsynth.random_bin(rng, k, 3000, max_extra=60, genome=rng.integers(0, 4, size=20_000, dtype=np.uint8))
+            assert nk > 3 * 32_768 // 2
+            p = hp(k, cutoff_min=1)
+            out, lut, st = c2.process_bin(p, img, nk, packs)
+            want_out, want_lut, want_st = O.process_bin(op(p), img, nk)
+            assert np.array_equal(st, want_st) and np.array_equal(out, want_out) and np.array_equal(lut, want_lut), k
+    finally:
+        c2.close()
+        monkeypatch.delenv("KMC_HIP_DEBUG_PORTION_LOG2")
+        capi.Context((0,)).close()  # kmc_hip_init re-reads the variable: the session's context is back on full portions
