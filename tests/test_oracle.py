@@ -261,3 +261,20 @@ def test_oracle_matches_a_bruteforce_string_model(k, pl, both, kw):
     assert np.array_equal(out, want_out)
     if pl and not p.output_type:
         assert np.array_equal(lut, want_lut)
+
+
+def test_cabi_init_fails_loudly_without_a_gpu():
+    """No CPU fallback behind the C-ABI either: without a device kmc_hip_init returns KMC_HIP_EDEVICE and says why."""
+    if os.path.exists("/dev/kfd"):
+        pytest.skip("a GPU is present")
+    from kmc_amd import capi
+
+    L = capi.load()
+    h = C.c_void_p()
+    ids = (C.c_int * 1)(0)
+    rc = L.kmc_hip_init(ids, 1, C.byref(h))
+    assert rc == -2 and not h.value, rc  # KMC_HIP_EDEVICE
+    msg = L.kmc_hip_last_error(None)
+    assert msg and len(msg) > 3
+    with pytest.raises(capi.KmcHipError):
+        capi.Context((0,))
