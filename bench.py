@@ -122,16 +122,18 @@ def main():
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (torch.cuda.is_available() is False); there is no CPU path")
-    torch.cuda.set_device(local_rank)
+    # one rank per GPU; if the launcher already narrowed the visible devices to one per process, that one is ordinal 0
+    dev_index = local_rank if torch.cuda.device_count() > local_rank else 0
+    torch.cuda.set_device(dev_index)
     dist = None
     if world > 1:
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
-    dev = torch.device("cuda", local_rank)
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", dev_index))
+    dev = torch.device("cuda", dev_index)
 
-    ctx = capi.Context((local_rank,))
+    ctx = capi.Context((dev_index,))
     k = args.k
     t_gen = time.time()
     n_threads = max(1, (os.cpu_count() or 8) // max(world, 1))
