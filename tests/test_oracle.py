@@ -140,7 +140,8 @@ def _md5(p):
     return hashlib.md5(open(p, "rb").read()).hexdigest()
 
 
-@pytest.mark.parametrize("flags", [["-k27"], ["-k55", "-ci1"], ["-k127"], ["-k27", "-b", "-cs3", "-ci1"], ["-k32", "-cx5", "-ci1"]],
+@pytest.mark.parametrize("flags", [["-k27"], ["-k55", "-ci1"], ["-k127"], ["-k27", "-b", "-cs3", "-ci1"], ["-k32", "-cx5", "-ci1"],
+                                   ["-k27", "-sm", "-m2"]],  # strict-memory mode: the plug-in worker + the stubbed CSmallSort must not disturb it
                          ids=lambda f: "".join(f))
 def test_oracle_database_equals_reference(flags, ref_bins, tmp_path):
     """End-to-end pin: reference pipeline + oracle sorter (kmc_oracle) writes .kmc_pre/.kmc_suf byte-identical
