@@ -154,7 +154,8 @@ def test_oracle_database_equals_reference(flags, ref_bins, tmp_path):
     synth.make_fastq(fq, seed=99, genome_len=60_000, n_reads=4000)
     # the plug-in worker emits bins in hand-out order whatever the number of workers (KmcOrderedEmit), so the
     # multi-worker run (-sr3) must give the same bytes as the reference's single-sorter run
-    for exe, out, mode in (("kmc", "ref", ["-sr1"]), ("kmc_oracle", "orc", ["-sr1"]), ("kmc_oracle", "orc3", ["-t4", "-sr3"])):
+    for exe, out, mode in (("kmc", "ref", ["-sr1"]), ("kmc_oracle", "orc", ["-sr1"]), ("kmc_oracle", "orc3", ["-t4", "-sr3"]),
+                           ("kmc_oracle", "orc12", ["-t16", "-sr12"])):
         tmp = tmp_path / ("tmp_" + out)
         tmp.mkdir()
         subprocess.check_call([ref_bins[exe], *flags, *mode, fq, str(tmp_path / out), str(tmp)], stdout=subprocess.DEVNULL,
@@ -162,6 +163,7 @@ def test_oracle_database_equals_reference(flags, ref_bins, tmp_path):
     for ext in (".kmc_pre", ".kmc_suf"):
         assert _md5(str(tmp_path / ("ref" + ext))) == _md5(str(tmp_path / ("orc" + ext)))
         assert _md5(str(tmp_path / ("ref" + ext))) == _md5(str(tmp_path / ("orc3" + ext)))
+        assert _md5(str(tmp_path / ("ref" + ext))) == _md5(str(tmp_path / ("orc12" + ext)))
 
 
 def test_dropin_binary_fails_loudly_without_a_gpu(ref_bins, tmp_path):
