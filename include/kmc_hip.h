@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define KMC_HIP_ABI_VERSION 1
+#define KMC_HIP_ABI_VERSION 2
 
 enum {
 	KMC_HIP_OK = 0,
@@ -63,6 +63,7 @@ void kmc_hip_destroy(kmc_hip_ctx *ctx);
 const char *kmc_hip_last_error(kmc_hip_ctx *ctx); /* thread-local message of the calling thread's last failure */
 int kmc_hip_abi_version(void);
 int kmc_hip_num_devices(kmc_hip_ctx *ctx);
+int kmc_hip_device_count(void); /* HIP devices visible to the process (0 when the runtime is unusable) */
 int kmc_hip_num_slots(void); /* stream slots per device usable with _submit/_wait (independent bins in flight) */
 
 /* Derived sizes, so callers size buffers exactly like kb_reader.h:141-165 does. */
@@ -77,8 +78,13 @@ uint64_t kmc_hip_lut_entries(const kmc_hip_bin_params *p);                   /* 
  * zero), result left IN `recs` (host memory).
  * Replaces: SortFunction<CKmer<SIZE>> (raduls.h:19-20) = RadulsSort::RadixSortMSD_* (raduls_impl.h:769-776)
  * / RadixSort::RadixSortMSD (radix.h:845-852) as called at kb_sorter.h:775; key_bytes = rec_len there.
- * (The reference leaves the result in `tmp` when rec_len is odd; this entry always returns it in place.) */
+ * (The reference leaves the result in `tmp` when rec_len is odd; this entry always returns it in place — see _into.) */
 int kmc_hip_sort_records(kmc_hip_ctx *ctx, int dev, void *recs, uint64_t n, uint32_t words, uint32_t key_bytes);
+
+/* Same, with the sorted records delivered to `dst` (host memory; may equal recs). This is what the SortFunction adapter
+ * (kmc_amd/host/hip_sort_function.h) binds: the reference wants the result in `tmp` when key_bytes is odd and in `kmers`
+ * when it is even (kb_sorter.h:776-779, raduls_impl.h:552-561), so the adapter passes dst = tmp or kmers. */
+int kmc_hip_sort_records_into(kmc_hip_ctx *ctx, int dev, const void *recs, void *dst, uint64_t n, uint32_t words, uint32_t key_bytes);
 
 /* Same, on device-resident records (d_recs, d_tmp: n*words*8 bytes each, 256-B aligned). On return
  * *d_result points at whichever of the two holds the sorted records. Stream-synchronous. */
@@ -123,11 +129,29 @@ int kmc_hip_process_bin_wait(kmc_hip_ctx *ctx, int dev, int slot, uint64_t *out_
  * Returns after enqueueing unless `sync` != 0. Asynchronous calls are spread round-robin over several internal streams
  * (bins are independent), so consecutive small bins overlap (a bin with more than 2 GiB of record arrays always takes
  * the first stream: it fills the GPU alone); kmc_hip_synchronize(dev) waits for all of them and reports any deferred
- * device error. Output buffers of calls in flight must be distinct. */
+ * device error (errors are kept in a per-stream sticky word that only a synchronising call clears). Output buffers of calls in flight must be distinct. */
 int kmc_hip_process_bin_device(kmc_hip_ctx *ctx, int dev, const kmc_hip_bin_params *params,
                                const uint8_t *d_superkmers, uint64_t size, uint64_t n_rec,
                                const uint64_t *d_pack_start, uint64_t n_packs, uint8_t *d_out, uint64_t out_capacity,
                                uint64_t *d_out_bytes, uint64_t *d_lut, uint64_t *d_stats, int sync);
+
+/* Many device-resident bins in one call (per-GPU bin queue): bin i is enqueued on internal stream
+ * (i mod n_streams), in index order per stream, by one host thread per stream — a bin is ~16 launches, so hundreds of
+ * small bins are bound by the host's launch rate unless several threads submit (KMC's default is 512 bins per run,
+ * kmc.h n_bins). n_streams <= 0 picks the default (8), capped at kmc_hip_num_slots(). Returns after enqueueing;
+ * kmc_hip_synchronize(dev) waits and reports deferred device errors. Output buffers of all bins must be distinct.
+ * Replaces: the hand-out of bins to n_sorters CWKmerBinSorter threads (kmc.h:1576-1584, queues.h:2087-2128). */
+typedef struct kmc_hip_bin_desc {
+	const uint8_t *d_superkmers;
+	uint64_t size, n_rec;
+	const uint64_t *d_pack_start;
+	uint64_t n_packs;
+	uint8_t *d_out;
+	uint64_t out_capacity;
+	uint64_t *d_out_bytes, *d_lut, *d_stats;
+} kmc_hip_bin_desc;
+int kmc_hip_process_bins_device(kmc_hip_ctx *ctx, int dev, const kmc_hip_bin_params *params, const kmc_hip_bin_desc *bins,
+                                uint64_t n_bins, int n_streams);
 
 /* ---- end-of-run tallies ---------------------------------------------------------------------- */
 
@@ -143,8 +167,10 @@ int kmc_hip_allreduce_stats(kmc_hip_ctx *ctx, uint64_t *per_dev_stats);
  * [3]=radix scatter passes, [4]=compact, [5]=total enqueue->done; measured with hipEvents on the bin's stream.
  * Replaces: USE_TIMERS / MEASURE_TIMES compile-time probes (raduls_impl.h:30,567-657). */
 int kmc_hip_last_timings(kmc_hip_ctx *ctx, int dev, float ms[6]);
-/* Number of radix scatter launches and their summed duration for the last bin (roofline input for bench.py). */
-int kmc_hip_last_scatter_stats(kmc_hip_ctx *ctx, int dev, uint32_t *n_launches, float *total_ms, uint64_t *keys_per_launch /* average records per launch */);
+/* Radix scatter (k_onesweep) launches of every bin completed on `dev` since the last reset: how many, their summed
+ * duration (HIP events around each launch, on the launch's own stream) and the records they moved — the roofline
+ * input of bench.py. Waits for the device's streams. */
+int kmc_hip_scatter_totals(kmc_hip_ctx *ctx, int dev, int reset, uint64_t *n_launches, double *total_ms, uint64_t *total_records);
 /* Device memory helpers so non-HIP callers (ctypes tests, the C++ worker) need not link HIP themselves. */
 int kmc_hip_malloc(kmc_hip_ctx *ctx, int dev, uint64_t bytes, void **d_ptr);
 int kmc_hip_free(kmc_hip_ctx *ctx, int dev, void *d_ptr);
@@ -152,6 +178,8 @@ int kmc_hip_memcpy_h2d(kmc_hip_ctx *ctx, int dev, void *d_dst, const void *src, 
 int kmc_hip_memcpy_d2h(kmc_hip_ctx *ctx, int dev, void *dst, const void *d_src, uint64_t bytes);
 int kmc_hip_host_register(kmc_hip_ctx *ctx, void *ptr, uint64_t bytes);   /* pin the caller's arena (CMemoryBins buffer) */
 int kmc_hip_host_unregister(kmc_hip_ctx *ctx, void *ptr);
+int kmc_hip_host_alloc(kmc_hip_ctx *ctx, uint64_t bytes, void **ptr);      /* pinned host memory (hipHostMalloc) for _submit/_wait callers */
+int kmc_hip_host_free(kmc_hip_ctx *ctx, void *ptr);
 int kmc_hip_synchronize(kmc_hip_ctx *ctx, int dev);
 
 /* ---- stage-isolating test hooks (not used by the worker): run only index+expand, or only compaction ---- */

@@ -38,6 +38,23 @@ class BinParams(C.Structure):
     ]
 
 
+class BinDesc(C.Structure):
+    """struct kmc_hip_bin_desc: one device-resident bin of kmc_hip_process_bins_device."""
+
+    _fields_ = [
+        ("d_superkmers", C.c_void_p),
+        ("size", C.c_uint64),
+        ("n_rec", C.c_uint64),
+        ("d_pack_start", C.c_void_p),
+        ("n_packs", C.c_uint64),
+        ("d_out", C.c_void_p),
+        ("out_capacity", C.c_uint64),
+        ("d_out_bytes", C.c_void_p),
+        ("d_lut", C.c_void_p),
+        ("d_stats", C.c_void_p),
+    ]
+
+
 def make_params(k, both_strands=1, cutoff_min=2, cutoff_max=10**9, counter_max=255, lut_prefix_len=3, output_type=0,
                 without_output=0) -> BinParams:
     return BinParams(k, both_strands, cutoff_min, without_output, cutoff_max, counter_max, lut_prefix_len, output_type)
@@ -46,12 +63,14 @@ def make_params(k, both_strands=1, cutoff_min=2, cutoff_max=10**9, counter_max=2
 # every symbol include/kmc_hip.h declares (tests check the library exports them all)
 SYMBOLS = [
     "kmc_hip_init", "kmc_hip_destroy", "kmc_hip_last_error", "kmc_hip_abi_version", "kmc_hip_num_devices", "kmc_hip_num_slots",
+    "kmc_hip_device_count",
     "kmc_hip_words", "kmc_hip_counter_size", "kmc_hip_out_rec_bytes", "kmc_hip_lut_entries",
-    "kmc_hip_sort_records", "kmc_hip_sort_records_device",
+    "kmc_hip_sort_records", "kmc_hip_sort_records_into", "kmc_hip_sort_records_device",
     "kmc_hip_process_bin", "kmc_hip_process_bin_submit", "kmc_hip_process_bin_wait", "kmc_hip_process_bin_device",
-    "kmc_hip_allreduce_stats", "kmc_hip_last_timings", "kmc_hip_last_scatter_stats",
+    "kmc_hip_process_bins_device",
+    "kmc_hip_allreduce_stats", "kmc_hip_last_timings", "kmc_hip_scatter_totals",
     "kmc_hip_malloc", "kmc_hip_free", "kmc_hip_memcpy_h2d", "kmc_hip_memcpy_d2h",
-    "kmc_hip_host_register", "kmc_hip_host_unregister", "kmc_hip_synchronize",
+    "kmc_hip_host_register", "kmc_hip_host_unregister", "kmc_hip_host_alloc", "kmc_hip_host_free", "kmc_hip_synchronize",
     "kmc_hip_debug_expand", "kmc_hip_debug_compact",
 ]
 
@@ -88,6 +107,7 @@ def load():
     L.kmc_hip_lut_entries.argtypes = [C.POINTER(BinParams)]
     L.kmc_hip_lut_entries.restype = C.c_uint64
     L.kmc_hip_sort_records.argtypes = [vp, C.c_int, vp, C.c_uint64, C.c_uint32, C.c_uint32]
+    L.kmc_hip_sort_records_into.argtypes = [vp, C.c_int, vp, vp, C.c_uint64, C.c_uint32, C.c_uint32]
     L.kmc_hip_sort_records_device.argtypes = [vp, C.c_int, vp, vp, C.c_uint64, C.c_uint32, C.c_uint32, C.POINTER(vp)]
     L.kmc_hip_process_bin.argtypes = [vp, C.c_int, C.POINTER(BinParams), vp, C.c_uint64, C.c_uint64, vp, C.c_uint64, vp, C.c_uint64,
                                       u64p, vp, u64p]
@@ -98,7 +118,10 @@ def load():
                                              C.c_uint64, vp, vp, vp, C.c_int]
     L.kmc_hip_allreduce_stats.argtypes = [vp, u64p]
     L.kmc_hip_last_timings.argtypes = [vp, C.c_int, C.POINTER(C.c_float)]
-    L.kmc_hip_last_scatter_stats.argtypes = [vp, C.c_int, C.POINTER(C.c_uint32), C.POINTER(C.c_float), u64p]
+    L.kmc_hip_scatter_totals.argtypes = [vp, C.c_int, C.c_int, u64p, C.POINTER(C.c_double), u64p]
+    L.kmc_hip_process_bins_device.argtypes = [vp, C.c_int, C.POINTER(BinParams), C.POINTER(BinDesc), C.c_uint64, C.c_int]
+    L.kmc_hip_host_alloc.argtypes = [vp, C.c_uint64, C.POINTER(vp)]
+    L.kmc_hip_host_free.argtypes = [vp, vp]
     L.kmc_hip_malloc.argtypes = [vp, C.c_int, C.c_uint64, C.POINTER(vp)]
     L.kmc_hip_free.argtypes = [vp, C.c_int, vp]
     L.kmc_hip_memcpy_h2d.argtypes = [vp, C.c_int, vp, vp, C.c_uint64]
@@ -239,10 +262,28 @@ class Context:
         self._chk(self.L.kmc_hip_last_timings(self.h, dev, ms))
         return dict(zip(("index", "expand", "hist", "scatter", "compact", "total"), [float(x) for x in ms]))
 
-    def last_scatter_stats(self, dev: int = 0):
-        n, t, k = C.c_uint32(), C.c_float(), C.c_uint64()
-        self._chk(self.L.kmc_hip_last_scatter_stats(self.h, dev, C.byref(n), C.byref(t), C.byref(k)))
+    def scatter_totals(self, reset: bool = True, dev: int = 0):
+        """(launches, summed ms, records moved) of all k_onesweep launches completed on `dev` since the last reset."""
+        n, t, k = C.c_uint64(), C.c_double(), C.c_uint64()
+        self._chk(self.L.kmc_hip_scatter_totals(self.h, dev, 1 if reset else 0, C.byref(n), C.byref(t), C.byref(k)))
         return n.value, t.value, k.value
+
+    def process_bins_device(self, p: BinParams, descs, n_streams: int = 0, dev: int = 0):
+        """Enqueue many device-resident bins (ctypes array of BinDesc); returns after enqueueing — call synchronize()."""
+        self._chk(self.L.kmc_hip_process_bins_device(self.h, dev, C.byref(p), descs, len(descs), n_streams))
+
+    def host_alloc(self, nbytes: int) -> np.ndarray:
+        """Pinned host memory as a uint8 array (free with host_free(arr))."""
+        p = C.c_void_p()
+        self._chk(self.L.kmc_hip_host_alloc(self.h, nbytes, C.byref(p)))
+        a = np.ctypeslib.as_array(C.cast(p, u8p), shape=(max(nbytes, 1),))
+        return a
+
+    def host_free(self, arr: np.ndarray):
+        self._chk(self.L.kmc_hip_host_free(self.h, C.c_void_p(arr.ctypes.data)))
+
+    def device_count(self) -> int:
+        return self.L.kmc_hip_device_count()
 
     def allreduce_stats(self, per_dev: np.ndarray) -> np.ndarray:
         a = np.ascontiguousarray(per_dev, dtype=np.uint64).copy()

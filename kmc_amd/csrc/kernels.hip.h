@@ -357,6 +357,7 @@ __global__ void __launch_bounds__(256) k_parse_packs(const uint8_t *__restrict__
 #ifndef EXP_KWIN_KMERS
 #define EXP_KWIN_KMERS 8192
 #endif
+constexpr u32 EXP_FUSE_MAX_PASS = 16; /* the sort's histograms are fused into the expansion up to this many passes (k <= 64) */
 constexpr int EXP_CHUNK = EXP_CHUNK_BYTES, EXP_TAIL = 160, EXP_MAX_SK = EXP_CHUNK / 2, EXP_KWIN = EXP_KWIN_KMERS, EXP_BLOCK = EXP_BLOCK_THREADS;
 
 template <int SIZE, bool FUSE_HIST>
@@ -1295,30 +1296,29 @@ __global__ void __launch_bounds__(CP_BLOCK, CP_MIN_WAVES) k_compact(const u64 *_
 	}
 }
 
-/* lut[i] = sum over shards */
-__global__ void __launch_bounds__(256) k_lut_reduce(const u64 *__restrict__ shards, u32 n_shards, u64 entries, u64 *__restrict__ lut)
+/* End of a bin, one launch: block b sums LUT entries [256 b, 256 b + 256) over the shards (when the LUT was sharded);
+ * wave 0 of block 0 also folds the tally shards: stats[0..2] = sums, stats[3] = n_total = n_rec (kb_sorter.h:1166). */
+__global__ void __launch_bounds__(256) k_finish(const u64 *__restrict__ stat_shards, u64 *__restrict__ stats, u64 n,
+                                                const u64 *__restrict__ lut_shards, u32 n_shards, u64 entries, u64 *__restrict__ lut)
 {
 	const u64 i = (u64)blockIdx.x * 256 + threadIdx.x;
-	if (i >= entries)
-		return;
-	u64 v = 0;
-	for (u32 sidx = 0; sidx < n_shards; ++sidx)
-		v += shards[(size_t)sidx * entries + i];
-	lut[i] = v;
-}
-
-/* stats[0..2] = sum of the shards; stats[3] = n_total = n_rec (kb_sorter.h:1166) */
-__global__ void __launch_bounds__(64) k_stats_reduce(const u64 *__restrict__ shards, u64 *__restrict__ stats, u64 n)
-{
-	const u32 lane = threadIdx.x;
-	for (int j = 0; j < 3; ++j) {
-		u64 v = lane < CP_SHARDS ? shards[lane * 4 + j] : 0;
-		v = wave_sum<u64>(v);
-		if (lane == 0)
-			stats[j] = v;
+	if (i < entries) {
+		u64 v = 0;
+		for (u32 sidx = 0; sidx < n_shards; ++sidx)
+			v += lut_shards[(size_t)sidx * entries + i];
+		lut[i] = v;
 	}
-	if (lane == 0)
-		stats[3] = n;
+	if (blockIdx.x == 0 && threadIdx.x < 64) {
+		const u32 lane = threadIdx.x;
+		for (int j = 0; j < 3; ++j) {
+			u64 v = lane < CP_SHARDS ? stat_shards[lane * 4 + j] : 0;
+			v = wave_sum<u64>(v);
+			if (lane == 0)
+				stats[j] = v;
+		}
+		if (lane == 0)
+			stats[3] = n;
+	}
 }
 
 #endif

@@ -1,7 +1,8 @@
 /*
  * kmc_amd/csrc/kmc_hip.hip — host side of libkmc_hip.so: the C-ABI of include/kmc_hip.h over the gfx950
- * kernels in kernels.hip.h. One context owns, per device, two "slots" (stream + grow-only HBM buffers), so the
- * C++ worker can keep two bins in flight (H2D of bin i+1 under the kernels of bin i).
+ * kernels in kernels.hip.h. One context owns, per device, N_SLOTS "slots" (stream + grow-only HBM buffers), so
+ * callers can keep several bins in flight (H2D of one bin under the kernels of another; small bins fill each other's
+ * launch gaps).
  *
  * Reference mapping: this file plays the role of CKmerBinSorter<SIZE>::ProcessBins' body
  * (kmc_core/kb_sorter.h:210-237): Expand -> Sort -> Compact for one bin, but as a queue of kernels on a
@@ -14,8 +15,10 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <memory>
 #include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/kmc_hip.h"
@@ -62,11 +65,11 @@ int ensure(DBuf &b, size_t bytes)
 	return 0;
 }
 
-/* layout of the per-slot "small" device block (bytes) */
+/* layout of the per-slot "small" device block (bytes); cleared at the start of every bin */
 constexpr size_t SM_TOTALS = 0;      /* u64[2]  #super-k-mers, #k-mers   */
 constexpr size_t SM_STATS = 16;      /* u64[4]                           */
 constexpr size_t SM_OUTBYTES = 48;   /* u64                              */
-constexpr size_t SM_ERR = 56;        /* u32                              */
+constexpr size_t SM_ERR = 56;        /* u32: copy of the slot's sticky error word, taken when a host-boundary bin ends */
 constexpr size_t SM_DBASE_WORK = 256; /* u64[2][256] per-portion digit bases (ping-pong) */
 constexpr size_t SM_SHARDS = 256 + 2 * 256 * 8;   /* u64[CP_SHARDS][4] tally shards of the compaction */
 constexpr size_t SM_COUNTERS = SM_SHARDS + CP_SHARDS * 4 * 8; /* u32[N_COUNTERS] ticket counters, one per launch */
@@ -74,13 +77,15 @@ constexpr size_t N_COUNTERS = 4096;
 constexpr size_t SM_BYTES = SM_COUNTERS + N_COUNTERS * 4;
 
 #ifndef KMC_N_SLOTS
-#define KMC_N_SLOTS 8 /* 512 bins of 3.2 M k-mers: 1 slot 237 ms, 2 slots 133, 4 slots 104, 8 slots 95 (then the host launch rate binds) */
+#define KMC_N_SLOTS 16 /* 512 bins of 3.2 M k-mers, device resident: 1 stream 237 ms, 2: 133, 4: 104, 8: 95 (then the host launch rate
+                        * binds); the stage-2 worker spreads up to 16 sorter threads over them */
 #endif
 constexpr int N_SLOTS = KMC_N_SLOTS;
+constexpr int N_BATCH_STREAMS = 8; /* default fan-out of kmc_hip_process_bins_device */
 constexpr u64 PORTION_MAX = 1ull << 29; /* records per scatter launch (30-bit look-back counts) */
-/* Tests shrink the portion ($KMC_HIP_DEBUG_PORTION_LOG2, 10..29, read at kmc_hip_init) so that a small, oracle-checkable sort
- * crosses many portion boundaries (digit bases carried from launch to launch) — the path a bin of > 2^29 k-mers takes. */
-static u64 PORTION = PORTION_MAX;
+/* Tests shrink the portion ($KMC_HIP_DEBUG_PORTION_LOG2, 10..29, read at kmc_hip_init, kept per context) so that a small,
+ * oracle-checkable sort crosses many portion boundaries (digit bases carried from launch to launch) — the path a bin of
+ * more than 2^29 k-mers takes. */
 
 struct HostRes {
 	u64 totals[2];
@@ -90,15 +95,28 @@ struct HostRes {
 	u32 pad;
 };
 
+/* Everything a bin needs zeroed on the device lies in ONE region (one memset per bin instead of ~14: with 512 small bins
+ * per run the host launch rate is what binds): start bitmap | expand look-back words | digit histograms | compaction
+ * look-back words | one scatter status area per onesweep launch. Offsets are 256-byte aligned. */
+struct ZeroPlan {
+	size_t bitmap = 0, exp_status = 0, ghist = 0, cp_status = 0, sc_status = 0, sc_stride = 0, total = 0;
+};
+inline size_t up256(size_t x) { return (x + 255) & ~(size_t)255; }
+
 struct Slot {
 	hipStream_t stream = nullptr;
-	DBuf in, pack_start, bitmap;
-	DBuf recA, recB, ghist, dbase, status, out, lut, lutsh, small;
+	std::mutex mtx; /* serialises enqueueing on this slot (asynchronous device-resident calls may come from several threads) */
+	u64 portion = PORTION_MAX;
+	DBuf in, pack_start;
+	DBuf recA, recB, zero, dbase, out, lut, lutsh, small, sticky;
 	HostRes *h_res = nullptr; /* pinned */
 	hipEvent_t ev[6] = {};
+	/* one event pair per scatter launch since the last harvest (roofline input) */
 	std::vector<hipEvent_t> sc_ev;
+	std::vector<u32> sc_cnt;
 	u32 sc_used = 0;
-	u64 sc_keys = 0;
+	double sc_ms_total = 0;
+	u64 sc_keys_total = 0, sc_launch_total = 0;
 	bool timed = false;
 	/* pending async bin */
 	bool pending = false;
@@ -111,8 +129,9 @@ struct Slot {
 
 struct Dev {
 	int ordinal = 0;
-	u32 rr = 0; /* round-robin slot choice of asynchronous device-resident calls */
-	Slot slot[N_SLOTS]; /* [0],[1]: the submit/wait slots of the host-buffer API; all of them: round-robin for async device-resident calls */
+	u32 rr = 0; /* round-robin slot choice of asynchronous device-resident calls (under rr_mtx) */
+	std::mutex rr_mtx;
+	Slot slot[N_SLOTS];
 	DBuf rccl_buf;
 };
 
@@ -121,9 +140,10 @@ u32 counter_bytes(u64 cutoff_max, u64 counter_max) { return kmc_counter_bytes(cu
 } // namespace
 
 struct kmc_hip_ctx {
-	std::vector<Dev> devs;
+	std::vector<std::unique_ptr<Dev>> devs;
 	std::vector<ncclComm_t> comms;
 	bool comms_ready = false;
+	u64 portion = PORTION_MAX;
 	std::mutex mtx;
 };
 
@@ -133,12 +153,33 @@ int set_dev(kmc_hip_ctx *ctx, int dev)
 {
 	if (!ctx || dev < 0 || dev >= (int)ctx->devs.size())
 		return fail(KMC_HIP_EINVAL, "bad ctx/dev");
-	HIPCHK(hipSetDevice(ctx->devs[dev].ordinal));
+	HIPCHK(hipSetDevice(ctx->devs[dev]->ordinal));
 	return 0;
 }
 
-int slot_init(Slot &s)
+/* Kernels that want more than 64 KiB of dynamic LDS must opt in, per device (the attribute belongs to the device's copy of
+ * the function): k_onesweep<SIZE> for SIZE >= 6 (k > 160), the histogram-fusing k_expand at 16 passes (k = 61..64). */
+template <int SIZE> int set_func_attrs()
 {
+	if (rs_lds_bytes<SIZE>() > 65536)
+		HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_onesweep<SIZE>), hipFuncAttributeMaxDynamicSharedMemorySize,
+		                           (int)rs_lds_bytes<SIZE>()));
+	if (exp_lds_bytes<true>(EXP_FUSE_MAX_PASS) > 65536)
+		HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_expand<SIZE, true>), hipFuncAttributeMaxDynamicSharedMemorySize,
+		                           (int)exp_lds_bytes<true>(EXP_FUSE_MAX_PASS)));
+	return 0;
+}
+int set_all_func_attrs()
+{
+	int rc = 0;
+	(void)((rc = set_func_attrs<1>()) || (rc = set_func_attrs<2>()) || (rc = set_func_attrs<3>()) || (rc = set_func_attrs<4>()) ||
+	       (rc = set_func_attrs<5>()) || (rc = set_func_attrs<6>()) || (rc = set_func_attrs<7>()) || (rc = set_func_attrs<8>()));
+	return rc;
+}
+
+int slot_init(Slot &s, u64 portion)
+{
+	s.portion = portion;
 	HIPCHK(hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking));
 	HIPCHK(hipHostMalloc((void **)&s.h_res, sizeof(HostRes), hipHostMallocDefault));
 	memset(s.h_res, 0, sizeof(HostRes));
@@ -146,12 +187,15 @@ int slot_init(Slot &s)
 		HIPCHK(hipEventCreate(&e));
 	if (int rc = ensure(s.small, SM_BYTES))
 		return rc;
+	if (int rc = ensure(s.sticky, 256))
+		return rc;
+	HIPCHK(hipMemset(s.sticky.p, 0, 256));
 	return 0;
 }
 
 void slot_destroy(Slot &s)
 {
-	for (DBuf *b : {&s.in, &s.pack_start, &s.bitmap, &s.recA, &s.recB, &s.ghist, &s.dbase, &s.status, &s.out, &s.lut, &s.lutsh, &s.small})
+	for (DBuf *b : {&s.in, &s.pack_start, &s.recA, &s.recB, &s.zero, &s.dbase, &s.out, &s.lut, &s.lutsh, &s.small, &s.sticky})
 		if (b->p)
 			(void)hipFree(b->p);
 	if (s.h_res)
@@ -166,50 +210,105 @@ void slot_destroy(Slot &s)
 }
 
 template <typename T> T *small_ptr(Slot &s, size_t off) { return reinterpret_cast<T *>(static_cast<char *>(s.small.p) + off); }
+template <typename T> T *zero_ptr(Slot &s, size_t off) { return reinterpret_cast<T *>(static_cast<char *>(s.zero.p) + off); }
+u32 *err_ptr(Slot &s) { return static_cast<u32 *>(s.sticky.p); }
 
-int sc_event(Slot &s, hipEvent_t &e)
+int sc_event_pair(Slot &s, hipEvent_t &e0, hipEvent_t &e1, u32 cnt)
 {
-	if (s.sc_used == s.sc_ev.size()) {
+	while (s.sc_ev.size() < (size_t)s.sc_used + 2) {
 		hipEvent_t ne;
 		HIPCHK(hipEventCreate(&ne));
 		s.sc_ev.push_back(ne);
 	}
-	e = s.sc_ev[s.sc_used++];
+	e0 = s.sc_ev[s.sc_used];
+	e1 = s.sc_ev[s.sc_used + 1];
+	s.sc_used += 2;
+	s.sc_cnt.push_back(cnt);
+	return 0;
+}
+
+/* after the slot's stream is idle: fold the recorded scatter launches into the slot's totals */
+int harvest(Slot &s)
+{
+	for (u32 i = 0; i + 1 < s.sc_used; i += 2) {
+		float t = 0;
+		HIPCHK(hipEventElapsedTime(&t, s.sc_ev[i], s.sc_ev[i + 1]));
+		s.sc_ms_total += t;
+		s.sc_keys_total += s.sc_cnt[i / 2];
+		++s.sc_launch_total;
+	}
+	s.sc_used = 0;
+	s.sc_cnt.clear();
+	return 0;
+}
+
+/* the slot's sticky device error word: kernels OR into it, nothing on the per-bin path clears it, so an error raised by an
+ * earlier asynchronous bin on this slot survives until somebody looks (kmc_hip_synchronize, a synchronous call, _wait) */
+int read_and_clear_sticky(Slot &s, u32 &err)
+{
+	HIPCHK(hipMemcpy(&err, s.sticky.p, 4, hipMemcpyDeviceToHost));
+	if (err)
+		HIPCHK(hipMemset(s.sticky.p, 0, 4));
+	return 0;
+}
+
+/* ---- zero-region planning --------------------------------------------------------------------------------------- */
+template <int SIZE> ZeroPlan make_plan(const Slot &s, u64 size, u64 n_rec, u32 n_pass, bool front, bool sort, bool compact)
+{
+	ZeroPlan z;
+	size_t off = 0;
+	if (front) {
+		z.bitmap = off;
+		off += up256(((size + 31) / 32 + 2) * 4);
+		z.exp_status = off;
+		off += up256(((size + EXP_CHUNK - 1) / EXP_CHUNK) * 8 + 8);
+	}
+	if (front || sort) {
+		z.ghist = off;
+		off += up256((size_t)n_pass * 256 * 8);
+	}
+	if (compact) {
+		z.cp_status = off;
+		off += up256(((n_rec + CpCfg<SIZE>::TILE - 1) / CpCfg<SIZE>::TILE) * 8 + 8);
+	}
+	if (sort && n_rec >= 2) {
+		const u64 max_tiles = (std::min(n_rec, s.portion) + RsCfg<SIZE>::TILE - 1) / RsCfg<SIZE>::TILE;
+		const u64 n_launch = (u64)n_pass * ((n_rec + s.portion - 1) / s.portion);
+		z.sc_status = off;
+		z.sc_stride = up256((size_t)max_tiles * 256 * 4);
+		off += z.sc_stride * n_launch;
+	}
+	z.total = off;
+	return z;
+}
+
+int apply_plan(Slot &s, const ZeroPlan &z)
+{
+	if (!z.total)
+		return 0;
+	if (int rc = ensure(s.zero, z.total))
+		return rc;
+	HIPCHK(hipMemsetAsync(s.zero.p, 0, z.total, s.stream));
 	return 0;
 }
 
 /* ---- the sort: histogram of every digit + n_pass onesweep launches (per portion) --------------------------- */
 template <int SIZE>
-int sort_device_t(Slot &s, u64 *d_recs, u64 *d_tmp, u64 n, u32 n_pass, u64 **d_result, u32 &counter_idx, bool hist_done = false)
+int sort_device_t(Slot &s, const ZeroPlan &z, u64 *d_recs, u64 *d_tmp, u64 n, u32 n_pass, u64 **d_result, u32 &counter_idx, bool hist_done)
 {
 	u64 *src = d_recs, *dst = d_tmp;
 	if (n < 2 || n_pass == 0) {
 		*d_result = src;
 		return 0;
 	}
-	if (int rc = ensure(s.ghist, (size_t)n_pass * 256 * 8))
-		return rc;
 	if (int rc = ensure(s.dbase, (size_t)n_pass * 256 * 8))
 		return rc;
-	const u64 max_tiles = (std::min(n, PORTION) + RsCfg<SIZE>::TILE - 1) / RsCfg<SIZE>::TILE;
-	if (int rc = ensure(s.status, (size_t)max_tiles * 256 * 4))
-		return rc;
-	u64 *ghist = (u64 *)s.ghist.p, *dbase = (u64 *)s.dbase.p;
-	u32 *status = (u32 *)s.status.p;
-	u32 *err = small_ptr<u32>(s, SM_ERR);
+	u64 *ghist = zero_ptr<u64>(s, z.ghist), *dbase = (u64 *)s.dbase.p;
+	u32 *err = err_ptr(s);
 	u32 *counters = small_ptr<u32>(s, SM_COUNTERS);
 	u64 *work = small_ptr<u64>(s, SM_DBASE_WORK);
 
-	if (rs_lds_bytes<SIZE>() > 65536) {
-		static bool attr_done = false; /* per instantiation */
-		if (!attr_done) {
-			HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_onesweep<SIZE>), hipFuncAttributeMaxDynamicSharedMemorySize,
-			                           (int)rs_lds_bytes<SIZE>()));
-			attr_done = true;
-		}
-	}
 	if (!hist_done) {
-		HIPCHK(hipMemsetAsync(ghist, 0, (size_t)n_pass * 256 * 8, s.stream));
 		u64 blocks = (n + 255) / 256;
 		if (blocks > 256 * 8)
 			blocks = 256 * 8; /* 8 workgroups per CU, grid-stride */
@@ -218,21 +317,20 @@ int sort_device_t(Slot &s, u64 *d_recs, u64 *d_tmp, u64 n, u32 n_pass, u64 **d_r
 	k_hist_scan<<<dim3(n_pass), dim3(256), 0, s.stream>>>(ghist, dbase);
 	if (s.timed)
 		HIPCHK(hipEventRecord(s.ev[3], s.stream));
+	u32 launch = 0;
 	for (u32 pass = 0; pass < n_pass; ++pass) {
 		const u64 *base_in = dbase + (size_t)pass * 256;
 		int flip = 0;
-		for (u64 start = 0; start < n; start += PORTION) {
-			const u32 cnt = (u32)std::min(PORTION, n - start);
+		for (u64 start = 0; start < n; start += s.portion) {
+			const u32 cnt = (u32)std::min(s.portion, n - start);
 			const u32 tiles = (cnt + RsCfg<SIZE>::TILE - 1) / RsCfg<SIZE>::TILE;
 			if (counter_idx >= N_COUNTERS)
 				return fail(KMC_HIP_EINVAL, "too many scatter launches for one bin");
-			HIPCHK(hipMemsetAsync(status, 0, (size_t)tiles * 256 * 4, s.stream));
+			u32 *status = zero_ptr<u32>(s, z.sc_status + (size_t)launch * z.sc_stride);
 			u64 *base_out = work + (size_t)flip * 256;
 			hipEvent_t e0 = nullptr, e1 = nullptr;
 			if (s.timed) {
-				if (int rc = sc_event(s, e0))
-					return rc;
-				if (int rc = sc_event(s, e1))
+				if (int rc = sc_event_pair(s, e0, e1, cnt))
 					return rc;
 				HIPCHK(hipEventRecord(e0, s.stream));
 			}
@@ -241,7 +339,7 @@ int sort_device_t(Slot &s, u64 *d_recs, u64 *d_tmp, u64 n, u32 n_pass, u64 **d_r
 			if (s.timed)
 				HIPCHK(hipEventRecord(e1, s.stream));
 			++counter_idx;
-			s.sc_keys += cnt;
+			++launch;
 			base_in = base_out;
 			flip ^= 1;
 		}
@@ -252,17 +350,26 @@ int sort_device_t(Slot &s, u64 *d_recs, u64 *d_tmp, u64 n, u32 n_pass, u64 **d_r
 	return 0;
 }
 
-int sort_device(Slot &s, u64 *d_recs, u64 *d_tmp, u64 n, u32 words, u32 n_pass, u64 **d_result, u32 &counter_idx)
+template <int SIZE> int sort_only_t(Slot &s, u64 *d_recs, u64 *d_tmp, u64 n, u32 n_pass, u64 **d_result)
+{
+	const ZeroPlan z = make_plan<SIZE>(s, 0, n, n_pass, false, true, false);
+	if (int rc = apply_plan(s, z))
+		return rc;
+	u32 counter_idx = 0;
+	return sort_device_t<SIZE>(s, z, d_recs, d_tmp, n, n_pass, d_result, counter_idx, false);
+}
+
+int sort_device(Slot &s, u64 *d_recs, u64 *d_tmp, u64 n, u32 words, u32 n_pass, u64 **d_result)
 {
 	switch (words) {
-	case 1: return sort_device_t<1>(s, d_recs, d_tmp, n, n_pass, d_result, counter_idx);
-	case 2: return sort_device_t<2>(s, d_recs, d_tmp, n, n_pass, d_result, counter_idx);
-	case 3: return sort_device_t<3>(s, d_recs, d_tmp, n, n_pass, d_result, counter_idx);
-	case 4: return sort_device_t<4>(s, d_recs, d_tmp, n, n_pass, d_result, counter_idx);
-	case 5: return sort_device_t<5>(s, d_recs, d_tmp, n, n_pass, d_result, counter_idx);
-	case 6: return sort_device_t<6>(s, d_recs, d_tmp, n, n_pass, d_result, counter_idx);
-	case 7: return sort_device_t<7>(s, d_recs, d_tmp, n, n_pass, d_result, counter_idx);
-	case 8: return sort_device_t<8>(s, d_recs, d_tmp, n, n_pass, d_result, counter_idx);
+	case 1: return sort_only_t<1>(s, d_recs, d_tmp, n, n_pass, d_result);
+	case 2: return sort_only_t<2>(s, d_recs, d_tmp, n, n_pass, d_result);
+	case 3: return sort_only_t<3>(s, d_recs, d_tmp, n, n_pass, d_result);
+	case 4: return sort_only_t<4>(s, d_recs, d_tmp, n, n_pass, d_result);
+	case 5: return sort_only_t<5>(s, d_recs, d_tmp, n, n_pass, d_result);
+	case 6: return sort_only_t<6>(s, d_recs, d_tmp, n, n_pass, d_result);
+	case 7: return sort_only_t<7>(s, d_recs, d_tmp, n, n_pass, d_result);
+	case 8: return sort_only_t<8>(s, d_recs, d_tmp, n, n_pass, d_result);
 	}
 	return fail(KMC_HIP_EINVAL, "words must be 1..8");
 }
@@ -296,35 +403,28 @@ int check_params(const kmc_hip_bin_params *p, DevParams &P)
 
 /* ---- front end: mark super-k-mer starts (per pack), then expand slice-parallel with the sort's histograms fused in ---- */
 template <int SIZE>
-int front_end(Slot &s, const DevParams &P, const uint8_t *d_in, u64 size, u64 n_rec, const u64 *d_pack_start, u64 n_packs, u32 n_pass,
-              u32 &counter_idx, bool &hist_done)
+int front_end(Slot &s, const ZeroPlan &z, const DevParams &P, const uint8_t *d_in, u64 size, u64 n_rec, const u64 *d_pack_start, u64 n_packs,
+              u32 n_pass, u32 &counter_idx, bool &hist_done)
 {
-	u32 *err = small_ptr<u32>(s, SM_ERR);
+	u32 *err = err_ptr(s);
 	u32 *counters = small_ptr<u32>(s, SM_COUNTERS);
-	const u64 bm_words = (size + 31) / 32 + 2;
 	const u64 n_chunks = (size + EXP_CHUNK - 1) / EXP_CHUNK;
 	if (n_chunks > 0x7FFFFFF0ull || n_packs > 0x7FFFFFF0ull)
 		return fail(KMC_HIP_EINVAL, "bin too large");
-	int rc = 0;
-	if ((rc = ensure(s.bitmap, bm_words * 4)) || (rc = ensure(s.status, n_chunks * 8)) || (rc = ensure(s.ghist, (size_t)n_pass * 256 * 8)))
-		return rc;
-	HIPCHK(hipMemsetAsync(s.bitmap.p, 0, bm_words * 4, s.stream));
-	HIPCHK(hipMemsetAsync(s.status.p, 0, n_chunks * 8, s.stream));
-	k_parse_packs<<<dim3((u32)n_packs), dim3(256), 0, s.stream>>>(d_in, d_pack_start, (u32)n_packs, P.k, (u32 *)s.bitmap.p, err);
+	u32 *bitmap = zero_ptr<u32>(s, z.bitmap);
+	u64 *status = zero_ptr<u64>(s, z.exp_status);
+	u64 *ghist = zero_ptr<u64>(s, z.ghist);
+	k_parse_packs<<<dim3((u32)n_packs), dim3(256), 0, s.stream>>>(d_in, d_pack_start, (u32)n_packs, P.k, bitmap, err);
 	if (s.timed)
 		HIPCHK(hipEventRecord(s.ev[1], s.stream));
-	const bool fuse = n_pass <= 16 && n_rec >= 2; /* LDS: 1 KB of counters per pass next to the 33 KB of slice state */
-	if (fuse)
-		HIPCHK(hipMemsetAsync(s.ghist.p, 0, (size_t)n_pass * 256 * 8, s.stream));
+	const bool fuse = n_pass <= EXP_FUSE_MAX_PASS && n_rec >= 2; /* LDS: 1 KB of counters per pass next to the 33 KB of slice state */
 	const u32 blocks = (u32)std::min<u64>(n_chunks, 256 * 2 * (1024 / EXP_BLOCK));
 	if (fuse)
 		k_expand<SIZE, true><<<dim3(blocks), dim3(EXP_BLOCK), exp_lds_bytes<true>(n_pass), s.stream>>>(
-		    d_in, size, (const u32 *)s.bitmap.p, P.k, P.both_strands, n_pass, n_rec, (u64 *)s.recA.p, (u64 *)s.ghist.p, (u64 *)s.status.p,
-		    counters + counter_idx, (u32)n_chunks, err);
+		    d_in, size, bitmap, P.k, P.both_strands, n_pass, n_rec, (u64 *)s.recA.p, ghist, status, counters + counter_idx, (u32)n_chunks, err);
 	else
 		k_expand<SIZE, false><<<dim3(blocks), dim3(EXP_BLOCK), exp_lds_bytes<false>(n_pass), s.stream>>>(
-		    d_in, size, (const u32 *)s.bitmap.p, P.k, P.both_strands, n_pass, n_rec, (u64 *)s.recA.p, (u64 *)s.ghist.p, (u64 *)s.status.p,
-		    counters + counter_idx, (u32)n_chunks, err);
+		    d_in, size, bitmap, P.k, P.both_strands, n_pass, n_rec, (u64 *)s.recA.p, ghist, status, counters + counter_idx, (u32)n_chunks, err);
 	++counter_idx;
 	hist_done = fuse;
 	if (s.timed)
@@ -333,12 +433,12 @@ int front_end(Slot &s, const DevParams &P, const uint8_t *d_in, u64 size, u64 n_
 	return 0;
 }
 
-/* ---- compaction launch (+ tally / LUT shard reductions) ---- */
+/* ---- compaction launch (+ tally / LUT shard reductions in one small kernel) ---- */
 template <int SIZE>
-int launch_compact(Slot &s, const u64 *sorted, u64 n, const DevParams &P, uint8_t *d_out, u64 out_capacity, u64 *d_lut, u64 lut_entries,
-                   u64 *d_stats, u64 *d_out_bytes, u32 &counter_idx)
+int launch_compact(Slot &s, const ZeroPlan &z, const u64 *sorted, u64 n, const DevParams &P, uint8_t *d_out, u64 out_capacity, u64 *d_lut,
+                   u64 lut_entries, u64 *d_stats, u64 *d_out_bytes, u32 &counter_idx)
 {
-	u32 *err = small_ptr<u32>(s, SM_ERR);
+	u32 *err = err_ptr(s);
 	u32 *counters = small_ptr<u32>(s, SM_COUNTERS);
 	const u64 c_tiles = (n + CpCfg<SIZE>::TILE - 1) / CpCfg<SIZE>::TILE;
 	if (c_tiles > 0x7FFFFFFFull)
@@ -346,8 +446,6 @@ int launch_compact(Slot &s, const u64 *sorted, u64 n, const DevParams &P, uint8_
 	if (counter_idx >= N_COUNTERS)
 		return fail(KMC_HIP_EINVAL, "too many launches for one bin");
 	int rc = 0;
-	if ((rc = ensure(s.status, c_tiles * 8)))
-		return rc;
 	const bool use_lut = lut_entries && !P.without_output && !P.kff;
 	const u32 n_sh = !use_lut ? 1u : (lut_entries <= 1024 ? 32u : (lut_entries <= 16384 ? 4u : 1u));
 	u64 *lut_base = d_lut;
@@ -356,15 +454,16 @@ int launch_compact(Slot &s, const u64 *sorted, u64 n, const DevParams &P, uint8_
 			return rc;
 		HIPCHK(hipMemsetAsync(s.lutsh.p, 0, (size_t)n_sh * lut_entries * 8, s.stream));
 		lut_base = (u64 *)s.lutsh.p;
+	} else if (use_lut) {
+		HIPCHK(hipMemsetAsync(d_lut, 0, lut_entries * 8, s.stream));
 	}
-	HIPCHK(hipMemsetAsync(s.status.p, 0, c_tiles * 8, s.stream));
 	k_compact<SIZE><<<dim3((u32)((c_tiles + CP_TPB - 1) / CP_TPB)), dim3(CP_BLOCK), 0, s.stream>>>(
-	    sorted, n, P, d_out, out_capacity, lut_base, n_sh, lut_entries, small_ptr<u64>(s, SM_SHARDS), d_out_bytes, (u64 *)s.status.p,
+	    sorted, n, P, d_out, out_capacity, lut_base, n_sh, lut_entries, small_ptr<u64>(s, SM_SHARDS), d_out_bytes, zero_ptr<u64>(s, z.cp_status),
 	    counters + counter_idx, (u32)c_tiles, err);
 	++counter_idx;
-	k_stats_reduce<<<dim3(1), dim3(64), 0, s.stream>>>(small_ptr<u64>(s, SM_SHARDS), d_stats, n);
-	if (use_lut && n_sh > 1)
-		k_lut_reduce<<<dim3((u32)((lut_entries + 255) / 256)), dim3(256), 0, s.stream>>>((const u64 *)s.lutsh.p, n_sh, lut_entries, d_lut);
+	const u64 red_entries = (use_lut && n_sh > 1) ? lut_entries : 0;
+	k_finish<<<dim3((u32)std::max<u64>(1, (red_entries + 255) / 256)), dim3(256), 0, s.stream>>>(small_ptr<u64>(s, SM_SHARDS), d_stats, n,
+	                                                                                             (const u64 *)s.lutsh.p, n_sh, red_entries, d_lut);
 	HIPCHK(hipGetLastError());
 	return 0;
 }
@@ -376,23 +475,17 @@ int run_bin_device_t(Slot &s, const DevParams &P, const uint8_t *d_in, u64 size,
 {
 	const u32 k = P.k;
 	const u32 n_pass = (2 * k + 7) / 8; /* = ceil(k/4) = rec_len of the plain k-mer path (kb_sorter.h:769) */
-	u32 *err = small_ptr<u32>(s, SM_ERR);
-	u64 *totals = small_ptr<u64>(s, SM_TOTALS);
-	u32 *counters = small_ptr<u32>(s, SM_COUNTERS);
 	u32 counter_idx = 0;
-	s.sc_used = 0;
-	s.sc_keys = 0;
 
-	HIPCHK(hipMemsetAsync(s.small.p, 0, SM_BYTES, s.stream));
-	HIPCHK(hipMemsetAsync(d_stats, 0, 4 * 8, s.stream));
-	HIPCHK(hipMemsetAsync(d_out_bytes, 0, 8, s.stream));
-	if (lut_entries && !P.without_output)
-		HIPCHK(hipMemsetAsync(d_lut, 0, lut_entries * 8, s.stream));
-	if (s.timed)
-		HIPCHK(hipEventRecord(s.ev[0], s.stream));
-	if (n_rec == 0 || size == 0) {
+	if ((n_rec == 0) != (size == 0))
+		return fail(KMC_HIP_ECORRUPT, "exactly one of size / n_rec is zero");
+	if (n_rec == 0) {
+		HIPCHK(hipMemsetAsync(d_stats, 0, 4 * 8, s.stream));
+		HIPCHK(hipMemsetAsync(d_out_bytes, 0, 8, s.stream));
+		if (lut_entries && !P.without_output)
+			HIPCHK(hipMemsetAsync(d_lut, 0, lut_entries * 8, s.stream));
 		if (s.timed)
-			for (int i = 1; i < 6; ++i)
+			for (int i = 0; i < 6; ++i)
 				HIPCHK(hipEventRecord(s.ev[i], s.stream));
 		return 0;
 	}
@@ -402,12 +495,18 @@ int run_bin_device_t(Slot &s, const DevParams &P, const uint8_t *d_in, u64 size,
 	int rc = 0;
 	if ((rc = ensure(s.recA, n_rec * SIZE * 8 + 256)) || (rc = ensure(s.recB, n_rec * SIZE * 8 + 256)))
 		return rc;
+	const ZeroPlan z = make_plan<SIZE>(s, size, n_rec, n_pass, true, true, true);
+	HIPCHK(hipMemsetAsync(s.small.p, 0, SM_BYTES, s.stream));
+	if ((rc = apply_plan(s, z)))
+		return rc;
+	if (s.timed)
+		HIPCHK(hipEventRecord(s.ev[0], s.stream));
 	bool hist_done = false;
-	if ((rc = front_end<SIZE>(s, P, d_in, size, n_rec, d_pack_start, n_packs, n_pass, counter_idx, hist_done)))
+	if ((rc = front_end<SIZE>(s, z, P, d_in, size, n_rec, d_pack_start, n_packs, n_pass, counter_idx, hist_done)))
 		return rc;
 	/* sort */
 	u64 *sorted = nullptr;
-	if ((rc = sort_device_t<SIZE>(s, (u64 *)s.recA.p, (u64 *)s.recB.p, n_rec, n_pass, &sorted, counter_idx, hist_done)))
+	if ((rc = sort_device_t<SIZE>(s, z, (u64 *)s.recA.p, (u64 *)s.recB.p, n_rec, n_pass, &sorted, counter_idx, hist_done)))
 		return rc;
 	if (s.timed) {
 		if (n_rec < 2)
@@ -415,7 +514,7 @@ int run_bin_device_t(Slot &s, const DevParams &P, const uint8_t *d_in, u64 size,
 		HIPCHK(hipEventRecord(s.ev[4], s.stream));
 	}
 	/* compact */
-	if ((rc = launch_compact<SIZE>(s, sorted, n_rec, P, d_out, out_capacity, d_lut, lut_entries, d_stats, d_out_bytes, counter_idx)))
+	if ((rc = launch_compact<SIZE>(s, z, sorted, n_rec, P, d_out, out_capacity, d_lut, lut_entries, d_stats, d_out_bytes, counter_idx)))
 		return rc;
 	if (s.timed)
 		HIPCHK(hipEventRecord(s.ev[5], s.stream));
@@ -454,6 +553,11 @@ int err_to_code(u32 err)
 	return 0;
 }
 
+/* a bin whose record arrays exceed this fills the GPU on its own: it always takes slot 0, so that not every slot it
+ * would visit keeps two arrays of that size (slot buffers only grow) */
+constexpr u64 ASYNC_BIG_BYTES = 1ull << 31;
+bool is_big(const DevParams &P, u64 n_rec) { return n_rec * (u64)((P.k + 31) / 32) * 8 * 2 > ASYNC_BIG_BYTES; }
+
 } // namespace
 
 /* ---- stage-isolating test hooks (tests/ use them to localise a parity failure to one kernel group) ---- */
@@ -464,23 +568,27 @@ int debug_expand_t(Slot &s, const DevParams &P, u64 size, u64 n_rec, u64 np)
 	int rc = 0;
 	if ((rc = ensure(s.recA, n_rec * SIZE * 8 + 256)))
 		return rc;
+	const u32 n_pass = (2 * P.k + 7) / 8;
+	const ZeroPlan z = make_plan<SIZE>(s, size, n_rec, n_pass, true, false, false);
 	HIPCHK(hipMemsetAsync(s.small.p, 0, SM_BYTES, s.stream));
+	if ((rc = apply_plan(s, z)))
+		return rc;
 	u32 counter_idx = 0;
 	bool hist_done = false;
-	return front_end<SIZE>(s, P, (const uint8_t *)s.in.p, size, n_rec, (const u64 *)s.pack_start.p, np, (2 * P.k + 7) / 8, counter_idx, hist_done);
+	return front_end<SIZE>(s, z, P, (const uint8_t *)s.in.p, size, n_rec, (const u64 *)s.pack_start.p, np, n_pass, counter_idx, hist_done);
 }
 template <int SIZE>
 int debug_compact_t(Slot &s, const DevParams &P, u64 n, u64 out_capacity, u64 lut_entries)
 {
+	const ZeroPlan z = make_plan<SIZE>(s, 0, n, 0, false, false, true);
 	HIPCHK(hipMemsetAsync(s.small.p, 0, SM_BYTES, s.stream));
-	if (lut_entries)
-		HIPCHK(hipMemsetAsync(s.lut.p, 0, lut_entries * 8, s.stream));
+	if (int rc = apply_plan(s, z))
+		return rc;
 	u32 counter_idx = 0;
-	return launch_compact<SIZE>(s, (const u64 *)s.recA.p, n, P, (uint8_t *)s.out.p, out_capacity, (u64 *)s.lut.p, lut_entries,
+	return launch_compact<SIZE>(s, z, (const u64 *)s.recA.p, n, P, (uint8_t *)s.out.p, out_capacity, (u64 *)s.lut.p, lut_entries,
 	                            small_ptr<u64>(s, SM_STATS), small_ptr<u64>(s, SM_OUTBYTES), counter_idx);
 }
 } // namespace
-
 
 /* ================================================================================================ C-ABI */
 
@@ -496,6 +604,14 @@ uint32_t kmc_hip_out_rec_bytes(const kmc_hip_bin_params *p)
 }
 uint64_t kmc_hip_lut_entries(const kmc_hip_bin_params *p) { return p->lut_prefix_len ? 1ull << (2 * p->lut_prefix_len) : 0; }
 
+int kmc_hip_device_count(void)
+{
+	int count = 0;
+	if (hipGetDeviceCount(&count) != hipSuccess)
+		return 0;
+	return count;
+}
+
 int kmc_hip_init(const int *device_ids, int n_dev, kmc_hip_ctx **out)
 {
 	if (!out || n_dev < 1)
@@ -504,28 +620,31 @@ int kmc_hip_init(const int *device_ids, int n_dev, kmc_hip_ctx **out)
 	HIPCHK(hipGetDeviceCount(&count));
 	if (count < 1)
 		return fail(KMC_HIP_EDEVICE, "no HIP device visible");
-	PORTION = PORTION_MAX;
+	kmc_hip_ctx *ctx = new kmc_hip_ctx();
 	if (const char *e = getenv("KMC_HIP_DEBUG_PORTION_LOG2")) {
 		const int lg = atoi(e);
 		if (lg >= 10 && lg <= 29)
-			PORTION = 1ull << lg;
+			ctx->portion = 1ull << lg;
 	}
-	kmc_hip_ctx *ctx = new kmc_hip_ctx();
-	ctx->devs.resize(n_dev);
 	for (int i = 0; i < n_dev; ++i) {
 		const int ord = device_ids ? device_ids[i] : i;
 		if (ord < 0 || ord >= count) {
-			delete ctx;
+			kmc_hip_destroy(ctx);
 			return fail(KMC_HIP_EINVAL, "device ordinal out of range");
 		}
-		ctx->devs[i].ordinal = ord;
+		ctx->devs.emplace_back(new Dev());
+		ctx->devs[i]->ordinal = ord;
 		hipError_t e = hipSetDevice(ord);
 		if (e != hipSuccess) {
-			delete ctx;
+			kmc_hip_destroy(ctx);
 			return fail_hip("hipSetDevice", e);
 		}
-		for (auto &s : ctx->devs[i].slot)
-			if (int rc = slot_init(s)) {
+		if (int rc = set_all_func_attrs()) {
+			kmc_hip_destroy(ctx);
+			return rc;
+		}
+		for (auto &s : ctx->devs[i]->slot)
+			if (int rc = slot_init(s, ctx->portion)) {
 				kmc_hip_destroy(ctx);
 				return rc;
 			}
@@ -539,12 +658,12 @@ void kmc_hip_destroy(kmc_hip_ctx *ctx)
 	if (!ctx)
 		return;
 	for (auto &d : ctx->devs) {
-		(void)hipSetDevice(d.ordinal);
+		(void)hipSetDevice(d->ordinal);
 		(void)hipDeviceSynchronize();
-		for (auto &s : d.slot)
+		for (auto &s : d->slot)
 			slot_destroy(s);
-		if (d.rccl_buf.p)
-			(void)hipFree(d.rccl_buf.p);
+		if (d->rccl_buf.p)
+			(void)hipFree(d->rccl_buf.p);
 	}
 	if (ctx->comms_ready)
 		for (auto &c : ctx->comms)
@@ -599,21 +718,56 @@ int kmc_hip_host_unregister(kmc_hip_ctx *ctx, void *ptr)
 	HIPCHK(hipHostUnregister(ptr));
 	return 0;
 }
+int kmc_hip_host_alloc(kmc_hip_ctx *ctx, uint64_t bytes, void **ptr)
+{
+	if (!ctx || !ptr)
+		return fail(KMC_HIP_EINVAL, "kmc_hip_host_alloc: bad arguments");
+	HIPCHK(hipHostMalloc(ptr, bytes ? bytes : 1, hipHostMallocPortable));
+	return 0;
+}
+int kmc_hip_host_free(kmc_hip_ctx *ctx, void *ptr)
+{
+	if (!ctx)
+		return fail(KMC_HIP_EINVAL, "ctx == NULL");
+	HIPCHK(hipHostFree(ptr));
+	return 0;
+}
 int kmc_hip_synchronize(kmc_hip_ctx *ctx, int dev)
 {
 	if (int rc = set_dev(ctx, dev))
 		return rc;
-	for (auto &s : ctx->devs[dev].slot)
+	u32 err = 0;
+	for (auto &s : ctx->devs[dev]->slot) {
+		std::lock_guard<std::mutex> lck(s.mtx);
 		HIPCHK(hipStreamSynchronize(s.stream));
-	u32 err = 0, e1 = 0;
-	for (auto &s : ctx->devs[dev].slot) {
-		HIPCHK(hipMemcpy(&e1, small_ptr<u32>(s, SM_ERR), 4, hipMemcpyDeviceToHost));
+		if (int rc = harvest(s))
+			return rc;
+		u32 e1 = 0;
+		if (int rc = read_and_clear_sticky(s, e1))
+			return rc;
 		err |= e1;
 	}
 	return err_to_code(err);
 }
 
 /* ---- narrow boundary ---- */
+static int sort_records_device_locked(Slot &s, void *d_recs, void *d_tmp, uint64_t n, uint32_t words, uint32_t key_bytes, void **d_result)
+{
+	s.timed = true;
+	HIPCHK(hipMemsetAsync(s.small.p, 0, SM_BYTES, s.stream));
+	u64 *res = nullptr;
+	if (int rc = sort_device(s, (u64 *)d_recs, (u64 *)d_tmp, n, words, key_bytes, &res))
+		return rc;
+	HIPCHK(hipStreamSynchronize(s.stream));
+	if (int rc = harvest(s))
+		return rc;
+	u32 err = 0;
+	if (int rc = read_and_clear_sticky(s, err))
+		return rc;
+	*d_result = res;
+	return err_to_code(err);
+}
+
 int kmc_hip_sort_records_device(kmc_hip_ctx *ctx, int dev, void *d_recs, void *d_tmp, uint64_t n, uint32_t words, uint32_t key_bytes,
                                 void **d_result)
 {
@@ -621,46 +775,67 @@ int kmc_hip_sort_records_device(kmc_hip_ctx *ctx, int dev, void *d_recs, void *d
 		return rc;
 	if (words < 1 || words > 8 || key_bytes > 8 * words || !d_result)
 		return fail(KMC_HIP_EINVAL, "kmc_hip_sort_records_device: bad arguments");
-	Slot &s = ctx->devs[dev].slot[0];
-	s.timed = true;
-	s.sc_used = 0;
-	s.sc_keys = 0;
-	HIPCHK(hipMemsetAsync(s.small.p, 0, SM_BYTES, s.stream));
-	u32 counter_idx = 0;
-	u64 *res = nullptr;
-	if (int rc = sort_device(s, (u64 *)d_recs, (u64 *)d_tmp, n, words, key_bytes, &res, counter_idx))
-		return rc;
-	HIPCHK(hipStreamSynchronize(s.stream));
-	u32 err = 0;
-	HIPCHK(hipMemcpy(&err, small_ptr<u32>(s, SM_ERR), 4, hipMemcpyDeviceToHost));
-	*d_result = res;
-	return err_to_code(err);
+	Slot &s = ctx->devs[dev]->slot[0];
+	std::lock_guard<std::mutex> lck(s.mtx);
+	return sort_records_device_locked(s, d_recs, d_tmp, n, words, key_bytes, d_result);
 }
 
-int kmc_hip_sort_records(kmc_hip_ctx *ctx, int dev, void *recs, uint64_t n, uint32_t words, uint32_t key_bytes)
+int kmc_hip_sort_records_into(kmc_hip_ctx *ctx, int dev, const void *recs, void *dst, uint64_t n, uint32_t words, uint32_t key_bytes)
 {
 	if (int rc = set_dev(ctx, dev))
 		return rc;
 	if (words < 1 || words > 8 || key_bytes > 8 * words)
 		return fail(KMC_HIP_EINVAL, "kmc_hip_sort_records: bad arguments");
-	if (n < 2)
-		return 0;
-	if (!recs)
+	if (n && (!recs || !dst))
 		return fail(KMC_HIP_EINVAL, "recs == NULL");
-	Slot &s = ctx->devs[dev].slot[0];
 	const size_t bytes = (size_t)n * words * 8;
+	if (n < 2) {
+		if (n && dst != recs)
+			memcpy(dst, recs, bytes);
+		return 0;
+	}
+	Slot &s = ctx->devs[dev]->slot[0];
+	std::lock_guard<std::mutex> lck(s.mtx); /* slot 0's record arrays are the staging area: one host sort at a time per device */
 	int rc = 0;
 	if ((rc = ensure(s.recA, bytes + 256)) || (rc = ensure(s.recB, bytes + 256)))
 		return rc;
-	HIPCHK(hipMemcpy(s.recA.p, recs, bytes, hipMemcpyHostToDevice));
+	HIPCHK(hipMemcpyAsync(s.recA.p, recs, bytes, hipMemcpyHostToDevice, s.stream));
 	void *res = nullptr;
-	if ((rc = kmc_hip_sort_records_device(ctx, dev, s.recA.p, s.recB.p, n, words, key_bytes, &res)))
+	if ((rc = sort_records_device_locked(s, s.recA.p, s.recB.p, n, words, key_bytes, &res)))
 		return rc;
-	HIPCHK(hipMemcpy(recs, res, bytes, hipMemcpyDeviceToHost));
+	HIPCHK(hipMemcpyAsync(dst, res, bytes, hipMemcpyDeviceToHost, s.stream));
+	HIPCHK(hipStreamSynchronize(s.stream));
 	return 0;
 }
 
+int kmc_hip_sort_records(kmc_hip_ctx *ctx, int dev, void *recs, uint64_t n, uint32_t words, uint32_t key_bytes)
+{
+	return kmc_hip_sort_records_into(ctx, dev, recs, recs, n, words, key_bytes);
+}
+
 /* ---- full boundary ---- */
+static int process_bin_device_on(kmc_hip_ctx *ctx, int dev, Slot &s, const DevParams &P, u64 lut_entries, const uint8_t *d_superkmers,
+                                 uint64_t size, uint64_t n_rec, const uint64_t *d_pack_start, uint64_t n_packs, uint8_t *d_out,
+                                 uint64_t out_capacity, uint64_t *d_out_bytes, uint64_t *d_lut, uint64_t *d_stats, int sync)
+{
+	(void)ctx;
+	(void)dev;
+	std::lock_guard<std::mutex> lck(s.mtx);
+	s.timed = true;
+	if (int rc = run_bin_device(s, P, d_superkmers, size, n_rec, (const u64 *)d_pack_start, n_packs, d_out, out_capacity, (u64 *)d_out_bytes,
+	                            (u64 *)d_lut, lut_entries, (u64 *)d_stats))
+		return rc;
+	if (!sync)
+		return 0;
+	HIPCHK(hipStreamSynchronize(s.stream));
+	if (int rc = harvest(s))
+		return rc;
+	u32 err = 0;
+	if (int rc = read_and_clear_sticky(s, err))
+		return rc;
+	return err_to_code(err);
+}
+
 int kmc_hip_process_bin_device(kmc_hip_ctx *ctx, int dev, const kmc_hip_bin_params *params, const uint8_t *d_superkmers, uint64_t size,
                                uint64_t n_rec, const uint64_t *d_pack_start, uint64_t n_packs, uint8_t *d_out, uint64_t out_capacity,
                                uint64_t *d_out_bytes, uint64_t *d_lut, uint64_t *d_stats, int sync)
@@ -673,23 +848,76 @@ int kmc_hip_process_bin_device(kmc_hip_ctx *ctx, int dev, const kmc_hip_bin_para
 	if (!d_out_bytes || !d_stats || (size && (!d_superkmers || !d_pack_start)))
 		return fail(KMC_HIP_EINVAL, "kmc_hip_process_bin_device: NULL device pointer");
 	/* asynchronous calls go round-robin over the device's stream slots, so the launch gaps and serial tails of one
-	 * (small) bin are filled by the kernels of the next ones; a synchronous call always uses slot 0, and so does a bin
-	 * whose record arrays exceed ASYNC_BIG_BYTES: it fills the GPU on its own, and every slot it visited would keep
-	 * two arrays of that size (slot buffers only grow) */
-	constexpr u64 ASYNC_BIG_BYTES = 1ull << 31;
-	const bool big = n_rec * (u64)kmc_hip_words(P.k) * 8 * 2 > ASYNC_BIG_BYTES;
-	Slot &s = ctx->devs[dev].slot[(sync || big) ? 0 : (ctx->devs[dev].rr++ % N_SLOTS)];
-	s.timed = true;
-	const u64 lut_entries = kmc_hip_lut_entries(params);
-	if (int rc = run_bin_device(s, P, d_superkmers, size, n_rec, (const u64 *)d_pack_start, n_packs, d_out, out_capacity,
-	                            (u64 *)d_out_bytes, (u64 *)d_lut, P.kff ? 0 : lut_entries, (u64 *)d_stats))
+	 * (small) bin are filled by the kernels of the next ones; a synchronous call always uses slot 0, and so does a big bin */
+	Dev &d = *ctx->devs[dev];
+	int si = 0;
+	if (!sync && !is_big(P, n_rec)) {
+		std::lock_guard<std::mutex> lck(d.rr_mtx);
+		si = (int)(d.rr++ % N_BATCH_STREAMS);
+	}
+	const u64 lut_entries = P.kff ? 0 : kmc_hip_lut_entries(params);
+	return process_bin_device_on(ctx, dev, d.slot[si], P, lut_entries, d_superkmers, size, n_rec, d_pack_start, n_packs, d_out, out_capacity,
+	                             d_out_bytes, d_lut, d_stats, sync);
+}
+
+int kmc_hip_process_bins_device(kmc_hip_ctx *ctx, int dev, const kmc_hip_bin_params *params, const kmc_hip_bin_desc *bins, uint64_t n_bins,
+                                int n_streams)
+{
+	if (int rc = set_dev(ctx, dev))
 		return rc;
-	if (!sync)
-		return 0;
-	HIPCHK(hipStreamSynchronize(s.stream));
-	u32 err = 0;
-	HIPCHK(hipMemcpy(&err, small_ptr<u32>(s, SM_ERR), 4, hipMemcpyDeviceToHost));
-	return err_to_code(err);
+	DevParams P;
+	if (int rc = check_params(params, P))
+		return rc;
+	if (n_bins && !bins)
+		return fail(KMC_HIP_EINVAL, "bins == NULL");
+	if (n_streams <= 0)
+		n_streams = N_BATCH_STREAMS;
+	if (n_streams > N_SLOTS)
+		n_streams = N_SLOTS;
+	for (uint64_t i = 0; i < n_bins; ++i)
+		if (!bins[i].d_out_bytes || !bins[i].d_stats || (bins[i].size && (!bins[i].d_superkmers || !bins[i].d_pack_start)))
+			return fail(KMC_HIP_EINVAL, "kmc_hip_process_bins_device: NULL device pointer in a bin descriptor");
+	const u64 lut_entries = P.kff ? 0 : kmc_hip_lut_entries(params);
+	Dev &d = *ctx->devs[dev];
+	/* Bin i goes to stream slot (i mod n_streams), in index order per slot; one host thread per slot enqueues (a bin is ~16 launches:
+	 * with hundreds of small bins a single submitting thread is the bottleneck, not the GPU). Big bins all take slot 0. */
+	std::vector<int> rcs((size_t)n_streams, 0);
+	std::vector<std::string> msgs((size_t)n_streams);
+	auto work = [&](int t) {
+		if (hipSetDevice(d.ordinal) != hipSuccess) {
+			rcs[t] = KMC_HIP_EDEVICE;
+			msgs[t] = "hipSetDevice failed in a submitting thread";
+			return;
+		}
+		for (uint64_t i = 0; i < n_bins; ++i) {
+			const kmc_hip_bin_desc &b = bins[i];
+			const int si = is_big(P, b.n_rec) ? 0 : (int)(i % (uint64_t)n_streams);
+			if (si != t)
+				continue;
+			int rc = process_bin_device_on(ctx, dev, d.slot[si], P, lut_entries, b.d_superkmers, b.size, b.n_rec, b.d_pack_start, b.n_packs,
+			                               b.d_out, b.out_capacity, b.d_out_bytes, b.d_lut, b.d_stats, 0);
+			if (rc) {
+				rcs[t] = rc;
+				msgs[t] = g_err;
+				return;
+			}
+		}
+	};
+	if (n_streams == 1 || n_bins < 2) {
+		for (int t = 0; t < n_streams; ++t)
+			work(t);
+	} else {
+		std::vector<std::thread> th;
+		for (int t = 1; t < n_streams; ++t)
+			th.emplace_back(work, t);
+		work(0);
+		for (auto &x : th)
+			x.join();
+	}
+	for (int t = 0; t < n_streams; ++t)
+		if (rcs[t])
+			return fail(rcs[t], msgs[t]);
+	return 0;
 }
 
 int kmc_hip_process_bin_submit(kmc_hip_ctx *ctx, int dev, int slot, const kmc_hip_bin_params *params, const uint8_t *superkmers,
@@ -703,7 +931,8 @@ int kmc_hip_process_bin_submit(kmc_hip_ctx *ctx, int dev, int slot, const kmc_hi
 	DevParams P;
 	if (int rc = check_params(params, P))
 		return rc;
-	Slot &s = ctx->devs[dev].slot[slot];
+	Slot &s = ctx->devs[dev]->slot[slot];
+	std::lock_guard<std::mutex> lck(s.mtx);
 	if (s.pending)
 		return fail(KMC_HIP_EINVAL, "slot already has a bin in flight");
 	if (size && !superkmers)
@@ -758,6 +987,9 @@ int kmc_hip_process_bin_submit(kmc_hip_ctx *ctx, int dev, int slot, const kmc_hi
 	                         P.without_output ? 0 : out_capacity, small_ptr<u64>(s, SM_OUTBYTES), (u64 *)s.lut.p, lut_entries,
 	                         small_ptr<u64>(s, SM_STATS))))
 		return rc;
+	if (n_rec == 0) /* the empty-bin path does not touch the small block */
+		HIPCHK(hipMemsetAsync(s.small.p, 0, 64, s.stream));
+	HIPCHK(hipMemcpyAsync(small_ptr<u32>(s, SM_ERR), s.sticky.p, 4, hipMemcpyDeviceToDevice, s.stream));
 	HIPCHK(hipMemcpyAsync(s.h_res, s.small.p, sizeof(HostRes), hipMemcpyDeviceToHost, s.stream));
 	s.pending = true;
 	s.h_out = out_suffix;
@@ -774,21 +1006,28 @@ int kmc_hip_process_bin_wait(kmc_hip_ctx *ctx, int dev, int slot, uint64_t *out_
 		return rc;
 	if (slot < 0 || slot >= N_SLOTS)
 		return fail(KMC_HIP_EINVAL, "slot out of range (see kmc_hip_num_slots)");
-	Slot &s = ctx->devs[dev].slot[slot];
+	Slot &s = ctx->devs[dev]->slot[slot];
+	std::lock_guard<std::mutex> lck(s.mtx);
 	if (!s.pending)
 		return fail(KMC_HIP_EINVAL, "no bin in flight on this slot");
 	s.pending = false;
 	HIPCHK(hipStreamSynchronize(s.stream));
-	const HostRes r = *s.h_res;
-	if (int rc = err_to_code(r.err))
+	if (int rc = harvest(s))
 		return rc;
+	const HostRes r = *s.h_res;
+	if (r.err) {
+		HIPCHK(hipMemset(s.sticky.p, 0, 4));
+		return err_to_code(r.err);
+	}
 	if (r.out_bytes > s.out_capacity)
 		return fail(KMC_HIP_ECAPACITY, "out_capacity too small for the counted k-mers");
 	if (!s.without_output) {
+		/* exact-size copies: out_bytes is only known now (the capacity is ~10x the counted bytes at the default cutoffs) */
 		if (r.out_bytes)
-			HIPCHK(hipMemcpy(s.h_out, s.out.p, r.out_bytes, hipMemcpyDeviceToHost));
+			HIPCHK(hipMemcpyAsync(s.h_out, s.out.p, r.out_bytes, hipMemcpyDeviceToHost, s.stream));
 		if (s.lut_entries)
-			HIPCHK(hipMemcpy(s.h_lut, s.lut.p, s.lut_entries * 8, hipMemcpyDeviceToHost));
+			HIPCHK(hipMemcpyAsync(s.h_lut, s.lut.p, s.lut_entries * 8, hipMemcpyDeviceToHost, s.stream));
+		HIPCHK(hipStreamSynchronize(s.stream));
 	}
 	if (out_bytes)
 		*out_bytes = r.out_bytes;
@@ -818,7 +1057,8 @@ int kmc_hip_debug_expand(kmc_hip_ctx *ctx, int dev, const kmc_hip_bin_params *pa
 		return rc;
 	if (!size || !n_rec || !n_packs)
 		return fail(KMC_HIP_EINVAL, "kmc_hip_debug_expand needs a non-empty bin with packs");
-	Slot &s = ctx->devs[dev].slot[0];
+	Slot &s = ctx->devs[dev]->slot[0];
+	std::lock_guard<std::mutex> lck(s.mtx);
 	std::vector<u64> ps(1, 0);
 	for (u64 i = 0; i < n_packs; ++i)
 		ps.push_back(ps.back() + pack_bytes[i]);
@@ -845,7 +1085,8 @@ int kmc_hip_debug_expand(kmc_hip_ctx *ctx, int dev, const kmc_hip_bin_params *pa
 		return rc;
 	HIPCHK(hipStreamSynchronize(s.stream));
 	u32 err = 0;
-	HIPCHK(hipMemcpy(&err, small_ptr<u32>(s, SM_ERR), 4, hipMemcpyDeviceToHost));
+	if ((rc = read_and_clear_sticky(s, err)))
+		return rc;
 	if ((rc = err_to_code(err)))
 		return rc;
 	HIPCHK(hipMemcpy(out_recs, s.recA.p, n_rec * words * 8, hipMemcpyDeviceToHost));
@@ -862,7 +1103,8 @@ int kmc_hip_debug_compact(kmc_hip_ctx *ctx, int dev, const kmc_hip_bin_params *p
 		return rc;
 	if (!n)
 		return fail(KMC_HIP_EINVAL, "kmc_hip_debug_compact needs n > 0");
-	Slot &s = ctx->devs[dev].slot[0];
+	Slot &s = ctx->devs[dev]->slot[0];
+	std::lock_guard<std::mutex> lck(s.mtx);
 	const u32 words = (P.k + 31) / 32;
 	const u64 lut_entries = P.kff ? 0 : kmc_hip_lut_entries(params);
 	int rc = 0;
@@ -884,7 +1126,10 @@ int kmc_hip_debug_compact(kmc_hip_ctx *ctx, int dev, const kmc_hip_bin_params *p
 	HIPCHK(hipStreamSynchronize(s.stream));
 	HostRes r;
 	HIPCHK(hipMemcpy(&r, s.small.p, sizeof r, hipMemcpyDeviceToHost));
-	if ((rc = err_to_code(r.err)))
+	u32 err = 0;
+	if ((rc = read_and_clear_sticky(s, err)))
+		return rc;
+	if ((rc = err_to_code(err)))
 		return rc;
 	if (r.out_bytes > out_capacity)
 		return fail(KMC_HIP_ECAPACITY, "out_capacity too small");
@@ -910,7 +1155,7 @@ int kmc_hip_allreduce_stats(kmc_hip_ctx *ctx, uint64_t *per_dev_stats)
 	if (!ctx->comms_ready) {
 		std::vector<int> ords(n);
 		for (int i = 0; i < n; ++i)
-			ords[i] = ctx->devs[i].ordinal;
+			ords[i] = ctx->devs[i]->ordinal;
 		ctx->comms.resize(n);
 		ncclResult_t r = ncclCommInitAll(ctx->comms.data(), n, ords.data());
 		if (r != ncclSuccess)
@@ -920,14 +1165,14 @@ int kmc_hip_allreduce_stats(kmc_hip_ctx *ctx, uint64_t *per_dev_stats)
 	for (int i = 0; i < n; ++i) {
 		if (int rc = set_dev(ctx, i))
 			return rc;
-		if (int rc = ensure(ctx->devs[i].rccl_buf, 64))
+		if (int rc = ensure(ctx->devs[i]->rccl_buf, 64))
 			return rc;
-		HIPCHK(hipMemcpy(ctx->devs[i].rccl_buf.p, per_dev_stats + 4 * i, 32, hipMemcpyHostToDevice));
+		HIPCHK(hipMemcpy(ctx->devs[i]->rccl_buf.p, per_dev_stats + 4 * i, 32, hipMemcpyHostToDevice));
 	}
 	ncclResult_t r = ncclGroupStart();
 	for (int i = 0; i < n && r == ncclSuccess; ++i) {
-		(void)hipSetDevice(ctx->devs[i].ordinal);
-		r = ncclAllReduce(ctx->devs[i].rccl_buf.p, ctx->devs[i].rccl_buf.p, 4, ncclUint64, ncclSum, ctx->comms[i], ctx->devs[i].slot[0].stream);
+		(void)hipSetDevice(ctx->devs[i]->ordinal);
+		r = ncclAllReduce(ctx->devs[i]->rccl_buf.p, ctx->devs[i]->rccl_buf.p, 4, ncclUint64, ncclSum, ctx->comms[i], ctx->devs[i]->slot[0].stream);
 	}
 	ncclResult_t r2 = ncclGroupEnd();
 	if (r != ncclSuccess || r2 != ncclSuccess)
@@ -935,8 +1180,8 @@ int kmc_hip_allreduce_stats(kmc_hip_ctx *ctx, uint64_t *per_dev_stats)
 	for (int i = 0; i < n; ++i) {
 		if (int rc = set_dev(ctx, i))
 			return rc;
-		HIPCHK(hipStreamSynchronize(ctx->devs[i].slot[0].stream));
-		HIPCHK(hipMemcpy(per_dev_stats + 4 * i, ctx->devs[i].rccl_buf.p, 32, hipMemcpyDeviceToHost));
+		HIPCHK(hipStreamSynchronize(ctx->devs[i]->slot[0].stream));
+		HIPCHK(hipMemcpy(per_dev_stats + 4 * i, ctx->devs[i]->rccl_buf.p, 32, hipMemcpyDeviceToHost));
 	}
 	return 0;
 }
@@ -965,7 +1210,8 @@ int kmc_hip_last_timings(kmc_hip_ctx *ctx, int dev, float ms[6])
 {
 	if (int rc = set_dev(ctx, dev))
 		return rc;
-	Slot &s = ctx->devs[dev].slot[0];
+	Slot &s = ctx->devs[dev]->slot[0];
+	std::lock_guard<std::mutex> lck(s.mtx);
 	HIPCHK(hipStreamSynchronize(s.stream));
 	for (int i = 0; i < 5; ++i)
 		HIPCHK(hipEventElapsedTime(&ms[i], s.ev[i], s.ev[i + 1]));
@@ -973,24 +1219,32 @@ int kmc_hip_last_timings(kmc_hip_ctx *ctx, int dev, float ms[6])
 	return 0;
 }
 
-int kmc_hip_last_scatter_stats(kmc_hip_ctx *ctx, int dev, uint32_t *n_launches, float *total_ms, uint64_t *keys_per_launch)
+int kmc_hip_scatter_totals(kmc_hip_ctx *ctx, int dev, int reset, uint64_t *n_launches, double *total_ms, uint64_t *total_records)
 {
 	if (int rc = set_dev(ctx, dev))
 		return rc;
-	Slot &s = ctx->devs[dev].slot[0];
-	HIPCHK(hipStreamSynchronize(s.stream));
-	float tot = 0;
-	for (u32 i = 0; i + 1 < s.sc_used; i += 2) {
-		float t = 0;
-		HIPCHK(hipEventElapsedTime(&t, s.sc_ev[i], s.sc_ev[i + 1]));
-		tot += t;
+	u64 nl = 0, keys = 0;
+	double ms = 0;
+	for (auto &s : ctx->devs[dev]->slot) {
+		std::lock_guard<std::mutex> lck(s.mtx);
+		HIPCHK(hipStreamSynchronize(s.stream));
+		if (int rc = harvest(s))
+			return rc;
+		nl += s.sc_launch_total;
+		keys += s.sc_keys_total;
+		ms += s.sc_ms_total;
+		if (reset) {
+			s.sc_launch_total = 0;
+			s.sc_keys_total = 0;
+			s.sc_ms_total = 0;
+		}
 	}
 	if (n_launches)
-		*n_launches = s.sc_used / 2;
+		*n_launches = nl;
 	if (total_ms)
-		*total_ms = tot;
-	if (keys_per_launch)
-		*keys_per_launch = s.sc_used >= 2 ? s.sc_keys / (s.sc_used / 2) : 0; /* average records per launch */
+		*total_ms = ms;
+	if (total_records)
+		*total_records = keys;
 	return 0;
 }
 

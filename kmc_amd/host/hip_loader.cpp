@@ -38,6 +38,7 @@ struct Api {
 	              uint8_t *, uint64_t, uint64_t *) = nullptr;
 	int (*wait)(kmc_hip_ctx *, int, int, uint64_t *, uint64_t *) = nullptr;
 	int (*num_slots)(void) = nullptr;
+	int (*sort_into)(kmc_hip_ctx *, int, const void *, void *, uint64_t, uint32_t, uint32_t) = nullptr;
 	int n_slots = 1;
 	std::mutex slot_mtx[64][16]; /* the C-ABI wants calls on one (device, slot) serialised; workers may outnumber slots */
 	int (*host_register)(kmc_hip_ctx *, void *, uint64_t) = nullptr;
@@ -101,7 +102,8 @@ void load_api_impl()
 	if (!sym(a.so, "kmc_hip_init", a.init, a.err) || !sym(a.so, "kmc_hip_destroy", a.destroy, a.err) ||
 	    !sym(a.so, "kmc_hip_last_error", a.last_error, a.err) || !sym(a.so, "kmc_hip_abi_version", a.abi_version, a.err) ||
 	    !sym(a.so, "kmc_hip_process_bin_submit", a.submit, a.err) || !sym(a.so, "kmc_hip_process_bin_wait", a.wait, a.err) ||
-	    !sym(a.so, "kmc_hip_host_register", a.host_register, a.err) || !sym(a.so, "kmc_hip_num_slots", a.num_slots, a.err)) {
+	    !sym(a.so, "kmc_hip_host_register", a.host_register, a.err) || !sym(a.so, "kmc_hip_num_slots", a.num_slots, a.err) ||
+	    !sym(a.so, "kmc_hip_sort_records_into", a.sort_into, a.err)) {
 		a.so = nullptr;
 		return;
 	}
@@ -203,6 +205,24 @@ struct EagerInit {
 	}
 } g_eager;
 } // namespace
+
+/* the narrow boundary (hip_sort_function.h): one GPU sort on behalf of a reference sorter thread. Threads are spread over the
+ * configured devices; on one device host sorts take turns (the library serialises them on the device's staging arrays). */
+int kmc_hip_host_sort(const void *recs, void *dst, uint64_t n, uint32_t words, uint32_t key_bytes, std::string &err)
+{
+	std::call_once(g_once, load_api);
+	if (!g_api.ctx) {
+		err = g_api.err.empty() ? "HIP engine not initialised" : g_api.err;
+		return KMC_HIP_EDEVICE;
+	}
+	static std::atomic<unsigned> next_thread{0};
+	thread_local unsigned my_idx = next_thread++;
+	const int dev = (int)(my_idx % (unsigned)(g_api.n_dev > 0 ? g_api.n_dev : 1));
+	int rc = g_api.sort_into(g_api.ctx, dev, recs, dst, n, words, key_bytes);
+	if (rc)
+		err = g_api.last_error(g_api.ctx);
+	return rc;
+}
 
 KmcBinEngine *kmc_make_bin_engine(int worker_idx, int /*n_workers*/)
 {

@@ -6,7 +6,8 @@
  * with the same constructor, operator()() and GetDebugStats(), so CKMC<SIZE>::ProcessStage2_impl
  * (kmc.h:1576-1584, :1736-1741) builds against it unchanged. Instead of Expand/Sort/Compact on the CPU
  * (kb_sorter.h:223-231) each bin is handed to a KmcBinEngine (bin_engine.h): the HIP engine behind
- * include/kmc_hip.h, or — in the oracle-pinning build only — oracle/stage2_oracle.c.
+ * include/kmc_hip.h (hip_loader.cpp). (Test infrastructure plugs its own engine in through the same interface:
+ * oracle/oracle_engine.h, used only by the oracle-pinning build `kmc_oracle`.)
  *
  * How it is compiled in (oracle/Makefile): kmc_runner.cpp, the one translation unit that
  * instantiates CKMC<SIZE>, is compiled with
@@ -80,82 +81,7 @@ public:
 
 #include "bin_engine.h"
 
-#ifdef KMC_PLUGIN_ENGINE_ORACLE
-#include "stage2_oracle.h"
-#include <cstdlib>
-#include <cstring>
-/* TEST-ONLY engine: the CPU restatement, optionally teeing every bin (input image + outputs) to
- * $KMC_BIN_DUMP so tests/golden fixtures can be cut from real reference stage-1 bins. */
-struct KmcOracleEngine : KmcBinEngine {
-	std::string err;
-	int process_bin(const kmc_hip_bin_params &p, const uint8_t *sk, uint64_t size, uint64_t n_rec,
-	                const uint64_t *pack_bytes, uint64_t n_packs, uint8_t *out, uint64_t cap, uint64_t *out_bytes,
-	                uint64_t *lut, uint64_t stats[4]) override
-	{
-		oracle_params op;
-		op.kmer_len = p.kmer_len;
-		op.both_strands = p.both_strands;
-		op.cutoff_min = p.cutoff_min;
-		op.without_output = p.without_output;
-		op.cutoff_max = p.cutoff_max;
-		op.counter_max = p.counter_max;
-		op.lut_prefix_len = p.lut_prefix_len;
-		op.output_type = p.output_type;
-		const char *dump = getenv("KMC_BIN_DUMP");
-		std::vector<uint8_t> copy;
-		if (dump)
-			copy.assign(sk, sk + size); /* out may alias sk */
-		int rc = oracle_process_bin(&op, sk, size, n_rec, out, cap, out_bytes, lut, stats);
-		if (rc) {
-			err = "oracle_process_bin failed, code " + std::to_string(rc);
-			return rc;
-		}
-		if (dump) {
-			static std::mutex mtx;
-			std::lock_guard<std::mutex> lck(mtx);
-			FILE *f = fopen(dump, "ab");
-			if (f) {
-				uint64_t lut_n = p.lut_prefix_len ? 1ull << (2 * p.lut_prefix_len) : 0;
-				uint64_t hdr[8] = {0x4B4D4342494E3031ull /* "KMCBIN01" */, size, n_rec, n_packs, *out_bytes, lut_n, 0, 0};
-				fwrite(hdr, 8, 8, f);
-				fwrite(&p, sizeof p, 1, f);
-				fwrite(stats, 8, 4, f);
-				fwrite(pack_bytes, 8, n_packs, f);
-				fwrite(copy.data(), 1, size, f);
-				fwrite(out, 1, *out_bytes, f);
-				fwrite(lut, 8, lut_n, f);
-				fclose(f);
-			}
-		}
-		return 0;
-	}
-	std::string last_error() override { return err; }
-};
-inline KmcBinEngine *kmc_make_bin_engine(int, int) { return new KmcOracleEngine(); }
-#endif
-
-/* Ordered hand-off to the completer. The reference's database bytes depend on the order bins reach kq
- * (kb_completer.cpp:131-221): with several CPU sorters that order is a race, which is why reference
- * runs are only reproducible with -sr1. Here every bin gets a sequence number when it is handed out (GetNext is
- * taken under a mutex, so numbers follow CBinDesc's sorted order) and is pushed to kq strictly in that sequence,
- * however many workers / GPUs / stream slots finish out of order: the DB equals the reference's -sr1 bytes for ANY -sr. */
-struct KmcOrderedEmit {
-	std::mutex take_mtx, emit_mtx;
-	CThrowingOnCancelConditionVariable cv; /* cancelled by CCriticalErrorHandler like every other wait in kmc_core */
-	uint64 next_take = 0, next_emit = 0;
-	static std::shared_ptr<KmcOrderedEmit> for_queue(CKmerQueue *kq)
-	{
-		static std::mutex m;
-		static std::map<CKmerQueue *, std::weak_ptr<KmcOrderedEmit>> live;
-		std::lock_guard<std::mutex> lck(m);
-		auto sp = live[kq].lock();
-		if (!sp) {
-			sp = std::make_shared<KmcOrderedEmit>();
-			live[kq] = sp;
-		}
-		return sp;
-	}
-};
+#include "kmc_order.h" /* KmcOrderedEmit: emission order + KMC_HIP_VERBOSE statistics, shared with kb_reader_plugin.h */
 
 template <unsigned SIZE> class CWKmerBinSorter {
 	std::shared_ptr<KmcOrderedEmit> order;
@@ -219,13 +145,16 @@ public:
 		const uint64 out_rec_bytes = kmc_hip_out_rec_bytes_host(bp);
 		std::vector<uint64> pack_bytes;
 
+		const long long t_start = KmcOrderedEmit::now_ns();
 		while (true) {
 			uint64 seq = 0;
 			{
+				const long long t0 = KmcOrderedEmit::now_ns();
 				std::lock_guard<std::mutex> lck(order->take_mtx);
 				if (!sorters_manager->GetNext(bin_id, data, size, n_rec, n_sorting_threads))
 					break;
 				seq = order->next_take++;
+				order->ns_getnext += KmcOrderedEmit::now_ns() - t0;
 			}
 			CMemDiskFile *file;
 			string desc;
@@ -250,8 +179,10 @@ public:
 
 			uint64 out_bytes = 0;
 			uint64 stats[4] = {0, 0, 0, 0};
+			const long long t1 = KmcOrderedEmit::now_ns();
 			int rc = engine->process_bin(bp, data, tmp_size, n_rec, pack_bytes.data(), pack_bytes.size(), out_buffer,
 			                             out_capacity, &out_bytes, (uint64 *)raw_lut, stats);
+			order->ns_engine += KmcOrderedEmit::now_ns() - t1;
 			if (rc != 0) {
 				std::ostringstream ostr;
 				ostr << "Error: stage-2 bin engine failed on bin " << bin_id << " (code " << rc << "): " << engine->last_error();
@@ -272,16 +203,24 @@ public:
 			if (!bp.without_output && !(max_x && n_plus_x_recs == 0))
 				data_packs.emplace_back(0, out_bytes);
 			{
+				const long long t2 = KmcOrderedEmit::now_ns();
 				std::unique_lock<std::mutex> lck(order->emit_mtx);
 				order->cv.wait(lck, [&] { return order->next_emit == seq; });
+				const long long t3 = KmcOrderedEmit::now_ns();
 				kq->push(bin_id, out_buffer, data_packs, raw_lut, lut_recs * sizeof(uint64), stats[0], stats[1], stats[2],
 				         stats[3]);
 				++order->next_emit;
+				order->ns_turn += t3 - t2;
+				order->ns_push += KmcOrderedEmit::now_ns() - t3;
 			}
 			order->cv.notify_all();
+			++order->n_bins;
 
 			sorters_manager->ReturnThreads(n_sorting_threads, bin_id);
 		}
+		order->ns_worker_wall += KmcOrderedEmit::now_ns() - t_start;
+		if (++order->n_workers_done == n_workers)
+			order->report(n_workers);
 		kq->mark_completed();
 	}
 

@@ -1,0 +1,65 @@
+/*
+ * kmc_amd/host/kmc_order.h — state shared by the two stage-2 plug-ins (kb_reader_plugin.h, kb_sorter_plugin.h) of one run:
+ * the emission order of bins and, for KMC_HIP_VERBOSE=1, where the stage-2 threads spent their time.
+ *
+ * Ordered hand-off to the completer. The reference's database bytes depend on the order bins reach kq
+ * (kb_completer.cpp:131-221): with several CPU sorters that order is a race, which is why reference
+ * runs are only reproducible with -sr1. Here every bin gets a sequence number when GetNext hands it to a worker (taken
+ * under a mutex; bins reach the bin queue in CBinDesc's sorted order, queues.h:499-571, from the reference's reader and
+ * from the reader plug-in alike) and is pushed to kq strictly in that sequence, however many workers / GPUs / stream
+ * slots finish out of order: the DB equals the reference's -sr1 bytes for ANY -sr.
+ */
+#ifndef KMC_AMD_ORDER_H
+#define KMC_AMD_ORDER_H
+
+#include <atomic>
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+#include <map>
+#include <memory>
+#include <mutex>
+#include <vector>
+
+#include "defs.h"
+#include "params.h"
+#include "critical_error_handler.h"
+
+struct KmcOrderedEmit {
+	std::mutex take_mtx, emit_mtx;
+	CThrowingOnCancelConditionVariable cv; /* cancelled by CCriticalErrorHandler like every other wait in kmc_core */
+	uint64 next_take = 0, next_emit = 0;
+	/* KMC_HIP_VERBOSE=1: nanoseconds summed over threads */
+	std::atomic<long long> ns_reader_init{0}, ns_reader_read{0}, ns_reader_wall{0}, ns_getnext{0}, ns_engine{0}, ns_turn{0}, ns_push{0},
+	    ns_worker_wall{0};
+	std::atomic<long long> n_bins{0}, n_workers_done{0}, n_readers{0};
+	static long long now_ns()
+	{
+		return std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now().time_since_epoch()).count();
+	}
+	void report(int n_workers)
+	{
+		if (!getenv("KMC_HIP_VERBOSE"))
+			return;
+		fprintf(stderr,
+		        "[kmc_hip stage 2] %lld bins, %d workers, %lld reader threads | reader: admit %.3f s, read %.3f s (summed), wall %.3f s | workers "
+		        "(summed over threads): wait for a bin %.3f s, engine %.3f s, wait for the turn to push %.3f s, push %.3f s, wall %.3f s\n",
+		        n_bins.load(), n_workers, n_readers.load(), ns_reader_init.load() * 1e-9, ns_reader_read.load() * 1e-9, ns_reader_wall.load() * 1e-9,
+		        ns_getnext.load() * 1e-9, ns_engine.load() * 1e-9, ns_turn.load() * 1e-9, ns_push.load() * 1e-9, ns_worker_wall.load() * 1e-9);
+	}
+
+	static std::shared_ptr<KmcOrderedEmit> for_queue(CKmerQueue *kq)
+	{
+		static std::mutex m;
+		static std::map<CKmerQueue *, std::weak_ptr<KmcOrderedEmit>> live;
+		std::lock_guard<std::mutex> lck(m);
+		auto sp = live[kq].lock();
+		if (!sp) {
+			sp = std::make_shared<KmcOrderedEmit>();
+			live[kq] = sp;
+		}
+		return sp;
+	}
+};
+
+#endif

@@ -129,7 +129,7 @@ def test_cabi_library_exports_every_declared_symbol():
     L = capi.load()
     for name in declared:
         assert hasattr(L, name), name
-    assert L.kmc_hip_abi_version() == 1
+    assert L.kmc_hip_abi_version() == 2
     # pure host-side helpers agree with the oracle
     for cx, cs in ((10**9, 255), (10**9, 1), (200, 70000), (10**9, 70000), (10**9, 2**24)):
         assert L.kmc_hip_counter_size(cx, cs) == O.lib().oracle_counter_size(cx, cs)
@@ -164,6 +164,32 @@ def test_oracle_database_equals_reference(flags, ref_bins, tmp_path):
         assert _md5(str(tmp_path / ("ref" + ext))) == _md5(str(tmp_path / ("orc" + ext)))
         assert _md5(str(tmp_path / ("ref" + ext))) == _md5(str(tmp_path / ("orc3" + ext)))
         assert _md5(str(tmp_path / ("ref" + ext))) == _md5(str(tmp_path / ("orc12" + ext)))
+
+
+@pytest.mark.parametrize("flags", [["-k27"], ["-k55", "-ci1"], ["-k27", "-sm", "-m2"], ["-k27", "-r"]], ids=lambda f: "".join(f))
+def test_reader_plugin_keeps_the_reference_database(flags, ref_bins, tmp_path):
+    """kb_reader_plugin.h (several threads read bin files at once; bins are admitted to the arena and pushed to the bin
+    queue in CBinDesc's sorted order) + the worker plug-in + the oracle engine: .kmc_pre/.kmc_suf byte-identical to the
+    reference's -sr1 run for any number of reader and worker threads, in strict-memory mode and in RAM-only mode."""
+    if ref_bins is None or not os.path.exists(os.path.join(ROOT, "oracle", "_ref", "kmc_oracle_pr")):
+        pytest.skip("oracle/_ref/kmc_oracle_pr not built")
+    from kmc_amd import synth
+
+    exe_pr = os.path.join(ROOT, "oracle", "_ref", "kmc_oracle_pr")
+    fq = str(tmp_path / "in.fq")
+    synth.make_fastq(fq, seed=31, genome_len=80_000, n_reads=6000)
+    runs = [(ref_bins["kmc"], "ref", ["-sr1"], {})]
+    for readers, mode in (("1", ["-sr1"]), ("3", ["-t4", "-sr2"]), ("8", ["-t16", "-sr12"]), ("64", ["-t8", "-sr5"])):
+        runs.append((exe_pr, f"pr{readers}", mode, {"KMC_HIP_READERS": readers}))
+    for exe, out, mode, extra in runs:
+        tmp = tmp_path / ("tmp_" + out)
+        tmp.mkdir()
+        r = subprocess.run([exe, *flags, *mode, fq, str(tmp_path / out), str(tmp)], env=dict(os.environ, KMC_HIP_VERBOSE="1", **extra),
+                           capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    for _, out, _, _ in runs[1:]:
+        for ext in (".kmc_pre", ".kmc_suf"):
+            assert _md5(str(tmp_path / ("ref" + ext))) == _md5(str(tmp_path / (out + ext))), (out, ext)
 
 
 def test_dropin_binary_fails_loudly_without_a_gpu(ref_bins, tmp_path):
