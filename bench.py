@@ -1,21 +1,33 @@
 #!/usr/bin/env python3
 """bench.py — KMC stage-2 (bin sort & count) throughput on MI355X.
 
-Metric (BASELINE.json): stage-2 Gk-mers/s (+ unique k-mers/s), k=27. One "step" = one pass of the whole hot path
-(index -> expand -> histogram -> 7 LSD scatter passes -> compaction) over one resident bin image.
-Workload at N=1 = BASELINE.json configs[1]: k=27, 150 bp synthetic reads, ~2 Gbp, ALL k-mers as a single bin
-(13.3 M reads of a 66 Mbp genome -> ~1.65 G k-mers, 13.2 GB of 8-byte records) on one GPU.
-N>1: one process per GPU, every rank sorts its own bin of that size (weak scaling, no data-path collective);
-the four tallies are summed once with torch.distributed all_reduce (RCCL) inside the timed region.
+Metric (BASELINE.json): stage-2 Gk-mers/s (+ unique k-mers/s), k=27, bit-exact database.
 
-Inputs are resident in HBM when the timed region starts (the PCIe-inclusive rate is in DESIGN.md, not here).
-`roofline`: the dominant kernel is k_onesweep (one launch = one 8-bit pass over <= 2^29 records); achieved =
-algorithmic bytes of a pass (2*W = 16 B per record) / its average launch time measured with HIP
-events on the library's own stream; peak = 8 TB/s (MI355X_MICROARCH.md). `cpu_baseline`: the REAL reference
-(oracle/_ref/kmc, built from /root/reference by oracle/Makefile) timed on this box's host cores on the same
-workload (its stage 2 has ~1 s of fixed cost, so a smaller sample would under-report it) — a reported baseline only.
+Workload = BASELINE.json configs[2] (the shape the 1/2/4/8-GPU metric is quoted on, SURVEY.md §8d "C3"): k=27, 150 bp synthetic
+reads, ~30 Gbp (200 M reads of a 1 Gbp random genome, seed 2026, 1 % substitutions, random strand), cut into 512 signature
+bins of minimizer super-k-mers with KMC's parameters for that input (cutoff_min 2, counter_max 255, lut_prefix_len 7 by the
+rule of kmc.h:1434-1469) -> ~24.8 G k-mers. One "step" = ALL bins through the whole hot path (parse -> expand (+histograms) ->
+7 onesweep passes -> compaction) with the bin images already resident in HBM.
+
+  --gpus 1 : all 512 bins on one GPU (configs[2]).
+  --gpus N : the SAME 512 bins sharded over N ranks (one process per GPU) by LPT on their k-mer counts (the order KMC hands
+             bins to sorters, queues.h:499-558), no data-path collective; the four tallies are summed with ONE all-reduce
+             (RCCL) inside the timed region. value = all k-mers of the bin set / max-over-ranks time => STRONG scaling (configs[3]).
+             Each rank generates 1/N of the reads; bin pieces are exchanged through a scratch directory before the timed region.
+
+Extra keys of the N=1 line (each measured after the timed region, none inside it):
+  value_host_boundary : the same bins through kmc_hip_process_bin_submit/_wait from pinned host memory (PCIe inclusive)
+  secondary.single_bin: configs[1] — 2 Gbp, all k-mers as ONE bin (the kernel-level datum of round 1)
+  secondary.bins512_2gbp: the 2 Gbp sample cut into 512 bins (3.2 M k-mers per bin), tallies checked against the reference
+  cpu_baseline / e2e  : the REAL reference (oracle/_ref/kmc, built from /root/reference by oracle/Makefile) and the drop-in
+                        (oracle/_ref/kmc_hip = reference pipeline + this library) on a FASTQ of the SAME reads as the 2 Gbp sample:
+                        "2nd stage" seconds of each, the five statistics compared.
+`roofline`: dominant kernel k_onesweep (one launch = one 8-bit LSD pass over one bin); achieved = algorithmic bytes of the
+launches in the timed region (2*W = 16 B per record and pass) / their summed duration (HIP events around
+every launch, on the launch's own stream); peak = 8 TB/s (MI355X_MICROARCH.md).
 """
 import argparse
+import ctypes as C
 import json
 import os
 import re
@@ -23,6 +35,7 @@ import shutil
 import subprocess
 import sys
 import tempfile
+import threading
 import time
 
 import numpy as np
@@ -33,7 +46,31 @@ sys.path.insert(0, ROOT)
 from kmc_amd import capi, sharding  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
-PMC_PROFILE = os.path.join(ROOT, "profiles", "r01", "final", "pmc_hbm_traffic.json")  # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes
+PMC_PROFILE = os.path.join(ROOT, "profiles", "r02", "pmc_hbm_traffic.json")  # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes
+
+# BASELINE.json configs -> generator parameters
+CONFIGS = {
+    "configs[2]": dict(reads=200_000_000, genome=1_000_000_000, bins=512,
+                       desc="configs[2]: k=%d, 150 bp synthetic reads, ~30 Gbp (200 M reads of a 1 Gbp genome), all 512 signature bins"),
+    "configs[1]": dict(reads=13_300_000, genome=66_000_000, bins=1,
+                       desc="configs[1]: k=%d, 150 bp synthetic reads, ~2 Gbp, all k-mers as a single bin"),
+    "2gbp-512bins": dict(reads=13_300_000, genome=66_000_000, bins=512,
+                         desc="2 Gbp sample of the configs[2] read model (13.3 M reads of a 66 Mbp genome, 30x), k=%d, 512 signature bins"),
+}
+SEED = 2026
+
+
+def kmc_lut_prefix_len(k: int, n_reads: int, n_bins: int) -> int:
+    """Params.lut_prefix_len as CKMC::ProcessStage2_impl picks it without a histogram estimate (kmc.h:1434-1469)."""
+    n_est = 4 * n_reads
+    best, best_mem = 0, 1 << 62
+    for p in range(2, 16):
+        if (k - p) % 4 or p >= k:
+            continue
+        mem = n_est * (k - p) // 4 + n_bins * (1 << (2 * p)) * 8
+        if mem < best_mem:
+            best, best_mem = p, mem
+    return best
 
 
 def pmc_traffic(kernel: str, records_per_launch: float):
@@ -41,78 +78,302 @@ def pmc_traffic(kernel: str, records_per_launch: float):
     counters cannot be collected from inside the timed run)."""
     try:
         d = json.load(open(PMC_PROFILE))
-        if abs(d["k_onesweep_records_per_launch_avg"] - records_per_launch) > 0.01 * records_per_launch:
+        if abs(d["records_per_launch_avg"] - records_per_launch) > 0.02 * records_per_launch:
             return None
         return d["kernels"][kernel]["hbm_bytes_per_launch"]
     except Exception:
         return None
 
 
-def cpu_baseline(k: int, sample_reads: int, genome_len: int, runs: int = 2):
-    """Reference KMC stage 2 on the host cores. The default sample is the WHOLE N=1 workload (13.3 M reads): the
-    reference's stage 2 carries about a second of fixed cost (sorter calibration, arena initialisation), so a small
-    sample under-reports it by 2x; the full workload is ~7 s per kmc run plus ~15 s of FASTQ writing."""
-    exe = os.path.join(ROOT, "oracle", "_ref", "kmc")
+def scratch_dir(need_bytes: int):
+    cands = [d for d in ("/dev/shm", os.environ.get("TMPDIR") or "/tmp", "/tmp", os.path.join(ROOT, "gpurun_out")) if os.path.isdir(d)]
+    space = {d: shutil.disk_usage(d).free for d in cands}
+    for d in cands:
+        if space[d] >= need_bytes:
+            return d, space[d]
+    best = max(cands, key=lambda d: space[d])
+    return best, space[best]
+
+
+# ---------------------------------------------------------------------------------------------------------------- workload
+class Workload:
+    """This rank's share of the bin set, resident in HBM, as kmc_hip_bin_desc records."""
+
+    def __init__(self, ctx, p, k):
+        self.ctx, self.p, self.k = ctx, p, k
+        self.bins = []  # (bin id, size, n_rec, n_packs, n_super) of own bins
+        self.allocs = []
+        self.total_kmers_all = 0  # over ALL ranks
+        self.n_bins_all = 0
+        self.setup_s = {}
+
+    def free(self):
+        for a in self.allocs:
+            self.ctx.free(a)
+        self.allocs = []
+
+
+def build_workload(ctx, args, k, p, rank, world, keep_host=False):
+    """Generate + shard the bin set (kmc_amd/sharding.py), upload this rank's bins. Returns Workload."""
+    w = Workload(ctx, p, k)
+    n_threads = max(1, (os.cpu_count() or 8) // max(world, 1))
+    sb = sharding.generate_sharded_bins(SEED, args.genome, args.reads, k, args.bins, rank, world, n_threads)
+    w.setup_s.update(sb.timings)
+    own = sb.own
+
+    t = time.time()
+    rec_bytes = ctx.out_rec_bytes(p)
+    lut_n = ctx.lut_entries(p)
+    in_off, ps_off, out_off = [], [], []
+    a = b_ = c = 0
+    for b in own:
+        in_off.append(a)
+        a += (int(sb.size[b]) + 256 + 255) & ~255
+        ps_off.append(b_)
+        b_ += (int(sb.n_packs[b]) + 1) * 8
+        out_off.append(c)
+        c += ((((int(sb.n_rec[b]) + 1) // max(p.cutoff_min, 1)) * rec_bytes) + 256 + 255) & ~255
+    d_in = ctx.malloc(max(a, 256))
+    d_ps = ctx.malloc(max(b_, 256))
+    d_out = ctx.malloc(max(c, 256))
+    d_lut = ctx.malloc(max(lut_n, 1) * 8 * max(len(own), 1))
+    d_small = ctx.malloc(64 * max(len(own), 1))
+    w.allocs = [d_in, d_ps, d_out, d_lut, d_small]
+    w.d_small, w.d_out, w.d_lut, w.out_off, w.lut_n, w.rec_bytes = d_small, d_out, d_lut, out_off, lut_n, rec_bytes
+    descs = (capi.BinDesc * max(len(own), 1))()
+    zeros = np.zeros(256, dtype=np.uint8)
+    host_imgs = []
+    for i, b in enumerate(own):
+        off = 0
+        for img, _ in sb.pieces[b]:
+            if img.size:
+                ctx.h2d(d_in + in_off[i] + off, np.ascontiguousarray(img))
+            off += int(img.size)
+        assert off == int(sb.size[b])
+        ctx.h2d(d_in + in_off[i] + off, zeros)
+        pk_all = sb.packs(b)
+        ps = np.concatenate([[0], np.cumsum(pk_all)]).astype(np.uint64)
+        ctx.h2d(d_ps + ps_off[i], ps)
+        cap = ((int(sb.n_rec[b]) + 1) // max(p.cutoff_min, 1)) * rec_bytes
+        descs[i] = capi.BinDesc(d_in + in_off[i], int(sb.size[b]), int(sb.n_rec[b]), d_ps + ps_off[i], int(sb.n_packs[b]), d_out + out_off[i], cap,
+                                d_small + 64 * i + 32, d_lut + lut_n * 8 * i, d_small + 64 * i)
+        w.bins.append((b, int(sb.size[b]), int(sb.n_rec[b]), int(sb.n_packs[b]), int(sb.n_super[b])))
+        if keep_host:
+            host_imgs.append((sb.image(b), pk_all))
+    w.setup_s["upload"] = time.time() - t
+    w.setup_s["upload_GBs"] = float(sum(x[1] for x in w.bins)) / max(w.setup_s["upload"], 1e-9) / 1e9
+    w.descs, w.n_own = descs, len(own)
+    w.total_kmers_all = int(np.sum(sb.n_rec))
+    w.total_super_all = int(np.sum(sb.n_super))
+    w.total_bytes_all = int(np.sum(sb.size))
+    w.n_bins_all = args.bins
+    w.own_kmers = int(sum(x[2] for x in w.bins))
+    w.host_imgs = host_imgs
+    w.sb = sb
+    if not keep_host:
+        sb.close()
+        w.sb = None
+    return w
+
+
+def run_step(ctx, w, n_streams):
+    if w.n_own:
+        ctx.L.kmc_hip_process_bins_device(ctx.h, 0, C.byref(w.p), w.descs, w.n_own, n_streams)
+    ctx.synchronize()
+
+
+def read_results(ctx, w):
+    """per-bin (stats[4], out_bytes) of the last step"""
+    small = np.zeros(8 * max(w.n_own, 1), dtype=np.uint64)
+    ctx.d2h(small, w.d_small)
+    return small.reshape(-1, 8)[: w.n_own]
+
+
+def output_digest(ctx, w, res):
+    """Order-independent digest of everything the step wrote (suffix/counter records + LUTs of every own bin):
+    sum over bins of a position-weighted 64-bit checksum, mod 2^64. Equal for any --gpus N."""
+    dig = 0
+    for i in range(w.n_own):
+        ob = int(res[i, 4])
+        pad = (-ob) % 8
+        buf = np.zeros(ob + pad, dtype=np.uint8)
+        if ob:
+            ctx.d2h(buf[:ob], w.d_out + w.out_off[i])
+        lut = np.zeros(max(w.lut_n, 1), dtype=np.uint64)
+        if w.lut_n:
+            ctx.d2h(lut, w.d_lut + w.lut_n * 8 * i)
+        for arr in (buf.view(np.uint64), lut):
+            if arr.size:
+                idx = np.arange(1, arr.size + 1, dtype=np.uint64)
+                dig = (dig + int(arr.sum(dtype=np.uint64)) + int((arr * idx).sum(dtype=np.uint64)) * 31 + (w.bins[i][0] + 1) * arr.size) & ((1 << 64) - 1)
+    return dig
+
+
+# ---------------------------------------------------------------------------------------------------------------- host boundary
+def host_boundary_pass(ctx, w, n_threads=8, passes=2):
+    """All own bins through kmc_hip_process_bin_submit/_wait from PINNED host memory: thread t owns stream slots 2t, 2t+1 and
+    keeps two bins in flight (H2D of bin j+1 under the kernels of bin j, D2H at wait time). Returns (best seconds, tallies)."""
+    p, L = w.p, ctx.L
+    n_slots = L.kmc_hip_num_slots()
+    n_threads = max(1, min(n_threads, n_slots // 2))
+    total = sum(((x[1] + 255) & ~255) for x in w.bins) + 256
+    t = time.time()
+    pin = ctx.host_alloc(total)
+    offs, o = [], 0
+    for (img, pk), meta in zip(w.host_imgs, w.bins):
+        pin[o:o + img.size] = img
+        offs.append(o)
+        o += (img.size + 255) & ~255
+    cap_max = max([((x[2] + 1) // max(p.cutoff_min, 1)) * w.rec_bytes for x in w.bins] + [1])
+    outs = [ctx.host_alloc(cap_max + 256) for _ in range(2 * n_threads)]
+    luts = [ctx.host_alloc(max(w.lut_n, 1) * 8) for _ in range(2 * n_threads)]
+    t_pin = time.time() - t
+    errors = []
+
+    def worker(tid, acc):
+        mine = list(range(tid, w.n_own, n_threads))
+        inflight = []  # slots (0/1) in submission order, at most two
+        ob, st = C.c_uint64(), (C.c_uint64 * 4)()
+
+        def wait(sl):
+            rc = L.kmc_hip_process_bin_wait(ctx.h, 0, 2 * tid + sl, C.byref(ob), st)
+            if rc:
+                raise RuntimeError(L.kmc_hip_last_error(ctx.h).decode())
+            for q in range(4):
+                acc[q] += st[q]
+            acc[4] += ob.value
+
+        try:
+            for j, i in enumerate(mine):
+                sl = j & 1
+                if len(inflight) == 2:
+                    wait(inflight.pop(0))  # == sl: the slot this bin is about to reuse
+                b, size, n_rec, n_packs, _ = w.bins[i]
+                pk = w.host_imgs[i][1]
+                cap = ((n_rec + 1) // max(p.cutoff_min, 1)) * w.rec_bytes
+                rc = L.kmc_hip_process_bin_submit(ctx.h, 0, 2 * tid + sl, C.byref(p), C.c_void_p(pin.ctypes.data + offs[i]), size, n_rec,
+                                                  pk.ctypes.data_as(C.c_void_p), pk.size, C.c_void_p(outs[2 * tid + sl].ctypes.data), cap,
+                                                  C.c_void_p(luts[2 * tid + sl].ctypes.data))
+                if rc:
+                    raise RuntimeError(L.kmc_hip_last_error(ctx.h).decode())
+                inflight.append(sl)
+            while inflight:
+                wait(inflight.pop(0))
+        except Exception as e:  # noqa: BLE001
+            errors.append(repr(e))
+
+    best, tallies = None, None
+    for _ in range(passes):
+        accs = [[0, 0, 0, 0, 0] for _ in range(n_threads)]
+        ths = [threading.Thread(target=worker, args=(t_, accs[t_])) for t_ in range(n_threads)]
+        t0 = time.perf_counter()
+        for th in ths:
+            th.start()
+        for th in ths:
+            th.join()
+        dt = time.perf_counter() - t0
+        if errors:
+            break
+        if best is None or dt < best:
+            best = dt
+        tallies = [sum(a[q] for a in accs) for q in range(5)]
+    for a in outs + luts:
+        ctx.host_free(a)
+    ctx.host_free(pin)
+    if errors:
+        raise RuntimeError("; ".join(errors))
+    return best, tallies, t_pin, n_threads
+
+
+# ---------------------------------------------------------------------------------------------------------------- reference legs
+_STAT_PATTERNS = {
+    "below_min": r"No\. of k-mers below min\. threshold\s*:\s*(\d+)",
+    "above_max": r"No\. of k-mers above max\. threshold\s*:\s*(\d+)",
+    "unique": r"No\. of unique k-mers\s*:\s*(\d+)",
+    "unique_counted": r"No\. of unique counted k-mers\s*:\s*(\d+)",
+    "total": r"Total no\. of k-mers\s*:\s*(\d+)",
+}
+
+
+def _run_kmc(exe, flags, fq, td, tag, env=None):
+    tmp = os.path.join(td, "tmp_" + tag)
+    os.makedirs(tmp, exist_ok=True)
+    r = subprocess.run([exe, *flags, fq, os.path.join(td, "db_" + tag), tmp], capture_output=True, text=True, env=env)
+    shutil.rmtree(tmp, ignore_errors=True)
+    if r.returncode != 0:
+        raise RuntimeError(f"{os.path.basename(exe)} failed: {(r.stdout + r.stderr)[-600:]}")
+    m1 = re.search(r"1st stage:\s*([0-9.eE+-]+)s", r.stdout)
+    m2 = re.search(r"2nd stage:\s*([0-9.eE+-]+)s", r.stdout)
+    stats = {k: int(re.search(v, r.stdout).group(1)) for k, v in _STAT_PATTERNS.items() if re.search(v, r.stdout)}
+    verbose = [ln for ln in r.stderr.splitlines() if ln.startswith("[kmc_hip")]
+    return float(m1.group(1)), float(m2.group(1)), stats, verbose
+
+
+def reference_legs(k: int, reads: int, genome: int, runs: int = 2):
+    """cpu_baseline + e2e on a FASTQ of the SAME reads as the 2 Gbp sample (kmc_amd/csrc/synth_bins.cpp writes both)."""
+    ref = os.path.join(ROOT, "oracle", "_ref", "kmc")
+    hip = os.path.join(ROOT, "oracle", "_ref", "kmc_hip")
     cores = os.cpu_count() or 1
-    if os.path.exists(exe):
-        from kmc_amd import synth
-
-        # the FASTQ (~316 B per read), kmc's temporary bins and its output need room; prefer RAM-backed storage
-        need = int(sample_reads * 316 * 1.7) + (1 << 28)
-        cands = [d for d in ("/dev/shm", os.environ.get("TMPDIR") or "/tmp", ROOT) if os.path.isdir(d)]
-        space = {d: shutil.disk_usage(d).free for d in cands}
-        best = next((d for d in cands if space[d] >= need), max(cands, key=lambda d: space[d]))
-        if space[best] < need:  # shrink the sample rather than fail
-            sample_reads = max(int(sample_reads * space[best] / need * 0.9), 100_000)
-        with tempfile.TemporaryDirectory(dir=best) as td:
-            fq = os.path.join(td, "s.fq")
-            synth.make_fastq(fq, seed=2026, genome_len=genome_len, n_reads=sample_reads)
-            times, total, uniq = [], 0, 0
-            threads = min(cores, 128)
-            ram_gb = os.sysconf("SC_PAGE_SIZE") * os.sysconf("SC_PHYS_PAGES") >> 30
-            mem = max(2, min(128, ram_gb // 2))
-            for i in range(runs):
-                tmp = os.path.join(td, f"t{i}")
-                os.makedirs(tmp)
-                r = subprocess.run([exe, f"-k{k}", f"-t{threads}", f"-m{mem}", "-hp", fq, os.path.join(td, "o"), tmp], capture_output=True, text=True)
-                if r.returncode != 0:
-                    break
-                m = re.search(r"2nd stage:\s*([0-9.eE+-]+)s", r.stdout)
-                t = re.search(r"Total no. of k-mers\s*:\s*(\d+)", r.stdout)
-                u = re.search(r"No. of unique k-mers\s*:\s*(\d+)", r.stdout)
-                if not (m and t):
-                    break
-                times.append(float(m.group(1)))
-                total, uniq = int(t.group(1)), int(u.group(1)) if u else 0
-            if times:
-                t2 = min(times)
-                return {"value": total / t2 / 1e9, "unit": "Gk-mers/s", "cores": threads, "kind": "reference",
-                        "sample": f"reference kmc 3.2.4 -k{k} -t{threads} -m{mem}, '2nd stage' wall, best of {len(times)}; {sample_reads} reads x150bp "
-                                  f"of a {genome_len} bp genome = {total} k-mers ({uniq} unique)",
-                        "stage2_s": t2, "unique_kmers_per_s": uniq / t2}
-    # no reference binary on this box: time the single-threaded C oracle (a port) on a smaller sample
-    sys.path.insert(0, os.path.join(ROOT, "tests"))
-    import oracle_py as O
-
-    (img, nrec, _, _), = capi.synth_bins(seed=2026, genome_len=genome_len // 10, n_reads=sample_reads // 10, k=k, n_bins=1)
-    t0 = time.time()
-    _, _, st = O.process_bin(O.make_params(k), img, nrec)
-    dt = time.time() - t0
-    return {"value": nrec / dt / 1e9, "unit": "Gk-mers/s", "cores": 1, "kind": "port",
-            "sample": f"oracle/stage2_oracle.c single thread on {nrec} k-mers", "stage2_s": dt, "unique_kmers_per_s": float(st[0]) / dt}
+    threads = min(cores, 128)
+    ram_gb = os.sysconf("SC_PAGE_SIZE") * os.sysconf("SC_PHYS_PAGES") >> 30
+    mem = max(2, min(128, ram_gb // 2))
+    need = int(reads * 316 * 2.0) + (1 << 28)
+    d, free = scratch_dir(need)
+    if free < need:
+        reads = max(int(reads * free / need * 0.9), 100_000)
+    out = {}
+    with tempfile.TemporaryDirectory(dir=d) as td:
+        fq = os.path.join(td, "s.fq")
+        t = time.time()
+        capi.synth_fastq(fq, seed=SEED, genome_len=genome, n_reads=reads)
+        t_fq = time.time() - t
+        sample = f"{reads} reads x150bp of a {genome} bp genome (seed {SEED}; the reads of the 2 Gbp sample), FASTQ written in {t_fq:.1f} s"
+        ref_runs = [_run_kmc(ref, [f"-k{k}", f"-t{threads}", f"-m{mem}", "-hp"], fq, td, f"ref{i}") for i in range(runs)]
+        s1, s2, st, _ = min(ref_runs, key=lambda x: x[1])
+        out["cpu_baseline"] = {"value": st["total"] / s2 / 1e9, "unit": "Gk-mers/s", "cores": threads, "kind": "reference",
+                               "sample": f"reference kmc 3.2.4 -k{k} -t{threads} -m{mem}, '2nd stage' wall, best of {runs}; {sample} = {st['total']} k-mers",
+                               "stage2_s": s2, "stage1_s": s1, "unique_kmers_per_s": st["unique"] / s2, "stats": st}
+        if os.path.exists(hip):
+            env = dict(os.environ, KMC_HIP_LIB=capi.lib_path(), KMC_HIP_VERBOSE="1")
+            hip_runs = [_run_kmc(hip, [f"-k{k}", f"-t{threads}", f"-m{mem}", "-sr16", "-hp"], fq, td, f"hip{i}", env) for i in range(runs)]
+            h1, h2, hst, verbose = min(hip_runs, key=lambda x: x[1])
+            out["e2e"] = {"what": "'2nd stage' seconds of the reference's own pipeline on the same FASTQ: unmodified (oracle/_ref/kmc) vs with the "
+                                  "stage-2 worker and bin reader swapped for this library (oracle/_ref/kmc_hip -sr16); stage 1, arena, completer and "
+                                  "database writer are the reference's in both",
+                          "ref_stage2_s": s2, "hip_stage2_s": h2, "speedup": s2 / h2, "hip_Gkmers_per_s": hst["total"] / h2 / 1e9,
+                          "ref_Gkmers_per_s": st["total"] / s2 / 1e9, "stats_equal": hst == st, "hip_stats": hst, "hip_stage1_s": h1,
+                          "all_hip_stage2_s": [x[1] for x in hip_runs], "all_ref_stage2_s": [x[1] for x in ref_runs], "worker_report": verbose[-1:] }
+    return out
 
 
+def secondary_leg(name: str, k: int, extra):
+    cfg = CONFIGS[name]
+    cmd = [sys.executable, os.path.abspath(__file__), "--leg", name, "--k", str(k), "--reads", str(cfg["reads"]), "--genome", str(cfg["genome"]),
+           "--bins", str(cfg["bins"]), "--steps", "3", "--warmup", "1", *extra]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    for ln in reversed(r.stdout.splitlines()):
+        if ln.startswith("{"):
+            return json.loads(ln)
+    return {"error": (r.stdout + r.stderr)[-500:]}
+
+
+# ---------------------------------------------------------------------------------------------------------------- main
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--k", type=int, default=27)
-    ap.add_argument("--reads", type=int, default=13_300_000, help="reads per GPU (150 bp); default = configs[1] (~2 Gbp)")
-    ap.add_argument("--genome", type=int, default=66_000_000)
-    ap.add_argument("--lut-prefix", type=int, default=3)
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-sample-reads", type=int, default=0, help="reads of the CPU-baseline sample (0 = the whole --reads workload)")
+    ap.add_argument("--reads", type=int, default=CONFIGS["configs[2]"]["reads"], help="150 bp reads of the whole job")
+    ap.add_argument("--genome", type=int, default=CONFIGS["configs[2]"]["genome"])
+    ap.add_argument("--bins", type=int, default=CONFIGS["configs[2]"]["bins"])
+    ap.add_argument("--lut-prefix", type=int, default=-1, help="-1 = KMC's own choice for this input (kmc.h:1434-1469)")
+    ap.add_argument("--streams", type=int, default=0, help="stream slots kmc_hip_process_bins_device fans out over (0 = library default)")
+    ap.add_argument("--leg", default="", help="internal: run as a secondary leg with this workload name")
+    ap.add_argument("--no-cpu-baseline", action="store_true", help="skip the reference/e2e legs")
+    ap.add_argument("--no-host-boundary", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true")
+    ap.add_argument("--no-digest", action="store_true")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -133,91 +394,133 @@ def main():
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", dev_index))
     dev = torch.device("cuda", dev_index)
 
-    ctx = capi.Context((dev_index,))
+    is_main = not args.leg
+    name = args.leg or next((n for n, c in CONFIGS.items() if (c["reads"], c["genome"], c["bins"]) == (args.reads, args.genome, args.bins)), "custom")
     k = args.k
-    t_gen = time.time()
-    n_threads = max(1, (os.cpu_count() or 8) // max(world, 1))
-    (img, n_rec, packs, n_super), = capi.synth_bins(seed=2026 + rank, genome_len=args.genome, n_reads=args.reads, k=k, n_bins=1, n_threads=n_threads)
-    t_gen = time.time() - t_gen
-    p = capi.make_params(k, lut_prefix_len=args.lut_prefix)
-    rec_bytes = ctx.out_rec_bytes(p)
-    out_cap = ((n_rec + 1) // 2) * rec_bytes
-    lut_n = ctx.lut_entries(p)
-    pack_start = np.concatenate([[0], np.cumsum(packs)]).astype(np.uint64)
-
-    d_in = ctx.malloc(img.size + 256)
-    d_ps = ctx.malloc(pack_start.nbytes)
-    d_out = ctx.malloc(out_cap + 256)
-    d_lut = ctx.malloc(max(lut_n, 1) * 8)
-    d_small = ctx.malloc(64)
-    d_stats, d_ob = d_small, d_small + 32
-    t_h2d = time.time()
-    ctx.h2d(d_in, img)
-    ctx.h2d(d_ps, pack_start)
-    t_h2d = time.time() - t_h2d
-
-    def step():
-        ctx.process_bin_device(p, d_in, img.size, n_rec, d_ps, packs.size, d_out, out_cap, d_ob, d_lut, d_stats, sync=True)
+    ctx = capi.Context((dev_index,))
+    pl = args.lut_prefix if args.lut_prefix >= 0 else kmc_lut_prefix_len(k, args.reads, args.bins)
+    p = capi.make_params(k, lut_prefix_len=pl)
+    want_host = is_main and world == 1 and not args.no_host_boundary
+    w = build_workload(ctx, args, k, p, rank, world, keep_host=want_host)
 
     for _ in range(args.warmup):
-        step()
+        run_step(ctx, w, args.streams)
+    ctx.scatter_totals(reset=True)
     if dist:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        step()
-    small = np.zeros(8, dtype=np.uint64)
-    ctx.d2h(small, d_small)
-    tallies = sharding.allreduce_tallies(small[:4], device=dev)  # the one RCCL collective of the path (32 bytes)
+        run_step(ctx, w, args.streams)
+    res = read_results(ctx, w)
+    own_tallies = res[:, :4].sum(axis=0, dtype=np.uint64) if w.n_own else np.zeros(4, dtype=np.uint64)
+    tallies = sharding.allreduce_tallies(own_tallies, device=dev)  # the one RCCL collective of the path (32 bytes)
     torch.cuda.synchronize()
     if dist:
         dist.barrier()
     dt = time.perf_counter() - t0
+    n_launch, sc_ms, sc_recs = ctx.scatter_totals(reset=True)
     if dist:
         tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
-        ntot = torch.tensor([n_rec], dtype=torch.int64, device=dev)
-        dist.all_reduce(ntot)
-        n_total_all = int(ntot.item())
-    else:
-        n_total_all = n_rec
+        sc = torch.tensor([float(n_launch), sc_ms, float(sc_recs)], dtype=torch.float64, device=dev)
+        dist.all_reduce(sc)
+        n_launch, sc_ms, sc_recs = int(sc[0].item()), float(sc[1].item()), int(sc[2].item())
 
-    timings = ctx.last_timings()
-    n_launch, sc_ms, sc_keys = ctx.last_scatter_stats()
+    # ---- self-checks on the timed run's own output (every rank)
+    rec_bytes = w.rec_bytes
+    ok = True
+    for i in range(w.n_own):
+        u, bmin, amax, tot, ob = (int(x) for x in res[i, :5])
+        ok &= tot == w.bins[i][2] and ob == (u - bmin - amax) * rec_bytes
+    ok &= int(tallies[3]) == w.total_kmers_all
+    digest = None
+    if not args.no_digest:
+        dg = output_digest(ctx, w, res)
+        if dist:
+            parts = [None] * world
+            dist.all_gather_object(parts, dg)
+            dg = sum(parts) & ((1 << 64) - 1)
+        digest = "%016x" % dg
+    if dist:
+        okt = torch.tensor([1 if ok else 0], dtype=torch.int64, device=dev)
+        dist.all_reduce(okt, op=dist.ReduceOp.MIN)
+        ok = bool(okt.item())
+
+    timings = ctx.last_timings() if w.n_own else {}
+    out = None
     if rank == 0:
         W = 8 * ((k + 31) // 32)
+        P = (2 * k + 7) // 8
+        kern = "k_onesweep<%d>" % ((k + 31) // 32)
         avg_ms = sc_ms / max(n_launch, 1)
-        achieved = (2 * W * sc_keys) / (avg_ms * 1e-3) / 1e9 if n_launch else 0.0
-        value = n_total_all * args.steps / dt / 1e9
-        res = {
-            "metric": "stage-2 Gk-mers/s, k=%d (bin sort & count: expand + 8-bit LSD radix sort + compaction), bit-exact vs reference KMC" % k,
+        rpl = sc_recs / max(n_launch, 1)
+        achieved = (2 * W * sc_recs) / (sc_ms * 1e-3) / 1e9 if n_launch else 0.0
+        value = w.total_kmers_all * args.steps / dt / 1e9
+        desc = (CONFIGS[name]["desc"] % k) if name in CONFIGS else f"custom: k={k}, {args.reads} reads of a {args.genome} bp genome, {args.bins} bins"
+        out = {
+            "metric": "stage-2 Gk-mers/s, k=%d (bin sort & count: parse + expand + 8-bit LSD radix sort + compaction over all signature bins)" % k,
             "value": value, "unit": "Gk-mers/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": "u64", "data": "synthetic",
-            "config": {"workload": "configs[1]: k=%d, 150 bp synthetic reads, %.2f Gbp per GPU, all k-mers of a GPU as a single bin (radix sort + count on one MI355X each)" % (k, args.reads * 150 / 1e9),
-                       "kmers_per_gpu": n_rec, "superkmers_per_gpu": n_super, "bin_image_bytes": int(img.size), "record_bytes": W,
-                       "radix_passes": (2 * k + 7) // 8, "cutoff_min": 2, "counter_max": 255, "lut_prefix_len": args.lut_prefix,
-                       "parallelism": "bins sharded, 1 process/GPU, tallies all-reduced (RCCL)" if world > 1 else "1 GPU"},
+            "config": {"workload": desc + (" on 1 MI355X" if world == 1 else f", sharded over {world} MI355X by LPT (per-GPU bin queues, RCCL tally reduce)"),
+                       "kmers": w.total_kmers_all, "superkmers": w.total_super_all, "bin_image_bytes": w.total_bytes_all, "bins": w.n_bins_all,
+                       "bins_rank0": w.n_own, "kmers_rank0": w.own_kmers, "record_bytes": W, "radix_passes": P, "cutoff_min": 2, "counter_max": 255,
+                       "lut_prefix_len": pl, "streams": args.streams or 8,
+                       "parallelism": "bins sharded over ranks (LPT), 1 process/GPU, tallies all-reduced (RCCL)" if world > 1 else "1 GPU"},
             "unique_kmers_per_s": float(tallies[0]) * args.steps / dt,
             "tallies": {"n_unique": int(tallies[0]), "n_cutoff_min": int(tallies[1]), "n_cutoff_max": int(tallies[2]), "n_total": int(tallies[3])},
-            "phases_ms_last_step": timings,
-            "stage2_algorithmic_bytes_per_kmer": W * (2 * ((2 * k + 7) // 8) + 3),
-            "stage2_algorithmic_GBs": W * (2 * ((2 * k + 7) // 8) + 3) * n_rec / (timings["total"] * 1e-3) / 1e9,
-            "roofline": {"bound": "hbm", "kernel": "k_onesweep<%d>" % ((k + 31) // 32), "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic("k_onesweep<%d>" % ((k + 31) // 32), sc_keys),
-                         "traffic_unit": "HBM bytes per launch (PMC FETCH_SIZE x2 + WRITE_SIZE, profiles/r01/final/pmc_hbm_traffic.json)",
-                         "algorithmic_bytes_per_launch": 2 * W * sc_keys, "launches_per_step": n_launch, "avg_launch_ms": avg_ms,
-                         "records_per_launch": sc_keys, "algorithmic_bytes_per_record_per_launch": 2 * W},
-            "setup_s": {"generate": t_gen, "h2d": t_h2d, "h2d_GBs": img.size / max(t_h2d, 1e-9) / 1e9},
+            "self_check": {"per_bin_total_and_out_bytes_consistent": bool(ok), "output_digest": digest},
+            "stage2_algorithmic_bytes_per_kmer": W * (2 * P + 3),
+            "stage2_algorithmic_GBs": W * (2 * P + 3) * value,
+            "stage2_frac_of_hbm_peak": W * (2 * P + 3) * value / HBM_PEAK_GBS,
+            "roofline": {"bound": "hbm", "kernel": kern, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(kern, rpl),
+                         "traffic_unit": "HBM bytes per launch (PMC FETCH_SIZE x2 + WRITE_SIZE, profiles/r02/pmc_hbm_traffic.json)",
+                         "algorithmic_bytes_per_launch": 2 * W * rpl, "launches_in_timed_region": n_launch, "avg_launch_ms": avg_ms,
+                         "records_per_launch": rpl, "algorithmic_bytes_per_record_per_launch": 2 * W,
+                         "note": "launches of up to %d bins overlap on separate streams; durations are per launch, on its own stream" % (args.streams or 8)},
+            "phases_ms_last_bin_slot0": timings,
+            "setup_s": w.setup_s,
         }
-        if world == 1 and not args.no_cpu_baseline:
+    # ---- after the timed region: host boundary, secondary workloads, the reference (rank 0 of a 1-GPU run only)
+    if rank == 0 and world == 1 and is_main:
+        if want_host:
             try:
-                res["cpu_baseline"] = cpu_baseline(k, args.cpu_sample_reads or args.reads, args.genome if not args.cpu_sample_reads else max(args.genome * args.cpu_sample_reads // args.reads, 1_000_000))
+                secs, ht, t_pin, nth = host_boundary_pass(ctx, w)
+                out["value_host_boundary"] = w.total_kmers_all / secs / 1e9
+                out["host_boundary"] = {"what": "the same bins through kmc_hip_process_bin_submit/_wait from pinned host memory, %d host threads x 2 stream "
+                                                "slots (H2D + kernels + D2H of every bin; PCIe inclusive), best of 2 passes" % nth,
+                                        "seconds": secs, "bytes_in": w.total_bytes_all, "bytes_out": int(ht[4]), "pin_and_stage_s": t_pin,
+                                        "tallies_equal_device_resident": [int(x) for x in ht[:4]] == [int(x) for x in tallies]}
+            except Exception as e:  # noqa: BLE001
+                out["host_boundary"] = {"error": repr(e)}
+        w.free()
+        w.host_imgs = []
+        if w.sb:
+            w.sb.close()
+        if not args.no_secondary:
+            sec = {}
+            s1 = secondary_leg("configs[1]", k, [])
+            sec["single_bin"] = {kk: s1.get(kk) for kk in ("value", "ms_per_step", "config", "roofline", "tallies", "phases_ms_last_bin_slot0", "stage2_frac_of_hbm_peak", "error") if kk in s1}
+            s2 = secondary_leg("2gbp-512bins", k, [])
+            sec["bins512_2gbp"] = {kk: s2.get(kk) for kk in ("value", "ms_per_step", "config", "roofline", "tallies", "stage2_frac_of_hbm_peak", "error") if kk in s2}
+            out["secondary"] = sec
+        if not args.no_cpu_baseline:
+            try:
+                legs = reference_legs(k, CONFIGS["2gbp-512bins"]["reads"], CONFIGS["2gbp-512bins"]["genome"])
+                out.update(legs)
+                s2t = out.get("secondary", {}).get("bins512_2gbp", {}).get("tallies")
+                st = legs["cpu_baseline"]["stats"]
+                if s2t:
+                    out["self_check"]["gpu_tallies_equal_reference_on_2gbp_sample"] = (
+                        s2t["n_unique"] == st["unique"] and s2t["n_cutoff_min"] == st["below_min"] and s2t["n_cutoff_max"] == st["above_max"]
+                        and s2t["n_total"] == st["total"])
             except Exception as e:  # the baseline is informative; never lose the GPU number over it
-                res["cpu_baseline"] = {"value": None, "unit": "Gk-mers/s", "cores": 0, "kind": "reference", "sample": f"failed: {e}"}
-        print(json.dumps(res))
+                out["cpu_baseline"] = {"value": None, "unit": "Gk-mers/s", "cores": 0, "kind": "reference", "sample": f"failed: {e}"}
+    if rank == 0:
+        print(json.dumps(out))
     if dist:
         dist.destroy_process_group()
     ctx.close()

@@ -295,33 +295,80 @@ class Context:
 _SYN = None
 
 
-def synth_bins(seed: int, genome_len: int, n_reads: int, k: int, n_bins: int = 1, read_len: int = 150, err: float = 0.01,
-               sig_len: int = 9, n_threads: int = 0):
-    """Returns a list of (image uint8 ndarray, n_rec, pack_bytes uint64 ndarray, n_super) per bin."""
+def _syn():
     global _SYN
     if _SYN is None:
         p = _build.LIB_SYNTH
         if not os.path.exists(p):
             _build.build_synth()
         _SYN = C.CDLL(p)
-        _SYN.kmc_synth_bins.restype = C.c_void_p
-        _SYN.kmc_synth_bins.argtypes = [C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint32, C.c_double, C.c_uint32, C.c_uint32, C.c_uint32,
-                                        C.c_int, C.POINTER(C.POINTER(u8p)), C.POINTER(u64p), C.POINTER(u64p),
-                                        C.POINTER(C.POINTER(u64p)), C.POINTER(u64p), C.POINTER(u64p)]
+        _SYN.kmc_synth_bins_range.restype = C.c_void_p
+        _SYN.kmc_synth_bins_range.argtypes = [C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint32, C.c_double, C.c_uint32, C.c_uint32,
+                                              C.c_uint32, C.c_int, C.POINTER(C.POINTER(u8p)), C.POINTER(u64p), C.POINTER(u64p),
+                                              C.POINTER(C.POINTER(u64p)), C.POINTER(u64p), C.POINTER(u64p)]
         _SYN.kmc_synth_free.argtypes = [C.c_void_p]
         _SYN.kmc_synth_free.restype = None
+        _SYN.kmc_synth_chunk_reads.restype = C.c_uint64
+        _SYN.kmc_synth_fastq.restype = C.c_uint64
+        _SYN.kmc_synth_fastq.argtypes = [C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint32, C.c_double, C.c_char_p, C.c_int]
+    return _SYN
+
+
+def synth_chunk_reads() -> int:
+    """read ranges given to synth_bins(read_begin=...) must start on a multiple of this"""
+    return int(_syn().kmc_synth_chunk_reads())
+
+
+class SynthBins:
+    """Bin images made by libkmc_synth.so, as zero-copy views into its buffers (valid until close())."""
+
+    def __init__(self, handle, bins):
+        self._h = handle
+        self.bins = bins  # list of (image uint8 view, n_rec, pack_bytes uint64 view, n_super)
+
+    def close(self):
+        if self._h:
+            self.bins = []
+            _syn().kmc_synth_free(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def synth_bins(seed: int, genome_len: int, n_reads: int, k: int, n_bins: int = 1, read_len: int = 150, err: float = 0.01,
+               sig_len: int = 9, n_threads: int = 0, read_begin: int = 0, read_end=None, copy: bool = True):
+    """Bins of reads [read_begin, read_end) (default: all n_reads) of the model. copy=True returns a list of
+    (image uint8 ndarray, n_rec, pack_bytes uint64 ndarray, n_super) per bin; copy=False returns a SynthBins holding views."""
+    S = _syn()
+    if read_end is None:
+        read_end = n_reads
     imgs, sizes, nrec, packs, npacks, nsup = C.POINTER(u8p)(), u64p(), u64p(), C.POINTER(u64p)(), u64p(), u64p()
-    h = _SYN.kmc_synth_bins(seed, genome_len, n_reads, read_len, err, k, sig_len, n_bins, n_threads, C.byref(imgs), C.byref(sizes),
-                            C.byref(nrec), C.byref(packs), C.byref(npacks), C.byref(nsup))
+    h = S.kmc_synth_bins_range(seed, genome_len, read_begin, read_end, read_len, err, k, sig_len, n_bins, n_threads, C.byref(imgs),
+                               C.byref(sizes), C.byref(nrec), C.byref(packs), C.byref(npacks), C.byref(nsup))
     if not h:
         raise ValueError("kmc_synth_bins: bad arguments or out of memory")
     out = []
-    try:
-        for b in range(n_bins):
-            sz = sizes[b]
-            img = np.ctypeslib.as_array(imgs[b], shape=(sz,)).copy() if sz else np.zeros(0, dtype=np.uint8)
-            pk = np.ctypeslib.as_array(packs[b], shape=(npacks[b],)).copy() if npacks[b] else np.zeros(0, dtype=np.uint64)
-            out.append((img, int(nrec[b]), pk, int(nsup[b])))
-    finally:
-        _SYN.kmc_synth_free(h)
-    return out
+    for b in range(n_bins):
+        sz = sizes[b]
+        img = np.ctypeslib.as_array(imgs[b], shape=(sz,)) if sz else np.zeros(0, dtype=np.uint8)
+        pk = np.ctypeslib.as_array(packs[b], shape=(npacks[b],)) if npacks[b] else np.zeros(0, dtype=np.uint64)
+        if copy:
+            img, pk = img.copy(), pk.copy()
+        out.append((img, int(nrec[b]), pk, int(nsup[b])))
+    if copy:
+        S.kmc_synth_free(h)
+        return out
+    return SynthBins(h, out)
+
+
+def synth_fastq(path: str, seed: int, genome_len: int, n_reads: int, read_len: int = 150, err: float = 0.01, n_threads: int = 0,
+                read_begin: int = 0) -> int:
+    """The same reads synth_bins() cuts into bins, as FASTQ (for the reference kmc). Returns bytes written."""
+    n = _syn().kmc_synth_fastq(seed, genome_len, read_begin, n_reads, read_len, err, path.encode(), n_threads)
+    if not n:
+        raise OSError(f"kmc_synth_fastq could not write {path}")
+    return int(n)

@@ -53,6 +53,7 @@ constexpr u32 SPIN_LIMIT = 1u << 24;                                            
 template <int SIZE> struct RsCfg { /* records per thread in a scatter tile: RS_WORDS_PER_THREAD x 8 B per thread for every SIZE */
 	static constexpr int ITEMS = (RS_WORDS_PER_THREAD / SIZE) > 2 ? (RS_WORDS_PER_THREAD / SIZE) : 2;
 	static constexpr int TILE = RS_BLOCK * ITEMS;
+	static_assert(TILE <= 32768, "tile-relative slots are kept as 16-bit values (0xFFFF marks an absent record)");
 	static constexpr int STAGES = (ITEMS % RS_STAGES_REQ == 0) ? RS_STAGES_REQ : 1; /* LDS staging slices per tile */
 };
 #ifndef CP_WORDS_PER_THREAD
@@ -225,7 +226,7 @@ __global__ void __launch_bounds__(256) k_parse_packs(const uint8_t *__restrict__
 	 *       latency pipelines)
 	 *   L2  one lane hops sub-block to sub-block from the chunk's entry offset: 32 dependent LDS reads instead of ~500
 	 *   L3  one lane per sub-block walks it from its now-known entry and builds the sub-block's 128 start bits */
-	__shared__ uint8_t s_b[PARSE_CHUNK];
+	__shared__ __attribute__((aligned(16))) uint8_t s_b[PARSE_CHUNK];
 	__shared__ unsigned short s_X[PARSE_CHUNK];
 	__shared__ unsigned short s_ent[PARSE_NSUB]; /* entry position + 1 of each sub-block (0 = chain does not start here) */
 	__shared__ u32 s_vis[PARSE_CHUNK / 32];
@@ -235,15 +236,28 @@ __global__ void __launch_bounds__(256) k_parse_packs(const uint8_t *__restrict__
 	if (p >= n_packs)
 		return;
 	const u64 pos0 = pack_start[p], end = pack_start[p + 1];
-	u32 entry = 0; /* offset inside the current chunk of the first record start */
-	for (u64 c0 = pos0; c0 < end; c0 += PARSE_CHUNK) {
-		const u32 clen = (end - c0) < (u64)PARSE_CHUNK ? (u32)(end - c0) : (u32)PARSE_CHUNK;
+	/* Chunks are cut at multiples of PARSE_CHUNK of the IMAGE (not of the pack), and the first one starts at the 16-byte boundary
+	 * below the pack start: every chunk is staged with one aligned 16-byte load per thread (byte loads cost 16 instructions per
+	 * thread and chunk). The few bytes in front of the pack are never visited: the chain starts at `entry`. */
+	u32 entry = (u32)(pos0 & 15); /* offset inside the current chunk of the first record start */
+	u64 c_next = pos0 & ~15ull;
+	while (c_next < end) {
+		const u64 c0 = c_next;
+		const u64 bound = ((c0 >> 12) + 1) << 12;
+		static_assert(PARSE_CHUNK == 4096, "chunk boundaries are computed with shifts");
+		const u64 c1 = bound < end ? bound : end;
+		const u32 clen = (u32)(c1 - c0);
+		c_next = c1;
 		if (entry >= clen) { /* only for a ragged image; the final check below reports it */
 			entry -= clen;
 			continue;
 		}
-		for (u32 i = tid; i < clen; i += 256)
-			s_b[i] = data[c0 + i];
+		{
+			const uint4 *g = reinterpret_cast<const uint4 *>(data + c0); /* 16-byte aligned; the image has >= 256 readable bytes of slack */
+			uint4 *l = reinterpret_cast<uint4 *>(s_b);
+			if (tid * 16 < clen)
+				l[tid] = g[tid];
+		}
 		if (tid < PARSE_NSUB)
 			s_ent[tid] = 0;
 		__syncthreads();
@@ -540,10 +554,12 @@ __global__ void __launch_bounds__(EXP_BLOCK) k_expand(const uint8_t *__restrict_
 						kmc_canonical_at<SIZE>(s_b + s_skpos[si] + 1, off, k, both_strands != 0, v);
 					}
 					store_rec<SIZE>(out + gj * SIZE, v);
+#ifndef EXP_NO_HIST /* tuning builds only (-DEXP_NO_HIST): what do the fused histograms cost? (the sort is garbage then) */
 					if (FUSE_HIST) {
 						for (u32 b = 0; b < n_pass; ++b)
 							atomicAdd(&s_h[b * 256 + kmc_get_byte<SIZE>(v, b)], 1u);
 					}
+#endif
 				}
 			}
 			__syncthreads();
@@ -697,7 +713,7 @@ __global__ void __launch_bounds__(RS_BLOCK, (SIZE <= 4 ? RS_MIN_WAVES : RS_MIN_W
 		auto tile_body = [&](auto full_tag) __attribute__((always_inline)) {
 		constexpr bool FULL = decltype(full_tag)::value;
 		u64 key[ITEMS][SIZE];
-		u32 rank[ITEMS];
+		u32 rank2[(ITEMS + 1) / 2]; /* tile-relative slots (< TILE <= 16384), two per register */
 		const u32 wbase = wave * (ITEMS * 64) + lane;
 #pragma unroll
 		for (int r = 0; r < ITEMS; ++r) {
@@ -761,7 +777,11 @@ __global__ void __launch_bounds__(RS_BLOCK, (SIZE <= 4 ? RS_MIN_WAVES : RS_MIN_W
 		/* ---- step 4: ranking. The slot counter read in round r is consumed one round later, the lowest peer advances
 		 * it with a NON-returning LDS add: LDS executes one wave's operations in order, so the read of round r+1 sees
 		 * the add of round r and nothing waits on LDS inside a round. */
-		u32 below_prev = 0;
+		u32 below_prev = 0, base_prev = 0;
+#pragma unroll
+		for (int r = 0; r < ITEMS; ++r)
+			if ((r & 1) == 0)
+				rank2[r >> 1] = 0;
 #pragma unroll
 		for (int r = 0; r < ITEMS; ++r) {
 			const bool valid = FULL || (wbase + r * 64) < tile_n;
@@ -778,21 +798,20 @@ __global__ void __launch_bounds__(RS_BLOCK, (SIZE <= 4 ? RS_MIN_WAVES : RS_MIN_W
 				hi = __builtin_amdgcn_bitop3_b32(sb, hi, (u32)(m >> 32), 0x84);
 			}
 			const u32 below = __builtin_amdgcn_mbcnt_hi(hi, __builtin_amdgcn_mbcnt_lo(lo, 0));
-			if (r > 0)
-				rank[r - 1] += below_prev;
+			if (r > 0) {
+				const u32 full = (!FULL && (wbase + (r - 1) * 64) >= tile_n) ? 0xFFFFu : (base_prev + below_prev);
+				rank2[(r - 1) >> 1] |= full << (((r - 1) & 1) * 16);
+			}
 			u32 *ctr = &s_whist[wave * 256 + d];
-			rank[r] = __hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); /* other lanes add to it */
+			base_prev = __hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); /* other lanes add to it */
 			if (valid && below == 0)
 				(void)__hip_atomic_fetch_add(ctr, (u32)(__popc(lo) + __popc(hi)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 			below_prev = below;
 			__builtin_amdgcn_sched_barrier(0); /* keep rounds in order: interleaving them only inflates SGPR/VGPR live ranges */
 		}
-		rank[ITEMS - 1] += below_prev;
-		if (!FULL) {
-#pragma unroll
-			for (int r = 0; r < ITEMS; ++r)
-				if ((wbase + r * 64) >= tile_n)
-					rank[r] = 0xFFFFFFFFu;
+		{
+			const u32 full = (!FULL && (wbase + (ITEMS - 1) * 64) >= tile_n) ? 0xFFFFu : (base_prev + below_prev);
+			rank2[(ITEMS - 1) >> 1] |= full << (((ITEMS - 1) & 1) * 16);
 		}
 		TRACE_STAMP(0, tile, 4);
 
@@ -859,7 +878,7 @@ __global__ void __launch_bounds__(RS_BLOCK, (SIZE <= 4 ? RS_MIN_WAVES : RS_MIN_W
 				break;
 #pragma unroll
 			for (int r = 0; r < ITEMS; ++r) {
-				const u32 rel = rank[r] - lo;
+				const u32 rel = ((rank2[r >> 1] >> ((r & 1) * 16)) & 0xFFFFu) - lo; /* invalid records carry 0xFFFF: never inside a slice */
 				if (rel < (u32)STAGE_N) {
 #pragma unroll
 					for (int w = 0; w < SIZE; ++w)
@@ -913,20 +932,14 @@ template <int SIZE> constexpr size_t rs_lds_bytes()
  * atomics (+end, -begin) instead of one per k-mer. */
 
 template <int SIZE>
-__device__ __forceinline__ u64 run_start_search(const u64 *__restrict__ S, u64 base, u32 lane)
+__device__ __forceinline__ u64 run_start_search(const u64 *__restrict__ S, u64 base, u32 lane, const u64 (&v)[SIZE], bool eq_below)
 {
-	/* smallest i <= base with S[i] == S[base]; executed by one full wave */
-	u64 v[SIZE];
-	load_rec<SIZE>(S + base * SIZE, v);
+	/* smallest i <= base with S[i] == S[base] (= v); executed by one full wave. `eq_below`: lane l's verdict on
+	 * S[base-1-l] == v, from records that were loaded together with the tile (no dependent round trip in the common case:
+	 * a run that crosses the tile boundary almost always starts within the 64 records below it). */
 	u64 lo = 0, hi = base;
 	{ /* round 1: the 64 records just below the tile */
-		bool eq = false;
-		if (base >= (u64)lane + 1) {
-			u64 x[SIZE];
-			load_rec<SIZE>(S + (base - 1 - lane) * SIZE, x);
-			eq = kmc_equal<SIZE>(x, v);
-		}
-		const u64 mask = __ballot(eq);
+		const u64 mask = __ballot(eq_below);
 		if (~mask)
 			return base - (u64)(__ffsll(~mask) - 1);
 		hi = base - 64;
@@ -979,6 +992,7 @@ __global__ void __launch_bounds__(CP_BLOCK, CP_MIN_WAVES) k_compact(const u64 *_
 	__shared__ u32 s_tal[3];
 	__shared__ u32 s_tile, s_need;
 	__shared__ u64 s_run_start, s_tile_off;
+	__shared__ u64 s_first[SIZE]; /* the tile's first record, for the wave that resolves a run crossing the tile boundary */
 
 	if (threadIdx.x == 0)
 		s_tile = atomicAdd(tile_counter, 1u);
@@ -1018,6 +1032,20 @@ __global__ void __launch_bounds__(CP_BLOCK, CP_MIN_WAVES) k_compact(const u64 *_
 			load_rec<SIZE>(S + (first - 1) * SIZE, prev);
 		if (have_next)
 			load_rec<SIZE>(S + (first + cnt_t) * SIZE, next);
+		/* the last wave also fetches the 64 records below the tile now (one coalesced load that travels with the tile's own):
+		 * 3 of 4 tiles start inside a run, and finding that run's start used to cost a dependent round trip + jitter in
+		 * front of the look-back */
+		u64 below[SIZE];
+		bool have_below = false;
+		if (wave == CP_BLOCK / 64 - 1 && base >= (u64)lane + 1) {
+			load_rec<SIZE>(S + (base - 1 - lane) * SIZE, below);
+			have_below = true;
+		}
+		if (tid == 0 && cnt_t > 0) {
+#pragma unroll
+			for (int w = 0; w < SIZE; ++w)
+				s_first[w] = key[0][w];
+		}
 
 		/* pass A: head/tail flags, last head position in this thread (as index+1, 0 = none) */
 		u32 head_bits = 0, tail_bits = 0;
@@ -1055,8 +1083,12 @@ __global__ void __launch_bounds__(CP_BLOCK, CP_MIN_WAVES) k_compact(const u64 *_
 		if (pending)
 			s_need = 1;
 		__syncthreads();
-		if (s_need && wave == 0) {
-			const u64 st = run_start_search<SIZE>(S, base, lane);
+		if (s_need && wave == CP_BLOCK / 64 - 1) {
+			u64 v[SIZE];
+#pragma unroll
+			for (int w = 0; w < SIZE; ++w)
+				v[w] = s_first[w];
+			const u64 st = run_start_search<SIZE>(S, base, lane, v, have_below && kmc_equal<SIZE>(below, v));
 			if (lane == 0)
 				s_run_start = st;
 		}

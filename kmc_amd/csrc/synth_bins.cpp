@@ -12,6 +12,7 @@
  */
 #include <algorithm>
 #include <cstdint>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <thread>
@@ -66,11 +67,45 @@ void put_superkmer(BinBuf &b, const uint8_t *sym, uint32_t n, uint32_t k)
 	b.n_rec += n - k + 1;
 }
 
+/* read r of the model: window at a uniform start, per-base substitution with probability err, random strand */
+inline void make_read(uint64_t seed, const std::vector<uint8_t> &genome, uint64_t r, uint32_t L, uint64_t err_thr, std::vector<uint8_t> &rd)
+{
+	const uint64_t G = genome.size();
+	Rng g(seed, r);
+	const uint64_t st = g.next() % (G - L + 1);
+	const bool flip = g.next() & 1;
+	for (uint32_t i = 0; i < L; ++i) {
+		uint8_t s = genome[st + i];
+		if (g.next() < err_thr)
+			s = (uint8_t)((s + 1 + g.next() % 3) & 3);
+		rd[i] = s;
+	}
+	if (flip) {
+		std::reverse(rd.begin(), rd.end());
+		for (auto &s : rd)
+			s = 3 - s;
+	}
+}
+
+void make_genome(uint64_t seed, uint64_t genome_len, int n_threads, std::vector<uint8_t> &genome)
+{
+	genome.resize(genome_len);
+	std::vector<std::thread> th;
+	const uint64_t per = (genome_len + n_threads - 1) / n_threads;
+	for (int t = 0; t < n_threads; ++t)
+		th.emplace_back([&, t] {
+			const uint64_t a = t * per, b = std::min(genome_len, a + per);
+			for (uint64_t i = a; i < b; ++i)
+				genome[i] = (uint8_t)(mix64(seed * 0x100000001B3ull + i) & 3);
+		});
+	for (auto &x : th)
+		x.join();
+}
+
 void gen_chunk(uint64_t seed, const std::vector<uint8_t> &genome, uint64_t r0, uint64_t r1, uint32_t L, double err, uint32_t k, uint32_t m,
                uint32_t n_bins, Chunk &out)
 {
 	out.bins.assign(n_bins, BinBuf());
-	const uint64_t G = genome.size();
 	const uint64_t err_thr = (uint64_t)(err * 18446744073709551615.0);
 	std::vector<uint8_t> rd(L);
 	std::vector<uint32_t> mm(L), mn(L);
@@ -78,20 +113,7 @@ void gen_chunk(uint64_t seed, const std::vector<uint8_t> &genome, uint64_t r0, u
 	const uint32_t mmask = (m < 16) ? ((1u << (2 * m)) - 1) : 0xFFFFFFFFu;
 	std::vector<uint32_t> dq(L);
 	for (uint64_t r = r0; r < r1; ++r) {
-		Rng g(seed, r);
-		const uint64_t st = g.next() % (G - L + 1);
-		const bool flip = g.next() & 1;
-		for (uint32_t i = 0; i < L; ++i) {
-			uint8_t s = genome[st + i];
-			if (g.next() < err_thr)
-				s = (uint8_t)((s + 1 + g.next() % 3) & 3);
-			rd[i] = s;
-		}
-		if (flip) {
-			std::reverse(rd.begin(), rd.end());
-			for (auto &s : rd)
-				s = 3 - s;
-		}
+		make_read(seed, genome, r, L, err_thr, rd);
 		/* canonical m-mers */
 		uint32_t f = 0, rc = 0;
 		for (uint32_t i = 0; i < L; ++i) {
@@ -141,29 +163,23 @@ struct Result {
 
 extern "C" {
 
-/* Generate `n_bins` bin images. Arrays of length n_bins are returned through the out_* pointers (malloc'ed; free
- * everything with kmc_synth_free(handle)). Returns an opaque handle or NULL. */
-void *kmc_synth_bins(uint64_t seed, uint64_t genome_len, uint64_t n_reads, uint32_t read_len, double err, uint32_t k, uint32_t sig_len,
-                     uint32_t n_bins, int n_threads, uint8_t ***out_images, uint64_t **out_sizes, uint64_t **out_n_rec,
-                     uint64_t ***out_pack_bytes, uint64_t **out_n_packs, uint64_t **out_n_super)
+/* Generate `n_bins` bin images from reads [read_begin, read_end) of the model (read r is a pure function of (seed, r), and every
+ * READS_PER_CHUNK-aligned chunk of reads closes its own expander packs, so images made from chunk-aligned sub-ranges concatenate,
+ * bin by bin, to exactly the image of the whole range: bench.py --gpus N generates 1/N of the reads per rank). Arrays of length
+ * n_bins are returned through the out_* pointers (malloc'ed; free everything with kmc_synth_free(handle)). Returns an opaque
+ * handle or NULL. */
+void *kmc_synth_bins_range(uint64_t seed, uint64_t genome_len, uint64_t read_begin, uint64_t read_end, uint32_t read_len, double err, uint32_t k,
+                           uint32_t sig_len, uint32_t n_bins, int n_threads, uint8_t ***out_images, uint64_t **out_sizes, uint64_t **out_n_rec,
+                           uint64_t ***out_pack_bytes, uint64_t **out_n_packs, uint64_t **out_n_super)
 {
-	if (k < sig_len || sig_len < 1 || sig_len > 15 || read_len < k || genome_len < read_len || n_bins < 1 || k > 256)
+	if (k < sig_len || sig_len < 1 || sig_len > 15 || read_len < k || genome_len < read_len || n_bins < 1 || k > 256 || read_end < read_begin ||
+	    read_begin % READS_PER_CHUNK)
 		return nullptr;
 	if (n_threads < 1)
 		n_threads = (int)std::max(1u, std::thread::hardware_concurrency());
-	std::vector<uint8_t> genome(genome_len);
-	{
-		std::vector<std::thread> th;
-		const uint64_t per = (genome_len + n_threads - 1) / n_threads;
-		for (int t = 0; t < n_threads; ++t)
-			th.emplace_back([&, t] {
-				const uint64_t a = t * per, b = std::min(genome_len, a + per);
-				for (uint64_t i = a; i < b; ++i)
-					genome[i] = (uint8_t)(mix64(seed * 0x100000001B3ull + i) & 3);
-			});
-		for (auto &x : th)
-			x.join();
-	}
+	std::vector<uint8_t> genome;
+	make_genome(seed, genome_len, n_threads, genome);
+	const uint64_t n_reads = read_end - read_begin;
 	const uint64_t n_chunks = (n_reads + READS_PER_CHUNK - 1) / READS_PER_CHUNK;
 	std::vector<Chunk> chunks(n_chunks);
 	{
@@ -171,8 +187,8 @@ void *kmc_synth_bins(uint64_t seed, uint64_t genome_len, uint64_t n_reads, uint3
 		for (int t = 0; t < n_threads; ++t)
 			th.emplace_back([&, t] {
 				for (uint64_t c = t; c < n_chunks; c += n_threads)
-					gen_chunk(seed, genome, c * READS_PER_CHUNK, std::min(n_reads, (c + 1) * READS_PER_CHUNK), read_len, err, k, sig_len,
-					          n_bins, chunks[c]);
+					gen_chunk(seed, genome, read_begin + c * READS_PER_CHUNK, read_begin + std::min(n_reads, (c + 1) * READS_PER_CHUNK), read_len,
+					          err, k, sig_len, n_bins, chunks[c]);
 			});
 		for (auto &x : th)
 			x.join();
@@ -228,6 +244,76 @@ void *kmc_synth_bins(uint64_t seed, uint64_t genome_len, uint64_t n_reads, uint3
 	if (out_n_super)
 		*out_n_super = R->n_super.data();
 	return R;
+}
+
+void *kmc_synth_bins(uint64_t seed, uint64_t genome_len, uint64_t n_reads, uint32_t read_len, double err, uint32_t k, uint32_t sig_len,
+                     uint32_t n_bins, int n_threads, uint8_t ***out_images, uint64_t **out_sizes, uint64_t **out_n_rec,
+                     uint64_t ***out_pack_bytes, uint64_t **out_n_packs, uint64_t **out_n_super)
+{
+	return kmc_synth_bins_range(seed, genome_len, 0, n_reads, read_len, err, k, sig_len, n_bins, n_threads, out_images, out_sizes, out_n_rec,
+	                            out_pack_bytes, out_n_packs, out_n_super);
+}
+
+uint64_t kmc_synth_chunk_reads(void) { return READS_PER_CHUNK; }
+
+/* The SAME reads [read_begin, read_end) as 4-line FASTQ ("@r<id>", bases, "+", quality 'I'), so that the reference kmc can be run on
+ * exactly the k-mer multiset the synthetic bins hold (bench.py compares its tallies with the GPU's). Returns bytes written, 0 on error. */
+uint64_t kmc_synth_fastq(uint64_t seed, uint64_t genome_len, uint64_t read_begin, uint64_t read_end, uint32_t read_len, double err,
+                         const char *path, int n_threads)
+{
+	if (genome_len < read_len || read_end < read_begin || !path)
+		return 0;
+	if (n_threads < 1)
+		n_threads = (int)std::max(1u, std::thread::hardware_concurrency());
+	std::vector<uint8_t> genome;
+	make_genome(seed, genome_len, n_threads, genome);
+	FILE *f = fopen(path, "wb");
+	if (!f)
+		return 0;
+	const uint64_t err_thr = (uint64_t)(err * 18446744073709551615.0);
+	const uint32_t L = read_len;
+	const uint64_t rec = 1 + 1 + 12 + 1 + L + 1 + 1 + 1 + L + 1; /* "@r" + 12 digits + "\n" + bases + "\n+\n" + qualities + "\n" */
+	const uint64_t BATCH = 1 << 20; /* reads per write */
+	std::vector<char> buf(BATCH * rec);
+	uint64_t total = 0;
+	bool ok = true;
+	for (uint64_t b0 = read_begin; b0 < read_end && ok; b0 += BATCH) {
+		const uint64_t b1 = std::min(read_end, b0 + BATCH), nb = b1 - b0;
+		std::vector<std::thread> th;
+		const uint64_t per = (nb + n_threads - 1) / n_threads;
+		for (int t = 0; t < n_threads; ++t)
+			th.emplace_back([&, t] {
+				std::vector<uint8_t> rd(L);
+				const uint64_t a = b0 + t * per, e = std::min(b1, a + per);
+				for (uint64_t r = a; r < e; ++r) {
+					make_read(seed, genome, r, L, err_thr, rd);
+					char *p = buf.data() + (r - b0) * rec;
+					*p++ = '@';
+					*p++ = 'r';
+					uint64_t id = r;
+					for (int d = 11; d >= 0; --d) {
+						p[d] = (char)('0' + id % 10);
+						id /= 10;
+					}
+					p += 12;
+					*p++ = '\n';
+					for (uint32_t i = 0; i < L; ++i)
+						*p++ = "ACGT"[rd[i]];
+					*p++ = '\n';
+					*p++ = '+';
+					*p++ = '\n';
+					memset(p, 'I', L);
+					p += L;
+					*p++ = '\n';
+				}
+			});
+		for (auto &x : th)
+			x.join();
+		ok = fwrite(buf.data(), 1, nb * rec, f) == nb * rec;
+		total += nb * rec;
+	}
+	ok = (fclose(f) == 0) && ok;
+	return ok ? total : 0;
 }
 
 void kmc_synth_free(void *handle)

@@ -359,3 +359,243 @@ def test_sort_and_bin_cross_portion_boundaries(monkeypatch):
         c2.close()
         monkeypatch.delenv("KMC_HIP_DEBUG_PORTION_LOG2")
         capi.Context((0,)).close()  # kmc_hip_init re-reads the variable: the session's context is back on full portions
+
+
+# ------------------------------------------------------------------------------------------------ many bins in one call
+def _run_batch(ctx, p, bins, n_streams=0, shrink_cap_of=None):
+    """bins: list of (image, n_rec, pack_bytes, ...). Uploads everything, ONE kmc_hip_process_bins_device call, returns per bin
+    (out bytes array, lut array, stats[4])."""
+    rec = ctx.out_rec_bytes(p)
+    nl = ctx.lut_entries(p)
+    n = len(bins)
+    descs = (capi.BinDesc * n)()
+    allocs, caps = [], []
+    for i, b in enumerate(bins):
+        img, nrec, packs = b[0], b[1], b[2]
+        ps = np.concatenate([[0], np.cumsum(packs)]).astype(np.uint64)
+        cap = ((nrec + 1) // max(p.cutoff_min, 1)) * rec
+        if shrink_cap_of is not None and i == shrink_cap_of:
+            cap = rec  # room for one record only
+        d_in = ctx.malloc(img.size + 256)
+        d_ps = ctx.malloc(ps.nbytes)
+        d_out = ctx.malloc(cap + 256)
+        d_lut = ctx.malloc(max(nl, 1) * 8)
+        d_small = ctx.malloc(64)
+        ctx.h2d(d_in, np.concatenate([img, np.zeros(256, dtype=np.uint8)]))
+        ctx.h2d(d_ps, ps)
+        allocs.append((d_in, d_ps, d_out, d_lut, d_small))
+        caps.append(cap)
+        descs[i] = capi.BinDesc(d_in, img.size, nrec, d_ps, packs.size, d_out, cap, d_small + 32, d_lut, d_small)
+    err = None
+    try:
+        ctx.process_bins_device(p, descs, n_streams)
+        ctx.synchronize()
+    except capi.KmcHipError as e:
+        err = e
+    out = []
+    for i in range(n):
+        small = np.zeros(8, dtype=np.uint64)
+        ctx.d2h(small, allocs[i][4])
+        ob = int(small[4])
+        o = np.zeros(min(ob, caps[i]), dtype=np.uint8)
+        if o.size:
+            ctx.d2h(o, allocs[i][2])
+        lut = np.zeros(max(nl, 1), dtype=np.uint64)
+        if nl:
+            ctx.d2h(lut, allocs[i][3])
+        out.append((o, lut[:nl], small[:4].copy()))
+    for a in allocs:
+        for d in a:
+            ctx.free(d)
+    return out, err
+
+
+@pytest.mark.parametrize("n_bins,reads,genome,pl,streams", [(512, 400_000, 2_000_000, 7, 0), (16, 400_000, 2_000_000, 7, 3), (64, 60_000, 300_000, 3, 16)])
+def test_many_bins_in_one_call_match_the_oracle_per_bin(ctx, n_bins, reads, genome, pl, streams):
+    """configs[2]'s shape in small: one read set cut into signature bins (30x coverage, lut_prefix_len 7 as KMC picks for 30 Gbp),
+    ALL bins through ONE kmc_hip_process_bins_device call (bin i on stream i mod n_streams, several host threads enqueueing),
+    every bin compared with the oracle bit for bit — suffix records, LUT, tallies."""
+    bins = capi.synth_bins(seed=2026, genome_len=genome, n_reads=reads, k=27, n_bins=n_bins)
+    p = hp(27, lut_prefix_len=pl)
+    got, err = _run_batch(ctx, p, bins, streams)
+    assert err is None, err
+    tot = np.zeros(4, dtype=np.uint64)
+    for i, (img, nrec, packs, _) in enumerate(bins):
+        w_out, w_lut, w_st = O.process_bin(op(p), img, nrec)
+        assert np.array_equal(got[i][2], w_st), (i, got[i][2], w_st)
+        assert np.array_equal(got[i][0], w_out), (i, _first_diff(got[i][0], w_out))
+        assert np.array_equal(got[i][1], w_lut), i
+        tot += w_st
+    assert int(tot[3]) == sum(b[1] for b in bins)
+
+
+def test_deferred_device_error_of_an_early_async_bin_is_not_lost(ctx):
+    """an error raised by an asynchronous bin used to be wiped by the next bin on the same stream slot. 40 bins on
+    2 streams, bin 1's out_capacity holds one record: kmc_hip_synchronize must still report KMC_HIP_ECAPACITY, the other bins
+    must be correct, and the error must be gone afterwards."""
+    bins = capi.synth_bins(seed=3, genome_len=100_000, n_reads=20_000, k=27, n_bins=40)
+    p = hp(27, cutoff_min=1)
+    got, err = _run_batch(ctx, p, bins, n_streams=2, shrink_cap_of=1)
+    assert err is not None and err.code == -5, err
+    for i, (img, nrec, packs, _) in enumerate(bins):
+        if i == 1:
+            continue
+        w_out, w_lut, w_st = O.process_bin(op(p), img, nrec)
+        assert np.array_equal(got[i][2], w_st) and np.array_equal(got[i][0], w_out) and np.array_equal(got[i][1], w_lut), i
+    ctx.synchronize()  # the sticky word was cleared by the failing synchronize
+    got, err = _run_batch(ctx, p, bins[:4], n_streams=2)
+    assert err is None
+
+
+def test_size_and_n_rec_must_both_be_zero_or_neither(ctx):
+    rng = np.random.default_rng(5)
+    img, nk, packs = binsynth.random_bin(rng, 27, 50)
+    for image, n in ((img, 0), (np.zeros(0, dtype=np.uint8), 7)):
+        with pytest.raises(capi.KmcHipError) as e:
+            ctx.process_bin(hp(27), image, n, packs if image.size else None)
+        assert e.value.code == -4
+
+
+def test_sort_records_into_a_second_buffer(ctx):
+    """kmc_hip_sort_records_into: what the SortFunction adapter binds (result in `tmp` when rec_len is odd)."""
+    rng = np.random.default_rng(77)
+    for n in (0, 1, 70_001):
+        a = rng.integers(0, 2**54, size=(n, 1), dtype=np.uint64)
+        src, dst = a.copy(), np.zeros_like(a)
+        rc = ctx.L.kmc_hip_sort_records_into(ctx.h, 0, src.ctypes.data_as(C.c_void_p), dst.ctypes.data_as(C.c_void_p), n, 1, 7)
+        assert rc == 0
+        assert np.array_equal(src, a) or n < 2  # the source is not required to survive, but is not written for n >= 2 either
+        assert np.array_equal(dst[:, 0], np.sort(a[:, 0]))
+
+
+# ------------------------------------------------------------------------------------------------ drop-ins at bench scale
+def _kmc(exe, flags, fq, out, tmp, env=None, timeout=900):
+    os.makedirs(tmp, exist_ok=True)
+    r = subprocess.run([exe, *flags, fq, out, tmp], env=env, capture_output=True, text=True, timeout=timeout)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    return r
+
+
+def _hip_env(**extra):
+    return dict(os.environ, KMC_HIP_LIB=capi.lib_path(), **extra)
+
+
+@pytest.mark.parametrize("k,reads,genome", [(27, 13_300_000, 66_000_000), (55, 4_000_000, 20_000_000)], ids=["k27-2Gbp", "k55-0.6Gbp"])
+def test_dropin_database_at_bench_scale(k, reads, genome, ref_bins, tmp_path):
+    """bit-exactness was only shown up to ~12 M k-mers. Here the drop-in (kmc_hip: worker + reader plug-ins,
+    16 workers, 8 reader threads) and the unmodified reference (-sr1) count the configs[1]-sized input (1.65 G k-mers at k=27):
+    .kmc_pre/.kmc_suf must be byte-identical."""
+    if ref_bins is None:
+        pytest.skip("oracle/_ref binaries were not shipped")
+    import shutil
+
+    base = "/dev/shm" if os.path.isdir("/dev/shm") and shutil.disk_usage("/dev/shm").free > reads * 316 * 3 else str(tmp_path)
+    import tempfile
+
+    with tempfile.TemporaryDirectory(dir=base) as td:
+        fq = os.path.join(td, "in.fq")
+        capi.synth_fastq(fq, seed=2026, genome_len=genome, n_reads=reads)
+        _kmc(ref_bins["kmc"], [f"-k{k}", "-t64", "-m64", "-sr1"], fq, os.path.join(td, "ref"), os.path.join(td, "t_ref"))
+        r = _kmc(ref_bins["kmc_hip"], [f"-k{k}", "-t64", "-m64", "-sr16"], fq, os.path.join(td, "hip"), os.path.join(td, "t_hip"),
+                 env=_hip_env(KMC_HIP_VERBOSE="1"))
+        for ext in (".kmc_pre", ".kmc_suf"):
+            assert _md5(os.path.join(td, "ref" + ext)) == _md5(os.path.join(td, "hip" + ext)), ext
+        log = os.path.join(ROOT, "gpurun_out", f"dropin_bench_scale_k{k}.log")
+        if os.path.isdir(os.path.dirname(log)):
+            open(log, "w").write(r.stdout + r.stderr)
+
+
+@pytest.mark.parametrize("flags", [["-k27"], ["-k21"], ["-k55"], ["-k127"]], ids=lambda f: "".join(f))
+def test_narrow_boundary_sortfunction_adapter(flags, ref_bins, tmp_path):
+    """oracle/_ref/kmc_hipsort = the reference with ONLY its SortFunction replaced by the GPU sort (hip_sort_function.h; the
+    reference's own CKmerBinSorter expands and compacts on the CPU): rec_len even (k=27: 8, k=127: 32 -> result in place) and
+    odd (k=21: 7, k=55: 15 -> result in tmp). Database byte-identical to the unmodified reference, both with one sorter."""
+    exe = os.path.join(ROOT, "oracle", "_ref", "kmc_hipsort")
+    if ref_bins is None or not os.path.exists(exe):
+        pytest.skip("oracle/_ref/kmc_hipsort was not shipped")
+    from kmc_amd import synth
+
+    fq = str(tmp_path / "in.fq")
+    synth.make_fastq(fq, **synth.CONFIGS["C1"])
+    _kmc(ref_bins["kmc"], [*flags, "-t4", "-sr1"], fq, str(tmp_path / "ref"), str(tmp_path / "t_ref"))
+    _kmc(exe, [*flags, "-t4", "-sr1"], fq, str(tmp_path / "hs"), str(tmp_path / "t_hs"), env=_hip_env())
+    for ext in (".kmc_pre", ".kmc_suf"):
+        assert _md5(str(tmp_path / ("ref" + ext))) == _md5(str(tmp_path / ("hs" + ext))), ext
+
+
+def test_kff_output_end_to_end(ref_bins, tmp_path):
+    """SURVEY §8f rank 4: -okff. The compaction kernel writes KFF record order (big-endian counter, no LUT, kb_sorter.h:1043-1049);
+    the reference's own KFF writer packs it. The .kff file must be byte-identical to the unmodified reference's."""
+    if ref_bins is None:
+        pytest.skip("oracle/_ref binaries were not shipped")
+    from kmc_amd import synth
+
+    fq = str(tmp_path / "in.fq")
+    synth.make_fastq(fq, **synth.CONFIGS["C1"])
+    for k in (27, 55):
+        _kmc(ref_bins["kmc"], [f"-k{k}", "-okff", "-t4", "-sr1"], fq, str(tmp_path / f"ref{k}"), str(tmp_path / f"t_ref{k}"))
+        _kmc(ref_bins["kmc_hip"], [f"-k{k}", "-okff", "-t8", "-sr4"], fq, str(tmp_path / f"hip{k}"), str(tmp_path / f"t_hip{k}"), env=_hip_env())
+        assert _md5(str(tmp_path / f"ref{k}.kff")) == _md5(str(tmp_path / f"hip{k}.kff")), k
+
+
+@pytest.mark.parametrize("readers,flags", [("1", ["-sr1"]), ("8", ["-t16", "-sr12"]), ("8", ["-t8", "-sr4", "-r"])], ids=["r1-sr1", "r8-sr12", "r8-sr4-ram"])
+def test_reader_plugin_with_the_hip_worker(readers, flags, ref_bins, tmp_path):
+    """kmc_hip (worker + reader plug-ins) for several reader/worker counts, disk and RAM-only (-r) temporaries, against the
+    reference's -sr1 database; kmc_hip_sr (reference reader kept) must agree too."""
+    if ref_bins is None:
+        pytest.skip("oracle/_ref binaries were not shipped")
+    from kmc_amd import synth
+
+    fq = str(tmp_path / "in.fq")
+    synth.make_fastq(fq, **synth.CONFIGS["C1"])
+    ram = [f for f in flags if f == "-r"]
+    _kmc(ref_bins["kmc"], ["-k27", "-sr1", *ram], fq, str(tmp_path / "ref"), str(tmp_path / "t_ref"))
+    _kmc(ref_bins["kmc_hip"], ["-k27", *flags], fq, str(tmp_path / "hip"), str(tmp_path / "t_hip"), env=_hip_env(KMC_HIP_READERS=readers))
+    sr = os.path.join(ROOT, "oracle", "_ref", "kmc_hip_sr")
+    outs = ["hip"]
+    if os.path.exists(sr):
+        _kmc(sr, ["-k27", *flags], fq, str(tmp_path / "hipsr"), str(tmp_path / "t_hipsr"), env=_hip_env())
+        outs.append("hipsr")
+    for o in outs:
+        for ext in (".kmc_pre", ".kmc_suf"):
+            assert _md5(str(tmp_path / ("ref" + ext))) == _md5(str(tmp_path / (o + ext))), (o, ext)
+
+
+# ------------------------------------------------------------------------------------------------ more than one device
+def _n_devices():
+    try:
+        return capi.load().kmc_hip_device_count()
+    except Exception:
+        return 0
+
+
+def test_two_devices_worker_allreduce_and_wide_records(ref_bins, tmp_path):
+    """the multi-device code had never met a second device. On a box with >= 2 GPUs: a context on devices
+    (0, 1) — k=200 (SIZE 7: > 64 KiB of dynamic LDS, needs the per-device function attribute) on the SECOND device against the
+    oracle; kmc_hip_allreduce_stats over 2 devices; the drop-in with KMC_HIP_DEVICES=0,1 against the reference database."""
+    if _n_devices() < 2:
+        pytest.skip("needs two GPUs")
+    c2 = capi.Context((0, 1))
+    try:
+        rng = np.random.default_rng(200)
+        img, nk, packs = binsynth.random_bin(rng, 200, 1500, max_extra=60)
+        p = hp(200, lut_prefix_len=4)
+        for dev in (1, 0):
+            out, lut, st = c2.process_bin(p, img, nk, packs, dev=dev)
+            w = O.process_bin(op(p), img, nk)
+            assert np.array_equal(out, w[0]) and np.array_equal(lut, w[1]) and np.array_equal(st, w[2]), dev
+        a = np.array([[1, 2, 3, 2**40], [10, 20, 30, 5]], dtype=np.uint64)
+        r = c2.allreduce_stats(a)
+        assert np.array_equal(r[0], a.sum(axis=0)) and np.array_equal(r[1], a.sum(axis=0))
+    finally:
+        c2.close()
+    if ref_bins is None:
+        return
+    from kmc_amd import synth
+
+    fq = str(tmp_path / "in.fq")
+    synth.make_fastq(fq, **synth.CONFIGS["C1"])
+    _kmc(ref_bins["kmc"], ["-k27", "-sr1"], fq, str(tmp_path / "ref"), str(tmp_path / "t_ref"))
+    _kmc(ref_bins["kmc_hip"], ["-k27", "-t8", "-sr6"], fq, str(tmp_path / "hip"), str(tmp_path / "t_hip"), env=_hip_env(KMC_HIP_DEVICES="0,1"))
+    for ext in (".kmc_pre", ".kmc_suf"):
+        assert _md5(str(tmp_path / ("ref" + ext))) == _md5(str(tmp_path / ("hip" + ext))), ext

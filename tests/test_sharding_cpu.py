@@ -5,6 +5,7 @@ import os
 import socket
 
 import numpy as np
+import pytest
 import torch.multiprocessing as mp
 
 import oracle_py as O
@@ -64,3 +65,67 @@ def test_two_rank_tally_allreduce_matches_single_process():
     for rank, mine, tot in res:
         assert tot == want.tolist()
     assert (np.array(res[0][1], dtype=np.uint64) + np.array(res[1][1], dtype=np.uint64)).tolist() == want.tolist()
+
+
+def _shard_worker(rank, world, port, q, scratch):
+    import hashlib
+    import torch.distributed as dist
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    # 70 000 reads = 2 full generator chunks + a partial one; n_bins > world so every rank owns several bins
+    sb = sharding.generate_sharded_bins(seed=77, genome_len=120_000, n_reads=70_000, k=27, n_bins=24, rank=rank, world=world, n_threads=2,
+                                        scratch_base=scratch)
+    own = {}
+    for b in sb.own:
+        img, pk = sb.image(b), sb.packs(b)
+        own[b] = (hashlib.md5(np.ascontiguousarray(img).tobytes()).hexdigest(), hashlib.md5(pk.tobytes()).hexdigest(), int(sb.n_rec[b]), int(sb.size[b]))
+    # the oracle over own bins + the one collective of the path
+    p = O.make_params(27)
+    mine = np.zeros(4, dtype=np.uint64)
+    for b in sb.own:
+        mine += O.process_bin(p, np.ascontiguousarray(sb.image(b)), int(sb.n_rec[b]))[2]
+    tot = sharding.allreduce_tallies(mine)
+    sb.close()
+    q.put((rank, own, tot.tolist()))
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_sharded_generation_reassembles_the_single_process_bin_set(world, tmp_path):
+    """bench.py --gpus N: every rank generates 1/N of the reads, pieces are exchanged through a scratch directory, bins go to ranks
+    by LPT. The union over ranks must be EXACTLY the bin set one process generates (images, pack lists, k-mer counts), each bin on
+    exactly one rank, and the all-reduced tallies must equal the single-process tallies."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_shard_worker, args=(r, world, port, q, str(tmp_path))) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=300) for _ in procs]
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    import hashlib
+
+    bins = capi.synth_bins(seed=77, genome_len=120_000, n_reads=70_000, k=27, n_bins=24, n_threads=1)
+    seen = {}
+    for rank, own, tot in res:
+        for b, v in own.items():
+            assert b not in seen, "a bin landed on two ranks"
+            seen[b] = v
+    assert sorted(seen) == list(range(24))
+    p = O.make_params(27)
+    want = np.zeros(4, dtype=np.uint64)
+    for b, (img, nrec, pk, _) in enumerate(bins):
+        assert seen[b] == (hashlib.md5(img.tobytes()).hexdigest(), hashlib.md5(pk.tobytes()).hexdigest(), nrec, img.size), b
+        want += O.process_bin(p, img, nrec)[2]
+    for rank, own, tot in res:
+        assert tot == want.tolist()
+    # LPT balance: no rank holds more than the ideal share + the largest bin
+    loads = [sum(v[2] for v in own.values()) for _, own, _ in res]
+    assert max(loads) <= sum(loads) / world + max(b[1] for b in bins)
+    assert not [f for f in os.listdir(tmp_path) if f.startswith("kmcbins_")], "the exchange directory must be removed"

@@ -13,6 +13,11 @@ VARIANTS = {
     "k8": ["-DRS_LOOKBACK_K=8"],
     "cp3": ["-DCP_MIN_WAVES=3"],
     "b512x16": ["-DRS_BLOCK_THREADS=512", "-DRS_WORDS_PER_THREAD=16", "-DRS_MIN_WAVES=6"],
+    "w16s4": ["-DRS_WORDS_PER_THREAD=16", "-DRS_STAGES=4"],  # 16 K-record tiles (512-byte runs), 2 workgroups/CU, ~19 VGPRs spilled
+    "w16s4_1cu": ["-DRS_WORDS_PER_THREAD=16", "-DRS_STAGES=4", "-DRS_MIN_WAVES=4"],  # same tile, 128 VGPRs, 1 workgroup/CU
+    "nohist": ["-DEXP_NO_HIST"],  # expand without the fused histograms (sort output is garbage): what do the LDS atomics cost?
+    "exp256": ["-DEXP_BLOCK_THREADS=256"],
+    "cp8": ["-DCP_WORDS_PER_THREAD=8", "-DCP_MIN_WAVES=8"],  # compaction: 2048-record tiles, 64 VGPRs, twice the workgroups per CU
 }
 
 
