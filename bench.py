@@ -117,7 +117,7 @@ def build_workload(ctx, args, k, p, rank, world, keep_host=False):
     """Generate + shard the bin set (kmc_amd/sharding.py), upload this rank's bins. Returns Workload."""
     w = Workload(ctx, p, k)
     n_threads = max(1, (os.cpu_count() or 8) // max(world, 1))
-    sb = sharding.generate_sharded_bins(SEED, args.genome, args.reads, k, args.bins, rank, world, n_threads)
+    sb = sharding.generate_sharded_bins(SEED, args.genome, args.reads, k, args.bins, rank, world, n_threads, cache_dir=args.cache or None)
     w.setup_s.update(sb.timings)
     own = sb.own
 
@@ -342,7 +342,7 @@ def reference_legs(k: int, reads: int, genome: int, runs: int = 2):
                                   "database writer are the reference's in both",
                           "ref_stage2_s": s2, "hip_stage2_s": h2, "speedup": s2 / h2, "hip_Gkmers_per_s": hst["total"] / h2 / 1e9,
                           "ref_Gkmers_per_s": st["total"] / s2 / 1e9, "stats_equal": hst == st, "hip_stats": hst, "hip_stage1_s": h1,
-                          "all_hip_stage2_s": [x[1] for x in hip_runs], "all_ref_stage2_s": [x[1] for x in ref_runs], "worker_report": verbose[-1:] }
+                          "all_hip_stage2_s": [x[1] for x in hip_runs], "all_ref_stage2_s": [x[1] for x in ref_runs], "worker_report": verbose}
     return out
 
 
@@ -374,6 +374,7 @@ def main():
     ap.add_argument("--no-host-boundary", action="store_true")
     ap.add_argument("--no-secondary", action="store_true")
     ap.add_argument("--no-digest", action="store_true")
+    ap.add_argument("--cache", default="", help="directory for the generated bin set (tuning sessions: generate once, reuse)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))

@@ -15,6 +15,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <sys/mman.h>
 #include <thread>
 #include <vector>
 
@@ -33,39 +34,67 @@ struct Rng { /* counter-based: stream (seed, read) is independent of scheduling 
 	uint64_t next() { return mix64(key + 0x632BE59BD9B4E019ull * ++ctr); }
 };
 
-struct BinBuf {
-	std::vector<uint8_t> bytes;
-	std::vector<uint64_t> packs;
-	uint64_t n_rec = 0, n_super = 0;
+constexpr uint64_t READS_PER_CHUNK = 1 << 15;
+constexpr uint32_t PACK_SUPERKMERS = 4096; /* kb_collector.h:46 */
+
+/* Two passes over the reads of a chunk, no per-chunk buffers (the first version kept a vector per (chunk, bin): 3 M vectors and
+ * 60 GB of allocator traffic for the 30 Gbp workload, which scaled to 256 threads very badly): pass 1 COUNTS what every
+ * (chunk, bin) cell will hold, the cells' offsets inside the final images follow from prefix sums, pass 2 regenerates the
+ * reads (they are a pure function of (seed, read)) and WRITES the super-k-mers in place. */
+struct Cell {
+	uint64_t bytes = 0, n_rec = 0;
+	uint32_t n_super = 0;
+};
+
+struct CountSink {
+	Cell *cells; /* [n_bins] of this chunk */
+	void put(uint32_t bin, const uint8_t *, uint32_t n, uint32_t k)
+	{
+		Cell &c = cells[bin];
+		c.bytes += 1 + (n + 3) / 4;
+		c.n_rec += n - k + 1;
+		++c.n_super;
+	}
+};
+
+struct Cursor {
+	uint8_t *p = nullptr;
+	uint64_t *pk = nullptr;
 	uint64_t cur_pack_bytes = 0;
 	uint32_t cur_pack_sk = 0;
 };
 
-struct Chunk {
-	std::vector<BinBuf> bins;
-};
-
-constexpr uint64_t READS_PER_CHUNK = 1 << 15;
-
-void put_superkmer(BinBuf &b, const uint8_t *sym, uint32_t n, uint32_t k)
-{
-	if (b.cur_pack_sk >= 4096) {
-		b.packs.push_back(b.cur_pack_bytes);
-		b.cur_pack_bytes = 0;
-		b.cur_pack_sk = 0;
+struct WriteSink {
+	Cursor *cur; /* [n_bins], positioned at this chunk's cells */
+	void put(uint32_t bin, const uint8_t *sym, uint32_t n, uint32_t k)
+	{
+		Cursor &c = cur[bin];
+		if (c.cur_pack_sk >= PACK_SUPERKMERS) {
+			*c.pk++ = c.cur_pack_bytes;
+			c.cur_pack_bytes = 0;
+			c.cur_pack_sk = 0;
+		}
+		const uint32_t nb = 1 + (n + 3) / 4;
+		uint8_t *p = c.p;
+		p[0] = (uint8_t)(n - k);
+		for (uint32_t i = 1; i < nb; ++i)
+			p[i] = 0;
+		for (uint32_t i = 0; i < n; ++i)
+			p[1 + (i >> 2)] |= (uint8_t)(sym[i] << (6 - 2 * (i & 3)));
+		c.p += nb;
+		c.cur_pack_bytes += nb;
+		++c.cur_pack_sk;
 	}
-	const size_t at = b.bytes.size();
-	const uint32_t nb = 1 + (n + 3) / 4;
-	b.bytes.resize(at + nb, 0);
-	uint8_t *p = b.bytes.data() + at;
-	p[0] = (uint8_t)(n - k);
-	for (uint32_t i = 0; i < n; ++i)
-		p[1 + (i >> 2)] |= (uint8_t)(sym[i] << (6 - 2 * (i & 3)));
-	b.cur_pack_bytes += nb;
-	++b.cur_pack_sk;
-	++b.n_super;
-	b.n_rec += n - k + 1;
-}
+	void close_packs(uint32_t n_bins)
+	{
+		for (uint32_t b = 0; b < n_bins; ++b)
+			if (cur[b].cur_pack_bytes) { /* every chunk closes its own packs */
+				*cur[b].pk++ = cur[b].cur_pack_bytes;
+				cur[b].cur_pack_bytes = 0;
+				cur[b].cur_pack_sk = 0;
+			}
+	}
+};
 
 /* read r of the model: window at a uniform start, per-base substitution with probability err, random strand */
 inline void make_read(uint64_t seed, const std::vector<uint8_t> &genome, uint64_t r, uint32_t L, uint64_t err_thr, std::vector<uint8_t> &rd)
@@ -102,10 +131,10 @@ void make_genome(uint64_t seed, uint64_t genome_len, int n_threads, std::vector<
 		x.join();
 }
 
+template <typename Sink>
 void gen_chunk(uint64_t seed, const std::vector<uint8_t> &genome, uint64_t r0, uint64_t r1, uint32_t L, double err, uint32_t k, uint32_t m,
-               uint32_t n_bins, Chunk &out)
+               uint32_t n_bins, Sink &out)
 {
-	out.bins.assign(n_bins, BinBuf());
 	const uint64_t err_thr = (uint64_t)(err * 18446744073709551615.0);
 	std::vector<uint8_t> rd(L);
 	std::vector<uint32_t> mm(L), mn(L);
@@ -140,17 +169,11 @@ void gen_chunk(uint64_t seed, const std::vector<uint8_t> &genome, uint64_t r0, u
 		for (uint32_t i = 1; i <= n_k; ++i) {
 			if (i == n_k || mn[i] != mn[start] || i - start >= 256) {
 				const uint32_t bin = (uint32_t)(mix64(mn[start]) % n_bins);
-				put_superkmer(out.bins[bin], rd.data() + start, (i - start) + k - 1, k);
+				out.put(bin, rd.data() + start, (i - start) + k - 1, k);
 				start = i;
 			}
 		}
 	}
-	for (auto &b : out.bins)
-		if (b.cur_pack_bytes) {
-			b.packs.push_back(b.cur_pack_bytes);
-			b.cur_pack_bytes = 0;
-			b.cur_pack_sk = 0;
-		}
 }
 
 struct Result {
@@ -162,6 +185,8 @@ struct Result {
 } // namespace
 
 extern "C" {
+
+void kmc_synth_free(void *handle);
 
 /* Generate `n_bins` bin images from reads [read_begin, read_end) of the model (read r is a pure function of (seed, r), and every
  * READS_PER_CHUNK-aligned chunk of reads closes its own expander packs, so images made from chunk-aligned sub-ranges concatenate,
@@ -181,18 +206,27 @@ void *kmc_synth_bins_range(uint64_t seed, uint64_t genome_len, uint64_t read_beg
 	make_genome(seed, genome_len, n_threads, genome);
 	const uint64_t n_reads = read_end - read_begin;
 	const uint64_t n_chunks = (n_reads + READS_PER_CHUNK - 1) / READS_PER_CHUNK;
-	std::vector<Chunk> chunks(n_chunks);
-	{
+	auto chunk_range = [&](uint64_t c, uint64_t &a, uint64_t &b) {
+		a = read_begin + c * READS_PER_CHUNK;
+		b = read_begin + std::min(n_reads, (c + 1) * READS_PER_CHUNK);
+	};
+	auto run_threads = [&](auto body) {
 		std::vector<std::thread> th;
 		for (int t = 0; t < n_threads; ++t)
-			th.emplace_back([&, t] {
-				for (uint64_t c = t; c < n_chunks; c += n_threads)
-					gen_chunk(seed, genome, read_begin + c * READS_PER_CHUNK, read_begin + std::min(n_reads, (c + 1) * READS_PER_CHUNK), read_len,
-					          err, k, sig_len, n_bins, chunks[c]);
-			});
+			th.emplace_back([&, t] { body(t); });
 		for (auto &x : th)
 			x.join();
-	}
+	};
+	/* pass 1: count */
+	std::vector<Cell> cells((size_t)n_chunks * n_bins);
+	run_threads([&](int t) {
+		for (uint64_t c = t; c < n_chunks; c += n_threads) {
+			uint64_t a, b;
+			chunk_range(c, a, b);
+			CountSink sink{cells.data() + (size_t)c * n_bins};
+			gen_chunk(seed, genome, a, b, read_len, err, k, sig_len, n_bins, sink);
+		}
+	});
 	Result *R = new Result();
 	R->image.assign(n_bins, nullptr);
 	R->packs.assign(n_bins, nullptr);
@@ -200,42 +234,58 @@ void *kmc_synth_bins_range(uint64_t seed, uint64_t genome_len, uint64_t read_beg
 	R->n_rec.assign(n_bins, 0);
 	R->n_super.assign(n_bins, 0);
 	R->n_packs.assign(n_bins, 0);
+	/* offsets of every cell inside its bin's image / pack list (exclusive prefix over chunks), kept in the cells */
+	std::vector<uint64_t> pack_off((size_t)n_chunks * n_bins);
+	bool ok = true;
 	for (uint32_t b = 0; b < n_bins; ++b) {
 		uint64_t sz = 0, np = 0;
-		for (auto &c : chunks) {
-			sz += c.bins[b].bytes.size();
-			np += c.bins[b].packs.size();
-			R->n_rec[b] += c.bins[b].n_rec;
-			R->n_super[b] += c.bins[b].n_super;
+		for (uint64_t c = 0; c < n_chunks; ++c) {
+			Cell &cl = cells[(size_t)c * n_bins + b];
+			const uint64_t bytes = cl.bytes;
+			R->n_rec[b] += cl.n_rec;
+			R->n_super[b] += cl.n_super;
+			cl.bytes = sz; /* now: byte offset of the cell */
+			pack_off[(size_t)c * n_bins + b] = np;
+			sz += bytes;
+			np += (cl.n_super + PACK_SUPERKMERS - 1) / PACK_SUPERKMERS;
 		}
 		R->size[b] = sz;
 		R->n_packs[b] = np;
-		R->image[b] = (uint8_t *)malloc(sz + 256);
+		const size_t want = sz + 256;
+		if (want >= (8u << 20)) { /* big images: 2 MiB-aligned and advised huge, 256 threads first-touching 4 KiB pages do not scale */
+			const size_t al = 2u << 20, rounded = (want + al - 1) / al * al;
+			R->image[b] = (uint8_t *)aligned_alloc(al, rounded);
+			if (R->image[b])
+				(void)madvise(R->image[b], rounded, MADV_HUGEPAGE);
+		} else
+			R->image[b] = (uint8_t *)malloc(want);
 		R->packs[b] = (uint64_t *)malloc((np + 1) * 8);
 		if (!R->image[b] || !R->packs[b])
-			return nullptr;
-		memset(R->image[b] + sz, 0, 256);
+			ok = false;
+		else
+			memset(R->image[b] + sz, 0, 256);
 	}
-	{ /* concatenate chunk pieces in chunk order (parallel over bins x chunks by offset) */
-		std::vector<std::thread> th;
-		for (int t = 0; t < n_threads; ++t)
-			th.emplace_back([&, t] {
-				for (uint32_t b = t; b < n_bins; b += n_threads) {
-					uint64_t off = 0, po = 0;
-					for (auto &c : chunks) {
-						auto &bb = c.bins[b];
-						if (!bb.bytes.empty())
-							memcpy(R->image[b] + off, bb.bytes.data(), bb.bytes.size());
-						off += bb.bytes.size();
-						for (auto p : bb.packs)
-							R->packs[b][po++] = p;
-						std::vector<uint8_t>().swap(bb.bytes);
-					}
-				}
-			});
-		for (auto &x : th)
-			x.join();
+	if (!ok) {
+		kmc_synth_free(R);
+		return nullptr;
 	}
+	/* pass 2: write in place */
+	run_threads([&](int t) {
+		std::vector<Cursor> cur(n_bins);
+		for (uint64_t c = t; c < n_chunks; c += n_threads) {
+			uint64_t a, b;
+			chunk_range(c, a, b);
+			for (uint32_t bi = 0; bi < n_bins; ++bi) {
+				cur[bi].p = R->image[bi] + cells[(size_t)c * n_bins + bi].bytes;
+				cur[bi].pk = R->packs[bi] + pack_off[(size_t)c * n_bins + bi];
+				cur[bi].cur_pack_bytes = 0;
+				cur[bi].cur_pack_sk = 0;
+			}
+			WriteSink sink{cur.data()};
+			gen_chunk(seed, genome, a, b, read_len, err, k, sig_len, n_bins, sink);
+			sink.close_packs(n_bins);
+		}
+	});
 	*out_images = R->image.data();
 	*out_sizes = R->size.data();
 	*out_n_rec = R->n_rec.data();

@@ -70,7 +70,26 @@ class ShardedBins:
             self._cleanup = None
 
 
-def generate_sharded_bins(seed, genome_len, n_reads, k, n_bins, rank=0, world=1, n_threads=0, scratch_base=None) -> ShardedBins:
+def _load_cached(path_prefix, n_bins):
+    import os
+
+    if not (os.path.exists(path_prefix + ".npz") and os.path.exists(path_prefix + ".bin")):
+        return None
+    m = dict(np.load(path_prefix + ".npz"))
+    if len(m["sizes"]) != n_bins:
+        return None
+    sb = ShardedBins()
+    mm = np.memmap(path_prefix + ".bin", dtype=np.uint8, mode="r") if os.path.getsize(path_prefix + ".bin") else np.zeros(0, dtype=np.uint8)
+    offs = np.concatenate([[0], np.cumsum(m["sizes"])])
+    poffs = np.concatenate([[0], np.cumsum(m["npk"])])
+    sb.own = list(range(n_bins))
+    sb.size, sb.n_rec, sb.n_packs, sb.n_super = m["sizes"], m["nrec"], m["npk"], m["nsup"]
+    sb.pieces = {b: [(mm[offs[b]:offs[b + 1]], m["packs"][poffs[b]:poffs[b + 1]])] for b in sb.own}
+    sb._keep = [mm]
+    return sb
+
+
+def generate_sharded_bins(seed, genome_len, n_reads, k, n_bins, rank=0, world=1, n_threads=0, scratch_base=None, cache_dir=None) -> ShardedBins:
     """The SAME `n_bins` signature bins whatever `world` is, sharded over ranks (BASELINE configs[3]).
 
     Every rank generates a chunk-aligned 1/world of the reads into all bins (kmc_amd/csrc/synth_bins.cpp: a bin image is the
@@ -84,6 +103,14 @@ def generate_sharded_bins(seed, genome_len, n_reads, k, n_bins, rank=0, world=1,
 
     from . import capi
 
+    cache = None
+    if cache_dir and world == 1:  # tuning sessions: several bench runs in one gpurun call share the generated bin set
+        cache = os.path.join(cache_dir, f"kmcbins_s{seed}_g{genome_len}_r{n_reads}_k{k}_b{n_bins}")
+        t = time.time()
+        got = _load_cached(cache, n_bins)
+        if got is not None:
+            got.timings["load_cached"] = time.time() - t
+            return got
     sb = ShardedBins()
     cr = capi.synth_chunk_reads()
     n_chunks = (n_reads + cr - 1) // cr
@@ -102,6 +129,15 @@ def generate_sharded_bins(seed, genome_len, n_reads, k, n_bins, rank=0, world=1,
         sb.size, sb.n_rec, sb.n_packs, sb.n_super = sizes, nrec, npk, nsup
         sb.pieces = {b: [(syn.bins[b][0], syn.bins[b][2])] for b in sb.own}
         sb._keep = [syn]
+        if cache:
+            t = time.time()
+            with open(cache + ".bin", "wb") as f:
+                for b in range(n_bins):
+                    if syn.bins[b][0].size:
+                        f.write(memoryview(syn.bins[b][0]))
+            np.savez(cache + ".npz", sizes=sizes, nrec=nrec, npk=npk, nsup=nsup,
+                     packs=np.concatenate([np.asarray(b[2], dtype=np.uint64) for b in syn.bins]) if npk.sum() else np.zeros(0, dtype=np.uint64))
+            sb.timings["save_cache"] = time.time() - t
         return sb
 
     import torch.distributed as dist

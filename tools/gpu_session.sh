@@ -1,7 +1,7 @@
 #!/bin/bash
 # One gpurun call = one measurement session; everything lands under gpurun_out/$TAG. Usage: tools/gpu_session.sh TAG step...
 TAG=$1; shift
-OUT=gpurun_out/$TAG; mkdir -p $OUT
+OUT=gpurun_out/$TAG; mkdir -p $OUT /dev/shm/kmccache
 export TMPDIR=/tmp HSA_ENABLE_IPC_MODE_LEGACY=0
 one_bin="--leg configs[1] --reads 13300000 --genome 66000000 --bins 1 --steps 3 --warmup 1 --no-digest"
 bins512="--leg 2gbp-512bins --reads 13300000 --genome 66000000 --bins 512 --steps 3 --warmup 1 --no-digest"
@@ -12,6 +12,8 @@ for step in "$@"; do
     tests)   timeout 1500 python -m pytest tests -m gpu -x -q > $OUT/pytest_gpu.txt 2>&1; tail -3 $OUT/pytest_gpu.txt ;;
     bench)   timeout 1200 python bench.py > $OUT/bench.json 2> $OUT/bench.err; tail -c 600 $OUT/bench.err ;;
     benchq)  timeout 900 python bench.py --no-cpu-baseline --no-secondary > $OUT/benchq.json 2> $OUT/benchq.err; tail -c 300 $OUT/benchq.err ;;
+    e2e)     timeout 900 python tools/e2e_matrix.py > $OUT/e2e_matrix.jsonl 2> $OUT/e2e_matrix.err ;;
+    streams:*) n=${step#streams:}; timeout 900 python bench.py --cache /dev/shm/kmccache --streams $n --no-cpu-baseline --no-secondary --no-host-boundary --no-digest --steps 3 > $OUT/c3_streams$n.json 2> $OUT/c3_streams$n.err ;;
     host)    timeout 600 python tools/ubench_host.py > $OUT/ubench_host.json 2> $OUT/ubench_host.err ;;
     var:*)   v=${step#var:}; KMC_HIP_LIB=kmc_amd/variants/libkmc_hip_$v.so timeout 600 python bench.py $one_bin > $OUT/onebin_$v.json 2> $OUT/onebin_$v.err ;;
     var512:*) v=${step#var512:}; KMC_HIP_LIB=kmc_amd/variants/libkmc_hip_$v.so timeout 600 python bench.py $bins512 > $OUT/bins512_$v.json 2> $OUT/bins512_$v.err ;;
@@ -22,5 +24,5 @@ for step in "$@"; do
   esac
   echo "[$step] $(( $(date +%s) - t0 )) s"
 done
-find $OUT -name "*.db" -size +20M -delete 2>/dev/null
+rm -rf /dev/shm/kmccache_never; find $OUT -name "*.db" -size +20M -delete 2>/dev/null
 du -sh $OUT | cat
