@@ -372,22 +372,27 @@ __global__ void __launch_bounds__(256) k_parse_packs(const uint8_t *__restrict__
 #define EXP_KWIN_KMERS 8192
 #endif
 constexpr u32 EXP_FUSE_MAX_PASS = 16; /* the sort's histograms are fused into the expansion up to this many passes (k <= 64) */
-constexpr int EXP_CHUNK = EXP_CHUNK_BYTES, EXP_TAIL = 160, EXP_MAX_SK = EXP_CHUNK / 2, EXP_KWIN = EXP_KWIN_KMERS, EXP_BLOCK = EXP_BLOCK_THREADS;
+constexpr int EXP_CHUNK = EXP_CHUNK_BYTES, EXP_TAIL = 160, EXP_KWIN = EXP_KWIN_KMERS, EXP_BLOCK = EXP_BLOCK_THREADS;
+/* most super-k-mers that can START inside one slice: a record is 1 + ceil((k+e)/4) >= 1 + ceil(k/4) bytes long. The two LDS lists are
+ * sized by this (k=27: 1025 entries instead of a worst case of 4096 -> 38 KB instead of 57 KB per workgroup: 4 workgroups per CU, not 2) */
+__host__ __device__ constexpr u32 exp_max_sk(u32 k) { return (u32)EXP_CHUNK / (1 + ((k + 3) >> 2)) + 2; }
 
 template <int SIZE, bool FUSE_HIST>
 __global__ void __launch_bounds__(EXP_BLOCK) k_expand(const uint8_t *__restrict__ data, u64 size, const u32 *__restrict__ bitmap, u32 k,
                                                  u32 both_strands, u32 n_pass, u64 n_rec, u64 *__restrict__ out, u64 *__restrict__ ghist,
-                                                 u64 *status, u32 *ticket_ctr, u32 n_chunks, u32 *err)
+                                                 u64 *status, u32 *ticket_ctr, u32 n_chunks, u32 *err, u64 *__restrict__ digit_base,
+                                                 u32 *done_ctr)
 {
+	const u32 MAX_SK = exp_max_sk(k);
 	extern __shared__ __attribute__((aligned(16))) unsigned char s_raw[];
 	u64 *s_base = reinterpret_cast<u64 *>(s_raw);                             /* [2] (16 bytes keeps s_b 16-B aligned) */
 	uint8_t *s_b = s_raw + 16;                                                /* [EXP_CHUNK + EXP_TAIL] */
-	u32 *s_skoff = reinterpret_cast<u32 *>(s_b + EXP_CHUNK + EXP_TAIL);       /* [EXP_MAX_SK + 1] first k-mer of each super-k-mer */
-	u32 *s_tmp = s_skoff + EXP_MAX_SK + 1;                                    /* [24] scan scratch */
+	u32 *s_skoff = reinterpret_cast<u32 *>(s_b + EXP_CHUNK + EXP_TAIL);       /* [MAX_SK + 1] first k-mer of each super-k-mer */
+	u32 *s_tmp = s_skoff + MAX_SK + 1;                                        /* [24] scan scratch */
 	u32 *s_ticket = s_tmp + 24;                                                /* [3] */
 	u32 *s_h = s_ticket + 3;                                                  /* [n_pass * 256] when FUSE_HIST */
-	unsigned short *s_skpos = reinterpret_cast<unsigned short *>(s_h + (FUSE_HIST ? n_pass * 256 : 0)); /* [EXP_MAX_SK] byte position */
-	unsigned short *s_kidx = s_skpos + EXP_MAX_SK;                            /* [EXP_KWIN] k-mer (window-relative) -> super-k-mer */
+	unsigned short *s_skpos = reinterpret_cast<unsigned short *>(s_h + (FUSE_HIST ? n_pass * 256 : 0)); /* [MAX_SK] byte position */
+	unsigned short *s_kidx = s_skpos + ((MAX_SK + 1) & ~1u);                  /* [EXP_KWIN] k-mer (window-relative) -> super-k-mer */
 
 	if (FUSE_HIST) {
 		for (u32 i = threadIdx.x; i < n_pass * 256; i += EXP_BLOCK)
@@ -434,7 +439,7 @@ __global__ void __launch_bounds__(EXP_BLOCK) k_expand(const uint8_t *__restrict_
 			while (bb) {
 				const u32 bpos = (u32)__ffs((int)bb) - 1;
 				bb &= bb - 1;
-				if (i < (u32)EXP_MAX_SK) {
+				if (i < MAX_SK) {
 					s_skpos[i] = (unsigned short)(tid * 32 + bpos);
 					s_skoff[i] = ko;
 				}
@@ -486,10 +491,10 @@ __global__ void __launch_bounds__(EXP_BLOCK) k_expand(const uint8_t *__restrict_
 			}
 		}
 		if (tid == 0)
-			s_skoff[tot_sk < (u32)EXP_MAX_SK ? tot_sk : (u32)EXP_MAX_SK] = tot_k; /* sentinel */
+			s_skoff[tot_sk < MAX_SK ? tot_sk : MAX_SK] = tot_k; /* sentinel */
 		__syncthreads();
 		const u64 base = *s_base;
-		const u32 n_sk = tot_sk < (u32)EXP_MAX_SK ? tot_sk : (u32)EXP_MAX_SK;
+		const u32 n_sk = tot_sk < MAX_SK ? tot_sk : MAX_SK;
 		/* k-mers of the slice in windows of EXP_KWIN (one window unless the super-k-mers are unusually long) */
 		for (u32 w0 = 0; n_sk && w0 < tot_k; w0 += EXP_KWIN) {
 			const u32 wn = (tot_k - w0) < (u32)EXP_KWIN ? (tot_k - w0) : (u32)EXP_KWIN;
@@ -572,11 +577,30 @@ __global__ void __launch_bounds__(EXP_BLOCK) k_expand(const uint8_t *__restrict_
 			if (v)
 				atomicAdd(&ghist[i], (u64)v);
 		}
+		/* the workgroup that finishes LAST turns the complete histograms into the digit bases of every pass (one launch and its
+		 * gap less per bin than a separate scan kernel): its own atomics and everybody else's are performed before the
+		 * respective done_ctr increment (fence), so the agent-scope loads below see the final counts */
+		__threadfence();
+		__syncthreads();
+		if (threadIdx.x == 0)
+			s_ticket[1] = atomicAdd(done_ctr, 1u);
+		__syncthreads();
+		if (s_ticket[1] == gridDim.x - 1) {
+			u64 *s_scan = reinterpret_cast<u64 *>(s_raw + 16); /* the slice buffer is free now */
+			for (u32 b = 0; b < n_pass; ++b) {
+				const u64 v = threadIdx.x < 256 ? ld_agent(&ghist[b * 256 + threadIdx.x]) : 0ull;
+				u64 total;
+				const u64 ex = block_excl_sum<EXP_BLOCK / 64, u64>(v, s_scan, total);
+				if (threadIdx.x < 256)
+					digit_base[b * 256 + threadIdx.x] = ex;
+			}
+		}
 	}
 }
-template <bool FUSE_HIST> constexpr size_t exp_lds_bytes(u32 n_pass)
+template <bool FUSE_HIST> constexpr size_t exp_lds_bytes(u32 n_pass, u32 k)
 {
-	return 16 + (size_t)EXP_CHUNK + EXP_TAIL + (EXP_MAX_SK + 1 + 24 + 3) * 4 + (FUSE_HIST ? (size_t)n_pass * 1024 : 0) + EXP_MAX_SK * 2 + EXP_KWIN * 2 + 16;
+	return 16 + (size_t)EXP_CHUNK + EXP_TAIL + ((size_t)exp_max_sk(k) + 1 + 24 + 3) * 4 + (FUSE_HIST ? (size_t)n_pass * 1024 : 0) +
+	       (((size_t)exp_max_sk(k) + 1) & ~(size_t)1) * 2 + EXP_KWIN * 2 + 16;
 }
 
 /* ------------------------------------------------------------------------------------------------ histogram
@@ -981,7 +1005,7 @@ template <int SIZE>
 __global__ void __launch_bounds__(CP_BLOCK, CP_MIN_WAVES) k_compact(const u64 *__restrict__ S, u64 n, DevParams P, uint8_t *__restrict__ out,
                                                        u64 out_capacity, u64 *__restrict__ lut_base, u32 lut_shards, u64 lut_stride,
                                                        u64 *stat_shards /* [CP_SHARDS][4] */, u64 *out_bytes, u64 *status, u32 *tile_counter,
-                                                       u32 num_tiles, u32 *err)
+                                                       u32 num_tiles, u32 *err, u64 *__restrict__ stats, u64 *__restrict__ lut_out, u32 *done_ctr)
 {
 	constexpr int ITEMS = CpCfg<SIZE>::ITEMS;
 	constexpr int TILE = CpCfg<SIZE>::TILE;
@@ -1326,30 +1350,33 @@ __global__ void __launch_bounds__(CP_BLOCK, CP_MIN_WAVES) k_compact(const u64 *_
 		if (acc_a)
 			atomicAdd(&sh[2], acc_a);
 	}
-}
-
-/* End of a bin, one launch: block b sums LUT entries [256 b, 256 b + 256) over the shards (when the LUT was sharded);
- * wave 0 of block 0 also folds the tally shards: stats[0..2] = sums, stats[3] = n_total = n_rec (kb_sorter.h:1166). */
-__global__ void __launch_bounds__(256) k_finish(const u64 *__restrict__ stat_shards, u64 *__restrict__ stats, u64 n,
-                                                const u64 *__restrict__ lut_shards, u32 n_shards, u64 entries, u64 *__restrict__ lut)
-{
-	const u64 i = (u64)blockIdx.x * 256 + threadIdx.x;
-	if (i < entries) {
-		u64 v = 0;
-		for (u32 sidx = 0; sidx < n_shards; ++sidx)
-			v += lut_shards[(size_t)sidx * entries + i];
-		lut[i] = v;
-	}
-	if (blockIdx.x == 0 && threadIdx.x < 64) {
-		const u32 lane = threadIdx.x;
-		for (int j = 0; j < 3; ++j) {
-			u64 v = lane < CP_SHARDS ? stat_shards[lane * 4 + j] : 0;
-			v = wave_sum<u64>(v);
+	/* End of the bin, in the workgroup that finishes LAST (see k_expand's tail for the ordering argument): fold the tally shards into
+	 * stats[0..2], stats[3] = n_total = n_rec (kb_sorter.h:1166), and sum the LUT shards into the caller's LUT. */
+	__threadfence();
+	__syncthreads();
+	if (threadIdx.x == 0)
+		s_tile = atomicAdd(done_ctr, 1u);
+	__syncthreads();
+	if (s_tile == gridDim.x - 1) {
+		if (threadIdx.x < 64) {
+			const u32 lane = threadIdx.x;
+			for (int j = 0; j < 3; ++j) {
+				u64 v = lane < CP_SHARDS ? ld_agent(&stat_shards[lane * 4 + j]) : 0;
+				v = wave_sum<u64>(v);
+				if (lane == 0)
+					stats[j] = v;
+			}
 			if (lane == 0)
-				stats[j] = v;
+				stats[3] = n;
 		}
-		if (lane == 0)
-			stats[3] = n;
+		if (use_lut && lut_shards > 1) {
+			for (u64 i = threadIdx.x; i < lut_stride; i += CP_BLOCK) {
+				u64 v = 0;
+				for (u32 sidx = 0; sidx < lut_shards; ++sidx)
+					v += ld_agent(&lut_base[(size_t)sidx * lut_stride + i]);
+				lut_out[i] = v;
+			}
+		}
 	}
 }
 

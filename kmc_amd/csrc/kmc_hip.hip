@@ -65,7 +65,8 @@ int ensure(DBuf &b, size_t bytes)
 	return 0;
 }
 
-/* layout of the per-slot "small" device block (bytes); cleared at the start of every bin */
+/* layout of the per-slot "small" device block (bytes): the first SM_BYTES of the slot's zero region, cleared with it at the start
+ * of every bin */
 constexpr size_t SM_TOTALS = 0;      /* u64[2]  #super-k-mers, #k-mers   */
 constexpr size_t SM_STATS = 16;      /* u64[4]                           */
 constexpr size_t SM_OUTBYTES = 48;   /* u64                              */
@@ -81,7 +82,8 @@ constexpr size_t SM_BYTES = SM_COUNTERS + N_COUNTERS * 4;
                         * binds); the stage-2 worker spreads up to 16 sorter threads over them */
 #endif
 constexpr int N_SLOTS = KMC_N_SLOTS;
-constexpr int N_BATCH_STREAMS = 8; /* default fan-out of kmc_hip_process_bins_device */
+constexpr int N_BATCH_STREAMS = 8; /* default fan-out of kmc_hip_process_bins_device for small bins */
+constexpr u32 TIMING_SAMPLE = 8;   /* an event pair costs a few microseconds of stream time: asynchronous bins are timed 1 in 8 */
 constexpr u64 PORTION_MAX = 1ull << 29; /* records per scatter launch (30-bit look-back counts) */
 /* Tests shrink the portion ($KMC_HIP_DEBUG_PORTION_LOG2, 10..29, read at kmc_hip_init, kept per context) so that a small,
  * oracle-checkable sort crosses many portion boundaries (digit bases carried from launch to launch) — the path a bin of
@@ -99,7 +101,7 @@ struct HostRes {
  * per run the host launch rate is what binds): start bitmap | expand look-back words | digit histograms | compaction
  * look-back words | one scatter status area per onesweep launch. Offsets are 256-byte aligned. */
 struct ZeroPlan {
-	size_t bitmap = 0, exp_status = 0, ghist = 0, cp_status = 0, sc_status = 0, sc_stride = 0, total = 0;
+	size_t bitmap = 0, exp_status = 0, ghist = 0, cp_status = 0, lutsh = 0, sc_status = 0, sc_stride = 0, total = 0;
 };
 inline size_t up256(size_t x) { return (x + 255) & ~(size_t)255; }
 
@@ -108,7 +110,7 @@ struct Slot {
 	std::mutex mtx; /* serialises enqueueing on this slot (asynchronous device-resident calls may come from several threads) */
 	u64 portion = PORTION_MAX;
 	DBuf in, pack_start;
-	DBuf recA, recB, zero, dbase, out, lut, lutsh, small, sticky;
+	DBuf recA, recB, zero, dbase, out, lut, sticky;
 	HostRes *h_res = nullptr; /* pinned */
 	hipEvent_t ev[6] = {};
 	/* one event pair per scatter launch since the last harvest (roofline input) */
@@ -118,6 +120,7 @@ struct Slot {
 	double sc_ms_total = 0;
 	u64 sc_keys_total = 0, sc_launch_total = 0;
 	bool timed = false;
+	u32 async_seq = 0; /* asynchronous device-resident bins on this slot: every TIMING_SAMPLE-th one carries events */
 	/* pending async bin */
 	bool pending = false;
 	uint8_t *h_out = nullptr;
@@ -164,9 +167,9 @@ template <int SIZE> int set_func_attrs()
 	if (rs_lds_bytes<SIZE>() > 65536)
 		HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_onesweep<SIZE>), hipFuncAttributeMaxDynamicSharedMemorySize,
 		                           (int)rs_lds_bytes<SIZE>()));
-	if (exp_lds_bytes<true>(EXP_FUSE_MAX_PASS) > 65536)
+	if (exp_lds_bytes<true>(EXP_FUSE_MAX_PASS, 1) > 65536) /* worst case: the shortest records (smallest k) and 16 fused passes */
 		HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_expand<SIZE, true>), hipFuncAttributeMaxDynamicSharedMemorySize,
-		                           (int)exp_lds_bytes<true>(EXP_FUSE_MAX_PASS)));
+		                           (int)exp_lds_bytes<true>(EXP_FUSE_MAX_PASS, 1)));
 	return 0;
 }
 int set_all_func_attrs()
@@ -185,8 +188,9 @@ int slot_init(Slot &s, u64 portion)
 	memset(s.h_res, 0, sizeof(HostRes));
 	for (auto &e : s.ev)
 		HIPCHK(hipEventCreate(&e));
-	if (int rc = ensure(s.small, SM_BYTES))
+	if (int rc = ensure(s.zero, SM_BYTES))
 		return rc;
+	HIPCHK(hipMemset(s.zero.p, 0, SM_BYTES));
 	if (int rc = ensure(s.sticky, 256))
 		return rc;
 	HIPCHK(hipMemset(s.sticky.p, 0, 256));
@@ -195,7 +199,7 @@ int slot_init(Slot &s, u64 portion)
 
 void slot_destroy(Slot &s)
 {
-	for (DBuf *b : {&s.in, &s.pack_start, &s.recA, &s.recB, &s.zero, &s.dbase, &s.out, &s.lut, &s.lutsh, &s.small, &s.sticky})
+	for (DBuf *b : {&s.in, &s.pack_start, &s.recA, &s.recB, &s.zero, &s.dbase, &s.out, &s.lut, &s.sticky})
 		if (b->p)
 			(void)hipFree(b->p);
 	if (s.h_res)
@@ -209,7 +213,7 @@ void slot_destroy(Slot &s)
 		(void)hipStreamDestroy(s.stream);
 }
 
-template <typename T> T *small_ptr(Slot &s, size_t off) { return reinterpret_cast<T *>(static_cast<char *>(s.small.p) + off); }
+template <typename T> T *small_ptr(Slot &s, size_t off) { return reinterpret_cast<T *>(static_cast<char *>(s.zero.p) + off); }
 template <typename T> T *zero_ptr(Slot &s, size_t off) { return reinterpret_cast<T *>(static_cast<char *>(s.zero.p) + off); }
 u32 *err_ptr(Slot &s) { return static_cast<u32 *>(s.sticky.p); }
 
@@ -253,10 +257,13 @@ int read_and_clear_sticky(Slot &s, u32 &err)
 }
 
 /* ---- zero-region planning --------------------------------------------------------------------------------------- */
-template <int SIZE> ZeroPlan make_plan(const Slot &s, u64 size, u64 n_rec, u32 n_pass, bool front, bool sort, bool compact)
+u32 lut_shards_for(u64 lut_entries) { return lut_entries <= 1024 ? 32u : (lut_entries <= 16384 ? 4u : 1u); }
+
+template <int SIZE>
+ZeroPlan make_plan(const Slot &s, u64 size, u64 n_rec, u32 n_pass, bool front, bool sort, bool compact, u64 lut_shard_entries = 0)
 {
 	ZeroPlan z;
-	size_t off = 0;
+	size_t off = up256(SM_BYTES); /* the small block comes first */
 	if (front) {
 		z.bitmap = off;
 		off += up256(((size + 31) / 32 + 2) * 4);
@@ -270,6 +277,8 @@ template <int SIZE> ZeroPlan make_plan(const Slot &s, u64 size, u64 n_rec, u32 n
 	if (compact) {
 		z.cp_status = off;
 		off += up256(((n_rec + CpCfg<SIZE>::TILE - 1) / CpCfg<SIZE>::TILE) * 8 + 8);
+		z.lutsh = off;
+		off += up256(lut_shard_entries * 8); /* n_shards x entries when the LUT is sharded */
 	}
 	if (sort && n_rec >= 2) {
 		const u64 max_tiles = (std::min(n_rec, s.portion) + RsCfg<SIZE>::TILE - 1) / RsCfg<SIZE>::TILE;
@@ -284,8 +293,6 @@ template <int SIZE> ZeroPlan make_plan(const Slot &s, u64 size, u64 n_rec, u32 n
 
 int apply_plan(Slot &s, const ZeroPlan &z)
 {
-	if (!z.total)
-		return 0;
 	if (int rc = ensure(s.zero, z.total))
 		return rc;
 	HIPCHK(hipMemsetAsync(s.zero.p, 0, z.total, s.stream));
@@ -308,13 +315,13 @@ int sort_device_t(Slot &s, const ZeroPlan &z, u64 *d_recs, u64 *d_tmp, u64 n, u3
 	u32 *counters = small_ptr<u32>(s, SM_COUNTERS);
 	u64 *work = small_ptr<u64>(s, SM_DBASE_WORK);
 
-	if (!hist_done) {
+	if (!hist_done) { /* digit bases: the expansion's last workgroup made them when the histograms were fused into it */
 		u64 blocks = (n + 255) / 256;
 		if (blocks > 256 * 8)
 			blocks = 256 * 8; /* 8 workgroups per CU, grid-stride */
 		k_hist<SIZE><<<dim3((u32)blocks), dim3(256), (size_t)n_pass * 1024, s.stream>>>(src, n, n_pass, ghist);
+		k_hist_scan<<<dim3(n_pass), dim3(256), 0, s.stream>>>(ghist, dbase);
 	}
-	k_hist_scan<<<dim3(n_pass), dim3(256), 0, s.stream>>>(ghist, dbase);
 	if (s.timed)
 		HIPCHK(hipEventRecord(s.ev[3], s.stream));
 	u32 launch = 0;
@@ -417,15 +424,19 @@ int front_end(Slot &s, const ZeroPlan &z, const DevParams &P, const uint8_t *d_i
 	k_parse_packs<<<dim3((u32)n_packs), dim3(256), 0, s.stream>>>(d_in, d_pack_start, (u32)n_packs, P.k, bitmap, err);
 	if (s.timed)
 		HIPCHK(hipEventRecord(s.ev[1], s.stream));
-	const bool fuse = n_pass <= EXP_FUSE_MAX_PASS && n_rec >= 2; /* LDS: 1 KB of counters per pass next to the 33 KB of slice state */
-	const u32 blocks = (u32)std::min<u64>(n_chunks, 256 * 2 * (1024 / EXP_BLOCK));
-	if (fuse)
-		k_expand<SIZE, true><<<dim3(blocks), dim3(EXP_BLOCK), exp_lds_bytes<true>(n_pass), s.stream>>>(
-		    d_in, size, bitmap, P.k, P.both_strands, n_pass, n_rec, (u64 *)s.recA.p, ghist, status, counters + counter_idx, (u32)n_chunks, err);
-	else
-		k_expand<SIZE, false><<<dim3(blocks), dim3(EXP_BLOCK), exp_lds_bytes<false>(n_pass), s.stream>>>(
-		    d_in, size, bitmap, P.k, P.both_strands, n_pass, n_rec, (u64 *)s.recA.p, ghist, status, counters + counter_idx, (u32)n_chunks, err);
-	++counter_idx;
+	const bool fuse = n_pass <= EXP_FUSE_MAX_PASS && n_rec >= 2; /* LDS: 1 KB of counters per pass next to the slice state */
+	const u32 blocks = (u32)std::min<u64>(n_chunks, 256 * 4 * (512 / EXP_BLOCK)); /* persistent workgroups, up to 4 per CU */
+	if (fuse) {
+		if (int rc = ensure(s.dbase, (size_t)n_pass * 256 * 8))
+			return rc;
+		k_expand<SIZE, true><<<dim3(blocks), dim3(EXP_BLOCK), exp_lds_bytes<true>(n_pass, P.k), s.stream>>>(
+		    d_in, size, bitmap, P.k, P.both_strands, n_pass, n_rec, (u64 *)s.recA.p, ghist, status, counters + counter_idx, (u32)n_chunks, err,
+		    (u64 *)s.dbase.p, counters + counter_idx + 1);
+	} else
+		k_expand<SIZE, false><<<dim3(blocks), dim3(EXP_BLOCK), exp_lds_bytes<false>(n_pass, P.k), s.stream>>>(
+		    d_in, size, bitmap, P.k, P.both_strands, n_pass, n_rec, (u64 *)s.recA.p, ghist, status, counters + counter_idx, (u32)n_chunks, err,
+		    nullptr, counters + counter_idx + 1);
+	counter_idx += 2;
 	hist_done = fuse;
 	if (s.timed)
 		HIPCHK(hipEventRecord(s.ev[2], s.stream));
@@ -445,25 +456,18 @@ int launch_compact(Slot &s, const ZeroPlan &z, const u64 *sorted, u64 n, const D
 		return fail(KMC_HIP_EINVAL, "bin too large");
 	if (counter_idx >= N_COUNTERS)
 		return fail(KMC_HIP_EINVAL, "too many launches for one bin");
-	int rc = 0;
 	const bool use_lut = lut_entries && !P.without_output && !P.kff;
-	const u32 n_sh = !use_lut ? 1u : (lut_entries <= 1024 ? 32u : (lut_entries <= 16384 ? 4u : 1u));
+	const u32 n_sh = !use_lut ? 1u : lut_shards_for(lut_entries);
 	u64 *lut_base = d_lut;
-	if (use_lut && n_sh > 1) {
-		if ((rc = ensure(s.lutsh, (size_t)n_sh * lut_entries * 8)))
-			return rc;
-		HIPCHK(hipMemsetAsync(s.lutsh.p, 0, (size_t)n_sh * lut_entries * 8, s.stream));
-		lut_base = (u64 *)s.lutsh.p;
-	} else if (use_lut) {
+	if (use_lut && n_sh > 1)
+		lut_base = zero_ptr<u64>(s, z.lutsh); /* zeroed with the rest of the bin's zero region */
+	else if (use_lut)
 		HIPCHK(hipMemsetAsync(d_lut, 0, lut_entries * 8, s.stream));
-	}
+	/* the last workgroup to finish folds the tally shards into d_stats and the LUT shards into d_lut */
 	k_compact<SIZE><<<dim3((u32)((c_tiles + CP_TPB - 1) / CP_TPB)), dim3(CP_BLOCK), 0, s.stream>>>(
 	    sorted, n, P, d_out, out_capacity, lut_base, n_sh, lut_entries, small_ptr<u64>(s, SM_SHARDS), d_out_bytes, zero_ptr<u64>(s, z.cp_status),
-	    counters + counter_idx, (u32)c_tiles, err);
-	++counter_idx;
-	const u64 red_entries = (use_lut && n_sh > 1) ? lut_entries : 0;
-	k_finish<<<dim3((u32)std::max<u64>(1, (red_entries + 255) / 256)), dim3(256), 0, s.stream>>>(small_ptr<u64>(s, SM_SHARDS), d_stats, n,
-	                                                                                             (const u64 *)s.lutsh.p, n_sh, red_entries, d_lut);
+	    counters + counter_idx, (u32)c_tiles, err, d_stats, d_lut, counters + counter_idx + 1);
+	counter_idx += 2;
 	HIPCHK(hipGetLastError());
 	return 0;
 }
@@ -495,9 +499,10 @@ int run_bin_device_t(Slot &s, const DevParams &P, const uint8_t *d_in, u64 size,
 	int rc = 0;
 	if ((rc = ensure(s.recA, n_rec * SIZE * 8 + 256)) || (rc = ensure(s.recB, n_rec * SIZE * 8 + 256)))
 		return rc;
-	const ZeroPlan z = make_plan<SIZE>(s, size, n_rec, n_pass, true, true, true);
-	HIPCHK(hipMemsetAsync(s.small.p, 0, SM_BYTES, s.stream));
-	if ((rc = apply_plan(s, z)))
+	const bool use_lut = lut_entries && !P.without_output && !P.kff;
+	const u32 n_sh = use_lut ? lut_shards_for(lut_entries) : 1u;
+	const ZeroPlan z = make_plan<SIZE>(s, size, n_rec, n_pass, true, true, true, n_sh > 1 ? (u64)n_sh * lut_entries : 0);
+	if ((rc = apply_plan(s, z))) /* ONE memset per bin: small block, bitmap, look-back words, histograms, LUT shards, scatter status */
 		return rc;
 	if (s.timed)
 		HIPCHK(hipEventRecord(s.ev[0], s.stream));
@@ -570,7 +575,6 @@ int debug_expand_t(Slot &s, const DevParams &P, u64 size, u64 n_rec, u64 np)
 		return rc;
 	const u32 n_pass = (2 * P.k + 7) / 8;
 	const ZeroPlan z = make_plan<SIZE>(s, size, n_rec, n_pass, true, false, false);
-	HIPCHK(hipMemsetAsync(s.small.p, 0, SM_BYTES, s.stream));
 	if ((rc = apply_plan(s, z)))
 		return rc;
 	u32 counter_idx = 0;
@@ -580,8 +584,9 @@ int debug_expand_t(Slot &s, const DevParams &P, u64 size, u64 n_rec, u64 np)
 template <int SIZE>
 int debug_compact_t(Slot &s, const DevParams &P, u64 n, u64 out_capacity, u64 lut_entries)
 {
-	const ZeroPlan z = make_plan<SIZE>(s, 0, n, 0, false, false, true);
-	HIPCHK(hipMemsetAsync(s.small.p, 0, SM_BYTES, s.stream));
+	const bool use_lut = lut_entries && !P.without_output && !P.kff;
+	const u32 n_sh = use_lut ? lut_shards_for(lut_entries) : 1u;
+	const ZeroPlan z = make_plan<SIZE>(s, 0, n, 0, false, false, true, n_sh > 1 ? (u64)n_sh * lut_entries : 0);
 	if (int rc = apply_plan(s, z))
 		return rc;
 	u32 counter_idx = 0;
@@ -754,7 +759,6 @@ int kmc_hip_synchronize(kmc_hip_ctx *ctx, int dev)
 static int sort_records_device_locked(Slot &s, void *d_recs, void *d_tmp, uint64_t n, uint32_t words, uint32_t key_bytes, void **d_result)
 {
 	s.timed = true;
-	HIPCHK(hipMemsetAsync(s.small.p, 0, SM_BYTES, s.stream));
 	u64 *res = nullptr;
 	if (int rc = sort_device(s, (u64 *)d_recs, (u64 *)d_tmp, n, words, key_bytes, &res))
 		return rc;
@@ -821,7 +825,7 @@ static int process_bin_device_on(kmc_hip_ctx *ctx, int dev, Slot &s, const DevPa
 	(void)ctx;
 	(void)dev;
 	std::lock_guard<std::mutex> lck(s.mtx);
-	s.timed = true;
+	s.timed = sync || (s.async_seq++ % TIMING_SAMPLE) == 0;
 	if (int rc = run_bin_device(s, P, d_superkmers, size, n_rec, (const u64 *)d_pack_start, n_packs, d_out, out_capacity, (u64 *)d_out_bytes,
 	                            (u64 *)d_lut, lut_entries, (u64 *)d_stats))
 		return rc;
@@ -870,8 +874,15 @@ int kmc_hip_process_bins_device(kmc_hip_ctx *ctx, int dev, const kmc_hip_bin_par
 		return rc;
 	if (n_bins && !bins)
 		return fail(KMC_HIP_EINVAL, "bins == NULL");
-	if (n_streams <= 0)
-		n_streams = N_BATCH_STREAMS;
+	if (n_streams <= 0) {
+		/* auto: bins whose record arrays are large fill the GPU on their own, one after the other on ONE stream (2 streams: +2 %
+		 * at 48 M k-mers per bin, and the per-launch timings stop meaning anything); small bins need each other's company */
+		u64 recs = 0;
+		for (uint64_t i = 0; i < n_bins; ++i)
+			recs += bins[i].n_rec;
+		const u64 avg_bytes = n_bins ? recs / n_bins * (u64)((P.k + 31) / 32) * 8 : 0;
+		n_streams = avg_bytes >= (64ull << 20) ? 1 : N_BATCH_STREAMS;
+	}
 	if (n_streams > N_SLOTS)
 		n_streams = N_SLOTS;
 	for (uint64_t i = 0; i < n_bins; ++i)
@@ -988,9 +999,9 @@ int kmc_hip_process_bin_submit(kmc_hip_ctx *ctx, int dev, int slot, const kmc_hi
 	                         small_ptr<u64>(s, SM_STATS))))
 		return rc;
 	if (n_rec == 0) /* the empty-bin path does not touch the small block */
-		HIPCHK(hipMemsetAsync(s.small.p, 0, 64, s.stream));
+		HIPCHK(hipMemsetAsync(s.zero.p, 0, 64, s.stream));
 	HIPCHK(hipMemcpyAsync(small_ptr<u32>(s, SM_ERR), s.sticky.p, 4, hipMemcpyDeviceToDevice, s.stream));
-	HIPCHK(hipMemcpyAsync(s.h_res, s.small.p, sizeof(HostRes), hipMemcpyDeviceToHost, s.stream));
+	HIPCHK(hipMemcpyAsync(s.h_res, s.zero.p, sizeof(HostRes), hipMemcpyDeviceToHost, s.stream));
 	s.pending = true;
 	s.h_out = out_suffix;
 	s.h_lut = (u64 *)lut;
@@ -1125,7 +1136,7 @@ int kmc_hip_debug_compact(kmc_hip_ctx *ctx, int dev, const kmc_hip_bin_params *p
 		return rc;
 	HIPCHK(hipStreamSynchronize(s.stream));
 	HostRes r;
-	HIPCHK(hipMemcpy(&r, s.small.p, sizeof r, hipMemcpyDeviceToHost));
+	HIPCHK(hipMemcpy(&r, s.zero.p, sizeof r, hipMemcpyDeviceToHost));
 	u32 err = 0;
 	if ((rc = read_and_clear_sticky(s, err)))
 		return rc;

@@ -14,6 +14,7 @@
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
+#include <chrono>
 #include <cstring>
 #include <sys/mman.h>
 #include <thread>
@@ -217,6 +218,9 @@ void *kmc_synth_bins_range(uint64_t seed, uint64_t genome_len, uint64_t read_beg
 		for (auto &x : th)
 			x.join();
 	};
+	const bool verbose = getenv("KMC_SYNTH_VERBOSE") != nullptr;
+	auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+	const double t0 = now();
 	/* pass 1: count */
 	std::vector<Cell> cells((size_t)n_chunks * n_bins);
 	run_threads([&](int t) {
@@ -227,6 +231,7 @@ void *kmc_synth_bins_range(uint64_t seed, uint64_t genome_len, uint64_t read_beg
 			gen_chunk(seed, genome, a, b, read_len, err, k, sig_len, n_bins, sink);
 		}
 	});
+	const double t1 = now();
 	Result *R = new Result();
 	R->image.assign(n_bins, nullptr);
 	R->packs.assign(n_bins, nullptr);
@@ -270,6 +275,7 @@ void *kmc_synth_bins_range(uint64_t seed, uint64_t genome_len, uint64_t read_beg
 		return nullptr;
 	}
 	/* pass 2: write in place */
+	const double t2 = now();
 	run_threads([&](int t) {
 		std::vector<Cursor> cur(n_bins);
 		for (uint64_t c = t; c < n_chunks; c += n_threads) {
@@ -286,6 +292,9 @@ void *kmc_synth_bins_range(uint64_t seed, uint64_t genome_len, uint64_t read_beg
 			sink.close_packs(n_bins);
 		}
 	});
+	if (verbose)
+		fprintf(stderr, "[kmc_synth] %d threads, %llu reads, %u bins: count %.2f s, allocate %.2f s, write %.2f s\n", n_threads,
+		        (unsigned long long)n_reads, n_bins, t1 - t0, t2 - t1, now() - t2);
 	*out_images = R->image.data();
 	*out_sizes = R->size.data();
 	*out_n_rec = R->n_rec.data();

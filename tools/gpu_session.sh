@@ -2,7 +2,7 @@
 # One gpurun call = one measurement session; everything lands under gpurun_out/$TAG. Usage: tools/gpu_session.sh TAG step...
 TAG=$1; shift
 OUT=gpurun_out/$TAG; mkdir -p $OUT /dev/shm/kmccache
-export TMPDIR=/tmp HSA_ENABLE_IPC_MODE_LEGACY=0
+export TMPDIR=/tmp HSA_ENABLE_IPC_MODE_LEGACY=0 KMC_SYNTH_VERBOSE=1
 one_bin="--leg configs[1] --reads 13300000 --genome 66000000 --bins 1 --steps 3 --warmup 1 --no-digest"
 bins512="--leg 2gbp-512bins --reads 13300000 --genome 66000000 --bins 512 --steps 3 --warmup 1 --no-digest"
 for step in "$@"; do
@@ -14,6 +14,13 @@ for step in "$@"; do
     benchq)  timeout 900 python bench.py --no-cpu-baseline --no-secondary > $OUT/benchq.json 2> $OUT/benchq.err; tail -c 300 $OUT/benchq.err ;;
     e2e)     timeout 900 python tools/e2e_matrix.py > $OUT/e2e_matrix.jsonl 2> $OUT/e2e_matrix.err ;;
     streams:*) n=${step#streams:}; timeout 900 python bench.py --cache /dev/shm/kmccache --streams $n --no-cpu-baseline --no-secondary --no-host-boundary --no-digest --steps 3 > $OUT/c3_streams$n.json 2> $OUT/c3_streams$n.err ;;
+    small)   timeout 600 python bench.py --leg custom --reads 2000000 --genome 10000000 --bins 512 --steps 5 --warmup 1 --no-digest > $OUT/bins512small.json 2> $OUT/bins512small.err ;;
+    b512)    timeout 600 python bench.py $bins512 > $OUT/bins512.json 2> $OUT/bins512.err ;;
+    one)     timeout 600 python bench.py $one_bin > $OUT/onebin.json 2> $OUT/onebin.err ;;
+    synth:*) n=${step#synth:}; KMC_SYNTH_VERBOSE=1 timeout 600 python -c "
+import sys,time; sys.path.insert(0,'.')
+from kmc_amd import capi
+t=time.time(); s=capi.synth_bins(seed=2026, genome_len=1000000000, n_reads=200000000, k=27, n_bins=512, n_threads=$n, copy=False); print('threads $n total', time.time()-t)" > $OUT/synth_$n.txt 2>&1 ;;
     host)    timeout 600 python tools/ubench_host.py > $OUT/ubench_host.json 2> $OUT/ubench_host.err ;;
     var:*)   v=${step#var:}; KMC_HIP_LIB=kmc_amd/variants/libkmc_hip_$v.so timeout 600 python bench.py $one_bin > $OUT/onebin_$v.json 2> $OUT/onebin_$v.err ;;
     var512:*) v=${step#var512:}; KMC_HIP_LIB=kmc_amd/variants/libkmc_hip_$v.so timeout 600 python bench.py $bins512 > $OUT/bins512_$v.json 2> $OUT/bins512_$v.err ;;
