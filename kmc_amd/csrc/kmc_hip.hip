@@ -483,7 +483,13 @@ int run_bin_device_t(Slot &s, const DevParams &P, const uint8_t *d_in, u64 size,
 
 	if ((n_rec == 0) != (size == 0))
 		return fail(KMC_HIP_ECORRUPT, "exactly one of size / n_rec is zero");
+	/* d_stats / d_out_bytes == NULL: the slot's own small block (host-boundary path). Resolved only AFTER apply_plan: growing the
+	 * zero region moves the small block */
 	if (n_rec == 0) {
+		if (!d_stats)
+			d_stats = small_ptr<u64>(s, SM_STATS);
+		if (!d_out_bytes)
+			d_out_bytes = small_ptr<u64>(s, SM_OUTBYTES);
 		HIPCHK(hipMemsetAsync(d_stats, 0, 4 * 8, s.stream));
 		HIPCHK(hipMemsetAsync(d_out_bytes, 0, 8, s.stream));
 		if (lut_entries && !P.without_output)
@@ -504,6 +510,10 @@ int run_bin_device_t(Slot &s, const DevParams &P, const uint8_t *d_in, u64 size,
 	const ZeroPlan z = make_plan<SIZE>(s, size, n_rec, n_pass, true, true, true, n_sh > 1 ? (u64)n_sh * lut_entries : 0);
 	if ((rc = apply_plan(s, z))) /* ONE memset per bin: small block, bitmap, look-back words, histograms, LUT shards, scatter status */
 		return rc;
+	if (!d_stats)
+		d_stats = small_ptr<u64>(s, SM_STATS);
+	if (!d_out_bytes)
+		d_out_bytes = small_ptr<u64>(s, SM_OUTBYTES);
 	if (s.timed)
 		HIPCHK(hipEventRecord(s.ev[0], s.stream));
 	bool hist_done = false;
@@ -995,8 +1005,8 @@ int kmc_hip_process_bin_submit(kmc_hip_ctx *ctx, int dev, int slot, const kmc_hi
 	}
 	s.timed = true;
 	if ((rc = run_bin_device(s, P, (const uint8_t *)s.in.p, size, n_rec, (const u64 *)s.pack_start.p, np, (uint8_t *)s.out.p,
-	                         P.without_output ? 0 : out_capacity, small_ptr<u64>(s, SM_OUTBYTES), (u64 *)s.lut.p, lut_entries,
-	                         small_ptr<u64>(s, SM_STATS))))
+	                         P.without_output ? 0 : out_capacity, nullptr /* out_bytes and stats: the slot's small block */, (u64 *)s.lut.p,
+	                         lut_entries, nullptr)))
 		return rc;
 	if (n_rec == 0) /* the empty-bin path does not touch the small block */
 		HIPCHK(hipMemsetAsync(s.zero.p, 0, 64, s.stream));
