@@ -1371,11 +1371,18 @@ __global__ void __launch_bounds__(CP_BLOCK, CP_MIN_WAVES) k_compact(const u64 *_
 			if (lane == 0)
 				stats[3] = n;
 		}
-		if (use_lut && lut_shards > 1) {
+		if (use_lut && lut_shards > 1) { /* <= 8 K agent-scope loads (kmc_hip.hip lut_shards_for), 8 in flight per thread */
 			for (u64 i = threadIdx.x; i < lut_stride; i += CP_BLOCK) {
 				u64 v = 0;
-				for (u32 sidx = 0; sidx < lut_shards; ++sidx)
-					v += ld_agent(&lut_base[(size_t)sidx * lut_stride + i]);
+				for (u32 s0 = 0; s0 < lut_shards; s0 += 8) {
+					u64 part[8];
+#pragma unroll
+					for (int q = 0; q < 8; ++q)
+						part[q] = (s0 + q < lut_shards) ? ld_agent(&lut_base[(size_t)(s0 + q) * lut_stride + i]) : 0ull;
+#pragma unroll
+					for (int q = 0; q < 8; ++q)
+						v += part[q];
+				}
 				lut_out[i] = v;
 			}
 		}

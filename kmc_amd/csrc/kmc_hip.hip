@@ -257,7 +257,10 @@ int read_and_clear_sticky(Slot &s, u32 &err)
 }
 
 /* ---- zero-region planning --------------------------------------------------------------------------------------- */
-u32 lut_shards_for(u64 lut_entries) { return lut_entries <= 1024 ? 32u : (lut_entries <= 16384 ? 4u : 1u); }
+/* Small LUTs are sharded: in sorted order every tile in flight updates the same one or two entries, and same-address device atomics
+ * serialise (r01: 11 of the compaction's 12 ms at 64 entries). From 4^6 entries on the tiles in flight spread over enough of them.
+ * The shards are summed by the compaction's last workgroup, so shards x entries stays small (<= 8 K loads). */
+u32 lut_shards_for(u64 lut_entries) { return lut_entries <= 256 ? 32u : (lut_entries <= 1024 ? 8u : 1u); }
 
 template <int SIZE>
 ZeroPlan make_plan(const Slot &s, u64 size, u64 n_rec, u32 n_pass, bool front, bool sort, bool compact, u64 lut_shard_entries = 0)
@@ -835,7 +838,7 @@ static int process_bin_device_on(kmc_hip_ctx *ctx, int dev, Slot &s, const DevPa
 	(void)ctx;
 	(void)dev;
 	std::lock_guard<std::mutex> lck(s.mtx);
-	s.timed = sync || (s.async_seq++ % TIMING_SAMPLE) == 0;
+	s.timed = sync || (s.async_seq++ % TIMING_SAMPLE) == 0; /* async_seq restarts with kmc_hip_scatter_totals(reset) */
 	if (int rc = run_bin_device(s, P, d_superkmers, size, n_rec, (const u64 *)d_pack_start, n_packs, d_out, out_capacity, (u64 *)d_out_bytes,
 	                            (u64 *)d_lut, lut_entries, (u64 *)d_stats))
 		return rc;
@@ -1255,6 +1258,7 @@ int kmc_hip_scatter_totals(kmc_hip_ctx *ctx, int dev, int reset, uint64_t *n_lau
 		keys += s.sc_keys_total;
 		ms += s.sc_ms_total;
 		if (reset) {
+			s.async_seq = 0;
 			s.sc_launch_total = 0;
 			s.sc_keys_total = 0;
 			s.sc_ms_total = 0;
