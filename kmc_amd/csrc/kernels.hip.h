@@ -38,20 +38,25 @@ enum : u32 { KERR_CORRUPT = 1u, KERR_NREC = 2u, KERR_CAPACITY = 4u, KERR_WATCHDO
 #endif
 constexpr int RS_BLOCK = RS_BLOCK_THREADS, RS_WAVES = RS_BLOCK / 64;                           /* radix scatter workgroup       */
 #ifndef CP_BLOCK_THREADS
-#define CP_BLOCK_THREADS 256
+#define CP_BLOCK_THREADS 512 /* compaction of the 1.65 G k-mer bin: 256 threads 11.5 ms, 512 threads 10.6 ms (tile = threads x 16 records) */
 #endif
 constexpr int CP_BLOCK = CP_BLOCK_THREADS;                                                     /* compaction workgroup          */
 constexpr u32 SPIN_LIMIT = 1u << 24;                                              /* look-back watchdog (polls)    */
 
 #ifndef RS_WORDS_PER_THREAD
-#define RS_WORDS_PER_THREAD 8 /* 8-byte words held per thread in a scatter tile */
+#define RS_WORDS_PER_THREAD 8 /* 8-byte words held per thread in a scatter tile, records of 2+ words */
+#endif
+#ifndef RS_WORDS_PER_THREAD_1
+#define RS_WORDS_PER_THREAD_1 10 /* one-word records (k <= 32): 10 240-record tiles, 320-byte runs. One launch of 412 M records (round 2):
+                                  * 8 words 1.82-1.83 ms, 9: 1.83, 10: 1.69-1.74, 12 (9 VGPRs spilled): 1.71, 16 (19 spilled): 2.16 */
 #endif
 #ifndef RS_STAGES
-#define RS_STAGES 2
+#define RS_STAGES 2 /* 10 words: 2 slices 1.69-1.74 ms, 5 slices 1.88 */
 #endif
 #define RS_STAGES_REQ RS_STAGES
-template <int SIZE> struct RsCfg { /* records per thread in a scatter tile: RS_WORDS_PER_THREAD x 8 B per thread for every SIZE */
-	static constexpr int ITEMS = (RS_WORDS_PER_THREAD / SIZE) > 2 ? (RS_WORDS_PER_THREAD / SIZE) : 2;
+template <int SIZE> struct RsCfg { /* records per thread in a scatter tile */
+	static constexpr int WORDS = SIZE == 1 ? RS_WORDS_PER_THREAD_1 : RS_WORDS_PER_THREAD;
+	static constexpr int ITEMS = (WORDS / SIZE) > 2 ? (WORDS / SIZE) : 2;
 	static constexpr int TILE = RS_BLOCK * ITEMS;
 	static_assert(TILE <= 32768, "tile-relative slots are kept as 16-bit values (0xFFFF marks an absent record)");
 	static constexpr int STAGES = (ITEMS % RS_STAGES_REQ == 0) ? RS_STAGES_REQ : 1; /* LDS staging slices per tile */
@@ -366,7 +371,7 @@ __global__ void __launch_bounds__(256) k_parse_packs(const uint8_t *__restrict__
 #define EXP_BLOCK_THREADS 512 /* measured on the 1.65 G k-mer bin: 256 thr 13.7 ms, 512 thr 9.2 ms, 1024 thr 12.1 ms */
 #endif
 #ifndef EXP_CHUNK_BYTES
-#define EXP_CHUNK_BYTES 8192
+#define EXP_CHUNK_BYTES 16384 /* the 1.65 G k-mer bin: 4 KB slices 9.15 ms, 8 KB 7.85, 16 KB 7.15 (fewer scans and look-backs per byte) */
 #endif
 #ifndef EXP_KWIN_KMERS
 #define EXP_KWIN_KMERS 8192
@@ -377,6 +382,7 @@ constexpr int EXP_CHUNK = EXP_CHUNK_BYTES, EXP_TAIL = 160, EXP_KWIN = EXP_KWIN_K
  * sized by this (k=27: 1025 entries instead of a worst case of 4096 -> 38 KB instead of 57 KB per workgroup: 4 workgroups per CU, not 2) */
 __host__ __device__ constexpr u32 exp_max_sk(u32 k) { return (u32)EXP_CHUNK / (1 + ((k + 3) >> 2)) + 2; }
 
+static_assert(EXP_CHUNK / 32 <= EXP_BLOCK && EXP_CHUNK <= 65536, "one bitmap word per thread; 16-bit positions inside a slice");
 template <int SIZE, bool FUSE_HIST>
 __global__ void __launch_bounds__(EXP_BLOCK) k_expand(const uint8_t *__restrict__ data, u64 size, const u32 *__restrict__ bitmap, u32 k,
                                                  u32 both_strands, u32 n_pass, u64 n_rec, u64 *__restrict__ out, u64 *__restrict__ ghist,

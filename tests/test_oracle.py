@@ -192,6 +192,36 @@ def test_reader_plugin_keeps_the_reference_database(flags, ref_bins, tmp_path):
             assert _md5(str(tmp_path / ("ref" + ext))) == _md5(str(tmp_path / (out + ext))), (out, ext)
 
 
+@pytest.mark.parametrize("flags,env", [
+    (["-k27", "-p7", "-n100"], {"KMC_HIP_WRITERS": "1"}),      # other signature length / bin count: the bin -> signatures table
+    (["-k27", "-ci1", "-cs3"], {"KMC_HIP_WRITERS": "8"}),       # counter bytes 1 -> 1 byte at cs3, everything counted
+    (["-k33", "-cs100000"], {}),                                 # 3-byte counters, lut_prefix_len 5
+    (["-k27"], {"KMC_HIP_COMPLETER": "ref"}),                    # forced reference completer
+    (["-k27", "-okff"], {}),                                     # KFF: the plug-in hands over to the reference completer
+], ids=lambda x: "".join(x) if isinstance(x, list) else "-".join(f"{a}{b}" for a, b in x.items()) or "default")
+def test_completer_plugin_writes_the_reference_files(flags, env, ref_bins, tmp_path):
+    """kb_completer_plugin.h: offsets / LUT prefix sums / signature map on the popping thread, suffix data written by a pool
+    with pwrite. .kmc_pre/.kmc_suf (or .kff) byte-identical to the unmodified reference's -sr1 run."""
+    exe_pr = os.path.join(ROOT, "oracle", "_ref", "kmc_oracle_pr")
+    if ref_bins is None or not os.path.exists(exe_pr):
+        pytest.skip("oracle/_ref/kmc_oracle_pr not built")
+    from kmc_amd import synth
+
+    fq = str(tmp_path / "in.fq")
+    synth.make_fastq(fq, seed=41, genome_len=90_000, n_reads=7000)
+    for exe, out, mode, extra in ((ref_bins["kmc"], "ref", ["-sr1"], {}), (exe_pr, "pr", ["-t8", "-sr4"], env)):
+        tmp = tmp_path / ("tmp_" + out)
+        tmp.mkdir()
+        r = subprocess.run([exe, *flags, *mode, fq, str(tmp_path / out), str(tmp)], env=dict(os.environ, **extra), capture_output=True,
+                           text=True, timeout=300)
+        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    exts = (".kff",) if "-okff" in flags else (".kmc_pre", ".kmc_suf")
+    for ext in exts:
+        assert _md5(str(tmp_path / ("ref" + ext))) == _md5(str(tmp_path / ("pr" + ext))), ext
+    # the five statistics on stdout come from GetTotal()
+    assert re.findall(r"No\. of unique k-mers\s*:\s*(\d+)", r.stdout)
+
+
 def test_dropin_binary_fails_loudly_without_a_gpu(ref_bins, tmp_path):
     """The product worker has no CPU fallback: on a box without a GPU `kmc_hip` must stop with the engine's error
     (CCriticalErrorHandler), not count on the host. Covers the eager background initialisation of hip_loader.cpp too

@@ -13,8 +13,24 @@ VARIANTS = {
     "k8": ["-DRS_LOOKBACK_K=8"],
     "cp3": ["-DCP_MIN_WAVES=3"],
     "b512x16": ["-DRS_BLOCK_THREADS=512", "-DRS_WORDS_PER_THREAD=16", "-DRS_MIN_WAVES=6"],
-    "w16s4": ["-DRS_WORDS_PER_THREAD=16", "-DRS_STAGES=4"],  # 16 K-record tiles (512-byte runs), 2 workgroups/CU, ~19 VGPRs spilled
-    "w16s4_1cu": ["-DRS_WORDS_PER_THREAD=16", "-DRS_STAGES=4", "-DRS_MIN_WAVES=4"],  # same tile, 128 VGPRs, 1 workgroup/CU
+    "w8": ["-DRS_WORDS_PER_THREAD_1=8"],
+    "w16s4": ["-DRS_WORDS_PER_THREAD_1=16", "-DRS_STAGES=4"],  # 16 K-record tiles (512-byte runs), 2 workgroups/CU, ~19 VGPRs spilled
+    "w16s4_1cu": ["-DRS_WORDS_PER_THREAD_1=16", "-DRS_STAGES=4", "-DRS_MIN_WAVES=4"],  # same tile, 128 VGPRs, 1 workgroup/CU
+    "w12s3": ["-DRS_WORDS_PER_THREAD_1=12", "-DRS_STAGES=3"],  # 12 K-record tiles, 384-byte runs, 2 workgroups/CU
+    "w10s2": ["-DRS_WORDS_PER_THREAD_1=10", "-DRS_STAGES=2"],
+    "exp16k": ["-DEXP_CHUNK_BYTES=16384"],
+    "exp4k": ["-DEXP_CHUNK_BYTES=4096", "-DEXP_KWIN_KMERS=4096"],
+    "cp512": ["-DCP_BLOCK_THREADS=512"],
+    "w10s5": ["-DRS_WORDS_PER_THREAD_1=10", "-DRS_STAGES=5"],
+    "w9s3": ["-DRS_WORDS_PER_THREAD_1=9", "-DRS_STAGES=3"],
+    "w11s1": ["-DRS_WORDS_PER_THREAD_1=11", "-DRS_STAGES=1"],
+    "w10s2k2": ["-DRS_WORDS_PER_THREAD_1=10", "-DRS_STAGES=2", "-DRS_LOOKBACK_K=2"],
+    "w10s2k8": ["-DRS_WORDS_PER_THREAD_1=10", "-DRS_STAGES=2", "-DRS_LOOKBACK_K=8"],
+    "exp16kb1024": ["-DEXP_CHUNK_BYTES=16384", "-DEXP_BLOCK_THREADS=1024"],
+    "exp16kw16": ["-DEXP_CHUNK_BYTES=16384", "-DEXP_KWIN_KMERS=16384"],
+    "cp512w8": ["-DCP_BLOCK_THREADS=512", "-DCP_WORDS_PER_THREAD=8", "-DCP_MIN_WAVES=8"],
+    "cp512m3": ["-DCP_BLOCK_THREADS=512", "-DCP_MIN_WAVES=3"],
+    "combo1": ["-DRS_WORDS_PER_THREAD_1=10", "-DRS_STAGES=2", "-DEXP_CHUNK_BYTES=16384", "-DCP_BLOCK_THREADS=512"],
     "nohist": ["-DEXP_NO_HIST"],  # expand without the fused histograms (sort output is garbage): what do the LDS atomics cost?
     "exp256": ["-DEXP_BLOCK_THREADS=256"],
     "cp8": ["-DCP_WORDS_PER_THREAD=8", "-DCP_MIN_WAVES=8"],  # compaction: 2048-record tiles, 64 VGPRs, twice the workgroups per CU

@@ -8,7 +8,7 @@ bins512="--leg 2gbp-512bins --reads 13300000 --genome 66000000 --bins 512 --step
 for step in "$@"; do
   t0=$(date +%s)
   case $step in
-    facts)   { nproc; free -g | head -2; df -h /dev/shm /tmp . | cat; rocm-smi --showmeminfo vram 2>/dev/null | head -8; } > $OUT/facts.txt 2>&1 ;;
+    facts)   { nproc; cat /sys/fs/cgroup/cpu.max 2>/dev/null; cat /sys/kernel/mm/transparent_hugepage/enabled 2>/dev/null; free -g | head -2; df -h /dev/shm /tmp . | cat; rocm-smi --showmeminfo vram 2>/dev/null | head -8; } > $OUT/facts.txt 2>&1 ;;
     tests)   timeout 1500 python -m pytest tests -m gpu -x -q > $OUT/pytest_gpu.txt 2>&1; tail -3 $OUT/pytest_gpu.txt ;;
     bench)   timeout 1200 python bench.py > $OUT/bench.json 2> $OUT/bench.err; tail -c 600 $OUT/bench.err ;;
     benchq)  timeout 900 python bench.py --no-cpu-baseline --no-secondary > $OUT/benchq.json 2> $OUT/benchq.err; tail -c 300 $OUT/benchq.err ;;
@@ -25,8 +25,8 @@ t=time.time(); s=capi.synth_bins(seed=2026, genome_len=1000000000, n_reads=20000
     var:*)   v=${step#var:}; KMC_HIP_LIB=kmc_amd/variants/libkmc_hip_$v.so timeout 600 python bench.py $one_bin > $OUT/onebin_$v.json 2> $OUT/onebin_$v.err ;;
     var512:*) v=${step#var512:}; KMC_HIP_LIB=kmc_amd/variants/libkmc_hip_$v.so timeout 600 python bench.py $bins512 > $OUT/bins512_$v.json 2> $OUT/bins512_$v.err ;;
     k:*)     k=${step#k:}; timeout 900 python bench.py --k $k --no-cpu-baseline --no-secondary --no-host-boundary --steps 3 > $OUT/bench_k$k.json 2> $OUT/bench_k$k.err ;;
-    prof)    cd /tmp; timeout 1500 rocprofv3 --kernel-trace --stats -d $OLDPWD/$OUT/prof -o kt -- python $OLDPWD/bench.py --no-cpu-baseline --no-secondary --no-host-boundary --no-digest --steps 3 > $OLDPWD/$OUT/prof_bench.json 2> $OLDPWD/$OUT/prof.err; cd $OLDPWD ;;
-    pmc:*)   c=${step#pmc:}; cd /tmp; timeout 1500 rocprofv3 --pmc $c -d $OLDPWD/$OUT/pmc_$c -o pmc -- python $OLDPWD/bench.py --no-cpu-baseline --no-secondary --no-host-boundary --no-digest --steps 1 --warmup 0 > $OLDPWD/$OUT/pmc_$c.json 2> $OLDPWD/$OUT/pmc_$c.err; cd $OLDPWD ;;
+    prof)    cd /tmp; timeout 1500 rocprofv3 --kernel-trace --stats -f csv -d $OLDPWD/$OUT/prof -o kt -- python $OLDPWD/bench.py --no-cpu-baseline --no-secondary --no-host-boundary --no-digest --steps 3 > $OLDPWD/$OUT/prof_bench.json 2> $OLDPWD/$OUT/prof.err; cd $OLDPWD ;;
+    pmc:*)   c=${step#pmc:}; cd /tmp; timeout 1500 rocprofv3 --pmc $c -f csv -d $OLDPWD/$OUT/pmc_$c -o pmc -- python $OLDPWD/bench.py --no-cpu-baseline --no-secondary --no-host-boundary --no-digest --steps 1 --warmup 0 > $OLDPWD/$OUT/pmc_$c.json 2> $OLDPWD/$OUT/pmc_$c.err; cd $OLDPWD ;;
     *) echo "unknown step $step" ;;
   esac
   echo "[$step] $(( $(date +%s) - t0 )) s"

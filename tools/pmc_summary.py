@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Turns two rocprofv3 counter-collection CSVs (one --pmc FETCH_SIZE pass, one --pmc WRITE_SIZE pass, same command) into the
-per-kernel HBM traffic summary bench.py reads (profiles/<round>/final/pmc_hbm_traffic.json).
+per-kernel HBM traffic summary bench.py reads (profiles/<round>/pmc_hbm_traffic.json).
 
 Units and corrections as MI355X_MICROARCH.md §HBM prescribes and as calibrated on tools/ubench_scatter.hip: the counters
 are KiB; FETCH_SIZE reports half of the bytes read on gfx950 (x2), WRITE_SIZE is exact.
@@ -35,10 +35,10 @@ def main():
         rd = 2.0 * f_tot[k] * 1024.0 / n
         wr = w_tot.get(k, 0.0) * 1024.0 / max(w_cnt.get(k, 0), 1)
         kernels[k] = {"launches": n, "hbm_read_bytes_per_launch": rd, "hbm_write_bytes_per_launch": wr, "hbm_bytes_per_launch": rd + wr}
-    json.dump({"note": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes over `python bench.py --steps 2 --warmup 1 "
-                       "--no-cpu-baseline`. Counters are KiB; FETCH_SIZE x2 (gfx950 reports half, calibrated on tools/ubench_scatter.hip), "
+    json.dump({"note": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes over `python bench.py --steps 1 --warmup 0 "
+                       "--no-cpu-baseline --no-secondary --no-host-boundary --no-digest` (configs[2], one stream). Counters are KiB; FETCH_SIZE x2 (gfx950 reports half, calibrated on tools/ubench_scatter.hip), "
                        "WRITE_SIZE exact.",
-               "kernels": kernels, "k_onesweep_records_per_launch_avg": recs}, open(out, "w"), indent=1)
+               "kernels": kernels, "records_per_launch_avg": recs}, open(out, "w"), indent=1)
     for k, v in kernels.items():
         print(f"{k:40s} x{v['launches']:<4d} read {v['hbm_read_bytes_per_launch'] / 1e9:8.3f} GB  write {v['hbm_write_bytes_per_launch'] / 1e9:8.3f} GB")
 
