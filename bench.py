@@ -117,7 +117,7 @@ class Workload:
 def build_workload(ctx, args, k, p, rank, world, keep_host=False):
     """Generate + shard the bin set (kmc_amd/sharding.py), upload this rank's bins. Returns Workload."""
     w = Workload(ctx, p, k)
-    n_threads = max(1, min((os.cpu_count() or 8), 64 if world == 1 else 1 << 30) // max(world, 1))  # 1 GPU: beyond 64 threads the generator gets slower on the GPU box
+    n_threads = max(2, 2 * sharding.effective_cpus() // max(world, 1))  # the box may grant fewer CPUs (cgroup quota) than it shows
     sb = sharding.generate_sharded_bins(SEED, args.genome, args.reads, k, args.bins, rank, world, n_threads, cache_dir=args.cache or None)
     w.setup_s.update(sb.timings)
     own = sb.own
@@ -314,8 +314,8 @@ def reference_legs(k: int, reads: int, genome: int, runs: int = 2):
     """cpu_baseline + e2e on a FASTQ of the SAME reads as the 2 Gbp sample (kmc_amd/csrc/synth_bins.cpp writes both)."""
     ref = os.path.join(ROOT, "oracle", "_ref", "kmc")
     hip = os.path.join(ROOT, "oracle", "_ref", "kmc_hip")
-    cores = os.cpu_count() or 1
-    threads = min(cores, 128)
+    cores = sharding.effective_cpus()  # what the container may really use (cgroup quota), not the hardware threads it shows
+    threads = min(os.cpu_count() or 1, 128)
     ram_gb = os.sysconf("SC_PAGE_SIZE") * os.sysconf("SC_PHYS_PAGES") >> 30
     mem = max(2, min(128, ram_gb // 2))
     need = int(reads * 316 * 2.0) + (1 << 28)
@@ -331,8 +331,20 @@ def reference_legs(k: int, reads: int, genome: int, runs: int = 2):
         sample = f"{reads} reads x150bp of a {genome} bp genome (seed {SEED}; the reads of the 2 Gbp sample), FASTQ written in {t_fq:.1f} s"
         ref_runs = [_run_kmc(ref, [f"-k{k}", f"-t{threads}", f"-m{mem}", "-hp"], fq, td, f"ref{i}") for i in range(runs)]
         s1, s2, st, _ = min(ref_runs, key=lambda x: x[1])
-        out["cpu_baseline"] = {"value": st["total"] / s2 / 1e9, "unit": "Gk-mers/s", "cores": threads, "kind": "reference",
-                               "sample": f"reference kmc 3.2.4 -k{k} -t{threads} -m{mem}, '2nd stage' wall, best of {runs}; {sample} = {st['total']} k-mers",
+        # the reference is also tried with one thread per usable CPU; the better of the two thread counts is the baseline
+        t_alt = max(2, min(threads, cores))
+        if t_alt != threads:
+            ref_runs.append(_run_kmc(ref, [f"-k{k}", f"-t{t_alt}", f"-m{mem}", "-hp"], fq, td, "ref_alt"))
+            if ref_runs[-1][1] < s2:
+                s1, s2, st, _ = ref_runs[-1]
+                threads_used = t_alt
+            else:
+                threads_used = threads
+        else:
+            threads_used = threads
+        out["cpu_baseline"] = {"value": st["total"] / s2 / 1e9, "unit": "Gk-mers/s", "cores": cores, "kind": "reference",
+                               "sample": f"reference kmc 3.2.4 -k{k} -t{threads_used} -m{mem} ({os.cpu_count()} hardware threads visible, {cores} usable "
+                                         f"under the cgroup CPU quota), '2nd stage' wall, best of {len(ref_runs)}; {sample} = {st['total']} k-mers",
                                "stage2_s": s2, "stage1_s": s1, "unique_kmers_per_s": st["unique"] / s2, "stats": st}
         if os.path.exists(hip):
             env = dict(os.environ, KMC_HIP_LIB=capi.lib_path(), KMC_HIP_VERBOSE="1")

@@ -113,6 +113,7 @@ struct Slot {
 	DBuf recA, recB, zero, dbase, out, lut, sticky;
 	HostRes *h_res = nullptr; /* pinned */
 	hipEvent_t ev[6] = {};
+	hipEvent_t done_ev = nullptr; /* blocking-sync event: _wait must not spin (stage-2 workers outnumber the cores a container may use) */
 	/* one event pair per scatter launch since the last harvest (roofline input) */
 	std::vector<hipEvent_t> sc_ev;
 	std::vector<u32> sc_cnt;
@@ -188,6 +189,7 @@ int slot_init(Slot &s, u64 portion)
 	memset(s.h_res, 0, sizeof(HostRes));
 	for (auto &e : s.ev)
 		HIPCHK(hipEventCreate(&e));
+	HIPCHK(hipEventCreateWithFlags(&s.done_ev, hipEventBlockingSync | hipEventDisableTiming));
 	if (int rc = ensure(s.zero, SM_BYTES))
 		return rc;
 	HIPCHK(hipMemset(s.zero.p, 0, SM_BYTES));
@@ -209,6 +211,8 @@ void slot_destroy(Slot &s)
 			(void)hipEventDestroy(e);
 	for (auto &e : s.sc_ev)
 		(void)hipEventDestroy(e);
+	if (s.done_ev)
+		(void)hipEventDestroy(s.done_ev);
 	if (s.stream)
 		(void)hipStreamDestroy(s.stream);
 }
@@ -1015,6 +1019,7 @@ int kmc_hip_process_bin_submit(kmc_hip_ctx *ctx, int dev, int slot, const kmc_hi
 		HIPCHK(hipMemsetAsync(s.zero.p, 0, 64, s.stream));
 	HIPCHK(hipMemcpyAsync(small_ptr<u32>(s, SM_ERR), s.sticky.p, 4, hipMemcpyDeviceToDevice, s.stream));
 	HIPCHK(hipMemcpyAsync(s.h_res, s.zero.p, sizeof(HostRes), hipMemcpyDeviceToHost, s.stream));
+	HIPCHK(hipEventRecord(s.done_ev, s.stream));
 	s.pending = true;
 	s.h_out = out_suffix;
 	s.h_lut = (u64 *)lut;
@@ -1035,7 +1040,7 @@ int kmc_hip_process_bin_wait(kmc_hip_ctx *ctx, int dev, int slot, uint64_t *out_
 	if (!s.pending)
 		return fail(KMC_HIP_EINVAL, "no bin in flight on this slot");
 	s.pending = false;
-	HIPCHK(hipStreamSynchronize(s.stream));
+	HIPCHK(hipEventSynchronize(s.done_ev)); /* blocks in the kernel driver instead of spinning */
 	if (int rc = harvest(s))
 		return rc;
 	const HostRes r = *s.h_res;
@@ -1051,7 +1056,8 @@ int kmc_hip_process_bin_wait(kmc_hip_ctx *ctx, int dev, int slot, uint64_t *out_
 			HIPCHK(hipMemcpyAsync(s.h_out, s.out.p, r.out_bytes, hipMemcpyDeviceToHost, s.stream));
 		if (s.lut_entries)
 			HIPCHK(hipMemcpyAsync(s.h_lut, s.lut.p, s.lut_entries * 8, hipMemcpyDeviceToHost, s.stream));
-		HIPCHK(hipStreamSynchronize(s.stream));
+		HIPCHK(hipEventRecord(s.done_ev, s.stream));
+		HIPCHK(hipEventSynchronize(s.done_ev));
 	}
 	if (out_bytes)
 		*out_bytes = r.out_bytes;

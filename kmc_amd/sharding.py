@@ -9,6 +9,26 @@ import heapq
 import numpy as np
 
 
+def effective_cpus() -> int:
+    """CPUs this process may really use: the smaller of the visible CPUs, the affinity mask and the cgroup CPU quota
+    (the GPU boxes show 256 hardware threads but grant a 16-CPU quota: 256 busy threads then run slower than 32)."""
+    import math
+    import os
+
+    n = os.cpu_count() or 1
+    try:
+        n = min(n, len(os.sched_getaffinity(0)))
+    except Exception:
+        pass
+    try:
+        q, p = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            n = min(n, max(1, math.ceil(int(q) / int(p))))
+    except Exception:
+        pass
+    return n
+
+
 def lpt_assign(sizes, world: int):
     """Longest-processing-time assignment of bins to ranks. `sizes[i]` = cost of bin i (records to sort, the
     quantity CBinDesc::get_sorted_req_sizes orders bins by, queues.h:499-558). Returns world lists of bin ids, each

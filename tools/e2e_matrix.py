@@ -26,6 +26,11 @@ with tempfile.TemporaryDirectory(dir=base) as td:
     capi.synth_fastq(fq, seed=2026, genome_len=genome, n_reads=reads)
     print(json.dumps({"fastq_s": time.time() - t, "reads": reads, "genome": genome, "k": k}), flush=True)
     runs = [("kmc", ["-t128", "-m128"], {}),
+            ("kmc", ["-t16", "-m128"], {}),
+            ("kmc", ["-t32", "-m128"], {}),
+            ("kmc_hip", ["-t32", "-m128", "-sr16"], {}),
+            ("kmc_hip", ["-t32", "-m128", "-sr16"], {"KMC_HIP_COMPLETER": "ref"}),
+            ("kmc_hip", ["-t32", "-m128", "-sr12"], {"KMC_HIP_READERS": "4", "KMC_HIP_WRITERS": "2"}),
             ("kmc_hip", ["-t128", "-m128", "-sr16"], {}),
             ("kmc_hip", ["-t128", "-m128", "-sr16"], {"KMC_HIP_READERS": "1"}),
             ("kmc_hip", ["-t128", "-m128", "-sr16"], {"KMC_HIP_READERS": "16"}),
