@@ -386,6 +386,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true", help="skip the reference/e2e legs")
     ap.add_argument("--no-host-boundary", action="store_true")
     ap.add_argument("--no-secondary", action="store_true")
+    ap.add_argument("--no-two-streams", action="store_true", help="skip the value_two_streams leg (profiling runs: keeps overlapped launches out of the kernel statistics)")
     ap.add_argument("--no-digest", action="store_true")
     ap.add_argument("--cache", default="", help="directory for the generated bin set (tuning sessions: generate once, reuse)")
     args = ap.parse_args()
@@ -504,6 +505,8 @@ def main():
         # The timed region runs big bins back to back on ONE stream, so that a k_onesweep launch has the GPU to itself and its
         # duration means something (HIP events and rocprofv3 agree). Two bins in flight fill each other's tails and gaps:
         try:
+            if args.no_two_streams:
+                raise RuntimeError("skipped (--no-two-streams)")
             run_step(ctx, w, 2)
             t1 = time.perf_counter()
             for _ in range(2):

@@ -149,6 +149,8 @@ def generate_sharded_bins(seed, genome_len, n_reads, k, n_bins, rank=0, world=1,
         sb.size, sb.n_rec, sb.n_packs, sb.n_super = sizes, nrec, npk, nsup
         sb.pieces = {b: [(syn.bins[b][0], syn.bins[b][2])] for b in sb.own}
         sb._keep = [syn]
+        if cache and shutil.disk_usage(cache_dir).free < int(sizes.sum()) + (1 << 30):
+            cache = None  # no room: this run simply does not leave a cache behind
         if cache:
             t = time.time()
             with open(cache + ".bin", "wb") as f:

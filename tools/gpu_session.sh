@@ -10,7 +10,7 @@ for step in "$@"; do
   case $step in
     facts)   { nproc; cat /sys/fs/cgroup/cpu.max 2>/dev/null; cat /sys/kernel/mm/transparent_hugepage/enabled 2>/dev/null; free -g | head -2; df -h /dev/shm /tmp . | cat; rocm-smi --showmeminfo vram 2>/dev/null | head -8; } > $OUT/facts.txt 2>&1 ;;
     tests)   timeout 1500 python -m pytest tests -m gpu -x -q > $OUT/pytest_gpu.txt 2>&1; tail -3 $OUT/pytest_gpu.txt ;;
-    bench)   timeout 1200 python bench.py > $OUT/bench.json 2> $OUT/bench.err; tail -c 600 $OUT/bench.err ;;
+    bench)   timeout 1200 python bench.py --cache /dev/shm/kmccache > $OUT/bench.json 2> $OUT/bench.err; tail -c 600 $OUT/bench.err ;;
     benchq)  timeout 900 python bench.py --no-cpu-baseline --no-secondary > $OUT/benchq.json 2> $OUT/benchq.err; tail -c 300 $OUT/benchq.err ;;
     e2e)     timeout 900 python tools/e2e_matrix.py > $OUT/e2e_matrix.jsonl 2> $OUT/e2e_matrix.err ;;
     streams:*) n=${step#streams:}; timeout 900 python bench.py --cache /dev/shm/kmccache --streams $n --no-cpu-baseline --no-secondary --no-host-boundary --no-digest --steps 3 > $OUT/c3_streams$n.json 2> $OUT/c3_streams$n.err ;;
@@ -25,8 +25,9 @@ t=time.time(); s=capi.synth_bins(seed=2026, genome_len=1000000000, n_reads=20000
     var:*)   v=${step#var:}; KMC_HIP_LIB=kmc_amd/variants/libkmc_hip_$v.so timeout 600 python bench.py $one_bin > $OUT/onebin_$v.json 2> $OUT/onebin_$v.err ;;
     var512:*) v=${step#var512:}; KMC_HIP_LIB=kmc_amd/variants/libkmc_hip_$v.so timeout 600 python bench.py $bins512 > $OUT/bins512_$v.json 2> $OUT/bins512_$v.err ;;
     k:*)     k=${step#k:}; timeout 900 python bench.py --k $k --no-cpu-baseline --no-secondary --no-host-boundary --steps 3 > $OUT/bench_k$k.json 2> $OUT/bench_k$k.err ;;
-    prof)    cd /tmp; timeout 1500 rocprofv3 --kernel-trace --stats -f csv -d $OLDPWD/$OUT/prof -o kt -- python $OLDPWD/bench.py --no-cpu-baseline --no-secondary --no-host-boundary --no-digest --steps 3 > $OLDPWD/$OUT/prof_bench.json 2> $OLDPWD/$OUT/prof.err; cd $OLDPWD ;;
-    pmc:*)   c=${step#pmc:}; cd /tmp; timeout 1500 rocprofv3 --pmc $c -f csv -d $OLDPWD/$OUT/pmc_$c -o pmc -- python $OLDPWD/bench.py --no-cpu-baseline --no-secondary --no-host-boundary --no-digest --steps 1 --warmup 0 > $OLDPWD/$OUT/pmc_$c.json 2> $OLDPWD/$OUT/pmc_$c.err; cd $OLDPWD ;;
+    prof)    cd /tmp; timeout 1500 rocprofv3 --kernel-trace --stats -f csv -d $OLDPWD/$OUT/prof -o kt -- python $OLDPWD/bench.py --cache /dev/shm/kmccache --no-cpu-baseline --no-secondary --no-host-boundary --no-two-streams --no-digest --steps 3 > $OLDPWD/$OUT/prof_bench.json 2> $OLDPWD/$OUT/prof.err; cd $OLDPWD ;;
+    pmc:*)   c=${step#pmc:}; cd /tmp; timeout 1500 rocprofv3 --pmc $c -f csv -d $OLDPWD/$OUT/pmc_$c -o pmc -- python $OLDPWD/bench.py --cache /dev/shm/kmccache --no-cpu-baseline --no-secondary --no-host-boundary --no-two-streams --no-digest --steps 1 --warmup 0 > $OLDPWD/$OUT/pmc_$c.json 2> $OLDPWD/$OUT/pmc_$c.err; cd $OLDPWD ;;
+    trace)   KMC_HIP_LIB=kmc_amd/variants/libkmc_hip_trace.so timeout 300 python tools/trace_run.py $TAG > $OUT/trace_run.txt 2>&1; python tools/trace_report.py gpurun_out/trace_$TAG.npy > $OUT/trace_report.txt 2>&1; rm -f gpurun_out/trace_$TAG.npy ;;
     *) echo "unknown step $step" ;;
   esac
   echo "[$step] $(( $(date +%s) - t0 )) s"
