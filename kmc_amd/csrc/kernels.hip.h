@@ -28,6 +28,15 @@
 typedef kmc_u64 u64;
 typedef kmc_u32 u32;
 
+/* Three constructs have no spelling outside the device compiler. They are macros so that tests/hipemu (a host-side emulation of
+ * the device language, test infrastructure for the `-m "not gpu"` suite) can run this very source on the CPU; the product build
+ * always sees the definitions below. */
+#ifndef KMC_DYN_LDS
+#define KMC_DYN_LDS(type, name) extern __shared__ __attribute__((aligned(16))) type name[] /* the launch's dynamic LDS */
+#define KMC_LAUNDER(x) asm volatile("" : "+v"(x)) /* hide a lane-constant value from LICM: hoisted per-tile addresses cost VGPRs */
+#define KMC_WAIT_VMEM() asm volatile("s_waitcnt vmcnt(0)" ::: "memory") /* this wave's outstanding memory operations are performed */
+#endif
+
 /* device-side error bits (d_err) */
 enum : u32 { KERR_CORRUPT = 1u, KERR_NREC = 2u, KERR_CAPACITY = 4u, KERR_WATCHDOG = 8u };
 
@@ -38,7 +47,8 @@ enum : u32 { KERR_CORRUPT = 1u, KERR_NREC = 2u, KERR_CAPACITY = 4u, KERR_WATCHDO
 #endif
 constexpr int RS_BLOCK = RS_BLOCK_THREADS, RS_WAVES = RS_BLOCK / 64;                           /* radix scatter workgroup       */
 #ifndef CP_BLOCK_THREADS
-#define CP_BLOCK_THREADS 512 /* compaction of the 1.65 G k-mer bin: 256 threads 11.5 ms, 512 threads 10.6 ms (tile = threads x 16 records) */
+#define CP_BLOCK_THREADS 512 /* compaction: 8 waves x ROWS rows of 64 records. One 48 M k-mer bin: 256 threads (4096-record tiles) 0.326 ms,
+                              * 512 threads 0.237 ms, 256 threads x 8 rows 0.566 ms: per-tile costs (look-back, barriers, end-of-tile atomics) dominate */
 #endif
 constexpr int CP_BLOCK = CP_BLOCK_THREADS;                                                     /* compaction workgroup          */
 constexpr u32 SPIN_LIMIT = 1u << 24;                                              /* look-back watchdog (polls)    */
@@ -390,7 +400,7 @@ __global__ void __launch_bounds__(EXP_BLOCK) k_expand(const uint8_t *__restrict_
                                                  u32 *done_ctr)
 {
 	const u32 MAX_SK = exp_max_sk(k);
-	extern __shared__ __attribute__((aligned(16))) unsigned char s_raw[];
+	KMC_DYN_LDS(unsigned char, s_raw);
 	u64 *s_base = reinterpret_cast<u64 *>(s_raw);                             /* [2] (16 bytes keeps s_b 16-B aligned) */
 	uint8_t *s_b = s_raw + 16;                                                /* [EXP_CHUNK + EXP_TAIL] */
 	u32 *s_skoff = reinterpret_cast<u32 *>(s_b + EXP_CHUNK + EXP_TAIL);       /* [MAX_SK + 1] first k-mer of each super-k-mer */
@@ -413,7 +423,7 @@ __global__ void __launch_bounds__(EXP_BLOCK) k_expand(const uint8_t *__restrict_
 		if (c >= n_chunks)
 			break;
 		u32 tid = threadIdx.x;
-		asm volatile("" : "+v"(tid));
+		KMC_LAUNDER(tid);
 		const u32 lane = tid & 63, wave = tid >> 6;
 		const u64 c0 = (u64)c * EXP_CHUNK;
 		const u32 clen = (size - c0) < (u64)EXP_CHUNK ? (u32)(size - c0) : (u32)EXP_CHUNK;
@@ -588,7 +598,7 @@ __global__ void __launch_bounds__(EXP_BLOCK) k_expand(const uint8_t *__restrict_
 		 * respective done_ctr increment, so the agent-scope loads below see the final counts. Everything involved is a device-scope
 		 * atomic, so waiting for this wave's outstanding memory operations is all the ordering needed; a __threadfence() here would
 		 * also write back and invalidate the L2 (61 ms instead of 11 in the compaction, where every tile passes this point). */
-		asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+		KMC_WAIT_VMEM();
 		__syncthreads();
 		if (threadIdx.x == 0)
 			s_ticket[1] = atomicAdd(done_ctr, 1u);
@@ -618,22 +628,31 @@ template <bool FUSE_HIST> constexpr size_t exp_lds_bytes(u32 n_pass, u32 k)
 template <int SIZE>
 __global__ void __launch_bounds__(256) k_hist(const u64 *__restrict__ recs, u64 n, u32 n_pass, u64 *__restrict__ ghist)
 {
-	extern __shared__ __attribute__((aligned(16))) u32 s_h[]; /* n_pass * 256 */
+	KMC_DYN_LDS(u32, s_h); /* n_pass * 256 */
 	for (u32 i = threadIdx.x; i < n_pass * 256; i += 256)
 		s_h[i] = 0;
 	__syncthreads();
 	const u64 stride = (u64)gridDim.x * 256;
-	for (u64 i = (u64)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) {
+	const u32 lane = threadIdx.x & 63;
+	/* the loop bound is wave-uniform (all 64 lanes take the same trips, the tail is a predicate): the cross-lane operations below then
+	 * always see the whole wave */
+	for (u64 i0 = (u64)blockIdx.x * 256 + (threadIdx.x & ~63u); i0 < n; i0 += stride) {
+		const u64 i = i0 + lane;
+		const bool valid = i < n;
 		u64 x[SIZE];
-		load_rec<SIZE>(recs + i * SIZE, x);
-		const u64 act = __ballot(1);
+#pragma unroll
+		for (int w = 0; w < SIZE; ++w)
+			x[w] = 0;
+		if (valid)
+			load_rec<SIZE>(recs + i * SIZE, x);
+		const u64 act = __ballot(valid); /* lane 0 is valid whenever any lane is */
 		for (u32 b = 0; b < n_pass; ++b) {
 			const u32 d = kmc_get_byte<SIZE>(x, b);
 			const u32 d0 = (u32)__builtin_amdgcn_readfirstlane((int)d);
-			if (__ballot(d == d0) == act) {
-				if ((threadIdx.x & 63) == (u32)(__ffsll(act) - 1))
+			if (__ballot(valid && d == d0) == act) {
+				if (lane == 0)
 					atomicAdd(&s_h[b * 256 + d0], (u32)__popcll(act));
-			} else {
+			} else if (valid) {
 				atomicAdd(&s_h[b * 256 + d], 1u);
 			}
 		}
@@ -687,6 +706,12 @@ constexpr u32 ST_AGG = 1u << 30, ST_PREFIX = 2u << 30, ST_MASK = (1u << 30) - 1;
 #ifndef RS_LOOKBACK_K
 #define RS_LOOKBACK_K 4 /* status words per look-back round trip */
 #endif
+#ifndef RS_TILE_FROM_BLOCKIDX
+#define RS_TILE_FROM_BLOCKIDX 0 /* 1: tile = blockIdx.x instead of an atomic ticket (saves the ticket's round trip in front of every tile's loads).
+                                 * The look-back then relies on workgroups being STARTED in blockIdx order (lower ids are running or done when a
+                                 * higher one spins) — what the dispatcher does, but not an architectural promise; the watchdog turns a violation
+                                 * into KMC_HIP_EINTERNAL instead of a hang. Tuning option. */
+#endif
 #ifndef RS_TPB
 #define RS_TPB 1 /* tiles per ticket. Keep 1: a workgroup that owns consecutive tiles publishes the later ones late and every
                    * successor stalls on them (measured 150x slower at 2); larger tiles are the way to fewer tickets */
@@ -712,17 +737,23 @@ __global__ void __launch_bounds__(RS_BLOCK, (SIZE <= 4 ? RS_MIN_WAVES : RS_MIN_W
 {
 	constexpr int ITEMS = RsCfg<SIZE>::ITEMS;
 	constexpr int TILE = RsCfg<SIZE>::TILE;
-	extern __shared__ __attribute__((aligned(16))) unsigned char s_raw[];
+	KMC_DYN_LDS(unsigned char, s_raw);
 	u64 *s_goff = reinterpret_cast<u64 *>(s_raw);              /* [256]  global index of LDS slot 0 as seen by digit d */
 	u64 *s_keys = s_goff + 256;                                /* [SIZE*TILE/STAGES] word-major staging area            */
 	u32 *s_whist = reinterpret_cast<u32 *>(s_keys + SIZE * TILE / RsCfg<SIZE>::STAGES); /* [RS_WAVES*256] per-wave digit counters -> slots */
 	u32 *s_wsum = s_whist + RS_WAVES * 256;                    /* [4]                                                    */
 	u32 *s_tile = s_wsum + 4;                                  /* [1]                                                    */
 
+#if RS_TILE_FROM_BLOCKIDX
+	const u32 ticket = blockIdx.x;
+	(void)tile_counter;
+	(void)s_tile;
+#else
 	if (threadIdx.x == 0)
 		*s_tile = atomicAdd(tile_counter, 1u);
 	__syncthreads();
 	const u32 ticket = (u32)__builtin_amdgcn_readfirstlane((int)*s_tile); /* scalar: tile-level addresses live in SGPRs */
+#endif
 
 #pragma unroll 1
 	for (int it = 0; it < RS_TPB; ++it) {
@@ -731,7 +762,7 @@ __global__ void __launch_bounds__(RS_BLOCK, (SIZE <= 4 ? RS_MIN_WAVES : RS_MIN_W
 			break;
 		/* lane-constant addresses must be recomputed per tile: hoisted out of this loop they cost ~60 VGPRs and spill */
 		u32 tid = threadIdx.x;
-		asm volatile("" : "+v"(tid));
+		KMC_LAUNDER(tid);
 		const u32 lane = tid & 63, wave = tid >> 6;
 #pragma unroll
 		for (int i = 0; i < 4; ++i)
@@ -759,7 +790,7 @@ __global__ void __launch_bounds__(RS_BLOCK, (SIZE <= 4 ? RS_MIN_WAVES : RS_MIN_W
 			}
 		}
 #ifdef KMC_TRACE
-		asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); /* tuning build only: separate the load latency from the rest */
+		KMC_WAIT_VMEM(); /* tuning build only: separate the load latency from the rest */
 #endif
 		TRACE_STAMP(0, tile, 1);
 
@@ -952,30 +983,29 @@ template <int SIZE> constexpr size_t rs_lds_bytes()
 }
 
 /* ------------------------------------------------------------------------------------------------ compaction
- * ONE read of the sorted records. Thread t of a tile owns ITEMS consecutive records (run detection is then a
- * register-only loop); a run is attributed to the tile that holds its LAST record:
- *   count = index(last) - index(first) + 1, where `first` is found in-thread, else from a workgroup max-scan of
- *   "last run head so far", else (the run started before the tile — at most one such run per tile) by a
- *   wave-cooperative 64-ary lower_bound in the sorted array.
- * Cutoff/clamp semantics: kb_sorter.h:1174-1192 (compare BEFORE clamping; count is uint32). Output records and
- * LUT: kb_sorter.h:1196-1203. Output order must be ascending k-mer => tile order: the tile's offset among counted
- * k-mers comes from a 64-bit decoupled look-back (one word per tile). LUT updates are aggregated per tile: the
- * prefixes of the tile's counted k-mers are a sorted list in LDS, and each run of equal prefixes costs two global
- * atomics (+end, -begin) instead of one per k-mer. */
+ * ONE coalesced read of the sorted records. Wave w of a tile owns ROWS consecutive rows of 64 records; lane l of row r holds
+ * record cbase + 64 r + l, so every load instruction of a wave reads 512*SIZE contiguous bytes.
+ *   tails   record i ends a run iff S[i] != S[i+1] (neighbour lane: one shuffle; the row's last lane takes the next row's first
+ *           record). One ballot per row gives the row's 64 tail bits as a scalar mask.
+ *   counts  count of the run ending at i = i - (position of the previous tail). Inside a row that is bit arithmetic on the mask
+ *           (clz of the bits below the lane); across rows a scalar carry; across waves one LDS word per wave ("my last tail");
+ *           across tiles the 64 records below the tile are inspected the same way, and only a run longer than that needs the
+ *           64-ary search below. No workgroup-wide scan, one barrier.
+ *   classes cutoffs and clamp per tail lane (kb_sorter.h:1174-1192: compare BEFORE clamping; the count is uint32), three ballots per
+ *           row give counted / below / above as masks: the tallies are popcounts, a counted record's rank in the tile is
+ *           wave offset + row offset + mbcnt.
+ *   output  ascending k-mer = tile order: the tile's offset among counted k-mers comes from a 64-bit decoupled look-back (one word
+ *           per tile) run by wave 0 while the other waves already place their records in the LDS window (tile-relative ranks);
+ *           the window is streamed out as aligned dwords. Records and LUT: kb_sorter.h:1196-1203. LUT updates are aggregated per
+ *           tile: the prefixes of the tile's counted k-mers are a sorted list in LDS and each run of equal prefixes costs two
+ *           global atomics (+end, -begin).
+ * (Round 1-2a kept 16 consecutive records per THREAD: 16 load instructions of 64 scattered 8-byte pieces each, a workgroup-wide
+ * max-scan for the run heads and one for the ranks: 26.7 us per 8192-record tile, 10.1 of them in the loads — profiles/r02/trace_report_496M_bin.txt.) */
 
-template <int SIZE>
-__device__ __forceinline__ u64 run_start_search(const u64 *__restrict__ S, u64 base, u32 lane, const u64 (&v)[SIZE], bool eq_below)
+/* smallest i in [0, hi] with S[i] == v, given S[hi] == v and S sorted; executed by one full wave (64-ary search) */
+template <int SIZE> __device__ __forceinline__ u64 run_start_search(const u64 *__restrict__ S, u64 hi, u32 lane, const u64 (&v)[SIZE])
 {
-	/* smallest i <= base with S[i] == S[base] (= v); executed by one full wave. `eq_below`: lane l's verdict on
-	 * S[base-1-l] == v, from records that were loaded together with the tile (no dependent round trip in the common case:
-	 * a run that crosses the tile boundary almost always starts within the 64 records below it). */
-	u64 lo = 0, hi = base;
-	{ /* round 1: the 64 records just below the tile */
-		const u64 mask = __ballot(eq_below);
-		if (~mask)
-			return base - (u64)(__ffsll(~mask) - 1);
-		hi = base - 64;
-	}
+	u64 lo = 0;
 	while (lo < hi) {
 		const u64 span = hi - lo;
 		const u64 step = (span + 63) / 64;
@@ -1000,14 +1030,25 @@ __device__ __forceinline__ u64 run_start_search(const u64 *__restrict__ S, u64 b
 	return lo;
 }
 
-#ifndef CP_TPB
-#define CP_TPB 1 /* tiles per ticket (see RS_TPB) */
-#endif
+__device__ __forceinline__ u64 wave_first(u64 v) /* lane 0's value in every lane (two v_readfirstlane) */
+{
+	const u32 lo = (u32)__builtin_amdgcn_readfirstlane((int)(u32)v), hi = (u32)__builtin_amdgcn_readfirstlane((int)(u32)(v >> 32));
+	return ((u64)hi << 32) | lo;
+}
+
 constexpr int CP_STAGE = 16384; /* bytes of output assembled in LDS per window */
 constexpr int CP_SHARDS = 32; /* tally shards: same-address device atomics serialise at ~11 ns each */
+constexpr int CP_DONE_SHARDS = 32; /* "finished" counters: done_ctr[0] + one per shard (the launch's counter block is 1 + CP_DONE_SHARDS words) */
+#ifndef CP_TILE_FROM_BLOCKIDX
+#define CP_TILE_FROM_BLOCKIDX 0
+#endif
+#ifndef CP_TPB
+#define CP_TPB 1 /* tiles per ticket; must stay 1 (see RS_TPB) */
+#endif
+static_assert(CP_TPB == 1, "one compaction tile per workgroup");
 
 #ifndef CP_MIN_WAVES
-#define CP_MIN_WAVES 4 /* waves per SIMD the register allocator must leave room for: 128 VGPRs (4 spilled dwords at SIZE 1) buy a 4th workgroup per CU, 12.0 -> 10.9 ms */
+#define CP_MIN_WAVES 4 /* waves per SIMD the register allocator must leave room for */
 #endif
 template <int SIZE>
 __global__ void __launch_bounds__(CP_BLOCK, CP_MIN_WAVES) k_compact(const u64 *__restrict__ S, u64 n, DevParams P, uint8_t *__restrict__ out,
@@ -1015,156 +1056,165 @@ __global__ void __launch_bounds__(CP_BLOCK, CP_MIN_WAVES) k_compact(const u64 *_
                                                        u64 *stat_shards /* [CP_SHARDS][4] */, u64 *out_bytes, u64 *status, u32 *tile_counter,
                                                        u32 num_tiles, u32 *err, u64 *__restrict__ stats, u64 *__restrict__ lut_out, u32 *done_ctr)
 {
-	constexpr int ITEMS = CpCfg<SIZE>::ITEMS;
+	constexpr int ROWS = CpCfg<SIZE>::ITEMS;
 	constexpr int TILE = CpCfg<SIZE>::TILE;
-	__shared__ u64 s_tmp[CP_BLOCK / 64 + 1];
-	__shared__ u32 s_tmp32[CP_BLOCK / 64 + 1];
+	constexpr int NW = CP_BLOCK / 64;
+	constexpr long long NONE = -2; /* "no tail in this wave's rows" (-1 is a real value: no tail before record 0) */
+	__shared__ long long s_wlast[NW]; /* global index of the last tail inside wave w's rows */
+	__shared__ long long s_carry_in;  /* global index of the last tail below the tile, -1 if there is none */
+	__shared__ u32 s_wcnt[NW];        /* counted k-mers of wave w */
+	__shared__ u32 s_wtal[NW][3];     /* unique / below min / above max of wave w */
 	__shared__ u32 s_pref[TILE];
 	__shared__ __attribute__((aligned(16))) uint8_t s_stage[CP_STAGE];
-	__shared__ u32 s_tal[3];
-	__shared__ u32 s_tile, s_need;
-	__shared__ u64 s_run_start, s_tile_off;
-	__shared__ u64 s_first[SIZE]; /* the tile's first record, for the wave that resolves a run crossing the tile boundary */
+	__shared__ u32 s_tile;
+	__shared__ u64 s_tile_off;
 
+#if CP_TILE_FROM_BLOCKIDX
+	const u32 tile = blockIdx.x; /* see RS_TILE_FROM_BLOCKIDX */
+	(void)tile_counter;
+#else
 	if (threadIdx.x == 0)
 		s_tile = atomicAdd(tile_counter, 1u);
 	__syncthreads();
-	const u32 ticket = (u32)__builtin_amdgcn_readfirstlane((int)s_tile);
-	u64 acc_u = 0, acc_b = 0, acc_a = 0; /* thread 0: tallies of this workgroup's tiles */
+	const u32 tile = (u32)__builtin_amdgcn_readfirstlane((int)s_tile);
+#endif
 	const u32 rec_bytes = P.sbytes + P.cbytes;
 	const bool use_lut = P.lut_prefix_len != 0 && !P.kff && !P.without_output;
 
-#pragma unroll 1
-	for (int it = 0; it < CP_TPB; ++it) {
-		const u32 tile = ticket * CP_TPB + it;
-		if (tile >= num_tiles)
-			break;
-		u32 tid = threadIdx.x;
-		asm volatile("" : "+v"(tid)); /* keep per-tile addresses out of the loop preheader (register pressure) */
+	if (tile < num_tiles) {
+		const u32 tid = threadIdx.x;
 		const u32 lane = tid & 63, wave = tid >> 6;
-		if (tid == 0) {
-			s_need = 0;
-			s_tal[0] = s_tal[1] = s_tal[2] = 0;
-		}
-		__syncthreads();
+		const u64 lane_lt = (1ull << lane) - 1;
 		TRACE_STAMP(1, tile, 0);
 		TRACE_STAMP(1, tile, 1);
 		const u64 base = (u64)tile * TILE;
-		const u64 first = base + (u64)tid * ITEMS;
-		const int cnt_t = first >= n ? 0 : ((n - first) < (u64)ITEMS ? (int)(n - first) : ITEMS);
+		const u64 cbase = base + (u64)wave * (ROWS * 64);
 
-		u64 key[ITEMS][SIZE], prev[SIZE], next[SIZE];
+		/* ---- loads: the wave's rows, the record after them, and (last wave) the 64 records below the tile */
+		u64 key[ROWS][SIZE];
 #pragma unroll
-		for (int i = 0; i < ITEMS; ++i)
-			if (i < cnt_t)
-				load_rec<SIZE>(S + (first + i) * SIZE, key[i]);
-		const bool have_prev = cnt_t > 0 && first > 0;
-		const bool have_next = cnt_t > 0 && first + cnt_t < n;
-		if (have_prev)
-			load_rec<SIZE>(S + (first - 1) * SIZE, prev);
-		if (have_next)
-			load_rec<SIZE>(S + (first + cnt_t) * SIZE, next);
-		/* the last wave also fetches the 64 records below the tile now (one coalesced load that travels with the tile's own):
-		 * 3 of 4 tiles start inside a run, and finding that run's start used to cost a dependent round trip + jitter in
-		 * front of the look-back */
-		u64 below[SIZE];
-		bool have_below = false;
-		if (wave == CP_BLOCK / 64 - 1 && base >= (u64)lane + 1) {
-			load_rec<SIZE>(S + (base - 1 - lane) * SIZE, below);
-			have_below = true;
-		}
-		if (tid == 0 && cnt_t > 0) {
+		for (int r = 0; r < ROWS; ++r) {
+			const u64 i = cbase + (u64)r * 64 + lane;
+			if (i < n)
+				load_rec<SIZE>(S + i * SIZE, key[r]);
+			else {
 #pragma unroll
-			for (int w = 0; w < SIZE; ++w)
-				s_first[w] = key[0][w];
-		}
-
-		/* pass A: head/tail flags, last head position in this thread (as index+1, 0 = none) */
-		u32 head_bits = 0, tail_bits = 0;
-		u64 last_head1 = 0;
-#pragma unroll
-		for (int i = 0; i < ITEMS; ++i) {
-			if (i < cnt_t) {
-				bool head, tail;
-				if (i == 0)
-					head = !have_prev || !kmc_equal<SIZE>(key[0], prev);
-				else
-					head = !kmc_equal<SIZE>(key[i], key[i - 1]);
-				if (i == cnt_t - 1)
-					tail = !have_next || !kmc_equal<SIZE>(key[i], next);
-				else
-					tail = !kmc_equal<SIZE>(key[i], key[i + 1 < ITEMS ? i + 1 : i]);
-				if (head) {
-					head_bits |= 1u << i;
-					last_head1 = first + i + 1;
-				}
-				if (tail)
-					tail_bits |= 1u << i;
+				for (int w = 0; w < SIZE; ++w)
+					key[r][w] = 0;
 			}
+		}
+		u64 after[SIZE];
+		{
+			const u64 i = cbase + (u64)ROWS * 64; /* the same address in every lane */
+			if (i < n)
+				load_rec<SIZE>(S + i * SIZE, after);
+			else {
+#pragma unroll
+				for (int w = 0; w < SIZE; ++w)
+					after[w] = 0;
+			}
+		}
+		u64 b0[SIZE], b1[SIZE];
+		bool have_b = false;
+		if (wave == NW - 1 && base + lane >= 64) { /* j = base - 64 + lane >= 0; j + 1 <= base < n */
+			load_rec<SIZE>(S + (base - 64 + lane) * SIZE, b0);
+			load_rec<SIZE>(S + (base - 63 + lane) * SIZE, b1);
+			have_b = true;
+		}
+
+		/* ---- tails */
+		u32 tail_bits = 0; /* bit r: this lane's record of row r ends a run */
+		long long wlast = NONE;
+#pragma unroll
+		for (int r = 0; r < ROWS; ++r) {
+			const u64 i = cbase + (u64)r * 64 + lane;
+			bool differs = false;
+#pragma unroll
+			for (int w = 0; w < SIZE; ++w) {
+				u64 nx = __shfl_down(key[r][w], 1);
+				const u64 first_next = (r + 1 < ROWS) ? wave_first(key[r + 1 < ROWS ? r + 1 : r][w]) : after[w];
+				if (lane == 63)
+					nx = first_next;
+				differs = differs || (nx != key[r][w]);
+			}
+			const bool is_tail = i < n && (i + 1 == n || differs);
+			const u64 m = __ballot(is_tail);
+			if (is_tail)
+				tail_bits |= 1u << r;
+			if (m)
+				wlast = (long long)(cbase + (u64)r * 64) + 63 - __clzll((long long)m);
+			__builtin_amdgcn_sched_barrier(0); /* rows in order: interleaved, their scalar masks and first-lane values overflow the SGPRs */
+		}
+		if (lane == 0)
+			s_wlast[wave] = wlast;
+		if (wave == NW - 1) {
+			long long carry = -1;
+			if (base > 0) {
+				const u64 bm = __ballot(have_b && !kmc_equal<SIZE>(b0, b1)); /* tail at j iff S[j] != S[j+1] */
+				if (bm)
+					carry = (long long)base - 64 + 63 - __clzll((long long)bm);
+				else if (base > 64) {
+					/* S[base-64 .. base] are all equal: the run that crosses into the tile started further down */
+					u64 v[SIZE];
+					load_rec<SIZE>(S + (base - 64) * SIZE, v);
+					carry = (long long)run_start_search<SIZE>(S, base - 64, lane, v) - 1;
+				}
+			}
+			if (lane == 0)
+				s_carry_in = carry;
 		}
 		TRACE_STAMP(1, tile, 2);
-		const u64 carry1 = block_excl_max<CP_BLOCK / 64, u64>(last_head1, s_tmp); /* last head before this thread, in-tile */
+		__syncthreads();
 		TRACE_STAMP(1, tile, 3);
-		/* does this thread hold a tail whose run started before the tile? (tail before any head, no head carried in) */
-		bool pending = false;
-		if (carry1 == 0 && tail_bits) {
-			const u32 first_tail = (u32)__ffs((int)tail_bits) - 1;
-			const u32 heads_before = head_bits & ((2u << first_tail) - 1);
-			pending = heads_before == 0;
-		}
-		if (pending)
-			s_need = 1;
-		__syncthreads();
-		if (s_need && wave == CP_BLOCK / 64 - 1) {
-			u64 v[SIZE];
-#pragma unroll
-			for (int w = 0; w < SIZE; ++w)
-				v[w] = s_first[w];
-			const u64 st = run_start_search<SIZE>(S, base, lane, v, have_below && kmc_equal<SIZE>(below, v));
-			if (lane == 0)
-				s_run_start = st;
-		}
-		__syncthreads();
 
-		TRACE_STAMP(1, tile, 4);
-		/* pass B: counts and classes */
-		u32 count[ITEMS];
-		u32 counted_bits = 0, nu = 0, nb = 0, na = 0, nc = 0;
-		{
-			u64 cur_head1 = carry1 ? carry1 : (s_need ? s_run_start + 1 : 0);
+		/* ---- counts and classes */
+		long long carry = s_carry_in;
 #pragma unroll
-			for (int i = 0; i < ITEMS; ++i) {
-				count[i] = 0;
-				if (i < cnt_t) {
-					if (head_bits & (1u << i))
-						cur_head1 = first + i + 1;
-					if (tail_bits & (1u << i)) {
-						const u32 c = (u32)(first + i + 1 - (cur_head1 - 1)); /* uint32 like the reference counter */
-						++nu;
-						if (c < P.cutoff_min)
-							++nb;
-						else if (c > P.cutoff_max)
-							++na;
-						else {
-							++nc;
-							counted_bits |= 1u << i;
-							count[i] = c > P.counter_max ? P.counter_max : c;
-						}
-					}
-				}
-			}
+		for (int w = 0; w < NW; ++w) {
+			const long long x = s_wlast[w];
+			if (w < (int)wave && x != NONE)
+				carry = x;
 		}
-		/* tallies: wave reduce -> LDS */
-		{
-			const u32 a = wave_sum<u32>(nu), b2 = wave_sum<u32>(nb), c = wave_sum<u32>(na);
-			if (lane == 0) {
-				atomicAdd(&s_tal[0], a);
-				atomicAdd(&s_tal[1], b2);
-				atomicAdd(&s_tal[2], c);
-			}
+		TRACE_STAMP(1, tile, 4);
+		u32 cnt[ROWS];
+		u32 counted_bits = 0, nu = 0, nb = 0, na = 0, nc = 0; /* n*: wave totals, identical in every lane */
+#pragma unroll
+		for (int r = 0; r < ROWS; ++r) {
+			const long long rowbase = (long long)(cbase + (u64)r * 64);
+			const bool is_tail = (tail_bits >> r) & 1u;
+			const u64 m = __ballot(is_tail);
+			const u64 m_lt = m & lane_lt;
+			const long long prev = m_lt ? rowbase + 63 - __clzll((long long)m_lt) : carry;
+			const u32 c = (u32)(rowbase + (long long)lane - prev); /* uint32 like the reference counter */
+			const bool below = is_tail && c < P.cutoff_min;
+			const bool above = is_tail && !below && c > P.cutoff_max;
+			const bool counted = is_tail && !below && !above;
+			cnt[r] = c > P.counter_max ? P.counter_max : c;
+			if (counted)
+				counted_bits |= 1u << r;
+			nu += (u32)__popcll(m);
+			nb += (u32)__popcll(__ballot(below));
+			na += (u32)__popcll(__ballot(above));
+			nc += (u32)__popcll(__ballot(counted));
+			if (m)
+				carry = rowbase + 63 - __clzll((long long)m);
+			__builtin_amdgcn_sched_barrier(0);
 		}
-		u32 tile_counted;
-		const u32 thread_off = block_excl_sum<CP_BLOCK / 64, u32>(nc, s_tmp32, tile_counted);
+		if (lane == 0) {
+			s_wcnt[wave] = nc;
+			s_wtal[wave][0] = nu;
+			s_wtal[wave][1] = nb;
+			s_wtal[wave][2] = na;
+		}
+		__syncthreads();
+		u32 wave_off = 0, tile_counted = 0;
+#pragma unroll
+		for (int w = 0; w < NW; ++w) {
+			const u32 x = s_wcnt[w];
+			if (w < (int)wave)
+				wave_off += x;
+			tile_counted += x;
+		}
 		TRACE_STAMP(1, tile, 5);
 		if (wave == 0) {
 			/* tile offset among counted k-mers: 64-bit decoupled look-back, one word per tile, inspected 64 tiles
@@ -1205,167 +1255,187 @@ __global__ void __launch_bounds__(CP_BLOCK, CP_MIN_WAVES) k_compact(const u64 *_
 					st_agent(&status[tile], ST64_PREFIX | (excl + tile_counted));
 			}
 			if (lane == 0) {
-				acc_u += s_tal[0];
-				acc_b += s_tal[1];
-				acc_a += s_tal[2];
 				s_tile_off = excl;
 				if (tile == num_tiles - 1)
 					*out_bytes = P.without_output ? 0 : (excl + tile_counted) * (u64)rec_bytes;
+				/* the tile's tallies, sharded */
+				u32 tu = 0, tb = 0, ta = 0;
+#pragma unroll
+				for (int w = 0; w < NW; ++w) {
+					tu += s_wtal[w][0];
+					tb += s_wtal[w][1];
+					ta += s_wtal[w][2];
+				}
+				u64 *sh = stat_shards + (size_t)(tile % CP_SHARDS) * 4;
+				if (tu)
+					atomicAdd(&sh[0], (u64)tu);
+				if (tb)
+					atomicAdd(&sh[1], (u64)tb);
+				if (ta)
+					atomicAdd(&sh[2], (u64)ta);
 			}
 		}
 		TRACE_STAMP(1, tile, 6);
-		__syncthreads();
 
-		/* pass C: emit. Records are assembled in an LDS window and streamed out as aligned dwords: per-lane byte
-		 * stores straight to HBM were 59 % of this kernel's time. */
-		if (!P.without_output) {
-			const u64 gbyte0 = s_tile_off * rec_bytes;            /* global byte offset of this tile's first record */
+		/* ---- emit. Records are assembled in an LDS window at their tile-relative rank (known without the look-back) and
+		 * streamed out as aligned dwords once the tile's offset is known: per-lane byte stores straight to HBM were 59 % of
+		 * the first version's time. */
+		if (!P.without_output && tile_counted) {
+			/* rank of this lane's counted record of row r = wave offset + counted records of earlier rows + lower lanes; recomputed
+			 * (one ballot per row) wherever it is needed instead of being kept in ROWS registers */
+#define CP_FOR_EACH_COUNTED(BODY)                                                                                                  \
+	{                                                                                                                              \
+		u32 row_off = wave_off;                                                                                                    \
+		_Pragma("unroll") for (int r = 0; r < ROWS; ++r)                                                                           \
+		{                                                                                                                          \
+			const bool mine = (counted_bits >> r) & 1u;                                                                            \
+			const u64 cm = __ballot(mine);                                                                                         \
+			const u32 rank = row_off + (u32)__popcll(cm & lane_lt);                                                                \
+			row_off += (u32)__popcll(cm);                                                                                          \
+			if (mine) {                                                                                                            \
+				BODY                                                                                                               \
+			}                                                                                                                      \
+			__builtin_amdgcn_sched_barrier(0);                                                                                     \
+		}                                                                                                                          \
+	}
+			if (use_lut)
+				CP_FOR_EACH_COUNTED(s_pref[rank] = (u32)kmc_remove_suffix<SIZE>(key[r], 2 * (P.k - P.lut_prefix_len));)
 			const u32 tile_bytes = tile_counted * rec_bytes;
-			const bool fits = gbyte0 + tile_bytes <= out_capacity; /* uniform over the workgroup */
-			if (!fits && tid == 0)
-				atomicOr(err, KERR_CAPACITY);
-			if (use_lut) {
-				u32 j = thread_off;
-#pragma unroll
-				for (int i = 0; i < ITEMS; ++i)
-					if (counted_bits & (1u << i))
-						s_pref[j++] = (u32)kmc_remove_suffix<SIZE>(key[i], 2 * (P.k - P.lut_prefix_len));
-			}
 			if (rec_bytes <= 8) {
 				/* fast path (k <= ~36): a record is one 64-bit value in output byte order; records go to an LDS window,
 				 * then every thread composes aligned output dwords from it */
 				u64 *s_rec = reinterpret_cast<u64 *>(s_stage);
 				constexpr u32 WREC = CP_STAGE / 8;
-				for (u32 r0 = 0; fits && r0 < tile_counted; r0 += WREC) {
+				for (u32 r0 = 0; r0 < tile_counted; r0 += WREC) {
 					const u32 r1 = (tile_counted - r0) < WREC ? tile_counted : r0 + WREC;
-					u32 j = thread_off;
+					CP_FOR_EACH_COUNTED(
+						if (rank >= r0 && rank < r1) {
+							u64 rv = P.sbytes ? __builtin_bswap64(key[r][0] << (8 * (8 - P.sbytes))) : 0ull;
+							if (P.cbytes) {
+								const u32 cv = P.kff ? (__builtin_bswap32(cnt[r]) >> (8 * (4 - P.cbytes))) : cnt[r];
+								rv |= (u64)cv << (8 * P.sbytes);
+							}
+							s_rec[rank - r0] = rv;
+						})
+					__syncthreads(); /* the window is complete; in the first round this also publishes s_tile_off */
+					const u64 gbyte0 = s_tile_off * rec_bytes; /* global byte offset of this tile's first record */
+					const bool fits = gbyte0 + tile_bytes <= out_capacity; /* uniform over the workgroup */
+					if (!fits && tid == 0)
+						atomicOr(err, KERR_CAPACITY);
+					if (fits) {
+						const u64 g0 = gbyte0 + (u64)r0 * rec_bytes;
+						const u32 len = (r1 - r0) * rec_bytes;
+						u32 head = (u32)((4 - ((uintptr_t)(out + g0) & 3)) & 3);
+						if (head > len)
+							head = len;
+						const u32 ndw = (len - head) >> 2;
+						const u32 tail0 = head + (ndw << 2);
+						if (tid < head)
+							out[g0 + tid] = (uint8_t)(s_rec[tid / rec_bytes] >> (8 * (tid % rec_bytes)));
+						if (tid >= 32 && tid - 32 < len - tail0) {
+							const u32 bi = tail0 + (tid - 32);
+							out[g0 + bi] = (uint8_t)(s_rec[bi / rec_bytes] >> (8 * (bi % rec_bytes)));
+						}
+						u32 *gd = reinterpret_cast<u32 *>(out + g0 + head);
+						for (u32 w = tid; w < ndw; w += CP_BLOCK) {
+							const u32 i0 = head + (w << 2);
+							u32 ri = i0 / rec_bytes, q = i0 - ri * rec_bytes;
+							u64 cur = s_rec[ri];
+							u32 word = 0;
 #pragma unroll
-					for (int i = 0; i < ITEMS; ++i) {
-						if (counted_bits & (1u << i)) {
-							if (j >= r0 && j < r1) {
-								u64 rv = P.sbytes ? __builtin_bswap64(key[i][0] << (8 * (8 - P.sbytes))) : 0ull;
-								if (P.cbytes) {
-									const u32 cv = P.kff ? (__builtin_bswap32(count[i]) >> (8 * (4 - P.cbytes))) : count[i];
-									rv |= (u64)cv << (8 * P.sbytes);
+							for (int t = 0; t < 4; ++t) {
+								word |= ((u32)(cur >> (8 * q)) & 0xFFu) << (8 * t);
+								if (++q == rec_bytes) {
+									q = 0;
+									++ri;
+									cur = s_rec[ri < WREC ? ri : WREC - 1];
 								}
-								s_rec[j - r0] = rv;
 							}
-							++j;
+							gd[w] = word;
 						}
-					}
-					__syncthreads();
-					const u64 g0 = gbyte0 + (u64)r0 * rec_bytes;
-					const u32 len = (r1 - r0) * rec_bytes;
-					u32 head = (u32)((4 - ((uintptr_t)(out + g0) & 3)) & 3);
-					if (head > len)
-						head = len;
-					const u32 ndw = (len - head) >> 2;
-					const u32 tail0 = head + (ndw << 2);
-					if (tid < head)
-						out[g0 + tid] = (uint8_t)(s_rec[tid / rec_bytes] >> (8 * (tid % rec_bytes)));
-					if (tid >= 32 && tid - 32 < len - tail0) {
-						const u32 bi = tail0 + (tid - 32);
-						out[g0 + bi] = (uint8_t)(s_rec[bi / rec_bytes] >> (8 * (bi % rec_bytes)));
-					}
-					u32 *gd = reinterpret_cast<u32 *>(out + g0 + head);
-					for (u32 w = tid; w < ndw; w += CP_BLOCK) {
-						const u32 i0 = head + (w << 2);
-						u32 ri = i0 / rec_bytes, q = i0 - ri * rec_bytes;
-						u64 cur = s_rec[ri];
-						u32 word = 0;
-#pragma unroll
-						for (int t = 0; t < 4; ++t) {
-							word |= ((u32)(cur >> (8 * q)) & 0xFFu) << (8 * t);
-							if (++q == rec_bytes) {
-								q = 0;
-								++ri;
-								cur = s_rec[ri < WREC ? ri : WREC - 1];
-							}
-						}
-						gd[w] = word;
 					}
 					__syncthreads();
 				}
-			} else
-			for (u32 c0 = 0; fits && c0 < tile_bytes; c0 += CP_STAGE) {
-				const u32 c1 = (tile_bytes - c0) < (u32)CP_STAGE ? tile_bytes : c0 + CP_STAGE;
-				u32 j = thread_off;
-#pragma unroll
-				for (int i = 0; i < ITEMS; ++i) {
-					if (counted_bits & (1u << i)) {
-						const u32 b0 = j * rec_bytes;
-						if (b0 < c1 && b0 + rec_bytes > c0) {
+			} else {
+				for (u32 c0 = 0; c0 < tile_bytes; c0 += CP_STAGE) {
+					const u32 c1 = (tile_bytes - c0) < (u32)CP_STAGE ? tile_bytes : c0 + CP_STAGE;
+					CP_FOR_EACH_COUNTED(
+						const u32 bb = rank * rec_bytes;
+						if (bb < c1 && bb + rec_bytes > c0) {
 							for (u32 q = 0; q < rec_bytes; ++q) {
-								const u32 bpos = b0 + q;
+								const u32 bpos = bb + q;
 								if (bpos >= c0 && bpos < c1) {
 									u32 val;
 									if (q < P.sbytes)
-										val = kmc_get_byte<SIZE>(key[i], P.sbytes - 1 - q);
+										val = kmc_get_byte<SIZE>(key[r], P.sbytes - 1 - q);
 									else {
 										const u32 cq = q - P.sbytes;
-										val = count[i] >> (8 * (P.kff ? (P.cbytes - 1 - cq) : cq));
+										val = cnt[r] >> (8 * (P.kff ? (P.cbytes - 1 - cq) : cq));
 									}
 									s_stage[bpos - c0] = (uint8_t)val;
 								}
 							}
+						})
+					__syncthreads();
+					const u64 gbyte0 = s_tile_off * rec_bytes;
+					const bool fits = gbyte0 + tile_bytes <= out_capacity;
+					if (!fits && tid == 0)
+						atomicOr(err, KERR_CAPACITY);
+					if (fits) {
+						/* window [c0,c1) -> out[gbyte0+c0 ...): leading bytes up to 4-byte alignment, dwords, trailing bytes */
+						const u64 g0 = gbyte0 + c0;
+						const u32 len = c1 - c0;
+						u32 head = (u32)((4 - ((uintptr_t)(out + g0) & 3)) & 3);
+						if (head > len)
+							head = len;
+						const u32 ndw = (len - head) >> 2;
+						const u32 tail0 = head + (ndw << 2);
+						if (tid < head)
+							out[g0 + tid] = s_stage[tid];
+						if (tid >= 32 && tid - 32 < len - tail0)
+							out[g0 + tail0 + (tid - 32)] = s_stage[tail0 + (tid - 32)];
+						u32 *gd = reinterpret_cast<u32 *>(out + g0 + head);
+						for (u32 w = tid; w < ndw; w += CP_BLOCK) {
+							const uint8_t *sp = s_stage + head + (w << 2);
+							gd[w] = (u32)sp[0] | ((u32)sp[1] << 8) | ((u32)sp[2] << 16) | ((u32)sp[3] << 24);
 						}
-						++j;
 					}
+					__syncthreads();
 				}
-				__syncthreads();
-				/* window [c0,c1) -> out[gbyte0+c0 ...): leading bytes up to 4-byte alignment, dwords, trailing bytes */
-				const u64 g0 = gbyte0 + c0;
-				const u32 len = c1 - c0;
-				u32 head = (u32)((4 - ((uintptr_t)(out + g0) & 3)) & 3);
-				if (head > len)
-					head = len;
-				const u32 ndw = (len - head) >> 2;
-				const u32 tail0 = head + (ndw << 2);
-				if (tid < head)
-					out[g0 + tid] = s_stage[tid];
-				if (tid >= 32 && tid - 32 < len - tail0)
-					out[g0 + tail0 + (tid - 32)] = s_stage[tail0 + (tid - 32)];
-				u32 *gd = reinterpret_cast<u32 *>(out + g0 + head);
-				for (u32 w = tid; w < ndw; w += CP_BLOCK) {
-					const uint8_t *sp = s_stage + head + (w << 2);
-					gd[w] = (u32)sp[0] | ((u32)sp[1] << 8) | ((u32)sp[2] << 16) | ((u32)sp[3] << 24);
-				}
-				__syncthreads();
 			}
-		}
-		__syncthreads();
-		if (use_lut) {
-			/* small LUTs are sharded: in sorted order every tile in flight updates the same one or two entries, and
-			 * same-address device atomics serialise at ~11 ns each (that alone was 11 of this kernel's 12 ms) */
-			u64 *lut = lut_base + (size_t)(tile % lut_shards) * lut_stride;
-			for (u32 j = tid; j < tile_counted; j += CP_BLOCK) {
-				const u32 pf = s_pref[j];
-				if (j + 1 == tile_counted || s_pref[j + 1] != pf)
-					atomicAdd(&lut[pf], (u64)(j + 1));
-				if (j > 0 && s_pref[j - 1] != pf)
-					atomicAdd(&lut[pf], (u64)0 - (u64)j);
+			if (use_lut) {
+				/* small LUTs are sharded: in sorted order every tile in flight updates the same one or two entries, and
+				 * same-address device atomics serialise at ~11 ns each (that alone was 11 of this kernel's 12 ms in round 1) */
+				u64 *lut = lut_base + (size_t)(tile % lut_shards) * lut_stride;
+				for (u32 j = tid; j < tile_counted; j += CP_BLOCK) {
+					const u32 pf = s_pref[j];
+					if (j + 1 == tile_counted || s_pref[j + 1] != pf)
+						atomicAdd(&lut[pf], (u64)(j + 1));
+					if (j > 0 && s_pref[j - 1] != pf)
+						atomicAdd(&lut[pf], (u64)0 - (u64)j);
+				}
 			}
 		}
 		TRACE_STAMP(1, tile, 7);
-		__syncthreads(); /* LDS scratch is reused by the next tile */
-	}
-	if (threadIdx.x == 0) {
-		u64 *sh = stat_shards + (size_t)(ticket % CP_SHARDS) * 4;
-		if (acc_u)
-			atomicAdd(&sh[0], acc_u);
-		if (acc_b)
-			atomicAdd(&sh[1], acc_b);
-		if (acc_a)
-			atomicAdd(&sh[2], acc_a);
-	}
+		}
 	/* End of the bin, in the workgroup that finishes LAST (see k_expand's tail for the ordering argument): fold the tally shards into
 	 * stats[0..2], stats[3] = n_total = n_rec (kb_sorter.h:1166), and sum the LUT shards into the caller's LUT. */
-	asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+	KMC_WAIT_VMEM();
 	__syncthreads();
-	if (threadIdx.x == 0)
-		s_tile = atomicAdd(done_ctr, 1u);
+	if (threadIdx.x == 0) {
+		/* "am I the last one" in two levels: a same-address device atomic takes ~11 ns, and one per tile on ONE word (next to the
+		 * ticket's) capped the kernel at ~45 tiles per microsecond. A workgroup counts itself in on shard (tile mod 32); whoever
+		 * completes a shard counts the shard in on done_ctr[0]; whoever completes that is the last workgroup of the launch. */
+		const u32 sh = tile % CP_DONE_SHARDS;
+		const u32 expect = (num_tiles - sh + CP_DONE_SHARDS - 1) / CP_DONE_SHARDS; /* tiles t < num_tiles with t mod 32 == sh (sh < num_tiles) */
+		const u32 n_sh = num_tiles < (u32)CP_DONE_SHARDS ? num_tiles : (u32)CP_DONE_SHARDS;
+		u32 last = 0;
+		if (atomicAdd(&done_ctr[1 + sh], 1u) + 1 == expect)
+			last = atomicAdd(&done_ctr[0], 1u) + 1 == n_sh;
+		s_tile = last;
+	}
 	__syncthreads();
-	if (s_tile == gridDim.x - 1) {
+	if (s_tile) {
 		if (threadIdx.x < 64) {
 			const u32 lane = threadIdx.x;
 			for (int j = 0; j < 3; ++j) {
@@ -1394,5 +1464,6 @@ __global__ void __launch_bounds__(CP_BLOCK, CP_MIN_WAVES) k_compact(const u64 *_
 		}
 	}
 }
+#undef CP_FOR_EACH_COUNTED
 
 #endif

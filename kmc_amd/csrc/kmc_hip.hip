@@ -461,7 +461,7 @@ int launch_compact(Slot &s, const ZeroPlan &z, const u64 *sorted, u64 n, const D
 	const u64 c_tiles = (n + CpCfg<SIZE>::TILE - 1) / CpCfg<SIZE>::TILE;
 	if (c_tiles > 0x7FFFFFFFull)
 		return fail(KMC_HIP_EINVAL, "bin too large");
-	if (counter_idx >= N_COUNTERS)
+	if (counter_idx + 2 + CP_DONE_SHARDS > N_COUNTERS)
 		return fail(KMC_HIP_EINVAL, "too many launches for one bin");
 	const bool use_lut = lut_entries && !P.without_output && !P.kff;
 	const u32 n_sh = !use_lut ? 1u : lut_shards_for(lut_entries);
@@ -474,7 +474,7 @@ int launch_compact(Slot &s, const ZeroPlan &z, const u64 *sorted, u64 n, const D
 	k_compact<SIZE><<<dim3((u32)((c_tiles + CP_TPB - 1) / CP_TPB)), dim3(CP_BLOCK), 0, s.stream>>>(
 	    sorted, n, P, d_out, out_capacity, lut_base, n_sh, lut_entries, small_ptr<u64>(s, SM_SHARDS), d_out_bytes, zero_ptr<u64>(s, z.cp_status),
 	    counters + counter_idx, (u32)c_tiles, err, d_stats, d_lut, counters + counter_idx + 1);
-	counter_idx += 2;
+	counter_idx += 2 + CP_DONE_SHARDS; /* ticket, done, done shards */
 	HIPCHK(hipGetLastError());
 	return 0;
 }

@@ -1,0 +1,64 @@
+"""ctypes binding of tests/hipemu/libkmc_emu.so — TEST INFRASTRUCTURE: the kernels of kmc_amd/csrc/kernels.hip.h executed on the
+CPU under the emulation of tests/hipemu (no GPU, no libkmc_hip.so). See tests/test_kernels_emulated.py."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+EMU_DIR = os.path.join(ROOT, "tests", "hipemu")
+_LIB = None
+
+
+def build(force=False) -> str:
+    so = os.path.join(EMU_DIR, "libkmc_emu.so")
+    srcs = [os.path.join(EMU_DIR, "emu_kernels.cpp"), os.path.join(EMU_DIR, "include", "hip", "hip_runtime.h"),
+            os.path.join(ROOT, "kmc_amd", "csrc", "kernels.hip.h"), os.path.join(ROOT, "kmc_amd", "csrc", "kmer_ops.h")]
+    if force or not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in srcs):
+        subprocess.check_call(["g++", "-std=c++17", "-O1", "-g", "-fPIC", "-shared", "-pthread", "-Wall", "-Wno-unknown-pragmas", "-Wno-unused-function",
+                               "-Wno-unused-variable", "-Wno-unused-but-set-variable", "-Wno-attributes", "-I", os.path.join(EMU_DIR, "include"),
+                               srcs[0], "-o", so])
+    return so
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        L = C.CDLL(build())
+        L.emu_run.restype = C.c_int
+        L.emu_run.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_uint64, C.c_uint64, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p,
+                              C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p]
+        _LIB = L
+    return _LIB
+
+
+def _params(p):
+    return np.array([p.kmer_len, p.both_strands, p.cutoff_min, p.without_output, p.cutoff_max, p.counter_max, p.lut_prefix_len, p.output_type, 0, 0],
+                    dtype=np.uint32)
+
+
+def run(p, stage_mask, img=None, n_rec=0, pack_bytes=None, recs=None, out_capacity=None):
+    """p: any struct with the kmc_hip_bin_params fields. Returns dict(err, recs, sorted, out, lut, stats)."""
+    words = (p.kmer_len + 31) // 32
+    if recs is not None:
+        n_rec = recs.shape[0]
+    buf = np.zeros((2, max(n_rec, 1), words), dtype=np.uint64)
+    if recs is not None:
+        buf[0, :n_rec] = recs
+    img = np.zeros(0, dtype=np.uint8) if img is None else np.ascontiguousarray(img)
+    ps = np.concatenate([[0], np.cumsum(pack_bytes)]).astype(np.uint64) if pack_bytes is not None else np.zeros(1, dtype=np.uint64)
+    lut_n = (1 << (2 * p.lut_prefix_len)) if (p.lut_prefix_len and p.output_type == 0) else 0
+    rb = max(1, 40 + 8 * words)
+    cap = out_capacity if out_capacity is not None else (n_rec + 1) * rb
+    out = np.zeros(cap + 64, dtype=np.uint8)
+    lut = np.zeros(max(lut_n, 1), dtype=np.uint64)
+    stats = np.zeros(4, dtype=np.uint64)
+    ob = C.c_uint64(0)
+    si = C.c_int(0)
+    pr = _params(p)
+    err = lib().emu_run(pr.ctypes.data, stage_mask, img.ctypes.data if img.size else None, img.size, n_rec, ps.ctypes.data, ps.size - 1,
+                        buf.ctypes.data, C.addressof(si), out.ctypes.data, cap, C.addressof(ob), lut.ctypes.data, stats.ctypes.data)
+    return dict(err=err, recs=buf[0, :n_rec], sorted=buf[si.value, :n_rec], out=out[: ob.value].copy(), lut=lut[:lut_n].copy(), stats=stats)

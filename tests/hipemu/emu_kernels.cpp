@@ -1,0 +1,175 @@
+/*
+ * tests/hipemu/emu_kernels.cpp — TEST INFRASTRUCTURE: runs the kernels of kmc_amd/csrc/kernels.hip.h on the CPU under the
+ * emulation in tests/hipemu/include/hip/hip_runtime.h, launched the way kmc_amd/csrc/kmc_hip.hip launches them on the GPU
+ * (same grids, workgroup sizes, LDS sizes, zeroed work areas). Used only by tests/test_kernels_emulated.py (`-m "not gpu"`):
+ * it lets kernel logic be checked against the oracle in a container without a GPU. Never linked into libkmc_hip.so.
+ */
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdio>
+#include <vector>
+
+#include "../../kmc_amd/csrc/kernels.hip.h"
+
+namespace {
+
+struct Params {
+	u32 k, both_strands, cutoff_min, without_output;
+	u64 cutoff_max, counter_max;
+	u32 lut_prefix_len, output_type;
+};
+
+DevParams dev_params(const Params &p)
+{
+	DevParams P;
+	P.k = p.k;
+	P.both_strands = p.both_strands ? 1 : 0;
+	P.cutoff_min = p.cutoff_min;
+	P.cutoff_max = (u32)p.cutoff_max;
+	P.counter_max = (u32)p.counter_max;
+	P.lut_prefix_len = p.lut_prefix_len;
+	P.sbytes = kmc_suffix_bytes(p.k, p.lut_prefix_len);
+	P.cbytes = kmc_counter_bytes(p.cutoff_max, p.counter_max);
+	P.kff = p.output_type == 1;
+	P.without_output = p.without_output ? 1 : 0;
+	return P;
+}
+
+u32 lut_shards_for(u64 lut_entries) { return lut_entries <= 256 ? 32u : (lut_entries <= 1024 ? 8u : 1u); }
+
+template <int SIZE> int expand_t(const DevParams &P, const uint8_t *img, u64 size, u64 n_rec, const u64 *pack_start, u64 n_packs, u64 *recs, u64 *dbase, u32 *err)
+{
+	const u32 n_pass = (2 * P.k + 7) / 8;
+	std::vector<u32> bitmap((size + 31) / 32 + 2, 0);
+	const u64 n_chunks = (size + EXP_CHUNK - 1) / EXP_CHUNK;
+	std::vector<u64> status(n_chunks + 1, 0), ghist((size_t)n_pass * 256, 0);
+	u32 counters[2] = {0, 0};
+	/* the image needs 256 readable bytes of slack, like the device buffer */
+	std::vector<uint8_t> in(size + 512, 0);
+	memcpy(in.data(), img, size);
+	hipemu::launch(dim3((u32)n_packs), dim3(256), 0, [&] { k_parse_packs(in.data(), pack_start, (u32)n_packs, P.k, bitmap.data(), err); });
+	if (getenv("KMC_EMU_VERBOSE"))
+		fprintf(stderr, "[emu] parse done, err %u\n", *err);
+	const bool fuse = n_pass <= EXP_FUSE_MAX_PASS && n_rec >= 2;
+	const u32 blocks = (u32)std::min<u64>(n_chunks, 4); /* persistent workgroups pulling slice tickets */
+	if (fuse)
+		hipemu::launch(dim3(blocks), dim3(EXP_BLOCK), exp_lds_bytes<true>(n_pass, P.k), [&] {
+			k_expand<SIZE, true>(in.data(), size, bitmap.data(), P.k, P.both_strands, n_pass, n_rec, recs, ghist.data(), status.data(), &counters[0],
+			                     (u32)n_chunks, err, dbase, &counters[1]);
+		});
+	else
+		hipemu::launch(dim3(blocks), dim3(EXP_BLOCK), exp_lds_bytes<false>(n_pass, P.k), [&] {
+			k_expand<SIZE, false>(in.data(), size, bitmap.data(), P.k, P.both_strands, n_pass, n_rec, recs, ghist.data(), status.data(), &counters[0],
+			                      (u32)n_chunks, err, nullptr, &counters[1]);
+		});
+	return fuse ? 1 : 0;
+}
+
+template <int SIZE> u64 *sort_t(u64 *a, u64 *b, u64 n, u32 n_pass, const u64 *dbase_in, bool hist_done, u32 *err)
+{
+	if (n < 2 || n_pass == 0)
+		return a;
+	std::vector<u64> ghist((size_t)n_pass * 256, 0), dbase((size_t)n_pass * 256, 0);
+	if (hist_done)
+		memcpy(dbase.data(), dbase_in, dbase.size() * 8);
+	else {
+		hipemu::launch(dim3((u32)std::min<u64>((n + 255) / 256, 4)), dim3(256), (size_t)n_pass * 1024, [&] { k_hist<SIZE>(a, n, n_pass, ghist.data()); });
+		hipemu::launch(dim3(n_pass), dim3(256), 0, [&] { k_hist_scan(ghist.data(), dbase.data()); });
+	}
+	u64 *src = a, *dst = b;
+	const u32 tiles = (u32)((n + RsCfg<SIZE>::TILE - 1) / RsCfg<SIZE>::TILE);
+	for (u32 pass = 0; pass < n_pass; ++pass) {
+		std::vector<u32> status((size_t)tiles * 256, 0);
+		u32 counter = 0;
+		u64 next[256];
+		hipemu::launch(dim3(tiles), dim3(RS_BLOCK), rs_lds_bytes<SIZE>(), [&] {
+			k_onesweep<SIZE>(src, dst, (u32)n, pass, dbase.data() + (size_t)pass * 256, next, status.data(), &counter, tiles, err);
+		});
+		std::swap(src, dst);
+	}
+	return src;
+}
+
+template <int SIZE>
+void compact_t(const DevParams &P, const u64 *sorted, u64 n, uint8_t *out, u64 out_capacity, u64 *out_bytes, u64 *lut, u64 lut_entries, u64 *stats, u32 *err)
+{
+	const u64 c_tiles = (n + CpCfg<SIZE>::TILE - 1) / CpCfg<SIZE>::TILE;
+	const bool use_lut = lut_entries && !P.without_output && !P.kff;
+	const u32 n_sh = use_lut ? lut_shards_for(lut_entries) : 1u;
+	std::vector<u64> lutsh(n_sh > 1 ? (size_t)n_sh * lut_entries : 1, 0), status(c_tiles + 1, 0), shards(CP_SHARDS * 4, 0);
+	u64 *lut_base = lut;
+	if (use_lut && n_sh > 1)
+		lut_base = lutsh.data();
+	else if (use_lut)
+		memset(lut, 0, lut_entries * 8);
+	u32 counters[2 + CP_DONE_SHARDS] = {};
+	/* the kernel reads up to one record past a thread's block only inside [0, n): no slack needed */
+	hipemu::launch(dim3((u32)c_tiles), dim3(CP_BLOCK), 0, [&] {
+		k_compact<SIZE>(sorted, n, P, out, out_capacity, lut_base, n_sh, lut_entries, shards.data(), out_bytes, status.data(), &counters[0], (u32)c_tiles, err,
+		                stats, lut, &counters[1]);
+	});
+}
+
+template <int SIZE>
+int run_t(const Params &p, int stage_mask, const uint8_t *img, u64 size, u64 n_rec, const u64 *pack_start, u64 n_packs, u64 *recs /* [2][n_rec*SIZE] */,
+          u64 **sorted_out, uint8_t *out, u64 out_capacity, u64 *out_bytes, u64 *lut, u64 *stats, u32 *err)
+{
+	const DevParams P = dev_params(p);
+	const u32 n_pass = (2 * P.k + 7) / 8;
+	u64 *a = recs, *b = recs + n_rec * SIZE;
+	std::vector<u64> dbase((size_t)n_pass * 256, 0);
+	int hist_done = 0;
+	if (stage_mask & 1)
+		hist_done = expand_t<SIZE>(P, img, size, n_rec, pack_start, n_packs, a, dbase.data(), err);
+	u64 *sorted = a;
+	if (stage_mask & 2)
+		sorted = sort_t<SIZE>(a, b, n_rec, n_pass, dbase.data(), hist_done != 0, err);
+	if (sorted_out)
+		*sorted_out = sorted;
+	if (stage_mask & 4) {
+		const u64 lut_entries = (P.kff || !p.lut_prefix_len) ? 0 : 1ull << (2 * p.lut_prefix_len);
+		compact_t<SIZE>(P, sorted, n_rec, out, out_capacity, out_bytes, lut, lut_entries, stats, err);
+	}
+	return 0;
+}
+
+} // namespace
+
+extern "C" {
+
+/* stage_mask: 1 = parse + expand (image -> recs[0]), 2 = sort (recs[0] -> *sorted_index = 0 or 1: which half of `recs` holds the result),
+ * 4 = compaction of the sorted half. `recs` = 2 x n_rec x words uint64. Returns the device error word. */
+int emu_run(const unsigned *params10, int stage_mask, const uint8_t *img, u64 size, u64 n_rec, const u64 *pack_start, u64 n_packs, u64 *recs,
+            int *sorted_index, uint8_t *out, u64 out_capacity, u64 *out_bytes, u64 *lut, u64 *stats)
+{
+	Params p;
+	p.k = params10[0];
+	p.both_strands = params10[1];
+	p.cutoff_min = params10[2];
+	p.without_output = params10[3];
+	p.cutoff_max = params10[4];
+	p.counter_max = params10[5];
+	p.lut_prefix_len = params10[6];
+	p.output_type = params10[7];
+	u32 err = 0;
+	u64 *sorted = nullptr;
+	const u32 words = (p.k + 31) / 32;
+#define RUN(N) run_t<N>(p, stage_mask, img, size, n_rec, pack_start, n_packs, recs, &sorted, out, out_capacity, out_bytes, lut, stats, &err)
+	switch (words) {
+	case 1: RUN(1); break;
+	case 2: RUN(2); break;
+	case 3: RUN(3); break;
+	case 4: RUN(4); break;
+	case 5: RUN(5); break;
+	case 6: RUN(6); break;
+	case 7: RUN(7); break;
+	case 8: RUN(8); break;
+	default: return -1;
+	}
+#undef RUN
+	if (sorted_index)
+		*sorted_index = sorted == recs ? 0 : 1;
+	return (int)err;
+}
+}

@@ -1,0 +1,100 @@
+"""The kernel SOURCE of kmc_amd/csrc/kernels.hip.h executed on the CPU (tests/hipemu: one OS thread per GPU thread, wave64 cross-lane
+operations through per-wave exchanges) and compared bit for bit with the oracle. This is how kernel logic is checked in a container
+without a GPU before a GPU minute is spent; the `-m gpu` suite remains the parity test of the product (libkmc_hip.so on gfx950).
+Not covered here: k_onesweep (its ranking relies on the lock-step execution of a wave's LDS operations, which OS threads do not have)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import binsynth
+import emu
+import oracle_py as O
+
+
+def _oracle_compact(p, srt):
+    n, words = srt.shape
+    out = np.zeros(n * (8 * words + 8) + 8, dtype=np.uint8)
+    lut = np.zeros(max(O.lut_entries(p), 1), dtype=np.uint64)
+    st = np.zeros(4, dtype=np.uint64)
+    ob = C.c_uint64()
+    srt = np.ascontiguousarray(srt)
+    rc = O.lib().oracle_compact(C.byref(p), srt.ctypes.data_as(C.POINTER(C.c_uint64)), n, out.ctypes.data_as(C.POINTER(C.c_uint8)), out.size,
+                                C.byref(ob), lut.ctypes.data_as(C.POINTER(C.c_uint64)), st.ctypes.data_as(C.POINTER(C.c_uint64)))
+    assert rc == 0
+    return out[: ob.value], lut[: O.lut_entries(p)], st
+
+
+def _check_compact(p, srt):
+    r = emu.run(p, 4, recs=srt)
+    w_out, w_lut, w_st = _oracle_compact(p, srt)
+    assert r["err"] == 0
+    assert np.array_equal(r["stats"], w_st), (r["stats"], w_st)
+    assert np.array_equal(r["out"], w_out)
+    if p.output_type == 0 and p.lut_prefix_len:
+        assert np.array_equal(r["lut"], w_lut)
+
+
+@pytest.mark.parametrize("k,pl", [(27, 3), (27, 7), (55, 3), (127, 3), (32, 4), (64, 0), (200, 3)])
+def test_emulated_compaction_matches_oracle(k, pl):
+    rng = np.random.default_rng(k + pl)
+    g = rng.integers(0, 4, size=8_000, dtype=np.uint8)
+    img, nk, _ = binsynth.random_bin(rng, k, 1200, max_extra=60, genome=g)
+    for kw in (dict(cutoff_min=2), dict(cutoff_min=1, counter_max=3), dict(cutoff_min=1, cutoff_max=4), dict(cutoff_min=3, counter_max=70000)):
+        p = O.make_params(k, lut_prefix_len=pl, output_type=0 if pl else 1, **kw)
+        _check_compact(p, O.sort(O.expand(p, img)))
+
+
+def test_emulated_compaction_runs_longer_than_tiles_and_waves():
+    """runs that cross row, wave and tile boundaries, and runs longer than the 64 records inspected below a tile (64-ary search)"""
+    reps = [1, 700, 2, 9000, 1, 1, 20_000, 3, 4097, 4096, 4095, 1, 63, 64, 65, 1023, 1024, 1025, 1]
+    vals = np.sort(np.random.default_rng(5).choice(2**40, size=len(reps), replace=False).astype(np.uint64)) << np.uint64(10)
+    srt = np.repeat(vals, reps).reshape(-1, 1)
+    for kw in (dict(cutoff_min=2), dict(cutoff_min=1, counter_max=255), dict(cutoff_min=1, cutoff_max=4096, counter_max=10**6), dict(cutoff_min=65, cutoff_max=9000)):
+        _check_compact(O.make_params(27, lut_prefix_len=3, **kw), srt)
+
+
+@pytest.mark.parametrize("n", [1, 2, 63, 64, 65, 255, 256, 257, 4095, 4096, 4097, 8193])
+def test_emulated_compaction_edge_sizes(n):
+    rng = np.random.default_rng(n)
+    srt = np.sort(rng.integers(0, max(2, n // 3), size=n).astype(np.uint64) << np.uint64(17)).reshape(-1, 1)
+    for kw in (dict(cutoff_min=1), dict(cutoff_min=2, counter_max=2)):
+        _check_compact(O.make_params(27, lut_prefix_len=7, **kw), srt)
+    srt2 = np.repeat(srt, 2, axis=1)  # two-word records (k = 55): both words take part in the comparison
+    srt2[:, 0] = np.arange(n, dtype=np.uint64) // 2  # low word: pairs
+    srt2[:, 1] = srt2[:, 1] >> np.uint64(30)
+    order = np.lexsort((srt2[:, 0], srt2[:, 1]))
+    _check_compact(O.make_params(55, lut_prefix_len=3, cutoff_min=1), np.ascontiguousarray(srt2[order]))
+
+
+def test_emulated_compaction_without_output_and_capacity_error():
+    rng = np.random.default_rng(9)
+    srt = np.sort(rng.integers(0, 3000, size=10_000).astype(np.uint64) << np.uint64(20)).reshape(-1, 1)
+    p = O.make_params(27, lut_prefix_len=3, cutoff_min=1, without_output=1)
+    r = emu.run(p, 4, recs=srt)
+    _, _, w_st = _oracle_compact(O.make_params(27, lut_prefix_len=3, cutoff_min=1), srt)
+    assert r["err"] == 0 and r["out"].size == 0 and np.array_equal(r["stats"], w_st)
+    r = emu.run(O.make_params(27, lut_prefix_len=3, cutoff_min=1), 4, recs=srt, out_capacity=1000)
+    assert r["err"] & 4  # KERR_CAPACITY
+
+
+@pytest.mark.parametrize("k,both", [(27, 1), (27, 0), (55, 1), (14, 1), (127, 1)])
+def test_emulated_parse_and_expand_match_oracle(k, both):
+    rng = np.random.default_rng(k + both)
+    img, nk, packs = binsynth.random_bin(rng, k, 2500, max_extra=120, pack_size=257)
+    p = O.make_params(k, both_strands=both, lut_prefix_len=0, output_type=1)
+    r = emu.run(p, 1, img, nk, packs)
+    assert r["err"] == 0
+    assert np.array_equal(r["recs"], O.expand(p, img))
+
+
+def test_emulated_front_end_and_compaction_around_the_oracle_sort():
+    """parse + expand (emulated) -> sort (oracle) -> compaction (emulated) == oracle_process_bin"""
+    rng = np.random.default_rng(77)
+    g = rng.integers(0, 4, size=6_000, dtype=np.uint8)
+    img, nk, packs = binsynth.random_bin(rng, 27, 1500, max_extra=40, genome=g, pack_size=300)
+    p = O.make_params(27, lut_prefix_len=3)
+    recs = emu.run(p, 1, img, nk, packs)["recs"]
+    r = emu.run(p, 4, recs=O.sort(recs))
+    w_out, w_lut, w_st = O.process_bin(p, img, nk)
+    assert np.array_equal(r["out"], w_out) and np.array_equal(r["lut"], w_lut) and np.array_equal(r["stats"], w_st)

@@ -33,6 +33,15 @@ VARIANTS = {
     "combo1": ["-DRS_WORDS_PER_THREAD_1=10", "-DRS_STAGES=2", "-DEXP_CHUNK_BYTES=16384", "-DCP_BLOCK_THREADS=512"],
     "nohist": ["-DEXP_NO_HIST"],  # expand without the fused histograms (sort output is garbage): what do the LDS atomics cost?
     "exp256": ["-DEXP_BLOCK_THREADS=256"],
+    "cp_b512": ["-DCP_BLOCK_THREADS=512"],  # r02 row/ballot compaction: 8 waves per tile
+    "cp_b256": ["-DCP_BLOCK_THREADS=256"],
+    "cp_b256bidx": ["-DCP_BLOCK_THREADS=256", "-DCP_TILE_FROM_BLOCKIDX=1"],
+    "cp_bidx": ["-DCP_TILE_FROM_BLOCKIDX=1"],  # compaction tiles in blockIdx order (no ticket atomic)
+    "rs_bidx": ["-DRS_TILE_FROM_BLOCKIDX=1"],  # scatter tiles in blockIdx order
+    "bidx2": ["-DCP_TILE_FROM_BLOCKIDX=1", "-DRS_TILE_FROM_BLOCKIDX=1"],
+    "cp_r8": ["-DCP_WORDS_PER_THREAD=8"],  # 8 rows per wave (2048-record tiles at one-word records)
+    "cp_r8m6": ["-DCP_WORDS_PER_THREAD=8", "-DCP_MIN_WAVES=6"],
+    "cp_m5": ["-DCP_MIN_WAVES=5"],
     "cp8": ["-DCP_WORDS_PER_THREAD=8", "-DCP_MIN_WAVES=8"],  # compaction: 2048-record tiles, 64 VGPRs, twice the workgroups per CU
 }
 

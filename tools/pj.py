@@ -1,6 +1,8 @@
 #!/usr/bin/env python3
-"""print the essentials of a bench.py JSON line"""
+"""print the essentials of bench.py JSON lines"""
 import json, sys
 for f in sys.argv[1:]:
     d = json.load(open(f))
-    print(f, round(d["value"], 2), "Gk/s", round(d["ms_per_step"], 1), "ms", {k: round(v, 2) for k, v in d["phases_ms_last_step"].items()}, "scatter GB/s", round(d["roofline"]["achieved"]))
+    r = d["roofline"]
+    print(f, round(d["value"], 2), "Gk/s", round(d["ms_per_step"], 1), "ms/step |", r["kernel"], round(r["frac"], 3), "of peak,", round(r["avg_launch_ms"] * 1e3, 1),
+          "us/launch | last bin ms", {k: round(v, 3) for k, v in d["phases_ms_last_bin_slot0"].items()}, "|", d["self_check"])
