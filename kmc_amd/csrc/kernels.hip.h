@@ -230,6 +230,11 @@ constexpr u64 ST64_AGG = 1ull << 62, ST64_PREFIX = 2ull << 62, ST64_MASK = (1ull
  * the chain with one lane per pack (4096 dependent global loads per pack, ~1 us each: 8 ms per bin however small);
  * v2 used pointer doubling over all positions (log2 rounds of two LDS sweeps: 53 k cycles per chunk). */
 constexpr int PARSE_CHUNK = 4096, PARSE_SUB = 128, PARSE_NSUB = PARSE_CHUNK / PARSE_SUB;
+#ifndef PARSE_CAND_POS
+#define PARSE_CAND_POS 24 /* entry positions per sub-block resolved speculatively (multiple of 8); deeper entries take the exact slow path */
+#endif
+constexpr int PARSE_CAND = PARSE_CAND_POS;
+static_assert(PARSE_CAND % 8 == 0 && PARSE_CAND >= 8 && PARSE_CAND <= PARSE_SUB, "PARSE_CAND");
 
 __global__ void __launch_bounds__(256) k_parse_packs(const uint8_t *__restrict__ data, const u64 *__restrict__ pack_start, u32 n_packs, u32 k,
                                                       u32 *__restrict__ bitmap, u32 *err)
@@ -256,35 +261,46 @@ __global__ void __launch_bounds__(256) k_parse_packs(const uint8_t *__restrict__
 	 * thread and chunk). The few bytes in front of the pack are never visited: the chain starts at `entry`. */
 	u32 entry = (u32)(pos0 & 15); /* offset inside the current chunk of the first record start */
 	u64 c_next = pos0 & ~15ull;
+	static_assert(PARSE_CHUNK == 4096, "chunk boundaries are computed with shifts");
+	/* the chunk after the one being resolved is already on its way (one 16-byte register per thread): a pack is ~10 chunks that depend
+	 * on each other through `entry`, and each used to start with an exposed trip to HBM */
+	uint4 staged = make_uint4(0, 0, 0, 0);
+	if (c_next < end) {
+		const u64 b0 = ((c_next >> 12) + 1) << 12;
+		if ((u64)tid * 16 < (b0 < end ? b0 : end) - c_next)
+			staged = reinterpret_cast<const uint4 *>(data + c_next)[tid]; /* 16-byte aligned; the image has >= 256 readable bytes of slack */
+	}
 	while (c_next < end) {
 		const u64 c0 = c_next;
 		const u64 bound = ((c0 >> 12) + 1) << 12;
-		static_assert(PARSE_CHUNK == 4096, "chunk boundaries are computed with shifts");
 		const u64 c1 = bound < end ? bound : end;
 		const u32 clen = (u32)(c1 - c0);
 		c_next = c1;
+		if (tid * 16 < clen)
+			reinterpret_cast<uint4 *>(s_b)[tid] = staged; /* every reader of the previous chunk is past the barrier that ends the loop body */
+		if (c1 < end) {
+			const u64 b1 = c1 + PARSE_CHUNK; /* c1 is a multiple of PARSE_CHUNK here */
+			if ((u64)tid * 16 < (b1 < end ? b1 : end) - c1)
+				staged = reinterpret_cast<const uint4 *>(data + c1)[tid];
+		}
 		if (entry >= clen) { /* only for a ragged image; the final check below reports it */
 			entry -= clen;
+			__syncthreads();
 			continue;
-		}
-		{
-			const uint4 *g = reinterpret_cast<const uint4 *>(data + c0); /* 16-byte aligned; the image has >= 256 readable bytes of slack */
-			uint4 *l = reinterpret_cast<uint4 *>(s_b);
-			if (tid * 16 < clen)
-				l[tid] = g[tid];
 		}
 		if (tid < PARSE_NSUB)
 			s_ent[tid] = 0;
 		__syncthreads();
-		/* L1. Only the first `maxlen` positions of a sub-block can be where the chain enters it (the record before
-		 * starts below the sub-block and is at most maxlen bytes long), so only they need X: thread (sub = tid/8,
-		 * o = tid%8) runs the candidates sub*128 + o + 8i, i < ceil(min(maxlen,128)/8) — 9 of 16 at k=27 — and the hop
-		 * loop stops as soon as the wave has no chain left inside its sub-blocks. */
+		/* L1. Thread (sub = tid/8, o = tid%8) runs the candidate entry positions sub*128 + o + 8i of its sub-block, i < PARSE_CAND/8; the
+		 * hop loop stops as soon as the wave has no chain left inside its sub-blocks. */
 		{
-			constexpr int NC = PARSE_SUB / 8;
+			constexpr int NC = PARSE_CAND / 8;
 			static_assert(PARSE_NSUB * 8 == 256, "one sub-block per 8 threads");
-			const u32 maxlen = 1 + ((k + 255 + 3) >> 2); /* e <= 255 (splitter.cpp:656) */
-			const u32 ni = ((maxlen < (u32)PARSE_SUB ? maxlen : (u32)PARSE_SUB) + 7) >> 3;
+			/* a record is at most maxlen = 1 + ceil((k+255)/4) >= 65 bytes (e <= 255, splitter.cpp:656), so a chain can enter a
+			 * sub-block anywhere in its first maxlen positions — but a record of real data is far shorter than the format allows
+			 * (e rarely exceeds a few dozen), so only the first PARSE_CAND positions are speculated on (3 rounds instead of the 9
+			 * that maxlen asks for at k=27: 0.152 -> ... ms per 57 MB bin); the rare chain that enters deeper is walked by L2 itself.
+			 * Exactness does not depend on the bound. */
 			const u32 sb0 = (tid >> 3) * PARSE_SUB, sb_end = sb0 + PARSE_SUB;
 			u32 q[NC];
 #pragma unroll
@@ -295,7 +311,7 @@ __global__ void __launch_bounds__(256) k_parse_packs(const uint8_t *__restrict__
 				bool moved = false;
 #pragma unroll
 				for (int i = 0; i < NC; ++i) {
-					if ((u32)i < ni && q[i] < sb_end && q[i] < clen) {
+					if (q[i] < sb_end && q[i] < clen) {
 						q[i] += 1 + ((k + s_b[q[i]] + 3) >> 2);
 						moved = true;
 					}
@@ -306,7 +322,7 @@ __global__ void __launch_bounds__(256) k_parse_packs(const uint8_t *__restrict__
 #pragma unroll
 			for (int i = 0; i < NC; ++i) {
 				const u32 p0 = sb0 + (tid & 7) + 8 * i;
-				if ((u32)i < ni && p0 < clen)
+				if (p0 < clen)
 					s_X[p0] = (unsigned short)q[i]; /* < clen + 130 */
 			}
 		}
@@ -316,7 +332,13 @@ __global__ void __launch_bounds__(256) k_parse_packs(const uint8_t *__restrict__
 			u32 q = entry;
 			while (q < clen) {
 				s_ent[q / PARSE_SUB] = (unsigned short)(q + 1);
-				q = s_X[q];
+				if ((q & (PARSE_SUB - 1)) < (u32)PARSE_CAND)
+					q = s_X[q];
+				else { /* entered deeper than L1 speculated: walk this sub-block here */
+					const u32 sb_end = (q | (PARSE_SUB - 1)) + 1;
+					while (q < sb_end && q < clen)
+						q += 1 + ((k + s_b[q] + 3) >> 2);
+				}
 			}
 			s_exit = q;
 		}

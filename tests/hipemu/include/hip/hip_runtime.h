@@ -39,6 +39,7 @@ struct uint4 {
 struct ulonglong2 {
 	unsigned long long x, y;
 };
+static inline uint4 make_uint4(unsigned a, unsigned b, unsigned c, unsigned d) { return uint4{a, b, c, d}; }
 static inline ulonglong2 make_ulonglong2(unsigned long long a, unsigned long long b) { return ulonglong2{a, b}; }
 
 namespace hipemu {

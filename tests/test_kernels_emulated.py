@@ -98,3 +98,15 @@ def test_emulated_front_end_and_compaction_around_the_oracle_sort():
     r = emu.run(p, 4, recs=O.sort(recs))
     w_out, w_lut, w_st = O.process_bin(p, img, nk)
     assert np.array_equal(r["out"], w_out) and np.array_equal(r["lut"], w_lut) and np.array_equal(r["stats"], w_st)
+
+
+@pytest.mark.parametrize("k,max_extra,pack_size,n_super", [(27, 255, 37, 1500), (27, 40, 10**9, 6000), (14, 255, 4096, 3000), (256, 255, 500, 800), (31, 0, 4096, 5000)])
+def test_emulated_parse_deep_entries_and_pack_shapes(k, max_extra, pack_size, n_super):
+    """records longer than the speculated entry window (PARSE_CAND positions per 128-byte sub-block) take the exact slow path of the
+    chain walk; single huge packs cross many parse chunks; e = 0 everywhere gives the shortest records"""
+    rng = np.random.default_rng(k + max_extra + n_super)
+    img, nk, packs = binsynth.random_bin(rng, k, n_super, max_extra=max_extra, pack_size=pack_size)
+    p = O.make_params(k, lut_prefix_len=0, output_type=1)
+    r = emu.run(p, 1, img, nk, packs)
+    assert r["err"] == 0
+    assert np.array_equal(r["recs"], O.expand(p, img))
