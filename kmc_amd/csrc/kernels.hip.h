@@ -72,11 +72,17 @@ template <int SIZE> struct RsCfg { /* records per thread in a scatter tile */
 	static constexpr int STAGES = (ITEMS % RS_STAGES_REQ == 0) ? RS_STAGES_REQ : 1; /* LDS staging slices per tile */
 };
 #ifndef CP_WORDS_PER_THREAD
-#define CP_WORDS_PER_THREAD 16
+#define CP_WORDS_PER_THREAD 16 /* 8-byte words per lane of a compaction tile (records of 2+ words): rows per wave = words / SIZE */
+#endif
+#ifndef CP_WORDS_PER_THREAD_1
+#define CP_WORDS_PER_THREAD_1 8 /* one-word records: 8 rows per wave (4096-record tiles), 64 VGPRs -> 4 workgroups per CU. One 48 M k-mer bin:
+                                 * 16 rows / 128 VGPRs / 2 per CU 0.225 ms, 8 rows 0.215 ms */
 #endif
 template <int SIZE> struct CpCfg {
-	static constexpr int ITEMS = (CP_WORDS_PER_THREAD / SIZE) > 2 ? (CP_WORDS_PER_THREAD / SIZE) : 2;
+	static constexpr int WORDS = SIZE == 1 ? CP_WORDS_PER_THREAD_1 : CP_WORDS_PER_THREAD;
+	static constexpr int ITEMS = (WORDS / SIZE) > 2 ? (WORDS / SIZE) : 2; /* rows of 64 records per wave */
 	static constexpr int TILE = CP_BLOCK * ITEMS;
+	static constexpr int MIN_WAVES = SIZE == 1 ? 8 : 4; /* waves per SIMD the register allocator must leave room for */
 };
 
 /* per-run constants handed to the kernels by value */
@@ -231,7 +237,7 @@ constexpr u64 ST64_AGG = 1ull << 62, ST64_PREFIX = 2ull << 62, ST64_MASK = (1ull
  * v2 used pointer doubling over all positions (log2 rounds of two LDS sweeps: 53 k cycles per chunk). */
 constexpr int PARSE_CHUNK = 4096, PARSE_SUB = 128, PARSE_NSUB = PARSE_CHUNK / PARSE_SUB;
 #ifndef PARSE_CAND_POS
-#define PARSE_CAND_POS 24 /* entry positions per sub-block resolved speculatively (multiple of 8); deeper entries take the exact slow path */
+#define PARSE_CAND_POS 16 /* entry positions per sub-block resolved speculatively (multiple of 8); deeper entries take the exact slow path */
 #endif
 constexpr int PARSE_CAND = PARSE_CAND_POS;
 static_assert(PARSE_CAND % 8 == 0 && PARSE_CAND >= 8 && PARSE_CAND <= PARSE_SUB, "PARSE_CAND");
@@ -298,8 +304,8 @@ __global__ void __launch_bounds__(256) k_parse_packs(const uint8_t *__restrict__
 			static_assert(PARSE_NSUB * 8 == 256, "one sub-block per 8 threads");
 			/* a record is at most maxlen = 1 + ceil((k+255)/4) >= 65 bytes (e <= 255, splitter.cpp:656), so a chain can enter a
 			 * sub-block anywhere in its first maxlen positions — but a record of real data is far shorter than the format allows
-			 * (e rarely exceeds a few dozen), so only the first PARSE_CAND positions are speculated on (3 rounds instead of the 9
-			 * that maxlen asks for at k=27: 0.152 -> ... ms per 57 MB bin); the rare chain that enters deeper is walked by L2 itself.
+			 * (e rarely exceeds a few dozen), so only the first PARSE_CAND positions are speculated on (2 rounds instead of the 9
+			 * that maxlen asks for at k=27: 0.152 -> 0.089 ms per 57 MB bin, with the prefetch of the next chunk); the rare chain that enters deeper is walked by L2 itself.
 			 * Exactness does not depend on the bound. */
 			const u32 sb0 = (tid >> 3) * PARSE_SUB, sb_end = sb0 + PARSE_SUB;
 			u32 q[NC];
@@ -1060,7 +1066,6 @@ __device__ __forceinline__ u64 wave_first(u64 v) /* lane 0's value in every lane
 
 constexpr int CP_STAGE = 16384; /* bytes of output assembled in LDS per window */
 constexpr int CP_SHARDS = 32; /* tally shards: same-address device atomics serialise at ~11 ns each */
-constexpr int CP_DONE_SHARDS = 32; /* "finished" counters: done_ctr[0] + one per shard (the launch's counter block is 1 + CP_DONE_SHARDS words) */
 #ifndef CP_TILE_FROM_BLOCKIDX
 #define CP_TILE_FROM_BLOCKIDX 0
 #endif
@@ -1069,21 +1074,17 @@ constexpr int CP_DONE_SHARDS = 32; /* "finished" counters: done_ctr[0] + one per
 #endif
 static_assert(CP_TPB == 1, "one compaction tile per workgroup");
 
-#ifndef CP_MIN_WAVES
-#define CP_MIN_WAVES 4 /* waves per SIMD the register allocator must leave room for */
-#endif
 template <int SIZE>
-__global__ void __launch_bounds__(CP_BLOCK, CP_MIN_WAVES) k_compact(const u64 *__restrict__ S, u64 n, DevParams P, uint8_t *__restrict__ out,
+__global__ void __launch_bounds__(CP_BLOCK, CpCfg<SIZE>::MIN_WAVES) k_compact(const u64 *__restrict__ S, u64 n, DevParams P, uint8_t *__restrict__ out,
                                                        u64 out_capacity, u64 *__restrict__ lut_base, u32 lut_shards, u64 lut_stride,
                                                        u64 *stat_shards /* [CP_SHARDS][4] */, u64 *out_bytes, u64 *status, u32 *tile_counter,
-                                                       u32 num_tiles, u32 *err, u64 *__restrict__ stats, u64 *__restrict__ lut_out, u32 *done_ctr)
+                                                       u32 num_tiles, u32 *err)
 {
 	constexpr int ROWS = CpCfg<SIZE>::ITEMS;
 	constexpr int TILE = CpCfg<SIZE>::TILE;
 	constexpr int NW = CP_BLOCK / 64;
-	constexpr long long NONE = -2; /* "no tail in this wave's rows" (-1 is a real value: no tail before record 0) */
-	__shared__ long long s_wlast[NW]; /* global index of the last tail inside wave w's rows */
-	__shared__ long long s_carry_in;  /* global index of the last tail below the tile, -1 if there is none */
+	__shared__ u32 s_wlast[NW]; /* tile-relative position of the last tail inside wave w's rows, 0xFFFFFFFF if there is none */
+	__shared__ u32 s_carry_in;  /* position of the last tail below the tile, relative to the tile (mod 2^32; -1 = none before record 0) */
 	__shared__ u32 s_wcnt[NW];        /* counted k-mers of wave w */
 	__shared__ u32 s_wtal[NW][3];     /* unique / below min / above max of wave w */
 	__shared__ u32 s_pref[TILE];
@@ -1105,20 +1106,25 @@ __global__ void __launch_bounds__(CP_BLOCK, CP_MIN_WAVES) k_compact(const u64 *_
 
 	if (tile < num_tiles) {
 		const u32 tid = threadIdx.x;
-		const u32 lane = tid & 63, wave = tid >> 6;
+		const u32 lane = tid & 63;
+		const u32 wave = (u32)__builtin_amdgcn_readfirstlane((int)(tid >> 6)); /* scalar: everything derived from it stays on the scalar unit */
 		const u64 lane_lt = (1ull << lane) - 1;
 		TRACE_STAMP(1, tile, 0);
 		TRACE_STAMP(1, tile, 1);
+		/* Positions are kept TILE-RELATIVE in 32 bits (the kernel is bound by its VALU instructions: 2027 per wave and tile in the first
+		 * version of this design, profiles/r02/pmc_sq_counters_quarter.txt): a count is a difference of two positions modulo 2^32, which is
+		 * exactly the reference's uint32 counter, also for a previous tail far below the tile. */
 		const u64 base = (u64)tile * TILE;
-		const u64 cbase = base + (u64)wave * (ROWS * 64);
+		const u32 n_rel = (n - base) > 0xFFFFFFFFull ? 0xFFFFFFFFu : (u32)(n - base); /* records from the tile's first one to the end of the bin */
+		const u32 crel = wave * (ROWS * 64);                                             /* the wave's first record */
+		const u64 *Sw = S + (base + crel) * SIZE;
 
 		/* ---- loads: the wave's rows, the record after them, and (last wave) the 64 records below the tile */
 		u64 key[ROWS][SIZE];
 #pragma unroll
 		for (int r = 0; r < ROWS; ++r) {
-			const u64 i = cbase + (u64)r * 64 + lane;
-			if (i < n)
-				load_rec<SIZE>(S + i * SIZE, key[r]);
+			if (crel + r * 64 + lane < n_rel)
+				load_rec<SIZE>(Sw + (size_t)(r * 64 + lane) * SIZE, key[r]);
 			else {
 #pragma unroll
 				for (int w = 0; w < SIZE; ++w)
@@ -1126,15 +1132,12 @@ __global__ void __launch_bounds__(CP_BLOCK, CP_MIN_WAVES) k_compact(const u64 *_
 			}
 		}
 		u64 after[SIZE];
-		{
-			const u64 i = cbase + (u64)ROWS * 64; /* the same address in every lane */
-			if (i < n)
-				load_rec<SIZE>(S + i * SIZE, after);
-			else {
+		if (crel + ROWS * 64 < n_rel) /* the same address in every lane */
+			load_rec<SIZE>(Sw + (size_t)(ROWS * 64) * SIZE, after);
+		else {
 #pragma unroll
-				for (int w = 0; w < SIZE; ++w)
-					after[w] = 0;
-			}
+			for (int w = 0; w < SIZE; ++w)
+				after[w] = 0;
 		}
 		u64 b0[SIZE], b1[SIZE];
 		bool have_b = false;
@@ -1144,12 +1147,11 @@ __global__ void __launch_bounds__(CP_BLOCK, CP_MIN_WAVES) k_compact(const u64 *_
 			have_b = true;
 		}
 
-		/* ---- tails */
-		u32 tail_bits = 0; /* bit r: this lane's record of row r ends a run */
-		long long wlast = NONE;
+		/* ---- tails: record i ends a run iff it differs from record i+1, or is the last one */
+		u32 tail_bits = 0;       /* bit r: this lane's record of row r ends a run */
+		u32 wlast = 0xFFFFFFFFu; /* tile-relative position of the wave's last tail */
 #pragma unroll
 		for (int r = 0; r < ROWS; ++r) {
-			const u64 i = cbase + (u64)r * 64 + lane;
 			bool differs = false;
 #pragma unroll
 			for (int w = 0; w < SIZE; ++w) {
@@ -1159,27 +1161,28 @@ __global__ void __launch_bounds__(CP_BLOCK, CP_MIN_WAVES) k_compact(const u64 *_
 					nx = first_next;
 				differs = differs || (nx != key[r][w]);
 			}
-			const bool is_tail = i < n && (i + 1 == n || differs);
+			const u32 pos = crel + r * 64 + lane;
+			const bool is_tail = pos < n_rel && (differs || pos + 1 == n_rel);
 			const u64 m = __ballot(is_tail);
 			if (is_tail)
 				tail_bits |= 1u << r;
 			if (m)
-				wlast = (long long)(cbase + (u64)r * 64) + 63 - __clzll((long long)m);
+				wlast = crel + r * 64 + 63 - (u32)__clzll((long long)m);
 			__builtin_amdgcn_sched_barrier(0); /* rows in order: interleaved, their scalar masks and first-lane values overflow the SGPRs */
 		}
 		if (lane == 0)
 			s_wlast[wave] = wlast;
 		if (wave == NW - 1) {
-			long long carry = -1;
+			u32 carry = 0xFFFFFFFFu; /* -1: no tail before record 0 */
 			if (base > 0) {
 				const u64 bm = __ballot(have_b && !kmc_equal<SIZE>(b0, b1)); /* tail at j iff S[j] != S[j+1] */
 				if (bm)
-					carry = (long long)base - 64 + 63 - __clzll((long long)bm);
+					carry = (u32)(63 - __clzll((long long)bm)) - 64u;
 				else if (base > 64) {
 					/* S[base-64 .. base] are all equal: the run that crosses into the tile started further down */
 					u64 v[SIZE];
 					load_rec<SIZE>(S + (base - 64) * SIZE, v);
-					carry = (long long)run_start_search<SIZE>(S, base - 64, lane, v) - 1;
+					carry = (u32)(run_start_search<SIZE>(S, base - 64, lane, v) - 1 - base);
 				}
 			}
 			if (lane == 0)
@@ -1189,37 +1192,42 @@ __global__ void __launch_bounds__(CP_BLOCK, CP_MIN_WAVES) k_compact(const u64 *_
 		__syncthreads();
 		TRACE_STAMP(1, tile, 3);
 
-		/* ---- counts and classes */
-		long long carry = s_carry_in;
+		/* ---- counts, classes and ranks */
+		u32 carry = s_carry_in;
 #pragma unroll
 		for (int w = 0; w < NW; ++w) {
-			const long long x = s_wlast[w];
-			if (w < (int)wave && x != NONE)
+			const u32 x = s_wlast[w];
+			if (w < (int)wave && x != 0xFFFFFFFFu)
 				carry = x;
 		}
+		carry = (u32)__builtin_amdgcn_readfirstlane((int)carry);
 		TRACE_STAMP(1, tile, 4);
 		u32 cnt[ROWS];
-		u32 counted_bits = 0, nu = 0, nb = 0, na = 0, nc = 0; /* n*: wave totals, identical in every lane */
+		u32 rank2[(ROWS + 1) / 2]; /* wave-relative rank among counted k-mers, 16 bits each; 0xFFFF = not counted */
+		u32 nu = 0, nb = 0, na = 0, nc = 0; /* wave totals (scalar) */
 #pragma unroll
 		for (int r = 0; r < ROWS; ++r) {
-			const long long rowbase = (long long)(cbase + (u64)r * 64);
-			const bool is_tail = (tail_bits >> r) & 1u;
-			const u64 m = __ballot(is_tail);
+			const u32 rowrel = crel + r * 64;
+			const u64 m = __ballot((tail_bits >> r) & 1u);
 			const u64 m_lt = m & lane_lt;
-			const long long prev = m_lt ? rowbase + 63 - __clzll((long long)m_lt) : carry;
-			const u32 c = (u32)(rowbase + (long long)lane - prev); /* uint32 like the reference counter */
-			const bool below = is_tail && c < P.cutoff_min;
-			const bool above = is_tail && !below && c > P.cutoff_max;
-			const bool counted = is_tail && !below && !above;
+			const u32 prev = m_lt ? rowrel + 63 - (u32)__clzll((long long)m_lt) : carry;
+			const u32 c = rowrel + lane - prev; /* uint32 like the reference counter */
+			const u64 mb = __ballot(c < P.cutoff_min) & m;
+			const u64 ma = __ballot(c > P.cutoff_max) & m & ~mb;
+			const u64 mc = m & ~mb & ~ma;
 			cnt[r] = c > P.counter_max ? P.counter_max : c;
-			if (counted)
-				counted_bits |= 1u << r;
+			const u32 rk = __builtin_amdgcn_mbcnt_hi((u32)(mc >> 32), __builtin_amdgcn_mbcnt_lo((u32)mc, nc));
+			const u32 rk16 = ((mc >> lane) & 1ull) ? rk : 0xFFFFu;
+			if (r & 1)
+				rank2[r >> 1] |= rk16 << 16;
+			else
+				rank2[r >> 1] = rk16;
 			nu += (u32)__popcll(m);
-			nb += (u32)__popcll(__ballot(below));
-			na += (u32)__popcll(__ballot(above));
-			nc += (u32)__popcll(__ballot(counted));
+			nb += (u32)__popcll(mb);
+			na += (u32)__popcll(ma);
+			nc += (u32)__popcll(mc);
 			if (m)
-				carry = rowbase + 63 - __clzll((long long)m);
+				carry = rowrel + 63 - (u32)__clzll((long long)m);
 			__builtin_amdgcn_sched_barrier(0);
 		}
 		if (lane == 0) {
@@ -1303,42 +1311,37 @@ __global__ void __launch_bounds__(CP_BLOCK, CP_MIN_WAVES) k_compact(const u64 *_
 		 * streamed out as aligned dwords once the tile's offset is known: per-lane byte stores straight to HBM were 59 % of
 		 * the first version's time. */
 		if (!P.without_output && tile_counted) {
-			/* rank of this lane's counted record of row r = wave offset + counted records of earlier rows + lower lanes; recomputed
-			 * (one ballot per row) wherever it is needed instead of being kept in ROWS registers */
-#define CP_FOR_EACH_COUNTED(BODY)                                                                                                  \
-	{                                                                                                                              \
-		u32 row_off = wave_off;                                                                                                    \
-		_Pragma("unroll") for (int r = 0; r < ROWS; ++r)                                                                           \
-		{                                                                                                                          \
-			const bool mine = (counted_bits >> r) & 1u;                                                                            \
-			const u64 cm = __ballot(mine);                                                                                         \
-			const u32 rank = row_off + (u32)__popcll(cm & lane_lt);                                                                \
-			row_off += (u32)__popcll(cm);                                                                                          \
-			if (mine) {                                                                                                            \
-				BODY                                                                                                               \
-			}                                                                                                                      \
-			__builtin_amdgcn_sched_barrier(0);                                                                                     \
-		}                                                                                                                          \
-	}
-			if (use_lut)
-				CP_FOR_EACH_COUNTED(s_pref[rank] = (u32)kmc_remove_suffix<SIZE>(key[r], 2 * (P.k - P.lut_prefix_len));)
 			const u32 tile_bytes = tile_counted * rec_bytes;
+			const u32 pshift = 2 * (P.k - P.lut_prefix_len);
 			if (rec_bytes <= 8) {
 				/* fast path (k <= ~36): a record is one 64-bit value in output byte order; records go to an LDS window,
 				 * then every thread composes aligned output dwords from it */
 				u64 *s_rec = reinterpret_cast<u64 *>(s_stage);
 				constexpr u32 WREC = CP_STAGE / 8;
+				/* byte offset -> record: x / rec_bytes as a multiply and a shift (a 32-bit division is ~40 VALU instructions and the
+				 * copy-out needs five); exact for x < 2^14 = CP_STAGE and rec_bytes <= 8: the error x e / (d 2^17) < 1/8 <= 1/d */
+				static_assert(CP_STAGE <= 16384, "div_rb is exact below 2^14");
+				const u32 inv17 = (131072u + rec_bytes - 1) / rec_bytes;
+				auto div_rb = [&](u32 x) { return (x * inv17) >> 17; };
 				for (u32 r0 = 0; r0 < tile_counted; r0 += WREC) {
 					const u32 r1 = (tile_counted - r0) < WREC ? tile_counted : r0 + WREC;
-					CP_FOR_EACH_COUNTED(
-						if (rank >= r0 && rank < r1) {
-							u64 rv = P.sbytes ? __builtin_bswap64(key[r][0] << (8 * (8 - P.sbytes))) : 0ull;
-							if (P.cbytes) {
-								const u32 cv = P.kff ? (__builtin_bswap32(cnt[r]) >> (8 * (4 - P.cbytes))) : cnt[r];
-								rv |= (u64)cv << (8 * P.sbytes);
+#pragma unroll
+					for (int r = 0; r < ROWS; ++r) {
+						const u32 rk16 = (rank2[r >> 1] >> ((r & 1) * 16)) & 0xFFFFu;
+						if (rk16 != 0xFFFFu) {
+							const u32 rank = wave_off + rk16;
+							if (use_lut && r0 == 0)
+								s_pref[rank] = (u32)kmc_remove_suffix<SIZE>(key[r], pshift);
+							if (rank >= r0 && rank < r1) {
+								u64 rv = P.sbytes ? __builtin_bswap64(key[r][0] << (8 * (8 - P.sbytes))) : 0ull;
+								if (P.cbytes) {
+									const u32 cv = P.kff ? (__builtin_bswap32(cnt[r]) >> (8 * (4 - P.cbytes))) : cnt[r];
+									rv |= (u64)cv << (8 * P.sbytes);
+								}
+								s_rec[rank - r0] = rv;
 							}
-							s_rec[rank - r0] = rv;
-						})
+						}
+					}
 					__syncthreads(); /* the window is complete; in the first round this also publishes s_tile_off */
 					const u64 gbyte0 = s_tile_off * rec_bytes; /* global byte offset of this tile's first record */
 					const bool fits = gbyte0 + tile_bytes <= out_capacity; /* uniform over the workgroup */
@@ -1352,16 +1355,16 @@ __global__ void __launch_bounds__(CP_BLOCK, CP_MIN_WAVES) k_compact(const u64 *_
 							head = len;
 						const u32 ndw = (len - head) >> 2;
 						const u32 tail0 = head + (ndw << 2);
-						if (tid < head)
-							out[g0 + tid] = (uint8_t)(s_rec[tid / rec_bytes] >> (8 * (tid % rec_bytes)));
+						if (tid < head) /* head <= 3 < rec_bytes unless records are shorter than that: tid / rec_bytes via div_rb */
+							out[g0 + tid] = (uint8_t)(s_rec[div_rb(tid)] >> (8 * (tid - div_rb(tid) * rec_bytes)));
 						if (tid >= 32 && tid - 32 < len - tail0) {
-							const u32 bi = tail0 + (tid - 32);
-							out[g0 + bi] = (uint8_t)(s_rec[bi / rec_bytes] >> (8 * (bi % rec_bytes)));
+							const u32 bi = tail0 + (tid - 32), br = div_rb(bi);
+							out[g0 + bi] = (uint8_t)(s_rec[br] >> (8 * (bi - br * rec_bytes)));
 						}
 						u32 *gd = reinterpret_cast<u32 *>(out + g0 + head);
 						for (u32 w = tid; w < ndw; w += CP_BLOCK) {
 							const u32 i0 = head + (w << 2);
-							u32 ri = i0 / rec_bytes, q = i0 - ri * rec_bytes;
+							u32 ri = div_rb(i0), q = i0 - ri * rec_bytes;
 							u64 cur = s_rec[ri];
 							u32 word = 0;
 #pragma unroll
@@ -1381,23 +1384,31 @@ __global__ void __launch_bounds__(CP_BLOCK, CP_MIN_WAVES) k_compact(const u64 *_
 			} else {
 				for (u32 c0 = 0; c0 < tile_bytes; c0 += CP_STAGE) {
 					const u32 c1 = (tile_bytes - c0) < (u32)CP_STAGE ? tile_bytes : c0 + CP_STAGE;
-					CP_FOR_EACH_COUNTED(
-						const u32 bb = rank * rec_bytes;
-						if (bb < c1 && bb + rec_bytes > c0) {
-							for (u32 q = 0; q < rec_bytes; ++q) {
-								const u32 bpos = bb + q;
-								if (bpos >= c0 && bpos < c1) {
-									u32 val;
-									if (q < P.sbytes)
-										val = kmc_get_byte<SIZE>(key[r], P.sbytes - 1 - q);
-									else {
-										const u32 cq = q - P.sbytes;
-										val = cnt[r] >> (8 * (P.kff ? (P.cbytes - 1 - cq) : cq));
+#pragma unroll
+					for (int r = 0; r < ROWS; ++r) {
+						const u32 rk16 = (rank2[r >> 1] >> ((r & 1) * 16)) & 0xFFFFu;
+						if (rk16 != 0xFFFFu) {
+							const u32 rank = wave_off + rk16;
+							if (use_lut && c0 == 0)
+								s_pref[rank] = (u32)kmc_remove_suffix<SIZE>(key[r], pshift);
+							const u32 bb = rank * rec_bytes;
+							if (bb < c1 && bb + rec_bytes > c0) {
+								for (u32 q = 0; q < rec_bytes; ++q) {
+									const u32 bpos = bb + q;
+									if (bpos >= c0 && bpos < c1) {
+										u32 val;
+										if (q < P.sbytes)
+											val = kmc_get_byte<SIZE>(key[r], P.sbytes - 1 - q);
+										else {
+											const u32 cq = q - P.sbytes;
+											val = cnt[r] >> (8 * (P.kff ? (P.cbytes - 1 - cq) : cq));
+										}
+										s_stage[bpos - c0] = (uint8_t)val;
 									}
-									s_stage[bpos - c0] = (uint8_t)val;
 								}
 							}
-						})
+						}
+					}
 					__syncthreads();
 					const u64 gbyte0 = s_tile_off * rec_bytes;
 					const bool fits = gbyte0 + tile_bytes <= out_capacity;
@@ -1439,53 +1450,42 @@ __global__ void __launch_bounds__(CP_BLOCK, CP_MIN_WAVES) k_compact(const u64 *_
 			}
 		}
 		TRACE_STAMP(1, tile, 7);
-		}
-	/* End of the bin, in the workgroup that finishes LAST (see k_expand's tail for the ordering argument): fold the tally shards into
-	 * stats[0..2], stats[3] = n_total = n_rec (kb_sorter.h:1166), and sum the LUT shards into the caller's LUT. */
-	KMC_WAIT_VMEM();
-	__syncthreads();
-	if (threadIdx.x == 0) {
-		/* "am I the last one" in two levels: a same-address device atomic takes ~11 ns, and one per tile on ONE word (next to the
-		 * ticket's) capped the kernel at ~45 tiles per microsecond. A workgroup counts itself in on shard (tile mod 32); whoever
-		 * completes a shard counts the shard in on done_ctr[0]; whoever completes that is the last workgroup of the launch. */
-		const u32 sh = tile % CP_DONE_SHARDS;
-		const u32 expect = (num_tiles - sh + CP_DONE_SHARDS - 1) / CP_DONE_SHARDS; /* tiles t < num_tiles with t mod 32 == sh (sh < num_tiles) */
-		const u32 n_sh = num_tiles < (u32)CP_DONE_SHARDS ? num_tiles : (u32)CP_DONE_SHARDS;
-		u32 last = 0;
-		if (atomicAdd(&done_ctr[1 + sh], 1u) + 1 == expect)
-			last = atomicAdd(&done_ctr[0], 1u) + 1 == n_sh;
-		s_tile = last;
 	}
-	__syncthreads();
-	if (s_tile) {
-		if (threadIdx.x < 64) {
-			const u32 lane = threadIdx.x;
-			for (int j = 0; j < 3; ++j) {
-				u64 v = lane < CP_SHARDS ? ld_agent(&stat_shards[lane * 4 + j]) : 0;
-				v = wave_sum<u64>(v);
-				if (lane == 0)
-					stats[j] = v;
-			}
+}
+
+/* End of the bin: fold the tally shards into stats[0..2], stats[3] = n_total = n_rec (kb_sorter.h:1166), and sum the LUT shards into the
+ * caller's LUT. One small workgroup after the compaction. (Rounds 2a-2b had the compaction's last workgroup do this: every tile then ended
+ * with "wait for my atomics, count myself in, barrier" — ~4 us during which the workgroup's registers and LDS sat idle; with ~12 rounds of
+ * tiles per CU and bin that cost more than this launch does.) */
+__global__ void __launch_bounds__(256) k_compact_fold(const u64 *__restrict__ stat_shards, u64 *__restrict__ stats, u64 n, const u64 *__restrict__ lut_base,
+                                                       u32 lut_shards, u64 lut_stride, u64 *__restrict__ lut_out)
+{
+	if (threadIdx.x < 64) {
+		const u32 lane = threadIdx.x;
+		for (int j = 0; j < 3; ++j) {
+			u64 v = lane < CP_SHARDS ? stat_shards[lane * 4 + j] : 0;
+			v = wave_sum<u64>(v);
 			if (lane == 0)
-				stats[3] = n;
+				stats[j] = v;
 		}
-		if (use_lut && lut_shards > 1) { /* <= 8 K agent-scope loads (kmc_hip.hip lut_shards_for), 8 in flight per thread */
-			for (u64 i = threadIdx.x; i < lut_stride; i += CP_BLOCK) {
-				u64 v = 0;
-				for (u32 s0 = 0; s0 < lut_shards; s0 += 8) {
-					u64 part[8];
+		if (lane == 0)
+			stats[3] = n;
+	}
+	if (lut_shards > 1) { /* <= 8 K loads (kmc_hip.hip lut_shards_for), 8 in flight per thread */
+		for (u64 i = threadIdx.x; i < lut_stride; i += 256) {
+			u64 v = 0;
+			for (u32 s0 = 0; s0 < lut_shards; s0 += 8) {
+				u64 part[8];
 #pragma unroll
-					for (int q = 0; q < 8; ++q)
-						part[q] = (s0 + q < lut_shards) ? ld_agent(&lut_base[(size_t)(s0 + q) * lut_stride + i]) : 0ull;
+				for (int q = 0; q < 8; ++q)
+					part[q] = (s0 + q < lut_shards) ? lut_base[(size_t)(s0 + q) * lut_stride + i] : 0ull;
 #pragma unroll
-					for (int q = 0; q < 8; ++q)
-						v += part[q];
-				}
-				lut_out[i] = v;
+				for (int q = 0; q < 8; ++q)
+					v += part[q];
 			}
+			lut_out[i] = v;
 		}
 	}
 }
-#undef CP_FOR_EACH_COUNTED
 
 #endif

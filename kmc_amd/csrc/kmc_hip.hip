@@ -451,7 +451,7 @@ int front_end(Slot &s, const ZeroPlan &z, const DevParams &P, const uint8_t *d_i
 	return 0;
 }
 
-/* ---- compaction launch (+ tally / LUT shard reductions in one small kernel) ---- */
+/* ---- compaction launch + the fold of tally / LUT shards (one small workgroup) ---- */
 template <int SIZE>
 int launch_compact(Slot &s, const ZeroPlan &z, const u64 *sorted, u64 n, const DevParams &P, uint8_t *d_out, u64 out_capacity, u64 *d_lut,
                    u64 lut_entries, u64 *d_stats, u64 *d_out_bytes, u32 &counter_idx)
@@ -461,7 +461,7 @@ int launch_compact(Slot &s, const ZeroPlan &z, const u64 *sorted, u64 n, const D
 	const u64 c_tiles = (n + CpCfg<SIZE>::TILE - 1) / CpCfg<SIZE>::TILE;
 	if (c_tiles > 0x7FFFFFFFull)
 		return fail(KMC_HIP_EINVAL, "bin too large");
-	if (counter_idx + 2 + CP_DONE_SHARDS > N_COUNTERS)
+	if (counter_idx >= N_COUNTERS)
 		return fail(KMC_HIP_EINVAL, "too many launches for one bin");
 	const bool use_lut = lut_entries && !P.without_output && !P.kff;
 	const u32 n_sh = !use_lut ? 1u : lut_shards_for(lut_entries);
@@ -470,11 +470,11 @@ int launch_compact(Slot &s, const ZeroPlan &z, const u64 *sorted, u64 n, const D
 		lut_base = zero_ptr<u64>(s, z.lutsh); /* zeroed with the rest of the bin's zero region */
 	else if (use_lut)
 		HIPCHK(hipMemsetAsync(d_lut, 0, lut_entries * 8, s.stream));
-	/* the last workgroup to finish folds the tally shards into d_stats and the LUT shards into d_lut */
-	k_compact<SIZE><<<dim3((u32)((c_tiles + CP_TPB - 1) / CP_TPB)), dim3(CP_BLOCK), 0, s.stream>>>(
-	    sorted, n, P, d_out, out_capacity, lut_base, n_sh, lut_entries, small_ptr<u64>(s, SM_SHARDS), d_out_bytes, zero_ptr<u64>(s, z.cp_status),
-	    counters + counter_idx, (u32)c_tiles, err, d_stats, d_lut, counters + counter_idx + 1);
-	counter_idx += 2 + CP_DONE_SHARDS; /* ticket, done, done shards */
+	k_compact<SIZE><<<dim3((u32)c_tiles), dim3(CP_BLOCK), 0, s.stream>>>(sorted, n, P, d_out, out_capacity, lut_base, n_sh, lut_entries, small_ptr<u64>(s, SM_SHARDS),
+	                                                                       d_out_bytes, zero_ptr<u64>(s, z.cp_status), counters + counter_idx, (u32)c_tiles, err);
+	counter_idx += 1;
+	/* tally shards -> d_stats, LUT shards -> d_lut */
+	k_compact_fold<<<dim3(1), dim3(256), 0, s.stream>>>(small_ptr<u64>(s, SM_SHARDS), d_stats, n, lut_base, use_lut ? n_sh : 1u, lut_entries, d_lut);
 	HIPCHK(hipGetLastError());
 	return 0;
 }

@@ -103,12 +103,11 @@ void compact_t(const DevParams &P, const u64 *sorted, u64 n, uint8_t *out, u64 o
 		lut_base = lutsh.data();
 	else if (use_lut)
 		memset(lut, 0, lut_entries * 8);
-	u32 counters[2 + CP_DONE_SHARDS] = {};
-	/* the kernel reads up to one record past a thread's block only inside [0, n): no slack needed */
+	u32 counter = 0;
 	hipemu::launch(dim3((u32)c_tiles), dim3(CP_BLOCK), 0, [&] {
-		k_compact<SIZE>(sorted, n, P, out, out_capacity, lut_base, n_sh, lut_entries, shards.data(), out_bytes, status.data(), &counters[0], (u32)c_tiles, err,
-		                stats, lut, &counters[1]);
+		k_compact<SIZE>(sorted, n, P, out, out_capacity, lut_base, n_sh, lut_entries, shards.data(), out_bytes, status.data(), &counter, (u32)c_tiles, err);
 	});
+	hipemu::launch(dim3(1), dim3(256), 0, [&] { k_compact_fold(shards.data(), stats, n, lut_base, use_lut ? n_sh : 1u, lut_entries, lut); });
 }
 
 template <int SIZE>

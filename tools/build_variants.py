@@ -11,7 +11,6 @@ VARIANTS = {
     "trace": ["-DKMC_TRACE"],  # per-tile phase stamps, read by tools/trace_run.py
     "k2": ["-DRS_LOOKBACK_K=2"],
     "k8": ["-DRS_LOOKBACK_K=8"],
-    "cp3": ["-DCP_MIN_WAVES=3"],
     "b512x16": ["-DRS_BLOCK_THREADS=512", "-DRS_WORDS_PER_THREAD=16", "-DRS_MIN_WAVES=6"],
     "w8": ["-DRS_WORDS_PER_THREAD_1=8"],
     "w16s4": ["-DRS_WORDS_PER_THREAD_1=16", "-DRS_STAGES=4"],  # 16 K-record tiles (512-byte runs), 2 workgroups/CU, ~19 VGPRs spilled
@@ -19,7 +18,11 @@ VARIANTS = {
     "w12s3": ["-DRS_WORDS_PER_THREAD_1=12", "-DRS_STAGES=3"],  # 12 K-record tiles, 384-byte runs, 2 workgroups/CU
     "w10s2": ["-DRS_WORDS_PER_THREAD_1=10", "-DRS_STAGES=2"],
     "exp16k": ["-DEXP_CHUNK_BYTES=16384"],
-    "exp4k": ["-DEXP_CHUNK_BYTES=4096", "-DEXP_KWIN_KMERS=4096"],
+    "exp4k": ["-DEXP_CHUNK_BYTES=4096"],
+    "exp8k": ["-DEXP_CHUNK_BYTES=8192"],
+    "parse16": ["-DPARSE_CAND_POS=16"],
+    "parse40": ["-DPARSE_CAND_POS=40"],
+    "exp8kb256": ["-DEXP_CHUNK_BYTES=8192", "-DEXP_BLOCK_THREADS=256"],
     "cp512": ["-DCP_BLOCK_THREADS=512"],
     "w10s5": ["-DRS_WORDS_PER_THREAD_1=10", "-DRS_STAGES=5"],
     "w9s3": ["-DRS_WORDS_PER_THREAD_1=9", "-DRS_STAGES=3"],
@@ -27,22 +30,13 @@ VARIANTS = {
     "w10s2k2": ["-DRS_WORDS_PER_THREAD_1=10", "-DRS_STAGES=2", "-DRS_LOOKBACK_K=2"],
     "w10s2k8": ["-DRS_WORDS_PER_THREAD_1=10", "-DRS_STAGES=2", "-DRS_LOOKBACK_K=8"],
     "exp16kb1024": ["-DEXP_CHUNK_BYTES=16384", "-DEXP_BLOCK_THREADS=1024"],
-    "exp16kw16": ["-DEXP_CHUNK_BYTES=16384", "-DEXP_KWIN_KMERS=16384"],
-    "cp512w8": ["-DCP_BLOCK_THREADS=512", "-DCP_WORDS_PER_THREAD=8", "-DCP_MIN_WAVES=8"],
-    "cp512m3": ["-DCP_BLOCK_THREADS=512", "-DCP_MIN_WAVES=3"],
     "combo1": ["-DRS_WORDS_PER_THREAD_1=10", "-DRS_STAGES=2", "-DEXP_CHUNK_BYTES=16384", "-DCP_BLOCK_THREADS=512"],
     "nohist": ["-DEXP_NO_HIST"],  # expand without the fused histograms (sort output is garbage): what do the LDS atomics cost?
     "exp256": ["-DEXP_BLOCK_THREADS=256"],
-    "cp_b512": ["-DCP_BLOCK_THREADS=512"],  # r02 row/ballot compaction: 8 waves per tile
-    "cp_b256": ["-DCP_BLOCK_THREADS=256"],
-    "cp_b256bidx": ["-DCP_BLOCK_THREADS=256", "-DCP_TILE_FROM_BLOCKIDX=1"],
+    "cp_r16": ["-DCP_WORDS_PER_THREAD_1=16"],  # one-word records: 16 rows per wave (8192-record tiles; 64 VGPRs force spills)
     "cp_bidx": ["-DCP_TILE_FROM_BLOCKIDX=1"],  # compaction tiles in blockIdx order (no ticket atomic)
     "rs_bidx": ["-DRS_TILE_FROM_BLOCKIDX=1"],  # scatter tiles in blockIdx order
     "bidx2": ["-DCP_TILE_FROM_BLOCKIDX=1", "-DRS_TILE_FROM_BLOCKIDX=1"],
-    "cp_r8": ["-DCP_WORDS_PER_THREAD=8"],  # 8 rows per wave (2048-record tiles at one-word records)
-    "cp_r8m6": ["-DCP_WORDS_PER_THREAD=8", "-DCP_MIN_WAVES=6"],
-    "cp_m5": ["-DCP_MIN_WAVES=5"],
-    "cp8": ["-DCP_WORDS_PER_THREAD=8", "-DCP_MIN_WAVES=8"],  # compaction: 2048-record tiles, 64 VGPRs, twice the workgroups per CU
 }
 
 
