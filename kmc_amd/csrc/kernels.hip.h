@@ -51,7 +51,6 @@ constexpr int RS_BLOCK = RS_BLOCK_THREADS, RS_WAVES = RS_BLOCK / 64;            
                               * 512 threads 0.237 ms, 256 threads x 8 rows 0.566 ms: per-tile costs (look-back, barriers, end-of-tile atomics) dominate */
 #endif
 constexpr int CP_BLOCK = CP_BLOCK_THREADS;                                                     /* compaction workgroup          */
-constexpr u32 SPIN_LIMIT = 1u << 24;                                              /* look-back watchdog (polls)    */
 
 #ifndef RS_WORDS_PER_THREAD
 #define RS_WORDS_PER_THREAD 8 /* 8-byte words held per thread in a scatter tile, records of 2+ words */
@@ -226,6 +225,76 @@ template <int SIZE> __device__ __forceinline__ void store_rec(u64 *p, const u64 
 
 /* 64-bit look-back words (one per tile/slice): [63:62] flag (0 empty, 1 aggregate, 2 inclusive prefix), [61:0] count */
 constexpr u64 ST64_AGG = 1ull << 62, ST64_PREFIX = 2ull << 62, ST64_MASK = (1ull << 62) - 1;
+constexpr u32 SPIN_LIMIT = 1u << 24; /* look-back watchdog (polls) */
+
+#ifndef LB64_WINDOWS
+#define LB64_WINDOWS 1 /* 64-tile windows fetched per round trip of the 64-bit look-back. One 48 M k-mer bin, compaction: 1 window 0.222 ms,
+                        * 4: 0.253, 8: 0.273, 16: 0.311 */
+#endif
+/* Decoupled look-back over 64-bit status words, executed by ONE full wave of tile `tile`: publishes the tile's aggregate, walks back over
+ * earlier tiles until it meets an inclusive prefix, publishes the tile's own inclusive prefix and returns the exclusive one (valid in lane 0).
+ * Tiles start ~20 ns apart and publish their aggregate microseconds later, so the nearest tile that already HAS its prefix is hundreds of
+ * tiles back (compaction: ~6 windows of 64, 6.4 of a tile's 16 us, profiles/r02/trace_report_compact_4096.txt). Fetching several windows per
+ * round trip does NOT help (measured above: the walk got slower, 8.4 us at 8 windows): as in the scatter kernel the walk is bound by the
+ * device-coherent status bytes that ~1000 tiles in flight pull from the same few cache lines, not by the number of round trips. A window with
+ * an unpublished tile in front of the nearest prefix stops the round: what lies before it is kept, the rest is fetched again after a short
+ * sleep. The spin is bounded (watchdog). */
+__device__ __forceinline__ u64 lookback64(u64 *status, u32 tile, u64 aggregate, u32 lane, u32 *err, u32 err_watchdog_bit)
+{
+	if (tile == 0) {
+		if (lane == 0)
+			st_agent(&status[0], ST64_PREFIX | aggregate);
+		return 0;
+	}
+	if (lane == 0)
+		st_agent(&status[tile], ST64_AGG | aggregate);
+	long long tbase = (long long)tile - 1;
+	u64 acc = 0; /* this lane's share of the exclusive prefix */
+	u32 spins = 0;
+	bool done = false;
+	while (!done) {
+		u64 v[LB64_WINDOWS];
+#pragma unroll
+		for (int j = 0; j < LB64_WINDOWS; ++j) {
+			const long long t = tbase - 64 * j - (long long)lane;
+			v[j] = t >= 0 ? ld_agent(&status[t]) : ST64_PREFIX; /* virtual empty prefix before tile 0 */
+		}
+		int used = 0;
+		bool blocked = false;
+#pragma unroll
+		for (int j = 0; j < LB64_WINDOWS; ++j) {
+			if (!done && !blocked) { /* wave-uniform */
+				const u64 flag = v[j] & ~ST64_MASK;
+				const u64 m_pref = __ballot(flag == ST64_PREFIX);
+				const u64 m_zero = __ballot(flag == 0);
+				const int pl = m_pref ? (__ffsll(m_pref) - 1) : 64; /* nearest tile of this window that already has its prefix */
+				const u64 need = pl < 63 ? ((2ull << pl) - 1) : ~0ull;
+				if (m_zero & need)
+					blocked = true; /* a tile we depend on has not published yet */
+				else {
+					if ((int)lane <= pl)
+						acc += v[j] & ST64_MASK;
+					++used;
+					if (pl < 64)
+						done = true;
+				}
+			}
+		}
+		tbase -= 64 * used;
+		if (!done && blocked) {
+			if (++spins > SPIN_LIMIT || (spins % 1024 == 0 && (ld_agent(err) & err_watchdog_bit))) {
+				if (lane == 0)
+					atomicOr(err, err_watchdog_bit);
+				break;
+			}
+			__builtin_amdgcn_s_sleep(1);
+		}
+	}
+	const u64 excl = wave_sum<u64>(acc);
+	if (lane == 0)
+		st_agent(&status[tile], ST64_PREFIX | (excl + aggregate));
+	return excl;
+}
 
 /* ------------------------------------------------------------------------------------------------ parse
  * The bin image is a chain of variable-length records (one byte of length information per record); the only
@@ -493,41 +562,7 @@ __global__ void __launch_bounds__(EXP_BLOCK) k_expand(const uint8_t *__restrict_
 		}
 		/* slice offset among k-mers: decoupled look-back, one 64-bit word per slice, 64 slices per round trip */
 		if (wave == 0) {
-			u64 excl = 0;
-			if (c == 0) {
-				if (lane == 0)
-					st_agent(&status[0], ST64_PREFIX | (u64)tot_k);
-			} else {
-				if (lane == 0)
-					st_agent(&status[c], ST64_AGG | (u64)tot_k);
-				long long tbase = (long long)c - 1;
-				u32 spins = 0;
-				while (true) {
-					const long long t = tbase - (long long)lane;
-					const u64 v = t >= 0 ? ld_agent(&status[t]) : ST64_PREFIX;
-					const u64 flag = v & ~ST64_MASK;
-					const u64 m_pref = __ballot(flag == ST64_PREFIX);
-					const u64 m_zero = __ballot(flag == 0);
-					const int pl = m_pref ? (__ffsll(m_pref) - 1) : 64;
-					const u64 need = pl < 63 ? ((2ull << pl) - 1) : ~0ull;
-					if (m_zero & need) {
-						if (++spins > SPIN_LIMIT || (spins % 1024 == 0 && ld_agent(err) & KERR_WATCHDOG)) {
-							if (lane == 0)
-								atomicOr(err, KERR_WATCHDOG);
-							break;
-						}
-						__builtin_amdgcn_s_sleep(1);
-						continue;
-					}
-					const u64 part = wave_sum<u64>((int)lane <= pl ? (v & ST64_MASK) : 0ull);
-					excl += part;
-					if (pl < 64)
-						break;
-					tbase -= 64;
-				}
-				if (lane == 0)
-					st_agent(&status[c], ST64_PREFIX | (excl + tot_k));
-			}
+			const u64 excl = lookback64(status, c, (u64)tot_k, lane, err, KERR_WATCHDOG);
 			if (lane == 0) {
 				*s_base = excl;
 				if (c == n_chunks - 1 && excl + tot_k != n_rec)
@@ -1249,41 +1284,7 @@ __global__ void __launch_bounds__(CP_BLOCK, CpCfg<SIZE>::MIN_WAVES) k_compact(co
 		if (wave == 0) {
 			/* tile offset among counted k-mers: 64-bit decoupled look-back, one word per tile, inspected 64 tiles
 			 * at a time by the lanes of wave 0 (a one-word-per-hop walk costs ~1 us per hop) */
-			u64 excl = 0;
-			if (tile == 0) {
-				if (lane == 0)
-					st_agent(&status[0], ST64_PREFIX | (u64)tile_counted);
-			} else {
-				if (lane == 0)
-					st_agent(&status[tile], ST64_AGG | (u64)tile_counted);
-				long long tbase = (long long)tile - 1;
-				u32 spins = 0;
-				while (true) {
-					const long long t = tbase - (long long)lane;
-					const u64 v = t >= 0 ? ld_agent(&status[t]) : ST64_PREFIX; /* virtual empty prefix before tile 0 */
-					const u64 flag = v & ~ST64_MASK;
-					const u64 m_pref = __ballot(flag == ST64_PREFIX);
-					const u64 m_zero = __ballot(flag == 0);
-					const int pl = m_pref ? (__ffsll(m_pref) - 1) : 64; /* nearest tile that already has its prefix */
-					const u64 need = pl < 63 ? ((2ull << pl) - 1) : ~0ull;
-					if (m_zero & need) { /* a tile we depend on has not published yet */
-						if (++spins > SPIN_LIMIT || (spins % 1024 == 0 && ld_agent(err) & KERR_WATCHDOG)) {
-							if (lane == 0)
-								atomicOr(err, KERR_WATCHDOG);
-							break;
-						}
-						__builtin_amdgcn_s_sleep(1);
-						continue;
-					}
-					const u64 part = wave_sum<u64>((int)lane <= pl ? (v & ST64_MASK) : 0ull);
-					excl += part; /* valid in lane 0 */
-					if (pl < 64)
-						break;
-					tbase -= 64;
-				}
-				if (lane == 0)
-					st_agent(&status[tile], ST64_PREFIX | (excl + tile_counted));
-			}
+			const u64 excl = lookback64(status, tile, (u64)tile_counted, lane, err, KERR_WATCHDOG);
 			if (lane == 0) {
 				s_tile_off = excl;
 				if (tile == num_tiles - 1)

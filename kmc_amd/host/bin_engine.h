@@ -21,8 +21,6 @@ struct KmcBinEngine {
 	                        const uint64_t *pack_bytes, uint64_t n_packs, uint8_t *out_suffix, uint64_t out_capacity,
 	                        uint64_t *out_bytes, uint64_t *lut, uint64_t stats[4]) = 0;
 	virtual std::string last_error() = 0;
-	/* optional: let the engine pin the host arena the bins live in (CMemoryBins buffer) */
-	virtual void register_arena(void * /*ptr*/, uint64_t /*bytes*/) {}
 };
 
 /* Provided by exactly one of: hip_loader.cpp (HIP) or the oracle adapter inside kb_sorter_plugin.h. */

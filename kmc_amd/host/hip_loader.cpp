@@ -41,7 +41,6 @@ struct Api {
 	int (*sort_into)(kmc_hip_ctx *, int, const void *, void *, uint64_t, uint32_t, uint32_t) = nullptr;
 	int n_slots = 1;
 	std::mutex slot_mtx[64][16]; /* the C-ABI wants calls on one (device, slot) serialised; workers may outnumber slots */
-	int (*host_register)(kmc_hip_ctx *, void *, uint64_t) = nullptr;
 	kmc_hip_ctx *ctx = nullptr;
 	int n_dev = 0;
 	std::string err;
@@ -102,7 +101,7 @@ void load_api_impl()
 	if (!sym(a.so, "kmc_hip_init", a.init, a.err) || !sym(a.so, "kmc_hip_destroy", a.destroy, a.err) ||
 	    !sym(a.so, "kmc_hip_last_error", a.last_error, a.err) || !sym(a.so, "kmc_hip_abi_version", a.abi_version, a.err) ||
 	    !sym(a.so, "kmc_hip_process_bin_submit", a.submit, a.err) || !sym(a.so, "kmc_hip_process_bin_wait", a.wait, a.err) ||
-	    !sym(a.so, "kmc_hip_host_register", a.host_register, a.err) || !sym(a.so, "kmc_hip_num_slots", a.num_slots, a.err) ||
+	    !sym(a.so, "kmc_hip_num_slots", a.num_slots, a.err) ||
 	    !sym(a.so, "kmc_hip_sort_records_into", a.sort_into, a.err)) {
 		a.so = nullptr;
 		return;
@@ -176,11 +175,6 @@ struct HipEngine : KmcBinEngine {
 		return rc;
 	}
 	std::string last_error() override { return err; }
-	void register_arena(void *ptr, uint64_t bytes) override
-	{
-		if (g_api.ctx)
-			(void)g_api.host_register(g_api.ctx, ptr, bytes);
-	}
 };
 
 } // namespace

@@ -31,8 +31,17 @@ def lib():
         L.emu_run.restype = C.c_int
         L.emu_run.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_uint64, C.c_uint64, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p,
                               C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.emu_lookback.restype = C.c_uint64
+        L.emu_lookback.argtypes = [C.c_void_p, C.c_uint32, C.c_uint64, C.c_void_p]
         _LIB = L
     return _LIB
+
+
+def lookback(status: np.ndarray, tile: int, aggregate: int):
+    """lookback64 of kernels.hip.h for `tile` over a prepared uint64 status array; returns (exclusive prefix, device error word)"""
+    err = C.c_uint32(0)
+    r = lib().emu_lookback(status.ctypes.data, tile, aggregate, C.addressof(err))
+    return int(r), err.value
 
 
 def _params(p):

@@ -137,6 +137,19 @@ int run_t(const Params &p, int stage_mask, const uint8_t *img, u64 size, u64 n_r
 
 extern "C" {
 
+/* lookback64 on a prepared status array (no concurrency): returns the exclusive prefix wave 0 / lane 0 computes for `tile`; status[tile] is
+ * overwritten with the inclusive prefix word */
+unsigned long long emu_lookback(u64 *status, unsigned tile, unsigned long long aggregate, unsigned *err)
+{
+	u64 res = 0;
+	hipemu::launch(dim3(1), dim3(64), 0, [&] {
+		const u64 e = lookback64(status, tile, aggregate, threadIdx.x & 63, err, KERR_WATCHDOG);
+		if (threadIdx.x == 0)
+			res = e;
+	});
+	return res;
+}
+
 /* stage_mask: 1 = parse + expand (image -> recs[0]), 2 = sort (recs[0] -> *sorted_index = 0 or 1: which half of `recs` holds the result),
  * 4 = compaction of the sorted half. `recs` = 2 x n_rec x words uint64. Returns the device error word. */
 int emu_run(const unsigned *params10, int stage_mask, const uint8_t *img, u64 size, u64 n_rec, const u64 *pack_start, u64 n_packs, u64 *recs,

@@ -110,3 +110,27 @@ def test_emulated_parse_deep_entries_and_pack_shapes(k, max_extra, pack_size, n_
     r = emu.run(p, 1, img, nk, packs)
     assert r["err"] == 0
     assert np.array_equal(r["recs"], O.expand(p, img))
+
+
+@pytest.mark.parametrize("tile,back", [(0, 0), (1, 1), (5, 5), (64, 1), (64, 64), (65, 65), (700, 3), (700, 63), (700, 64), (700, 65), (700, 350),
+                                       (700, 511), (700, 512), (700, 513), (700, 700), (5000, 1500)])
+def test_emulated_lookback_walks_several_windows_per_round_trip(tile, back):
+    """the 64-bit decoupled look-back fetches several 64-tile windows per round trip: the nearest inclusive prefix `back` tiles behind,
+    aggregates in between, unpublished words (zero) beyond the prefix must not matter; before tile 0 lies a virtual empty prefix"""
+    AGG, PREFIX = 1 << 62, 2 << 62
+    rng = np.random.default_rng(tile * 1000 + back)
+    status = np.zeros(tile + 1, dtype=np.uint64)
+    agg = rng.integers(0, 5000, size=tile + 1)
+    want = 0
+    if tile:
+        p = tile - back  # the tile that holds a prefix (p < 0: none, the walk reaches the virtual prefix before tile 0)
+        if p >= 0:
+            incl = int(rng.integers(0, 1 << 40))
+            status[p] = PREFIX | incl
+            want = incl
+        for t in range(max(p + 1, 0), tile):
+            status[t] = AGG | int(agg[t])
+            want += int(agg[t])
+    got, err = emu.lookback(status, tile, 1234)
+    assert err == 0 and got == want
+    assert int(status[tile]) == PREFIX | (want + 1234)

@@ -20,6 +20,9 @@ VARIANTS = {
     "exp16k": ["-DEXP_CHUNK_BYTES=16384"],
     "exp4k": ["-DEXP_CHUNK_BYTES=4096"],
     "exp8k": ["-DEXP_CHUNK_BYTES=8192"],
+    "lb1": ["-DLB64_WINDOWS=1"],  # 64-bit look-back (compaction, expand): 64-tile windows per round trip
+    "lb4": ["-DLB64_WINDOWS=4"],
+    "lb16": ["-DLB64_WINDOWS=16"],
     "parse16": ["-DPARSE_CAND_POS=16"],
     "parse40": ["-DPARSE_CAND_POS=40"],
     "exp8kb256": ["-DEXP_CHUNK_BYTES=8192", "-DEXP_BLOCK_THREADS=256"],

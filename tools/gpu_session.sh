@@ -15,6 +15,7 @@ for step in "$@"; do
     e2e)     timeout 900 python tools/e2e_matrix.py > $OUT/e2e_matrix.jsonl 2> $OUT/e2e_matrix.err ;;
     streams:*) n=${step#streams:}; timeout 900 python bench.py --cache /dev/shm/kmccache --streams $n --no-cpu-baseline --no-secondary --no-host-boundary --no-digest --steps 3 > $OUT/c3_streams$n.json 2> $OUT/c3_streams$n.err ;;
     small)   timeout 600 python bench.py --leg custom --reads 2000000 --genome 10000000 --bins 512 --steps 5 --warmup 1 --no-digest > $OUT/bins512small.json 2> $OUT/bins512small.err ;;
+    small:*) n=${step#small:}; timeout 600 python bench.py --leg custom --reads 2000000 --genome 10000000 --bins 512 --steps 5 --warmup 1 --no-digest --streams $n > $OUT/bins512small_s$n.json 2> $OUT/bins512small_s$n.err; python tools/pj.py $OUT/bins512small_s$n.json | cut -c1-200 ;;
     b512)    timeout 600 python bench.py $bins512 > $OUT/bins512.json 2> $OUT/bins512.err ;;
     one)     timeout 600 python bench.py $one_bin > $OUT/onebin.json 2> $OUT/onebin.err ;;
     synth:*) n=${step#synth:}; KMC_SYNTH_VERBOSE=1 timeout 600 python -c "
