@@ -1,7 +1,8 @@
 """The kernel SOURCE of kmc_amd/csrc/kernels.hip.h executed on the CPU (tests/hipemu: one OS thread per GPU thread, wave64 cross-lane
 operations through per-wave exchanges) and compared bit for bit with the oracle. This is how kernel logic is checked in a container
 without a GPU before a GPU minute is spent; the `-m gpu` suite remains the parity test of the product (libkmc_hip.so on gfx950).
-Not covered here: k_onesweep (its ranking relies on the lock-step execution of a wave's LDS operations, which OS threads do not have)."""
+Not covered here: k_onesweep (its ranking relies on the lock-step execution of a wave's LDS operations, which OS threads do not have).
+All cases but the last use a build of the same source with 128-thread workgroups (tests/emu.py GEOMETRY_FLAGS), which emulates ~10x faster."""
 import ctypes as C
 
 import numpy as np
@@ -134,3 +135,17 @@ def test_emulated_lookback_walks_several_windows_per_round_trip(tile, back):
     got, err = emu.lookback(status, tile, 1234)
     assert err == 0 and got == want
     assert int(status[tile]) == PREFIX | (want + 1234)
+
+
+def test_emulated_kernels_with_the_product_tile_geometry():
+    """the cases above run a build with 128-thread workgroups (same source, ~10x faster to emulate); this one runs the product's geometry
+    (512-thread workgroups, 16 KB expand slices) once through the front end and the compaction"""
+    rng = np.random.default_rng(2026)
+    g = rng.integers(0, 4, size=3_000, dtype=np.uint8)
+    img, nk, packs = binsynth.random_bin(rng, 27, 500, max_extra=30, genome=g, pack_size=120)
+    p = O.make_params(27, lut_prefix_len=3)
+    recs = emu.run(p, 1, img, nk, packs, geometry="product")
+    assert recs["err"] == 0 and np.array_equal(recs["recs"], O.expand(p, img))
+    r = emu.run(p, 4, recs=O.sort(recs["recs"]), geometry="product")
+    w_out, w_lut, w_st = O.process_bin(p, img, nk)
+    assert np.array_equal(r["out"], w_out) and np.array_equal(r["lut"], w_lut) and np.array_equal(r["stats"], w_st)
