@@ -7,7 +7,8 @@ Workload = BASELINE.json configs[2] (the shape the 1/2/4/8-GPU metric is quoted 
 reads, ~30 Gbp (200 M reads of a 1 Gbp random genome, seed 2026, 1 % substitutions, random strand), cut into 512 signature
 bins of minimizer super-k-mers with KMC's parameters for that input (cutoff_min 2, counter_max 255, lut_prefix_len 7 by the
 rule of kmc.h:1434-1469) -> ~24.8 G k-mers. One "step" = ALL bins through the whole hot path (parse -> expand (+histograms) ->
-7 onesweep passes -> compaction) with the bin images already resident in HBM.
+7 onesweep passes -> compaction) with the bin images already resident in HBM. Consecutive bins share their scatter passes in groups of 4
+(kmc_hip.hip run_group_device_t: the top radix digit of a 27-mer has 2 spare bits that carry the bin's number inside the group).
 
   --gpus 1 : all 512 bins on one GPU (configs[2]).
   --gpus N : the SAME 512 bins sharded over N ranks (one process per GPU) by LPT on their k-mer counts (the order KMC hands
@@ -483,6 +484,7 @@ def main():
                        "kmers": w.total_kmers_all, "superkmers": w.total_super_all, "bin_image_bytes": w.total_bytes_all, "bins": w.n_bins_all,
                        "bins_rank0": w.n_own, "kmers_rank0": w.own_kmers, "record_bytes": W, "radix_passes": P, "cutoff_min": 2, "counter_max": 255,
                        "lut_prefix_len": pl, "streams": args.streams or "auto (1 stream when bins average >= 64 MB of records, else 8)",
+                       "bins_per_sort": min(1 << (8 * P - 2 * k), 16, int(os.environ.get("KMC_HIP_GROUP", "16"))),
                        "parallelism": "bins sharded over ranks (LPT), 1 process/GPU, tallies all-reduced (RCCL)" if world > 1 else "1 GPU"},
             "unique_kmers_per_s": float(tallies[0]) * args.steps / dt,
             "tallies": {"n_unique": int(tallies[0]), "n_cutoff_min": int(tallies[1]), "n_cutoff_max": int(tallies[2]), "n_total": int(tallies[3])},
@@ -495,8 +497,9 @@ def main():
                          "traffic_unit": "HBM bytes per launch (PMC FETCH_SIZE x2 + WRITE_SIZE, profiles/r02/pmc_hbm_traffic.json)",
                          "algorithmic_bytes_per_launch": 2 * W * rpl, "launches_in_timed_region": n_launch, "avg_launch_ms": avg_ms,
                          "records_per_launch": rpl, "algorithmic_bytes_per_record_per_launch": 2 * W,
-                         "note": "every 8th bin of a stream carries the event pairs (an event costs stream time); big bins run on one stream, so "
-                                 "launches do not overlap and the event durations are the kernel's own"},
+                         "note": "consecutive bins of a stream share one sort (bins_per_sort: the bin's number inside the group rides in the spare bits of the "
+                                 "top radix digit), so a launch covers that many bins; every 8th group of a stream carries the event pairs (an event costs "
+                                 "stream time); big bins run on one stream, so launches do not overlap and the event durations are the kernel's own"},
             "phases_ms_last_bin_slot0": timings,
             "setup_s": w.setup_s,
         }

@@ -140,6 +140,9 @@ int kmc_hip_process_bin_device(kmc_hip_ctx *ctx, int dev, const kmc_hip_bin_para
  * small bins are bound by the host's launch rate unless several threads submit (KMC's default is 512 bins per run,
  * kmc.h n_bins). n_streams <= 0 picks the default (8), capped at kmc_hip_num_slots(). Returns after enqueueing;
  * kmc_hip_synchronize(dev) waits and reports deferred device errors. Output buffers of all bins must be distinct.
+ * Consecutive bins of a stream are SORTED TOGETHER when the top radix digit has spare bits (8 ceil(k/4) - 2k of them: groups of 4 at
+ * k = 27, 55, 127): the bin's number inside the group is kept in those bits while the records are on the device, so one set of passes
+ * orders the group bin-major; front end and compaction stay per bin. $KMC_HIP_GROUP caps the group size (1 = every bin on its own).
  * Replaces: the hand-out of bins to n_sorters CWKmerBinSorter threads (kmc.h:1576-1584, queues.h:2087-2128). */
 typedef struct kmc_hip_bin_desc {
 	const uint8_t *d_superkmers;

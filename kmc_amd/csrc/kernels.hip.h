@@ -494,8 +494,11 @@ template <int SIZE, bool FUSE_HIST>
 __global__ void __launch_bounds__(EXP_BLOCK) k_expand(const uint8_t *__restrict__ data, u64 size, const u32 *__restrict__ bitmap, u32 k,
                                                  u32 both_strands, u32 n_pass, u64 n_rec, u64 *__restrict__ out, u64 *__restrict__ ghist,
                                                  u64 *status, u32 *ticket_ctr, u32 n_chunks, u32 *err, u64 *__restrict__ digit_base,
-                                                 u32 *done_ctr)
+                                                 u32 *done_ctr, u64 tag)
 {
+	/* `tag`: OR-ed into the record word that holds bit 2k — the spare bits of the top radix digit (8 ceil(k/4) - 2k of them). Several bins
+	 * expanded into one record array with tags 0, 1, 2 ... are sorted by ONE set of passes into bin-major order (kmc_hip.hip, grouped bins);
+	 * 0 for a bin on its own. */
 	const u32 MAX_SK = exp_max_sk(k);
 	KMC_DYN_LDS(unsigned char, s_raw);
 	u64 *s_base = reinterpret_cast<u64 *>(s_raw);                             /* [2] (16 bytes keeps s_b 16-B aligned) */
@@ -637,6 +640,10 @@ __global__ void __launch_bounds__(EXP_BLOCK) k_expand(const uint8_t *__restrict_
 					} else {
 						kmc_canonical_at<SIZE>(s_b + s_skpos[si] + 1, off, k, both_strands != 0, v);
 					}
+#pragma unroll
+					for (int w = 0; w < SIZE; ++w)
+						if (((2 * k) >> 6) == (u32)w)
+							v[w] |= tag; /* already shifted to its place inside the word that holds bit 2k (k = 32 SIZE: no spare bits, tag 0) */
 					store_rec<SIZE>(out + gj * SIZE, v);
 #ifndef EXP_NO_HIST /* tuning builds only (-DEXP_NO_HIST): what do the fused histograms cost? (the sort is garbage then) */
 					if (FUSE_HIST) {
@@ -1113,7 +1120,7 @@ template <int SIZE>
 __global__ void __launch_bounds__(CP_BLOCK, CpCfg<SIZE>::MIN_WAVES) k_compact(const u64 *__restrict__ S, u64 n, DevParams P, uint8_t *__restrict__ out,
                                                        u64 out_capacity, u64 *__restrict__ lut_base, u32 lut_shards, u64 lut_stride,
                                                        u64 *stat_shards /* [CP_SHARDS][4] */, u64 *out_bytes, u64 *status, u32 *tile_counter,
-                                                       u32 num_tiles, u32 *err)
+                                                       u32 num_tiles, u32 *err, u32 lut_mask /* 4^p - 1: drops a group tag above the k-mer */)
 {
 	constexpr int ROWS = CpCfg<SIZE>::ITEMS;
 	constexpr int TILE = CpCfg<SIZE>::TILE;
@@ -1332,7 +1339,7 @@ __global__ void __launch_bounds__(CP_BLOCK, CpCfg<SIZE>::MIN_WAVES) k_compact(co
 						if (rk16 != 0xFFFFu) {
 							const u32 rank = wave_off + rk16;
 							if (use_lut && r0 == 0)
-								s_pref[rank] = (u32)kmc_remove_suffix<SIZE>(key[r], pshift);
+								s_pref[rank] = (u32)kmc_remove_suffix<SIZE>(key[r], pshift) & lut_mask;
 							if (rank >= r0 && rank < r1) {
 								u64 rv = P.sbytes ? __builtin_bswap64(key[r][0] << (8 * (8 - P.sbytes))) : 0ull;
 								if (P.cbytes) {
@@ -1391,7 +1398,7 @@ __global__ void __launch_bounds__(CP_BLOCK, CpCfg<SIZE>::MIN_WAVES) k_compact(co
 						if (rk16 != 0xFFFFu) {
 							const u32 rank = wave_off + rk16;
 							if (use_lut && c0 == 0)
-								s_pref[rank] = (u32)kmc_remove_suffix<SIZE>(key[r], pshift);
+								s_pref[rank] = (u32)kmc_remove_suffix<SIZE>(key[r], pshift) & lut_mask;
 							const u32 bb = rank * rec_bytes;
 							if (bb < c1 && bb + rec_bytes > c0) {
 								for (u32 q = 0; q < rec_bytes; ++q) {

@@ -417,32 +417,33 @@ int check_params(const kmc_hip_bin_params *p, DevParams &P)
 
 /* ---- front end: mark super-k-mer starts (per pack), then expand slice-parallel with the sort's histograms fused in ---- */
 template <int SIZE>
-int front_end(Slot &s, const ZeroPlan &z, const DevParams &P, const uint8_t *d_in, u64 size, u64 n_rec, const u64 *d_pack_start, u64 n_packs,
-              u32 n_pass, u32 &counter_idx, bool &hist_done)
+int front_end(Slot &s, size_t off_bitmap, size_t off_exp_status, size_t off_ghist, const DevParams &P, const uint8_t *d_in, u64 size, u64 n_rec,
+              const u64 *d_pack_start, u64 n_packs, u32 n_pass, u32 &counter_idx, bool &hist_done, u64 *d_recs, u64 tag, bool fuse)
 {
 	u32 *err = err_ptr(s);
 	u32 *counters = small_ptr<u32>(s, SM_COUNTERS);
 	const u64 n_chunks = (size + EXP_CHUNK - 1) / EXP_CHUNK;
 	if (n_chunks > 0x7FFFFFF0ull || n_packs > 0x7FFFFFF0ull)
 		return fail(KMC_HIP_EINVAL, "bin too large");
-	u32 *bitmap = zero_ptr<u32>(s, z.bitmap);
-	u64 *status = zero_ptr<u64>(s, z.exp_status);
-	u64 *ghist = zero_ptr<u64>(s, z.ghist);
+	if (counter_idx + 2 > N_COUNTERS)
+		return fail(KMC_HIP_EINVAL, "too many launches for one bin");
+	u32 *bitmap = zero_ptr<u32>(s, off_bitmap);
+	u64 *status = zero_ptr<u64>(s, off_exp_status);
+	u64 *ghist = zero_ptr<u64>(s, off_ghist);
 	k_parse_packs<<<dim3((u32)n_packs), dim3(256), 0, s.stream>>>(d_in, d_pack_start, (u32)n_packs, P.k, bitmap, err);
 	if (s.timed)
 		HIPCHK(hipEventRecord(s.ev[1], s.stream));
-	const bool fuse = n_pass <= EXP_FUSE_MAX_PASS && n_rec >= 2; /* LDS: 1 KB of counters per pass next to the slice state */
 	const u32 blocks = (u32)std::min<u64>(n_chunks, 256 * 4 * (512 / EXP_BLOCK)); /* persistent workgroups, up to 4 per CU */
-	if (fuse) {
+	if (fuse) { /* LDS: 1 KB of counters per pass next to the slice state */
 		if (int rc = ensure(s.dbase, (size_t)n_pass * 256 * 8))
 			return rc;
 		k_expand<SIZE, true><<<dim3(blocks), dim3(EXP_BLOCK), exp_lds_bytes<true>(n_pass, P.k), s.stream>>>(
-		    d_in, size, bitmap, P.k, P.both_strands, n_pass, n_rec, (u64 *)s.recA.p, ghist, status, counters + counter_idx, (u32)n_chunks, err,
-		    (u64 *)s.dbase.p, counters + counter_idx + 1);
+		    d_in, size, bitmap, P.k, P.both_strands, n_pass, n_rec, d_recs, ghist, status, counters + counter_idx, (u32)n_chunks, err,
+		    (u64 *)s.dbase.p, counters + counter_idx + 1, tag);
 	} else
 		k_expand<SIZE, false><<<dim3(blocks), dim3(EXP_BLOCK), exp_lds_bytes<false>(n_pass, P.k), s.stream>>>(
-		    d_in, size, bitmap, P.k, P.both_strands, n_pass, n_rec, (u64 *)s.recA.p, ghist, status, counters + counter_idx, (u32)n_chunks, err,
-		    nullptr, counters + counter_idx + 1);
+		    d_in, size, bitmap, P.k, P.both_strands, n_pass, n_rec, d_recs, ghist, status, counters + counter_idx, (u32)n_chunks, err,
+		    nullptr, counters + counter_idx + 1, tag);
 	counter_idx += 2;
 	hist_done = fuse;
 	if (s.timed)
@@ -453,8 +454,8 @@ int front_end(Slot &s, const ZeroPlan &z, const DevParams &P, const uint8_t *d_i
 
 /* ---- compaction launch + the fold of tally / LUT shards (one small workgroup) ---- */
 template <int SIZE>
-int launch_compact(Slot &s, const ZeroPlan &z, const u64 *sorted, u64 n, const DevParams &P, uint8_t *d_out, u64 out_capacity, u64 *d_lut,
-                   u64 lut_entries, u64 *d_stats, u64 *d_out_bytes, u32 &counter_idx)
+int launch_compact(Slot &s, size_t off_cp_status, size_t off_lutsh, const u64 *sorted, u64 n, const DevParams &P, uint8_t *d_out, u64 out_capacity,
+                   u64 *d_lut, u64 lut_entries, u64 *d_stats, u64 *d_out_bytes, u32 &counter_idx, u64 *tally_shards)
 {
 	u32 *err = err_ptr(s);
 	u32 *counters = small_ptr<u32>(s, SM_COUNTERS);
@@ -467,14 +468,15 @@ int launch_compact(Slot &s, const ZeroPlan &z, const u64 *sorted, u64 n, const D
 	const u32 n_sh = !use_lut ? 1u : lut_shards_for(lut_entries);
 	u64 *lut_base = d_lut;
 	if (use_lut && n_sh > 1)
-		lut_base = zero_ptr<u64>(s, z.lutsh); /* zeroed with the rest of the bin's zero region */
+		lut_base = zero_ptr<u64>(s, off_lutsh); /* zeroed with the rest of the zero region */
 	else if (use_lut)
 		HIPCHK(hipMemsetAsync(d_lut, 0, lut_entries * 8, s.stream));
-	k_compact<SIZE><<<dim3((u32)c_tiles), dim3(CP_BLOCK), 0, s.stream>>>(sorted, n, P, d_out, out_capacity, lut_base, n_sh, lut_entries, small_ptr<u64>(s, SM_SHARDS),
-	                                                                       d_out_bytes, zero_ptr<u64>(s, z.cp_status), counters + counter_idx, (u32)c_tiles, err);
+	k_compact<SIZE><<<dim3((u32)c_tiles), dim3(CP_BLOCK), 0, s.stream>>>(sorted, n, P, d_out, out_capacity, lut_base, n_sh, lut_entries, tally_shards, d_out_bytes,
+	                                                                       zero_ptr<u64>(s, off_cp_status), counters + counter_idx, (u32)c_tiles, err,
+	                                                                       P.lut_prefix_len ? (u32)((1ull << (2 * P.lut_prefix_len)) - 1) : 0u);
 	counter_idx += 1;
 	/* tally shards -> d_stats, LUT shards -> d_lut */
-	k_compact_fold<<<dim3(1), dim3(256), 0, s.stream>>>(small_ptr<u64>(s, SM_SHARDS), d_stats, n, lut_base, use_lut ? n_sh : 1u, lut_entries, d_lut);
+	k_compact_fold<<<dim3(1), dim3(256), 0, s.stream>>>(tally_shards, d_stats, n, lut_base, use_lut ? n_sh : 1u, lut_entries, d_lut);
 	HIPCHK(hipGetLastError());
 	return 0;
 }
@@ -524,7 +526,8 @@ int run_bin_device_t(Slot &s, const DevParams &P, const uint8_t *d_in, u64 size,
 	if (s.timed)
 		HIPCHK(hipEventRecord(s.ev[0], s.stream));
 	bool hist_done = false;
-	if ((rc = front_end<SIZE>(s, z, P, d_in, size, n_rec, d_pack_start, n_packs, n_pass, counter_idx, hist_done)))
+	if ((rc = front_end<SIZE>(s, z.bitmap, z.exp_status, z.ghist, P, d_in, size, n_rec, d_pack_start, n_packs, n_pass, counter_idx, hist_done, (u64 *)s.recA.p, 0,
+	                          n_pass <= EXP_FUSE_MAX_PASS && n_rec >= 2)))
 		return rc;
 	/* sort */
 	u64 *sorted = nullptr;
@@ -536,7 +539,8 @@ int run_bin_device_t(Slot &s, const DevParams &P, const uint8_t *d_in, u64 size,
 		HIPCHK(hipEventRecord(s.ev[4], s.stream));
 	}
 	/* compact */
-	if ((rc = launch_compact<SIZE>(s, z, sorted, n_rec, P, d_out, out_capacity, d_lut, lut_entries, d_stats, d_out_bytes, counter_idx)))
+	if ((rc = launch_compact<SIZE>(s, z.cp_status, z.lutsh, sorted, n_rec, P, d_out, out_capacity, d_lut, lut_entries, d_stats, d_out_bytes, counter_idx,
+	                               small_ptr<u64>(s, SM_SHARDS))))
 		return rc;
 	if (s.timed)
 		HIPCHK(hipEventRecord(s.ev[5], s.stream));
@@ -559,6 +563,133 @@ int run_bin_device(Slot &s, const DevParams &P, const uint8_t *d_in, u64 size, u
 	case 8: RUN(8);
 	}
 #undef RUN
+	return fail(KMC_HIP_EINVAL, "kmer_len out of range");
+}
+
+/* ---- several bins through ONE sort ------------------------------------------------------------------------------
+ * The top radix digit of a k-mer has 8 ceil(k/4) - 2k spare bits (2 at k = 27, 55, 127). Bins expanded into one record array with the bin's
+ * number inside the group in those bits are put into bin-major order by the SAME number of passes one bin needs — as launches 2^spare times
+ * as large (a 48 M-record launch runs at 0.46-0.47 of the HBM peak, a 190 M-record one at ~0.485: fewer ramps and drains per record) and
+ * 2^spare times fewer of them. Front end and compaction stay per bin, on the bin's slice of the shared arrays. */
+u32 group_capacity(u32 k)
+{
+	static const int limit = [] {
+		const char *e = getenv("KMC_HIP_GROUP"); /* 1 = every bin on its own */
+		const int v = e ? atoi(e) : 16;
+		return v < 1 ? 1 : v;
+	}();
+	const u32 spare = 8 * ((2 * k + 7) / 8) - 2 * k;
+	const u32 cap = 1u << (spare > 4 ? 4 : spare);
+	return cap < (u32)limit ? cap : (u32)limit;
+}
+constexpr u64 GROUP_MAX_RECORD_BYTES = 6ull << 30; /* per record array of a group */
+
+template <int SIZE>
+int run_group_device_t(Slot &s, const DevParams &P, const kmc_hip_bin_desc *const *bins, u32 g, u64 lut_entries)
+{
+	const u32 k = P.k;
+	const u32 n_pass = (2 * k + 7) / 8;
+	const bool use_lut = lut_entries && !P.without_output && !P.kff;
+	const u32 n_sh = use_lut ? lut_shards_for(lut_entries) : 1u;
+	const bool fuse = n_pass <= EXP_FUSE_MAX_PASS;
+	u64 N = 0;
+	std::vector<u64> rec_off(g);
+	struct Off {
+		size_t bitmap, exp_status, cp_status, lutsh, tally;
+	};
+	std::vector<Off> off(g);
+	size_t zoff = up256(SM_BYTES);
+	for (u32 i = 0; i < g; ++i) {
+		const kmc_hip_bin_desc &b = *bins[i];
+		if ((b.n_rec == 0) != (b.size == 0))
+			return fail(KMC_HIP_ECORRUPT, "exactly one of size / n_rec is zero");
+		if (b.n_rec && (b.n_packs == 0 || b.n_packs > 0xFFFFFFF0ull))
+			return fail(KMC_HIP_EINVAL, "n_packs out of range");
+		rec_off[i] = N;
+		N += b.n_rec;
+		off[i].bitmap = zoff;
+		zoff += up256(((b.size + 31) / 32 + 2) * 4);
+		off[i].exp_status = zoff;
+		zoff += up256(((b.size + EXP_CHUNK - 1) / EXP_CHUNK) * 8 + 8);
+		off[i].cp_status = zoff;
+		zoff += up256(((b.n_rec + CpCfg<SIZE>::TILE - 1) / CpCfg<SIZE>::TILE) * 8 + 8);
+		off[i].lutsh = zoff;
+		zoff += up256(n_sh > 1 ? (size_t)n_sh * lut_entries * 8 : 0);
+		off[i].tally = zoff;
+		zoff += up256(CP_SHARDS * 4 * 8);
+	}
+	ZeroPlan z;
+	z.ghist = zoff;
+	zoff += up256((size_t)n_pass * 256 * 8);
+	if (N >= 2) {
+		const u64 max_tiles = (std::min(N, s.portion) + RsCfg<SIZE>::TILE - 1) / RsCfg<SIZE>::TILE;
+		const u64 n_launch = (u64)n_pass * ((N + s.portion - 1) / s.portion);
+		z.sc_status = zoff;
+		z.sc_stride = up256((size_t)max_tiles * 256 * 4);
+		zoff += z.sc_stride * n_launch;
+	}
+	z.total = zoff;
+	int rc = 0;
+	if ((rc = ensure(s.recA, N * SIZE * 8 + 256)) || (rc = ensure(s.recB, N * SIZE * 8 + 256)) || (rc = apply_plan(s, z)))
+		return rc;
+	if (s.timed)
+		HIPCHK(hipEventRecord(s.ev[0], s.stream));
+	u32 counter_idx = 0;
+	bool hist_done = false;
+	const u32 tag_shift = (2 * k) & 63;
+	for (u32 i = 0; i < g; ++i) {
+		const kmc_hip_bin_desc &b = *bins[i];
+		if (b.n_rec == 0) {
+			HIPCHK(hipMemsetAsync(b.d_stats, 0, 4 * 8, s.stream));
+			HIPCHK(hipMemsetAsync(b.d_out_bytes, 0, 8, s.stream));
+			if (lut_entries && !P.without_output)
+				HIPCHK(hipMemsetAsync(b.d_lut, 0, lut_entries * 8, s.stream));
+			continue;
+		}
+		if ((rc = front_end<SIZE>(s, off[i].bitmap, off[i].exp_status, z.ghist, P, b.d_superkmers, b.size, b.n_rec, (const u64 *)b.d_pack_start, b.n_packs, n_pass,
+		                          counter_idx, hist_done, (u64 *)s.recA.p + rec_off[i] * SIZE, (u64)i << tag_shift, fuse)))
+			return rc;
+	}
+	u64 *sorted = (u64 *)s.recA.p;
+	if (N) {
+		if (!fuse)
+			hist_done = false; /* k > 64: one k_hist over the group's records */
+		if ((rc = sort_device_t<SIZE>(s, z, (u64 *)s.recA.p, (u64 *)s.recB.p, N, n_pass, &sorted, counter_idx, hist_done)))
+			return rc;
+	}
+	if (s.timed) {
+		if (N < 2)
+			HIPCHK(hipEventRecord(s.ev[3], s.stream));
+		HIPCHK(hipEventRecord(s.ev[4], s.stream));
+	}
+	for (u32 i = 0; i < g; ++i) {
+		const kmc_hip_bin_desc &b = *bins[i];
+		if (b.n_rec == 0)
+			continue;
+		if ((rc = launch_compact<SIZE>(s, off[i].cp_status, off[i].lutsh, sorted + rec_off[i] * SIZE, b.n_rec, P, b.d_out, b.out_capacity, (u64 *)b.d_lut, lut_entries,
+		                               (u64 *)b.d_stats, (u64 *)b.d_out_bytes, counter_idx, zero_ptr<u64>(s, off[i].tally))))
+			return rc;
+	}
+	if (s.timed)
+		HIPCHK(hipEventRecord(s.ev[5], s.stream));
+	HIPCHK(hipGetLastError());
+	return 0;
+}
+
+int run_group_device(Slot &s, const DevParams &P, const kmc_hip_bin_desc *const *bins, u32 g, u64 lut_entries)
+{
+	std::lock_guard<std::mutex> lck(s.mtx);
+	s.timed = (s.async_seq++ % TIMING_SAMPLE) == 0;
+	switch ((P.k + 31) / 32) {
+	case 1: return run_group_device_t<1>(s, P, bins, g, lut_entries);
+	case 2: return run_group_device_t<2>(s, P, bins, g, lut_entries);
+	case 3: return run_group_device_t<3>(s, P, bins, g, lut_entries);
+	case 4: return run_group_device_t<4>(s, P, bins, g, lut_entries);
+	case 5: return run_group_device_t<5>(s, P, bins, g, lut_entries);
+	case 6: return run_group_device_t<6>(s, P, bins, g, lut_entries);
+	case 7: return run_group_device_t<7>(s, P, bins, g, lut_entries);
+	case 8: return run_group_device_t<8>(s, P, bins, g, lut_entries);
+	}
 	return fail(KMC_HIP_EINVAL, "kmer_len out of range");
 }
 
@@ -596,7 +727,8 @@ int debug_expand_t(Slot &s, const DevParams &P, u64 size, u64 n_rec, u64 np)
 		return rc;
 	u32 counter_idx = 0;
 	bool hist_done = false;
-	return front_end<SIZE>(s, z, P, (const uint8_t *)s.in.p, size, n_rec, (const u64 *)s.pack_start.p, np, n_pass, counter_idx, hist_done);
+	return front_end<SIZE>(s, z.bitmap, z.exp_status, z.ghist, P, (const uint8_t *)s.in.p, size, n_rec, (const u64 *)s.pack_start.p, np, n_pass, counter_idx, hist_done,
+	                       (u64 *)s.recA.p, 0, n_pass <= EXP_FUSE_MAX_PASS && n_rec >= 2);
 }
 template <int SIZE>
 int debug_compact_t(Slot &s, const DevParams &P, u64 n, u64 out_capacity, u64 lut_entries)
@@ -607,8 +739,8 @@ int debug_compact_t(Slot &s, const DevParams &P, u64 n, u64 out_capacity, u64 lu
 	if (int rc = apply_plan(s, z))
 		return rc;
 	u32 counter_idx = 0;
-	return launch_compact<SIZE>(s, z, (const u64 *)s.recA.p, n, P, (uint8_t *)s.out.p, out_capacity, (u64 *)s.lut.p, lut_entries,
-	                            small_ptr<u64>(s, SM_STATS), small_ptr<u64>(s, SM_OUTBYTES), counter_idx);
+	return launch_compact<SIZE>(s, z.cp_status, z.lutsh, (const u64 *)s.recA.p, n, P, (uint8_t *)s.out.p, out_capacity, (u64 *)s.lut.p, lut_entries,
+	                            small_ptr<u64>(s, SM_STATS), small_ptr<u64>(s, SM_OUTBYTES), counter_idx, small_ptr<u64>(s, SM_SHARDS));
 }
 } // namespace
 
@@ -911,24 +1043,52 @@ int kmc_hip_process_bins_device(kmc_hip_ctx *ctx, int dev, const kmc_hip_bin_par
 	 * with hundreds of small bins a single submitting thread is the bottleneck, not the GPU). Big bins all take slot 0. */
 	std::vector<int> rcs((size_t)n_streams, 0);
 	std::vector<std::string> msgs((size_t)n_streams);
+	const u32 G = group_capacity(P.k);
+	const u64 rec_bytes_of = (u64)((P.k + 31) / 32) * 8;
 	auto work = [&](int t) {
 		if (hipSetDevice(d.ordinal) != hipSuccess) {
 			rcs[t] = KMC_HIP_EDEVICE;
 			msgs[t] = "hipSetDevice failed in a submitting thread";
 			return;
 		}
+		/* this stream's bins, in index order; consecutive ones share one sort (run_group_device_t) while the group's record array stays small */
+		std::vector<const kmc_hip_bin_desc *> grp;
+		u64 grp_recs = 0;
+		auto flush = [&]() -> int {
+			int rc = 0;
+			if (grp.size() == 1) {
+				const kmc_hip_bin_desc &b = *grp[0];
+				rc = process_bin_device_on(ctx, dev, d.slot[t], P, lut_entries, b.d_superkmers, b.size, b.n_rec, b.d_pack_start, b.n_packs, b.d_out, b.out_capacity,
+				                           b.d_out_bytes, b.d_lut, b.d_stats, 0);
+			} else if (grp.size() > 1)
+				rc = run_group_device(d.slot[t], P, grp.data(), (u32)grp.size(), lut_entries);
+			grp.clear();
+			grp_recs = 0;
+			return rc;
+		};
 		for (uint64_t i = 0; i < n_bins; ++i) {
 			const kmc_hip_bin_desc &b = bins[i];
 			const int si = is_big(P, b.n_rec) ? 0 : (int)(i % (uint64_t)n_streams);
 			if (si != t)
 				continue;
-			int rc = process_bin_device_on(ctx, dev, d.slot[si], P, lut_entries, b.d_superkmers, b.size, b.n_rec, b.d_pack_start, b.n_packs,
-			                               b.d_out, b.out_capacity, b.d_out_bytes, b.d_lut, b.d_stats, 0);
+			int rc = 0;
+			if (!grp.empty() && (grp.size() >= G || (grp_recs + b.n_rec) * rec_bytes_of > GROUP_MAX_RECORD_BYTES))
+				rc = flush();
+			if (!rc) {
+				grp.push_back(&b);
+				grp_recs += b.n_rec;
+				if (G < 2)
+					rc = flush();
+			}
 			if (rc) {
 				rcs[t] = rc;
 				msgs[t] = g_err;
 				return;
 			}
+		}
+		if (int rc = flush()) {
+			rcs[t] = rc;
+			msgs[t] = g_err;
 		}
 	};
 	if (n_streams == 1 || n_bins < 2) {

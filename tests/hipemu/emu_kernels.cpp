@@ -56,12 +56,12 @@ template <int SIZE> int expand_t(const DevParams &P, const uint8_t *img, u64 siz
 	if (fuse)
 		hipemu::launch(dim3(blocks), dim3(EXP_BLOCK), exp_lds_bytes<true>(n_pass, P.k), [&] {
 			k_expand<SIZE, true>(in.data(), size, bitmap.data(), P.k, P.both_strands, n_pass, n_rec, recs, ghist.data(), status.data(), &counters[0],
-			                     (u32)n_chunks, err, dbase, &counters[1]);
+			                     (u32)n_chunks, err, dbase, &counters[1], 0ull);
 		});
 	else
 		hipemu::launch(dim3(blocks), dim3(EXP_BLOCK), exp_lds_bytes<false>(n_pass, P.k), [&] {
 			k_expand<SIZE, false>(in.data(), size, bitmap.data(), P.k, P.both_strands, n_pass, n_rec, recs, ghist.data(), status.data(), &counters[0],
-			                      (u32)n_chunks, err, nullptr, &counters[1]);
+			                      (u32)n_chunks, err, nullptr, &counters[1], 0ull);
 		});
 	return fuse ? 1 : 0;
 }
@@ -105,7 +105,8 @@ void compact_t(const DevParams &P, const u64 *sorted, u64 n, uint8_t *out, u64 o
 		memset(lut, 0, lut_entries * 8);
 	u32 counter = 0;
 	hipemu::launch(dim3((u32)c_tiles), dim3(CP_BLOCK), 0, [&] {
-		k_compact<SIZE>(sorted, n, P, out, out_capacity, lut_base, n_sh, lut_entries, shards.data(), out_bytes, status.data(), &counter, (u32)c_tiles, err);
+		k_compact<SIZE>(sorted, n, P, out, out_capacity, lut_base, n_sh, lut_entries, shards.data(), out_bytes, status.data(), &counter, (u32)c_tiles, err,
+		                P.lut_prefix_len ? (u32)((1ull << (2 * P.lut_prefix_len)) - 1) : 0u);
 	});
 	hipemu::launch(dim3(1), dim3(256), 0, [&] { k_compact_fold(shards.data(), stats, n, lut_base, use_lut ? n_sh : 1u, lut_entries, lut); });
 }

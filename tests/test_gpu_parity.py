@@ -410,13 +410,16 @@ def _run_batch(ctx, p, bins, n_streams=0, shrink_cap_of=None):
     return out, err
 
 
-@pytest.mark.parametrize("n_bins,reads,genome,pl,streams", [(512, 400_000, 2_000_000, 7, 0), (16, 400_000, 2_000_000, 7, 3), (64, 60_000, 300_000, 3, 16)])
-def test_many_bins_in_one_call_match_the_oracle_per_bin(ctx, n_bins, reads, genome, pl, streams):
+@pytest.mark.parametrize("n_bins,reads,genome,pl,streams,k", [(512, 400_000, 2_000_000, 7, 0, 27), (16, 400_000, 2_000_000, 7, 3, 27), (64, 60_000, 300_000, 3, 16, 27),
+                                                              (23, 300_000, 1_500_000, 7, 1, 27), (40, 100_000, 500_000, 5, 2, 25), (21, 100_000, 500_000, 3, 2, 55),
+                                                              (10, 100_000, 500_000, 4, 1, 32), (9, 40_000, 200_000, 3, 1, 127)])
+def test_many_bins_in_one_call_match_the_oracle_per_bin(ctx, n_bins, reads, genome, pl, streams, k):
     """configs[2]'s shape in small: one read set cut into signature bins (30x coverage, lut_prefix_len 7 as KMC picks for 30 Gbp),
-    ALL bins through ONE kmc_hip_process_bins_device call (bin i on stream i mod n_streams, several host threads enqueueing),
-    every bin compared with the oracle bit for bit — suffix records, LUT, tallies."""
-    bins = capi.synth_bins(seed=2026, genome_len=genome, n_reads=reads, k=27, n_bins=n_bins)
-    p = hp(27, lut_prefix_len=pl)
+    ALL bins through ONE kmc_hip_process_bins_device call (bin i on stream i mod n_streams, several host threads enqueueing; consecutive
+    bins of a stream share one sort, tagged in the spare bits of the top radix digit: groups of 4 at k = 27, 55, 127, of 16 at k = 25, none
+    at k = 32), every bin compared with the oracle bit for bit — suffix records, LUT, tallies."""
+    bins = capi.synth_bins(seed=2026, genome_len=genome, n_reads=reads, k=k, n_bins=n_bins)
+    p = hp(k, lut_prefix_len=pl)
     got, err = _run_batch(ctx, p, bins, streams)
     assert err is None, err
     tot = np.zeros(4, dtype=np.uint64)
