@@ -89,6 +89,52 @@ struct DevParams {
 	u32 k, both_strands, cutoff_min, cutoff_max, counter_max, lut_prefix_len, sbytes, cbytes, kff, without_output;
 };
 
+/* Group descriptors: parse, expand, compaction and fold work on up to GRP_MAX bins per launch (the bins of one grouped sort, kmc_hip.hip
+ * run_group_device_t; a bin on its own is a group of one). Passed BY VALUE as kernel arguments: a workgroup finds its bin by walking the
+ * prefix array of work items (packs / slices / tiles) — scalar loads from the kernel-argument segment, nothing to upload. */
+constexpr int GRP_MAX = 16;
+struct GrpParse {
+	u32 g, pack_prefix[GRP_MAX + 1]; /* packs of bin b: [pack_prefix[b], pack_prefix[b+1]) */
+	const uint8_t *data[GRP_MAX];
+	const u64 *pack_start[GRP_MAX];
+	u32 *bitmap[GRP_MAX];
+};
+struct GrpExpand {
+	u32 g, chunk_prefix[GRP_MAX + 1]; /* EXP_CHUNK-byte slices */
+	const uint8_t *data[GRP_MAX];
+	u64 size[GRP_MAX], n_rec[GRP_MAX];
+	const u32 *bitmap[GRP_MAX];
+	u64 *out[GRP_MAX];    /* the bin's slice of the shared record array */
+	u64 *status[GRP_MAX]; /* look-back words, one per slice of the bin */
+	u64 tag[GRP_MAX];     /* the bin's number inside the group, shifted to bit 2k of the record word that holds it */
+};
+struct GrpCompact {
+	u32 g, tile_prefix[GRP_MAX + 1];
+	const u64 *S[GRP_MAX]; /* the bin's slice of the sorted array */
+	u64 n[GRP_MAX];
+	uint8_t *out[GRP_MAX];
+	u64 out_capacity[GRP_MAX];
+	u64 *lut_base[GRP_MAX]; /* the bin's LUT (or its shards) */
+	u64 *tally[GRP_MAX];    /* [CP_SHARDS][4] */
+	u64 *out_bytes[GRP_MAX];
+	u64 *status[GRP_MAX];
+};
+struct GrpFold {
+	const u64 *tally[GRP_MAX];
+	u64 *stats[GRP_MAX];
+	u64 n[GRP_MAX];
+	const u64 *lut_base[GRP_MAX];
+	u64 *lut_out[GRP_MAX];
+};
+/* bin of work item `item` (wave-uniform) */
+__device__ __forceinline__ u32 grp_find(const u32 (&prefix)[GRP_MAX + 1], u32 g, u32 item)
+{
+	u32 b = 0;
+	while (b + 1 < g && item >= prefix[b + 1])
+		++b;
+	return b;
+}
+
 /* ------------------------------------------------------------------------------------------------ tracing (tuning builds only)
  * -DKMC_TRACE: thread 0 of sampled tiles stamps s_memtime at phase boundaries into g_trace (8 u64 per tile). */
 #ifdef KMC_TRACE
@@ -311,8 +357,7 @@ constexpr int PARSE_CHUNK = 4096, PARSE_SUB = 128, PARSE_NSUB = PARSE_CHUNK / PA
 constexpr int PARSE_CAND = PARSE_CAND_POS;
 static_assert(PARSE_CAND % 8 == 0 && PARSE_CAND >= 8 && PARSE_CAND <= PARSE_SUB, "PARSE_CAND");
 
-__global__ void __launch_bounds__(256) k_parse_packs(const uint8_t *__restrict__ data, const u64 *__restrict__ pack_start, u32 n_packs, u32 k,
-                                                      u32 *__restrict__ bitmap, u32 *err)
+__global__ void __launch_bounds__(256) k_parse_packs(const GrpParse gp, u32 k, u32 *err)
 {
 	/* Three levels per PARSE_CHUNK bytes staged in LDS (the chain has <= chunk/Lmin hops; walking it serially costs one
 	 * dependent load per hop):
@@ -327,10 +372,13 @@ __global__ void __launch_bounds__(256) k_parse_packs(const uint8_t *__restrict__
 	__shared__ u32 s_vis[PARSE_CHUNK / 32];
 	__shared__ u32 s_exit;
 	const u32 tid = threadIdx.x;
-	const u32 p = blockIdx.x;
-	if (p >= n_packs)
+	if (blockIdx.x >= gp.pack_prefix[gp.g])
 		return;
-	const u64 pos0 = pack_start[p], end = pack_start[p + 1];
+	const u32 bin = grp_find(gp.pack_prefix, gp.g, blockIdx.x);
+	const u32 p = blockIdx.x - gp.pack_prefix[bin];
+	const uint8_t *__restrict__ data = gp.data[bin];
+	u32 *__restrict__ bitmap = gp.bitmap[bin];
+	const u64 pos0 = gp.pack_start[bin][p], end = gp.pack_start[bin][p + 1];
 	/* Chunks are cut at multiples of PARSE_CHUNK of the IMAGE (not of the pack), and the first one starts at the 16-byte boundary
 	 * below the pack start: every chunk is staged with one aligned 16-byte load per thread (byte loads cost 16 instructions per
 	 * thread and chunk). The few bytes in front of the pack are never visited: the chain starts at `entry`. */
@@ -491,14 +539,13 @@ __host__ __device__ constexpr u32 exp_max_sk(u32 k) { return (u32)EXP_CHUNK / (1
 
 static_assert(EXP_CHUNK / 32 <= EXP_BLOCK && EXP_CHUNK <= 65536, "one bitmap word per thread; 16-bit positions inside a slice");
 template <int SIZE, bool FUSE_HIST>
-__global__ void __launch_bounds__(EXP_BLOCK) k_expand(const uint8_t *__restrict__ data, u64 size, const u32 *__restrict__ bitmap, u32 k,
-                                                 u32 both_strands, u32 n_pass, u64 n_rec, u64 *__restrict__ out, u64 *__restrict__ ghist,
-                                                 u64 *status, u32 *ticket_ctr, u32 n_chunks, u32 *err, u64 *__restrict__ digit_base,
-                                                 u32 *done_ctr, u64 tag)
+__global__ void __launch_bounds__(EXP_BLOCK) k_expand(const GrpExpand ge, u32 k, u32 both_strands, u32 n_pass, u64 *__restrict__ ghist, u32 *ticket_ctr,
+                                                 u32 *err, u64 *__restrict__ digit_base, u32 *done_ctr)
 {
-	/* `tag`: OR-ed into the record word that holds bit 2k — the spare bits of the top radix digit (8 ceil(k/4) - 2k of them). Several bins
-	 * expanded into one record array with tags 0, 1, 2 ... are sorted by ONE set of passes into bin-major order (kmc_hip.hip, grouped bins);
-	 * 0 for a bin on its own. */
+	/* The slices of all bins of the group form one ticket space. ge.tag[bin] is OR-ed into the record word that holds bit 2k — the spare
+	 * bits of the top radix digit (8 ceil(k/4) - 2k of them): bins expanded into one record array with tags 0, 1, 2 ... are sorted by ONE set
+	 * of passes into bin-major order (kmc_hip.hip run_group_device_t); 0 for a bin on its own. */
+	const u32 n_chunks = ge.chunk_prefix[ge.g];
 	const u32 MAX_SK = exp_max_sk(k);
 	KMC_DYN_LDS(unsigned char, s_raw);
 	u64 *s_base = reinterpret_cast<u64 *>(s_raw);                             /* [2] (16 bytes keeps s_b 16-B aligned) */
@@ -519,9 +566,17 @@ __global__ void __launch_bounds__(EXP_BLOCK) k_expand(const uint8_t *__restrict_
 		if (threadIdx.x == 0)
 			s_ticket[0] = atomicAdd(ticket_ctr, 1u);
 		__syncthreads();
-		const u32 c = s_ticket[0];
-		if (c >= n_chunks)
+		const u32 cg = s_ticket[0];
+		if (cg >= n_chunks)
 			break;
+		const u32 bin = (u32)__builtin_amdgcn_readfirstlane((int)grp_find(ge.chunk_prefix, ge.g, cg));
+		const u32 c = cg - ge.chunk_prefix[bin];                 /* slice of the bin */
+		const u32 bin_chunks = ge.chunk_prefix[bin + 1] - ge.chunk_prefix[bin];
+		const uint8_t *__restrict__ data = ge.data[bin];
+		const u32 *__restrict__ bitmap = ge.bitmap[bin];
+		const u64 size = ge.size[bin], n_rec = ge.n_rec[bin], tag = ge.tag[bin];
+		u64 *__restrict__ out = ge.out[bin];
+		u64 *status = ge.status[bin];
 		u32 tid = threadIdx.x;
 		KMC_LAUNDER(tid);
 		const u32 lane = tid & 63, wave = tid >> 6;
@@ -568,7 +623,7 @@ __global__ void __launch_bounds__(EXP_BLOCK) k_expand(const uint8_t *__restrict_
 			const u64 excl = lookback64(status, c, (u64)tot_k, lane, err, KERR_WATCHDOG);
 			if (lane == 0) {
 				*s_base = excl;
-				if (c == n_chunks - 1 && excl + tot_k != n_rec)
+				if (c == bin_chunks - 1 && excl + tot_k != n_rec)
 					atomicOr(err, KERR_NREC); /* CBinDesc n_rec must agree with the byte stream */
 			}
 		}
@@ -1117,10 +1172,8 @@ constexpr int CP_SHARDS = 32; /* tally shards: same-address device atomics seria
 static_assert(CP_TPB == 1, "one compaction tile per workgroup");
 
 template <int SIZE>
-__global__ void __launch_bounds__(CP_BLOCK, CpCfg<SIZE>::MIN_WAVES) k_compact(const u64 *__restrict__ S, u64 n, DevParams P, uint8_t *__restrict__ out,
-                                                       u64 out_capacity, u64 *__restrict__ lut_base, u32 lut_shards, u64 lut_stride,
-                                                       u64 *stat_shards /* [CP_SHARDS][4] */, u64 *out_bytes, u64 *status, u32 *tile_counter,
-                                                       u32 num_tiles, u32 *err, u32 lut_mask /* 4^p - 1: drops a group tag above the k-mer */)
+__global__ void __launch_bounds__(CP_BLOCK, CpCfg<SIZE>::MIN_WAVES) k_compact(const GrpCompact gc, DevParams P, u32 lut_shards, u64 lut_stride, u32 *tile_counter,
+                                                                               u32 *err, u32 lut_mask /* 4^p - 1: drops a group tag above the k-mer */)
 {
 	constexpr int ROWS = CpCfg<SIZE>::ITEMS;
 	constexpr int TILE = CpCfg<SIZE>::TILE;
@@ -1135,14 +1188,27 @@ __global__ void __launch_bounds__(CP_BLOCK, CpCfg<SIZE>::MIN_WAVES) k_compact(co
 	__shared__ u64 s_tile_off;
 
 #if CP_TILE_FROM_BLOCKIDX
-	const u32 tile = blockIdx.x; /* see RS_TILE_FROM_BLOCKIDX */
+	const u32 gtile = blockIdx.x; /* see RS_TILE_FROM_BLOCKIDX */
 	(void)tile_counter;
 #else
 	if (threadIdx.x == 0)
 		s_tile = atomicAdd(tile_counter, 1u);
 	__syncthreads();
-	const u32 tile = (u32)__builtin_amdgcn_readfirstlane((int)s_tile);
+	const u32 gtile = (u32)__builtin_amdgcn_readfirstlane((int)s_tile);
 #endif
+	/* the tiles of all bins of the group form one ticket space; everything below is about ONE bin */
+	const u32 total_tiles = gc.tile_prefix[gc.g];
+	const u32 bin = gtile < total_tiles ? (u32)__builtin_amdgcn_readfirstlane((int)grp_find(gc.tile_prefix, gc.g, gtile)) : 0;
+	const u32 tile = gtile - gc.tile_prefix[bin];
+	const u32 num_tiles = gtile < total_tiles ? gc.tile_prefix[bin + 1] - gc.tile_prefix[bin] : 0; /* 0: no tile for this workgroup */
+	const u64 *__restrict__ S = gc.S[bin];
+	const u64 n = gc.n[bin];
+	uint8_t *__restrict__ out = gc.out[bin];
+	const u64 out_capacity = gc.out_capacity[bin];
+	u64 *__restrict__ lut_base = gc.lut_base[bin];
+	u64 *stat_shards = gc.tally[bin];
+	u64 *out_bytes = gc.out_bytes[bin];
+	u64 *status = gc.status[bin];
 	const u32 rec_bytes = P.sbytes + P.cbytes;
 	const bool use_lut = P.lut_prefix_len != 0 && !P.kff && !P.without_output;
 
@@ -1465,9 +1531,13 @@ __global__ void __launch_bounds__(CP_BLOCK, CpCfg<SIZE>::MIN_WAVES) k_compact(co
  * caller's LUT. One small workgroup after the compaction. (Rounds 2a-2b had the compaction's last workgroup do this: every tile then ended
  * with "wait for my atomics, count myself in, barrier" — ~4 us during which the workgroup's registers and LDS sat idle; with ~12 rounds of
  * tiles per CU and bin that cost more than this launch does.) */
-__global__ void __launch_bounds__(256) k_compact_fold(const u64 *__restrict__ stat_shards, u64 *__restrict__ stats, u64 n, const u64 *__restrict__ lut_base,
-                                                       u32 lut_shards, u64 lut_stride, u64 *__restrict__ lut_out)
+__global__ void __launch_bounds__(256) k_compact_fold(const GrpFold gf, u32 lut_shards, u64 lut_stride)
 {
+	const u32 bin = blockIdx.x; /* one workgroup per bin of the group */
+	const u64 *__restrict__ stat_shards = gf.tally[bin];
+	u64 *__restrict__ stats = gf.stats[bin];
+	const u64 *__restrict__ lut_base = gf.lut_base[bin];
+	u64 *__restrict__ lut_out = gf.lut_out[bin];
 	if (threadIdx.x < 64) {
 		const u32 lane = threadIdx.x;
 		for (int j = 0; j < 3; ++j) {
@@ -1477,7 +1547,7 @@ __global__ void __launch_bounds__(256) k_compact_fold(const u64 *__restrict__ st
 				stats[j] = v;
 		}
 		if (lane == 0)
-			stats[3] = n;
+			stats[3] = gf.n[bin];
 	}
 	if (lut_shards > 1) { /* <= 8 K loads (kmc_hip.hip lut_shards_for), 8 in flight per thread */
 		for (u64 i = threadIdx.x; i < lut_stride; i += 256) {

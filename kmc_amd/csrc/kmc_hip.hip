@@ -101,7 +101,7 @@ struct HostRes {
  * per run the host launch rate is what binds): start bitmap | expand look-back words | digit histograms | compaction
  * look-back words | one scatter status area per onesweep launch. Offsets are 256-byte aligned. */
 struct ZeroPlan {
-	size_t bitmap = 0, exp_status = 0, ghist = 0, cp_status = 0, lutsh = 0, sc_status = 0, sc_stride = 0, total = 0;
+	size_t ghist = 0, sc_status = 0, sc_stride = 0, total = 0; /* the per-bin parts are in BinPlan */
 };
 inline size_t up256(size_t x) { return (x + 255) & ~(size_t)255; }
 
@@ -266,30 +266,48 @@ int read_and_clear_sticky(Slot &s, u32 &err)
  * The shards are summed by the compaction's last workgroup, so shards x entries stays small (<= 8 K loads). */
 u32 lut_shards_for(u64 lut_entries) { return lut_entries <= 256 ? 32u : (lut_entries <= 1024 ? 8u : 1u); }
 
+/* one bin's share of a group (a bin on its own is a group of one): its buffers and where it sits in the zero region and the shared arrays */
+struct BinPlan {
+	const uint8_t *d_in = nullptr;
+	u64 size = 0, n_rec = 0, n_packs = 0;
+	const u64 *d_pack_start = nullptr;
+	uint8_t *d_out = nullptr;
+	u64 out_capacity = 0;
+	u64 *d_out_bytes = nullptr, *d_lut = nullptr, *d_stats = nullptr;
+	size_t off_bitmap = 0, off_exp_status = 0, off_cp_status = 0, off_lutsh = 0, off_tally = 0;
+	u64 rec_off = 0; /* first record of the bin in the group's record arrays */
+};
+
+/* lays out the zero region of a group: small block | per bin: bitmap, expand look-back words, compaction look-back words, LUT shards, tally
+ * shards | digit histograms | one scatter status area per onesweep launch over the group's `n_total` records */
 template <int SIZE>
-ZeroPlan make_plan(const Slot &s, u64 size, u64 n_rec, u32 n_pass, bool front, bool sort, bool compact, u64 lut_shard_entries = 0)
+ZeroPlan plan_group(const Slot &s, std::vector<BinPlan> &bins, u64 n_total, u32 n_pass, bool front, bool sort, bool compact, u64 lut_shard_entries)
 {
 	ZeroPlan z;
-	size_t off = up256(SM_BYTES); /* the small block comes first */
-	if (front) {
-		z.bitmap = off;
-		off += up256(((size + 31) / 32 + 2) * 4);
-		z.exp_status = off;
-		off += up256(((size + EXP_CHUNK - 1) / EXP_CHUNK) * 8 + 8);
+	size_t off = up256(SM_BYTES);
+	for (BinPlan &b : bins) {
+		if (front) {
+			b.off_bitmap = off;
+			off += up256(((b.size + 31) / 32 + 2) * 4);
+			b.off_exp_status = off;
+			off += up256(((b.size + EXP_CHUNK - 1) / EXP_CHUNK) * 8 + 8);
+		}
+		if (compact) {
+			b.off_cp_status = off;
+			off += up256(((b.n_rec + CpCfg<SIZE>::TILE - 1) / CpCfg<SIZE>::TILE) * 8 + 8);
+			b.off_lutsh = off;
+			off += up256(lut_shard_entries * 8); /* n_shards x entries when the LUT is sharded */
+			b.off_tally = off;
+			off += up256(CP_SHARDS * 4 * 8);
+		}
 	}
 	if (front || sort) {
 		z.ghist = off;
 		off += up256((size_t)n_pass * 256 * 8);
 	}
-	if (compact) {
-		z.cp_status = off;
-		off += up256(((n_rec + CpCfg<SIZE>::TILE - 1) / CpCfg<SIZE>::TILE) * 8 + 8);
-		z.lutsh = off;
-		off += up256(lut_shard_entries * 8); /* n_shards x entries when the LUT is sharded */
-	}
-	if (sort && n_rec >= 2) {
-		const u64 max_tiles = (std::min(n_rec, s.portion) + RsCfg<SIZE>::TILE - 1) / RsCfg<SIZE>::TILE;
-		const u64 n_launch = (u64)n_pass * ((n_rec + s.portion - 1) / s.portion);
+	if (sort && n_total >= 2) {
+		const u64 max_tiles = (std::min(n_total, s.portion) + RsCfg<SIZE>::TILE - 1) / RsCfg<SIZE>::TILE;
+		const u64 n_launch = (u64)n_pass * ((n_total + s.portion - 1) / s.portion);
 		z.sc_status = off;
 		z.sc_stride = up256((size_t)max_tiles * 256 * 4);
 		off += z.sc_stride * n_launch;
@@ -366,7 +384,8 @@ int sort_device_t(Slot &s, const ZeroPlan &z, u64 *d_recs, u64 *d_tmp, u64 n, u3
 
 template <int SIZE> int sort_only_t(Slot &s, u64 *d_recs, u64 *d_tmp, u64 n, u32 n_pass, u64 **d_result)
 {
-	const ZeroPlan z = make_plan<SIZE>(s, 0, n, n_pass, false, true, false);
+	std::vector<BinPlan> none;
+	const ZeroPlan z = plan_group<SIZE>(s, none, n, n_pass, false, true, false, 0);
 	if (int rc = apply_plan(s, z))
 		return rc;
 	u32 counter_idx = 0;
@@ -415,35 +434,58 @@ int check_params(const kmc_hip_bin_params *p, DevParams &P)
 	return 0;
 }
 
-/* ---- front end: mark super-k-mer starts (per pack), then expand slice-parallel with the sort's histograms fused in ---- */
+/* ---- front end of a group: mark super-k-mer starts (one workgroup per pack of any bin), then expand slice-parallel (one ticket space over
+ * the slices of all bins) with the sort's histograms fused in; the last workgroup turns the histograms into digit bases ---- */
 template <int SIZE>
-int front_end(Slot &s, size_t off_bitmap, size_t off_exp_status, size_t off_ghist, const DevParams &P, const uint8_t *d_in, u64 size, u64 n_rec,
-              const u64 *d_pack_start, u64 n_packs, u32 n_pass, u32 &counter_idx, bool &hist_done, u64 *d_recs, u64 tag, bool fuse)
+int front_end_group(Slot &s, const std::vector<BinPlan> &bins, size_t off_ghist, const DevParams &P, u32 n_pass, u32 &counter_idx, bool &hist_done,
+                    u64 *d_recs, bool fuse)
 {
+	if (bins.empty())
+		return 0;
+	if (bins.size() > (size_t)GRP_MAX)
+		return fail(KMC_HIP_EINVAL, "group too large");
 	u32 *err = err_ptr(s);
 	u32 *counters = small_ptr<u32>(s, SM_COUNTERS);
-	const u64 n_chunks = (size + EXP_CHUNK - 1) / EXP_CHUNK;
-	if (n_chunks > 0x7FFFFFF0ull || n_packs > 0x7FFFFFF0ull)
-		return fail(KMC_HIP_EINVAL, "bin too large");
 	if (counter_idx + 2 > N_COUNTERS)
 		return fail(KMC_HIP_EINVAL, "too many launches for one bin");
-	u32 *bitmap = zero_ptr<u32>(s, off_bitmap);
-	u64 *status = zero_ptr<u64>(s, off_exp_status);
+	GrpParse gp = {};
+	GrpExpand ge = {};
+	gp.g = ge.g = (u32)bins.size();
+	u64 packs = 0, chunks = 0;
+	const u32 tag_shift = (2 * P.k) & 63;
+	for (size_t i = 0; i < bins.size(); ++i) {
+		const BinPlan &b = bins[i];
+		gp.pack_prefix[i] = (u32)packs;
+		ge.chunk_prefix[i] = (u32)chunks;
+		packs += b.n_packs;
+		chunks += (b.size + EXP_CHUNK - 1) / EXP_CHUNK;
+		if (packs > 0x7FFFFFF0ull || chunks > 0x7FFFFFF0ull)
+			return fail(KMC_HIP_EINVAL, "bin too large");
+		gp.data[i] = ge.data[i] = b.d_in;
+		gp.pack_start[i] = b.d_pack_start;
+		gp.bitmap[i] = zero_ptr<u32>(s, b.off_bitmap);
+		ge.bitmap[i] = gp.bitmap[i];
+		ge.size[i] = b.size;
+		ge.n_rec[i] = b.n_rec;
+		ge.out[i] = d_recs + b.rec_off * SIZE;
+		ge.status[i] = zero_ptr<u64>(s, b.off_exp_status);
+		ge.tag[i] = (u64)i << tag_shift; /* 0 for a group of one */
+	}
+	gp.pack_prefix[bins.size()] = (u32)packs;
+	ge.chunk_prefix[bins.size()] = (u32)chunks;
 	u64 *ghist = zero_ptr<u64>(s, off_ghist);
-	k_parse_packs<<<dim3((u32)n_packs), dim3(256), 0, s.stream>>>(d_in, d_pack_start, (u32)n_packs, P.k, bitmap, err);
+	k_parse_packs<<<dim3((u32)packs), dim3(256), 0, s.stream>>>(gp, P.k, err);
 	if (s.timed)
 		HIPCHK(hipEventRecord(s.ev[1], s.stream));
-	const u32 blocks = (u32)std::min<u64>(n_chunks, 256 * 4 * (512 / EXP_BLOCK)); /* persistent workgroups, up to 4 per CU */
+	const u32 blocks = (u32)std::min<u64>(chunks, 256 * 4 * (512 / EXP_BLOCK)); /* persistent workgroups, up to 4 per CU */
 	if (fuse) { /* LDS: 1 KB of counters per pass next to the slice state */
 		if (int rc = ensure(s.dbase, (size_t)n_pass * 256 * 8))
 			return rc;
 		k_expand<SIZE, true><<<dim3(blocks), dim3(EXP_BLOCK), exp_lds_bytes<true>(n_pass, P.k), s.stream>>>(
-		    d_in, size, bitmap, P.k, P.both_strands, n_pass, n_rec, d_recs, ghist, status, counters + counter_idx, (u32)n_chunks, err,
-		    (u64 *)s.dbase.p, counters + counter_idx + 1, tag);
+		    ge, P.k, P.both_strands, n_pass, ghist, counters + counter_idx, err, (u64 *)s.dbase.p, counters + counter_idx + 1);
 	} else
 		k_expand<SIZE, false><<<dim3(blocks), dim3(EXP_BLOCK), exp_lds_bytes<false>(n_pass, P.k), s.stream>>>(
-		    d_in, size, bitmap, P.k, P.both_strands, n_pass, n_rec, d_recs, ghist, status, counters + counter_idx, (u32)n_chunks, err,
-		    nullptr, counters + counter_idx + 1, tag);
+		    ge, P.k, P.both_strands, n_pass, ghist, counters + counter_idx, err, nullptr, counters + counter_idx + 1);
 	counter_idx += 2;
 	hist_done = fuse;
 	if (s.timed)
@@ -452,131 +494,68 @@ int front_end(Slot &s, size_t off_bitmap, size_t off_exp_status, size_t off_ghis
 	return 0;
 }
 
-/* ---- compaction launch + the fold of tally / LUT shards (one small workgroup) ---- */
+/* ---- compaction of a group (one ticket space over the tiles of all bins, each bin on its slice of the sorted array) + the fold of tally /
+ * LUT shards (one small workgroup per bin) ---- */
 template <int SIZE>
-int launch_compact(Slot &s, size_t off_cp_status, size_t off_lutsh, const u64 *sorted, u64 n, const DevParams &P, uint8_t *d_out, u64 out_capacity,
-                   u64 *d_lut, u64 lut_entries, u64 *d_stats, u64 *d_out_bytes, u32 &counter_idx, u64 *tally_shards)
+int compact_group(Slot &s, const std::vector<BinPlan> &bins, const u64 *sorted, const DevParams &P, u64 lut_entries, u32 &counter_idx)
 {
+	if (bins.empty())
+		return 0;
 	u32 *err = err_ptr(s);
 	u32 *counters = small_ptr<u32>(s, SM_COUNTERS);
-	const u64 c_tiles = (n + CpCfg<SIZE>::TILE - 1) / CpCfg<SIZE>::TILE;
-	if (c_tiles > 0x7FFFFFFFull)
-		return fail(KMC_HIP_EINVAL, "bin too large");
 	if (counter_idx >= N_COUNTERS)
 		return fail(KMC_HIP_EINVAL, "too many launches for one bin");
 	const bool use_lut = lut_entries && !P.without_output && !P.kff;
 	const u32 n_sh = !use_lut ? 1u : lut_shards_for(lut_entries);
-	u64 *lut_base = d_lut;
-	if (use_lut && n_sh > 1)
-		lut_base = zero_ptr<u64>(s, off_lutsh); /* zeroed with the rest of the zero region */
-	else if (use_lut)
-		HIPCHK(hipMemsetAsync(d_lut, 0, lut_entries * 8, s.stream));
-	k_compact<SIZE><<<dim3((u32)c_tiles), dim3(CP_BLOCK), 0, s.stream>>>(sorted, n, P, d_out, out_capacity, lut_base, n_sh, lut_entries, tally_shards, d_out_bytes,
-	                                                                       zero_ptr<u64>(s, off_cp_status), counters + counter_idx, (u32)c_tiles, err,
-	                                                                       P.lut_prefix_len ? (u32)((1ull << (2 * P.lut_prefix_len)) - 1) : 0u);
+	GrpCompact gc = {};
+	GrpFold gf = {};
+	gc.g = (u32)bins.size();
+	u64 tiles = 0;
+	for (size_t i = 0; i < bins.size(); ++i) {
+		const BinPlan &b = bins[i];
+		gc.tile_prefix[i] = (u32)tiles;
+		tiles += (b.n_rec + CpCfg<SIZE>::TILE - 1) / CpCfg<SIZE>::TILE;
+		if (tiles > 0x7FFFFFFFull)
+			return fail(KMC_HIP_EINVAL, "bin too large");
+		u64 *lut_base = b.d_lut;
+		if (use_lut && n_sh > 1)
+			lut_base = zero_ptr<u64>(s, b.off_lutsh); /* zeroed with the rest of the zero region */
+		else if (use_lut)
+			HIPCHK(hipMemsetAsync(b.d_lut, 0, lut_entries * 8, s.stream));
+		gc.S[i] = sorted + b.rec_off * SIZE;
+		gc.n[i] = gf.n[i] = b.n_rec;
+		gc.out[i] = b.d_out;
+		gc.out_capacity[i] = b.out_capacity;
+		gc.lut_base[i] = lut_base;
+		gc.tally[i] = zero_ptr<u64>(s, b.off_tally);
+		gc.out_bytes[i] = b.d_out_bytes;
+		gc.status[i] = zero_ptr<u64>(s, b.off_cp_status);
+		gf.tally[i] = gc.tally[i];
+		gf.stats[i] = b.d_stats;
+		gf.lut_base[i] = lut_base;
+		gf.lut_out[i] = b.d_lut;
+	}
+	gc.tile_prefix[bins.size()] = (u32)tiles;
+	k_compact<SIZE><<<dim3((u32)tiles), dim3(CP_BLOCK), 0, s.stream>>>(gc, P, n_sh, lut_entries, counters + counter_idx, err,
+	                                                                   P.lut_prefix_len ? (u32)((1ull << (2 * P.lut_prefix_len)) - 1) : 0u);
 	counter_idx += 1;
-	/* tally shards -> d_stats, LUT shards -> d_lut */
-	k_compact_fold<<<dim3(1), dim3(256), 0, s.stream>>>(tally_shards, d_stats, n, lut_base, use_lut ? n_sh : 1u, lut_entries, d_lut);
+	k_compact_fold<<<dim3((u32)bins.size()), dim3(256), 0, s.stream>>>(gf, use_lut ? n_sh : 1u, lut_entries);
 	HIPCHK(hipGetLastError());
 	return 0;
 }
 
-/* ---- one bin, everything device resident --------------------------------------------------------------------- */
-template <int SIZE>
-int run_bin_device_t(Slot &s, const DevParams &P, const uint8_t *d_in, u64 size, u64 n_rec, const u64 *d_pack_start,
-                     u64 n_packs, uint8_t *d_out, u64 out_capacity, u64 *d_out_bytes, u64 *d_lut, u64 lut_entries, u64 *d_stats)
-{
-	const u32 k = P.k;
-	const u32 n_pass = (2 * k + 7) / 8; /* = ceil(k/4) = rec_len of the plain k-mer path (kb_sorter.h:769) */
-	u32 counter_idx = 0;
-
-	if ((n_rec == 0) != (size == 0))
-		return fail(KMC_HIP_ECORRUPT, "exactly one of size / n_rec is zero");
-	/* d_stats / d_out_bytes == NULL: the slot's own small block (host-boundary path). Resolved only AFTER apply_plan: growing the
-	 * zero region moves the small block */
-	if (n_rec == 0) {
-		if (!d_stats)
-			d_stats = small_ptr<u64>(s, SM_STATS);
-		if (!d_out_bytes)
-			d_out_bytes = small_ptr<u64>(s, SM_OUTBYTES);
-		HIPCHK(hipMemsetAsync(d_stats, 0, 4 * 8, s.stream));
-		HIPCHK(hipMemsetAsync(d_out_bytes, 0, 8, s.stream));
-		if (lut_entries && !P.without_output)
-			HIPCHK(hipMemsetAsync(d_lut, 0, lut_entries * 8, s.stream));
-		if (s.timed)
-			for (int i = 0; i < 6; ++i)
-				HIPCHK(hipEventRecord(s.ev[i], s.stream));
-		return 0;
-	}
-	if (n_packs == 0 || n_packs > 0xFFFFFFF0ull)
-		return fail(KMC_HIP_EINVAL, "n_packs out of range");
-
-	int rc = 0;
-	if ((rc = ensure(s.recA, n_rec * SIZE * 8 + 256)) || (rc = ensure(s.recB, n_rec * SIZE * 8 + 256)))
-		return rc;
-	const bool use_lut = lut_entries && !P.without_output && !P.kff;
-	const u32 n_sh = use_lut ? lut_shards_for(lut_entries) : 1u;
-	const ZeroPlan z = make_plan<SIZE>(s, size, n_rec, n_pass, true, true, true, n_sh > 1 ? (u64)n_sh * lut_entries : 0);
-	if ((rc = apply_plan(s, z))) /* ONE memset per bin: small block, bitmap, look-back words, histograms, LUT shards, scatter status */
-		return rc;
-	if (!d_stats)
-		d_stats = small_ptr<u64>(s, SM_STATS);
-	if (!d_out_bytes)
-		d_out_bytes = small_ptr<u64>(s, SM_OUTBYTES);
-	if (s.timed)
-		HIPCHK(hipEventRecord(s.ev[0], s.stream));
-	bool hist_done = false;
-	if ((rc = front_end<SIZE>(s, z.bitmap, z.exp_status, z.ghist, P, d_in, size, n_rec, d_pack_start, n_packs, n_pass, counter_idx, hist_done, (u64 *)s.recA.p, 0,
-	                          n_pass <= EXP_FUSE_MAX_PASS && n_rec >= 2)))
-		return rc;
-	/* sort */
-	u64 *sorted = nullptr;
-	if ((rc = sort_device_t<SIZE>(s, z, (u64 *)s.recA.p, (u64 *)s.recB.p, n_rec, n_pass, &sorted, counter_idx, hist_done)))
-		return rc;
-	if (s.timed) {
-		if (n_rec < 2)
-			HIPCHK(hipEventRecord(s.ev[3], s.stream));
-		HIPCHK(hipEventRecord(s.ev[4], s.stream));
-	}
-	/* compact */
-	if ((rc = launch_compact<SIZE>(s, z.cp_status, z.lutsh, sorted, n_rec, P, d_out, out_capacity, d_lut, lut_entries, d_stats, d_out_bytes, counter_idx,
-	                               small_ptr<u64>(s, SM_SHARDS))))
-		return rc;
-	if (s.timed)
-		HIPCHK(hipEventRecord(s.ev[5], s.stream));
-	HIPCHK(hipGetLastError());
-	return 0;
-}
-
-int run_bin_device(Slot &s, const DevParams &P, const uint8_t *d_in, u64 size, u64 n_rec, const u64 *d_pack_start, u64 n_packs,
-                   uint8_t *d_out, u64 out_capacity, u64 *d_out_bytes, u64 *d_lut, u64 lut_entries, u64 *d_stats)
-{
-#define RUN(N) return run_bin_device_t<N>(s, P, d_in, size, n_rec, d_pack_start, n_packs, d_out, out_capacity, d_out_bytes, d_lut, lut_entries, d_stats)
-	switch ((P.k + 31) / 32) {
-	case 1: RUN(1);
-	case 2: RUN(2);
-	case 3: RUN(3);
-	case 4: RUN(4);
-	case 5: RUN(5);
-	case 6: RUN(6);
-	case 7: RUN(7);
-	case 8: RUN(8);
-	}
-#undef RUN
-	return fail(KMC_HIP_EINVAL, "kmer_len out of range");
-}
-
-/* ---- several bins through ONE sort ------------------------------------------------------------------------------
+/* ---- a group of bins, everything device resident -------------------------------------------------------------------
  * The top radix digit of a k-mer has 8 ceil(k/4) - 2k spare bits (2 at k = 27, 55, 127). Bins expanded into one record array with the bin's
  * number inside the group in those bits are put into bin-major order by the SAME number of passes one bin needs — as launches 2^spare times
- * as large (a 48 M-record launch runs at 0.46-0.47 of the HBM peak, a 190 M-record one at ~0.485: fewer ramps and drains per record) and
- * 2^spare times fewer of them. Front end and compaction stay per bin, on the bin's slice of the shared arrays. */
+ * as large (a 48 M-record launch runs at 0.46-0.47 of the HBM peak, a 190 M-record one at 0.51: fewer ramps and drains per record) and
+ * 2^spare times fewer of them. Parse, expand, compaction and fold are one launch each per group as well (kernels.hip.h Grp*). A bin on its
+ * own is a group of one. */
 u32 group_capacity(u32 k)
 {
 	static const int limit = [] {
 		const char *e = getenv("KMC_HIP_GROUP"); /* 1 = every bin on its own */
-		const int v = e ? atoi(e) : 16;
-		return v < 1 ? 1 : v;
+		const int v = e ? atoi(e) : GRP_MAX;
+		return v < 1 ? 1 : (v > GRP_MAX ? GRP_MAX : v);
 	}();
 	const u32 spare = 8 * ((2 * k + 7) / 8) - 2 * k;
 	const u32 cap = 1u << (spare > 4 ? 4 : spare);
@@ -584,113 +563,122 @@ u32 group_capacity(u32 k)
 }
 constexpr u64 GROUP_MAX_RECORD_BYTES = 6ull << 30; /* per record array of a group */
 
+/* d_stats / d_out_bytes == NULL in a descriptor (groups of one only): the slot's own small block (host-boundary path) */
 template <int SIZE>
-int run_group_device_t(Slot &s, const DevParams &P, const kmc_hip_bin_desc *const *bins, u32 g, u64 lut_entries)
+int run_group_device_t(Slot &s, const DevParams &P, const kmc_hip_bin_desc *const *descs, u32 g, u64 lut_entries)
 {
 	const u32 k = P.k;
-	const u32 n_pass = (2 * k + 7) / 8;
+	const u32 n_pass = (2 * k + 7) / 8; /* = ceil(k/4) = rec_len of the plain k-mer path (kb_sorter.h:769) */
 	const bool use_lut = lut_entries && !P.without_output && !P.kff;
 	const u32 n_sh = use_lut ? lut_shards_for(lut_entries) : 1u;
-	const bool fuse = n_pass <= EXP_FUSE_MAX_PASS;
+	std::vector<BinPlan> bins; /* the non-empty bins */
 	u64 N = 0;
-	std::vector<u64> rec_off(g);
-	struct Off {
-		size_t bitmap, exp_status, cp_status, lutsh, tally;
-	};
-	std::vector<Off> off(g);
-	size_t zoff = up256(SM_BYTES);
 	for (u32 i = 0; i < g; ++i) {
-		const kmc_hip_bin_desc &b = *bins[i];
-		if ((b.n_rec == 0) != (b.size == 0))
+		const kmc_hip_bin_desc &d = *descs[i];
+		if ((d.n_rec == 0) != (d.size == 0))
 			return fail(KMC_HIP_ECORRUPT, "exactly one of size / n_rec is zero");
-		if (b.n_rec && (b.n_packs == 0 || b.n_packs > 0xFFFFFFF0ull))
+		if (d.n_rec == 0)
+			continue;
+		if (d.n_packs == 0 || d.n_packs > 0xFFFFFFF0ull)
 			return fail(KMC_HIP_EINVAL, "n_packs out of range");
-		rec_off[i] = N;
-		N += b.n_rec;
-		off[i].bitmap = zoff;
-		zoff += up256(((b.size + 31) / 32 + 2) * 4);
-		off[i].exp_status = zoff;
-		zoff += up256(((b.size + EXP_CHUNK - 1) / EXP_CHUNK) * 8 + 8);
-		off[i].cp_status = zoff;
-		zoff += up256(((b.n_rec + CpCfg<SIZE>::TILE - 1) / CpCfg<SIZE>::TILE) * 8 + 8);
-		off[i].lutsh = zoff;
-		zoff += up256(n_sh > 1 ? (size_t)n_sh * lut_entries * 8 : 0);
-		off[i].tally = zoff;
-		zoff += up256(CP_SHARDS * 4 * 8);
+		BinPlan b;
+		b.d_in = d.d_superkmers;
+		b.size = d.size;
+		b.n_rec = d.n_rec;
+		b.n_packs = d.n_packs;
+		b.d_pack_start = (const u64 *)d.d_pack_start;
+		b.d_out = d.d_out;
+		b.out_capacity = d.out_capacity;
+		b.d_out_bytes = (u64 *)d.d_out_bytes;
+		b.d_lut = (u64 *)d.d_lut;
+		b.d_stats = (u64 *)d.d_stats;
+		b.rec_off = N;
+		N += d.n_rec;
+		bins.push_back(b);
 	}
-	ZeroPlan z;
-	z.ghist = zoff;
-	zoff += up256((size_t)n_pass * 256 * 8);
-	if (N >= 2) {
-		const u64 max_tiles = (std::min(N, s.portion) + RsCfg<SIZE>::TILE - 1) / RsCfg<SIZE>::TILE;
-		const u64 n_launch = (u64)n_pass * ((N + s.portion - 1) / s.portion);
-		z.sc_status = zoff;
-		z.sc_stride = up256((size_t)max_tiles * 256 * 4);
-		zoff += z.sc_stride * n_launch;
-	}
-	z.total = zoff;
+	/* the sort's histograms are fused into the expansion up to 16 passes (k <= 64); a bin on its own with a single record has nothing to sort */
+	const bool fuse = n_pass <= EXP_FUSE_MAX_PASS && N >= 2;
 	int rc = 0;
-	if ((rc = ensure(s.recA, N * SIZE * 8 + 256)) || (rc = ensure(s.recB, N * SIZE * 8 + 256)) || (rc = apply_plan(s, z)))
+	if (N && ((rc = ensure(s.recA, N * SIZE * 8 + 256)) || (rc = ensure(s.recB, N * SIZE * 8 + 256))))
 		return rc;
+	const ZeroPlan z = plan_group<SIZE>(s, bins, N, n_pass, true, true, true, n_sh > 1 ? (u64)n_sh * lut_entries : 0);
+	if ((rc = apply_plan(s, z))) /* ONE memset per group: small block, bitmaps, look-back words, histograms, LUT and tally shards, scatter status */
+		return rc;
+	for (BinPlan &b : bins) { /* resolved only AFTER apply_plan: growing the zero region moves the small block */
+		if (!b.d_stats)
+			b.d_stats = small_ptr<u64>(s, SM_STATS);
+		if (!b.d_out_bytes)
+			b.d_out_bytes = small_ptr<u64>(s, SM_OUTBYTES);
+	}
+	for (u32 i = 0; i < g; ++i) { /* empty bins: zero results, nothing else */
+		const kmc_hip_bin_desc &d = *descs[i];
+		if (d.n_rec)
+			continue;
+		u64 *st = d.d_stats ? (u64 *)d.d_stats : small_ptr<u64>(s, SM_STATS), *ob = d.d_out_bytes ? (u64 *)d.d_out_bytes : small_ptr<u64>(s, SM_OUTBYTES);
+		HIPCHK(hipMemsetAsync(st, 0, 4 * 8, s.stream));
+		HIPCHK(hipMemsetAsync(ob, 0, 8, s.stream));
+		if (lut_entries && !P.without_output)
+			HIPCHK(hipMemsetAsync(d.d_lut, 0, lut_entries * 8, s.stream));
+	}
 	if (s.timed)
 		HIPCHK(hipEventRecord(s.ev[0], s.stream));
 	u32 counter_idx = 0;
 	bool hist_done = false;
-	const u32 tag_shift = (2 * k) & 63;
-	for (u32 i = 0; i < g; ++i) {
-		const kmc_hip_bin_desc &b = *bins[i];
-		if (b.n_rec == 0) {
-			HIPCHK(hipMemsetAsync(b.d_stats, 0, 4 * 8, s.stream));
-			HIPCHK(hipMemsetAsync(b.d_out_bytes, 0, 8, s.stream));
-			if (lut_entries && !P.without_output)
-				HIPCHK(hipMemsetAsync(b.d_lut, 0, lut_entries * 8, s.stream));
-			continue;
-		}
-		if ((rc = front_end<SIZE>(s, off[i].bitmap, off[i].exp_status, z.ghist, P, b.d_superkmers, b.size, b.n_rec, (const u64 *)b.d_pack_start, b.n_packs, n_pass,
-		                          counter_idx, hist_done, (u64 *)s.recA.p + rec_off[i] * SIZE, (u64)i << tag_shift, fuse)))
-			return rc;
+	if ((rc = front_end_group<SIZE>(s, bins, z.ghist, P, n_pass, counter_idx, hist_done, (u64 *)s.recA.p, fuse)))
+		return rc;
+	if (s.timed && bins.empty()) {
+		HIPCHK(hipEventRecord(s.ev[1], s.stream));
+		HIPCHK(hipEventRecord(s.ev[2], s.stream));
 	}
 	u64 *sorted = (u64 *)s.recA.p;
-	if (N) {
-		if (!fuse)
-			hist_done = false; /* k > 64: one k_hist over the group's records */
-		if ((rc = sort_device_t<SIZE>(s, z, (u64 *)s.recA.p, (u64 *)s.recB.p, N, n_pass, &sorted, counter_idx, hist_done)))
-			return rc;
-	}
+	if (N && (rc = sort_device_t<SIZE>(s, z, (u64 *)s.recA.p, (u64 *)s.recB.p, N, n_pass, &sorted, counter_idx, hist_done)))
+		return rc;
 	if (s.timed) {
 		if (N < 2)
 			HIPCHK(hipEventRecord(s.ev[3], s.stream));
 		HIPCHK(hipEventRecord(s.ev[4], s.stream));
 	}
-	for (u32 i = 0; i < g; ++i) {
-		const kmc_hip_bin_desc &b = *bins[i];
-		if (b.n_rec == 0)
-			continue;
-		if ((rc = launch_compact<SIZE>(s, off[i].cp_status, off[i].lutsh, sorted + rec_off[i] * SIZE, b.n_rec, P, b.d_out, b.out_capacity, (u64 *)b.d_lut, lut_entries,
-		                               (u64 *)b.d_stats, (u64 *)b.d_out_bytes, counter_idx, zero_ptr<u64>(s, off[i].tally))))
-			return rc;
-	}
+	if ((rc = compact_group<SIZE>(s, bins, sorted, P, lut_entries, counter_idx)))
+		return rc;
 	if (s.timed)
 		HIPCHK(hipEventRecord(s.ev[5], s.stream));
 	HIPCHK(hipGetLastError());
 	return 0;
 }
 
-int run_group_device(Slot &s, const DevParams &P, const kmc_hip_bin_desc *const *bins, u32 g, u64 lut_entries)
+/* caller holds s.mtx and has set s.timed */
+int run_group_device(Slot &s, const DevParams &P, const kmc_hip_bin_desc *const *descs, u32 g, u64 lut_entries)
 {
-	std::lock_guard<std::mutex> lck(s.mtx);
-	s.timed = (s.async_seq++ % TIMING_SAMPLE) == 0;
 	switch ((P.k + 31) / 32) {
-	case 1: return run_group_device_t<1>(s, P, bins, g, lut_entries);
-	case 2: return run_group_device_t<2>(s, P, bins, g, lut_entries);
-	case 3: return run_group_device_t<3>(s, P, bins, g, lut_entries);
-	case 4: return run_group_device_t<4>(s, P, bins, g, lut_entries);
-	case 5: return run_group_device_t<5>(s, P, bins, g, lut_entries);
-	case 6: return run_group_device_t<6>(s, P, bins, g, lut_entries);
-	case 7: return run_group_device_t<7>(s, P, bins, g, lut_entries);
-	case 8: return run_group_device_t<8>(s, P, bins, g, lut_entries);
+	case 1: return run_group_device_t<1>(s, P, descs, g, lut_entries);
+	case 2: return run_group_device_t<2>(s, P, descs, g, lut_entries);
+	case 3: return run_group_device_t<3>(s, P, descs, g, lut_entries);
+	case 4: return run_group_device_t<4>(s, P, descs, g, lut_entries);
+	case 5: return run_group_device_t<5>(s, P, descs, g, lut_entries);
+	case 6: return run_group_device_t<6>(s, P, descs, g, lut_entries);
+	case 7: return run_group_device_t<7>(s, P, descs, g, lut_entries);
+	case 8: return run_group_device_t<8>(s, P, descs, g, lut_entries);
 	}
 	return fail(KMC_HIP_EINVAL, "kmer_len out of range");
+}
+
+/* one bin = a group of one */
+int run_bin_device(Slot &s, const DevParams &P, const uint8_t *d_in, u64 size, u64 n_rec, const u64 *d_pack_start, u64 n_packs, uint8_t *d_out,
+                   u64 out_capacity, u64 *d_out_bytes, u64 *d_lut, u64 lut_entries, u64 *d_stats)
+{
+	kmc_hip_bin_desc d;
+	d.d_superkmers = d_in;
+	d.size = size;
+	d.n_rec = n_rec;
+	d.d_pack_start = (const uint64_t *)d_pack_start;
+	d.n_packs = n_packs;
+	d.d_out = d_out;
+	d.out_capacity = out_capacity;
+	d.d_out_bytes = (uint64_t *)d_out_bytes;
+	d.d_lut = (uint64_t *)d_lut;
+	d.d_stats = (uint64_t *)d_stats;
+	const kmc_hip_bin_desc *p = &d;
+	return run_group_device(s, P, &p, 1, lut_entries);
 }
 
 int err_to_code(u32 err)
@@ -722,25 +710,36 @@ int debug_expand_t(Slot &s, const DevParams &P, u64 size, u64 n_rec, u64 np)
 	if ((rc = ensure(s.recA, n_rec * SIZE * 8 + 256)))
 		return rc;
 	const u32 n_pass = (2 * P.k + 7) / 8;
-	const ZeroPlan z = make_plan<SIZE>(s, size, n_rec, n_pass, true, false, false);
+	std::vector<BinPlan> bins(1);
+	bins[0].d_in = (const uint8_t *)s.in.p;
+	bins[0].size = size;
+	bins[0].n_rec = n_rec;
+	bins[0].n_packs = np;
+	bins[0].d_pack_start = (const u64 *)s.pack_start.p;
+	const ZeroPlan z = plan_group<SIZE>(s, bins, n_rec, n_pass, true, false, false, 0);
 	if ((rc = apply_plan(s, z)))
 		return rc;
 	u32 counter_idx = 0;
 	bool hist_done = false;
-	return front_end<SIZE>(s, z.bitmap, z.exp_status, z.ghist, P, (const uint8_t *)s.in.p, size, n_rec, (const u64 *)s.pack_start.p, np, n_pass, counter_idx, hist_done,
-	                       (u64 *)s.recA.p, 0, n_pass <= EXP_FUSE_MAX_PASS && n_rec >= 2);
+	return front_end_group<SIZE>(s, bins, z.ghist, P, n_pass, counter_idx, hist_done, (u64 *)s.recA.p, n_pass <= EXP_FUSE_MAX_PASS && n_rec >= 2);
 }
 template <int SIZE>
 int debug_compact_t(Slot &s, const DevParams &P, u64 n, u64 out_capacity, u64 lut_entries)
 {
 	const bool use_lut = lut_entries && !P.without_output && !P.kff;
 	const u32 n_sh = use_lut ? lut_shards_for(lut_entries) : 1u;
-	const ZeroPlan z = make_plan<SIZE>(s, 0, n, 0, false, false, true, n_sh > 1 ? (u64)n_sh * lut_entries : 0);
+	std::vector<BinPlan> bins(1);
+	bins[0].n_rec = n;
+	bins[0].d_out = (uint8_t *)s.out.p;
+	bins[0].out_capacity = out_capacity;
+	bins[0].d_lut = (u64 *)s.lut.p;
+	const ZeroPlan z = plan_group<SIZE>(s, bins, n, 0, false, false, true, n_sh > 1 ? (u64)n_sh * lut_entries : 0);
 	if (int rc = apply_plan(s, z))
 		return rc;
+	bins[0].d_stats = small_ptr<u64>(s, SM_STATS);
+	bins[0].d_out_bytes = small_ptr<u64>(s, SM_OUTBYTES);
 	u32 counter_idx = 0;
-	return launch_compact<SIZE>(s, z.cp_status, z.lutsh, (const u64 *)s.recA.p, n, P, (uint8_t *)s.out.p, out_capacity, (u64 *)s.lut.p, lut_entries,
-	                            small_ptr<u64>(s, SM_STATS), small_ptr<u64>(s, SM_OUTBYTES), counter_idx, small_ptr<u64>(s, SM_SHARDS));
+	return compact_group<SIZE>(s, bins, (const u64 *)s.recA.p, P, lut_entries, counter_idx);
 }
 } // namespace
 
@@ -1060,8 +1059,12 @@ int kmc_hip_process_bins_device(kmc_hip_ctx *ctx, int dev, const kmc_hip_bin_par
 				const kmc_hip_bin_desc &b = *grp[0];
 				rc = process_bin_device_on(ctx, dev, d.slot[t], P, lut_entries, b.d_superkmers, b.size, b.n_rec, b.d_pack_start, b.n_packs, b.d_out, b.out_capacity,
 				                           b.d_out_bytes, b.d_lut, b.d_stats, 0);
-			} else if (grp.size() > 1)
-				rc = run_group_device(d.slot[t], P, grp.data(), (u32)grp.size(), lut_entries);
+			} else if (grp.size() > 1) {
+				Slot &sl = d.slot[t];
+				std::lock_guard<std::mutex> lck(sl.mtx);
+				sl.timed = (sl.async_seq++ % TIMING_SAMPLE) == 0;
+				rc = run_group_device(sl, P, grp.data(), (u32)grp.size(), lut_entries);
+			}
 			grp.clear();
 			grp_recs = 0;
 			return rc;

@@ -24,7 +24,10 @@ def build(geometry="small", force=False) -> str:
     srcs = [os.path.join(EMU_DIR, "emu_kernels.cpp"), os.path.join(EMU_DIR, "include", "hip", "hip_runtime.h"),
             os.path.join(ROOT, "kmc_amd", "csrc", "kernels.hip.h"), os.path.join(ROOT, "kmc_amd", "csrc", "kmer_ops.h")]
     if force or not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in srcs):
-        subprocess.check_call(["g++", "-std=c++17", "-O1", "-g", "-fPIC", "-shared", "-pthread", "-w", *GEOMETRY_FLAGS[geometry],
+        # -fno-gnu-unique / hidden visibility / -Bsymbolic: the two geometries are two builds of the same templates; their static "LDS" arrays and
+        # inline variables must not be merged across the libraries when one process loads both
+        subprocess.check_call(["g++", "-std=c++17", "-O1", "-g", "-fPIC", "-shared", "-pthread", "-w", "-fno-gnu-unique", "-fvisibility=hidden",
+                               "-Wl,-Bsymbolic", *GEOMETRY_FLAGS[geometry],
                                "-I", os.path.join(EMU_DIR, "include"), srcs[0], "-o", so])
     return so
 

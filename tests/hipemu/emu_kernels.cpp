@@ -48,21 +48,31 @@ template <int SIZE> int expand_t(const DevParams &P, const uint8_t *img, u64 siz
 	/* the image needs 256 readable bytes of slack, like the device buffer */
 	std::vector<uint8_t> in(size + 512, 0);
 	memcpy(in.data(), img, size);
-	hipemu::launch(dim3((u32)n_packs), dim3(256), 0, [&] { k_parse_packs(in.data(), pack_start, (u32)n_packs, P.k, bitmap.data(), err); });
+	/* a group of one, as kmc_hip.hip front_end_group builds it */
+	GrpParse gp = {};
+	GrpExpand ge = {};
+	gp.g = ge.g = 1;
+	gp.pack_prefix[1] = (u32)n_packs;
+	ge.chunk_prefix[1] = (u32)n_chunks;
+	gp.data[0] = ge.data[0] = in.data();
+	gp.pack_start[0] = pack_start;
+	gp.bitmap[0] = bitmap.data();
+	ge.bitmap[0] = bitmap.data();
+	ge.size[0] = size;
+	ge.n_rec[0] = n_rec;
+	ge.out[0] = recs;
+	ge.status[0] = status.data();
+	hipemu::launch(dim3((u32)n_packs), dim3(256), 0, [&] { k_parse_packs(gp, P.k, err); });
 	if (getenv("KMC_EMU_VERBOSE"))
 		fprintf(stderr, "[emu] parse done, err %u\n", *err);
 	const bool fuse = n_pass <= EXP_FUSE_MAX_PASS && n_rec >= 2;
 	const u32 blocks = (u32)std::min<u64>(n_chunks, 4); /* persistent workgroups pulling slice tickets */
 	if (fuse)
-		hipemu::launch(dim3(blocks), dim3(EXP_BLOCK), exp_lds_bytes<true>(n_pass, P.k), [&] {
-			k_expand<SIZE, true>(in.data(), size, bitmap.data(), P.k, P.both_strands, n_pass, n_rec, recs, ghist.data(), status.data(), &counters[0],
-			                     (u32)n_chunks, err, dbase, &counters[1], 0ull);
-		});
+		hipemu::launch(dim3(blocks), dim3(EXP_BLOCK), exp_lds_bytes<true>(n_pass, P.k),
+		               [&] { k_expand<SIZE, true>(ge, P.k, P.both_strands, n_pass, ghist.data(), &counters[0], err, dbase, &counters[1]); });
 	else
-		hipemu::launch(dim3(blocks), dim3(EXP_BLOCK), exp_lds_bytes<false>(n_pass, P.k), [&] {
-			k_expand<SIZE, false>(in.data(), size, bitmap.data(), P.k, P.both_strands, n_pass, n_rec, recs, ghist.data(), status.data(), &counters[0],
-			                      (u32)n_chunks, err, nullptr, &counters[1], 0ull);
-		});
+		hipemu::launch(dim3(blocks), dim3(EXP_BLOCK), exp_lds_bytes<false>(n_pass, P.k),
+		               [&] { k_expand<SIZE, false>(ge, P.k, P.both_strands, n_pass, ghist.data(), &counters[0], err, nullptr, &counters[1]); });
 	return fuse ? 1 : 0;
 }
 
@@ -104,11 +114,26 @@ void compact_t(const DevParams &P, const u64 *sorted, u64 n, uint8_t *out, u64 o
 	else if (use_lut)
 		memset(lut, 0, lut_entries * 8);
 	u32 counter = 0;
+	GrpCompact gc = {};
+	GrpFold gf = {};
+	gc.g = 1;
+	gc.tile_prefix[1] = (u32)c_tiles;
+	gc.S[0] = sorted;
+	gc.n[0] = gf.n[0] = n;
+	gc.out[0] = out;
+	gc.out_capacity[0] = out_capacity;
+	gc.lut_base[0] = lut_base;
+	gc.tally[0] = shards.data();
+	gc.out_bytes[0] = out_bytes;
+	gc.status[0] = status.data();
+	gf.tally[0] = shards.data();
+	gf.stats[0] = stats;
+	gf.lut_base[0] = lut_base;
+	gf.lut_out[0] = lut;
 	hipemu::launch(dim3((u32)c_tiles), dim3(CP_BLOCK), 0, [&] {
-		k_compact<SIZE>(sorted, n, P, out, out_capacity, lut_base, n_sh, lut_entries, shards.data(), out_bytes, status.data(), &counter, (u32)c_tiles, err,
-		                P.lut_prefix_len ? (u32)((1ull << (2 * P.lut_prefix_len)) - 1) : 0u);
+		k_compact<SIZE>(gc, P, n_sh, lut_entries, &counter, err, P.lut_prefix_len ? (u32)((1ull << (2 * P.lut_prefix_len)) - 1) : 0u);
 	});
-	hipemu::launch(dim3(1), dim3(256), 0, [&] { k_compact_fold(shards.data(), stats, n, lut_base, use_lut ? n_sh : 1u, lut_entries, lut); });
+	hipemu::launch(dim3(1), dim3(256), 0, [&] { k_compact_fold(gf, use_lut ? n_sh : 1u, lut_entries); });
 }
 
 template <int SIZE>
@@ -137,10 +162,11 @@ int run_t(const Params &p, int stage_mask, const uint8_t *img, u64 size, u64 n_r
 } // namespace
 
 extern "C" {
+#define EMU_API __attribute__((visibility("default")))
 
 /* lookback64 on a prepared status array (no concurrency): returns the exclusive prefix wave 0 / lane 0 computes for `tile`; status[tile] is
  * overwritten with the inclusive prefix word */
-unsigned long long emu_lookback(u64 *status, unsigned tile, unsigned long long aggregate, unsigned *err)
+EMU_API unsigned long long emu_lookback(u64 *status, unsigned tile, unsigned long long aggregate, unsigned *err)
 {
 	u64 res = 0;
 	hipemu::launch(dim3(1), dim3(64), 0, [&] {
@@ -153,7 +179,7 @@ unsigned long long emu_lookback(u64 *status, unsigned tile, unsigned long long a
 
 /* stage_mask: 1 = parse + expand (image -> recs[0]), 2 = sort (recs[0] -> *sorted_index = 0 or 1: which half of `recs` holds the result),
  * 4 = compaction of the sorted half. `recs` = 2 x n_rec x words uint64. Returns the device error word. */
-int emu_run(const unsigned *params10, int stage_mask, const uint8_t *img, u64 size, u64 n_rec, const u64 *pack_start, u64 n_packs, u64 *recs,
+EMU_API int emu_run(const unsigned *params10, int stage_mask, const uint8_t *img, u64 size, u64 n_rec, const u64 *pack_start, u64 n_packs, u64 *recs,
             int *sorted_index, uint8_t *out, u64 out_capacity, u64 *out_bytes, u64 *lut, u64 *stats)
 {
 	Params p;
