@@ -550,17 +550,23 @@ int compact_group(Slot &s, const std::vector<BinPlan> &bins, const u64 *sorted, 
  * as large (a 48 M-record launch runs at 0.46-0.47 of the HBM peak, a 190 M-record one at 0.51: fewer ramps and drains per record) and
  * 2^spare times fewer of them. Parse, expand, compaction and fold are one launch each per group as well (kernels.hip.h Grp*). A bin on its
  * own is a group of one. */
-u32 group_capacity(u32 k)
+u32 group_capacity(u32 k, bool small_bins)
 {
 	static const int limit = [] {
 		const char *e = getenv("KMC_HIP_GROUP"); /* 1 = every bin on its own */
 		const int v = e ? atoi(e) : GRP_MAX;
 		return v < 1 ? 1 : (v > GRP_MAX ? GRP_MAX : v);
 	}();
-	const u32 spare = 8 * ((2 * k + 7) / 8) - 2 * k;
-	const u32 cap = 1u << (spare > 4 ? 4 : spare);
+	const u32 words = (k + 31) / 32;
+	const u32 spare = 8 * ((2 * k + 7) / 8) - 2 * k; /* bits of the top digit above the k-mer: tags that cost no pass */
+	const u32 room = 64 * words - 2 * k;             /* bits of the record above the k-mer */
+	/* Small bins are bound by launches, not by bytes: they are grouped GRP_MAX at a time even when the tag then needs a digit of its own
+	 * (one more pass over little data, and 3-4x fewer launches per bin). */
+	const u32 bits = small_bins ? (room > 4 ? 4 : room) : (spare > 4 ? 4 : spare);
+	const u32 cap = 1u << bits;
 	return cap < (u32)limit ? cap : (u32)limit;
 }
+constexpr u64 GROUP_SMALL_BIN_RECORDS = 4ull << 20; /* average records per bin below which bins count as small */
 constexpr u64 GROUP_MAX_RECORD_BYTES = 6ull << 30; /* per record array of a group */
 
 /* d_stats / d_out_bytes == NULL in a descriptor (groups of one only): the slot's own small block (host-boundary path) */
@@ -568,7 +574,6 @@ template <int SIZE>
 int run_group_device_t(Slot &s, const DevParams &P, const kmc_hip_bin_desc *const *descs, u32 g, u64 lut_entries)
 {
 	const u32 k = P.k;
-	const u32 n_pass = (2 * k + 7) / 8; /* = ceil(k/4) = rec_len of the plain k-mer path (kb_sorter.h:769) */
 	const bool use_lut = lut_entries && !P.without_output && !P.kff;
 	const u32 n_sh = use_lut ? lut_shards_for(lut_entries) : 1u;
 	std::vector<BinPlan> bins; /* the non-empty bins */
@@ -596,6 +601,14 @@ int run_group_device_t(Slot &s, const DevParams &P, const kmc_hip_bin_desc *cons
 		N += d.n_rec;
 		bins.push_back(b);
 	}
+	/* passes: ceil(k/4) = rec_len of the plain k-mer path (kb_sorter.h:769) — plus one when the group's tags do not fit the spare bits of
+	 * the top digit (groups of small bins, group_capacity) */
+	u32 tag_bits = 0;
+	while ((1u << tag_bits) < bins.size())
+		++tag_bits;
+	if (2 * k + tag_bits > 64u * SIZE)
+		return fail(KMC_HIP_EINVAL, "group too large for the record width");
+	const u32 n_pass = (2 * k + tag_bits + 7) / 8;
 	/* the sort's histograms are fused into the expansion up to 16 passes (k <= 64); a bin on its own with a single record has nothing to sort */
 	const bool fuse = n_pass <= EXP_FUSE_MAX_PASS && N >= 2;
 	int rc = 0;
@@ -1042,7 +1055,10 @@ int kmc_hip_process_bins_device(kmc_hip_ctx *ctx, int dev, const kmc_hip_bin_par
 	 * with hundreds of small bins a single submitting thread is the bottleneck, not the GPU). Big bins all take slot 0. */
 	std::vector<int> rcs((size_t)n_streams, 0);
 	std::vector<std::string> msgs((size_t)n_streams);
-	const u32 G = group_capacity(P.k);
+	u64 all_recs = 0;
+	for (uint64_t i = 0; i < n_bins; ++i)
+		all_recs += bins[i].n_rec;
+	const u32 G = group_capacity(P.k, n_bins && all_recs / n_bins < GROUP_SMALL_BIN_RECORDS);
 	const u64 rec_bytes_of = (u64)((P.k + 31) / 32) * 8;
 	auto work = [&](int t) {
 		if (hipSetDevice(d.ordinal) != hipSuccess) {
