@@ -67,13 +67,12 @@ int ensure(DBuf &b, size_t bytes)
 
 /* layout of the per-slot "small" device block (bytes): the first SM_BYTES of the slot's zero region, cleared with it at the start
  * of every bin */
-constexpr size_t SM_TOTALS = 0;      /* u64[2]  #super-k-mers, #k-mers   */
+/* bytes 0..15: unused */
 constexpr size_t SM_STATS = 16;      /* u64[4]                           */
 constexpr size_t SM_OUTBYTES = 48;   /* u64                              */
 constexpr size_t SM_ERR = 56;        /* u32: copy of the slot's sticky error word, taken when a host-boundary bin ends */
 constexpr size_t SM_DBASE_WORK = 256; /* u64[2][256] per-portion digit bases (ping-pong) */
-constexpr size_t SM_SHARDS = 256 + 2 * 256 * 8;   /* u64[CP_SHARDS][4] tally shards of the compaction */
-constexpr size_t SM_COUNTERS = SM_SHARDS + CP_SHARDS * 4 * 8; /* u32[N_COUNTERS] ticket counters, one per launch */
+constexpr size_t SM_COUNTERS = 256 + 2 * 256 * 8; /* u32[N_COUNTERS] ticket counters, one per launch (the tally shards of the compaction are per bin, BinPlan) */
 constexpr size_t N_COUNTERS = 4096;
 constexpr size_t SM_BYTES = SM_COUNTERS + N_COUNTERS * 4;
 
