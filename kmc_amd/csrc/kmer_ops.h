@@ -1,6 +1,6 @@
 /*
  * kmc_amd/csrc/kmer_ops.h — per-record arithmetic shared by every kernel (and compilable on the host
- * so tests/test_kmer_ops.py can check it bit-for-bit against the oracle without a GPU).
+ * so tests/test_oracle.py::test_kmer_ops_host_matches_oracle can check it bit for bit against the oracle without a GPU, and tests/hipemu can run the kernels on the CPU).
  *
  * Record = CKmer<SIZE> of the reference (kmc_core/kmer.h:22-67): SIZE x uint64, word 0 least
  * significant, k-mer right-aligned in the low 2k bits, first base in the most significant pair.

@@ -40,6 +40,10 @@ def lib(geometry="small"):
                               C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p]
         L.emu_lookback.restype = C.c_uint64
         L.emu_lookback.argtypes = [C.c_void_p, C.c_uint32, C.c_uint64, C.c_void_p]
+        L.emu_group_front.restype = C.c_int
+        L.emu_group_front.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32]
+        L.emu_group_compact.restype = C.c_int
+        L.emu_group_compact.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p]
         _LIBS[geometry] = L
     return _LIBS[geometry]
 
@@ -78,3 +82,39 @@ def run(p, stage_mask, img=None, n_rec=0, pack_bytes=None, recs=None, out_capaci
     err = lib(geometry).emu_run(pr.ctypes.data, stage_mask, img.ctypes.data if img.size else None, img.size, n_rec, ps.ctypes.data, ps.size - 1,
                         buf.ctypes.data, C.addressof(si), out.ctypes.data, cap, C.addressof(ob), lut.ctypes.data, stats.ctypes.data)
     return dict(err=err, recs=buf[0, :n_rec], sorted=buf[si.value, :n_rec], out=out[: ob.value].copy(), lut=lut[:lut_n].copy(), stats=stats)
+
+
+def _ptr_array(arrays):
+    return (C.c_void_p * len(arrays))(*[a.ctypes.data for a in arrays])
+
+
+def group_front(p, bins, n_pass, geometry="small"):
+    """bins: list of (image, n_rec, pack_bytes). Parse + expand of the whole group in one launch each. Returns (err, records [N, words])."""
+    words = (p.kmer_len + 31) // 32
+    imgs = [np.ascontiguousarray(b[0]) for b in bins]
+    sizes = np.array([b[0].size for b in bins], dtype=np.uint64)
+    nrec = np.array([b[1] for b in bins], dtype=np.uint64)
+    ps = [np.concatenate([[0], np.cumsum(b[2])]).astype(np.uint64) for b in bins]
+    npk = np.array([b[2].size for b in bins], dtype=np.uint64)
+    recs = np.zeros((int(nrec.sum()), words), dtype=np.uint64)
+    pr = _params(p)
+    err = lib(geometry).emu_group_front(pr.ctypes.data, len(bins), _ptr_array(imgs), sizes.ctypes.data, nrec.ctypes.data, _ptr_array(ps), npk.ctypes.data,
+                                        recs.ctypes.data, n_pass)
+    return err, recs
+
+
+def group_compact(p, sorted_recs, n_recs, geometry="small"):
+    """compaction + fold of a group on the bin-major sorted record array. Returns (err, [(out, lut, stats) per bin])."""
+    g = len(n_recs)
+    words = (p.kmer_len + 31) // 32
+    lut_n = (1 << (2 * p.lut_prefix_len)) if (p.lut_prefix_len and p.output_type == 0) else 0
+    cap = (max(n_recs) + 1) * (40 + 8 * words)
+    outs = [np.zeros(cap + 64, dtype=np.uint8) for _ in range(g)]
+    ob = np.zeros(g, dtype=np.uint64)
+    luts = np.zeros((g, max(lut_n, 1)), dtype=np.uint64)
+    stats = np.zeros((g, 4), dtype=np.uint64)
+    nr = np.array(n_recs, dtype=np.uint64)
+    srt = np.ascontiguousarray(sorted_recs)
+    pr = _params(p)
+    err = lib(geometry).emu_group_compact(pr.ctypes.data, g, srt.ctypes.data, nr.ctypes.data, _ptr_array(outs), cap, ob.ctypes.data, luts.ctypes.data, stats.ctypes.data)
+    return err, [(outs[i][: int(ob[i])].copy(), luts[i, :lut_n].copy(), stats[i].copy()) for i in range(g)]

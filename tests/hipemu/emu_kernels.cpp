@@ -159,6 +159,120 @@ int run_t(const Params &p, int stage_mask, const uint8_t *img, u64 size, u64 n_r
 	return 0;
 }
 
+/* ---- a group of bins, the way kmc_hip.hip front_end_group / compact_group build the descriptors ---- */
+template <int SIZE>
+int group_front_t(const DevParams &P, int g, const uint8_t *const *imgs, const u64 *sizes, const u64 *n_recs, const u64 *const *pack_starts, const u64 *n_packs,
+                  u64 *recs, u32 n_pass, u32 *err)
+{
+	GrpParse gp = {};
+	GrpExpand ge = {};
+	gp.g = ge.g = (u32)g;
+	std::vector<std::vector<uint8_t>> in(g);
+	std::vector<std::vector<u32>> bitmap(g);
+	std::vector<std::vector<u64>> status(g);
+	u64 packs = 0, chunks = 0, rec_off = 0;
+	const u32 tag_shift = (2 * P.k) & 63;
+	for (int i = 0; i < g; ++i) {
+		in[i].assign(sizes[i] + 512, 0);
+		memcpy(in[i].data(), imgs[i], sizes[i]);
+		bitmap[i].assign((sizes[i] + 31) / 32 + 2, 0);
+		const u64 nc = (sizes[i] + EXP_CHUNK - 1) / EXP_CHUNK;
+		status[i].assign(nc + 1, 0);
+		gp.pack_prefix[i] = (u32)packs;
+		ge.chunk_prefix[i] = (u32)chunks;
+		packs += n_packs[i];
+		chunks += nc;
+		gp.data[i] = ge.data[i] = in[i].data();
+		gp.pack_start[i] = pack_starts[i];
+		gp.bitmap[i] = bitmap[i].data();
+		ge.bitmap[i] = bitmap[i].data();
+		ge.size[i] = sizes[i];
+		ge.n_rec[i] = n_recs[i];
+		ge.out[i] = recs + rec_off * SIZE;
+		ge.status[i] = status[i].data();
+		ge.tag[i] = (u64)i << tag_shift;
+		rec_off += n_recs[i];
+	}
+	gp.pack_prefix[g] = (u32)packs;
+	ge.chunk_prefix[g] = (u32)chunks;
+	std::vector<u64> ghist((size_t)n_pass * 256, 0), dbase((size_t)n_pass * 256, 0);
+	u32 counters[2] = {0, 0};
+	hipemu::launch(dim3((u32)packs), dim3(256), 0, [&] { k_parse_packs(gp, P.k, err); });
+	const u32 blocks = (u32)std::min<u64>(chunks, 3);
+	hipemu::launch(dim3(blocks), dim3(EXP_BLOCK), exp_lds_bytes<true>(n_pass, P.k),
+	               [&] { k_expand<SIZE, true>(ge, P.k, P.both_strands, n_pass, ghist.data(), &counters[0], err, dbase.data(), &counters[1]); });
+	/* the fused histograms must cover every record of the group, tag included: digit totals == records */
+	for (u32 b = 0; b < n_pass; ++b) {
+		u64 tot = 0;
+		for (int d = 0; d < 256; ++d)
+			tot += ghist[(size_t)b * 256 + d];
+		if (tot != rec_off)
+			return -2;
+	}
+	return 0;
+}
+
+template <int SIZE>
+int group_compact_t(const DevParams &P, int g, const u64 *sorted, const u64 *n_recs, uint8_t *const *outs, u64 out_capacity, u64 *out_bytes, u64 *luts, u64 lut_entries,
+                    u64 *stats, u32 *err)
+{
+	const bool use_lut = lut_entries && !P.without_output && !P.kff;
+	const u32 n_sh = use_lut ? lut_shards_for(lut_entries) : 1u;
+	GrpCompact gc = {};
+	GrpFold gf = {};
+	gc.g = (u32)g;
+	std::vector<std::vector<u64>> lutsh(g), status(g), shards(g);
+	u64 tiles = 0, rec_off = 0;
+	for (int i = 0; i < g; ++i) {
+		const u64 nt = (n_recs[i] + CpCfg<SIZE>::TILE - 1) / CpCfg<SIZE>::TILE;
+		lutsh[i].assign(n_sh > 1 ? (size_t)n_sh * lut_entries : 1, 0);
+		status[i].assign(nt + 1, 0);
+		shards[i].assign(CP_SHARDS * 4, 0);
+		u64 *lut_i = luts + (size_t)i * (lut_entries ? lut_entries : 1);
+		u64 *lut_base = lut_i;
+		if (use_lut && n_sh > 1)
+			lut_base = lutsh[i].data();
+		else if (use_lut)
+			memset(lut_i, 0, lut_entries * 8);
+		gc.tile_prefix[i] = (u32)tiles;
+		tiles += nt;
+		gc.S[i] = sorted + rec_off * SIZE;
+		gc.n[i] = gf.n[i] = n_recs[i];
+		gc.out[i] = outs[i];
+		gc.out_capacity[i] = out_capacity;
+		gc.lut_base[i] = lut_base;
+		gc.tally[i] = shards[i].data();
+		gc.out_bytes[i] = out_bytes + i;
+		gc.status[i] = status[i].data();
+		gf.tally[i] = shards[i].data();
+		gf.stats[i] = stats + 4 * i;
+		gf.lut_base[i] = lut_base;
+		gf.lut_out[i] = lut_i;
+		rec_off += n_recs[i];
+	}
+	gc.tile_prefix[g] = (u32)tiles;
+	u32 counter = 0;
+	hipemu::launch(dim3((u32)tiles), dim3(CP_BLOCK), 0, [&] {
+		k_compact<SIZE>(gc, P, n_sh, lut_entries, &counter, err, P.lut_prefix_len ? (u32)((1ull << (2 * P.lut_prefix_len)) - 1) : 0u);
+	});
+	hipemu::launch(dim3((u32)g), dim3(256), 0, [&] { k_compact_fold(gf, use_lut ? n_sh : 1u, lut_entries); });
+	return 0;
+}
+
+Params params_of(const unsigned *params10)
+{
+	Params p;
+	p.k = params10[0];
+	p.both_strands = params10[1];
+	p.cutoff_min = params10[2];
+	p.without_output = params10[3];
+	p.cutoff_max = params10[4];
+	p.counter_max = params10[5];
+	p.lut_prefix_len = params10[6];
+	p.output_type = params10[7];
+	return p;
+}
+
 } // namespace
 
 extern "C" {
@@ -209,6 +323,38 @@ EMU_API int emu_run(const unsigned *params10, int stage_mask, const uint8_t *img
 #undef RUN
 	if (sorted_index)
 		*sorted_index = sorted == recs ? 0 : 1;
+	return (int)err;
+}
+
+/* parse + expand of a group of g bins into ONE record array (records of bin i carry tag i above the k-mer); n_pass as the host picks it
+ * for the group. Returns the device error word, -2 if the fused histograms do not cover every record. */
+EMU_API int emu_group_front(const unsigned *params10, int g, const uint8_t *const *imgs, const u64 *sizes, const u64 *n_recs, const u64 *const *pack_starts,
+                            const u64 *n_packs, u64 *recs, unsigned n_pass)
+{
+	const DevParams P = dev_params(params_of(params10));
+	u32 err = 0;
+	int rc = 0;
+	switch ((P.k + 31) / 32) {
+	case 1: rc = group_front_t<1>(P, g, imgs, sizes, n_recs, pack_starts, n_packs, recs, n_pass, &err); break;
+	case 2: rc = group_front_t<2>(P, g, imgs, sizes, n_recs, pack_starts, n_packs, recs, n_pass, &err); break;
+	default: return -1;
+	}
+	return rc ? rc : (int)err;
+}
+
+/* compaction + fold of a group on the bin-major sorted array; outs[g] buffers of out_capacity bytes, luts g x 4^p, stats g x 4 */
+EMU_API int emu_group_compact(const unsigned *params10, int g, const u64 *sorted, const u64 *n_recs, uint8_t *const *outs, u64 out_capacity, u64 *out_bytes,
+                              u64 *luts, u64 *stats)
+{
+	const Params p = params_of(params10);
+	const DevParams P = dev_params(p);
+	const u64 lut_entries = (P.kff || !p.lut_prefix_len) ? 0 : 1ull << (2 * p.lut_prefix_len);
+	u32 err = 0;
+	switch ((P.k + 31) / 32) {
+	case 1: group_compact_t<1>(P, g, sorted, n_recs, outs, out_capacity, out_bytes, luts, lut_entries, stats, &err); break;
+	case 2: group_compact_t<2>(P, g, sorted, n_recs, outs, out_capacity, out_bytes, luts, lut_entries, stats, &err); break;
+	default: return -1;
+	}
 	return (int)err;
 }
 }

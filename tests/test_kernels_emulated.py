@@ -149,3 +149,37 @@ def test_emulated_kernels_with_the_product_tile_geometry():
     r = emu.run(p, 4, recs=O.sort(recs["recs"]), geometry="product")
     w_out, w_lut, w_st = O.process_bin(p, img, nk)
     assert np.array_equal(r["out"], w_out) and np.array_equal(r["lut"], w_lut) and np.array_equal(r["stats"], w_st)
+
+
+@pytest.mark.parametrize("k,pl,g", [(27, 3, 4), (27, 7, 3), (25, 5, 9), (55, 3, 4), (27, 3, 16)])
+def test_emulated_group_of_bins_shares_one_record_array(k, pl, g):
+    """the grouped path of kmc_hip.hip: g bins parsed and expanded by ONE launch each into one record array, the bin's number inside the
+    group above the k-mer (in the spare bits of the top radix digit, or in a digit of its own: g = 9 and 16 at k = 27/25); after a sort
+    on the whole key the array is bin-major, and ONE compaction launch + one fold launch give every bin's records, LUT and tallies."""
+    rng = np.random.default_rng(k * 100 + g)
+    genome = rng.integers(0, 4, size=5_000, dtype=np.uint8)
+    bins = [binsynth.random_bin(rng, k, int(rng.integers(1, 400)), max_extra=40, genome=genome, pack_size=97) for _ in range(g)]
+    p = O.make_params(k, lut_prefix_len=pl)
+    tag_bits = max(1, (g - 1).bit_length())
+    n_pass = (2 * k + tag_bits + 7) // 8
+    err, recs = emu.group_front(p, bins, n_pass)
+    assert err == 0
+    words = recs.shape[1]
+    off = 0
+    want_sorted = []
+    for i, (img, nk, _) in enumerate(bins):
+        w = O.expand(p, img).copy()
+        w[:, (2 * k) // 64] |= np.uint64(i) << np.uint64((2 * k) % 64)  # the tag the kernel puts above the k-mer
+        assert np.array_equal(recs[off:off + nk], w), i
+        want_sorted.append(O.sort(w))
+        off += nk
+    srt = np.concatenate(want_sorted)  # bin-major = ascending on the tagged key
+    if words == 1:
+        assert np.array_equal(srt[:, 0], np.sort(recs[:, 0]))
+    err, got = emu.group_compact(p, srt, [b[1] for b in bins])
+    assert err == 0
+    for i, (img, nk, _) in enumerate(bins):
+        w_out, w_lut, w_st = O.process_bin(p, img, nk)
+        assert np.array_equal(got[i][2], w_st), (i, got[i][2], w_st)
+        assert np.array_equal(got[i][0], w_out), i
+        assert np.array_equal(got[i][1], w_lut), i
