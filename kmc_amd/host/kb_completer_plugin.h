@@ -40,6 +40,7 @@
 #include <unistd.h>
 #include "critical_error_handler.h"
 #include "exception_aware_thread.h"
+#include "kmc_order.h"
 
 class CWKmerBinCompleter {
 	std::unique_ptr<CWKmerBinCompleter_ref> ref; /* non-null: the reference completer runs (modes listed in the header comment) */
@@ -104,6 +105,7 @@ class CWKmerBinCompleter {
 
 	void first_stage()
 	{
+		KmcTimeline::mark("completer start");
 		fd_suf = open(suf_name.c_str(), O_CREAT | O_TRUNC | O_WRONLY, 0666);
 		if (fd_suf < 0)
 			CCriticalErrorHandler::Inst().HandleCriticalError("Error: Cannot create " + suf_name);
@@ -199,7 +201,9 @@ class CWKmerBinCompleter {
 			stop_writers();
 			throw;
 		}
+		KmcTimeline::mark("completer: queue drained");
 		stop_writers();
+		KmcTimeline::mark("completer: writers joined");
 	}
 
 	void second_stage()
@@ -227,6 +231,7 @@ class CWKmerBinCompleter {
 		if (fclose(out_pre) != 0)
 			CCriticalErrorHandler::Inst().HandleCriticalError("Error: Cannot write to " + pre_name);
 		out_pre = nullptr;
+		KmcTimeline::mark("completer: files closed");
 	}
 
 public:

@@ -225,6 +225,7 @@ public:
 
 	void operator()()
 	{
+		KmcTimeline::mark("reader start");
 		const long long t0 = KmcOrderedEmit::now_ns();
 		CPercentProgress percent_progress("Stage 2: ", true, percentProgressObserver);
 		percent_progress.SetMaxVal(bd->get_n_rec_sum());
@@ -248,6 +249,7 @@ public:
 		sorters_manager->NotifyQueueCompleted();
 		fflush(stdout);
 		order->ns_reader_wall += KmcOrderedEmit::now_ns() - t0;
+		KmcTimeline::mark("reader done");
 	}
 };
 

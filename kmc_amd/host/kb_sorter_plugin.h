@@ -111,6 +111,8 @@ public:
 		memory_bins = Queues.memory_bins.get();
 		sorters_manager = Queues.sorters_manager.get();
 		order = KmcOrderedEmit::for_queue(kq);
+		if (worker_counter().load() == 0)
+			KmcTimeline::mark("first worker constructed");
 
 		bp.kmer_len = Params.kmer_len;
 		bp.both_strands = Params.both_strands ? 1 : 0;
@@ -154,6 +156,8 @@ public:
 				if (!sorters_manager->GetNext(bin_id, data, size, n_rec, n_sorting_threads))
 					break;
 				seq = order->next_take++;
+				if (seq == 0)
+					KmcTimeline::mark("first bin taken");
 				order->ns_getnext += KmcOrderedEmit::now_ns() - t0;
 			}
 			CMemDiskFile *file;
@@ -219,8 +223,10 @@ public:
 			sorters_manager->ReturnThreads(n_sorting_threads, bin_id);
 		}
 		order->ns_worker_wall += KmcOrderedEmit::now_ns() - t_start;
-		if (++order->n_workers_done == n_workers)
+		if (++order->n_workers_done == n_workers) {
+			KmcTimeline::mark("last worker done");
 			order->report(n_workers);
+		}
 		kq->mark_completed();
 	}
 

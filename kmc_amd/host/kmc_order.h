@@ -18,12 +18,44 @@
 #include <cstdlib>
 #include <map>
 #include <memory>
+#include <utility>
 #include <mutex>
 #include <vector>
 
 #include "defs.h"
 #include "params.h"
 #include "critical_error_handler.h"
+
+/* KMC_HIP_VERBOSE=1: wall-clock marks of one run (reader / workers / completer), printed at exit as seconds since the first mark —
+ * where between its start and its end does "2nd stage" spend its time? */
+struct KmcTimeline {
+	std::mutex m;
+	std::vector<std::pair<const char *, long long>> marks;
+	bool on = getenv("KMC_HIP_VERBOSE") != nullptr;
+	static KmcTimeline &inst()
+	{
+		static KmcTimeline t;
+		return t;
+	}
+	static void mark(const char *what)
+	{
+		KmcTimeline &t = inst();
+		if (!t.on)
+			return;
+		const long long now = std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now().time_since_epoch()).count();
+		std::lock_guard<std::mutex> lck(t.m);
+		t.marks.emplace_back(what, now);
+	}
+	~KmcTimeline()
+	{
+		if (!on || marks.empty())
+			return;
+		fprintf(stderr, "[kmc_hip timeline]");
+		for (auto &e : marks)
+			fprintf(stderr, " %s %.3f |", e.first, (e.second - marks[0].second) * 1e-9);
+		fprintf(stderr, "\n");
+	}
+};
 
 struct KmcOrderedEmit {
 	std::mutex take_mtx, emit_mtx;

@@ -40,6 +40,8 @@ with tempfile.TemporaryDirectory(dir=base) as td:
             ("kmc_hip", ["-t128", "-m16", "-sr16"], {}),
             ("kmc_hip_sr", ["-t128", "-m128", "-sr16"], {}),
             ("kmc", ["-t128", "-m128", "-r"], {})]
+    if len(sys.argv) > 4:  # a subset of the runs, by index
+        runs = [runs[int(i)] for i in sys.argv[4].split(",")]
     for exe, flags, env in runs:
         p = os.path.join(REF, exe)
         if not os.path.exists(p):
