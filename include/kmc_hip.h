@@ -136,7 +136,7 @@ int kmc_hip_process_bin_device(kmc_hip_ctx *ctx, int dev, const kmc_hip_bin_para
                                uint64_t *d_out_bytes, uint64_t *d_lut, uint64_t *d_stats, int sync);
 
 /* Many device-resident bins in one call (per-GPU bin queue): bin i is enqueued on internal stream
- * (i mod n_streams), in index order per stream, by one host thread per stream — a bin is ~16 launches, so hundreds of
+ * (i mod n_streams), in index order per stream, by one host thread per stream — a group of bins is 13-14 launches, so hundreds of
  * small bins are bound by the host's launch rate unless several threads submit (KMC's default is 512 bins per run,
  * kmc.h n_bins). n_streams <= 0 picks the default (8), capped at kmc_hip_num_slots(). Returns after enqueueing;
  * kmc_hip_synchronize(dev) waits and reports deferred device errors. Output buffers of all bins must be distinct.

@@ -1,20 +1,24 @@
 /*
  * kmc_amd/csrc/kernels.hip.h — gfx950 (MI355X, wave64) kernels of the KMC stage-2 hot path.
  *
- *   index    k_pack_scan / k_pack_offsets / k_pack_index : locate super-k-mers inside expander packs
- *   expand   k_expand<SIZE>      : super-k-mer bytes -> canonical k-mer records   (ref kb_sorter.h:299-362)
- *   sort     k_hist<SIZE>        : all per-pass byte histograms in ONE read of the records
- *            k_hist_scan         : exclusive scan -> global digit bases
- *            k_onesweep<SIZE,..> : one 8-bit LSD pass, single read + single write per record, decoupled
+ *   parse    k_parse_packs       : mark the super-k-mer starts of every expander pack in a bitmap (speculative chain
+ *                                  resolution in LDS)
+ *   expand   k_expand<SIZE>      : super-k-mer bytes -> canonical k-mer records (ref kb_sorter.h:299-362), the sort's byte
+ *                                  histograms fused in, digit bases by the last workgroup
+ *   sort     k_hist<SIZE>, k_hist_scan : histograms / digit bases where they are not fused (k > 64, sort-only calls)
+ *            k_onesweep<SIZE>    : one 8-bit LSD pass, single read + single write per record, decoupled
  *                                  look-back across tiles, wave64 ballot ranking, LDS-staged scatter
  *                                  (replaces raduls_impl.h:546-754 / radix.h:469-842)
  *   compact  k_compact<SIZE>     : run-length count + cutoffs + suffix/counter bytes + prefix LUT + tallies
- *                                  in ONE read of the sorted records (ref kb_sorter.h:1128-1281)
+ *                                  in ONE coalesced read of the sorted records (ref kb_sorter.h:1128-1281)
+ *            k_compact_fold      : tally / LUT shards -> the caller's stats and LUT
+ *   parse, expand, compact and fold work on GROUPS of bins (Grp* descriptors): the bins that share one sort.
  *
- * All work is integer/byte permutation: HBM-bound, no MFMA. Design rules applied (cdna_hip_programming.md):
+ * All work is integer/byte permutation: HBM/LDS-bound, no MFMA. Design rules applied (cdna_hip_programming.md):
  * 64-wide ballots/popcounts, coalesced 512 B..1 KiB per wave-instruction, per-wave private LDS histograms
- * (no LDS atomics on the ranking path), >=4 workgroups per CU resident, inter-workgroup hand-off only through
- * single-word relaxed agent-scope atomics where the word IS the flag (Guideline 16 "R2"), every spin bounded.
+ * (no LDS atomics on the ranking path), inter-workgroup hand-off only through single-word relaxed agent-scope
+ * atomics where the word IS the flag (Guideline 16 "R2"), every spin bounded. The same source runs on the CPU under
+ * tests/hipemu (test infrastructure) — hence the three KMC_* macros below.
  */
 #ifndef KMC_AMD_KERNELS_HIP_H
 #define KMC_AMD_KERNELS_HIP_H

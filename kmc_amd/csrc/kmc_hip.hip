@@ -262,7 +262,7 @@ int read_and_clear_sticky(Slot &s, u32 &err)
 /* ---- zero-region planning --------------------------------------------------------------------------------------- */
 /* Small LUTs are sharded: in sorted order every tile in flight updates the same one or two entries, and same-address device atomics
  * serialise (r01: 11 of the compaction's 12 ms at 64 entries). From 4^6 entries on the tiles in flight spread over enough of them.
- * The shards are summed by the compaction's last workgroup, so shards x entries stays small (<= 8 K loads). */
+ * The shards are summed by k_compact_fold (one small workgroup per bin), so shards x entries stays small (<= 8 K loads). */
 u32 lut_shards_for(u64 lut_entries) { return lut_entries <= 256 ? 32u : (lut_entries <= 1024 ? 8u : 1u); }
 
 /* one bin's share of a group (a bin on its own is a group of one): its buffers and where it sits in the zero region and the shared arrays */
@@ -1051,7 +1051,7 @@ int kmc_hip_process_bins_device(kmc_hip_ctx *ctx, int dev, const kmc_hip_bin_par
 			return fail(KMC_HIP_EINVAL, "kmc_hip_process_bins_device: NULL device pointer in a bin descriptor");
 	const u64 lut_entries = P.kff ? 0 : kmc_hip_lut_entries(params);
 	Dev &d = *ctx->devs[dev];
-	/* Bin i goes to stream slot (i mod n_streams), in index order per slot; one host thread per slot enqueues (a bin is ~16 launches:
+	/* Bin i goes to stream slot (i mod n_streams), in index order per slot; one host thread per slot enqueues (a group of bins is 13-14 launches:
 	 * with hundreds of small bins a single submitting thread is the bottleneck, not the GPU). Big bins all take slot 0. */
 	std::vector<int> rcs((size_t)n_streams, 0);
 	std::vector<std::string> msgs((size_t)n_streams);
