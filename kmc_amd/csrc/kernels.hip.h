@@ -18,7 +18,7 @@
  * 64-wide ballots/popcounts, coalesced 512 B..1 KiB per wave-instruction, per-wave private LDS histograms
  * (no LDS atomics on the ranking path), inter-workgroup hand-off only through single-word relaxed agent-scope
  * atomics where the word IS the flag (Guideline 16 "R2"), every spin bounded. The same source runs on the CPU under
- * tests/hipemu (test infrastructure) — hence the three KMC_* macros below.
+ * tests/hipemu (test infrastructure) — hence the four KMC_* macros below.
  */
 #ifndef KMC_AMD_KERNELS_HIP_H
 #define KMC_AMD_KERNELS_HIP_H
@@ -32,13 +32,14 @@
 typedef kmc_u64 u64;
 typedef kmc_u32 u32;
 
-/* Three constructs have no spelling outside the device compiler. They are macros so that tests/hipemu (a host-side emulation of
+/* Four constructs have no spelling outside the device compiler. They are macros so that tests/hipemu (a host-side emulation of
  * the device language, test infrastructure for the `-m "not gpu"` suite) can run this very source on the CPU; the product build
  * always sees the definitions below. */
 #ifndef KMC_DYN_LDS
 #define KMC_DYN_LDS(type, name) extern __shared__ __attribute__((aligned(16))) type name[] /* the launch's dynamic LDS */
 #define KMC_LAUNDER(x) asm volatile("" : "+v"(x)) /* hide a lane-constant value from LICM: hoisted per-tile addresses cost VGPRs */
 #define KMC_WAIT_VMEM() asm volatile("s_waitcnt vmcnt(0)" ::: "memory") /* this wave's outstanding memory operations are performed */
+#define KMC_WAVE_LOCKSTEP() ((void)0) /* a point where the code relies on the wave's lanes executing an instruction together */
 #endif
 
 /* device-side error bits (d_err) */
@@ -542,6 +543,7 @@ constexpr int EXP_CHUNK = EXP_CHUNK_BYTES, EXP_TAIL = 160, EXP_KWIN = EXP_KWIN_K
 __host__ __device__ constexpr u32 exp_max_sk(u32 k) { return (u32)EXP_CHUNK / (1 + ((k + 3) >> 2)) + 2; }
 
 static_assert(EXP_CHUNK / 32 <= EXP_BLOCK && EXP_CHUNK <= 65536, "one bitmap word per thread; 16-bit positions inside a slice");
+static_assert(EXP_BLOCK >= 256, "the last workgroup scans 256 digits per pass, one per thread");
 template <int SIZE, bool FUSE_HIST>
 __global__ void __launch_bounds__(EXP_BLOCK) k_expand(const GrpExpand ge, u32 k, u32 both_strands, u32 n_pass, u64 *__restrict__ ghist, u32 *ticket_ctr,
                                                  u32 *err, u64 *__restrict__ digit_base, u32 *done_ctr)
@@ -896,6 +898,7 @@ __global__ void __launch_bounds__(RS_BLOCK, (SIZE <= 4 ? RS_MIN_WAVES : RS_MIN_W
 #pragma unroll
 		for (int i = 0; i < 4; ++i)
 			s_whist[wave * 256 + i * 64 + lane] = 0;
+		KMC_WAVE_LOCKSTEP(); /* the wave's own counters are zero before any of its lanes counts into them */
 		const u64 tile_base = (u64)tile * TILE;
 		const u32 tile_n = (n - tile_base) < (u64)TILE ? (u32)(n - tile_base) : (u32)TILE;
 		TRACE_STAMP(0, tile, 0);
@@ -996,6 +999,8 @@ __global__ void __launch_bounds__(RS_BLOCK, (SIZE <= 4 ? RS_MIN_WAVES : RS_MIN_W
 			}
 			u32 *ctr = &s_whist[wave * 256 + d];
 			base_prev = __hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); /* other lanes add to it */
+			KMC_WAVE_LOCKSTEP(); /* every lane has read the counter before any lane adds to it: free on the hardware (a wave executes one LDS
+			                      * instruction for all its lanes at once), a real rendezvous under tests/hipemu */
 			if (valid && below == 0)
 				(void)__hip_atomic_fetch_add(ctr, (u32)(__popc(lo) + __popc(hi)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 			below_prev = below;

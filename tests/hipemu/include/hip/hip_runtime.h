@@ -151,10 +151,11 @@ template <class F> void launch(dim3 grid, dim3 block, size_t dyn_bytes, F body)
 #define __forceinline__ inline __attribute__((always_inline))
 #define __launch_bounds__(...)
 #define __shared__ static
-/* the three constructs of kernels.hip.h that have no host spelling (see the defaults there) */
+/* the four constructs of kernels.hip.h that have no host spelling (see the defaults there) */
 #define KMC_DYN_LDS(type, name) type *name = reinterpret_cast<type *>(hipemu::g_launch->dyn)
 #define KMC_LAUNDER(x) ((void)(x))
 #define KMC_WAIT_VMEM() __atomic_thread_fence(__ATOMIC_SEQ_CST)
+#define KMC_WAVE_LOCKSTEP() hipemu::t_wave->bar.wait()
 
 static inline void __syncthreads() { hipemu::g_launch->block_bar.wait(); }
 

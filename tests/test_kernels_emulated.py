@@ -1,7 +1,8 @@
 """The kernel SOURCE of kmc_amd/csrc/kernels.hip.h executed on the CPU (tests/hipemu: one OS thread per GPU thread, wave64 cross-lane
 operations through per-wave exchanges) and compared bit for bit with the oracle. This is how kernel logic is checked in a container
 without a GPU before a GPU minute is spent; the `-m gpu` suite remains the parity test of the product (libkmc_hip.so on gfx950).
-Not covered here: k_onesweep (its ranking relies on the lock-step execution of a wave's LDS operations, which OS threads do not have).
+k_onesweep's ranking relies on a wave executing an LDS instruction for all its lanes at once; the one place is marked KMC_WAVE_LOCKSTEP()
+(nothing on the device — the ISA is byte-identical with and without it — a wave rendezvous here).
 All cases but the last use a build of the same source with 128-thread workgroups (tests/emu.py GEOMETRY_FLAGS), which emulates ~10x faster."""
 import ctypes as C
 
@@ -183,3 +184,32 @@ def test_emulated_group_of_bins_shares_one_record_array(k, pl, g):
         assert np.array_equal(got[i][2], w_st), (i, got[i][2], w_st)
         assert np.array_equal(got[i][0], w_out), i
         assert np.array_equal(got[i][1], w_lut), i
+
+
+@pytest.mark.parametrize("words,key_bytes,n", [(1, 7, 1), (1, 7, 2), (1, 7, 2559), (1, 7, 2560), (1, 7, 2561), (1, 8, 9000), (2, 14, 3000), (4, 32, 1500)])
+def test_emulated_onesweep_sort_matches_oracle(words, key_bytes, n):
+    """the 8-bit LSD passes (histograms, digit bases, one onesweep launch per pass with its decoupled look-back) on tiles of 256 threads"""
+    rng = np.random.default_rng(words * 1000 + n)
+    recs = rng.integers(0, 1 << 62, size=(n, words), dtype=np.uint64)
+    if key_bytes < 8 * words:  # bytes above the key are zero by construction (kb_sorter.h:757-780)
+        full, rem = divmod(key_bytes, 8)
+        recs[:, full + (1 if rem else 0):] = 0
+        if rem:
+            recs[:, full] &= np.uint64((1 << (8 * rem)) - 1)
+    k = {7: 27, 8: 32, 14: 55, 32: 127}[key_bytes]
+    p = O.make_params(k, lut_prefix_len=0, output_type=1)
+    r = emu.run(p, 2, recs=recs)
+    assert r["err"] == 0
+    assert np.array_equal(r["sorted"], O.sort(recs))
+
+
+def test_emulated_whole_bin_matches_oracle():
+    """parse -> expand (+ fused histograms, digit bases) -> 7 onesweep passes -> compaction -> fold, all emulated, against oracle_process_bin"""
+    rng = np.random.default_rng(4242)
+    g = rng.integers(0, 4, size=4_000, dtype=np.uint8)
+    img, nk, packs = binsynth.random_bin(rng, 27, 700, max_extra=30, genome=g, pack_size=150)
+    p = O.make_params(27, lut_prefix_len=3)
+    r = emu.run(p, 7, img, nk, packs)
+    w_out, w_lut, w_st = O.process_bin(p, img, nk)
+    assert r["err"] == 0
+    assert np.array_equal(r["out"], w_out) and np.array_equal(r["lut"], w_lut) and np.array_equal(r["stats"], w_st)
