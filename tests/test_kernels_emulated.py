@@ -213,3 +213,26 @@ def test_emulated_whole_bin_matches_oracle():
     w_out, w_lut, w_st = O.process_bin(p, img, nk)
     assert r["err"] == 0
     assert np.array_equal(r["out"], w_out) and np.array_equal(r["lut"], w_lut) and np.array_equal(r["stats"], w_st)
+
+
+def test_emulated_group_with_tiny_bins():
+    """bins of one super-k-mer (one k-mer, or a handful) next to a normal one in the same group: one-slice bins, one-tile bins, runs of one"""
+    rng = np.random.default_rng(99)
+    k = 27
+    bins = [binsynth.random_bin(rng, k, 1, max_extra=0), binsynth.random_bin(rng, k, 1, max_extra=5), binsynth.random_bin(rng, k, 250, max_extra=40),
+            binsynth.random_bin(rng, k, 2, max_extra=255)]
+    p = O.make_params(k, lut_prefix_len=3, cutoff_min=1)
+    err, recs = emu.group_front(p, bins, (2 * k + 2 + 7) // 8)
+    assert err == 0
+    parts, off = [], 0
+    for i, (img, nk, _) in enumerate(bins):
+        w = O.expand(p, img).copy()
+        w[:, 0] |= np.uint64(i) << np.uint64(2 * k)
+        assert np.array_equal(recs[off:off + nk], w), i
+        parts.append(O.sort(w))
+        off += nk
+    err, got = emu.group_compact(p, np.concatenate(parts), [b[1] for b in bins])
+    assert err == 0
+    for i, (img, nk, _) in enumerate(bins):
+        w_out, w_lut, w_st = O.process_bin(p, img, nk)
+        assert np.array_equal(got[i][2], w_st) and np.array_equal(got[i][0], w_out) and np.array_equal(got[i][1], w_lut), i
