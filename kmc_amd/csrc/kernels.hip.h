@@ -122,7 +122,8 @@ struct GrpCompact {
 	u64 *lut_base[GRP_MAX]; /* the bin's LUT (or its shards) */
 	u64 *tally[GRP_MAX];    /* [CP_SHARDS][4] */
 	u64 *out_bytes[GRP_MAX];
-	u64 *status[GRP_MAX];
+	u64 *status[GRP_MAX];    /* one word per tile: look-back word, or (two-phase output) the tile's number of counted k-mers */
+	uint8_t *scratch[GRP_MAX]; /* two-phase output: the bin's slice of the record array the sort left free */
 };
 struct GrpFold {
 	const u64 *tally[GRP_MAX];
@@ -130,6 +131,18 @@ struct GrpFold {
 	u64 n[GRP_MAX];
 	const u64 *lut_base[GRP_MAX];
 	u64 *lut_out[GRP_MAX];
+	/* two-phase output: tile counts -> exclusive prefixes (in place, total at [n_tiles]), out_bytes, capacity check */
+	u64 *status[GRP_MAX];
+	u32 n_tiles[GRP_MAX];
+	u64 *out_bytes[GRP_MAX];
+	u64 out_capacity[GRP_MAX];
+};
+struct GrpGather { /* two-phase output: tile t's records move from scratch + t * tile_pitch to out + prefix[t] * rec_bytes */
+	u32 g, tile_prefix[GRP_MAX + 1];
+	const uint8_t *scratch[GRP_MAX];
+	const u64 *prefix[GRP_MAX]; /* [n_tiles + 1] */
+	uint8_t *out[GRP_MAX];
+	u64 out_capacity[GRP_MAX];
 };
 /* bin of work item `item` (wave-uniform) */
 __device__ __forceinline__ u32 grp_find(const u32 (&prefix)[GRP_MAX + 1], u32 g, u32 item)
@@ -1182,8 +1195,13 @@ static_assert(CP_TPB == 1, "one compaction tile per workgroup");
 
 template <int SIZE>
 __global__ void __launch_bounds__(CP_BLOCK, CpCfg<SIZE>::MIN_WAVES) k_compact(const GrpCompact gc, DevParams P, u32 lut_shards, u64 lut_stride, u32 *tile_counter,
-                                                                               u32 *err, u32 lut_mask /* 4^p - 1: drops a group tag above the k-mer */)
+                                                                               u32 *err, u32 lut_mask /* 4^p - 1: drops a group tag above the k-mer */,
+                                                                               u32 two_phase)
 {
+	/* two_phase: a tile does not wait for its offset in the output (the look-back is 6.4 of a tile's 16 us) — it leaves its records at the
+	 * start of its own span of the record array the sort no longer needs and its count in status[tile]; k_compact_fold turns the counts into
+	 * offsets, k_compact_gather moves the records (5 % of the k-mers at cutoff_min 2) to their place. The host picks the mode: the span
+	 * (TILE records of 8 SIZE bytes) must hold the tile's counted records whatever the data (kmc_hip.hip compact_group). */
 	constexpr int ROWS = CpCfg<SIZE>::ITEMS;
 	constexpr int TILE = CpCfg<SIZE>::TILE;
 	constexpr int NW = CP_BLOCK / 64;
@@ -1366,10 +1384,15 @@ __global__ void __launch_bounds__(CP_BLOCK, CpCfg<SIZE>::MIN_WAVES) k_compact(co
 		if (wave == 0) {
 			/* tile offset among counted k-mers: 64-bit decoupled look-back, one word per tile, inspected 64 tiles
 			 * at a time by the lanes of wave 0 (a one-word-per-hop walk costs ~1 us per hop) */
-			const u64 excl = lookback64(status, tile, (u64)tile_counted, lane, err, KERR_WATCHDOG);
+			u64 excl = 0;
+			if (two_phase) {
+				if (lane == 0)
+					status[tile] = tile_counted;
+			} else
+				excl = lookback64(status, tile, (u64)tile_counted, lane, err, KERR_WATCHDOG);
 			if (lane == 0) {
 				s_tile_off = excl;
-				if (tile == num_tiles - 1)
+				if (!two_phase && tile == num_tiles - 1)
 					*out_bytes = P.without_output ? 0 : (excl + tile_counted) * (u64)rec_bytes;
 				/* the tile's tallies, sharded */
 				u32 tu = 0, tb = 0, ta = 0;
@@ -1396,6 +1419,7 @@ __global__ void __launch_bounds__(CP_BLOCK, CpCfg<SIZE>::MIN_WAVES) k_compact(co
 		if (!P.without_output && tile_counted) {
 			const u32 tile_bytes = tile_counted * rec_bytes;
 			const u32 pshift = 2 * (P.k - P.lut_prefix_len);
+			uint8_t *const dst = two_phase ? gc.scratch[bin] + (u64)tile * ((u64)TILE * SIZE * 8) : out; /* where this tile's bytes go */
 			if (rec_bytes <= 8) {
 				/* fast path (k <= ~36): a record is one 64-bit value in output byte order; records go to an LDS window,
 				 * then every thread composes aligned output dwords from it */
@@ -1426,25 +1450,25 @@ __global__ void __launch_bounds__(CP_BLOCK, CpCfg<SIZE>::MIN_WAVES) k_compact(co
 						}
 					}
 					__syncthreads(); /* the window is complete; in the first round this also publishes s_tile_off */
-					const u64 gbyte0 = s_tile_off * rec_bytes; /* global byte offset of this tile's first record */
-					const bool fits = gbyte0 + tile_bytes <= out_capacity; /* uniform over the workgroup */
+					const u64 gbyte0 = two_phase ? 0 : s_tile_off * rec_bytes; /* byte offset of this tile's first record in dst */
+					const bool fits = two_phase || gbyte0 + tile_bytes <= out_capacity; /* uniform over the workgroup */
 					if (!fits && tid == 0)
 						atomicOr(err, KERR_CAPACITY);
 					if (fits) {
 						const u64 g0 = gbyte0 + (u64)r0 * rec_bytes;
 						const u32 len = (r1 - r0) * rec_bytes;
-						u32 head = (u32)((4 - ((uintptr_t)(out + g0) & 3)) & 3);
+						u32 head = (u32)((4 - ((uintptr_t)(dst + g0) & 3)) & 3);
 						if (head > len)
 							head = len;
 						const u32 ndw = (len - head) >> 2;
 						const u32 tail0 = head + (ndw << 2);
 						if (tid < head) /* head <= 3 < rec_bytes unless records are shorter than that: tid / rec_bytes via div_rb */
-							out[g0 + tid] = (uint8_t)(s_rec[div_rb(tid)] >> (8 * (tid - div_rb(tid) * rec_bytes)));
+							dst[g0 + tid] = (uint8_t)(s_rec[div_rb(tid)] >> (8 * (tid - div_rb(tid) * rec_bytes)));
 						if (tid >= 32 && tid - 32 < len - tail0) {
 							const u32 bi = tail0 + (tid - 32), br = div_rb(bi);
-							out[g0 + bi] = (uint8_t)(s_rec[br] >> (8 * (bi - br * rec_bytes)));
+							dst[g0 + bi] = (uint8_t)(s_rec[br] >> (8 * (bi - br * rec_bytes)));
 						}
-						u32 *gd = reinterpret_cast<u32 *>(out + g0 + head);
+						u32 *gd = reinterpret_cast<u32 *>(dst + g0 + head);
 						for (u32 w = tid; w < ndw; w += CP_BLOCK) {
 							const u32 i0 = head + (w << 2);
 							u32 ri = div_rb(i0), q = i0 - ri * rec_bytes;
@@ -1493,24 +1517,24 @@ __global__ void __launch_bounds__(CP_BLOCK, CpCfg<SIZE>::MIN_WAVES) k_compact(co
 						}
 					}
 					__syncthreads();
-					const u64 gbyte0 = s_tile_off * rec_bytes;
-					const bool fits = gbyte0 + tile_bytes <= out_capacity;
+					const u64 gbyte0 = two_phase ? 0 : s_tile_off * rec_bytes;
+					const bool fits = two_phase || gbyte0 + tile_bytes <= out_capacity;
 					if (!fits && tid == 0)
 						atomicOr(err, KERR_CAPACITY);
 					if (fits) {
-						/* window [c0,c1) -> out[gbyte0+c0 ...): leading bytes up to 4-byte alignment, dwords, trailing bytes */
+						/* window [c0,c1) -> dst at gbyte0 + c0: leading bytes up to 4-byte alignment, dwords, trailing bytes */
 						const u64 g0 = gbyte0 + c0;
 						const u32 len = c1 - c0;
-						u32 head = (u32)((4 - ((uintptr_t)(out + g0) & 3)) & 3);
+						u32 head = (u32)((4 - ((uintptr_t)(dst + g0) & 3)) & 3);
 						if (head > len)
 							head = len;
 						const u32 ndw = (len - head) >> 2;
 						const u32 tail0 = head + (ndw << 2);
 						if (tid < head)
-							out[g0 + tid] = s_stage[tid];
+							dst[g0 + tid] = s_stage[tid];
 						if (tid >= 32 && tid - 32 < len - tail0)
-							out[g0 + tail0 + (tid - 32)] = s_stage[tail0 + (tid - 32)];
-						u32 *gd = reinterpret_cast<u32 *>(out + g0 + head);
+							dst[g0 + tail0 + (tid - 32)] = s_stage[tail0 + (tid - 32)];
+						u32 *gd = reinterpret_cast<u32 *>(dst + g0 + head);
 						for (u32 w = tid; w < ndw; w += CP_BLOCK) {
 							const uint8_t *sp = s_stage + head + (w << 2);
 							gd[w] = (u32)sp[0] | ((u32)sp[1] << 8) | ((u32)sp[2] << 16) | ((u32)sp[3] << 24);
@@ -1540,7 +1564,7 @@ __global__ void __launch_bounds__(CP_BLOCK, CpCfg<SIZE>::MIN_WAVES) k_compact(co
  * caller's LUT. One small workgroup after the compaction. (Rounds 2a-2b had the compaction's last workgroup do this: every tile then ended
  * with "wait for my atomics, count myself in, barrier" — ~4 us during which the workgroup's registers and LDS sat idle; with ~12 rounds of
  * tiles per CU and bin that cost more than this launch does.) */
-__global__ void __launch_bounds__(256) k_compact_fold(const GrpFold gf, u32 lut_shards, u64 lut_stride)
+__global__ void __launch_bounds__(256) k_compact_fold(const GrpFold gf, u32 lut_shards, u64 lut_stride, u32 two_phase, u32 rec_bytes, u32 *err)
 {
 	const u32 bin = blockIdx.x; /* one workgroup per bin of the group */
 	const u64 *__restrict__ stat_shards = gf.tally[bin];
@@ -1558,6 +1582,31 @@ __global__ void __launch_bounds__(256) k_compact_fold(const GrpFold gf, u32 lut_
 		if (lane == 0)
 			stats[3] = gf.n[bin];
 	}
+	if (two_phase) { /* tile counts -> exclusive prefixes, in place; the total goes to [n_tiles] and, in bytes, to out_bytes */
+		__shared__ u64 s_scan[5];
+		u64 *st = gf.status[bin];
+		const u32 nt = gf.n_tiles[bin];
+		/* each thread owns a run of consecutive tiles: one workgroup scan for the whole bin (~6000 tiles at 48 M k-mers) */
+		const u32 per = (nt + 255) / 256, i_lo = threadIdx.x * per;
+		u64 sum = 0;
+		for (u32 j = 0; j < per; ++j)
+			if (i_lo + j < nt)
+				sum += st[i_lo + j];
+		u64 carry;
+		u64 run = block_excl_sum<4, u64>(sum, s_scan, carry);
+		for (u32 j = 0; j < per; ++j)
+			if (i_lo + j < nt) {
+				const u64 v = st[i_lo + j];
+				st[i_lo + j] = run;
+				run += v;
+			}
+		if (threadIdx.x == 0) {
+			st[nt] = carry;
+			*gf.out_bytes[bin] = carry * rec_bytes;
+			if (carry * rec_bytes > gf.out_capacity[bin])
+				atomicOr(err, KERR_CAPACITY);
+		}
+	}
 	if (lut_shards > 1) { /* <= 8 K loads (kmc_hip.hip lut_shards_for), 8 in flight per thread */
 		for (u64 i = threadIdx.x; i < lut_stride; i += 256) {
 			u64 v = 0;
@@ -1572,6 +1621,45 @@ __global__ void __launch_bounds__(256) k_compact_fold(const GrpFold gf, u32 lut_
 			}
 			lut_out[i] = v;
 		}
+	}
+}
+
+/* Two-phase output, second phase: one WAVE per tile moves the tile's records from its span of the scratch array to their place in the bin's
+ * output (prefix from k_compact_fold). The source is dword-aligned, the destination is not: leading bytes, then aligned destination dwords
+ * funnel-shifted out of two source dwords, then trailing bytes. No barriers. */
+__global__ void __launch_bounds__(256) k_compact_gather(const GrpGather gg, u32 rec_bytes, u64 tile_pitch)
+{
+	const u32 lane = threadIdx.x & 63;
+	const u32 gtile = blockIdx.x * 4 + (threadIdx.x >> 6);
+	if (gtile >= gg.tile_prefix[gg.g])
+		return;
+	const u32 bin = grp_find(gg.tile_prefix, gg.g, gtile);
+	const u32 tile = gtile - gg.tile_prefix[bin];
+	const u32 nt = gg.tile_prefix[bin + 1] - gg.tile_prefix[bin];
+	const u64 *__restrict__ prefix = gg.prefix[bin];
+	if (prefix[nt] * rec_bytes > gg.out_capacity[bin])
+		return; /* KERR_CAPACITY was raised by the fold */
+	const u64 first = prefix[tile];
+	const u32 len = (u32)(prefix[tile + 1] - first) * rec_bytes;
+	if (!len)
+		return;
+	const uint8_t *__restrict__ src = gg.scratch[bin] + (u64)tile * tile_pitch;
+	uint8_t *__restrict__ dst = gg.out[bin] + first * rec_bytes;
+	u32 head = (u32)((4 - ((uintptr_t)dst & 3)) & 3);
+	if (head > len)
+		head = len;
+	const u32 ndw = (len - head) >> 2, tail0 = head + (ndw << 2);
+	if (lane < head)
+		dst[lane] = src[lane];
+	if (lane >= 32 && lane - 32 < len - tail0)
+		dst[tail0 + lane - 32] = src[tail0 + lane - 32];
+	const u32 *__restrict__ s32 = reinterpret_cast<const u32 *>(src);
+	u32 *__restrict__ d32 = reinterpret_cast<u32 *>(dst + head);
+	const u32 sh = 8 * head; /* destination dword w = source bytes [head + 4w, head + 4w + 4) */
+	for (u32 w = lane; w < ndw; w += 64) {
+		const u32 lo = s32[w];
+		const u32 hi = head ? s32[w + 1] : 0; /* inside the tile's span: head + 4w + 4 <= len */
+		d32[w] = head ? ((lo >> sh) | (hi << (32 - sh))) : lo;
 	}
 }
 

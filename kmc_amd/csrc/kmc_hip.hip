@@ -495,8 +495,11 @@ int front_end_group(Slot &s, const std::vector<BinPlan> &bins, size_t off_ghist,
 
 /* ---- compaction of a group (one ticket space over the tiles of all bins, each bin on its slice of the sorted array) + the fold of tally /
  * LUT shards (one small workgroup per bin) ---- */
+/* `scratch`: the record array the sort left free (same layout as `sorted`), or NULL. With it, and when a tile's span of it is certain to hold
+ * the tile's counted records — at most TILE / cutoff_min + 1 of them — the output is written in two phases (kernels.hip.h k_compact two_phase):
+ * no tile waits for its offset. */
 template <int SIZE>
-int compact_group(Slot &s, const std::vector<BinPlan> &bins, const u64 *sorted, const DevParams &P, u64 lut_entries, u32 &counter_idx)
+int compact_group(Slot &s, const std::vector<BinPlan> &bins, const u64 *sorted, u64 *scratch, const DevParams &P, u64 lut_entries, u32 &counter_idx)
 {
 	if (bins.empty())
 		return 0;
@@ -506,14 +509,24 @@ int compact_group(Slot &s, const std::vector<BinPlan> &bins, const u64 *sorted, 
 		return fail(KMC_HIP_EINVAL, "too many launches for one bin");
 	const bool use_lut = lut_entries && !P.without_output && !P.kff;
 	const u32 n_sh = !use_lut ? 1u : lut_shards_for(lut_entries);
+	const u32 rec_bytes = P.sbytes + P.cbytes;
+	const u64 tile_pitch = (u64)CpCfg<SIZE>::TILE * SIZE * 8;
+	static const bool allow_two_phase = [] {
+		const char *e = getenv("KMC_HIP_TWO_PHASE"); /* 0 = always the look-back */
+		return !e || atoi(e) != 0;
+	}();
+	const bool two_phase = allow_two_phase && scratch && !P.without_output &&
+	                       ((u64)CpCfg<SIZE>::TILE / std::max<u32>(P.cutoff_min, 1) + 1) * rec_bytes <= tile_pitch;
 	GrpCompact gc = {};
 	GrpFold gf = {};
-	gc.g = (u32)bins.size();
+	GrpGather gg = {};
+	gc.g = gg.g = (u32)bins.size();
 	u64 tiles = 0;
 	for (size_t i = 0; i < bins.size(); ++i) {
 		const BinPlan &b = bins[i];
-		gc.tile_prefix[i] = (u32)tiles;
-		tiles += (b.n_rec + CpCfg<SIZE>::TILE - 1) / CpCfg<SIZE>::TILE;
+		gc.tile_prefix[i] = gg.tile_prefix[i] = (u32)tiles;
+		const u64 bin_tiles = (b.n_rec + CpCfg<SIZE>::TILE - 1) / CpCfg<SIZE>::TILE;
+		tiles += bin_tiles;
 		if (tiles > 0x7FFFFFFFull)
 			return fail(KMC_HIP_EINVAL, "bin too large");
 		u64 *lut_base = b.d_lut;
@@ -533,12 +546,23 @@ int compact_group(Slot &s, const std::vector<BinPlan> &bins, const u64 *sorted, 
 		gf.stats[i] = b.d_stats;
 		gf.lut_base[i] = lut_base;
 		gf.lut_out[i] = b.d_lut;
+		gc.scratch[i] = two_phase ? (uint8_t *)(scratch + b.rec_off * SIZE) : nullptr;
+		gf.status[i] = gc.status[i];
+		gf.n_tiles[i] = (u32)bin_tiles;
+		gf.out_bytes[i] = b.d_out_bytes;
+		gf.out_capacity[i] = b.out_capacity;
+		gg.scratch[i] = gc.scratch[i];
+		gg.prefix[i] = gc.status[i];
+		gg.out[i] = b.d_out;
+		gg.out_capacity[i] = b.out_capacity;
 	}
-	gc.tile_prefix[bins.size()] = (u32)tiles;
+	gc.tile_prefix[bins.size()] = gg.tile_prefix[bins.size()] = (u32)tiles;
 	k_compact<SIZE><<<dim3((u32)tiles), dim3(CP_BLOCK), 0, s.stream>>>(gc, P, n_sh, lut_entries, counters + counter_idx, err,
-	                                                                   P.lut_prefix_len ? (u32)((1ull << (2 * P.lut_prefix_len)) - 1) : 0u);
+	                                                                   P.lut_prefix_len ? (u32)((1ull << (2 * P.lut_prefix_len)) - 1) : 0u, two_phase ? 1u : 0u);
 	counter_idx += 1;
-	k_compact_fold<<<dim3((u32)bins.size()), dim3(256), 0, s.stream>>>(gf, use_lut ? n_sh : 1u, lut_entries);
+	k_compact_fold<<<dim3((u32)bins.size()), dim3(256), 0, s.stream>>>(gf, use_lut ? n_sh : 1u, lut_entries, two_phase ? 1u : 0u, rec_bytes, err);
+	if (two_phase)
+		k_compact_gather<<<dim3((u32)((tiles + 3) / 4)), dim3(256), 0, s.stream>>>(gg, rec_bytes, tile_pitch);
 	HIPCHK(hipGetLastError());
 	return 0;
 }
@@ -651,7 +675,7 @@ int run_group_device_t(Slot &s, const DevParams &P, const kmc_hip_bin_desc *cons
 			HIPCHK(hipEventRecord(s.ev[3], s.stream));
 		HIPCHK(hipEventRecord(s.ev[4], s.stream));
 	}
-	if ((rc = compact_group<SIZE>(s, bins, sorted, P, lut_entries, counter_idx)))
+	if ((rc = compact_group<SIZE>(s, bins, sorted, N ? (sorted == (u64 *)s.recA.p ? (u64 *)s.recB.p : (u64 *)s.recA.p) : nullptr, P, lut_entries, counter_idx)))
 		return rc;
 	if (s.timed)
 		HIPCHK(hipEventRecord(s.ev[5], s.stream));
@@ -752,7 +776,7 @@ int debug_compact_t(Slot &s, const DevParams &P, u64 n, u64 out_capacity, u64 lu
 	bins[0].d_stats = small_ptr<u64>(s, SM_STATS);
 	bins[0].d_out_bytes = small_ptr<u64>(s, SM_OUTBYTES);
 	u32 counter_idx = 0;
-	return compact_group<SIZE>(s, bins, (const u64 *)s.recA.p, P, lut_entries, counter_idx);
+	return compact_group<SIZE>(s, bins, (const u64 *)s.recA.p, nullptr, P, lut_entries, counter_idx);
 }
 } // namespace
 

@@ -114,10 +114,25 @@ void compact_t(const DevParams &P, const u64 *sorted, u64 n, uint8_t *out, u64 o
 	else if (use_lut)
 		memset(lut, 0, lut_entries * 8);
 	u32 counter = 0;
+	const u32 rec_bytes = P.sbytes + P.cbytes;
+	const u64 tile_pitch = (u64)CpCfg<SIZE>::TILE * SIZE * 8;
+	const bool two_phase = !getenv("KMC_EMU_NO_TWO_PHASE") && !P.without_output &&
+	                       ((u64)CpCfg<SIZE>::TILE / std::max<u32>(P.cutoff_min, 1) + 1) * rec_bytes <= tile_pitch; /* the host's rule (compact_group) */
+	std::vector<uint8_t> scratch(two_phase ? c_tiles * tile_pitch + 256 : 1, 0xEE);
 	GrpCompact gc = {};
 	GrpFold gf = {};
-	gc.g = 1;
-	gc.tile_prefix[1] = (u32)c_tiles;
+	GrpGather gg = {};
+	gc.g = gg.g = 1;
+	gc.tile_prefix[1] = gg.tile_prefix[1] = (u32)c_tiles;
+	gc.scratch[0] = two_phase ? scratch.data() : nullptr;
+	gf.status[0] = status.data();
+	gf.n_tiles[0] = (u32)c_tiles;
+	gf.out_bytes[0] = out_bytes;
+	gf.out_capacity[0] = out_capacity;
+	gg.scratch[0] = scratch.data();
+	gg.prefix[0] = status.data();
+	gg.out[0] = out;
+	gg.out_capacity[0] = out_capacity;
 	gc.S[0] = sorted;
 	gc.n[0] = gf.n[0] = n;
 	gc.out[0] = out;
@@ -131,9 +146,11 @@ void compact_t(const DevParams &P, const u64 *sorted, u64 n, uint8_t *out, u64 o
 	gf.lut_base[0] = lut_base;
 	gf.lut_out[0] = lut;
 	hipemu::launch(dim3((u32)c_tiles), dim3(CP_BLOCK), 0, [&] {
-		k_compact<SIZE>(gc, P, n_sh, lut_entries, &counter, err, P.lut_prefix_len ? (u32)((1ull << (2 * P.lut_prefix_len)) - 1) : 0u);
+		k_compact<SIZE>(gc, P, n_sh, lut_entries, &counter, err, P.lut_prefix_len ? (u32)((1ull << (2 * P.lut_prefix_len)) - 1) : 0u, two_phase ? 1u : 0u);
 	});
-	hipemu::launch(dim3(1), dim3(256), 0, [&] { k_compact_fold(gf, use_lut ? n_sh : 1u, lut_entries); });
+	hipemu::launch(dim3(1), dim3(256), 0, [&] { k_compact_fold(gf, use_lut ? n_sh : 1u, lut_entries, two_phase ? 1u : 0u, rec_bytes, err); });
+	if (two_phase)
+		hipemu::launch(dim3((u32)((c_tiles + 3) / 4)), dim3(256), 0, [&] { k_compact_gather(gg, rec_bytes, tile_pitch); });
 }
 
 template <int SIZE>
@@ -218,10 +235,16 @@ int group_compact_t(const DevParams &P, int g, const u64 *sorted, const u64 *n_r
 {
 	const bool use_lut = lut_entries && !P.without_output && !P.kff;
 	const u32 n_sh = use_lut ? lut_shards_for(lut_entries) : 1u;
+	const u32 rec_bytes = P.sbytes + P.cbytes;
+	const u64 tile_pitch = (u64)CpCfg<SIZE>::TILE * SIZE * 8;
+	const bool two_phase = !getenv("KMC_EMU_NO_TWO_PHASE") && !P.without_output &&
+	                       ((u64)CpCfg<SIZE>::TILE / std::max<u32>(P.cutoff_min, 1) + 1) * rec_bytes <= tile_pitch;
 	GrpCompact gc = {};
 	GrpFold gf = {};
-	gc.g = (u32)g;
+	GrpGather gg = {};
+	gc.g = gg.g = (u32)g;
 	std::vector<std::vector<u64>> lutsh(g), status(g), shards(g);
+	std::vector<std::vector<uint8_t>> scratch(g);
 	u64 tiles = 0, rec_off = 0;
 	for (int i = 0; i < g; ++i) {
 		const u64 nt = (n_recs[i] + CpCfg<SIZE>::TILE - 1) / CpCfg<SIZE>::TILE;
@@ -234,8 +257,18 @@ int group_compact_t(const DevParams &P, int g, const u64 *sorted, const u64 *n_r
 			lut_base = lutsh[i].data();
 		else if (use_lut)
 			memset(lut_i, 0, lut_entries * 8);
-		gc.tile_prefix[i] = (u32)tiles;
+		gc.tile_prefix[i] = gg.tile_prefix[i] = (u32)tiles;
 		tiles += nt;
+		scratch[i].assign(two_phase ? nt * tile_pitch + 256 : 1, 0xEE);
+		gc.scratch[i] = two_phase ? scratch[i].data() : nullptr;
+		gf.status[i] = status[i].data();
+		gf.n_tiles[i] = (u32)nt;
+		gf.out_bytes[i] = out_bytes + i;
+		gf.out_capacity[i] = out_capacity;
+		gg.scratch[i] = scratch[i].data();
+		gg.prefix[i] = status[i].data();
+		gg.out[i] = outs[i];
+		gg.out_capacity[i] = out_capacity;
 		gc.S[i] = sorted + rec_off * SIZE;
 		gc.n[i] = gf.n[i] = n_recs[i];
 		gc.out[i] = outs[i];
@@ -250,12 +283,14 @@ int group_compact_t(const DevParams &P, int g, const u64 *sorted, const u64 *n_r
 		gf.lut_out[i] = lut_i;
 		rec_off += n_recs[i];
 	}
-	gc.tile_prefix[g] = (u32)tiles;
+	gc.tile_prefix[g] = gg.tile_prefix[g] = (u32)tiles;
 	u32 counter = 0;
 	hipemu::launch(dim3((u32)tiles), dim3(CP_BLOCK), 0, [&] {
-		k_compact<SIZE>(gc, P, n_sh, lut_entries, &counter, err, P.lut_prefix_len ? (u32)((1ull << (2 * P.lut_prefix_len)) - 1) : 0u);
+		k_compact<SIZE>(gc, P, n_sh, lut_entries, &counter, err, P.lut_prefix_len ? (u32)((1ull << (2 * P.lut_prefix_len)) - 1) : 0u, two_phase ? 1u : 0u);
 	});
-	hipemu::launch(dim3((u32)g), dim3(256), 0, [&] { k_compact_fold(gf, use_lut ? n_sh : 1u, lut_entries); });
+	hipemu::launch(dim3((u32)g), dim3(256), 0, [&] { k_compact_fold(gf, use_lut ? n_sh : 1u, lut_entries, two_phase ? 1u : 0u, rec_bytes, err); });
+	if (two_phase)
+		hipemu::launch(dim3((u32)((tiles + 3) / 4)), dim3(256), 0, [&] { k_compact_gather(gg, rec_bytes, tile_pitch); });
 	return 0;
 }
 
