@@ -236,3 +236,37 @@ def test_emulated_group_with_tiny_bins():
     for i, (img, nk, _) in enumerate(bins):
         w_out, w_lut, w_st = O.process_bin(p, img, nk)
         assert np.array_equal(got[i][2], w_st) and np.array_equal(got[i][0], w_out) and np.array_equal(got[i][1], w_lut), i
+
+
+def _valid_prefix_lens(k):
+    return [p for p in range(0, min(k, 8)) if p == 0 or ((k - p) % 4 == 0 and p < k)]
+
+
+@pytest.mark.parametrize("seed", range(24))
+def test_emulated_whole_bin_random_parameters(seed):
+    """a seeded sweep over the parameter space of CKMCParams that reaches the kernels: k (1-4 record words), strands, cutoffs, counter width,
+    LUT prefix length / KFF, output on or off — every stage emulated, the result against oracle_process_bin. Both output modes of the
+    compaction occur (the two-phase one whenever a tile's span is certain to hold its records)."""
+    rng = np.random.default_rng(1000 + seed)
+    k = int(rng.choice([9, 14, 21, 25, 27, 28, 31, 32, 33, 40, 55, 64, 70, 100, 127]))
+    both = int(rng.integers(0, 2))
+    pls = _valid_prefix_lens(k)
+    pl = int(rng.choice(pls))
+    kff = 1 if pl == 0 else 0
+    cutoff_min = int(rng.choice([1, 1, 2, 3, 5]))
+    cutoff_max = int(rng.choice([10**9, 10**9, 6, 40]))
+    counter_max = int(rng.choice([255, 255, 1, 3, 70000, 2**32 - 1]))
+    without_output = int(rng.random() < 0.1)
+    genome = rng.integers(0, 4, size=int(rng.integers(600, 4000)), dtype=np.uint8)
+    img, nk, packs = binsynth.random_bin(rng, k, int(rng.integers(1, 500)), max_extra=int(rng.choice([0, 10, 60, 255])), genome=genome if genome.size > k + 260 else None,
+                                         pack_size=int(rng.choice([1, 50, 4096])))
+    p = O.make_params(k, both_strands=both, cutoff_min=cutoff_min, cutoff_max=max(cutoff_max, cutoff_min), counter_max=counter_max, lut_prefix_len=pl,
+                      output_type=kff, without_output=without_output)
+    r = emu.run(p, 7, img, nk, packs)
+    assert r["err"] == 0
+    w_out, w_lut, w_st = O.process_bin(p, img, nk)
+    assert np.array_equal(r["stats"], w_st), (k, both, pl, cutoff_min, cutoff_max, counter_max, r["stats"], w_st)
+    if not without_output:
+        assert np.array_equal(r["out"], w_out), (k, both, pl, cutoff_min, cutoff_max, counter_max)
+        if not kff:
+            assert np.array_equal(r["lut"], w_lut)
