@@ -501,6 +501,8 @@ def main():
                                  "top radix digit), so a launch covers that many bins; every 8th group of a stream carries the event pairs (an event costs "
                                  "stream time); big bins run on one stream, so launches do not overlap and the event durations are the kernel's own"},
             "phases_ms_last_bin_slot0": timings,
+            "phases_note": "event intervals of the last timed GROUP of bins on stream slot 0 (bins_per_sort bins; one launch each of parse+index, expand, "
+                           "the scatter passes, compaction + fold + gather)",
             "setup_s": w.setup_s,
         }
     # ---- after the timed region: overlapped streams, host boundary, secondary workloads, the reference (rank 0 of a 1-GPU run only)
