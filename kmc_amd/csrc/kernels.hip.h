@@ -1185,6 +1185,9 @@ __device__ __forceinline__ u64 wave_first(u64 v) /* lane 0's value in every lane
 
 constexpr int CP_STAGE = 16384; /* bytes of output assembled in LDS per window */
 constexpr int CP_SHARDS = 32; /* tally shards: same-address device atomics serialise at ~11 ns each */
+#ifndef CP_FOLD_CHUNK
+#define CP_FOLD_CHUNK 4096 /* tile counts scanned per round of k_compact_fold (two-phase output) */
+#endif
 #ifndef CP_TILE_FROM_BLOCKIDX
 #define CP_TILE_FROM_BLOCKIDX 0
 #endif
@@ -1586,20 +1589,35 @@ __global__ void __launch_bounds__(256) k_compact_fold(const GrpFold gf, u32 lut_
 		__shared__ u64 s_scan[5];
 		u64 *st = gf.status[bin];
 		const u32 nt = gf.n_tiles[bin];
-		/* each thread owns a run of consecutive tiles: one workgroup scan for the whole bin (~6000 tiles at 48 M k-mers) */
-		const u32 per = (nt + 255) / 256, i_lo = threadIdx.x * per;
-		u64 sum = 0;
-		for (u32 j = 0; j < per; ++j)
-			if (i_lo + j < nt)
-				sum += st[i_lo + j];
-		u64 carry;
-		u64 run = block_excl_sum<4, u64>(sum, s_scan, carry);
-		for (u32 j = 0; j < per; ++j)
-			if (i_lo + j < nt) {
-				const u64 v = st[i_lo + j];
-				st[i_lo + j] = run;
+		/* 4096 tiles per round: coalesced into LDS, each thread scans its 16 consecutive words there, one workgroup scan, coalesced back
+		 * (a 48 M k-mer bin is ~12 000 tiles; a strided scan straight from memory took 39 us per group) */
+		constexpr u32 CH = CP_FOLD_CHUNK, PER = CH / 256;
+		static_assert(CH % 256 == 0 && CH >= 256, "CP_FOLD_CHUNK");
+		__shared__ u64 s_buf[CH];
+		u64 carry = 0;
+		for (u32 c0 = 0; c0 < nt; c0 += CH) {
+			const u32 cn = (nt - c0) < CH ? (nt - c0) : CH;
+			for (u32 i = threadIdx.x; i < CH; i += 256)
+				s_buf[i] = i < cn ? st[c0 + i] : 0;
+			__syncthreads();
+			u64 sum = 0;
+#pragma unroll
+			for (u32 j = 0; j < PER; ++j)
+				sum += s_buf[threadIdx.x * PER + j];
+			u64 total;
+			u64 run = carry + block_excl_sum<4, u64>(sum, s_scan, total);
+#pragma unroll
+			for (u32 j = 0; j < PER; ++j) {
+				const u64 v = s_buf[threadIdx.x * PER + j];
+				s_buf[threadIdx.x * PER + j] = run;
 				run += v;
 			}
+			__syncthreads();
+			for (u32 i = threadIdx.x; i < cn; i += 256)
+				st[c0 + i] = s_buf[i];
+			carry += total;
+			__syncthreads();
+		}
 		if (threadIdx.x == 0) {
 			st[nt] = carry;
 			*gf.out_bytes[bin] = carry * rec_bytes;

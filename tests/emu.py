@@ -15,7 +15,7 @@ EMU_DIR = os.path.join(ROOT, "tests", "hipemu")
 # Two builds of the same kernel source: the product's tile geometry (512-thread workgroups: hundreds of OS threads per emulated workgroup,
 # slow) and a small one (128/256-thread workgroups, 4 KB expand slices) that runs the same code paths ~10x faster. Tests use the small one
 # unless they ask for "product".
-GEOMETRY_FLAGS = {"small": ["-DCP_BLOCK_THREADS=128", "-DEXP_BLOCK_THREADS=256", "-DEXP_CHUNK_BYTES=4096", "-DRS_BLOCK_THREADS=256"], "product": []}
+GEOMETRY_FLAGS = {"small": ["-DCP_BLOCK_THREADS=128", "-DEXP_BLOCK_THREADS=256", "-DEXP_CHUNK_BYTES=4096", "-DRS_BLOCK_THREADS=256", "-DCP_FOLD_CHUNK=256"], "product": []}
 _LIBS = {}
 
 

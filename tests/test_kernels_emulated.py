@@ -270,3 +270,19 @@ def test_emulated_whole_bin_random_parameters(seed):
         assert np.array_equal(r["out"], w_out), (k, both, pl, cutoff_min, cutoff_max, counter_max)
         if not kff:
             assert np.array_equal(r["lut"], w_lut)
+
+
+def test_emulated_two_phase_output_over_several_fold_chunks():
+    """eight-word records make 256-record tiles in the small geometry: 330 tiles, i.e. two rounds of the fold's scan of tile counts (256 per
+    round there), then the gather of every tile's records to its place"""
+    rng = np.random.default_rng(31)
+    n = 330 * 256 - 17
+    vals = np.sort(rng.integers(0, 1 << 40, size=n // 3).astype(np.uint64))
+    keys = np.sort(rng.choice(vals, size=n))
+    srt = np.zeros((n, 8), dtype=np.uint64)
+    srt[:, 0] = keys << np.uint64(8)
+    srt[:, 7] = keys >> np.uint64(20)  # both the lowest and the highest word take part in the comparison; order stays ascending
+    order = np.lexsort(tuple(srt[:, w] for w in range(8)))
+    srt = np.ascontiguousarray(srt[order])
+    p = O.make_params(240, lut_prefix_len=4, cutoff_min=2)
+    _check_compact(p, srt)
