@@ -22,7 +22,8 @@ _LIBS = {}
 def build(geometry="small", force=False) -> str:
     so = os.path.join(EMU_DIR, f"libkmc_emu_{geometry}.so")
     srcs = [os.path.join(EMU_DIR, "emu_kernels.cpp"), os.path.join(EMU_DIR, "include", "hip", "hip_runtime.h"),
-            os.path.join(ROOT, "kmc_amd", "csrc", "kernels.hip.h"), os.path.join(ROOT, "kmc_amd", "csrc", "kmer_ops.h")]
+            os.path.join(ROOT, "kmc_amd", "csrc", "kernels.hip.h"), os.path.join(ROOT, "kmc_amd", "csrc", "kmer_ops.h"),
+            os.path.join(ROOT, "kmc_amd", "csrc", "stage1_kernels.hip.h")]
     if force or not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in srcs):
         # -fno-gnu-unique / hidden visibility / -Bsymbolic: the two geometries are two builds of the same templates; their static "LDS" arrays and
         # inline variables must not be merged across the libraries when one process loads both
@@ -44,6 +45,8 @@ def lib(geometry="small"):
         L.emu_group_front.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32]
         L.emu_group_compact.restype = C.c_int
         L.emu_group_compact.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.emu_s1_split.restype = C.c_int
+        L.emu_s1_split.argtypes = [C.c_void_p, C.c_uint64, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p]
         _LIBS[geometry] = L
     return _LIBS[geometry]
 
@@ -118,3 +121,19 @@ def group_compact(p, sorted_recs, n_recs, geometry="small"):
     pr = _params(p)
     err = lib(geometry).emu_group_compact(pr.ctypes.data, g, srt.ctypes.data, nr.ctypes.data, _ptr_array(outs), cap, ob.ctypes.data, luts.ctypes.data, stats.ctypes.data)
     return err, [(outs[i][: int(ob[i])].copy(), luts[i, :lut_n].copy(), stats[i].copy()) for i in range(g)]
+
+
+def s1_split(codes: np.ndarray, k: int, norm: np.ndarray, m: int = 9, geometry="small"):
+    """stage-1 kernels on a code stream (int8: 0..3, negative = invalid/separator). Returns (err, sig per position, sk_pos, sk_len, sk_sig)."""
+    codes = np.ascontiguousarray(codes, dtype=np.int8)
+    n = codes.size
+    sig = np.zeros(max(n, 1), dtype=np.uint32)
+    cap = n + 8
+    pos = np.zeros(cap, dtype=np.uint64)
+    ln = np.zeros(cap, dtype=np.uint32)
+    sg = np.zeros(cap, dtype=np.uint32)
+    nsk = C.c_uint64(0)
+    err = lib(geometry).emu_s1_split(codes.ctypes.data, n, k, m, np.ascontiguousarray(norm).ctypes.data, sig.ctypes.data, pos.ctypes.data, ln.ctypes.data,
+                                     sg.ctypes.data, cap, C.addressof(nsk))
+    j = nsk.value
+    return err, sig[:n], pos[:j].copy(), ln[:j].copy(), sg[:j].copy()

@@ -11,6 +11,7 @@
 #include <vector>
 
 #include "../../kmc_amd/csrc/kernels.hip.h"
+#include "../../kmc_amd/csrc/stage1_kernels.hip.h"
 
 namespace {
 
@@ -390,6 +391,22 @@ EMU_API int emu_group_compact(const unsigned *params10, int g, const u64 *sorted
 	case 2: group_compact_t<2>(P, g, sorted, n_recs, outs, out_capacity, out_bytes, luts, lut_entries, stats, &err); break;
 	default: return -1;
 	}
+	return (int)err;
+}
+
+/* stage-1 kernels: codes (0..3, negative = invalid / separator) -> signature per k-mer position, and the super-k-mers in position order.
+ * Returns the device error word; *n_sk = number of super-k-mers. */
+EMU_API int emu_s1_split(const int8_t *codes, u64 n, unsigned k, unsigned m, const u32 *norm, u32 *sig, u64 *sk_pos, u32 *sk_len, u32 *sk_sig, u64 sk_cap, u64 *n_sk)
+{
+	u32 err = 0;
+	*n_sk = 0;
+	if (!n)
+		return 0;
+	const u32 tiles = (u32)((n + S1_TILE - 1) / S1_TILE);
+	std::vector<u64> st_last(tiles, 0), st_cnt(tiles, 0);
+	u32 ticket = 0;
+	hipemu::launch(dim3(tiles), dim3(S1_BLOCK), 0, [&] { k_s1_signatures(codes, n, k, m, norm, sig); });
+	hipemu::launch(dim3(tiles), dim3(S1_BLOCK), 0, [&] { k_s1_cut(sig, n, k, st_last.data(), st_cnt.data(), &ticket, sk_pos, sk_len, sk_sig, sk_cap, n_sk, &err); });
 	return (int)err;
 }
 }

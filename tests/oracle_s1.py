@@ -26,6 +26,8 @@ def lib():
         L = C.CDLL(so)
         L.oracle_s1_norm.argtypes = [C.c_uint32, C.c_void_p]
         L.oracle_s1_is_allowed.argtypes = [C.c_uint32, C.c_uint32]
+        L.oracle_s1_split.restype = C.c_uint64
+        L.oracle_s1_split.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_uint64]
         L.oracle_s1_split_all.restype = C.c_int64
         L.oracle_s1_split_all.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64]
         _LIB = L
@@ -64,3 +66,14 @@ def split(seqs, k: int, sig_len: int = 9):
 def read_fastq_sequences(path):
     with open(path, "rb") as f:
         return [ln.rstrip(b"\r\n") for i, ln in enumerate(f) if i % 4 == 1]
+
+
+def split_stream(codes: np.ndarray, k: int, sig_len: int = 9):
+    """one code stream (reads joined by a negative separator) -> (pos, len, signature) of every super-k-mer, emission order"""
+    codes = np.ascontiguousarray(codes, dtype=np.int8)
+    norm = norm_table(sig_len)
+    cap = codes.size + 8
+    out = np.zeros((cap, 3), dtype=np.uint32)
+    n = lib().oracle_s1_split(codes.ctypes.data, codes.size, k, sig_len, norm.ctypes.data, out.ctypes.data, cap)
+    assert n <= cap
+    return out[:n, 0].copy(), out[:n, 1].copy(), out[:n, 2].copy()
