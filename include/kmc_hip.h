@@ -191,6 +191,15 @@ int kmc_hip_debug_expand(kmc_hip_ctx *ctx, int dev, const kmc_hip_bin_params *pa
 int kmc_hip_debug_compact(kmc_hip_ctx *ctx, int dev, const kmc_hip_bin_params *params, const uint64_t *sorted_recs, uint64_t n,
                           uint8_t *out_suffix, uint64_t out_capacity, uint64_t *out_bytes, uint64_t *lut, uint64_t stats[4]);
 
+/* ---- stage 1, first kernels (groundwork, NOT part of the drop-in) ----
+ * codes: one symbol per byte, 0..3 = A C G T, anything negative = N or a read boundary (join reads with one such byte). Computes on the
+ * device what CSplitter::ProcessReads (splitter.cpp:557-672) computes read by read: the minimizer signature (CMmer, kmc_api/mmer.h:25-110,
+ * signature_len 5..11) of the k-mer starting at every position -> sig[n] (0xFFFFFFFF where no valid k-mer starts), and the super-k-mers in
+ * position order -> sk_pos / sk_len (symbols: kmer_len + extra, extra <= 255) / sk_sig, *n_sk of them (KMC_HIP_ECAPACITY beyond sk_cap).
+ * The bin of a super-k-mer is s_mapper->get_bin_id(signature) (s_mapper.h, stays with the reference), its record kb_collector.cpp:57-71. */
+int kmc_hip_debug_split_reads(kmc_hip_ctx *ctx, int dev, const int8_t *codes, uint64_t n, uint32_t kmer_len, uint32_t signature_len, uint32_t *sig,
+                              uint64_t *sk_pos, uint32_t *sk_len, uint32_t *sk_sig, uint64_t sk_cap, uint64_t *n_sk);
+
 #ifdef __cplusplus
 }
 #endif

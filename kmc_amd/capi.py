@@ -71,7 +71,7 @@ SYMBOLS = [
     "kmc_hip_allreduce_stats", "kmc_hip_last_timings", "kmc_hip_scatter_totals",
     "kmc_hip_malloc", "kmc_hip_free", "kmc_hip_memcpy_h2d", "kmc_hip_memcpy_d2h",
     "kmc_hip_host_register", "kmc_hip_host_unregister", "kmc_hip_host_alloc", "kmc_hip_host_free", "kmc_hip_synchronize",
-    "kmc_hip_debug_expand", "kmc_hip_debug_compact",
+    "kmc_hip_debug_expand", "kmc_hip_debug_compact", "kmc_hip_debug_split_reads",
 ]
 
 _LIB = None
@@ -131,6 +131,7 @@ def load():
     L.kmc_hip_synchronize.argtypes = [vp, C.c_int]
     L.kmc_hip_debug_expand.argtypes = [vp, C.c_int, C.POINTER(BinParams), vp, C.c_uint64, C.c_uint64, vp, C.c_uint64, vp]
     L.kmc_hip_debug_compact.argtypes = [vp, C.c_int, C.POINTER(BinParams), vp, C.c_uint64, vp, C.c_uint64, u64p, vp, u64p]
+    L.kmc_hip_debug_split_reads.argtypes = [vp, C.c_int, vp, C.c_uint64, C.c_uint32, C.c_uint32, vp, vp, vp, vp, C.c_uint64, u64p]
     _LIB = L
     return L
 
@@ -226,6 +227,20 @@ class Context:
         self._chk(self.L.kmc_hip_debug_compact(self.h, dev, C.byref(p), _vp(r), n, _vp(out), out_capacity, C.byref(ob), _vp(lut),
                                                stats.ctypes.data_as(u64p)))
         return out[: ob.value].copy(), lut[:nl].copy(), stats
+
+    def debug_split_reads(self, codes: np.ndarray, k: int, sig_len: int = 9, dev: int = 0):
+        """stage-1 test hook: code stream (int8, negative = N / read boundary) -> (sig per position, sk_pos, sk_len, sk_sig)"""
+        codes = np.ascontiguousarray(codes, dtype=np.int8)
+        n = codes.size
+        sig = np.zeros(max(n, 1), dtype=np.uint32)
+        cap = n + 8
+        pos = np.zeros(cap, dtype=np.uint64)
+        ln = np.zeros(cap, dtype=np.uint32)
+        sg = np.zeros(cap, dtype=np.uint32)
+        nsk = C.c_uint64()
+        self._chk(self.L.kmc_hip_debug_split_reads(self.h, dev, _vp(codes), n, k, sig_len, _vp(sig), _vp(pos), _vp(ln), _vp(sg), cap, C.byref(nsk)))
+        j = nsk.value
+        return sig[:n], pos[:j].copy(), ln[:j].copy(), sg[:j].copy()
 
     # ---- device memory helpers
     def malloc(self, nbytes: int, dev: int = 0) -> int:

@@ -23,6 +23,7 @@
 
 #include "../../include/kmc_hip.h"
 #include "kernels.hip.h"
+#include "stage1_kernels.hip.h"
 
 namespace {
 
@@ -1376,6 +1377,96 @@ int kmc_hip_debug_compact(kmc_hip_ctx *ctx, int dev, const kmc_hip_bin_params *p
 	for (int i = 0; i < 4; ++i)
 		stats[i] = r.stats[i];
 	return 0;
+}
+
+/* ---- stage 1, first kernels: test hook (synchronous, own temporary buffers) ---- */
+int kmc_hip_debug_split_reads(kmc_hip_ctx *ctx, int dev, const int8_t *codes, uint64_t n, uint32_t kmer_len, uint32_t signature_len, uint32_t *sig,
+                              uint64_t *sk_pos, uint32_t *sk_len, uint32_t *sk_sig, uint64_t sk_cap, uint64_t *n_sk)
+{
+	if (int rc = set_dev(ctx, dev))
+		return rc;
+	if (!codes || !sig || !n_sk || (sk_cap && (!sk_pos || !sk_len || !sk_sig)))
+		return fail(KMC_HIP_EINVAL, "kmc_hip_debug_split_reads: NULL argument");
+	if (kmer_len < 1 || kmer_len > (uint32_t)S1_MAX_K || signature_len < 5 || signature_len > 11 || signature_len > kmer_len)
+		return fail(KMC_HIP_EINVAL, "kmc_hip_debug_split_reads: kmer_len 1..256, signature_len 5..11 and <= kmer_len");
+	*n_sk = 0;
+	if (!n)
+		return 0;
+	/* the normalisation table of kmc_api/mmer.h:39-95 (allowed m-mers, the smaller strand), built on the host */
+	const u32 special = 1u << (2 * signature_len);
+	std::vector<u32> norm(special);
+	auto allowed = [&](u32 x) {
+		if ((x & 0x3f) == 0x3f || (x & 0x3f) == 0x3b || (x & 0x3c) == 0x3c)
+			return false;
+		for (u32 j = 0; j < signature_len - 3; ++j) {
+			if ((x & 0xf) == 0)
+				return false;
+			x >>= 2;
+		}
+		return !(x == 0 || x == 0x04 || (x & 0xf) == 0);
+	};
+	for (u32 i = 0; i < special; ++i) {
+		u32 rev = 0, y = i;
+		for (u32 j = 0; j < signature_len; ++j) {
+			rev = (rev << 2) | (3 - (y & 3));
+			y >>= 2;
+		}
+		const u32 a = allowed(i) ? i : special, b = allowed(rev) ? rev : special;
+		norm[i] = a < b ? a : b;
+	}
+	Slot &s = ctx->devs[dev]->slot[0];
+	std::lock_guard<std::mutex> lck(s.mtx);
+	const u64 tiles = (n + S1_TILE - 1) / S1_TILE;
+	if (tiles > 0x7FFFFFFFull)
+		return fail(KMC_HIP_EINVAL, "too many symbols for one call");
+	void *d_codes = nullptr, *d_norm = nullptr, *d_sig = nullptr, *d_status = nullptr, *d_pos = nullptr, *d_len = nullptr, *d_ssig = nullptr, *d_small = nullptr;
+	auto release = [&] {
+		for (void *p : {d_codes, d_norm, d_sig, d_status, d_pos, d_len, d_ssig, d_small})
+			if (p)
+				(void)hipFree(p);
+	};
+#define S1CHK(call)                                                                                                    \
+	do {                                                                                                               \
+		hipError_t e__ = (call);                                                                                       \
+		if (e__ != hipSuccess) {                                                                                       \
+			release();                                                                                                 \
+			return fail_hip(#call, e__);                                                                               \
+		}                                                                                                              \
+	} while (0)
+	const u64 cap = sk_cap ? sk_cap : 1;
+	S1CHK(hipMalloc(&d_codes, n));
+	S1CHK(hipMalloc(&d_norm, (size_t)special * 4));
+	S1CHK(hipMalloc(&d_sig, n * 4));
+	S1CHK(hipMalloc(&d_status, tiles * 16));
+	S1CHK(hipMalloc(&d_pos, cap * 8));
+	S1CHK(hipMalloc(&d_len, cap * 4));
+	S1CHK(hipMalloc(&d_ssig, cap * 4));
+	S1CHK(hipMalloc(&d_small, 64));
+	S1CHK(hipMemcpyAsync(d_codes, codes, n, hipMemcpyHostToDevice, s.stream));
+	S1CHK(hipMemcpyAsync(d_norm, norm.data(), (size_t)special * 4, hipMemcpyHostToDevice, s.stream));
+	S1CHK(hipMemsetAsync(d_status, 0, tiles * 16, s.stream));
+	S1CHK(hipMemsetAsync(d_small, 0, 64, s.stream));
+	k_s1_signatures<<<dim3((u32)tiles), dim3(S1_BLOCK), 0, s.stream>>>((const int8_t *)d_codes, n, kmer_len, signature_len, (const u32 *)d_norm, (u32 *)d_sig);
+	k_s1_cut<<<dim3((u32)tiles), dim3(S1_BLOCK), 0, s.stream>>>((const u32 *)d_sig, n, kmer_len, (u64 *)d_status, (u64 *)d_status + tiles, (u32 *)d_small + 2,
+	                                                              (u64 *)d_pos, (u32 *)d_len, (u32 *)d_ssig, sk_cap, (u64 *)d_small, err_ptr(s));
+	S1CHK(hipGetLastError());
+	u64 cnt = 0;
+	S1CHK(hipMemcpyAsync(&cnt, d_small, 8, hipMemcpyDeviceToHost, s.stream));
+	S1CHK(hipMemcpyAsync(sig, d_sig, n * 4, hipMemcpyDeviceToHost, s.stream));
+	S1CHK(hipStreamSynchronize(s.stream));
+	const u64 take = cnt < sk_cap ? cnt : sk_cap;
+	if (take) {
+		S1CHK(hipMemcpy(sk_pos, d_pos, take * 8, hipMemcpyDeviceToHost));
+		S1CHK(hipMemcpy(sk_len, d_len, take * 4, hipMemcpyDeviceToHost));
+		S1CHK(hipMemcpy(sk_sig, d_ssig, take * 4, hipMemcpyDeviceToHost));
+	}
+#undef S1CHK
+	release();
+	*n_sk = cnt;
+	u32 err = 0;
+	if (int rc = read_and_clear_sticky(s, err))
+		return rc;
+	return err_to_code(err);
 }
 
 /* ---- tallies over devices: one RCCL all-reduce of 4 x uint64 ---- */
