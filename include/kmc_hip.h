@@ -200,6 +200,28 @@ int kmc_hip_debug_compact(kmc_hip_ctx *ctx, int dev, const kmc_hip_bin_params *p
 int kmc_hip_debug_split_reads(kmc_hip_ctx *ctx, int dev, const int8_t *codes, uint64_t n, uint32_t kmer_len, uint32_t signature_len, uint32_t *sig,
                               uint64_t *sk_pos, uint32_t *sk_len, uint32_t *sk_sig, uint64_t sk_cap, uint64_t *n_sk);
 
+/* ---- stage 1 on the device (groundwork, NOT yet wired into the reference's stage 1) ----
+ * Reads already in HBM as codes (as above) -> the signature bins of CSplitter::ProcessReads + CKmerBinCollector (splitter.cpp:557-672,
+ * kb_collector.cpp:57-106), left IN HBM in the layout kmc_hip_process_bins_device takes: no trip through the host, no temporary files
+ * (CKmerBinStorer, kb_storer.cpp) between the stages.
+ *   _plan : signatures, super-k-mers, per-bin totals. d_sig_to_bin[4^signature_len + 1] (device, int32) is the reference's signature map
+ *           (CSignatureMapper::get_bin_id, s_mapper.h:232; the map itself is built from stage-0 statistics and stays with the reference).
+ *           Fills the caller's HOST arrays: bin_base[n_bins + 1] (byte offset of each bin image in the buffer to allocate, 256-byte aligned;
+ *           the last entry is the buffer size incl. the readable slack stage 2 wants), bin_bytes / bin_superkmers / bin_kmers[n_bins],
+ *           pack_base[n_bins + 1] (first entry of each bin in the pack-start array; the last entry is the array length).
+ *   _emit : writes the bin images into d_bins[bin_base[n_bins]] and the pack boundaries into d_pack_start[pack_base[n_bins]]; d_codes and
+ *           d_sig_to_bin of the plan must still be valid. Afterwards bin b is
+ *           kmc_hip_bin_desc{d_bins + bin_base[b], bin_bytes[b], bin_kmers[b], d_pack_start + pack_base[b], pack_base[b+1] - pack_base[b] - 1, ...}.
+ *           Super-k-mers of a bin are NOT in read order (neither are the reference's with several splitter threads); stage 2 is order-blind.
+ *   _free : releases the plan (always call it, also after a failed _emit).
+ * One call handles up to 2^41 symbols; the plan keeps 16 bytes per super-k-mer (one per 10-40 symbols of real reads at k = 27) until _free. */
+typedef struct kmc_hip_s1_plan kmc_hip_s1_plan;
+int kmc_hip_split_reads_plan(kmc_hip_ctx *ctx, int dev, const int8_t *d_codes, uint64_t n, uint32_t kmer_len, uint32_t signature_len, const int32_t *d_sig_to_bin,
+                             uint32_t n_bins, kmc_hip_s1_plan **plan, uint64_t *bin_base, uint64_t *bin_bytes, uint64_t *bin_superkmers, uint64_t *bin_kmers,
+                             uint64_t *pack_base);
+int kmc_hip_split_reads_emit(kmc_hip_ctx *ctx, kmc_hip_s1_plan *plan, uint8_t *d_bins, uint64_t *d_pack_start);
+void kmc_hip_split_reads_free(kmc_hip_ctx *ctx, kmc_hip_s1_plan *plan);
+
 #ifdef __cplusplus
 }
 #endif

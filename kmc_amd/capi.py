@@ -72,6 +72,7 @@ SYMBOLS = [
     "kmc_hip_malloc", "kmc_hip_free", "kmc_hip_memcpy_h2d", "kmc_hip_memcpy_d2h",
     "kmc_hip_host_register", "kmc_hip_host_unregister", "kmc_hip_host_alloc", "kmc_hip_host_free", "kmc_hip_synchronize",
     "kmc_hip_debug_expand", "kmc_hip_debug_compact", "kmc_hip_debug_split_reads",
+    "kmc_hip_split_reads_plan", "kmc_hip_split_reads_emit", "kmc_hip_split_reads_free",
 ]
 
 _LIB = None
@@ -241,6 +242,30 @@ class Context:
         self._chk(self.L.kmc_hip_debug_split_reads(self.h, dev, _vp(codes), n, k, sig_len, _vp(sig), _vp(pos), _vp(ln), _vp(sg), cap, C.byref(nsk)))
         j = nsk.value
         return sig[:n], pos[:j].copy(), ln[:j].copy(), sg[:j].copy()
+
+    def split_reads_device(self, d_codes: int, n: int, k: int, sig_len: int, d_sig_to_bin: int, n_bins: int, dev: int = 0):
+        """stage 1 on the device (groundwork, include/kmc_hip.h): device code stream -> bins in HBM. Returns dict(d_bins, d_pack_start, base, bytes,
+        superkmers, kmers, pack_base); the caller frees d_bins / d_pack_start with free()."""
+        base = np.zeros(n_bins + 1, dtype=np.uint64)
+        pbase = np.zeros(n_bins + 1, dtype=np.uint64)
+        by, sk, km = (np.zeros(n_bins, dtype=np.uint64) for _ in range(3))
+        plan = C.c_void_p()
+        self.L.kmc_hip_split_reads_free.restype = None
+        self._chk(self.L.kmc_hip_split_reads_plan(self.h, dev, C.c_void_p(d_codes), C.c_uint64(n), C.c_uint32(k), C.c_uint32(sig_len), C.c_void_p(d_sig_to_bin),
+                                                  C.c_uint32(n_bins), C.byref(plan), _vp(base), _vp(by), _vp(sk), _vp(km), _vp(pbase)))
+        d_bins = d_ps = None
+        try:
+            d_bins = self.malloc(int(base[n_bins]), dev)
+            d_ps = self.malloc(int(pbase[n_bins]) * 8, dev)
+            self._chk(self.L.kmc_hip_split_reads_emit(self.h, plan, C.c_void_p(d_bins), C.c_void_p(d_ps)))
+        except Exception:
+            for q in (d_bins, d_ps):
+                if q:
+                    self.free(q, dev)
+            raise
+        finally:
+            self.L.kmc_hip_split_reads_free(self.h, plan)
+        return dict(d_bins=d_bins, d_pack_start=d_ps, base=base, bytes=by, superkmers=sk, kmers=km, pack_base=pbase)
 
     # ---- device memory helpers
     def malloc(self, nbytes: int, dev: int = 0) -> int:

@@ -1380,19 +1380,9 @@ int kmc_hip_debug_compact(kmc_hip_ctx *ctx, int dev, const kmc_hip_bin_params *p
 }
 
 /* ---- stage 1, first kernels: test hook (synchronous, own temporary buffers) ---- */
-int kmc_hip_debug_split_reads(kmc_hip_ctx *ctx, int dev, const int8_t *codes, uint64_t n, uint32_t kmer_len, uint32_t signature_len, uint32_t *sig,
-                              uint64_t *sk_pos, uint32_t *sk_len, uint32_t *sk_sig, uint64_t sk_cap, uint64_t *n_sk)
+/* the normalisation table of kmc_api/mmer.h:39-95 (allowed m-mers, the smaller strand; 4^m = no signature), built on the host */
+static std::vector<u32> s1_norm_table(uint32_t signature_len)
 {
-	if (int rc = set_dev(ctx, dev))
-		return rc;
-	if (!codes || !sig || !n_sk || (sk_cap && (!sk_pos || !sk_len || !sk_sig)))
-		return fail(KMC_HIP_EINVAL, "kmc_hip_debug_split_reads: NULL argument");
-	if (kmer_len < 1 || kmer_len > (uint32_t)S1_MAX_K || signature_len < 5 || signature_len > 11 || signature_len > kmer_len)
-		return fail(KMC_HIP_EINVAL, "kmc_hip_debug_split_reads: kmer_len 1..256, signature_len 5..11 and <= kmer_len");
-	*n_sk = 0;
-	if (!n)
-		return 0;
-	/* the normalisation table of kmc_api/mmer.h:39-95 (allowed m-mers, the smaller strand), built on the host */
 	const u32 special = 1u << (2 * signature_len);
 	std::vector<u32> norm(special);
 	auto allowed = [&](u32 x) {
@@ -1414,6 +1404,23 @@ int kmc_hip_debug_split_reads(kmc_hip_ctx *ctx, int dev, const int8_t *codes, ui
 		const u32 a = allowed(i) ? i : special, b = allowed(rev) ? rev : special;
 		norm[i] = a < b ? a : b;
 	}
+	return norm;
+}
+
+int kmc_hip_debug_split_reads(kmc_hip_ctx *ctx, int dev, const int8_t *codes, uint64_t n, uint32_t kmer_len, uint32_t signature_len, uint32_t *sig,
+                              uint64_t *sk_pos, uint32_t *sk_len, uint32_t *sk_sig, uint64_t sk_cap, uint64_t *n_sk)
+{
+	if (int rc = set_dev(ctx, dev))
+		return rc;
+	if (!codes || !sig || !n_sk || (sk_cap && (!sk_pos || !sk_len || !sk_sig)))
+		return fail(KMC_HIP_EINVAL, "kmc_hip_debug_split_reads: NULL argument");
+	if (kmer_len < 1 || kmer_len > (uint32_t)S1_MAX_K || signature_len < 5 || signature_len > 11 || signature_len > kmer_len)
+		return fail(KMC_HIP_EINVAL, "kmc_hip_debug_split_reads: kmer_len 1..256, signature_len 5..11 and <= kmer_len");
+	*n_sk = 0;
+	if (!n)
+		return 0;
+	const u32 special = 1u << (2 * signature_len);
+	const std::vector<u32> norm = s1_norm_table(signature_len);
 	Slot &s = ctx->devs[dev]->slot[0];
 	std::lock_guard<std::mutex> lck(s.mtx);
 	const u64 tiles = (n + S1_TILE - 1) / S1_TILE;
@@ -1447,8 +1454,9 @@ int kmc_hip_debug_split_reads(kmc_hip_ctx *ctx, int dev, const int8_t *codes, ui
 	S1CHK(hipMemsetAsync(d_status, 0, tiles * 16, s.stream));
 	S1CHK(hipMemsetAsync(d_small, 0, 64, s.stream));
 	k_s1_signatures<<<dim3((u32)tiles), dim3(S1_BLOCK), 0, s.stream>>>((const int8_t *)d_codes, n, kmer_len, signature_len, (const u32 *)d_norm, (u32 *)d_sig);
-	k_s1_cut<<<dim3((u32)tiles), dim3(S1_BLOCK), 0, s.stream>>>((const u32 *)d_sig, n, kmer_len, (u64 *)d_status, (u64 *)d_status + tiles, (u32 *)d_small + 2,
-	                                                              (u64 *)d_pos, (u32 *)d_len, (u32 *)d_ssig, sk_cap, (u64 *)d_small, err_ptr(s));
+	k_s1_cut<false><<<dim3((u32)tiles), dim3(S1_BLOCK), 0, s.stream>>>((const u32 *)d_sig, (const int8_t *)nullptr, 0u, (const u32 *)nullptr, n, kmer_len,
+	                                                                     (u64 *)d_status, (u64 *)d_status + tiles, (u32 *)d_small + 2, (u64 *)d_pos, (u32 *)d_len,
+	                                                                     (u32 *)d_ssig, sk_cap, (u64 *)d_small, err_ptr(s));
 	S1CHK(hipGetLastError());
 	u64 cnt = 0;
 	S1CHK(hipMemcpyAsync(&cnt, d_small, 8, hipMemcpyDeviceToHost, s.stream));
@@ -1467,6 +1475,166 @@ int kmc_hip_debug_split_reads(kmc_hip_ctx *ctx, int dev, const int8_t *codes, ui
 	if (int rc = read_and_clear_sticky(s, err))
 		return rc;
 	return err_to_code(err);
+}
+
+/* ---- stage 1 on the device: reads -> bins in HBM, ready for kmc_hip_process_bins_device ---- */
+struct kmc_hip_s1_plan {
+	int dev = 0;
+	uint32_t k = 0, n_bins = 0;
+	u64 n = 0, n_sk = 0;
+	const int8_t *d_codes = nullptr;
+	const int *d_map = nullptr;
+	void *d_pos = nullptr, *d_len = nullptr, *d_ssig = nullptr, *d_tot = nullptr, *d_lay = nullptr; /* d_lay: bin_base | pack_base | cursor */
+	bool emitted = false;
+};
+
+static void s1_plan_release(kmc_hip_s1_plan *p)
+{
+	for (void *q : {p->d_pos, p->d_len, p->d_ssig, p->d_tot, p->d_lay})
+		if (q)
+			(void)hipFree(q);
+	delete p;
+}
+
+int kmc_hip_split_reads_plan(kmc_hip_ctx *ctx, int dev, const int8_t *d_codes, uint64_t n, uint32_t kmer_len, uint32_t signature_len, const int32_t *d_sig_to_bin,
+                             uint32_t n_bins, kmc_hip_s1_plan **plan, uint64_t *bin_base, uint64_t *bin_bytes, uint64_t *bin_superkmers, uint64_t *bin_kmers,
+                             uint64_t *pack_base)
+{
+	if (int rc = set_dev(ctx, dev))
+		return rc;
+	if (!d_codes || !d_sig_to_bin || !plan || !bin_base || !bin_bytes || !bin_superkmers || !bin_kmers || !pack_base)
+		return fail(KMC_HIP_EINVAL, "kmc_hip_split_reads_plan: NULL argument");
+	if (kmer_len < 1 || kmer_len > (uint32_t)S1_MAX_K || signature_len < 5 || signature_len > 11 || signature_len > kmer_len)
+		return fail(KMC_HIP_EINVAL, "kmc_hip_split_reads_plan: kmer_len 1..256, signature_len 5..11 and <= kmer_len");
+	if (n_bins < 1 || n_bins > (uint32_t)S1_MAX_BINS)
+		return fail(KMC_HIP_EINVAL, "kmc_hip_split_reads_plan: n_bins 1..2048");
+	const u64 tiles = (n + S1_TILE - 1) / S1_TILE;
+	if (!n || tiles > 0x7FFFFFFFull)
+		return fail(KMC_HIP_EINVAL, "kmc_hip_split_reads_plan: 1 .. 2^41 symbols per call");
+	*plan = nullptr;
+	const u32 special = 1u << (2 * signature_len);
+	const std::vector<u32> norm = s1_norm_table(signature_len);
+	Slot &s = ctx->devs[dev]->slot[0];
+	std::lock_guard<std::mutex> lck(s.mtx);
+	kmc_hip_s1_plan *p = new kmc_hip_s1_plan;
+	p->dev = dev, p->k = kmer_len, p->n_bins = n_bins, p->n = n, p->d_codes = d_codes, p->d_map = d_sig_to_bin;
+	void *d_norm = nullptr, *d_status = nullptr, *d_small = nullptr;
+	auto release_tmp = [&] {
+		for (void *q : {d_norm, d_status, d_small})
+			if (q)
+				(void)hipFree(q);
+	};
+#define S1CHK(call)                                                                                                    \
+	do {                                                                                                               \
+		hipError_t e__ = (call);                                                                                       \
+		if (e__ != hipSuccess) {                                                                                       \
+			release_tmp();                                                                                             \
+			s1_plan_release(p);                                                                                        \
+			return fail_hip(#call, e__);                                                                               \
+		}                                                                                                              \
+	} while (0)
+	S1CHK(hipMalloc(&d_norm, (size_t)special * 4));
+	S1CHK(hipMalloc(&d_status, tiles * 16));
+	S1CHK(hipMalloc(&d_small, 64));
+	S1CHK(hipMalloc(&p->d_tot, (size_t)3 * n_bins * 8));
+	S1CHK(hipMalloc(&p->d_lay, (size_t)(3 * n_bins + 2) * 8));
+	S1CHK(hipMemcpyAsync(d_norm, norm.data(), (size_t)special * 4, hipMemcpyHostToDevice, s.stream));
+	/* signatures are computed inside the cutting kernel (never stored). The number of super-k-mers is only known after the cut: a first guess (one per 8 symbols; real reads give one per 10-40 at k = 27), and a
+	 * second cut with the exact number when the guess was short */
+	u64 cap = n / 8 + 4096, cnt = 0;
+	for (int attempt = 0; attempt < 2; ++attempt) {
+		S1CHK(hipMalloc(&p->d_pos, cap * 8));
+		S1CHK(hipMalloc(&p->d_len, cap * 4));
+		S1CHK(hipMalloc(&p->d_ssig, cap * 4));
+		S1CHK(hipMemsetAsync(d_status, 0, tiles * 16, s.stream));
+		S1CHK(hipMemsetAsync(d_small, 0, 64, s.stream));
+		k_s1_cut<true><<<dim3((u32)tiles), dim3(S1_BLOCK), 0, s.stream>>>((const u32 *)nullptr, d_codes, signature_len, (const u32 *)d_norm, n, kmer_len, (u64 *)d_status,
+		                                                                    (u64 *)d_status + tiles, (u32 *)d_small + 2, (u64 *)p->d_pos, (u32 *)p->d_len,
+		                                                                    (u32 *)p->d_ssig, cap, (u64 *)d_small, (u32 *)d_small + 4);
+		S1CHK(hipGetLastError());
+		u64 small[3] = {0, 0, 0}; /* count | ticket | the cut's own error word: a short guess must not poison the stream's sticky word */
+		S1CHK(hipMemcpyAsync(small, d_small, sizeof small, hipMemcpyDeviceToHost, s.stream));
+		S1CHK(hipStreamSynchronize(s.stream));
+		cnt = small[0];
+		if ((u32)small[2] & ~KERR_CAPACITY) {
+			release_tmp();
+			s1_plan_release(p);
+			return err_to_code((u32)small[2] & ~KERR_CAPACITY);
+		}
+		if (cnt <= cap)
+			break;
+		for (void **q : {&p->d_pos, &p->d_len, &p->d_ssig}) {
+			(void)hipFree(*q);
+			*q = nullptr;
+		}
+		cap = cnt;
+	}
+	p->n_sk = cnt;
+	S1CHK(hipMemsetAsync(p->d_tot, 0, (size_t)3 * n_bins * 8, s.stream));
+	u64 *tot = (u64 *)p->d_tot, *lay = (u64 *)p->d_lay;
+	const u32 sk_tiles = (u32)((cnt + S1_SK_TILE - 1) / S1_SK_TILE);
+	if (sk_tiles)
+		k_s1_bin_totals<<<dim3(sk_tiles), dim3(256), 0, s.stream>>>((const u32 *)p->d_len, (const u32 *)p->d_ssig, cnt, kmer_len, d_sig_to_bin, n_bins, tot, tot + n_bins,
+		                                                             tot + 2 * n_bins, err_ptr(s));
+	k_s1_bin_layout<<<dim3(1), dim3(256), 0, s.stream>>>(tot, n_bins, lay, lay + n_bins + 1, lay + 2 * n_bins + 2, (u64 *)nullptr);
+	S1CHK(hipGetLastError());
+	S1CHK(hipMemcpyAsync(bin_bytes, tot, (size_t)n_bins * 8, hipMemcpyDeviceToHost, s.stream));
+	S1CHK(hipMemcpyAsync(bin_superkmers, tot + n_bins, (size_t)n_bins * 8, hipMemcpyDeviceToHost, s.stream));
+	S1CHK(hipMemcpyAsync(bin_kmers, tot + 2 * n_bins, (size_t)n_bins * 8, hipMemcpyDeviceToHost, s.stream));
+	S1CHK(hipMemcpyAsync(bin_base, lay, (size_t)(n_bins + 1) * 8, hipMemcpyDeviceToHost, s.stream));
+	S1CHK(hipMemcpyAsync(pack_base, lay + n_bins + 1, (size_t)(n_bins + 1) * 8, hipMemcpyDeviceToHost, s.stream));
+	S1CHK(hipStreamSynchronize(s.stream));
+#undef S1CHK
+	release_tmp();
+	u32 err = 0;
+	if (int rc = read_and_clear_sticky(s, err)) {
+		s1_plan_release(p);
+		return rc;
+	}
+	if (err) {
+		s1_plan_release(p);
+		return err_to_code(err);
+	}
+	*plan = p;
+	return 0;
+}
+
+int kmc_hip_split_reads_emit(kmc_hip_ctx *ctx, kmc_hip_s1_plan *p, uint8_t *d_bins, uint64_t *d_pack_start)
+{
+	if (!p || !d_bins || !d_pack_start)
+		return fail(KMC_HIP_EINVAL, "kmc_hip_split_reads_emit: NULL argument");
+	if (p->emitted)
+		return fail(KMC_HIP_EINVAL, "kmc_hip_split_reads_emit: the plan was emitted already");
+	if (int rc = set_dev(ctx, p->dev))
+		return rc;
+	Slot &s = ctx->devs[p->dev]->slot[0];
+	std::lock_guard<std::mutex> lck(s.mtx);
+	u64 *tot = (u64 *)p->d_tot, *lay = (u64 *)p->d_lay;
+	const u32 nb = p->n_bins;
+	k_s1_bin_layout<<<dim3(1), dim3(256), 0, s.stream>>>(tot, nb, lay, lay + nb + 1, lay + 2 * nb + 2, (u64 *)d_pack_start);
+	const u32 sk_tiles = (u32)((p->n_sk + S1_SK_TILE - 1) / S1_SK_TILE);
+	if (sk_tiles)
+		k_s1_emit<<<dim3(sk_tiles), dim3(256), 0, s.stream>>>(p->d_codes, (const u64 *)p->d_pos, (const u32 *)p->d_len, (const u32 *)p->d_ssig, p->n_sk, p->k, p->d_map, nb,
+		                                                       lay, lay + nb + 1, lay + 2 * nb + 2, d_bins, (u64 *)d_pack_start);
+	hipError_t e = hipGetLastError();
+	if (e == hipSuccess)
+		e = hipStreamSynchronize(s.stream);
+	if (e != hipSuccess)
+		return fail_hip("k_s1_emit", e);
+	p->emitted = true;
+	u32 err = 0;
+	if (int rc = read_and_clear_sticky(s, err))
+		return rc;
+	return err_to_code(err);
+}
+
+void kmc_hip_split_reads_free(kmc_hip_ctx *ctx, kmc_hip_s1_plan *p)
+{
+	if (!p)
+		return;
+	if (ctx)
+		(void)set_dev(ctx, p->dev);
+	s1_plan_release(p);
 }
 
 /* ---- tallies over devices: one RCCL all-reduce of 4 x uint64 ---- */

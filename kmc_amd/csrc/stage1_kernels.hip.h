@@ -1,6 +1,6 @@
 /*
  * kmc_amd/csrc/stage1_kernels.hip.h — FIRST kernels of KMC's STAGE 1 on gfx950 (groundwork, not yet a drop-in:
- * no bin scatter, no FASTQ parsing, reachable only through the test hook kmc_hip_debug_split_reads).
+ * no FASTQ parsing, no hand-over to stage 2 yet, reachable only through the test hook kmc_hip_debug_split_reads).
  *
  * What the reference does (kmc_core/splitter.cpp:557-672, CSplitter::ProcessReads) is a sequential scan per read with a two-variable state
  * (current signature, its position). Its RESULT has a data-parallel description, which oracle/stage1_oracle.c's line-by-line restatement
@@ -12,8 +12,10 @@
  *   - a super-k-mer is a maximal run of consecutive valid k-mers with one signature value, cut into pieces of 256 k-mers counted from the
  *     run's start (one byte holds the number of extra symbols, splitter.cpp:651-658); its bin record is kb_collector.cpp:57-71.
  *
- *   k_s1_signatures : codes -> signature per k-mer position (0xFFFFFFFF where no valid k-mer starts)
- *   k_s1_cut        : signatures -> the super-k-mers in position order: first symbol, length in symbols, signature
+ *   k_s1_signatures : codes -> signature per k-mer position (0xFFFFFFFF where no valid k-mer starts); only the test hook stores them
+ *   k_s1_cut<FUSED> : signatures (from memory, or computed by the tile itself) -> the super-k-mers in position order: first symbol,
+ *                     length in symbols, signature
+ *   k_s1_bin_totals / k_s1_bin_layout / k_s1_emit : super-k-mers -> bin records, scattered into per-bin byte streams (see below)
  * Both are tile-parallel; k_s1_cut carries "where did the current run start" and "how many super-k-mers so far" across tiles with two
  * decoupled look-backs (max and sum) over 64-bit status words.
  */
@@ -26,20 +28,23 @@ constexpr int S1_BLOCK = 256, S1_PER = 4, S1_TILE = S1_BLOCK * S1_PER; /* positi
 constexpr int S1_MAX_K = 256;
 constexpr u32 S1_NOSIG = 0xFFFFFFFFu;
 
-/* norm[] (4^m uint32) lives in global memory: 1 MB at m = 9, L2-resident, one gather per position */
-__global__ void __launch_bounds__(S1_BLOCK) k_s1_signatures(const int8_t *__restrict__ codes, u64 n, u32 k, u32 m, const u32 *__restrict__ norm,
-                                                             u32 *__restrict__ sig)
+/* Signatures of the k-mers that start at positions base .. base + cnt - 1 (base may be -1; a position outside [0, n) has none) into
+ * s_sig[0 .. cnt), cnt <= S1_TILE + 2. All threads of the block call; the result is visible to all of them on return.
+ * norm[] (4^m uint32) lives in global memory: 1 MB at m = 9, L2-resident, one gather per position. */
+struct S1SigLds {
+	int8_t c[S1_TILE + 2 + S1_MAX_K];    /* symbols of the span: cnt + k - 1 */
+	u32 mm[S1_TILE + 2 + S1_MAX_K];      /* norm of the m-mer at each position */
+	u32 bad[S1_TILE + 2 + S1_MAX_K + 1]; /* exclusive prefix count of invalid symbols */
+	u32 tmp[S1_BLOCK / 64 + 1];
+};
+__device__ __forceinline__ void s1_signatures_to_lds(const int8_t *__restrict__ codes, u64 n, long long base, u32 cnt, u32 k, u32 m, const u32 *__restrict__ norm,
+                                                     S1SigLds &L, u32 *s_sig)
 {
-	__shared__ int8_t s_c[S1_TILE + S1_MAX_K];     /* symbols of the tile + the k - 1 after it */
-	__shared__ u32 s_mm[S1_TILE + S1_MAX_K];       /* norm of the m-mer at each position */
-	__shared__ u32 s_bad[S1_TILE + S1_MAX_K + 1];  /* exclusive prefix count of invalid symbols */
-	__shared__ u32 s_tmp[S1_BLOCK / 64 + 1];
 	const u32 tid = threadIdx.x;
-	const u64 t0 = (u64)blockIdx.x * S1_TILE;
-	const u32 span = S1_TILE + k - 1; /* symbols this tile looks at */
+	const u32 span = cnt + k - 1; /* symbols looked at */
 	for (u32 i = tid; i < span; i += S1_BLOCK) {
-		const u64 p = t0 + i;
-		s_c[i] = p < n ? codes[p] : (int8_t)-1;
+		const long long p = base + (long long)i;
+		L.c[i] = (p >= 0 && (u64)p < n) ? codes[p] : (int8_t)-1;
 	}
 	__syncthreads();
 	/* prefix count of invalid symbols over the span: thread t owns ceil(span / 256) consecutive symbols */
@@ -47,45 +52,56 @@ __global__ void __launch_bounds__(S1_BLOCK) k_s1_signatures(const int8_t *__rest
 		const u32 per = (span + S1_BLOCK - 1) / S1_BLOCK, lo = tid * per;
 		u32 c = 0;
 		for (u32 j = 0; j < per; ++j)
-			if (lo + j < span && s_c[lo + j] < 0)
+			if (lo + j < span && L.c[lo + j] < 0)
 				++c;
 		u32 total;
-		u32 run = block_excl_sum<S1_BLOCK / 64, u32>(c, s_tmp, total);
+		u32 run = block_excl_sum<S1_BLOCK / 64, u32>(c, L.tmp, total);
 		for (u32 j = 0; j < per; ++j)
 			if (lo + j < span) {
-				s_bad[lo + j] = run;
-				run += s_c[lo + j] < 0 ? 1u : 0u;
+				L.bad[lo + j] = run;
+				run += L.c[lo + j] < 0 ? 1u : 0u;
 			}
 		if (tid == S1_BLOCK - 1)
-			s_bad[span] = total;
+			L.bad[span] = total;
 	}
-	/* norm of every m-mer that starts in the tile or in the k - m positions after it */
-	const u32 n_mm = S1_TILE + k - m;
+	/* norm of every m-mer that starts at one of the cnt positions or in the k - m positions after them */
+	const u32 n_mm = cnt + k - m;
 	for (u32 i = tid; i < n_mm; i += S1_BLOCK) {
 		u32 x = 0;
 		bool ok = true;
 		for (u32 j = 0; j < m; ++j) {
-			const int8_t c = s_c[i + j];
+			const int8_t c = L.c[i + j];
 			ok = ok && c >= 0;
 			x = (x << 2) | (u32)(c & 3);
 		}
-		s_mm[i] = ok ? norm[x] : S1_NOSIG;
+		L.mm[i] = ok ? norm[x] : S1_NOSIG;
 	}
 	__syncthreads();
-	for (u32 i = tid; i < (u32)S1_TILE; i += S1_BLOCK) {
-		const u64 q = t0 + i;
-		if (q >= n)
-			break;
-		u32 s = S1_NOSIG;
-		if (q + k <= n && s_bad[i + k] == s_bad[i]) { /* a valid k-mer starts here */
+	for (u32 i = tid; i < cnt; i += S1_BLOCK) {
+		u32 sg = S1_NOSIG;
+		if (L.bad[i + k] == L.bad[i]) { /* k valid symbols: a k-mer starts here */
 			const u32 w = k - m + 1;
 			for (u32 j = 0; j < w; ++j) {
-				const u32 v = s_mm[i + j];
-				s = v < s ? v : s;
+				const u32 v = L.mm[i + j];
+				sg = v < sg ? v : sg;
 			}
 		}
-		sig[q] = s;
+		s_sig[i] = sg;
 	}
+	__syncthreads();
+}
+
+/* test hook path: the signature of every position to global memory */
+__global__ void __launch_bounds__(S1_BLOCK) k_s1_signatures(const int8_t *__restrict__ codes, u64 n, u32 k, u32 m, const u32 *__restrict__ norm,
+                                                             u32 *__restrict__ sig)
+{
+	__shared__ S1SigLds L;
+	__shared__ u32 s_sig[S1_TILE + 2];
+	const u64 t0 = (u64)blockIdx.x * S1_TILE;
+	s1_signatures_to_lds(codes, n, (long long)t0, S1_TILE, k, m, norm, L, s_sig);
+	for (u32 i = threadIdx.x; i < (u32)S1_TILE; i += S1_BLOCK)
+		if (t0 + i < n)
+			sig[t0 + i] = s_sig[i];
 }
 
 /* decoupled look-back like lookback64, but the combination is "the latest non-zero value" (value = position + 1 of the last run start):
@@ -136,10 +152,13 @@ __device__ __forceinline__ u64 lookback64_last(u64 *status, u32 tile, u64 own_la
 }
 
 /* status_last / status_cnt: one zeroed u64 per tile each. sk_* receive the super-k-mers in position order; *n_sk their number (written by
- * the last tile). sk_cap bounds the writes (KERR_CAPACITY beyond it). */
-__global__ void __launch_bounds__(S1_BLOCK) k_s1_cut(const u32 *__restrict__ sig, u64 n, u32 k, u64 *status_last, u64 *status_cnt, u32 *ticket_ctr,
-                                                      u64 *__restrict__ sk_pos, u32 *__restrict__ sk_len, u32 *__restrict__ sk_sig, u64 sk_cap, u64 *n_sk,
-                                                      u32 *err)
+ * the last tile). sk_cap bounds the writes (KERR_CAPACITY beyond it).
+ * FUSED = false: signatures come from `sig` (k_s1_signatures ran before; codes, m, norm unused). FUSED = true: the tile computes the S1_TILE + 2
+ * signatures it needs in LDS itself (sig unused): 1 byte per symbol read instead of 4 written + 4 read. */
+template <bool FUSED>
+__global__ void __launch_bounds__(S1_BLOCK) k_s1_cut(const u32 *__restrict__ sig, const int8_t *__restrict__ codes, u32 m, const u32 *__restrict__ norm, u64 n, u32 k,
+                                                      u64 *status_last, u64 *status_cnt, u32 *ticket_ctr, u64 *__restrict__ sk_pos, u32 *__restrict__ sk_len,
+                                                      u32 *__restrict__ sk_sig, u64 sk_cap, u64 *n_sk, u32 *err)
 {
 	__shared__ u64 s_tmp64[S1_BLOCK / 64 + 1];
 	__shared__ u32 s_tmp32[S1_BLOCK / 64 + 1];
@@ -155,10 +174,19 @@ __global__ void __launch_bounds__(S1_BLOCK) k_s1_cut(const u32 *__restrict__ sig
 		return;
 	const u64 t0 = (u64)tile * S1_TILE + (u64)tid * S1_PER; /* this thread's S1_PER consecutive positions */
 	u32 s[S1_PER + 2];                                        /* sig[t0 - 1 .. t0 + S1_PER] */
+	if constexpr (FUSED) {
+		__shared__ S1SigLds L;
+		__shared__ u32 s_sig[S1_TILE + 2];
+		s1_signatures_to_lds(codes, n, (long long)tile * S1_TILE - 1, S1_TILE + 2, k, m, norm, L, s_sig);
 #pragma unroll
-	for (int j = 0; j < S1_PER + 2; ++j) {
-		const long long q = (long long)t0 - 1 + j;
-		s[j] = (q >= 0 && (u64)q < n) ? sig[q] : S1_NOSIG;
+		for (int j = 0; j < S1_PER + 2; ++j)
+			s[j] = s_sig[tid * S1_PER + j];
+	} else {
+#pragma unroll
+		for (int j = 0; j < S1_PER + 2; ++j) {
+			const long long q = (long long)t0 - 1 + j;
+			s[j] = (q >= 0 && (u64)q < n) ? sig[q] : S1_NOSIG;
+		}
 	}
 	/* run starts inside this thread's positions: valid, and the k-mer before is invalid or has another signature */
 	u64 last1 = 0; /* position + 1 of the thread's last run start */
@@ -225,6 +253,152 @@ __global__ void __launch_bounds__(S1_BLOCK) k_s1_cut(const u32 *__restrict__ sig
 				atomicOr(err, KERR_CAPACITY);
 			++idx;
 		}
+}
+
+/* ------------------------------------------------------------------------------------------------ bin scatter
+ * super-k-mers -> bin records ([len - k][ceil(len/4) bytes of 2-bit symbols, first symbol in bits 7:6], kb_collector.cpp:57-71) in per-bin
+ * byte streams laid out one after the other in ONE buffer, each with the list of expander-pack boundaries stage 2 wants: what
+ * kmc_hip_process_bins_device takes as kmc_hip_bin_desc {d_superkmers, size, n_rec, d_pack_start, n_packs}.
+ *   k_s1_bin_totals : bytes, super-k-mers and k-mers per bin (LDS counters per workgroup, one global atomic per bin a workgroup touched)
+ *   k_s1_bin_layout : one workgroup: bin_base[b] (256-byte aligned; stage 2 stages the image with aligned 16-byte loads), the bin's slice of
+ *                     the pack-start array (ceil(bytes / S1_PACK_BYTES) packs + the closing entry), cursors at the bases
+ *   k_s1_emit       : a workgroup reserves, per bin it touches, ONE contiguous segment for its tile's records (global cursor atomic) and
+ *                     writes the records of the tile into their segments in arbitrary order. A segment starts on a record boundary, so the
+ *                     segment that covers the j-th multiple of S1_PACK_BYTES of its bin supplies pack boundary j (queues.h:376-396: a pack
+ *                     is any run of whole records): one boundary per multiple, none missing, packs of at most 2 S1_PACK_BYTES.
+ * The order of super-k-mers inside a bin is therefore not the read order. The reference's is not either with more than one splitter thread
+ * (each thread flushes its own buffers, kb_collector.cpp:88-106), and stage 2 sees only the multiset of k-mers. */
+#ifndef S1_SK_TILE_N
+#define S1_SK_TILE_N 1024
+#endif
+#ifndef S1_PACK_BYTES_N
+#define S1_PACK_BYTES_N (1u << 18)
+#endif
+constexpr int S1_SK_TILE = S1_SK_TILE_N;      /* super-k-mers per workgroup of k_s1_bin_totals / k_s1_emit */
+constexpr int S1_MAX_BINS = 2048;             /* KMC allows -n up to 2000 bins */
+constexpr u32 S1_PACK_BYTES = S1_PACK_BYTES_N; /* > the bytes one tile can put into one bin (1024 records of <= 1 + (256 + 255 + 3) / 4 bytes): a
+                                                * segment covers at most one multiple */
+constexpr u32 S1_BIN_ALIGN = 256;
+static_assert((u32)S1_SK_TILE * (1u + ((u32)S1_MAX_K + 255u + 3u) / 4u) < S1_PACK_BYTES, "a tile's segment must cover at most one pack boundary");
+
+__global__ void __launch_bounds__(256) k_s1_bin_totals(const u32 *__restrict__ sk_len, const u32 *__restrict__ sk_sig, u64 n_sk, u32 k, const int *__restrict__ sig_to_bin,
+                                                        u32 n_bins, u64 *__restrict__ bin_bytes, u64 *__restrict__ bin_sk, u64 *__restrict__ bin_kmers, u32 *err)
+{
+	__shared__ u32 s_bytes[S1_MAX_BINS], s_cnt[S1_MAX_BINS], s_km[S1_MAX_BINS];
+	for (u32 b = threadIdx.x; b < n_bins; b += 256)
+		s_bytes[b] = s_cnt[b] = s_km[b] = 0;
+	__syncthreads();
+	const u64 i0 = (u64)blockIdx.x * S1_SK_TILE;
+	for (u32 j = threadIdx.x; j < (u32)S1_SK_TILE; j += 256) {
+		const u64 i = i0 + j;
+		if (i < n_sk) {
+			const int b = sig_to_bin[sk_sig[i]];
+			if (b < 0 || (u32)b >= n_bins)
+				atomicOr(err, KERR_CORRUPT); /* a signature the map does not know */
+			else {
+				atomicAdd(&s_bytes[b], 1u + (sk_len[i] + 3u) / 4u);
+				atomicAdd(&s_cnt[b], 1u);
+				atomicAdd(&s_km[b], sk_len[i] - k + 1u);
+			}
+		}
+	}
+	__syncthreads();
+	for (u32 b = threadIdx.x; b < n_bins; b += 256)
+		if (s_cnt[b]) {
+			atomicAdd(&bin_bytes[b], (u64)s_bytes[b]);
+			atomicAdd(&bin_sk[b], (u64)s_cnt[b]);
+			atomicAdd(&bin_kmers[b], (u64)s_km[b]);
+		}
+}
+
+/* one workgroup of 256. bin_base[b]: first byte of bin b in the buffer, bin_base[n_bins]: bytes the buffer needs (incl. 256 B of readable slack
+ * behind the last bin); pack_base[b]: first entry of bin b in the pack-start array (bin b owns packs + 1 entries, the last one = its size),
+ * pack_base[n_bins]: entries in all. pack_start may be NULL (sizing call). */
+__global__ void __launch_bounds__(256) k_s1_bin_layout(const u64 *__restrict__ bin_bytes, u32 n_bins, u64 *__restrict__ bin_base, u64 *__restrict__ pack_base,
+                                                        u64 *__restrict__ cursor, u64 *__restrict__ pack_start)
+{
+	__shared__ u64 s_tmp[5];
+	const u32 per = (n_bins + 255) / 256, lo = threadIdx.x * per;
+	u64 sum = 0, packs = 0;
+	for (u32 j = 0; j < per; ++j)
+		if (lo + j < n_bins) {
+			const u64 by = bin_bytes[lo + j];
+			sum += (by + S1_BIN_ALIGN - 1) / S1_BIN_ALIGN * S1_BIN_ALIGN;
+			packs += (by + S1_PACK_BYTES - 1) / S1_PACK_BYTES + 1;
+		}
+	u64 total, total_packs;
+	u64 run = block_excl_sum<4, u64>(sum, s_tmp, total);
+	u64 prun = block_excl_sum<4, u64>(packs, s_tmp, total_packs);
+	for (u32 j = 0; j < per; ++j)
+		if (lo + j < n_bins) {
+			const u64 by = bin_bytes[lo + j], np = (by + S1_PACK_BYTES - 1) / S1_PACK_BYTES;
+			bin_base[lo + j] = run;
+			cursor[lo + j] = run;
+			pack_base[lo + j] = prun;
+			if (pack_start)
+				pack_start[prun + np] = by;
+			run += (by + S1_BIN_ALIGN - 1) / S1_BIN_ALIGN * S1_BIN_ALIGN;
+			prun += np + 1;
+		}
+	if (threadIdx.x == 0) {
+		bin_base[n_bins] = total + S1_BIN_ALIGN;
+		pack_base[n_bins] = total_packs;
+	}
+}
+
+__global__ void __launch_bounds__(256) k_s1_emit(const int8_t *__restrict__ codes, const u64 *__restrict__ sk_pos, const u32 *__restrict__ sk_len,
+                                                  const u32 *__restrict__ sk_sig, u64 n_sk, u32 k, const int *__restrict__ sig_to_bin, u32 n_bins,
+                                                  const u64 *__restrict__ bin_base, const u64 *__restrict__ pack_base, u64 *cursor, uint8_t *__restrict__ out,
+                                                  u64 *__restrict__ pack_start)
+{
+	__shared__ u32 s_bytes[S1_MAX_BINS]; /* bytes of this tile per bin, then the running offset inside the tile's segment */
+	__shared__ u64 s_base[S1_MAX_BINS];  /* where the tile's segment of each bin starts in `out` */
+	for (u32 b = threadIdx.x; b < n_bins; b += 256)
+		s_bytes[b] = 0;
+	__syncthreads();
+	const u64 i0 = (u64)blockIdx.x * S1_SK_TILE;
+	for (u32 j = threadIdx.x; j < (u32)S1_SK_TILE; j += 256) {
+		const u64 i = i0 + j;
+		if (i < n_sk) {
+			const int b = sig_to_bin[sk_sig[i]];
+			if (b >= 0 && (u32)b < n_bins)
+				atomicAdd(&s_bytes[b], 1u + (sk_len[i] + 3u) / 4u);
+		}
+	}
+	__syncthreads();
+	for (u32 b = threadIdx.x; b < n_bins; b += 256) {
+		const u32 bytes = s_bytes[b];
+		if (bytes) {
+			const u64 at = atomicAdd(&cursor[b], (u64)bytes);
+			s_base[b] = at;
+			const u64 rel = at - bin_base[b], j = (rel + S1_PACK_BYTES - 1) / S1_PACK_BYTES;
+			if (j * S1_PACK_BYTES < rel + bytes) /* this segment covers the j-th multiple of the pack size: its start is pack boundary j */
+				pack_start[pack_base[b] + j] = rel;
+		}
+		s_bytes[b] = 0;
+	}
+	__syncthreads();
+	for (u32 j = threadIdx.x; j < (u32)S1_SK_TILE; j += 256) {
+		const u64 i = i0 + j;
+		if (i >= n_sk)
+			continue;
+		const int b = sig_to_bin[sk_sig[i]];
+		if (b < 0 || (u32)b >= n_bins)
+			continue;
+		const u32 len = sk_len[i], bytes = 1u + (len + 3u) / 4u;
+		uint8_t *dst = out + s_base[b] + atomicAdd(&s_bytes[b], bytes);
+		const int8_t *src = codes + sk_pos[i];
+		dst[0] = (uint8_t)(len - k);
+		for (u32 q = 0; q < (len + 3u) / 4u; ++q) { /* four symbols per byte, first one in bits 7:6; missing ones are zero */
+			u32 v = 0;
+#pragma unroll
+			for (u32 t = 0; t < 4; ++t) {
+				const u32 p = 4 * q + t;
+				v = (v << 2) | (p < len ? (u32)(src[p] & 3) : 0u);
+			}
+			dst[1 + q] = (uint8_t)v;
+		}
+	}
 }
 
 #endif

@@ -15,7 +15,7 @@ EMU_DIR = os.path.join(ROOT, "tests", "hipemu")
 # Two builds of the same kernel source: the product's tile geometry (512-thread workgroups: hundreds of OS threads per emulated workgroup,
 # slow) and a small one (128/256-thread workgroups, 4 KB expand slices) that runs the same code paths ~10x faster. Tests use the small one
 # unless they ask for "product".
-GEOMETRY_FLAGS = {"small": ["-DCP_BLOCK_THREADS=128", "-DEXP_BLOCK_THREADS=256", "-DEXP_CHUNK_BYTES=4096", "-DRS_BLOCK_THREADS=256", "-DCP_FOLD_CHUNK=256"], "product": []}
+GEOMETRY_FLAGS = {"small": ["-DCP_BLOCK_THREADS=128", "-DEXP_BLOCK_THREADS=256", "-DEXP_CHUNK_BYTES=4096", "-DRS_BLOCK_THREADS=256", "-DCP_FOLD_CHUNK=256", "-DS1_SK_TILE_N=64", "-DS1_PACK_BYTES_N=16384"], "product": []}
 _LIBS = {}
 
 
@@ -46,7 +46,11 @@ def lib(geometry="small"):
         L.emu_group_compact.restype = C.c_int
         L.emu_group_compact.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p]
         L.emu_s1_split.restype = C.c_int
-        L.emu_s1_split.argtypes = [C.c_void_p, C.c_uint64, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p]
+        L.emu_s1_split.argtypes = [C.c_void_p, C.c_uint64, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p,
+                                   C.c_int]
+        L.emu_s1_scatter.restype = C.c_int
+        L.emu_s1_scatter.argtypes = [C.c_void_p] * 4 + [C.c_uint64, C.c_uint32, C.c_void_p, C.c_uint32] + [C.c_void_p] * 4 + [C.c_uint64, C.c_void_p, C.c_uint64]
+        L.emu_s1_geometry.argtypes = [C.c_void_p]
         _LIBS[geometry] = L
     return _LIBS[geometry]
 
@@ -123,8 +127,9 @@ def group_compact(p, sorted_recs, n_recs, geometry="small"):
     return err, [(outs[i][: int(ob[i])].copy(), luts[i, :lut_n].copy(), stats[i].copy()) for i in range(g)]
 
 
-def s1_split(codes: np.ndarray, k: int, norm: np.ndarray, m: int = 9, geometry="small"):
-    """stage-1 kernels on a code stream (int8: 0..3, negative = invalid/separator). Returns (err, sig per position, sk_pos, sk_len, sk_sig)."""
+def s1_split(codes: np.ndarray, k: int, norm: np.ndarray, m: int = 9, geometry="small", fused=True):
+    """stage-1 kernels on a code stream (int8: 0..3, negative = invalid/separator). Returns (err, sig per position, sk_pos, sk_len, sk_sig).
+    fused: the cutting kernel computes its signatures itself (kmc_hip_split_reads_plan); otherwise it reads k_s1_signatures' output (the test hook)."""
     codes = np.ascontiguousarray(codes, dtype=np.int8)
     n = codes.size
     sig = np.zeros(max(n, 1), dtype=np.uint32)
@@ -134,6 +139,36 @@ def s1_split(codes: np.ndarray, k: int, norm: np.ndarray, m: int = 9, geometry="
     sg = np.zeros(cap, dtype=np.uint32)
     nsk = C.c_uint64(0)
     err = lib(geometry).emu_s1_split(codes.ctypes.data, n, k, m, np.ascontiguousarray(norm).ctypes.data, sig.ctypes.data, pos.ctypes.data, ln.ctypes.data,
-                                     sg.ctypes.data, cap, C.addressof(nsk))
+                                     sg.ctypes.data, cap, C.addressof(nsk), 1 if fused else 0)
     j = nsk.value
     return err, sig[:n], pos[:j].copy(), ln[:j].copy(), sg[:j].copy()
+
+
+def s1_geometry(geometry="small"):
+    """(super-k-mers per scatter tile, pack size in bytes, bin alignment) of the build"""
+    g = (C.c_uint32 * 3)()
+    lib(geometry).emu_s1_geometry(g)
+    return tuple(g)
+
+
+def s1_scatter(codes, sk_pos, sk_len, sk_sig, k: int, sig_to_bin: np.ndarray, n_bins: int, geometry="small"):
+    """stage-1 bin scatter on the super-k-mer list of s1_split. Returns dict(err, base uint64[n_bins+1], totals uint64[3][n_bins] = bytes /
+    super-k-mers / k-mers, pack_base uint64[n_bins+1], out bytes, pack_start uint64[...])."""
+    codes = np.ascontiguousarray(codes, dtype=np.int8)
+    sk_pos = np.ascontiguousarray(sk_pos, dtype=np.uint64)
+    sk_len = np.ascontiguousarray(sk_len, dtype=np.uint32)
+    sk_sig = np.ascontiguousarray(sk_sig, dtype=np.uint32)
+    m = np.ascontiguousarray(sig_to_bin, dtype=np.int32)
+    n = sk_pos.size
+    _, pack_bytes, align = s1_geometry(geometry)
+    base = np.zeros(n_bins + 1, dtype=np.uint64)
+    pbase = np.zeros(n_bins + 1, dtype=np.uint64)
+    tot = np.zeros((3, n_bins), dtype=np.uint64)
+    payload = int(n + ((sk_len.astype(np.uint64) + 3) // 4).sum())
+    cap = payload + (n_bins + 2) * align
+    out = np.full(cap, 0xEE, dtype=np.uint8)
+    pcap = payload // pack_bytes + 2 * n_bins + 2
+    pack_start = np.full(pcap, 0xFFFFFFFFFFFFFFFF, dtype=np.uint64)
+    err = lib(geometry).emu_s1_scatter(codes.ctypes.data, sk_pos.ctypes.data, sk_len.ctypes.data, sk_sig.ctypes.data, n, k, m.ctypes.data, n_bins, base.ctypes.data,
+                                       pbase.ctypes.data, tot.ctypes.data, out.ctypes.data, cap, pack_start.ctypes.data, pcap)
+    return dict(err=err, base=base, pack_base=pbase, totals=tot, out=out[: int(base[n_bins])].copy(), pack_start=pack_start[: int(pbase[n_bins])].copy())

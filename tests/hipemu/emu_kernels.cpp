@@ -396,7 +396,9 @@ EMU_API int emu_group_compact(const unsigned *params10, int g, const u64 *sorted
 
 /* stage-1 kernels: codes (0..3, negative = invalid / separator) -> signature per k-mer position, and the super-k-mers in position order.
  * Returns the device error word; *n_sk = number of super-k-mers. */
-EMU_API int emu_s1_split(const int8_t *codes, u64 n, unsigned k, unsigned m, const u32 *norm, u32 *sig, u64 *sk_pos, u32 *sk_len, u32 *sk_sig, u64 sk_cap, u64 *n_sk)
+/* fused != 0: the cutting kernel computes the signatures itself (the product path of kmc_hip_split_reads_plan); `sig` is still filled, by k_s1_signatures */
+EMU_API int emu_s1_split(const int8_t *codes, u64 n, unsigned k, unsigned m, const u32 *norm, u32 *sig, u64 *sk_pos, u32 *sk_len, u32 *sk_sig, u64 sk_cap, u64 *n_sk,
+                         int fused)
 {
 	u32 err = 0;
 	*n_sk = 0;
@@ -406,7 +408,48 @@ EMU_API int emu_s1_split(const int8_t *codes, u64 n, unsigned k, unsigned m, con
 	std::vector<u64> st_last(tiles, 0), st_cnt(tiles, 0);
 	u32 ticket = 0;
 	hipemu::launch(dim3(tiles), dim3(S1_BLOCK), 0, [&] { k_s1_signatures(codes, n, k, m, norm, sig); });
-	hipemu::launch(dim3(tiles), dim3(S1_BLOCK), 0, [&] { k_s1_cut(sig, n, k, st_last.data(), st_cnt.data(), &ticket, sk_pos, sk_len, sk_sig, sk_cap, n_sk, &err); });
+	if (fused)
+		hipemu::launch(dim3(tiles), dim3(S1_BLOCK), 0, [&] {
+			k_s1_cut<true>((const u32 *)nullptr, codes, m, norm, n, k, st_last.data(), st_cnt.data(), &ticket, sk_pos, sk_len, sk_sig, sk_cap, n_sk, &err);
+		});
+	else
+		hipemu::launch(dim3(tiles), dim3(S1_BLOCK), 0, [&] {
+			k_s1_cut<false>(sig, (const int8_t *)nullptr, 0u, (const u32 *)nullptr, n, k, st_last.data(), st_cnt.data(), &ticket, sk_pos, sk_len, sk_sig, sk_cap, n_sk, &err);
+		});
 	return (int)err;
+}
+/* stage-1 bin scatter: super-k-mers -> bin records in per-bin streams + pack boundaries (k_s1_bin_totals, k_s1_bin_layout, k_s1_emit).
+ * bin_base, pack_base: n_bins + 1; totals: [3][n_bins] bytes / super-k-mers / k-mers; out: out_cap bytes; pack_start: pack_cap entries */
+EMU_API void emu_s1_geometry(u32 *g)
+{
+	g[0] = S1_SK_TILE;
+	g[1] = S1_PACK_BYTES;
+	g[2] = S1_BIN_ALIGN;
+}
+EMU_API int emu_s1_scatter(const int8_t *codes, const u64 *sk_pos, const u32 *sk_len, const u32 *sk_sig, u64 n_sk, unsigned k, const int *sig_to_bin, unsigned n_bins,
+                           u64 *bin_base, u64 *pack_base, u64 *totals, uint8_t *out, u64 out_cap, u64 *pack_start, u64 pack_cap)
+{
+	u32 err = 0;
+	std::vector<u64> cursor(n_bins, 0);
+	for (u64 i = 0; i < 3ull * n_bins; ++i)
+		totals[i] = 0;
+	const u32 tiles = (u32)((n_sk + S1_SK_TILE - 1) / S1_SK_TILE);
+	if (tiles)
+		hipemu::launch(dim3(tiles), dim3(256), 0,
+		               [&] { k_s1_bin_totals(sk_len, sk_sig, n_sk, k, sig_to_bin, n_bins, totals, totals + n_bins, totals + 2 * n_bins, &err); });
+	if (err)
+		return (int)err;
+	/* sizing call first (what a caller does before it allocates), then the real one */
+	hipemu::launch(dim3(1), dim3(256), 0, [&] { k_s1_bin_layout(totals, n_bins, bin_base, pack_base, cursor.data(), (u64 *)nullptr); });
+	if (bin_base[n_bins] > out_cap || pack_base[n_bins] > pack_cap)
+		return -1;
+	hipemu::launch(dim3(1), dim3(256), 0, [&] { k_s1_bin_layout(totals, n_bins, bin_base, pack_base, cursor.data(), pack_start); });
+	if (tiles)
+		hipemu::launch(dim3(tiles), dim3(256), 0,
+		               [&] { k_s1_emit(codes, sk_pos, sk_len, sk_sig, n_sk, k, sig_to_bin, n_bins, bin_base, pack_base, cursor.data(), out, pack_start); });
+	for (unsigned b = 0; b < n_bins; ++b)
+		if (cursor[b] != bin_base[b] + totals[b])
+			return -2; /* every reserved byte accounted for */
+	return 0;
 }
 }
