@@ -1444,18 +1444,19 @@ int kmc_hip_debug_split_reads(kmc_hip_ctx *ctx, int dev, const int8_t *codes, ui
 	S1CHK(hipMalloc(&d_codes, n));
 	S1CHK(hipMalloc(&d_norm, (size_t)special * 4));
 	S1CHK(hipMalloc(&d_sig, n * 4));
-	S1CHK(hipMalloc(&d_status, tiles * 16));
+	const u64 ctiles = s1_cut_tiles(n); /* the cutting kernel works on S1_SUB tiles per workgroup */
+	S1CHK(hipMalloc(&d_status, ctiles * 16));
 	S1CHK(hipMalloc(&d_pos, cap * 8));
 	S1CHK(hipMalloc(&d_len, cap * 4));
 	S1CHK(hipMalloc(&d_ssig, cap * 4));
 	S1CHK(hipMalloc(&d_small, 64));
 	S1CHK(hipMemcpyAsync(d_codes, codes, n, hipMemcpyHostToDevice, s.stream));
 	S1CHK(hipMemcpyAsync(d_norm, norm.data(), (size_t)special * 4, hipMemcpyHostToDevice, s.stream));
-	S1CHK(hipMemsetAsync(d_status, 0, tiles * 16, s.stream));
+	S1CHK(hipMemsetAsync(d_status, 0, ctiles * 16, s.stream));
 	S1CHK(hipMemsetAsync(d_small, 0, 64, s.stream));
 	k_s1_signatures<<<dim3((u32)tiles), dim3(S1_BLOCK), 0, s.stream>>>((const int8_t *)d_codes, n, kmer_len, signature_len, (const u32 *)d_norm, (u32 *)d_sig);
-	k_s1_cut<false><<<dim3((u32)tiles), dim3(S1_BLOCK), 0, s.stream>>>((const u32 *)d_sig, (const int8_t *)nullptr, 0u, (const u32 *)nullptr, n, kmer_len,
-	                                                                     (u64 *)d_status, (u64 *)d_status + tiles, (u32 *)d_small + 2, (u64 *)d_pos, (u32 *)d_len,
+	k_s1_cut<false><<<dim3((u32)ctiles), dim3(S1_BLOCK), 0, s.stream>>>((const u32 *)d_sig, (const int8_t *)nullptr, 0u, (const u32 *)nullptr, n, kmer_len,
+	                                                                      (u64 *)d_status, (u64 *)d_status + ctiles, (u32 *)d_small + 2, (u64 *)d_pos, (u32 *)d_len,
 	                                                                     (u32 *)d_ssig, sk_cap, (u64 *)d_small, err_ptr(s));
 	S1CHK(hipGetLastError());
 	u64 cnt = 0;
@@ -1508,7 +1509,7 @@ int kmc_hip_split_reads_plan(kmc_hip_ctx *ctx, int dev, const int8_t *d_codes, u
 		return fail(KMC_HIP_EINVAL, "kmc_hip_split_reads_plan: kmer_len 1..256, signature_len 5..11 and <= kmer_len");
 	if (n_bins < 1 || n_bins > (uint32_t)S1_MAX_BINS)
 		return fail(KMC_HIP_EINVAL, "kmc_hip_split_reads_plan: n_bins 1..2048");
-	const u64 tiles = (n + S1_TILE - 1) / S1_TILE;
+	const u64 tiles = s1_cut_tiles(n);
 	if (!n || tiles > 0x7FFFFFFFull)
 		return fail(KMC_HIP_EINVAL, "kmc_hip_split_reads_plan: 1 .. 2^41 symbols per call");
 	*plan = nullptr;

@@ -16,8 +16,8 @@
  *   k_s1_cut<FUSED> : signatures (from memory, or computed by the tile itself) -> the super-k-mers in position order: first symbol,
  *                     length in symbols, signature
  *   k_s1_bin_totals / k_s1_bin_layout / k_s1_emit : super-k-mers -> bin records, scattered into per-bin byte streams (see below)
- * Both are tile-parallel; k_s1_cut carries "where did the current run start" and "how many super-k-mers so far" across tiles with two
- * decoupled look-backs (max and sum) over 64-bit status words.
+ * Both are tile-parallel; k_s1_cut carries "where did the current run start" and "how many super-k-mers so far" across workgroups with two
+ * decoupled look-backs (latest non-zero, and sum) over 64-bit status words.
  */
 #ifndef KMC_AMD_STAGE1_KERNELS_HIP_H
 #define KMC_AMD_STAGE1_KERNELS_HIP_H
@@ -151,15 +151,25 @@ __device__ __forceinline__ u64 lookback64_last(u64 *status, u32 tile, u64 own_la
 	return found;
 }
 
-/* status_last / status_cnt: one zeroed u64 per tile each. sk_* receive the super-k-mers in position order; *n_sk their number (written by
- * the last tile). sk_cap bounds the writes (KERR_CAPACITY beyond it).
- * FUSED = false: signatures come from `sig` (k_s1_signatures ran before; codes, m, norm unused). FUSED = true: the tile computes the S1_TILE + 2
+/* One workgroup cuts S1_SUB consecutive tiles (S1_WG_TILE positions): one ticket and one pair of look-backs per workgroup — with one tile per
+ * workgroup the kernel ran at the rate of its same-address ticket atomic (50 tiles/us: 5.9 ms per 300 M positions, profiles/r02/s1_bench_v1*).
+ * status_last / status_cnt: one zeroed u64 per WORKGROUP tile each (s1_cut_tiles(n) of them). sk_* receive the super-k-mers in position order;
+ * *n_sk their number (written by the last tile). sk_cap bounds the writes (KERR_CAPACITY beyond it).
+ * FUSED = false: signatures come from `sig` (k_s1_signatures ran before; codes, m, norm unused). FUSED = true: the workgroup computes the
  * signatures it needs in LDS itself (sig unused): 1 byte per symbol read instead of 4 written + 4 read. */
+#ifndef S1_SUB_N
+#define S1_SUB_N 4
+#endif
+constexpr int S1_SUB = S1_SUB_N, S1_WG_TILE = S1_TILE * S1_SUB;
+static_assert(S1_PER == 4, "the pieces of a thread's positions are packed into one 32-bit word");
+__host__ __device__ inline u64 s1_cut_tiles(u64 n) { return (n + S1_WG_TILE - 1) / S1_WG_TILE; }
+
 template <bool FUSED>
 __global__ void __launch_bounds__(S1_BLOCK) k_s1_cut(const u32 *__restrict__ sig, const int8_t *__restrict__ codes, u32 m, const u32 *__restrict__ norm, u64 n, u32 k,
                                                       u64 *status_last, u64 *status_cnt, u32 *ticket_ctr, u64 *__restrict__ sk_pos, u32 *__restrict__ sk_len,
                                                       u32 *__restrict__ sk_sig, u64 sk_cap, u64 *n_sk, u32 *err)
 {
+	__shared__ u32 s_sig[S1_WG_TILE + 2]; /* signatures of positions w0 - 1 .. w0 + S1_WG_TILE */
 	__shared__ u64 s_tmp64[S1_BLOCK / 64 + 1];
 	__shared__ u32 s_tmp32[S1_BLOCK / 64 + 1];
 	__shared__ u64 s_carry_last1, s_carry_cnt;
@@ -169,90 +179,115 @@ __global__ void __launch_bounds__(S1_BLOCK) k_s1_cut(const u32 *__restrict__ sig
 		s_ticket = atomicAdd(ticket_ctr, 1u);
 	__syncthreads();
 	const u32 tile = s_ticket;
-	const u32 num_tiles = (u32)((n + S1_TILE - 1) / S1_TILE);
+	const u32 num_tiles = (u32)s1_cut_tiles(n);
 	if (tile >= num_tiles)
 		return;
-	const u64 t0 = (u64)tile * S1_TILE + (u64)tid * S1_PER; /* this thread's S1_PER consecutive positions */
-	u32 s[S1_PER + 2];                                        /* sig[t0 - 1 .. t0 + S1_PER] */
+	const u64 w0 = (u64)tile * S1_WG_TILE;
 	if constexpr (FUSED) {
 		__shared__ S1SigLds L;
-		__shared__ u32 s_sig[S1_TILE + 2];
-		s1_signatures_to_lds(codes, n, (long long)tile * S1_TILE - 1, S1_TILE + 2, k, m, norm, L, s_sig);
-#pragma unroll
-		for (int j = 0; j < S1_PER + 2; ++j)
-			s[j] = s_sig[tid * S1_PER + j];
+#pragma unroll 1
+		for (int sub = 0; sub < S1_SUB; ++sub)
+			s1_signatures_to_lds(codes, n, (long long)w0 - 1 + (long long)sub * S1_TILE, sub == S1_SUB - 1 ? S1_TILE + 2 : S1_TILE, k, m, norm, L, s_sig + sub * S1_TILE);
 	} else {
-#pragma unroll
-		for (int j = 0; j < S1_PER + 2; ++j) {
-			const long long q = (long long)t0 - 1 + j;
-			s[j] = (q >= 0 && (u64)q < n) ? sig[q] : S1_NOSIG;
+		for (u32 i = tid; i < (u32)S1_WG_TILE + 2; i += S1_BLOCK) {
+			const long long q = (long long)w0 - 1 + (long long)i;
+			s_sig[i] = (q >= 0 && (u64)q < n) ? sig[q] : S1_NOSIG;
 		}
+		__syncthreads();
 	}
-	/* run starts inside this thread's positions: valid, and the k-mer before is invalid or has another signature */
-	u64 last1 = 0; /* position + 1 of the thread's last run start */
+	/* Pass A, per sub-tile: run starts inside this thread's S1_PER positions (valid, and the k-mer before is invalid or has another
+	 * signature); the last one before the thread inside the sub-tile; the sub-tile's own last one. */
+	u64 before1[S1_SUB], sub_last1[S1_SUB]; /* position + 1, 0 = none */
 #pragma unroll
-	for (int j = 0; j < S1_PER; ++j)
-		if (s[j + 1] != S1_NOSIG && s[j] != s[j + 1])
-			last1 = t0 + j + 1;
-	const u64 before1 = block_excl_max<S1_BLOCK / 64, u64>(last1, s_tmp64); /* last run start + 1 before this thread, inside the tile */
-	/* the tile's own last run start: the maximum over the threads */
-	u64 tile_last1 = wave_incl_max<u64>(last1, lane);
-	if (lane == 63)
-		s_tmp64[wave] = tile_last1;
-	__syncthreads();
-	if (wave == 0) {
+	for (int sub = 0; sub < S1_SUB; ++sub) {
+		const u32 l0 = (u32)sub * S1_TILE + tid * S1_PER; /* index of position t0 - 1 in s_sig */
+		const u64 t0 = w0 + l0;
+		u64 last1 = 0;
+#pragma unroll
+		for (int j = 0; j < S1_PER; ++j)
+			if (s_sig[l0 + j + 1] != S1_NOSIG && s_sig[l0 + j] != s_sig[l0 + j + 1])
+				last1 = t0 + j + 1;
+		before1[sub] = block_excl_max<S1_BLOCK / 64, u64>(last1, s_tmp64);
+		u64 mx = wave_incl_max<u64>(last1, lane);
+		if (lane == 63)
+			s_tmp64[wave] = mx;
+		__syncthreads();
 		u64 w = 0;
 #pragma unroll
 		for (int i = 0; i < S1_BLOCK / 64; ++i)
 			w = s_tmp64[i] > w ? s_tmp64[i] : w;
+		sub_last1[sub] = w;
+		__syncthreads();
+	}
+	if (wave == 0) {
+		u64 w = 0;
+#pragma unroll
+		for (int sub = 0; sub < S1_SUB; ++sub)
+			w = sub_last1[sub] ? sub_last1[sub] : w; /* positions grow with sub: the last non-zero one */
 		const u64 carry = lookback64_last(status_last, tile, w, lane, err);
 		if (lane == 0)
 			s_carry_last1 = carry;
 	}
 	__syncthreads();
-	const u64 carry_last1 = s_carry_last1;
-	/* ends: a super-k-mer ends at q if q is valid and the next k-mer is invalid / has another signature / q is the 256th k-mer of its piece */
-	u64 cur1 = before1 ? before1 : carry_last1;
-	u32 n_end = 0, end_bits = 0;
-	u32 piece[S1_PER];
+	/* Pass B: ends. A super-k-mer ends at q if q is valid and the next k-mer is invalid / has another signature / q is the 256th k-mer of its
+	 * piece (pieces are counted from the run's start, wherever that was). */
+	u64 carry_last1 = s_carry_last1; /* the last run start before the sub-tile at hand */
+	u32 end_bits[S1_SUB], pieces[S1_SUB], off[S1_SUB], wg_ends = 0;
 #pragma unroll
-	for (int j = 0; j < S1_PER; ++j) {
-		const u64 q = t0 + j;
-		piece[j] = 0;
-		if (s[j + 1] != S1_NOSIG) {
-			if (s[j] != s[j + 1])
-				cur1 = q + 1; /* a run starts here */
-			const u32 in_piece = (u32)((q - (cur1 - 1)) & 255u); /* k-mers of this piece before q */
-			if (s[j + 2] != s[j + 1] || in_piece == 255u) {
-				end_bits |= 1u << j;
-				piece[j] = in_piece;
-				++n_end;
+	for (int sub = 0; sub < S1_SUB; ++sub) {
+		const u32 l0 = (u32)sub * S1_TILE + tid * S1_PER;
+		const u64 t0 = w0 + l0;
+		u64 cur1 = before1[sub] ? before1[sub] : carry_last1;
+		u32 n_end = 0;
+		end_bits[sub] = 0, pieces[sub] = 0;
+#pragma unroll
+		for (int j = 0; j < S1_PER; ++j) {
+			const u64 q = t0 + j;
+			const u32 prev = s_sig[l0 + j], me = s_sig[l0 + j + 1], next = s_sig[l0 + j + 2];
+			if (me != S1_NOSIG) {
+				if (prev != me)
+					cur1 = q + 1; /* a run starts here */
+				const u32 in_piece = (u32)((q - (cur1 - 1)) & 255u); /* k-mers of this piece before q */
+				if (next != me || in_piece == 255u) {
+					end_bits[sub] |= 1u << j;
+					pieces[sub] |= in_piece << (8 * j);
+					++n_end;
+				}
 			}
 		}
+		u32 sub_ends;
+		off[sub] = wg_ends + block_excl_sum<S1_BLOCK / 64, u32>(n_end, s_tmp32, sub_ends);
+		wg_ends += sub_ends;
+		carry_last1 = sub_last1[sub] ? sub_last1[sub] : carry_last1;
 	}
-	u32 tile_ends;
-	const u32 off = block_excl_sum<S1_BLOCK / 64, u32>(n_end, s_tmp32, tile_ends);
 	if (wave == 0) {
-		const u64 excl = lookback64(status_cnt, tile, (u64)tile_ends, lane, err, KERR_WATCHDOG);
+		const u64 excl = lookback64(status_cnt, tile, (u64)wg_ends, lane, err, KERR_WATCHDOG);
 		if (lane == 0) {
 			s_carry_cnt = excl;
 			if (tile == num_tiles - 1)
-				*n_sk = excl + tile_ends;
+				*n_sk = excl + wg_ends;
 		}
 	}
 	__syncthreads();
-	u64 idx = s_carry_cnt + off;
+	/* Pass C: the super-k-mers, in position order */
 #pragma unroll
-	for (int j = 0; j < S1_PER; ++j)
-		if (end_bits & (1u << j)) {
-			if (idx < sk_cap) {
-				sk_pos[idx] = t0 + j - piece[j];
-				sk_len[idx] = k + piece[j];
-				sk_sig[idx] = s[j + 1];
-			} else
-				atomicOr(err, KERR_CAPACITY);
-			++idx;
-		}
+	for (int sub = 0; sub < S1_SUB; ++sub) {
+		const u32 l0 = (u32)sub * S1_TILE + tid * S1_PER;
+		const u64 t0 = w0 + l0;
+		u64 idx = s_carry_cnt + off[sub];
+#pragma unroll
+		for (int j = 0; j < S1_PER; ++j)
+			if (end_bits[sub] & (1u << j)) {
+				const u32 piece = (pieces[sub] >> (8 * j)) & 255u;
+				if (idx < sk_cap) {
+					sk_pos[idx] = t0 + j - piece;
+					sk_len[idx] = k + piece;
+					sk_sig[idx] = s_sig[l0 + j + 1];
+				} else
+					atomicOr(err, KERR_CAPACITY);
+				++idx;
+			}
+	}
 }
 
 /* ------------------------------------------------------------------------------------------------ bin scatter

@@ -404,20 +404,21 @@ EMU_API int emu_s1_split(const int8_t *codes, u64 n, unsigned k, unsigned m, con
 	*n_sk = 0;
 	if (!n)
 		return 0;
-	const u32 tiles = (u32)((n + S1_TILE - 1) / S1_TILE);
-	std::vector<u64> st_last(tiles, 0), st_cnt(tiles, 0);
+	const u32 tiles = (u32)((n + S1_TILE - 1) / S1_TILE), ctiles = (u32)s1_cut_tiles(n);
+	std::vector<u64> st_last(ctiles, 0), st_cnt(ctiles, 0);
 	u32 ticket = 0;
 	hipemu::launch(dim3(tiles), dim3(S1_BLOCK), 0, [&] { k_s1_signatures(codes, n, k, m, norm, sig); });
 	if (fused)
-		hipemu::launch(dim3(tiles), dim3(S1_BLOCK), 0, [&] {
+		hipemu::launch(dim3(ctiles), dim3(S1_BLOCK), 0, [&] {
 			k_s1_cut<true>((const u32 *)nullptr, codes, m, norm, n, k, st_last.data(), st_cnt.data(), &ticket, sk_pos, sk_len, sk_sig, sk_cap, n_sk, &err);
 		});
 	else
-		hipemu::launch(dim3(tiles), dim3(S1_BLOCK), 0, [&] {
+		hipemu::launch(dim3(ctiles), dim3(S1_BLOCK), 0, [&] {
 			k_s1_cut<false>(sig, (const int8_t *)nullptr, 0u, (const u32 *)nullptr, n, k, st_last.data(), st_cnt.data(), &ticket, sk_pos, sk_len, sk_sig, sk_cap, n_sk, &err);
 		});
 	return (int)err;
 }
+
 /* stage-1 bin scatter: super-k-mers -> bin records in per-bin streams + pack boundaries (k_s1_bin_totals, k_s1_bin_layout, k_s1_emit).
  * bin_base, pack_base: n_bins + 1; totals: [3][n_bins] bytes / super-k-mers / k-mers; out: out_cap bytes; pack_start: pack_cap entries */
 EMU_API void emu_s1_geometry(u32 *g)

@@ -27,13 +27,14 @@ def _reads(rng, k, n_reads, read_len):
     return reads
 
 
-@pytest.mark.parametrize("fused", [True, False])
+@pytest.mark.parametrize("fused,geometry", [(True, "small"), (False, "small"), (True, "product")])
 @pytest.mark.parametrize("k,m", [(27, 9), (21, 9), (55, 9), (14, 7), (200, 9), (28, 11), (256, 11), (9, 9)])
-def test_emulated_stage1_signatures_and_cut_match_the_oracle(k, m, fused):
+def test_emulated_stage1_signatures_and_cut_match_the_oracle(k, m, fused, geometry):
+    """small geometry: two 1024-position tiles per cutting workgroup, product: four"""
     rng = np.random.default_rng(k * 10 + m)
     codes = _stream(_reads(rng, k, 40, 150))
     norm = S1.norm_table(m)
-    err, sig, pos, ln, sg = emu.s1_split(codes, k, norm, m, fused=fused)
+    err, sig, pos, ln, sg = emu.s1_split(codes, k, norm, m, fused=fused, geometry=geometry)
     assert err == 0
     w_pos, w_len, w_sig = S1.split_stream(codes, k, m)
     assert pos.size == w_pos.size, (pos.size, w_pos.size)
@@ -53,13 +54,13 @@ def test_emulated_stage1_tile_boundaries():
     rng = np.random.default_rng(5)
     acgt = np.frombuffer(b"ACGT", dtype=np.uint8)
     per = acgt[rng.integers(0, 4, size=13)].tobytes()
-    for pad in (0, 1, 1000, 1023, 1024, 1025, 2047):
+    for pad in (0, 1, 1000, 1023, 1024, 1025, 2047, 2048, 4095, 4096, 4097, 8191):
         codes = _stream([acgt[rng.integers(0, 4, size=pad)].tobytes() if pad else b"", (per * 400)[:4000], b"A" * 3000])
         norm = S1.norm_table(m)
-        for fused in (True, False):
-            err, sig, pos, ln, sg = emu.s1_split(codes, k, norm, m, fused=fused)
+        for fused, geometry in ((True, "small"), (False, "small"), (True, "product")):
+            err, sig, pos, ln, sg = emu.s1_split(codes, k, norm, m, fused=fused, geometry=geometry)
             w_pos, w_len, w_sig = S1.split_stream(codes, k, m)
-            assert err == 0 and np.array_equal(pos, w_pos.astype(np.uint64)) and np.array_equal(ln, w_len) and np.array_equal(sg, w_sig), (pad, fused)
+            assert err == 0 and np.array_equal(pos, w_pos.astype(np.uint64)) and np.array_equal(ln, w_len) and np.array_equal(sg, w_sig), (pad, fused, geometry)
 
 
 def _parse_bin(img, k):
@@ -173,3 +174,17 @@ def test_emulated_reads_to_database_records_stage1_into_stage2():
         assert np.array_equal(got["out"], w_out) and np.array_equal(got["lut"], w_lut) and np.array_equal(got["stats"], w_st), b
         total += w_st
     assert total[0] > total[1] > 0  # repeated k-mers were counted, and some passed the cutoff
+
+
+def test_emulated_stage1_cut_over_more_than_64_workgroup_tiles():
+    """both look-backs of the cutting kernel walk more than one window of 64 status words: 70 workgroup tiles, among them a run of one
+    signature that spans several tiles (poly-A) right where the second window starts"""
+    k, m = 27, 9
+    rng = np.random.default_rng(12)
+    acgt = np.frombuffer(b"ACGT", dtype=np.uint8)
+    reads = [acgt[rng.integers(0, 4, size=150)].tobytes() for _ in range(840)] + [b"A" * 9000] + [acgt[rng.integers(0, 4, size=150)].tobytes() for _ in range(60)]
+    codes = _stream(reads)
+    assert codes.size > 70 * 2048
+    err, _, pos, ln, sg = emu.s1_split(codes, k, S1.norm_table(m), m, fused=True)
+    w_pos, w_len, w_sig = S1.split_stream(codes, k, m)
+    assert err == 0 and np.array_equal(pos, w_pos.astype(np.uint64)) and np.array_equal(ln, w_len) and np.array_equal(sg, w_sig)
