@@ -1380,33 +1380,6 @@ int kmc_hip_debug_compact(kmc_hip_ctx *ctx, int dev, const kmc_hip_bin_params *p
 }
 
 /* ---- stage 1, first kernels: test hook (synchronous, own temporary buffers) ---- */
-/* the normalisation table of kmc_api/mmer.h:39-95 (allowed m-mers, the smaller strand; 4^m = no signature), built on the host */
-static std::vector<u32> s1_norm_table(uint32_t signature_len)
-{
-	const u32 special = 1u << (2 * signature_len);
-	std::vector<u32> norm(special);
-	auto allowed = [&](u32 x) {
-		if ((x & 0x3f) == 0x3f || (x & 0x3f) == 0x3b || (x & 0x3c) == 0x3c)
-			return false;
-		for (u32 j = 0; j < signature_len - 3; ++j) {
-			if ((x & 0xf) == 0)
-				return false;
-			x >>= 2;
-		}
-		return !(x == 0 || x == 0x04 || (x & 0xf) == 0);
-	};
-	for (u32 i = 0; i < special; ++i) {
-		u32 rev = 0, y = i;
-		for (u32 j = 0; j < signature_len; ++j) {
-			rev = (rev << 2) | (3 - (y & 3));
-			y >>= 2;
-		}
-		const u32 a = allowed(i) ? i : special, b = allowed(rev) ? rev : special;
-		norm[i] = a < b ? a : b;
-	}
-	return norm;
-}
-
 int kmc_hip_debug_split_reads(kmc_hip_ctx *ctx, int dev, const int8_t *codes, uint64_t n, uint32_t kmer_len, uint32_t signature_len, uint32_t *sig,
                               uint64_t *sk_pos, uint32_t *sk_len, uint32_t *sk_sig, uint64_t sk_cap, uint64_t *n_sk)
 {
@@ -1419,16 +1392,14 @@ int kmc_hip_debug_split_reads(kmc_hip_ctx *ctx, int dev, const int8_t *codes, ui
 	*n_sk = 0;
 	if (!n)
 		return 0;
-	const u32 special = 1u << (2 * signature_len);
-	const std::vector<u32> norm = s1_norm_table(signature_len);
 	Slot &s = ctx->devs[dev]->slot[0];
 	std::lock_guard<std::mutex> lck(s.mtx);
 	const u64 tiles = (n + S1_TILE - 1) / S1_TILE;
 	if (tiles > 0x7FFFFFFFull)
 		return fail(KMC_HIP_EINVAL, "too many symbols for one call");
-	void *d_codes = nullptr, *d_norm = nullptr, *d_sig = nullptr, *d_status = nullptr, *d_pos = nullptr, *d_len = nullptr, *d_ssig = nullptr, *d_small = nullptr;
+	void *d_codes = nullptr, *d_sig = nullptr, *d_status = nullptr, *d_pos = nullptr, *d_len = nullptr, *d_ssig = nullptr, *d_small = nullptr;
 	auto release = [&] {
-		for (void *p : {d_codes, d_norm, d_sig, d_status, d_pos, d_len, d_ssig, d_small})
+		for (void *p : {d_codes, d_sig, d_status, d_pos, d_len, d_ssig, d_small})
 			if (p)
 				(void)hipFree(p);
 	};
@@ -1442,7 +1413,6 @@ int kmc_hip_debug_split_reads(kmc_hip_ctx *ctx, int dev, const int8_t *codes, ui
 	} while (0)
 	const u64 cap = sk_cap ? sk_cap : 1;
 	S1CHK(hipMalloc(&d_codes, n));
-	S1CHK(hipMalloc(&d_norm, (size_t)special * 4));
 	S1CHK(hipMalloc(&d_sig, n * 4));
 	const u64 ctiles = s1_cut_tiles(n); /* the cutting kernel works on S1_SUB tiles per workgroup */
 	S1CHK(hipMalloc(&d_status, ctiles * 16));
@@ -1451,11 +1421,10 @@ int kmc_hip_debug_split_reads(kmc_hip_ctx *ctx, int dev, const int8_t *codes, ui
 	S1CHK(hipMalloc(&d_ssig, cap * 4));
 	S1CHK(hipMalloc(&d_small, 64));
 	S1CHK(hipMemcpyAsync(d_codes, codes, n, hipMemcpyHostToDevice, s.stream));
-	S1CHK(hipMemcpyAsync(d_norm, norm.data(), (size_t)special * 4, hipMemcpyHostToDevice, s.stream));
 	S1CHK(hipMemsetAsync(d_status, 0, ctiles * 16, s.stream));
 	S1CHK(hipMemsetAsync(d_small, 0, 64, s.stream));
-	k_s1_signatures<<<dim3((u32)tiles), dim3(S1_BLOCK), 0, s.stream>>>((const int8_t *)d_codes, n, kmer_len, signature_len, (const u32 *)d_norm, (u32 *)d_sig);
-	k_s1_cut<false><<<dim3((u32)ctiles), dim3(S1_BLOCK), 0, s.stream>>>((const u32 *)d_sig, (const int8_t *)nullptr, 0u, (const u32 *)nullptr, n, kmer_len,
+	k_s1_signatures<<<dim3((u32)tiles), dim3(S1_BLOCK), 0, s.stream>>>((const int8_t *)d_codes, n, kmer_len, signature_len, (u32 *)d_sig);
+	k_s1_cut<false><<<dim3((u32)ctiles), dim3(S1_BLOCK), 0, s.stream>>>((const u32 *)d_sig, (const int8_t *)nullptr, 0u, n, kmer_len,
 	                                                                      (u64 *)d_status, (u64 *)d_status + ctiles, (u32 *)d_small + 2, (u64 *)d_pos, (u32 *)d_len,
 	                                                                     (u32 *)d_ssig, sk_cap, (u64 *)d_small, err_ptr(s));
 	S1CHK(hipGetLastError());
@@ -1513,15 +1482,13 @@ int kmc_hip_split_reads_plan(kmc_hip_ctx *ctx, int dev, const int8_t *d_codes, u
 	if (!n || tiles > 0x7FFFFFFFull)
 		return fail(KMC_HIP_EINVAL, "kmc_hip_split_reads_plan: 1 .. 2^41 symbols per call");
 	*plan = nullptr;
-	const u32 special = 1u << (2 * signature_len);
-	const std::vector<u32> norm = s1_norm_table(signature_len);
 	Slot &s = ctx->devs[dev]->slot[0];
 	std::lock_guard<std::mutex> lck(s.mtx);
 	kmc_hip_s1_plan *p = new kmc_hip_s1_plan;
 	p->dev = dev, p->k = kmer_len, p->n_bins = n_bins, p->n = n, p->d_codes = d_codes, p->d_map = d_sig_to_bin;
-	void *d_norm = nullptr, *d_status = nullptr, *d_small = nullptr;
+	void *d_status = nullptr, *d_small = nullptr;
 	auto release_tmp = [&] {
-		for (void *q : {d_norm, d_status, d_small})
+		for (void *q : {d_status, d_small})
 			if (q)
 				(void)hipFree(q);
 	};
@@ -1534,12 +1501,10 @@ int kmc_hip_split_reads_plan(kmc_hip_ctx *ctx, int dev, const int8_t *d_codes, u
 			return fail_hip(#call, e__);                                                                               \
 		}                                                                                                              \
 	} while (0)
-	S1CHK(hipMalloc(&d_norm, (size_t)special * 4));
 	S1CHK(hipMalloc(&d_status, tiles * 16));
 	S1CHK(hipMalloc(&d_small, 64));
 	S1CHK(hipMalloc(&p->d_tot, (size_t)3 * n_bins * 8));
 	S1CHK(hipMalloc(&p->d_lay, (size_t)(3 * n_bins + 2) * 8));
-	S1CHK(hipMemcpyAsync(d_norm, norm.data(), (size_t)special * 4, hipMemcpyHostToDevice, s.stream));
 	/* signatures are computed inside the cutting kernel (never stored). The number of super-k-mers is only known after the cut: a first guess (one per 8 symbols; real reads give one per 10-40 at k = 27), and a
 	 * second cut with the exact number when the guess was short */
 	u64 cap = n / 8 + 4096, cnt = 0;
@@ -1549,7 +1514,7 @@ int kmc_hip_split_reads_plan(kmc_hip_ctx *ctx, int dev, const int8_t *d_codes, u
 		S1CHK(hipMalloc(&p->d_ssig, cap * 4));
 		S1CHK(hipMemsetAsync(d_status, 0, tiles * 16, s.stream));
 		S1CHK(hipMemsetAsync(d_small, 0, 64, s.stream));
-		k_s1_cut<true><<<dim3((u32)tiles), dim3(S1_BLOCK), 0, s.stream>>>((const u32 *)nullptr, d_codes, signature_len, (const u32 *)d_norm, n, kmer_len, (u64 *)d_status,
+		k_s1_cut<true><<<dim3((u32)tiles), dim3(S1_BLOCK), 0, s.stream>>>((const u32 *)nullptr, d_codes, signature_len, n, kmer_len, (u64 *)d_status,
 		                                                                    (u64 *)d_status + tiles, (u32 *)d_small + 2, (u64 *)p->d_pos, (u32 *)p->d_len,
 		                                                                    (u32 *)p->d_ssig, cap, (u64 *)d_small, (u32 *)d_small + 4);
 		S1CHK(hipGetLastError());

@@ -1,6 +1,7 @@
 /*
  * kmc_amd/csrc/stage1_kernels.hip.h — FIRST kernels of KMC's STAGE 1 on gfx950 (groundwork, not yet a drop-in:
- * no FASTQ parsing, no hand-over to stage 2 yet, reachable only through the test hook kmc_hip_debug_split_reads).
+ * no FASTQ parsing, the signature map is an input; reachable through kmc_hip_split_reads_plan/_emit, which leave bins in HBM in the layout
+ * kmc_hip_process_bins_device takes, and through the test hook kmc_hip_debug_split_reads). DESIGN.md §9.
  *
  * What the reference does (kmc_core/splitter.cpp:557-672, CSplitter::ProcessReads) is a sequential scan per read with a two-variable state
  * (current signature, its position). Its RESULT has a data-parallel description, which oracle/stage1_oracle.c's line-by-line restatement
@@ -28,17 +29,61 @@ constexpr int S1_BLOCK = 256, S1_PER = 4, S1_TILE = S1_BLOCK * S1_PER; /* positi
 constexpr int S1_MAX_K = 256;
 constexpr u32 S1_NOSIG = 0xFFFFFFFFu;
 
+/* norm of an m-mer (kmc_api/mmer.h:39-95: the smaller of the m-mer and its reverse complement among the ALLOWED ones, 4^m if neither is)
+ * computed, not looked up: the reference's table is 1 MB at m = 9, and one gather per position from it made the L2 -> L1 path the limit of
+ * the first version of these kernels (4.4 ms per 300 M positions, profiles/r02/s1_bench_v2_*). */
+__host__ __device__ __forceinline__ bool s1_allowed(u32 x, u32 m) /* mmer.h:39-64 */
+{
+	if ((x & 0x3f) == 0x3f || (x & 0x3f) == 0x3b || (x & 0x3c) == 0x3c) /* ends with TTT or TGT, or has TT in front of its last symbol */
+		return false;
+	const u32 is_a = ~(x | (x >> 1)) & 0x55555555u & ((1u << (2 * m)) - 1u); /* bit 2j: symbol j (from the end) is A */
+	const u32 aa = is_a & (is_a >> 2);                                      /* bit 2j: symbols j and j + 1 are both A */
+	if (aa & ((1u << (2 * (m - 2))) - 1u))                                  /* AA anywhere but in the two leading symbols */
+		return false;
+	return (x >> (2 * (m - 3))) != 0x04u; /* does not start with ACA */
+}
+__host__ __device__ __forceinline__ u32 s1_revcomp(u32 x, u32 m) /* mmer.h:69-80 */
+{
+	u32 y = ~x;
+	y = ((y & 0x33333333u) << 2) | ((y >> 2) & 0x33333333u); /* reverse the sixteen 2-bit groups of the word */
+	y = ((y & 0x0F0F0F0Fu) << 4) | ((y >> 4) & 0x0F0F0F0Fu);
+	y = ((y & 0x00FF00FFu) << 8) | ((y >> 8) & 0x00FF00FFu);
+	y = (y << 16) | (y >> 16);
+	return y >> (32 - 2 * m);
+}
+__host__ __device__ __forceinline__ u32 s1_norm(u32 x, u32 m)
+{
+	const u32 special = 1u << (2 * m), r = s1_revcomp(x, m);
+	const u32 a = s1_allowed(x, m) ? x : special, b = s1_allowed(r, m) ? r : special;
+	return a < b ? a : b;
+}
+
 /* Signatures of the k-mers that start at positions base .. base + cnt - 1 (base may be -1; a position outside [0, n) has none) into
  * s_sig[0 .. cnt), cnt <= S1_TILE + 2. All threads of the block call; the result is visible to all of them on return.
- * norm[] (4^m uint32) lives in global memory: 1 MB at m = 9, L2-resident, one gather per position. */
+ * A thread owns S1_SIG_PER CONSECUTIVE positions in both steps (an odd number: its LDS accesses are bank-conflict free): the m-mer is rolled
+ * from one position to the next (2 byte reads instead of m), and the minimum over the k - m + 1 m-mers of a k-mer is put together from what
+ * the thread's windows share, a suffix of the first S1_SIG_PER - 1 values and a prefix of the last ones (w + 4 reads for 5 windows instead
+ * of 5 w). A k-mer is valid iff all its m-mers are: the maximum over the same window tells (S1_NOSIG marks an m-mer with an invalid symbol). */
+constexpr int S1_SIG_PER = 5;
+static_assert(S1_BLOCK * S1_SIG_PER >= S1_TILE + 2 + S1_MAX_K - 5, "one round covers every m-mer of the span");
 struct S1SigLds {
-	int8_t c[S1_TILE + 2 + S1_MAX_K];    /* symbols of the span: cnt + k - 1 */
-	u32 mm[S1_TILE + 2 + S1_MAX_K];      /* norm of the m-mer at each position */
-	u32 bad[S1_TILE + 2 + S1_MAX_K + 1]; /* exclusive prefix count of invalid symbols */
-	u32 tmp[S1_BLOCK / 64 + 1];
+	int8_t c[(S1_TILE + 2 + S1_MAX_K + 3) / 4 * 4]; /* symbols of the span: cnt + k - 1 */
+	u32 mm[S1_BLOCK * S1_SIG_PER + S1_MAX_K + 8];   /* norm of the m-mer at each position of the span (reads run past the last one, unused) */
 };
-__device__ __forceinline__ void s1_signatures_to_lds(const int8_t *__restrict__ codes, u64 n, long long base, u32 cnt, u32 k, u32 m, const u32 *__restrict__ norm,
-                                                     S1SigLds &L, u32 *s_sig)
+struct S1MinMax {
+	u32 mn, mx;
+	__device__ __forceinline__ void add(u32 v)
+	{
+		mn = v < mn ? v : mn;
+		mx = v > mx ? v : mx;
+	}
+	__device__ __forceinline__ void add(const S1MinMax &o)
+	{
+		mn = o.mn < mn ? o.mn : mn;
+		mx = o.mx > mx ? o.mx : mx;
+	}
+};
+__device__ __forceinline__ void s1_signatures_to_lds(const int8_t *__restrict__ codes, u64 n, long long base, u32 cnt, u32 k, u32 m, S1SigLds &L, u32 *s_sig)
 {
 	const u32 tid = threadIdx.x;
 	const u32 span = cnt + k - 1; /* symbols looked at */
@@ -47,58 +92,73 @@ __device__ __forceinline__ void s1_signatures_to_lds(const int8_t *__restrict__ 
 		L.c[i] = (p >= 0 && (u64)p < n) ? codes[p] : (int8_t)-1;
 	}
 	__syncthreads();
-	/* prefix count of invalid symbols over the span: thread t owns ceil(span / 256) consecutive symbols */
-	{
-		const u32 per = (span + S1_BLOCK - 1) / S1_BLOCK, lo = tid * per;
-		u32 c = 0;
-		for (u32 j = 0; j < per; ++j)
-			if (lo + j < span && L.c[lo + j] < 0)
-				++c;
-		u32 total;
-		u32 run = block_excl_sum<S1_BLOCK / 64, u32>(c, L.tmp, total);
-		for (u32 j = 0; j < per; ++j)
-			if (lo + j < span) {
-				L.bad[lo + j] = run;
-				run += L.c[lo + j] < 0 ? 1u : 0u;
-			}
-		if (tid == S1_BLOCK - 1)
-			L.bad[span] = total;
-	}
 	/* norm of every m-mer that starts at one of the cnt positions or in the k - m positions after them */
-	const u32 n_mm = cnt + k - m;
-	for (u32 i = tid; i < n_mm; i += S1_BLOCK) {
-		u32 x = 0;
-		bool ok = true;
+	const u32 n_mm = cnt + k - m, i0 = tid * S1_SIG_PER;
+	if (i0 < n_mm) {
+		const u32 mask = (1u << (2 * m)) - 1u;
+		u32 x = 0, bad = 0;
 		for (u32 j = 0; j < m; ++j) {
-			const int8_t c = L.c[i + j];
-			ok = ok && c >= 0;
+			const int8_t c = L.c[i0 + j];
+			bad += c < 0 ? 1u : 0u;
 			x = (x << 2) | (u32)(c & 3);
 		}
-		L.mm[i] = ok ? norm[x] : S1_NOSIG;
-	}
-	__syncthreads();
-	for (u32 i = tid; i < cnt; i += S1_BLOCK) {
-		u32 sg = S1_NOSIG;
-		if (L.bad[i + k] == L.bad[i]) { /* k valid symbols: a k-mer starts here */
-			const u32 w = k - m + 1;
-			for (u32 j = 0; j < w; ++j) {
-				const u32 v = L.mm[i + j];
-				sg = v < sg ? v : sg;
+#pragma unroll
+		for (u32 jj = 0; jj < (u32)S1_SIG_PER; ++jj) {
+			const u32 i = i0 + jj;
+			if (i >= n_mm)
+				break;
+			L.mm[i] = bad ? S1_NOSIG : s1_norm(x & mask, m);
+			if (i + 1 < n_mm) {
+				const int8_t cin = L.c[i + m], cout = L.c[i];
+				bad += (cin < 0 ? 1u : 0u) - (cout < 0 ? 1u : 0u);
+				x = (x << 2) | (u32)(cin & 3);
 			}
 		}
-		s_sig[i] = sg;
+	}
+	__syncthreads();
+	const u32 w = k - m + 1;
+	if (i0 < cnt) {
+		if (w >= (u32)S1_SIG_PER) {
+			S1MinMax mid{S1_NOSIG, 0u};
+			for (u32 j = S1_SIG_PER - 1; j < w; ++j) /* shared by the thread's windows */
+				mid.add(L.mm[i0 + j]);
+			u32 a[S1_SIG_PER - 1], b[S1_SIG_PER - 1];
+#pragma unroll
+			for (int j = 0; j < S1_SIG_PER - 1; ++j) {
+				a[j] = L.mm[i0 + j];
+				b[j] = L.mm[i0 + w + j]; /* past the span for the last positions: only windows that do not exist use those */
+			}
+#pragma unroll
+			for (int i = 0; i < S1_SIG_PER; ++i) {
+				S1MinMax r = mid;
+#pragma unroll
+				for (int j = i; j < S1_SIG_PER - 1; ++j)
+					r.add(a[j]);
+#pragma unroll
+				for (int j = 0; j < i; ++j)
+					r.add(b[j]);
+				if (i0 + i < cnt)
+					s_sig[i0 + i] = r.mx == S1_NOSIG ? S1_NOSIG : r.mn;
+			}
+		} else { /* k within 3 of the signature length */
+			for (u32 i = i0; i < i0 + S1_SIG_PER && i < cnt; ++i) {
+				S1MinMax r{S1_NOSIG, 0u};
+				for (u32 j = 0; j < w; ++j)
+					r.add(L.mm[i + j]);
+				s_sig[i] = r.mx == S1_NOSIG ? S1_NOSIG : r.mn;
+			}
+		}
 	}
 	__syncthreads();
 }
 
 /* test hook path: the signature of every position to global memory */
-__global__ void __launch_bounds__(S1_BLOCK) k_s1_signatures(const int8_t *__restrict__ codes, u64 n, u32 k, u32 m, const u32 *__restrict__ norm,
-                                                             u32 *__restrict__ sig)
+__global__ void __launch_bounds__(S1_BLOCK) k_s1_signatures(const int8_t *__restrict__ codes, u64 n, u32 k, u32 m, u32 *__restrict__ sig)
 {
 	__shared__ S1SigLds L;
 	__shared__ u32 s_sig[S1_TILE + 2];
 	const u64 t0 = (u64)blockIdx.x * S1_TILE;
-	s1_signatures_to_lds(codes, n, (long long)t0, S1_TILE, k, m, norm, L, s_sig);
+	s1_signatures_to_lds(codes, n, (long long)t0, S1_TILE, k, m, L, s_sig);
 	for (u32 i = threadIdx.x; i < (u32)S1_TILE; i += S1_BLOCK)
 		if (t0 + i < n)
 			sig[t0 + i] = s_sig[i];
@@ -155,7 +215,7 @@ __device__ __forceinline__ u64 lookback64_last(u64 *status, u32 tile, u64 own_la
  * workgroup the kernel ran at the rate of its same-address ticket atomic (50 tiles/us: 5.9 ms per 300 M positions, profiles/r02/s1_bench_v1*).
  * status_last / status_cnt: one zeroed u64 per WORKGROUP tile each (s1_cut_tiles(n) of them). sk_* receive the super-k-mers in position order;
  * *n_sk their number (written by the last tile). sk_cap bounds the writes (KERR_CAPACITY beyond it).
- * FUSED = false: signatures come from `sig` (k_s1_signatures ran before; codes, m, norm unused). FUSED = true: the workgroup computes the
+ * FUSED = false: signatures come from `sig` (k_s1_signatures ran before; codes, m unused). FUSED = true: the workgroup computes the
  * signatures it needs in LDS itself (sig unused): 1 byte per symbol read instead of 4 written + 4 read. */
 #ifndef S1_SUB_N
 #define S1_SUB_N 4
@@ -165,7 +225,7 @@ static_assert(S1_PER == 4, "the pieces of a thread's positions are packed into o
 __host__ __device__ inline u64 s1_cut_tiles(u64 n) { return (n + S1_WG_TILE - 1) / S1_WG_TILE; }
 
 template <bool FUSED>
-__global__ void __launch_bounds__(S1_BLOCK) k_s1_cut(const u32 *__restrict__ sig, const int8_t *__restrict__ codes, u32 m, const u32 *__restrict__ norm, u64 n, u32 k,
+__global__ void __launch_bounds__(S1_BLOCK) k_s1_cut(const u32 *__restrict__ sig, const int8_t *__restrict__ codes, u32 m, u64 n, u32 k,
                                                       u64 *status_last, u64 *status_cnt, u32 *ticket_ctr, u64 *__restrict__ sk_pos, u32 *__restrict__ sk_len,
                                                       u32 *__restrict__ sk_sig, u64 sk_cap, u64 *n_sk, u32 *err)
 {
@@ -187,7 +247,7 @@ __global__ void __launch_bounds__(S1_BLOCK) k_s1_cut(const u32 *__restrict__ sig
 		__shared__ S1SigLds L;
 #pragma unroll 1
 		for (int sub = 0; sub < S1_SUB; ++sub)
-			s1_signatures_to_lds(codes, n, (long long)w0 - 1 + (long long)sub * S1_TILE, sub == S1_SUB - 1 ? S1_TILE + 2 : S1_TILE, k, m, norm, L, s_sig + sub * S1_TILE);
+			s1_signatures_to_lds(codes, n, (long long)w0 - 1 + (long long)sub * S1_TILE, sub == S1_SUB - 1 ? S1_TILE + 2 : S1_TILE, k, m, L, s_sig + sub * S1_TILE);
 	} else {
 		for (u32 i = tid; i < (u32)S1_WG_TILE + 2; i += S1_BLOCK) {
 			const long long q = (long long)w0 - 1 + (long long)i;
@@ -424,7 +484,17 @@ __global__ void __launch_bounds__(256) k_s1_emit(const int8_t *__restrict__ code
 		uint8_t *dst = out + s_base[b] + atomicAdd(&s_bytes[b], bytes);
 		const int8_t *src = codes + sk_pos[i];
 		dst[0] = (uint8_t)(len - k);
-		for (u32 q = 0; q < (len + 3u) / 4u; ++q) { /* four symbols per byte, first one in bits 7:6; missing ones are zero */
+		/* four symbols per byte, first one in bits 7:6. Eight symbols per (unaligned) 8-byte load while they last: one load per symbol made
+		 * this kernel wait for its 36 scattered byte loads per record */
+		u32 q = 0;
+		for (; 8u * (q / 2u) + 8u <= len; q += 2) {
+			u64 w8;
+			__builtin_memcpy(&w8, src + 4u * q, 8);
+			const u32 lo = (u32)w8, hi = (u32)(w8 >> 32);
+			dst[1 + q] = (uint8_t)(((lo & 3u) << 6) | (((lo >> 8) & 3u) << 4) | (((lo >> 16) & 3u) << 2) | ((lo >> 24) & 3u));
+			dst[2 + q] = (uint8_t)(((hi & 3u) << 6) | (((hi >> 8) & 3u) << 4) | (((hi >> 16) & 3u) << 2) | ((hi >> 24) & 3u));
+		}
+		for (; q < (len + 3u) / 4u; ++q) { /* the last 1 - 7 symbols; missing ones are zero */
 			u32 v = 0;
 #pragma unroll
 			for (u32 t = 0; t < 4; ++t) {

@@ -46,8 +46,8 @@ def lib(geometry="small"):
         L.emu_group_compact.restype = C.c_int
         L.emu_group_compact.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p]
         L.emu_s1_split.restype = C.c_int
-        L.emu_s1_split.argtypes = [C.c_void_p, C.c_uint64, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p,
-                                   C.c_int]
+        L.emu_s1_split.argtypes = [C.c_void_p, C.c_uint64, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_int]
+        L.emu_s1_norm_all.argtypes = [C.c_uint32, C.c_void_p]
         L.emu_s1_scatter.restype = C.c_int
         L.emu_s1_scatter.argtypes = [C.c_void_p] * 4 + [C.c_uint64, C.c_uint32, C.c_void_p, C.c_uint32] + [C.c_void_p] * 4 + [C.c_uint64, C.c_void_p, C.c_uint64]
         L.emu_s1_geometry.argtypes = [C.c_void_p]
@@ -127,7 +127,7 @@ def group_compact(p, sorted_recs, n_recs, geometry="small"):
     return err, [(outs[i][: int(ob[i])].copy(), luts[i, :lut_n].copy(), stats[i].copy()) for i in range(g)]
 
 
-def s1_split(codes: np.ndarray, k: int, norm: np.ndarray, m: int = 9, geometry="small", fused=True):
+def s1_split(codes: np.ndarray, k: int, m: int = 9, geometry="small", fused=True):
     """stage-1 kernels on a code stream (int8: 0..3, negative = invalid/separator). Returns (err, sig per position, sk_pos, sk_len, sk_sig).
     fused: the cutting kernel computes its signatures itself (kmc_hip_split_reads_plan); otherwise it reads k_s1_signatures' output (the test hook)."""
     codes = np.ascontiguousarray(codes, dtype=np.int8)
@@ -138,10 +138,17 @@ def s1_split(codes: np.ndarray, k: int, norm: np.ndarray, m: int = 9, geometry="
     ln = np.zeros(cap, dtype=np.uint32)
     sg = np.zeros(cap, dtype=np.uint32)
     nsk = C.c_uint64(0)
-    err = lib(geometry).emu_s1_split(codes.ctypes.data, n, k, m, np.ascontiguousarray(norm).ctypes.data, sig.ctypes.data, pos.ctypes.data, ln.ctypes.data,
+    err = lib(geometry).emu_s1_split(codes.ctypes.data, n, k, m, sig.ctypes.data, pos.ctypes.data, ln.ctypes.data,
                                      sg.ctypes.data, cap, C.addressof(nsk), 1 if fused else 0)
     j = nsk.value
     return err, sig[:n], pos[:j].copy(), ln[:j].copy(), sg[:j].copy()
+
+
+def s1_norm_all(m: int, geometry="small") -> np.ndarray:
+    """the kernels' computed normalisation of every m-mer (s1_norm of stage1_kernels.hip.h)"""
+    out = np.zeros(1 << (2 * m), dtype=np.uint32)
+    lib(geometry).emu_s1_norm_all(m, out.ctypes.data)
+    return out
 
 
 def s1_geometry(geometry="small"):

@@ -397,7 +397,7 @@ EMU_API int emu_group_compact(const unsigned *params10, int g, const u64 *sorted
 /* stage-1 kernels: codes (0..3, negative = invalid / separator) -> signature per k-mer position, and the super-k-mers in position order.
  * Returns the device error word; *n_sk = number of super-k-mers. */
 /* fused != 0: the cutting kernel computes the signatures itself (the product path of kmc_hip_split_reads_plan); `sig` is still filled, by k_s1_signatures */
-EMU_API int emu_s1_split(const int8_t *codes, u64 n, unsigned k, unsigned m, const u32 *norm, u32 *sig, u64 *sk_pos, u32 *sk_len, u32 *sk_sig, u64 sk_cap, u64 *n_sk,
+EMU_API int emu_s1_split(const int8_t *codes, u64 n, unsigned k, unsigned m, u32 *sig, u64 *sk_pos, u32 *sk_len, u32 *sk_sig, u64 sk_cap, u64 *n_sk,
                          int fused)
 {
 	u32 err = 0;
@@ -407,16 +407,23 @@ EMU_API int emu_s1_split(const int8_t *codes, u64 n, unsigned k, unsigned m, con
 	const u32 tiles = (u32)((n + S1_TILE - 1) / S1_TILE), ctiles = (u32)s1_cut_tiles(n);
 	std::vector<u64> st_last(ctiles, 0), st_cnt(ctiles, 0);
 	u32 ticket = 0;
-	hipemu::launch(dim3(tiles), dim3(S1_BLOCK), 0, [&] { k_s1_signatures(codes, n, k, m, norm, sig); });
+	hipemu::launch(dim3(tiles), dim3(S1_BLOCK), 0, [&] { k_s1_signatures(codes, n, k, m, sig); });
 	if (fused)
 		hipemu::launch(dim3(ctiles), dim3(S1_BLOCK), 0, [&] {
-			k_s1_cut<true>((const u32 *)nullptr, codes, m, norm, n, k, st_last.data(), st_cnt.data(), &ticket, sk_pos, sk_len, sk_sig, sk_cap, n_sk, &err);
+			k_s1_cut<true>((const u32 *)nullptr, codes, m, n, k, st_last.data(), st_cnt.data(), &ticket, sk_pos, sk_len, sk_sig, sk_cap, n_sk, &err);
 		});
 	else
 		hipemu::launch(dim3(ctiles), dim3(S1_BLOCK), 0, [&] {
-			k_s1_cut<false>(sig, (const int8_t *)nullptr, 0u, (const u32 *)nullptr, n, k, st_last.data(), st_cnt.data(), &ticket, sk_pos, sk_len, sk_sig, sk_cap, n_sk, &err);
+			k_s1_cut<false>(sig, (const int8_t *)nullptr, 0u, n, k, st_last.data(), st_cnt.data(), &ticket, sk_pos, sk_len, sk_sig, sk_cap, n_sk, &err);
 		});
 	return (int)err;
+}
+
+/* the kernels' computed m-mer normalisation for every m-mer of length m: out[4^m] */
+EMU_API void emu_s1_norm_all(unsigned m, u32 *out)
+{
+	for (u32 x = 0; x < (1u << (2 * m)); ++x)
+		out[x] = s1_norm(x, m);
 }
 
 /* stage-1 bin scatter: super-k-mers -> bin records in per-bin streams + pack boundaries (k_s1_bin_totals, k_s1_bin_layout, k_s1_emit).

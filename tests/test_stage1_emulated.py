@@ -28,13 +28,12 @@ def _reads(rng, k, n_reads, read_len):
 
 
 @pytest.mark.parametrize("fused,geometry", [(True, "small"), (False, "small"), (True, "product")])
-@pytest.mark.parametrize("k,m", [(27, 9), (21, 9), (55, 9), (14, 7), (200, 9), (28, 11), (256, 11), (9, 9)])
+@pytest.mark.parametrize("k,m", [(27, 9), (21, 9), (55, 9), (14, 7), (200, 9), (28, 11), (256, 11), (9, 9), (12, 9), (13, 9), (256, 5)])
 def test_emulated_stage1_signatures_and_cut_match_the_oracle(k, m, fused, geometry):
     """small geometry: two 1024-position tiles per cutting workgroup, product: four"""
     rng = np.random.default_rng(k * 10 + m)
     codes = _stream(_reads(rng, k, 40, 150))
-    norm = S1.norm_table(m)
-    err, sig, pos, ln, sg = emu.s1_split(codes, k, norm, m, fused=fused, geometry=geometry)
+    err, sig, pos, ln, sg = emu.s1_split(codes, k, m, fused=fused, geometry=geometry)
     assert err == 0
     w_pos, w_len, w_sig = S1.split_stream(codes, k, m)
     assert pos.size == w_pos.size, (pos.size, w_pos.size)
@@ -56,11 +55,16 @@ def test_emulated_stage1_tile_boundaries():
     per = acgt[rng.integers(0, 4, size=13)].tobytes()
     for pad in (0, 1, 1000, 1023, 1024, 1025, 2047, 2048, 4095, 4096, 4097, 8191):
         codes = _stream([acgt[rng.integers(0, 4, size=pad)].tobytes() if pad else b"", (per * 400)[:4000], b"A" * 3000])
-        norm = S1.norm_table(m)
         for fused, geometry in ((True, "small"), (False, "small"), (True, "product")):
-            err, sig, pos, ln, sg = emu.s1_split(codes, k, norm, m, fused=fused, geometry=geometry)
+            err, sig, pos, ln, sg = emu.s1_split(codes, k, m, fused=fused, geometry=geometry)
             w_pos, w_len, w_sig = S1.split_stream(codes, k, m)
             assert err == 0 and np.array_equal(pos, w_pos.astype(np.uint64)) and np.array_equal(ln, w_len) and np.array_equal(sg, w_sig), (pad, fused, geometry)
+
+
+@pytest.mark.parametrize("m", [5, 6, 7, 8, 9, 10, 11])
+def test_computed_mmer_normalisation_equals_the_reference_table(m):
+    """the kernels compute norm(m-mer) with bit operations instead of reading CMmer's table: all 4^m values against the oracle's table"""
+    assert np.array_equal(emu.s1_norm_all(m), S1.norm_table(m))
 
 
 def _parse_bin(img, k):
@@ -89,8 +93,7 @@ def test_emulated_stage1_bin_scatter_matches_the_oracle(k, m, n_bins):
     while len(S1.split(reads, k, m)[0]) <= 1100 or S1.split(reads, k, m)[2].size < need_bytes:  # more than one tile of super-k-mers
         reads += _reads(rng, k, 60, max(150, 2 * k))
     codes = _stream(reads)
-    norm = S1.norm_table(m)
-    err, _, pos, ln, sg = emu.s1_split(codes, k, norm, m)
+    err, _, pos, ln, sg = emu.s1_split(codes, k, m)
     assert err == 0 and pos.size > 1024
     smap = _sig_map(m, n_bins, 7)
     r = emu.s1_scatter(codes, pos, ln, sg, k, smap, n_bins)
@@ -129,7 +132,7 @@ def test_emulated_stage1_bin_scatter_reports_an_unknown_signature():
     k, m = 27, 9
     rng = np.random.default_rng(1)
     codes = _stream(_reads(rng, k, 30, 150))
-    err, _, pos, ln, sg = emu.s1_split(codes, k, S1.norm_table(m), m)
+    err, _, pos, ln, sg = emu.s1_split(codes, k, m)
     smap = _sig_map(m, 16, 3)
     bad = smap.copy()
     bad[sg[5]] = -1
@@ -156,7 +159,7 @@ def test_emulated_reads_to_database_records_stage1_into_stage2():
         reads.append(r)
     reads += [genome[:40] + b"N" + genome[40:90], b"A" * 400]
     codes = _stream(reads)
-    err, _, pos, ln, sg = emu.s1_split(codes, k, S1.norm_table(m), m)
+    err, _, pos, ln, sg = emu.s1_split(codes, k, m)
     assert err == 0
     smap = _sig_map(m, n_bins, 11)
     r = emu.s1_scatter(codes, pos, ln, sg, k, smap, n_bins)
@@ -185,6 +188,6 @@ def test_emulated_stage1_cut_over_more_than_64_workgroup_tiles():
     reads = [acgt[rng.integers(0, 4, size=150)].tobytes() for _ in range(840)] + [b"A" * 9000] + [acgt[rng.integers(0, 4, size=150)].tobytes() for _ in range(60)]
     codes = _stream(reads)
     assert codes.size > 70 * 2048
-    err, _, pos, ln, sg = emu.s1_split(codes, k, S1.norm_table(m), m, fused=True)
+    err, _, pos, ln, sg = emu.s1_split(codes, k, m, fused=True)
     w_pos, w_len, w_sig = S1.split_stream(codes, k, m)
     assert err == 0 and np.array_equal(pos, w_pos.astype(np.uint64)) and np.array_equal(ln, w_len) and np.array_equal(sg, w_sig)
