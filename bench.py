@@ -21,6 +21,7 @@ Extra keys of the N=1 line (each measured after the timed region, none inside it
   value_host_boundary : the same bins through kmc_hip_process_bin_submit/_wait from pinned host memory (PCIe inclusive)
   secondary.single_bin: configs[1] — 2 Gbp, all k-mers as ONE bin (the kernel-level datum of round 1)
   secondary.bins512_2gbp: the 2 Gbp sample cut into 512 bins (3.2 M k-mers per bin), tallies checked against the reference
+  secondary.stage1_groundwork: NOT stage 2 — the splitter groundwork of DESIGN.md 9 (codes in HBM -> bins in HBM), timed by tools/s1_bench.py
   cpu_baseline / e2e  : the REAL reference (oracle/_ref/kmc, built from /root/reference by oracle/Makefile) and the drop-in
                         (oracle/_ref/kmc_hip = reference pipeline + this library) on a FASTQ of the SAME reads as the 2 Gbp sample:
                         "2nd stage" seconds of each, the five statistics compared.
@@ -371,6 +372,20 @@ def secondary_leg(name: str, k: int, extra):
     return {"error": (r.stdout + r.stderr)[-500:]}
 
 
+def stage1_leg(k: int):
+    """NOT part of `value`: the stage-1 groundwork timed by tools/s1_bench.py in its own process — reads already in HBM as
+    codes -> signature bins in HBM, the hand-over kmc_hip_process_bins_device takes. Informative only; never loses the stage-2 line."""
+    cmd = [sys.executable, os.path.join(os.path.dirname(os.path.abspath(__file__)), "tools", "s1_bench.py"), "--k", str(k)]
+    try:
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=180)
+        for ln in reversed(r.stdout.splitlines()):
+            if ln.startswith("{"):
+                return json.loads(ln)
+        return {"error": (r.stdout + r.stderr)[-500:]}
+    except Exception as e:  # noqa: BLE001
+        return {"error": repr(e)}
+
+
 # ---------------------------------------------------------------------------------------------------------------- main
 def main():
     ap = argparse.ArgumentParser()
@@ -540,6 +555,7 @@ def main():
             sec["single_bin"] = {kk: s1.get(kk) for kk in ("value", "ms_per_step", "config", "roofline", "tallies", "phases_ms_last_bin_slot0", "stage2_frac_of_hbm_peak", "error") if kk in s1}
             s2 = secondary_leg("2gbp-512bins", k, [])
             sec["bins512_2gbp"] = {kk: s2.get(kk) for kk in ("value", "ms_per_step", "config", "roofline", "tallies", "stage2_frac_of_hbm_peak", "error") if kk in s2}
+            sec["stage1_groundwork"] = stage1_leg(k)
             out["secondary"] = sec
         if not args.no_cpu_baseline:
             try:

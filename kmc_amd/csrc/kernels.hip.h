@@ -1030,7 +1030,8 @@ __global__ void __launch_bounds__(RS_BLOCK, (SIZE <= 4 ? RS_MIN_WAVES : RS_MIN_W
 			u32 excl = 0;
 			if (tile > 0) {
 				int t = (int)tile - 1;
-				u32 spins = 0, rounds = 0;
+				u32 spins = 0;
+				[[maybe_unused]] u32 rounds = 0; /* read by the trace build only */
 				TRACE_STAMP(2, tile, 1);
 				/* decoupled look-back: walk back over earlier tiles, RS_LOOKBACK_K status words per round trip, until an
 				 * inclusive prefix is met; then publish this tile's */
