@@ -166,6 +166,14 @@ public:
 			bd->read(bin_id, file, desc, tmp_size, tmp_n_rec, n_plus_x_recs);
 			sum_n_rec += n_rec;
 			sum_n_plus_x_rec += n_plus_x_recs;
+			if (const char *dd = getenv("KMC_HIP_BINDESC_DUMP")) { /* tests: what stage 1 recorded for this bin (CBinDesc, queues.h:643-680) */
+				static std::mutex dump_mtx;
+				std::lock_guard<std::mutex> lck(dump_mtx);
+				if (FILE *f = fopen(dd, "a")) {
+					fprintf(f, "%d %llu %llu %llu\n", (int)bin_id, (unsigned long long)tmp_size, (unsigned long long)tmp_n_rec, (unsigned long long)n_plus_x_recs);
+					fclose(f);
+				}
+			}
 
 			list<pair<uint64, uint64>> packs;
 			epd->pop(bin_id, packs);

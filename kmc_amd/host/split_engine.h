@@ -1,0 +1,44 @@
+/*
+ * kmc_amd/host/split_engine.h — the per-part compute engine the stage-1 worker (kb_splitter_plugin.h) drives.
+ *
+ * One engine instance per splitter thread. split_part() does for one part of input text what CSplitter::ProcessReads does with its n_bins
+ * CKmerBinCollectors (splitter.cpp:557-672, kb_collector.cpp:34-106) up to, but not including, the bin-part buffers: it returns the bin
+ * records of the part grouped by bin, with the three sums the collector keeps per buffer. The worker copies them into pmm_bins buffers
+ * and pushes those to the storer exactly as the collectors would.
+ *   - oracle engine: oracle/stage1_oracle.c (TEST ONLY: oracle/oracle_engine_s1.h -> oracle/_ref/kmc_oracle_s1; pins the worker's protocol
+ *     and the oracle's parser and k+x-mer bookkeeping to the reference: the database must be byte-identical)
+ *   - HIP engine   : not written yet (kmc_hip_split_reads_* produce the records on the device; the text -> codes step and the
+ *     k+x-mer sums are the missing kernels)
+ */
+#ifndef KMC_AMD_SPLIT_ENGINE_H
+#define KMC_AMD_SPLIT_ENGINE_H
+
+#include <stdint.h>
+#include <string>
+
+struct KmcSplitParams {
+	uint32_t kmer_len, signature_len, n_bins, max_x;
+	int both_strands;
+	int file_type;             /* 0 = FASTA (one line per sequence), 1 = FASTQ */
+	uint64_t line_cap;         /* mem_part_pmm_reads: longer lines are cut into pieces overlapping by kmer_len - 1 symbols (splitter.cpp:141-145) */
+	const int32_t *sig_to_bin; /* CSignatureMapper's map, 4^signature_len + 1 entries (s_mapper.h:232) */
+};
+
+/* valid until the next split_part() on the same engine */
+struct KmcSplitResult {
+	const uint8_t *recs;       /* the records of all bins, bin after bin */
+	const uint64_t *bin_off;   /* n_bins + 1 byte offsets into recs */
+	const uint64_t *bin_kmers, *bin_superkmers, *bin_plus_x; /* n_bins each: n_recs, n_super_kmers, n_plus_x_recs of the collector */
+	uint64_t n_reads;          /* records whose title line the part holds (CSplitter::n_reads) */
+};
+
+struct KmcSplitEngine {
+	virtual ~KmcSplitEngine() {}
+	virtual int split_part(const uint8_t *text, uint64_t size, KmcSplitResult &out) = 0;
+	virtual std::string last_error() = 0;
+};
+
+/* Provided by exactly one engine implementation linked into the binary. */
+KmcSplitEngine *kmc_make_split_engine(const KmcSplitParams &params, int worker_idx, int n_workers);
+
+#endif

@@ -219,3 +219,191 @@ int64_t oracle_s1_split_all(const int8_t *seqs, const uint64_t *seq_off, uint64_
 	free(tmp);
 	return (int64_t)n;
 }
+
+/* ------------------------------------------------------------------------------------------------ collector bookkeeping
+ * n_plus_x_recs of one super-k-mer: how many (k+x)-mer records the reference's stage 2 will expand it into — the collector adds it up per
+ * bin part (kb_collector.cpp:83-100, kb_collector.h:72-118) and stage 2 sizes its arrays with the sums. seq: the super-k-mer's n symbols. */
+uint32_t oracle_s1_kxmer_recs(const int8_t *seq, uint32_t n, uint32_t kmer_len, uint32_t max_x, int both_strands)
+{
+	if (!max_x)
+		return 0; /* kb_collector.cpp:85: plain k-mers are sorted, nothing is counted */
+	if (!both_strands)
+		return 1 + (n - kmer_len) / (max_x + 1); /* kb_collector.cpp:87-88 */
+	/* kb_collector.h:72-118, DIVIDE_FACTOR = max_x + 1: a run of k-mers on which "k-mer < its reverse complement" (compared on their
+	 * first four symbols only, one byte each) keeps one answer makes 1 + run / (max_x + 1) records; every k-mer of a tie is its own record */
+	const uint32_t div = max_x + 1;
+	uint8_t kmer = (uint8_t)((seq[0] << 6) + (seq[1] << 4) + (seq[2] << 2) + seq[3]);
+	uint8_t rev = (uint8_t)(((3 - seq[kmer_len - 1]) << 6) + ((3 - seq[kmer_len - 2]) << 4) + ((3 - seq[kmer_len - 3]) << 2) + (3 - seq[kmer_len - 4]));
+	uint32_t kmer_pos = 4, rev_pos = kmer_len, x = 0, total = 0;
+	int state = kmer < rev ? 0 : (rev < kmer ? 1 : 2), ns;
+	for (uint32_t i = 0; i < n - kmer_len; ++i) {
+		rev = (uint8_t)(rev >> 2);
+		rev = (uint8_t)(rev + ((3 - seq[rev_pos++]) << 6));
+		kmer = (uint8_t)(kmer << 2);
+		kmer = (uint8_t)(kmer + seq[kmer_pos++]);
+		ns = kmer < rev ? 0 : (rev < kmer ? 1 : 2);
+		if (ns == state) {
+			if (state == 2)
+				++total;
+			else
+				++x;
+		} else {
+			state = ns;
+			total += 1 + x / div;
+			x = 0;
+		}
+	}
+	return total + 1 + x / div;
+}
+
+/* ------------------------------------------------------------------------------------------------ parts of input text
+ * CSplitter::GetSeq for short reads (splitter.cpp:92-303): one call hands out the next sequence of a part of a FASTA (file_type 0) or FASTQ
+ * (file_type 1) file as codes. `st` carries the reference's member state between calls. Returns 0 when the part is exhausted.
+ * line_cap = mem_part_pmm_reads: a longer line comes in pieces that overlap by kmer_len - 1 symbols. */
+typedef struct {
+	const uint8_t *part;
+	uint64_t part_size, part_pos, n_reads;
+	uint32_t curr_read_len;
+} oracle_s1_part;
+
+static const int8_t *s1_codes(void) /* splitter.cpp:41-47 */
+{
+	static int8_t codes[256];
+	static int init = 0;
+	if (!init) {
+		for (int i = 0; i < 256; ++i)
+			codes[i] = -1;
+		codes['A'] = codes['a'] = 0;
+		codes['C'] = codes['c'] = 1;
+		codes['G'] = codes['g'] = 2;
+		codes['T'] = codes['t'] = 3;
+		init = 1;
+	}
+	return codes;
+}
+
+static int s1_is_eol(uint8_t c) { return c == '\n' || c == '\r'; }
+
+static int s1_get_seq(oracle_s1_part *st, int file_type, uint32_t kmer_len, uint64_t line_cap, int8_t *seq, uint32_t *seq_size)
+{
+	const uint8_t *part = st->part;
+	const int8_t *codes = s1_codes();
+	if (st->part_pos >= st->part_size) /* :94 */
+		return 0;
+	uint8_t c = 0;
+	uint32_t pos = 0;
+	const uint8_t marker = file_type == 0 ? '>' : '@';
+	if (st->curr_read_len == 0) {
+		c = part[st->part_pos++]; /* title, :105-117 / :194-206 */
+		if (c != marker)
+			return 0;
+		++st->n_reads;
+		while (st->part_pos < st->part_size) {
+			c = part[st->part_pos++];
+			if (s1_is_eol(c))
+				break;
+		}
+		if (st->part_pos >= st->part_size)
+			return 0;
+		c = part[st->part_pos++]; /* second end-of-line byte, unless the read is empty, :119-123 / :208-212 */
+		if (c >= 32 || c == part[st->part_pos - 2])
+			st->part_pos--;
+		else if (st->part_pos >= st->part_size)
+			return 0;
+	}
+	/* sequence, :126-132 / :215-221 (first piece) and :152-158 / :236-242 (a further piece of a long line) */
+	while (st->part_pos < st->part_size && pos < line_cap) {
+		c = part[st->part_pos++];
+		if (s1_is_eol(c))
+			break;
+		seq[pos++] = codes[c];
+	}
+	if (file_type == 0) { /* FASTA: the part may end with the sequence, :134-137 / :160-163 */
+		*seq_size = pos;
+		if (st->part_pos >= st->part_size)
+			return 1;
+	} else { /* FASTQ: the quality line must follow, :222-223 / :243-244 */
+		if (st->part_pos >= st->part_size)
+			return 0;
+		*seq_size = pos;
+	}
+	const int first = st->curr_read_len == 0;
+	if (first)
+		st->curr_read_len = pos; /* :139 / :226 */
+	else
+		st->curr_read_len += pos - kmer_len + 1; /* :165 / :246 */
+	if (pos >= line_cap) { /* :141-145 etc.: the line goes on; the next piece starts kmer_len - 1 symbols back */
+		st->part_pos -= kmer_len - 1;
+		return 1;
+	}
+	if (file_type == 0) { /* :172-183 */
+		st->curr_read_len = 0;
+		if (st->part_pos >= st->part_size)
+			return 1;
+		const uint8_t tmp = part[st->part_pos++];
+		if (!s1_is_eol(tmp))
+			st->part_pos--;
+		else if (st->part_pos >= st->part_size)
+			return 1;
+		return 1;
+	}
+	c = part[st->part_pos++]; /* FASTQ :254-258: second end-of-line byte of the sequence line */
+	if (!s1_is_eol(c))
+		st->part_pos--;
+	else if (st->part_pos >= st->part_size)
+		return 0;
+	c = part[st->part_pos++]; /* plus line, :260-272 */
+	if (st->part_pos >= st->part_size)
+		return 0;
+	if (c != '+')
+		return 0;
+	while (st->part_pos < st->part_size) {
+		c = part[st->part_pos++];
+		if (s1_is_eol(c))
+			break;
+	}
+	if (st->part_pos >= st->part_size)
+		return 0;
+	c = part[st->part_pos++]; /* :274-278: second end-of-line byte, unless the quality is empty */
+	if (c >= 32 || c == part[st->part_pos - 2])
+		st->part_pos--;
+	else if (st->part_pos >= st->part_size)
+		return 0;
+	st->part_pos += st->curr_read_len; /* quality skipped by length, :281 */
+	st->curr_read_len = 0;
+	if (st->part_pos >= st->part_size)
+		return 0;
+	c = part[st->part_pos++]; /* :287 */
+	if (st->part_pos >= st->part_size) /* end of the last record, :290-291 */
+		return 1;
+	const uint8_t tmp = part[st->part_pos++]; /* :294-298 */
+	if (!s1_is_eol(tmp))
+		st->part_pos--;
+	else if (st->part_pos >= st->part_size)
+		return 1;
+	return 1;
+}
+
+/* All sequences of one part: codes back to back into `codes_out` (capacity >= part_size), seq_off[0 .. n_seq]; *n_reads = records whose
+ * title was seen. Returns the number of sequences handed out, or -1 when seq_cap is too small. */
+int64_t oracle_s1_parse_part(const uint8_t *part, uint64_t part_size, int file_type, uint32_t kmer_len, uint64_t line_cap, int8_t *codes_out, uint64_t *seq_off,
+                             uint64_t seq_cap, uint64_t *n_reads)
+{
+	oracle_s1_part st = {part, part_size, 0, 0, 0};
+	int8_t *line = (int8_t *)malloc(line_cap + 16);
+	uint64_t n = 0, at = 0;
+	uint32_t sz = 0;
+	seq_off[0] = 0;
+	while (s1_get_seq(&st, file_type, kmer_len, line_cap, line, &sz)) {
+		if (n >= seq_cap) {
+			free(line);
+			return -1;
+		}
+		memcpy(codes_out + at, line, sz);
+		at += sz;
+		seq_off[++n] = at;
+	}
+	free(line);
+	*n_reads = st.n_reads;
+	return (int64_t)n;
+}

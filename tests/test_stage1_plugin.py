@@ -1,0 +1,151 @@
+"""CPU: the stage-1 splitter worker plug-in (kmc_amd/host/kb_splitter_plugin.h — the drop-in boundary of a GPU stage 1)
+inside the REAL reference pipeline, with the stage-1 oracle as its per-part engine (oracle/_ref/kmc_oracle_s1, oracle/Makefile). The database
+must be byte-identical to the unmodified reference's: that pins the worker's protocol towards the storer and the bin descriptors, the oracle's
+text parser, and the k+x-mer sums the reference's stage 2 sizes its arrays with. kmc_oracle_all = every plug-in of this repo at once
+(splitter + stage-2 worker + bin reader + completer), both engines the oracles. Skipped where oracle/_ref is not built."""
+import hashlib
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from kmc_amd import synth
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REF = os.path.join(ROOT, "oracle", "_ref")
+needs_ref = pytest.mark.skipif(not os.path.exists(os.path.join(REF, "kmc_oracle_s1")), reason="oracle/_ref not built (needs /root/reference)")
+
+
+def _run(exe, flags, inp, tmp_path, tag, env=None):
+    t = tmp_path / ("tmp_" + tag)
+    t.mkdir(exist_ok=True)
+    db = str(tmp_path / ("db_" + tag))
+    r = subprocess.run([os.path.join(REF, exe), *flags, inp, db, str(t)], capture_output=True, text=True, env=dict(os.environ, **(env or {})))
+    assert r.returncode == 0, (exe, flags, (r.stdout + r.stderr)[-800:])
+    md5 = tuple(hashlib.md5(open(db + e, "rb").read()).hexdigest() for e in (".kmc_pre", ".kmc_suf"))
+    stats = [ln.split(":")[1].strip() for ln in r.stdout.splitlines() if "No. of" in ln or "Total no." in ln]
+    _run.report = [ln for ln in r.stderr.splitlines() if ln.startswith("[kmc_hip stage 1]")]
+    return md5, stats
+
+
+def _report_sum(what):
+    """sum over the workers' KMC_HIP_VERBOSE lines of the number in front of `what`"""
+    import re
+
+    return sum(int(m.group(1)) for ln in _run.report for m in [re.search(r"(\d+) " + re.escape(what), ln)] if m)
+
+
+def _rnd(rng, n):
+    return np.frombuffer(b"ACGT", dtype=np.uint8)[rng.integers(0, 4, size=n)].tobytes()
+
+
+@needs_ref
+@pytest.mark.parametrize("exe", ["kmc_oracle_s1", "kmc_oracle_all"])
+@pytest.mark.parametrize("flags", [["-k27", "-ci1", "-sp4"], ["-k21", "-sp1"], ["-k55", "-ci2", "-sp8"], ["-k27", "-b", "-ci1", "-sp3"], ["-k32", "-sp2"],
+                                   ["-k127", "-ci1", "-sp2"], ["-k27", "-p5", "-n64", "-sp2"]], ids=lambda f: "".join(f))
+def test_splitter_plugin_writes_the_reference_database(exe, flags, tmp_path):
+    fq = str(tmp_path / "in.fq")
+    synth.make_fastq(fq, seed=11, genome_len=300_000, n_reads=40_000, read_len=150)
+    common = ["-m2", "-sf1", "-sr1"]
+    want = _run("kmc", [f for f in flags if not f.startswith("-sp")] + common + ["-sp1"], fq, tmp_path, "ref")
+    got = _run(exe, flags + common, fq, tmp_path, "plug")
+    assert got == want
+
+
+def _edge_case_records(k):
+    rng = np.random.default_rng(5)
+    per = _rnd(rng, 11)
+    return [_rnd(rng, 150) + b"N" + _rnd(rng, 80) + b"NN" + _rnd(rng, k - 1) + b"n" + _rnd(rng, 200), (per * 80)[:700], _rnd(rng, k), _rnd(rng, k - 1), b"", b"N" * 40,
+            _rnd(rng, 3000), b"A" * 300, b"AC" * 200, _rnd(rng, 120).lower(), b"ACGTRYKM" * 20, _rnd(rng, 1)]
+
+
+@needs_ref
+@pytest.mark.parametrize("eol", [b"\n", b"\r\n"])
+@pytest.mark.parametrize("fmt", ["fq", "fa"])
+def test_splitter_plugin_on_text_edge_cases(fmt, eol, tmp_path):
+    """empty reads, reads shorter than k, N runs, lower case, IUPAC codes, CRLF line ends, FASTA — every way the text parser can be wrong"""
+    k = 27
+    rng = np.random.default_rng(3)
+    genome = _rnd(rng, 50_000)
+    recs = _edge_case_records(k) + [genome[a:a + 100] for a in rng.integers(0, len(genome) - 100, size=3000)]
+    path = str(tmp_path / ("in." + fmt))
+    with open(path, "wb") as f:
+        for i, r in enumerate(recs):
+            if fmt == "fq":
+                f.write(b"@r%d some text" % i + eol + r + eol + b"+" + eol + b"I" * len(r) + eol)
+            else:
+                f.write(b">r%d some text" % i + eol + r + eol)
+    flags = ["-k%d" % k, "-ci1", "-m2", "-sf1", "-sr1"] + (["-fa"] if fmt == "fa" else [])
+    want = _run("kmc", flags + ["-sp1"], path, tmp_path, "ref")
+    got = _run("kmc_oracle_s1", flags + ["-sp3"], path, tmp_path, "plug")
+    assert got == want
+
+
+@needs_ref
+def test_splitter_plugin_when_one_bin_takes_whole_parts(tmp_path):
+    """reads without any allowed m-mer all carry the special signature: one bin receives far more than a 64 KB buffer from every part, so the
+    worker cuts the piece record by record and counts the k+x-mer records itself (kmc_record_plus_x) — the reference's stage 2 then sizes and
+    fills its arrays with those sums"""
+    rng = np.random.default_rng(8)
+    path = str(tmp_path / "in.fq")
+    with open(path, "wb") as f:
+        for i in range(30_000):
+            r = [b"A" * 150, b"AC" * 75, _rnd(rng, 150), b"T" * 149 + b"G"][i % 4]
+            f.write(b"@r%d\n" % i + r + b"\n+\n" + b"I" * len(r) + b"\n")
+    for flags in (["-k27", "-ci1"], ["-k27", "-b", "-ci1"], ["-k40", "-ci1"]):
+        common = flags + ["-m2", "-sf1", "-sr1"]
+        want = _run("kmc", common + ["-sp1"], path, tmp_path, "ref")
+        assert _run("kmc_oracle_s1", common + ["-sp2"], path, tmp_path, "plug", env={"KMC_HIP_VERBOSE": "1"}) == want, flags
+        assert _report_sum("cut record by record") > 0
+
+
+@needs_ref
+def test_splitter_plugin_hands_long_read_parts_to_the_reference_splitter(tmp_path):
+    """a record larger than a part of the reader arrives as ReadType::long_read pieces: the worker pushes its own buffers and lets a reference
+    CSplitter of the same thread take those parts; short reads before and after go through the engine"""
+    rng = np.random.default_rng(9)
+    path = str(tmp_path / "in.fq")
+    with open(path, "wb") as f:
+        for i in range(2000):
+            r = _rnd(rng, 150)
+            f.write(b"@s%d\n" % i + r + b"\n+\n" + b"I" * 150 + b"\n")
+        big = _rnd(rng, 40_000_000)
+        f.write(b"@long\n" + big + b"\n+\n" + b"I" * len(big) + b"\n")
+        for i in range(2000):
+            r = _rnd(rng, 150)
+            f.write(b"@t%d\n" % i + r + b"\n+\n" + b"I" * 150 + b"\n")
+    common = ["-k27", "-ci1", "-m2", "-sf1", "-sr1"]
+    want = _run("kmc", common + ["-sp1"], path, tmp_path, "ref")
+    assert _run("kmc_oracle_s1", common + ["-sp2"], path, tmp_path, "plug", env={"KMC_HIP_VERBOSE": "1"}) == want
+    assert _report_sum("long-read parts") > 0 and _report_sum("parts through the engine") > 0
+
+
+@needs_ref
+def test_splitter_plugin_falls_back_for_jobs_it_does_not_cover(tmp_path):
+    fq = str(tmp_path / "in.fq")
+    synth.make_fastq(fq, seed=4, genome_len=50_000, n_reads=5_000, read_len=150)
+    for flags in (["-k27", "-hc"], ["-k27", "-e"]):  # homopolymer compression; histogram estimation while counting
+        common = flags + ["-ci1", "-m2", "-sf1", "-sr1"]
+        want = _run("kmc", common + ["-sp1"], fq, tmp_path, "ref")
+        assert _run("kmc_oracle_s1", common + ["-sp2"], fq, tmp_path, "plug", env={"KMC_HIP_VERBOSE": "1"}) == want, flags
+        assert not _run.report  # the reference worker ran the whole job
+
+
+@needs_ref
+@pytest.mark.parametrize("flags", [["-k27", "-ci1"], ["-k27", "-b"], ["-k21"], ["-k55"], ["-k28", "-ci1"]], ids=lambda f: "".join(f))
+def test_bin_descriptors_of_the_plugin_equal_the_reference_collectors(flags, tmp_path):
+    """per bin, what stage 1 leaves in CBinDesc — bytes, k-mers and n_plus_x_recs (the (k+x)-mer records stage 2 will expand the bin into) —
+    from the reference's collectors (kmc_oracle: reference stage 1) and from the plug-in over the oracle engine (kmc_oracle_all): the direct
+    pin of oracle_s1_kxmer_recs and of the worker's sums (canonical and -b counting take different branches, kb_collector.cpp:85-98)."""
+    fq = str(tmp_path / "in.fq")
+    synth.make_fastq(fq, seed=21, genome_len=200_000, n_reads=20_000, read_len=150)
+    out = {}
+    for exe in ("kmc_oracle", "kmc_oracle_all"):
+        dump = str(tmp_path / (exe + ".desc"))
+        _run(exe, flags + ["-m2", "-sf1", "-sp2", "-sr1"], fq, tmp_path, exe, env={"KMC_HIP_BINDESC_DUMP": dump})
+        rows = sorted(tuple(int(x) for x in ln.split()) for ln in open(dump))
+        out[exe] = rows
+    assert out["kmc_oracle"] == out["kmc_oracle_all"]
+    assert len(out["kmc_oracle"]) >= 64 and sum(r[2] for r in out["kmc_oracle"]) > 1_000_000
+    assert any(r[3] for r in out["kmc_oracle"]), "n_plus_x_recs is zero everywhere: the k+x-mer path was not exercised"
