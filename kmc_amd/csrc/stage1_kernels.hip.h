@@ -506,4 +506,186 @@ __global__ void __launch_bounds__(256) k_s1_emit(const int8_t *__restrict__ code
 	}
 }
 
+/* ------------------------------------------------------------------------------------------------ text -> codes, k+x-mer sums
+ * The two kernels a HIP KmcSplitEngine (kmc_amd/host/split_engine.h) still needs. EMULATION-TESTED ONLY (tests/test_stage1_emulated.py): written
+ * after the round's GPU budget was spent, launched by no host code yet.
+ *
+ * k_s1_text_to_codes: one part of FASTA (lines_per_record 2) or FASTQ (4) text as the reference's readers cut it — it starts at a record's
+ * title (fastq_reader.cpp) — to the code stream the kernels above take: the symbols of every sequence line (splitter.cpp:41-47: ACGT acgt ->
+ * 0..3, anything else negative) followed by ONE negative byte where the line ends. A line ends at '\n'; a '\r' right in front of it is
+ * dropped. Line number = number of '\n' before the byte (sum look-back over tiles), sequence lines are those with number = 1 mod
+ * lines_per_record, the output position of a byte = number of bytes kept before it (second look-back). nl_pos[i] = position of the i-th '\n'.
+ * This is CSplitter::GetSeq (splitter.cpp:92-303) for the inputs it is meant for; what GetSeq does with anything else (blank lines, a lone
+ * '\r', a quality line of another length than its sequence: it skips quality by LENGTH, :281) is not reproduced — k_s1_check_records
+ * recognises every such part, and the engine must hand those to the reference splitter. */
+constexpr int S1_TXT_PER = 16, S1_TXT_TILE = S1_BLOCK * S1_TXT_PER;
+constexpr u32 S1_TEXT_BAD = 16u; /* error bit: the part is outside what k_s1_text_to_codes reproduces */
+
+__device__ __forceinline__ int8_t s1_symbol_code(uint8_t c)
+{
+	const uint8_t l = c | 0x20u;
+	return l == 'a' ? 0 : l == 'c' ? 1 : l == 'g' ? 2 : l == 't' ? 3 : -1;
+}
+
+__global__ void __launch_bounds__(S1_BLOCK) k_s1_text_to_codes(const uint8_t *__restrict__ text, u64 n, u32 lines_per_record, u64 *status_lines, u64 *status_out,
+                                                                u32 *ticket_ctr, int8_t *__restrict__ codes, u64 *__restrict__ nl_pos, u64 nl_cap, u64 *totals, u32 *err)
+{
+	__shared__ u32 s_tmp[S1_BLOCK / 64 + 1];
+	__shared__ u64 s_carry;
+	__shared__ u32 s_ticket;
+	const u32 tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+	if (tid == 0)
+		s_ticket = atomicAdd(ticket_ctr, 1u);
+	__syncthreads();
+	const u32 tile = s_ticket;
+	const u32 num_tiles = (u32)((n + S1_TXT_TILE - 1) / S1_TXT_TILE);
+	if (tile >= num_tiles)
+		return;
+	const u64 p0 = (u64)tile * S1_TXT_TILE + (u64)tid * S1_TXT_PER;
+	uint8_t c[S1_TXT_PER + 1]; /* the thread's bytes and the one after them ('\r' looks ahead) */
+#pragma unroll
+	for (int j = 0; j <= S1_TXT_PER; ++j)
+		c[j] = p0 + j < n ? text[p0 + j] : (uint8_t)0;
+	u32 my_nl = 0;
+#pragma unroll
+	for (int j = 0; j < S1_TXT_PER; ++j)
+		my_nl += (p0 + j < n && c[j] == '\n') ? 1u : 0u;
+	u32 tile_nl;
+	const u32 nl_before = block_excl_sum<S1_BLOCK / 64, u32>(my_nl, s_tmp, tile_nl);
+	if (wave == 0) {
+		const u64 excl = lookback64(status_lines, tile, (u64)tile_nl, lane, err, KERR_WATCHDOG);
+		if (lane == 0) {
+			s_carry = excl;
+			if (tile == num_tiles - 1)
+				totals[0] = excl + tile_nl; /* '\n' in the part */
+		}
+	}
+	__syncthreads();
+	u64 line = s_carry + nl_before;
+	__syncthreads();
+	/* which bytes are kept: every byte of a sequence line except a '\r' (which must be followed by '\n'), the '\n' included (it becomes the separator) */
+	u32 keep = 0, n_keep = 0;
+#pragma unroll
+	for (int j = 0; j < S1_TXT_PER; ++j) {
+		if (p0 + j >= n)
+			break;
+		const bool is_nl = c[j] == '\n';
+		if (c[j] == '\r' && !(p0 + j + 1 < n && c[j + 1] == '\n'))
+			atomicOr(err, S1_TEXT_BAD);
+		if (c[j] < 32 && !is_nl && c[j] != '\r')
+			atomicOr(err, S1_TEXT_BAD); /* GetSeq swallows a control character behind a title's end of line (splitter.cpp:119-123) */
+		if ((line & (u64)(lines_per_record - 1)) == 1 && c[j] != '\r') { /* lines_per_record is 2 or 4 */
+			keep |= 1u << j;
+			++n_keep;
+		}
+		if (is_nl) {
+			if (line < nl_cap)
+				nl_pos[line] = p0 + j;
+			else
+				atomicOr(err, KERR_CAPACITY);
+			++line;
+		}
+	}
+	u32 tile_keep;
+	const u32 keep_before = block_excl_sum<S1_BLOCK / 64, u32>(n_keep, s_tmp, tile_keep);
+	if (wave == 0) {
+		const u64 excl = lookback64(status_out, tile, (u64)tile_keep, lane, err, KERR_WATCHDOG);
+		if (lane == 0) {
+			s_carry = excl;
+			if (tile == num_tiles - 1)
+				totals[1] = excl + tile_keep; /* bytes of the code stream */
+		}
+	}
+	__syncthreads();
+	u64 at = s_carry + keep_before;
+#pragma unroll
+	for (int j = 0; j < S1_TXT_PER; ++j)
+		if (keep & (1u << j))
+			codes[at++] = c[j] == '\n' ? (int8_t)-1 : s1_symbol_code(c[j]);
+}
+
+/* One thread per record (n_lines / lines_per_record of them; a FASTA part may end inside its last sequence line): the title starts with the
+ * marker, the third line of a FASTQ record with '+', sequence and quality have one length, and no line of a record is empty in a way GetSeq
+ * treats specially (an empty title or plus line cannot be: they hold their marker). Raises S1_TEXT_BAD. */
+__global__ void __launch_bounds__(256) k_s1_check_records(const uint8_t *__restrict__ text, u64 n, const u64 *__restrict__ nl_pos, u64 n_lines, u32 lines_per_record,
+                                                            u32 *err)
+{
+	const u64 r = (u64)blockIdx.x * 256 + threadIdx.x;
+	const u64 first = r * lines_per_record; /* number of the record's title line */
+	if (first > n_lines || (first == n_lines && (n_lines == 0 ? n == 0 : nl_pos[n_lines - 1] + 1 >= n)))
+		return; /* no such record: the text ends with the previous one */
+	const u64 start = first ? nl_pos[first - 1] + 1 : 0;
+	const uint8_t marker = lines_per_record == 4 ? '@' : '>';
+	bool bad = text[start] != marker;
+	auto line_len = [&](u64 ln) -> u64 { /* without its '\r' */
+		const u64 b = ln ? nl_pos[ln - 1] + 1 : 0, e = nl_pos[ln];
+		return e - b - ((e > b && text[e - 1] == '\r') ? 1 : 0);
+	};
+	if (lines_per_record == 4) {
+		if (first + 4 > n_lines)
+			bad = true; /* a FASTQ record must be whole, every line terminated (GetSeq drops it otherwise, splitter.cpp:222-223, :283-284) */
+		else {
+			bad = bad || text[nl_pos[first + 1] + 1] != '+';
+			bad = bad || line_len(first + 1) != line_len(first + 3);
+		}
+	} else if (first + 1 > n_lines)
+		bad = true; /* a FASTA title without its end of line */
+	if (bad)
+		atomicOr(err, S1_TEXT_BAD);
+}
+
+/* n_plus_x_recs per bin: how many (k+x)-mer records the reference's stage 2 expands each super-k-mer into (kb_collector.cpp:83-100,
+ * kb_collector.h:72-118) — the third sum a CKmerBinCollector keeps, which stage 2 sizes its arrays with. One thread per super-k-mer walks
+ * its k-mers comparing the first four symbols of the k-mer with those of its reverse complement. */
+__global__ void __launch_bounds__(256) k_s1_bin_plus_x(const int8_t *__restrict__ codes, const u64 *__restrict__ sk_pos, const u32 *__restrict__ sk_len,
+                                                        const u32 *__restrict__ sk_sig, u64 n_sk, u32 k, u32 max_x, u32 both_strands, const int *__restrict__ sig_to_bin,
+                                                        u32 n_bins, u64 *__restrict__ bin_plus_x)
+{
+	__shared__ u32 s_px[S1_MAX_BINS];
+	for (u32 b = threadIdx.x; b < n_bins; b += 256)
+		s_px[b] = 0;
+	__syncthreads();
+	const u64 i0 = (u64)blockIdx.x * S1_SK_TILE;
+	for (u32 j = threadIdx.x; j < (u32)S1_SK_TILE && max_x; j += 256) {
+		const u64 i = i0 + j;
+		if (i >= n_sk)
+			break;
+		const int b = sig_to_bin[sk_sig[i]];
+		if (b < 0 || (u32)b >= n_bins)
+			continue;
+		const u32 n = sk_len[i];
+		u32 total;
+		if (!both_strands)
+			total = 1 + (n - k) / (max_x + 1);
+		else {
+			const int8_t *q = codes + sk_pos[i];
+			u32 fwd = ((u32)q[0] << 6) | ((u32)q[1] << 4) | ((u32)q[2] << 2) | (u32)q[3];
+			u32 rc = ((3u - q[k - 1]) << 6) | ((3u - q[k - 2]) << 4) | ((3u - q[k - 3]) << 2) | (3u - q[k - 4]);
+			u32 state = fwd < rc ? 0u : (rc < fwd ? 1u : 2u), run = 0;
+			total = 0;
+			for (u32 t = 0; t + k < n; ++t) {
+				rc = (rc >> 2) | ((3u - q[k + t]) << 6);
+				fwd = ((fwd << 2) & 0xFFu) | (u32)q[4 + t];
+				const u32 st = fwd < rc ? 0u : (rc < fwd ? 1u : 2u);
+				if (st == state) {
+					if (st == 2)
+						++total;
+					else
+						++run;
+				} else {
+					state = st;
+					total += 1 + run / (max_x + 1);
+					run = 0;
+				}
+			}
+			total += 1 + run / (max_x + 1);
+		}
+		atomicAdd(&s_px[b], total);
+	}
+	__syncthreads();
+	for (u32 b = threadIdx.x; b < n_bins; b += 256)
+		if (s_px[b])
+			atomicAdd(&bin_plus_x[b], (u64)s_px[b]);
+}
+
 #endif

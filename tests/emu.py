@@ -51,6 +51,10 @@ def lib(geometry="small"):
         L.emu_s1_scatter.restype = C.c_int
         L.emu_s1_scatter.argtypes = [C.c_void_p] * 4 + [C.c_uint64, C.c_uint32, C.c_void_p, C.c_uint32] + [C.c_void_p] * 4 + [C.c_uint64, C.c_void_p, C.c_uint64]
         L.emu_s1_geometry.argtypes = [C.c_void_p]
+        L.emu_s1_text_to_codes.restype = C.c_int
+        L.emu_s1_text_to_codes.argtypes = [C.c_void_p, C.c_uint64, C.c_uint32, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p]
+        L.emu_s1_plus_x.restype = None
+        L.emu_s1_plus_x.argtypes = [C.c_void_p] * 4 + [C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p, C.c_uint32, C.c_void_p]
         _LIBS[geometry] = L
     return _LIBS[geometry]
 
@@ -179,3 +183,25 @@ def s1_scatter(codes, sk_pos, sk_len, sk_sig, k: int, sig_to_bin: np.ndarray, n_
     err = lib(geometry).emu_s1_scatter(codes.ctypes.data, sk_pos.ctypes.data, sk_len.ctypes.data, sk_sig.ctypes.data, n, k, m.ctypes.data, n_bins, base.ctypes.data,
                                        pbase.ctypes.data, tot.ctypes.data, out.ctypes.data, cap, pack_start.ctypes.data, pcap)
     return dict(err=err, base=base, pack_base=pbase, totals=tot, out=out[: int(base[n_bins])].copy(), pack_start=pack_start[: int(pbase[n_bins])].copy())
+
+
+def s1_text_to_codes(text: bytes, lines_per_record: int, geometry="small"):
+    """one part of FASTA (2) / FASTQ (4) text -> (err, code stream int8, positions of the line ends)"""
+    t = np.frombuffer(text, dtype=np.uint8)
+    codes = np.zeros(t.size + 16, dtype=np.int8)
+    nl = np.zeros(t.size + 16, dtype=np.uint64)
+    tot = np.zeros(2, dtype=np.uint64)
+    err = lib(geometry).emu_s1_text_to_codes(t.ctypes.data, t.size, lines_per_record, codes.ctypes.data, nl.ctypes.data, nl.size, tot.ctypes.data)
+    return err, codes[: int(tot[1])].copy(), nl[: int(tot[0])].copy()
+
+
+def s1_plus_x(codes, sk_pos, sk_len, sk_sig, k, max_x, both_strands, sig_to_bin, n_bins, geometry="small"):
+    codes = np.ascontiguousarray(codes, dtype=np.int8)
+    sk_pos = np.ascontiguousarray(sk_pos, dtype=np.uint64)
+    sk_len = np.ascontiguousarray(sk_len, dtype=np.uint32)
+    sk_sig = np.ascontiguousarray(sk_sig, dtype=np.uint32)
+    m = np.ascontiguousarray(sig_to_bin, dtype=np.int32)
+    out = np.zeros(n_bins, dtype=np.uint64)
+    lib(geometry).emu_s1_plus_x(codes.ctypes.data, sk_pos.ctypes.data, sk_len.ctypes.data, sk_sig.ctypes.data, sk_pos.size, k, max_x, 1 if both_strands else 0,
+                                m.ctypes.data, n_bins, out.ctypes.data)
+    return out

@@ -460,4 +460,32 @@ EMU_API int emu_s1_scatter(const int8_t *codes, const u64 *sk_pos, const u32 *sk
 			return -2; /* every reserved byte accounted for */
 	return 0;
 }
+
+/* text of one part -> code stream (+ positions of the line ends) and the record check; totals[0] = '\n' count, totals[1] = bytes of codes */
+EMU_API int emu_s1_text_to_codes(const uint8_t *text, u64 n, unsigned lines_per_record, int8_t *codes, u64 *nl_pos, u64 nl_cap, u64 *totals)
+{
+	u32 err = 0, ticket = 0;
+	totals[0] = totals[1] = 0;
+	if (!n)
+		return 0;
+	const u32 tiles = (u32)((n + S1_TXT_TILE - 1) / S1_TXT_TILE);
+	std::vector<u64> st_a(tiles, 0), st_b(tiles, 0);
+	hipemu::launch(dim3(tiles), dim3(S1_BLOCK), 0,
+	               [&] { k_s1_text_to_codes(text, n, lines_per_record, st_a.data(), st_b.data(), &ticket, codes, nl_pos, nl_cap, totals, &err); });
+	if (err & KERR_CAPACITY)
+		return (int)err;
+	const u64 recs = totals[0] / lines_per_record + 1;
+	hipemu::launch(dim3((u32)((recs + 255) / 256)), dim3(256), 0, [&] { k_s1_check_records(text, n, nl_pos, totals[0], lines_per_record, &err); });
+	return (int)err;
+}
+
+EMU_API void emu_s1_plus_x(const int8_t *codes, const u64 *sk_pos, const u32 *sk_len, const u32 *sk_sig, u64 n_sk, unsigned k, unsigned max_x, unsigned both_strands,
+                           const int *sig_to_bin, unsigned n_bins, u64 *bin_plus_x)
+{
+	for (unsigned b = 0; b < n_bins; ++b)
+		bin_plus_x[b] = 0;
+	const u32 tiles = (u32)((n_sk + S1_SK_TILE - 1) / S1_SK_TILE);
+	if (tiles)
+		hipemu::launch(dim3(tiles), dim3(256), 0, [&] { k_s1_bin_plus_x(codes, sk_pos, sk_len, sk_sig, n_sk, k, max_x, both_strands, sig_to_bin, n_bins, bin_plus_x); });
+}
 }

@@ -30,6 +30,10 @@ def lib():
         L.oracle_s1_split.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_uint64]
         L.oracle_s1_split_all.restype = C.c_int64
         L.oracle_s1_split_all.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64]
+        L.oracle_s1_kxmer_recs.restype = C.c_uint32
+        L.oracle_s1_kxmer_recs.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int]
+        L.oracle_s1_parse_part.restype = C.c_int64
+        L.oracle_s1_parse_part.argtypes = [C.c_void_p, C.c_uint64, C.c_int, C.c_uint32, C.c_uint64, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p]
         _LIB = L
     return _LIB
 
@@ -77,3 +81,19 @@ def split_stream(codes: np.ndarray, k: int, sig_len: int = 9):
     n = lib().oracle_s1_split(codes.ctypes.data, codes.size, k, sig_len, norm.ctypes.data, out.ctypes.data, cap)
     assert n <= cap
     return out[:n, 0].copy(), out[:n, 1].copy(), out[:n, 2].copy()
+
+
+def parse_part(text: bytes, file_type: int, k: int, line_cap: int = 131080):
+    """CSplitter::GetSeq over one part (0 = FASTA, 1 = FASTQ) -> (list of code arrays, n_reads)"""
+    t = np.frombuffer(text, dtype=np.uint8)
+    codes = np.zeros(t.size + 16, dtype=np.int8)
+    off = np.zeros(t.size // 2 + 16, dtype=np.uint64)
+    nr = C.c_uint64(0)
+    n = lib().oracle_s1_parse_part(t.ctypes.data, t.size, file_type, k, line_cap, codes.ctypes.data, off.ctypes.data, off.size - 1, C.addressof(nr))
+    assert n >= 0
+    return [codes[int(off[i]):int(off[i + 1])].copy() for i in range(n)], nr.value
+
+
+def kxmer_recs(seq: np.ndarray, k: int, max_x: int, both_strands: bool) -> int:
+    s = np.ascontiguousarray(seq, dtype=np.int8)
+    return int(lib().oracle_s1_kxmer_recs(s.ctypes.data, s.size, k, max_x, 1 if both_strands else 0))

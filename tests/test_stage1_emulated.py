@@ -191,3 +191,79 @@ def test_emulated_stage1_cut_over_more_than_64_workgroup_tiles():
     err, _, pos, ln, sg = emu.s1_split(codes, k, m, fused=True)
     w_pos, w_len, w_sig = S1.split_stream(codes, k, m)
     assert err == 0 and np.array_equal(pos, w_pos.astype(np.uint64)) and np.array_equal(ln, w_len) and np.array_equal(sg, w_sig)
+
+
+# ---- the kernels a HIP split engine still needs (kmc_amd/host/split_engine.h): text -> codes, k+x-mer sums. Emulation only so far.
+def _records_text(fmt, eol, recs):
+    out = []
+    for i, r in enumerate(recs):
+        if fmt == "fq":
+            out.append(b"@r%d x" % i + eol + r + eol + b"+" + (b"r%d" % i if i % 3 == 0 else b"") + eol + bytes([33 + (j * 7 + i) % 60 for j in range(len(r))]) + eol)
+        else:
+            out.append(b">r%d x" % i + eol + r + eol)
+    return b"".join(out)
+
+
+def _want_stream(seqs):
+    parts = []
+    for s in seqs:
+        parts += [s, np.array([-1], dtype=np.int8)]
+    return np.concatenate(parts) if parts else np.zeros(0, dtype=np.int8)
+
+
+@pytest.mark.parametrize("fmt,eol", [("fq", b"\n"), ("fq", b"\r\n"), ("fa", b"\n"), ("fa", b"\r\n")])
+def test_emulated_text_to_codes_matches_the_reference_parser(fmt, eol):
+    """the code stream of a part = the sequences CSplitter::GetSeq hands out (oracle_s1_parse_part, pinned by tests/test_stage1_plugin.py), each
+    followed by one separator; quality bytes that look like titles ('@' at a line start) and '+' inside titles must not confuse the line count"""
+    k = 27
+    rng = np.random.default_rng(17)
+    acgt = np.frombuffer(b"ACGT", dtype=np.uint8)
+    rnd = lambda n: acgt[rng.integers(0, 4, size=n)].tobytes()
+    recs = [rnd(int(rng.integers(1, 400))) for _ in range(300)] + [b"", rnd(30) + b"N" + rnd(5) + b"nnacgtRYK", b"", b"A", rnd(5000), b"acgt" * 10]
+    text = _records_text(fmt, eol, recs)
+    assert len(text) > 3 * 4096  # several tiles
+    err, codes, nl = emu.s1_text_to_codes(text, 4 if fmt == "fq" else 2)
+    assert err == 0
+    seqs, n_reads = S1.parse_part(text, 1 if fmt == "fq" else 0, k)
+    assert n_reads == len(recs) and len(seqs) == len(recs)
+    assert np.array_equal(codes, _want_stream(seqs))
+    assert np.array_equal(nl, np.flatnonzero(np.frombuffer(text, dtype=np.uint8) == 10).astype(np.uint64))
+    if fmt == "fa":  # a FASTA part may end inside its last sequence line: same sequences, no separator behind the last one
+        cut = text[: len(text) - len(eol)]
+        err, codes2, _ = emu.s1_text_to_codes(cut, 2)
+        assert err == 0 and np.array_equal(codes2, codes[:-1])
+        seqs2, _ = S1.parse_part(cut, 0, k)
+        assert all(np.array_equal(a, b) for a, b in zip(seqs2, seqs)) and len(seqs2) == len(seqs)
+
+
+@pytest.mark.parametrize("what", ["blank line", "short quality", "no plus", "lone cr", "missing last eol", "no title marker", "control char"])
+def test_emulated_text_check_flags_parts_outside_its_domain(what):
+    """anything GetSeq treats by rules the line model does not reproduce must be recognised, so that the engine can give the part to the
+    reference splitter"""
+    good = b"@a\nACGTACGT\n+\nIIIIIIII\n@b\nACGT\n+\nIIII\n"
+    bad = {"blank line": good.replace(b"@b", b"\n@b"), "short quality": good.replace(b"IIIIIIII", b"IIIIIII"), "no plus": good.replace(b"+\nIIII\n", b"-\nIIII\n"),
+           "lone cr": good.replace(b"ACGT\n+", b"AC\rGT\n+"), "missing last eol": good[:-1], "no title marker": b"x" + good[1:],
+           "control char": good.replace(b"@b\nACGT", b"@b\n\tACGT")}[what]
+    assert emu.s1_text_to_codes(good, 4)[0] == 0
+    assert emu.s1_text_to_codes(bad, 4)[0] & 16
+    assert emu.s1_text_to_codes(b">a\nACGT\n>b\nAC", 2)[0] == 0 and emu.s1_text_to_codes(b">a\nACGT\n>b", 2)[0] & 16
+
+
+@pytest.mark.parametrize("k,max_x,both", [(27, 3, True), (27, 3, False), (21, 3, True), (55, 2, True), (40, 1, True), (27, 0, True), (14, 3, True)])
+def test_emulated_kxmer_sums_match_the_oracle(k, max_x, both):
+    """n_plus_x_recs per bin (k_s1_bin_plus_x) against oracle_s1_kxmer_recs summed over the bin's super-k-mers; the oracle function is pinned to
+    the reference's collectors by tests/test_stage1_plugin.py::test_bin_descriptors_*"""
+    m, n_bins = 7 if k < 20 else 9, 37
+    rng = np.random.default_rng(k + max_x)
+    reads = _reads(rng, k, 60, 150) + [b"ACGT" * 100, b"AT" * 150, b"A" * 400]  # palindromic stretches: k-mer equals its reverse complement
+    while len(S1.split(reads, k, m)[0]) <= 1100:
+        reads += _reads(rng, k, 60, 150)
+    codes = _stream(reads)
+    err, _, pos, ln, sg = emu.s1_split(codes, k, m)
+    assert err == 0
+    smap = _sig_map(m, n_bins, 4)
+    got = emu.s1_plus_x(codes, pos, ln, sg, k, max_x, both, smap, n_bins)
+    want = np.zeros(n_bins, dtype=np.uint64)
+    for p, l, s in zip(pos, ln, sg):
+        want[smap[s]] += S1.kxmer_recs(codes[int(p):int(p) + int(l)], k, max_x, both)
+    assert np.array_equal(got, want) and (want.sum() > 0) == (max_x > 0)
