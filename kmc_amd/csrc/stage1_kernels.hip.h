@@ -605,10 +605,10 @@ __global__ void __launch_bounds__(S1_BLOCK) k_s1_text_to_codes(const uint8_t *__
 }
 
 /* One thread per record (n_lines / lines_per_record of them; a FASTA part may end inside its last sequence line): the title starts with the
- * marker, the third line of a FASTQ record with '+', sequence and quality have one length, and no line of a record is empty in a way GetSeq
- * treats specially (an empty title or plus line cannot be: they hold their marker). Raises S1_TEXT_BAD. */
+ * marker, the third line of a FASTQ record with '+', sequence and quality have one length, the sequence is shorter than line_cap
+ * (mem_part_pmm_reads: GetSeq cuts longer lines into overlapping pieces). Raises S1_TEXT_BAD. */
 __global__ void __launch_bounds__(256) k_s1_check_records(const uint8_t *__restrict__ text, u64 n, const u64 *__restrict__ nl_pos, u64 n_lines, u32 lines_per_record,
-                                                            u32 *err)
+                                                            u64 line_cap, u32 *err)
 {
 	const u64 r = (u64)blockIdx.x * 256 + threadIdx.x;
 	const u64 first = r * lines_per_record; /* number of the record's title line */
@@ -627,9 +627,14 @@ __global__ void __launch_bounds__(256) k_s1_check_records(const uint8_t *__restr
 		else {
 			bad = bad || text[nl_pos[first + 1] + 1] != '+';
 			bad = bad || line_len(first + 1) != line_len(first + 3);
+			bad = bad || line_len(first + 1) >= line_cap; /* GetSeq hands such a line out in overlapping pieces (splitter.cpp:226-231) */
 		}
 	} else if (first + 1 > n_lines)
 		bad = true; /* a FASTA title without its end of line */
+	else {
+		const u64 b = nl_pos[first] + 1, e = first + 1 < n_lines ? nl_pos[first + 1] : n;
+		bad = bad || e - b >= line_cap;
+	}
 	if (bad)
 		atomicOr(err, S1_TEXT_BAD);
 }

@@ -20,8 +20,9 @@
  * from the engine in one go), walked record by record only when a piece is larger than what an empty buffer holds.
  *
  * Falls back to the reference, per job: input other than FASTA / FASTQ, homopolymer compression, histogram estimation while counting;
- * per part: ReadType::long_read (the reader could not delimit whole records, queues.h:40) — our buffers are pushed first, then a
- * reference CSplitter of this thread takes the part.
+ * per part: ReadType::long_read (the reader could not delimit whole records, queues.h:40), and any part the engine reports as
+ * KMC_SPLIT_UNCOVERED (text on which it does not reproduce CSplitter::GetSeq) — our buffers are pushed first, then a reference CSplitter of
+ * this thread takes the part.
  */
 #ifndef KMC_AMD_KB_SPLITTER_PLUGIN_H
 #define KMC_AMD_KB_SPLITTER_PLUGIN_H
@@ -95,7 +96,7 @@ class CWSplitter {
 	bool both_strands;
 	uint64 n_reads = 0;
 	/* KMC_HIP_VERBOSE=1: one line per worker on stderr when it finishes */
-	uint64 st_parts = 0, st_long_parts = 0, st_pieces = 0, st_cut_pieces = 0, st_pushes = 0, st_bytes = 0;
+	uint64 st_parts = 0, st_long_parts = 0, st_uncovered_parts = 0, st_pieces = 0, st_cut_pieces = 0, st_pushes = 0, st_bytes = 0;
 	long long st_engine_ns = 0;
 
 	static bool covered(const CKMCParams &P)
@@ -151,6 +152,17 @@ class CWSplitter {
 			at += len;
 		}
 	}
+	/* the reference's own splitter for this part; its collectors reserve n_bins buffers, so ours go to the storer first */
+	void to_reference(uchar *part, uint64 size, ReadType read_type)
+	{
+		push_all();
+		if (!ref_splitter) {
+			ref_splitter = std::make_unique<CSplitter>(*params, *queues);
+			ref_splitter->InitBins(*params, *queues);
+		}
+		ref_splitter->ProcessReads(part, size, read_type);
+		pmm_fastq->free(part);
+	}
 	void push_all()
 	{
 		for (uint32 i = 0; i < (uint32)bins.size(); ++i)
@@ -204,34 +216,30 @@ public:
 			if (!pq->pop(part, size, read_type))
 				continue;
 			if (read_type != ReadType::normal_read) {
-				/* the reference's own splitter for this part; its collectors reserve n_bins buffers, so ours go to the storer first */
 				++st_long_parts;
-				push_all();
-				if (!ref_splitter) {
-					ref_splitter = std::make_unique<CSplitter>(*params, *queues);
-					ref_splitter->InitBins(*params, *queues);
-				}
-				ref_splitter->ProcessReads(part, size, read_type);
-				pmm_fastq->free(part);
+				to_reference(part, size, read_type);
 				continue;
 			}
 			KmcSplitResult r;
-			++st_parts;
 			const auto t0 = std::chrono::steady_clock::now();
 			const int rc = engine->split_part(part, size, r);
 			st_engine_ns += std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count();
+			if (rc == KMC_SPLIT_UNCOVERED) {
+				++st_uncovered_parts;
+				to_reference(part, size, read_type);
+				continue;
+			}
 			if (rc != 0) {
 				std::ostringstream ostr;
 				ostr << "Error: stage-1 split engine failed (code " << rc << "): " << engine->last_error();
 				CCriticalErrorHandler::Inst().HandleCriticalError(ostr.str());
 			}
+			++st_parts;
 			pmm_fastq->free(part);
 			n_reads += r.n_reads;
-			for (uint32 b = 0; b < (uint32)bins.size(); ++b) {
-				const uint64 bytes = r.bin_off[b + 1] - r.bin_off[b];
-				if (bytes)
-					append(b, r.recs + r.bin_off[b], bytes, r.bin_kmers[b], r.bin_superkmers[b], r.bin_plus_x[b]);
-			}
+			for (uint32 b = 0; b < (uint32)bins.size(); ++b)
+				if (r.bin_bytes[b])
+					append(b, r.recs + r.bin_off[b], r.bin_bytes[b], r.bin_kmers[b], r.bin_superkmers[b], r.bin_plus_x[b]);
 		}
 		push_all();
 		if (ref_splitter) {
@@ -244,9 +252,10 @@ public:
 		bpq->mark_completed();
 		engine.reset();
 		if (getenv("KMC_HIP_VERBOSE"))
-			fprintf(stderr, "[kmc_hip stage 1] worker: %llu parts through the engine (%.3f s inside), %llu long-read parts to the reference splitter, "
+			fprintf(stderr, "[kmc_hip stage 1] worker: %llu parts through the engine (%.3f s inside), %llu long-read parts and %llu uncovered parts to the reference splitter, "
 			                "%llu bin pieces (%llu cut record by record), %llu buffers / %.1f MB pushed\n",
-			        (unsigned long long)st_parts, st_engine_ns * 1e-9, (unsigned long long)st_long_parts, (unsigned long long)st_pieces,
+			        (unsigned long long)st_parts, st_engine_ns * 1e-9, (unsigned long long)st_long_parts, (unsigned long long)st_uncovered_parts,
+			        (unsigned long long)st_pieces,
 			        (unsigned long long)st_cut_pieces, (unsigned long long)st_pushes, st_bytes / 1e6);
 	}
 

@@ -26,11 +26,15 @@ struct KmcSplitParams {
 
 /* valid until the next split_part() on the same engine */
 struct KmcSplitResult {
-	const uint8_t *recs;       /* the records of all bins, bin after bin */
-	const uint64_t *bin_off;   /* n_bins + 1 byte offsets into recs */
+	const uint8_t *recs;       /* the records of all bins; bin b's are recs[bin_off[b] .. bin_off[b] + bin_bytes[b]) (a device engine aligns bins) */
+	const uint64_t *bin_off, *bin_bytes; /* n_bins each */
 	const uint64_t *bin_kmers, *bin_superkmers, *bin_plus_x; /* n_bins each: n_recs, n_super_kmers, n_plus_x_recs of the collector */
 	uint64_t n_reads;          /* records whose title line the part holds (CSplitter::n_reads) */
 };
+
+/* split_part() returns 0, a negative error code, or KMC_SPLIT_UNCOVERED: the part is text the engine does not reproduce CSplitter::GetSeq on
+ * (blank lines, quality of another length than its sequence, ...): nothing was produced, the worker gives the part to the reference splitter */
+enum { KMC_SPLIT_UNCOVERED = 1 };
 
 struct KmcSplitEngine {
 	virtual ~KmcSplitEngine() {}

@@ -34,7 +34,7 @@ struct KmcOracleSplitEngine : KmcSplitEngine {
 	std::string err;
 	std::vector<uint32_t> norm;
 	std::vector<int8_t> codes;
-	std::vector<uint64_t> seq_off, bin_off, kmers, supers, plus_x, fill;
+	std::vector<uint64_t> seq_off, bin_off, bytes, kmers, supers, plus_x, fill;
 	std::vector<oracle_s1_superkmer> sk;
 	std::vector<uint32_t> sk_seq;
 	std::vector<uint8_t> recs;
@@ -95,6 +95,10 @@ struct KmcOracleSplitEngine : KmcSplitEngine {
 		}
 		out.recs = recs.data();
 		out.bin_off = bin_off.data();
+		bytes.resize(nb);
+		for (uint32_t b = 0; b < nb; ++b)
+			bytes[b] = bin_off[b + 1] - bin_off[b];
+		out.bin_bytes = bytes.data();
 		out.bin_kmers = kmers.data();
 		out.bin_superkmers = supers.data();
 		out.bin_plus_x = plus_x.data();

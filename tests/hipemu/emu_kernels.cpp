@@ -475,7 +475,7 @@ EMU_API int emu_s1_text_to_codes(const uint8_t *text, u64 n, unsigned lines_per_
 	if (err & KERR_CAPACITY)
 		return (int)err;
 	const u64 recs = totals[0] / lines_per_record + 1;
-	hipemu::launch(dim3((u32)((recs + 255) / 256)), dim3(256), 0, [&] { k_s1_check_records(text, n, nl_pos, totals[0], lines_per_record, &err); });
+	hipemu::launch(dim3((u32)((recs + 255) / 256)), dim3(256), 0, [&] { k_s1_check_records(text, n, nl_pos, totals[0], lines_per_record, (u64)131080, &err); });
 	return (int)err;
 }
 

@@ -149,3 +149,54 @@ def test_bin_descriptors_of_the_plugin_equal_the_reference_collectors(flags, tmp
     assert out["kmc_oracle"] == out["kmc_oracle_all"]
     assert len(out["kmc_oracle"]) >= 64 and sum(r[2] for r in out["kmc_oracle"]) > 1_000_000
     assert any(r[3] for r in out["kmc_oracle"]), "n_plus_x_recs is zero everywhere: the k+x-mer path was not exercised"
+
+
+# ---- the stage-1 KERNELS inside the real pipeline: kmc_emu_s1 = reference KMC + the splitter worker + an engine that runs
+# kmc_amd/csrc/stage1_kernels.hip.h under the CPU emulation of tests/hipemu, in the order a HIP engine will launch them
+needs_emu = pytest.mark.skipif(not os.path.exists(os.path.join(REF, "kmc_emu_s1")), reason="oracle/_ref/kmc_emu_s1 not built (needs /root/reference)")
+
+
+def _small_text(fmt, eol, k, n_reads=1500):
+    rng = np.random.default_rng(13)
+    genome = _rnd(rng, 20_000)
+    recs = _edge_case_records(k) + [genome[a:a + 100] for a in rng.integers(0, len(genome) - 100, size=n_reads)]
+    out = []
+    for i, r in enumerate(recs):
+        if fmt == "fq":
+            out.append(b"@r%d some text" % i + eol + r + eol + b"+" + eol + b"@" * len(r) + eol)  # quality lines that start like titles
+        else:
+            out.append(b">r%d some text" % i + eol + r + eol)
+    return b"".join(out)
+
+
+@needs_emu
+@pytest.mark.parametrize("fmt,eol,flags", [("fq", b"\n", ["-k27", "-ci1"]), ("fq", b"\r\n", ["-k27", "-ci1", "-b"]), ("fa", b"\n", ["-k55", "-ci1"]),
+                                           ("fa", b"\r\n", ["-k21"]), ("fq", b"\n", ["-k127", "-ci1"])], ids=lambda v: v if isinstance(v, str) else None)
+def test_emulated_stage1_kernels_inside_the_reference_pipeline(fmt, eol, flags, tmp_path):
+    """text of the reader's parts -> k_s1_text_to_codes -> k_s1_check_records -> k_s1_cut -> k_s1_bin_totals + k_s1_bin_plus_x -> k_s1_bin_layout
+    -> k_s1_emit -> the worker's buffers -> reference storer, bin files, stage 2: the database and the statistics (reads, super-k-mers, k-mers)
+    must be the unmodified reference's"""
+    k = int(flags[0][2:])
+    path = str(tmp_path / ("in." + fmt))
+    with open(path, "wb") as f:
+        f.write(_small_text(fmt, eol, k))
+    common = flags + ["-m2", "-sf1", "-sr1"] + (["-fa"] if fmt == "fa" else [])
+    want = _run("kmc", common + ["-sp1"], path, tmp_path, "ref")
+    got = _run("kmc_emu_s1", common + ["-sp2"], path, tmp_path, "emu", env={"KMC_HIP_VERBOSE": "1"})
+    assert got == want
+    assert _report_sum("parts through the engine") > 0 and _report_sum("uncovered parts") == 0 and _report_sum("bin pieces") > 0
+
+
+@needs_emu
+def test_text_the_kernels_do_not_cover_goes_to_the_reference_splitter(tmp_path):
+    """a blank line between records is fine with CSplitter::GetSeq (splitter.cpp:293-298) but not with the kernels' line model: the record check
+    must flag the part, the worker must hand it to the reference splitter, and the database must not change"""
+    path = str(tmp_path / "in.fq")
+    text = _small_text("fq", b"\n", 27, n_reads=600)
+    cut = text.index(b"@r300 ")
+    with open(path, "wb") as f:
+        f.write(text[:cut] + b"\n" + text[cut:])
+    common = ["-k27", "-ci1", "-m2", "-sf1", "-sr1"]
+    want = _run("kmc", common + ["-sp1"], path, tmp_path, "ref")
+    got = _run("kmc_emu_s1", common + ["-sp1"], path, tmp_path, "emu", env={"KMC_HIP_VERBOSE": "1"})
+    assert got == want and _report_sum("uncovered parts") > 0
