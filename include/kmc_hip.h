@@ -222,6 +222,27 @@ int kmc_hip_split_reads_plan(kmc_hip_ctx *ctx, int dev, const int8_t *d_codes, u
 int kmc_hip_split_reads_emit(kmc_hip_ctx *ctx, kmc_hip_s1_plan *plan, uint8_t *d_bins, uint64_t *d_pack_start);
 void kmc_hip_split_reads_free(kmc_hip_ctx *ctx, kmc_hip_s1_plan *plan);
 
+/* ---- stage 1, one part of input text (the engine behind kmc_amd/host/kb_splitter_plugin.h; NOT YET RUN ON A GPU) ----
+ * Replaces, for one part the reference's readers cut (fastq_reader.cpp), CSplitter::ProcessReads and the n_bins CKmerBinCollectors up to the
+ * bin-part buffers (splitter.cpp:557-672, kb_collector.cpp:34-106): text (host) -> the part's bin records (host, bin b at recs + bin_off[b],
+ * bin_bytes[b] bytes; bins are 256-byte aligned, recs_capacity = size + 256 * (n_bins + 1) always suffices) and per bin the three sums a
+ * collector keeps: bin_kmers (n_recs), bin_superkmers (n_super_kmers), bin_plus_x (n_plus_x_recs, kb_collector.h:72-118); *n_reads = titles
+ * in the part. kmc_hip_split_set_map uploads CSignatureMapper's map (s_mapper.h:232; 4^signature_len + 1 entries) once per device.
+ * Returns 0, a negative KMC_HIP_E* code, or KMC_HIP_UNCOVERED: the text is not what the kernels reproduce CSplitter::GetSeq on (blank lines,
+ * quality of another length than its sequence, a lone '\r', a line of mem_part_pmm_reads symbols or more, ...) — nothing was produced and the
+ * caller gives the part to the reference splitter. Calls on one (dev, slot) are serialised. */
+#define KMC_HIP_UNCOVERED 1
+typedef struct kmc_hip_split_params {
+	uint32_t kmer_len, signature_len, n_bins, max_x; /* max_x: CKMCParams::max_x (0..3) */
+	uint32_t both_strands;
+	uint32_t file_type;                              /* 0 = FASTA (one line per sequence), 1 = FASTQ */
+	uint64_t line_cap;                               /* CKMCParams::mem_part_pmm_reads */
+} kmc_hip_split_params;
+int kmc_hip_split_set_map(kmc_hip_ctx *ctx, int dev, const int32_t *sig_to_bin, uint32_t signature_len);
+int kmc_hip_split_part(kmc_hip_ctx *ctx, int dev, int slot, const kmc_hip_split_params *p, const uint8_t *text, uint64_t size, uint8_t *recs,
+                       uint64_t recs_capacity, uint64_t *bin_off, uint64_t *bin_bytes, uint64_t *bin_kmers, uint64_t *bin_superkmers, uint64_t *bin_plus_x,
+                       uint64_t *n_reads);
+
 #ifdef __cplusplus
 }
 #endif

@@ -73,6 +73,7 @@ SYMBOLS = [
     "kmc_hip_host_register", "kmc_hip_host_unregister", "kmc_hip_host_alloc", "kmc_hip_host_free", "kmc_hip_synchronize",
     "kmc_hip_debug_expand", "kmc_hip_debug_compact", "kmc_hip_debug_split_reads",
     "kmc_hip_split_reads_plan", "kmc_hip_split_reads_emit", "kmc_hip_split_reads_free",
+    "kmc_hip_split_set_map", "kmc_hip_split_part",
 ]
 
 _LIB = None

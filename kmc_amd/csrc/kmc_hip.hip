@@ -137,6 +137,9 @@ struct Dev {
 	std::mutex rr_mtx;
 	Slot slot[N_SLOTS];
 	DBuf rccl_buf;
+	int *d_sig_map = nullptr; /* stage 1: the signature -> bin map of kmc_hip_split_set_map */
+	u32 sig_map_entries = 0;
+	std::mutex map_mtx;
 };
 
 u32 counter_bytes(u64 cutoff_max, u64 counter_max) { return kmc_counter_bytes(cutoff_max, counter_max); }
@@ -783,6 +786,56 @@ int debug_compact_t(Slot &s, const DevParams &P, u64 n, u64 out_capacity, u64 lu
 
 /* ================================================================================================ C-ABI */
 
+/* stage 1, one part of text: the backend of kmc_amd/csrc/stage1_chain.h on a HIP stream (used by kmc_hip_split_part below) */
+namespace {
+struct S1BackendFailure {
+	hipError_t e;
+	const char *what;
+};
+struct S1HipBackend {
+	hipStream_t stream;
+	std::vector<void *> blocks;
+	void *alloc(size_t bytes)
+	{
+		void *p = nullptr;
+		hipError_t e = hipMalloc(&p, bytes ? bytes : 1);
+		if (e != hipSuccess)
+			throw S1BackendFailure{e, "hipMalloc"};
+		blocks.push_back(p);
+		e = hipMemsetAsync(p, 0, bytes ? bytes : 1, stream);
+		if (e != hipSuccess)
+			throw S1BackendFailure{e, "hipMemsetAsync"};
+		return p;
+	}
+	void zero(void *p, size_t bytes)
+	{
+		hipError_t e = hipMemsetAsync(p, 0, bytes, stream);
+		if (e != hipSuccess)
+			throw S1BackendFailure{e, "hipMemsetAsync"};
+	}
+	bool d2h(void *dst, const void *src, size_t bytes)
+	{
+		hipError_t e = hipGetLastError(); /* a failed launch before this point */
+		if (e == hipSuccess)
+			e = hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, stream);
+		if (e == hipSuccess)
+			e = hipStreamSynchronize(stream);
+		if (e != hipSuccess)
+			throw S1BackendFailure{e, "device to host copy"};
+		return true;
+	}
+	void release()
+	{
+		for (void *p : blocks)
+			(void)hipFree(p);
+		blocks.clear();
+	}
+	~S1HipBackend() { release(); }
+};
+} // namespace
+#define S1_LAUNCH(B, be, kernel, grid, block, ...) hipLaunchKernelGGL(kernel, grid, block, 0, (be).stream, __VA_ARGS__)
+#include "stage1_chain.h"
+
 extern "C" {
 
 int kmc_hip_abi_version(void) { return KMC_HIP_ABI_VERSION; }
@@ -855,6 +908,8 @@ void kmc_hip_destroy(kmc_hip_ctx *ctx)
 			slot_destroy(s);
 		if (d->rccl_buf.p)
 			(void)hipFree(d->rccl_buf.p);
+		if (d->d_sig_map)
+			(void)hipFree(d->d_sig_map);
 	}
 	if (ctx->comms_ready)
 		for (auto &c : ctx->comms)
@@ -1601,6 +1656,88 @@ void kmc_hip_split_reads_free(kmc_hip_ctx *ctx, kmc_hip_s1_plan *p)
 	if (ctx)
 		(void)set_dev(ctx, p->dev);
 	s1_plan_release(p);
+}
+
+/* ---- stage 1, one part of input text: host text -> host records + collector sums (the engine of kb_splitter_plugin.h) ----
+ * NOT YET RUN ON A GPU (written after the round's GPU budget was spent). The launch sequence itself is kmc_amd/csrc/stage1_chain.h, which
+ * runs inside the real KMC pipeline under the CPU emulation (oracle/_ref/kmc_emu_s1); what is new here is the backend below. */
+
+int kmc_hip_split_set_map(kmc_hip_ctx *ctx, int dev, const int32_t *sig_to_bin, uint32_t signature_len)
+{
+	if (int rc = set_dev(ctx, dev))
+		return rc;
+	if (!sig_to_bin || signature_len < 5 || signature_len > 11)
+		return fail(KMC_HIP_EINVAL, "kmc_hip_split_set_map: map NULL or signature_len outside 5..11");
+	Dev &d = *ctx->devs[dev];
+	std::lock_guard<std::mutex> lck(d.map_mtx);
+	const u32 entries = (1u << (2 * signature_len)) + 1;
+	if (d.d_sig_map && d.sig_map_entries != entries) {
+		(void)hipFree(d.d_sig_map);
+		d.d_sig_map = nullptr;
+	}
+	if (!d.d_sig_map)
+		HIPCHK(hipMalloc((void **)&d.d_sig_map, (size_t)entries * 4));
+	HIPCHK(hipMemcpy(d.d_sig_map, sig_to_bin, (size_t)entries * 4, hipMemcpyHostToDevice));
+	d.sig_map_entries = entries;
+	return 0;
+}
+
+int kmc_hip_split_part(kmc_hip_ctx *ctx, int dev, int slot, const kmc_hip_split_params *p, const uint8_t *text, uint64_t size, uint8_t *recs,
+                       uint64_t recs_capacity, uint64_t *bin_off, uint64_t *bin_bytes, uint64_t *bin_kmers, uint64_t *bin_superkmers, uint64_t *bin_plus_x,
+                       uint64_t *n_reads)
+{
+	if (int rc = set_dev(ctx, dev))
+		return rc;
+	if (!p || (size && !text) || !recs || !bin_off || !bin_bytes || !bin_kmers || !bin_superkmers || !bin_plus_x || !n_reads || slot < 0 || slot >= N_SLOTS)
+		return fail(KMC_HIP_EINVAL, "kmc_hip_split_part: bad argument");
+	if (p->kmer_len < 1 || p->kmer_len > (uint32_t)S1_MAX_K || p->signature_len < 5 || p->signature_len > 11 || p->signature_len > p->kmer_len || p->n_bins < 1 ||
+	    p->n_bins > (uint32_t)S1_MAX_BINS || p->max_x > 3 || p->file_type > 1 || (p->max_x && p->kmer_len < 4))
+		return fail(KMC_HIP_EINVAL, "kmc_hip_split_part: unsupported parameters");
+	Dev &d = *ctx->devs[dev];
+	if (!d.d_sig_map || d.sig_map_entries != (1u << (2 * p->signature_len)) + 1)
+		return fail(KMC_HIP_EINVAL, "kmc_hip_split_part: kmc_hip_split_set_map was not called for this signature length");
+	Slot &s = d.slot[slot];
+	std::lock_guard<std::mutex> lck(s.mtx);
+	S1HipBackend be;
+	be.stream = s.stream;
+	S1PartParams sp;
+	sp.k = p->kmer_len;
+	sp.m = p->signature_len;
+	sp.n_bins = p->n_bins;
+	sp.max_x = p->max_x;
+	sp.both_strands = p->both_strands ? 1u : 0u;
+	sp.lines_per_record = p->file_type == 1 ? 4u : 2u;
+	sp.line_cap = p->line_cap;
+	sp.d_sig_to_bin = d.d_sig_map;
+	S1PartResult R;
+	try {
+		uint8_t *d_text = (uint8_t *)be.alloc(size + 16);
+		if (size) {
+			hipError_t e = hipMemcpyAsync(d_text, text, size, hipMemcpyHostToDevice, s.stream);
+			if (e != hipSuccess)
+				return fail_hip("hipMemcpyAsync(text)", e);
+		}
+		const int rc = s1_split_part(be, d_text, size, size && text[size - 1] == '\n', sp, R);
+		if (rc == S1_CHAIN_UNCOVERED)
+			return KMC_HIP_UNCOVERED;
+		if (rc != S1_CHAIN_OK)
+			return R.device_error ? err_to_code(R.device_error) : fail(KMC_HIP_EDEVICE, "kmc_hip_split_part: stage-1 chain failed");
+		if (R.recs_bytes > recs_capacity)
+			return fail(KMC_HIP_ECAPACITY, "kmc_hip_split_part: recs_capacity too small (size + 256 * (n_bins + 1) always suffices)");
+		if (R.recs_bytes)
+			be.d2h(recs, R.d_recs, R.recs_bytes);
+	} catch (const S1BackendFailure &f) {
+		return fail_hip(f.what, f.e);
+	}
+	for (uint32_t b = 0; b < p->n_bins; ++b) {
+		bin_off[b] = R.bin_off[b];
+		bin_bytes[b] = R.bin_bytes[b];
+		bin_kmers[b] = R.bin_kmers[b];
+		bin_superkmers[b] = R.bin_sk[b];
+		bin_plus_x[b] = R.bin_plus_x[b];
+	}
+	*n_reads = R.n_reads;
+	return 0;
 }
 
 /* ---- tallies over devices: one RCCL all-reduce of 4 x uint64 ---- */

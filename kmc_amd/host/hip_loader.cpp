@@ -224,3 +224,16 @@ KmcBinEngine *kmc_make_bin_engine(int worker_idx, int /*n_workers*/)
 	const int n = g_api.n_dev > 0 ? g_api.n_dev : 1;
 	return new HipEngine(worker_idx % n, (worker_idx / n) % g_api.n_slots);
 }
+
+/* for other engines bound to the same library (hip_split_loader.cpp): the loaded handle and the one context of the process */
+bool kmc_hip_loader_handles(void *&so, kmc_hip_ctx *&ctx, int &n_dev, int &n_slots, std::string &err)
+{
+	std::call_once(g_once, load_api);
+	so = g_api.so;
+	ctx = g_api.ctx;
+	n_dev = g_api.n_dev > 0 ? g_api.n_dev : 1;
+	n_slots = g_api.n_slots;
+	if (!g_api.ctx)
+		err = g_api.err.empty() ? "HIP engine not initialised" : g_api.err;
+	return g_api.ctx != nullptr;
+}

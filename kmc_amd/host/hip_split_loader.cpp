@@ -1,0 +1,110 @@
+/*
+ * kmc_amd/host/hip_split_loader.cpp — the HIP split engine of the stage-1 worker (kb_splitter_plugin.h): kmc_hip_split_part of
+ * include/kmc_hip.h through the library hip_loader.cpp already loaded. NOT YET RUN ON A GPU: the launch sequence behind
+ * kmc_hip_split_part is proven under emulation inside the reference pipeline (oracle/_ref/kmc_emu_s1), this glue is compile-checked only.
+ * No CPU fallback: without the library or a GPU the engine reports the error and the worker raises it.
+ */
+#include <dlfcn.h>
+
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "kmc_hip.h"
+#include "split_engine.h"
+
+bool kmc_hip_loader_handles(void *&so, kmc_hip_ctx *&ctx, int &n_dev, int &n_slots, std::string &err); /* hip_loader.cpp */
+
+namespace {
+struct SplitApi {
+	int (*set_map)(kmc_hip_ctx *, int, const int32_t *, uint32_t) = nullptr;
+	int (*split_part)(kmc_hip_ctx *, int, int, const kmc_hip_split_params *, const uint8_t *, uint64_t, uint8_t *, uint64_t, uint64_t *, uint64_t *, uint64_t *,
+	                  uint64_t *, uint64_t *, uint64_t *) = nullptr;
+	const char *(*last_error)(kmc_hip_ctx *) = nullptr;
+	kmc_hip_ctx *ctx = nullptr;
+	int n_dev = 1, n_slots = 1;
+	std::string err;
+	std::mutex map_mtx;
+	std::vector<char> map_set; /* per device */
+} g_split;
+std::once_flag g_split_once;
+
+void bind()
+{
+	void *so = nullptr;
+	if (!kmc_hip_loader_handles(so, g_split.ctx, g_split.n_dev, g_split.n_slots, g_split.err))
+		return;
+	g_split.set_map = reinterpret_cast<decltype(g_split.set_map)>(dlsym(so, "kmc_hip_split_set_map"));
+	g_split.split_part = reinterpret_cast<decltype(g_split.split_part)>(dlsym(so, "kmc_hip_split_part"));
+	g_split.last_error = reinterpret_cast<decltype(g_split.last_error)>(dlsym(so, "kmc_hip_last_error"));
+	if (!g_split.set_map || !g_split.split_part || !g_split.last_error) {
+		g_split.err = "libkmc_hip.so lacks kmc_hip_split_set_map / kmc_hip_split_part";
+		g_split.ctx = nullptr;
+	}
+	g_split.map_set.assign((size_t)g_split.n_dev, 0);
+}
+
+struct HipSplitEngine : KmcSplitEngine {
+	KmcSplitParams P;
+	int dev, slot;
+	std::string err;
+	std::vector<uint8_t> recs;
+	std::vector<uint64_t> arrays; /* bin_off | bin_bytes | bin_kmers | bin_superkmers | bin_plus_x */
+
+	HipSplitEngine(const KmcSplitParams &p, int dev, int slot) : P(p), dev(dev), slot(slot) { arrays.assign((size_t)5 * p.n_bins, 0); }
+	std::string last_error() override { return err; }
+	int split_part(const uint8_t *text, uint64_t size, KmcSplitResult &out) override
+	{
+		if (!g_split.ctx) {
+			err = g_split.err.empty() ? "HIP split engine not initialised" : g_split.err;
+			return KMC_HIP_EDEVICE;
+		}
+		{
+			std::lock_guard<std::mutex> lck(g_split.map_mtx);
+			if (!g_split.map_set[dev]) {
+				if (int rc = g_split.set_map(g_split.ctx, dev, P.sig_to_bin, P.signature_len)) {
+					err = g_split.last_error(g_split.ctx);
+					return rc;
+				}
+				g_split.map_set[dev] = 1;
+			}
+		}
+		kmc_hip_split_params hp;
+		hp.kmer_len = P.kmer_len;
+		hp.signature_len = P.signature_len;
+		hp.n_bins = P.n_bins;
+		hp.max_x = P.max_x;
+		hp.both_strands = P.both_strands ? 1u : 0u;
+		hp.file_type = (uint32_t)P.file_type;
+		hp.line_cap = P.line_cap;
+		const uint64_t cap = size + 256ull * (P.n_bins + 1);
+		if (recs.size() < cap)
+			recs.resize(cap);
+		const size_t nb = P.n_bins;
+		uint64_t n_reads = 0;
+		const int rc = g_split.split_part(g_split.ctx, dev, slot, &hp, text, size, recs.data(), cap, &arrays[0], &arrays[nb], &arrays[2 * nb], &arrays[3 * nb], &arrays[4 * nb],
+		                                  &n_reads);
+		if (rc == KMC_HIP_UNCOVERED)
+			return KMC_SPLIT_UNCOVERED;
+		if (rc) {
+			err = g_split.last_error(g_split.ctx);
+			return rc;
+		}
+		out.recs = recs.data();
+		out.bin_off = &arrays[0];
+		out.bin_bytes = &arrays[nb];
+		out.bin_kmers = &arrays[2 * nb];
+		out.bin_superkmers = &arrays[3 * nb];
+		out.bin_plus_x = &arrays[4 * nb];
+		out.n_reads = n_reads;
+		return 0;
+	}
+};
+} // namespace
+
+KmcSplitEngine *kmc_make_split_engine(const KmcSplitParams &params, int worker_idx, int /*n_workers*/)
+{
+	std::call_once(g_split_once, bind);
+	const int n = g_split.n_dev > 0 ? g_split.n_dev : 1;
+	return new HipSplitEngine(params, worker_idx % n, (worker_idx / n) % (g_split.n_slots > 0 ? g_split.n_slots : 1));
+}

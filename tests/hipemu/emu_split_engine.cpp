@@ -1,19 +1,39 @@
 /*
- * tests/hipemu/emu_split_engine.cpp — TEST INFRASTRUCTURE: a KmcSplitEngine (kmc_amd/host/split_engine.h) whose split_part() runs the stage-1
- * KERNELS of kmc_amd/csrc/stage1_kernels.hip.h under the CPU emulation of tests/hipemu, in the order a HIP engine will launch them:
- *   k_s1_text_to_codes -> k_s1_check_records -> k_s1_cut<true> -> k_s1_bin_totals + k_s1_bin_plus_x -> k_s1_bin_layout -> k_s1_emit.
- * Linked into oracle/_ref/kmc_emu_s1 (reference pipeline + kb_splitter_plugin.h): the kernel chain inside the real KMC, checked by the
- * database it leads to (tests/test_stage1_plugin.py). Emulated "LDS" is static storage, so calls are serialised.
+ * tests/hipemu/emu_split_engine.cpp — TEST INFRASTRUCTURE: a KmcSplitEngine (kmc_amd/host/split_engine.h) whose split_part() runs
+ * kmc_amd/csrc/stage1_chain.h — the launch sequence kmc_hip_split_part uses on the GPU — with host memory and the CPU emulation of the
+ * kernels (tests/hipemu) as its backend. Linked into oracle/_ref/kmc_emu_s1 (reference pipeline + kb_splitter_plugin.h): the kernel chain
+ * inside the real KMC, checked by the database it leads to (tests/test_stage1_plugin.py). Emulated "LDS" is static storage, so calls are
+ * serialised. $KMC_EMU_SK_GUESS_DIV sets the first guess of the super-k-mer count (a huge value forces the second cut).
  */
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
 #include <cstring>
+#include <memory>
 #include <mutex>
 #include <string>
 #include <vector>
 
 #include "../../kmc_amd/csrc/kernels.hip.h"
 #include "../../kmc_amd/csrc/stage1_kernels.hip.h"
+
+struct EmuBackend {
+	std::vector<std::unique_ptr<uint8_t[]>> blocks;
+	void *alloc(size_t bytes)
+	{
+		blocks.emplace_back(new uint8_t[bytes + 64]());
+		return blocks.back().get();
+	}
+	void zero(void *p, size_t bytes) { memset(p, 0, bytes); }
+	bool d2h(void *dst, const void *src, size_t bytes)
+	{
+		memcpy(dst, src, bytes);
+		return true;
+	}
+	void release() { blocks.clear(); }
+};
+#define S1_LAUNCH(B, be, kernel, grid, block, ...) hipemu::launch(grid, block, 0, [&] { kernel(__VA_ARGS__); })
+#include "../../kmc_amd/csrc/stage1_chain.h"
 #include "../../kmc_amd/host/split_engine.h"
 
 namespace {
@@ -22,10 +42,8 @@ std::mutex g_launch_mtx;
 struct EmuSplitEngine : KmcSplitEngine {
 	KmcSplitParams P;
 	std::string err_msg;
-	std::vector<int8_t> codes;
-	std::vector<u64> nl_pos, sk_pos, tot, lay, pack_start, plus_x, st_a, st_b, bin_off, bin_bytes, bin_kmers, bin_sk;
-	std::vector<u32> sk_len, sk_sig;
-	std::vector<uint8_t> recs;
+	EmuBackend be;
+	S1PartResult R;
 
 	explicit EmuSplitEngine(const KmcSplitParams &p) : P(p) {}
 	std::string last_error() override { return err_msg; }
@@ -33,86 +51,33 @@ struct EmuSplitEngine : KmcSplitEngine {
 	int split_part(const uint8_t *text, uint64_t size, KmcSplitResult &out) override
 	{
 		std::lock_guard<std::mutex> lck(g_launch_mtx);
-		const u32 nb = P.n_bins, lpr = P.file_type == 1 ? 4u : 2u;
-		u32 err = 0, ticket = 0;
-		u64 totals[2] = {0, 0};
-		/* text -> codes */
-		codes.assign(size + 16, 0);
-		nl_pos.assign(size + 16, 0);
-		if (size) {
-			const u32 tiles = (u32)((size + S1_TXT_TILE - 1) / S1_TXT_TILE);
-			st_a.assign(tiles, 0);
-			st_b.assign(tiles, 0);
-			hipemu::launch(dim3(tiles), dim3(S1_BLOCK), 0,
-			               [&] { k_s1_text_to_codes(text, size, lpr, st_a.data(), st_b.data(), &ticket, codes.data(), nl_pos.data(), nl_pos.size(), totals, &err); });
-			const u64 n_rec = totals[0] / lpr + 1;
-			hipemu::launch(dim3((u32)((n_rec + 255) / 256)), dim3(256), 0, [&] { k_s1_check_records(text, size, nl_pos.data(), totals[0], lpr, P.line_cap, &err); });
-		}
-		if (err & S1_TEXT_BAD)
+		be.release();
+		S1PartParams sp;
+		sp.k = P.kmer_len;
+		sp.m = P.signature_len;
+		sp.n_bins = P.n_bins;
+		sp.max_x = P.max_x;
+		sp.both_strands = P.both_strands ? 1u : 0u;
+		sp.lines_per_record = P.file_type == 1 ? 4u : 2u;
+		sp.line_cap = P.line_cap;
+		sp.d_sig_to_bin = P.sig_to_bin;
+		if (const char *g = getenv("KMC_EMU_SK_GUESS_DIV"))
+			sp.sk_guess_div = strtoull(g, nullptr, 10);
+		const int rc = s1_split_part(be, text, size, size && text[size - 1] == '\n', sp, R);
+		if (rc == S1_CHAIN_UNCOVERED)
 			return KMC_SPLIT_UNCOVERED;
-		if (err)
-			return fail(err, "text_to_codes");
-		const u64 n = totals[1];
-		/* codes -> super-k-mers */
-		u64 n_sk = 0;
-		sk_pos.assign(n + 8, 0);
-		sk_len.assign(n + 8, 0);
-		sk_sig.assign(n + 8, 0);
-		if (n) {
-			const u32 ct = (u32)s1_cut_tiles(n);
-			st_a.assign(ct, 0);
-			st_b.assign(ct, 0);
-			ticket = 0;
-			hipemu::launch(dim3(ct), dim3(S1_BLOCK), 0, [&] {
-				k_s1_cut<true>((const u32 *)nullptr, codes.data(), P.signature_len, n, P.kmer_len, st_a.data(), st_b.data(), &ticket, sk_pos.data(), sk_len.data(),
-				               sk_sig.data(), sk_pos.size(), &n_sk, &err);
-			});
+		if (rc != S1_CHAIN_OK) {
+			err_msg = "stage-1 chain failed: code " + std::to_string(rc) + ", device error word " + std::to_string(R.device_error);
+			return rc;
 		}
-		if (err)
-			return fail(err, "cut");
-		/* per-bin sums, layout, records */
-		tot.assign(3 * (size_t)nb, 0);
-		plus_x.assign(nb, 0);
-		lay.assign(3 * (size_t)nb + 2, 0);
-		const u32 sk_tiles = (u32)((n_sk + S1_SK_TILE - 1) / S1_SK_TILE);
-		if (sk_tiles) {
-			hipemu::launch(dim3(sk_tiles), dim3(256), 0, [&] {
-				k_s1_bin_totals(sk_len.data(), sk_sig.data(), n_sk, P.kmer_len, P.sig_to_bin, nb, tot.data(), tot.data() + nb, tot.data() + 2 * nb, &err);
-			});
-			hipemu::launch(dim3(sk_tiles), dim3(256), 0, [&] {
-				k_s1_bin_plus_x(codes.data(), sk_pos.data(), sk_len.data(), sk_sig.data(), n_sk, P.kmer_len, P.max_x, (u32)P.both_strands, P.sig_to_bin, nb, plus_x.data());
-			});
-		}
-		if (err)
-			return fail(err, "bin_totals");
-		hipemu::launch(dim3(1), dim3(256), 0, [&] { k_s1_bin_layout(tot.data(), nb, lay.data(), lay.data() + nb + 1, lay.data() + 2 * nb + 2, (u64 *)nullptr); });
-		recs.assign(lay[nb] + 16, 0);
-		pack_start.assign(lay[2 * (size_t)nb + 1] + 1, 0);
-		hipemu::launch(dim3(1), dim3(256), 0, [&] { k_s1_bin_layout(tot.data(), nb, lay.data(), lay.data() + nb + 1, lay.data() + 2 * nb + 2, pack_start.data()); });
-		if (sk_tiles)
-			hipemu::launch(dim3(sk_tiles), dim3(256), 0, [&] {
-				k_s1_emit(codes.data(), sk_pos.data(), sk_len.data(), sk_sig.data(), n_sk, P.kmer_len, P.sig_to_bin, nb, lay.data(), lay.data() + nb + 1,
-				          lay.data() + 2 * nb + 2, recs.data(), pack_start.data());
-			});
-		bin_off.assign(lay.begin(), lay.begin() + nb);
-		bin_bytes.assign(tot.begin(), tot.begin() + nb);
-		bin_sk.assign(tot.begin() + nb, tot.begin() + 2 * nb);
-		bin_kmers.assign(tot.begin() + 2 * nb, tot.begin() + 3 * nb);
-		out.recs = recs.data();
-		out.bin_off = (const uint64_t *)bin_off.data();
-		out.bin_bytes = (const uint64_t *)bin_bytes.data();
-		out.bin_kmers = (const uint64_t *)bin_kmers.data();
-		out.bin_superkmers = (const uint64_t *)bin_sk.data();
-		out.bin_plus_x = (const uint64_t *)plus_x.data();
-		/* titles in the part: every lines_per_record-th line, an unterminated last line included */
-		const u64 lines = totals[0] + ((size && text[size - 1] != '\n') ? 1 : 0);
-		out.n_reads = (lines + lpr - 1) / lpr;
+		out.recs = R.d_recs;
+		out.bin_off = (const uint64_t *)R.bin_off.data();
+		out.bin_bytes = (const uint64_t *)R.bin_bytes.data();
+		out.bin_kmers = (const uint64_t *)R.bin_kmers.data();
+		out.bin_superkmers = (const uint64_t *)R.bin_sk.data();
+		out.bin_plus_x = (const uint64_t *)R.bin_plus_x.data();
+		out.n_reads = R.n_reads;
 		return 0;
-	}
-	int fail(u32 e, const char *where)
-	{
-		err_msg = std::string("emulated kernel error in ") + where + ", device error word " + std::to_string(e);
-		return -(int)e;
 	}
 };
 } // namespace

@@ -200,3 +200,43 @@ def test_text_the_kernels_do_not_cover_goes_to_the_reference_splitter(tmp_path):
     want = _run("kmc", common + ["-sp1"], path, tmp_path, "ref")
     got = _run("kmc_emu_s1", common + ["-sp1"], path, tmp_path, "emu", env={"KMC_HIP_VERBOSE": "1"})
     assert got == want and _report_sum("uncovered parts") > 0
+
+
+@needs_emu
+def test_emulated_chain_retries_the_cut_when_its_first_guess_is_short(tmp_path):
+    """the number of super-k-mers is known only after the cutting kernel ran: the chain guesses, and cuts again with the exact number when the
+    guess was short (kmc_amd/csrc/stage1_chain.h). A guess of 4096 against ~7 000 super-k-mers forces that path."""
+    path = str(tmp_path / "in.fq")
+    with open(path, "wb") as f:
+        f.write(_small_text("fq", b"\n", 27))
+    common = ["-k27", "-ci1", "-m2", "-sf1", "-sr1"]
+    want = _run("kmc", common + ["-sp1"], path, tmp_path, "ref")
+    n_sk = int([ln for ln in subprocess.run([os.path.join(REF, "kmc"), *common, path, str(tmp_path / "x"), str(tmp_path)], capture_output=True, text=True).stdout.splitlines()
+                if "super-k-mers" in ln][0].split(":")[1])
+    assert n_sk > 4096
+    assert _run("kmc_emu_s1", common + ["-sp1"], path, tmp_path, "emu", env={"KMC_EMU_SK_GUESS_DIV": "1000000000000"}) == want
+
+
+def test_hip_stage1_binary_fails_loudly_without_a_gpu(tmp_path):
+    """kmc_hip_s1 (every plug-in over libkmc_hip.so, the splitter over kmc_hip_split_part) has no CPU fallback either: without a GPU the first
+    part must stop the run with the engine's error, not be split on the host"""
+    exe = os.path.join(REF, "kmc_hip_s1")
+    if not os.path.exists(exe):
+        pytest.skip("oracle/_ref/kmc_hip_s1 not built")
+    if os.path.exists("/dev/kfd"):
+        pytest.skip("a GPU is present")
+    fq = str(tmp_path / "in.fq")
+    synth.make_fastq(fq, seed=7, genome_len=20_000, n_reads=500)
+    for eager in ("1", "0"):
+        tmp = tmp_path / ("tmp" + eager)
+        tmp.mkdir()
+        env = dict(os.environ, KMC_HIP_LIB=os.path.join(ROOT, "kmc_amd", "libkmc_hip.so"), KMC_HIP_EAGER_INIT=eager)
+        r = subprocess.run([exe, "-k27", "-t2", fq, str(tmp_path / ("out" + eager)), str(tmp)], env=env, capture_output=True, text=True, timeout=120)
+        assert r.returncode != 0, r.stdout + r.stderr
+        assert "split engine" in r.stdout + r.stderr and ("no ROCm-capable device" in r.stdout + r.stderr or "HIP" in r.stdout + r.stderr), r.stdout + r.stderr
+    # with the reference splitter forced, stage 1 passes and the stage-2 worker is the one that stops the run
+    env = dict(os.environ, KMC_HIP_LIB=os.path.join(ROOT, "kmc_amd", "libkmc_hip.so"), KMC_HIP_SPLITTER_REF="1")
+    tmp = tmp_path / "tmpref"
+    tmp.mkdir()
+    r = subprocess.run([exe, "-k27", "-t2", fq, str(tmp_path / "outref"), str(tmp)], env=env, capture_output=True, text=True, timeout=120)
+    assert r.returncode != 0 and "split engine" not in r.stdout + r.stderr
