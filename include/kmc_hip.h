@@ -225,7 +225,9 @@ void kmc_hip_split_reads_free(kmc_hip_ctx *ctx, kmc_hip_s1_plan *plan);
 /* ---- stage 1, one part of input text (the engine behind kmc_amd/host/kb_splitter_plugin.h; NOT YET RUN ON A GPU) ----
  * Replaces, for one part the reference's readers cut (fastq_reader.cpp), CSplitter::ProcessReads and the n_bins CKmerBinCollectors up to the
  * bin-part buffers (splitter.cpp:557-672, kb_collector.cpp:34-106): text (host) -> the part's bin records (host, bin b at recs + bin_off[b],
- * bin_bytes[b] bytes; bins are 256-byte aligned, recs_capacity = size + 256 * (n_bins + 1) always suffices) and per bin the three sums a
+ * bin_bytes[b] bytes; bins are 256-byte aligned. *recs_bytes = bytes of `recs` the part needs: about 0.3 bytes per symbol + 256 per bin for
+ * real reads, but up to 1 + k/4 bytes per k-mer when every k-mer is its own super-k-mer — KMC_HIP_ECAPACITY asks for a second call with a
+ * larger buffer) and per bin the three sums a
  * collector keeps: bin_kmers (n_recs), bin_superkmers (n_super_kmers), bin_plus_x (n_plus_x_recs, kb_collector.h:72-118); *n_reads = titles
  * in the part. kmc_hip_split_set_map uploads CSignatureMapper's map (s_mapper.h:232; 4^signature_len + 1 entries) once per device.
  * Returns 0, a negative KMC_HIP_E* code, or KMC_HIP_UNCOVERED: the text is not what the kernels reproduce CSplitter::GetSeq on (blank lines,
@@ -240,7 +242,7 @@ typedef struct kmc_hip_split_params {
 } kmc_hip_split_params;
 int kmc_hip_split_set_map(kmc_hip_ctx *ctx, int dev, const int32_t *sig_to_bin, uint32_t signature_len);
 int kmc_hip_split_part(kmc_hip_ctx *ctx, int dev, int slot, const kmc_hip_split_params *p, const uint8_t *text, uint64_t size, uint8_t *recs,
-                       uint64_t recs_capacity, uint64_t *bin_off, uint64_t *bin_bytes, uint64_t *bin_kmers, uint64_t *bin_superkmers, uint64_t *bin_plus_x,
+                       uint64_t recs_capacity, uint64_t *recs_bytes, uint64_t *bin_off, uint64_t *bin_bytes, uint64_t *bin_kmers, uint64_t *bin_superkmers, uint64_t *bin_plus_x,
                        uint64_t *n_reads);
 
 #ifdef __cplusplus

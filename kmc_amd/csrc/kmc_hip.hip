@@ -1683,12 +1683,12 @@ int kmc_hip_split_set_map(kmc_hip_ctx *ctx, int dev, const int32_t *sig_to_bin, 
 }
 
 int kmc_hip_split_part(kmc_hip_ctx *ctx, int dev, int slot, const kmc_hip_split_params *p, const uint8_t *text, uint64_t size, uint8_t *recs,
-                       uint64_t recs_capacity, uint64_t *bin_off, uint64_t *bin_bytes, uint64_t *bin_kmers, uint64_t *bin_superkmers, uint64_t *bin_plus_x,
+                       uint64_t recs_capacity, uint64_t *recs_bytes, uint64_t *bin_off, uint64_t *bin_bytes, uint64_t *bin_kmers, uint64_t *bin_superkmers, uint64_t *bin_plus_x,
                        uint64_t *n_reads)
 {
 	if (int rc = set_dev(ctx, dev))
 		return rc;
-	if (!p || (size && !text) || !recs || !bin_off || !bin_bytes || !bin_kmers || !bin_superkmers || !bin_plus_x || !n_reads || slot < 0 || slot >= N_SLOTS)
+	if (!p || (size && !text) || !recs || !recs_bytes || !bin_off || !bin_bytes || !bin_kmers || !bin_superkmers || !bin_plus_x || !n_reads || slot < 0 || slot >= N_SLOTS)
 		return fail(KMC_HIP_EINVAL, "kmc_hip_split_part: bad argument");
 	if (p->kmer_len < 1 || p->kmer_len > (uint32_t)S1_MAX_K || p->signature_len < 5 || p->signature_len > 11 || p->signature_len > p->kmer_len || p->n_bins < 1 ||
 	    p->n_bins > (uint32_t)S1_MAX_BINS || p->max_x > 3 || p->file_type > 1 || (p->max_x && p->kmer_len < 4))
@@ -1696,6 +1696,7 @@ int kmc_hip_split_part(kmc_hip_ctx *ctx, int dev, int slot, const kmc_hip_split_
 	Dev &d = *ctx->devs[dev];
 	if (!d.d_sig_map || d.sig_map_entries != (1u << (2 * p->signature_len)) + 1)
 		return fail(KMC_HIP_EINVAL, "kmc_hip_split_part: kmc_hip_split_set_map was not called for this signature length");
+	*recs_bytes = 0;
 	Slot &s = d.slot[slot];
 	std::lock_guard<std::mutex> lck(s.mtx);
 	S1HipBackend be;
@@ -1722,8 +1723,9 @@ int kmc_hip_split_part(kmc_hip_ctx *ctx, int dev, int slot, const kmc_hip_split_
 			return KMC_HIP_UNCOVERED;
 		if (rc != S1_CHAIN_OK)
 			return R.device_error ? err_to_code(R.device_error) : fail(KMC_HIP_EDEVICE, "kmc_hip_split_part: stage-1 chain failed");
+		*recs_bytes = R.recs_bytes;
 		if (R.recs_bytes > recs_capacity)
-			return fail(KMC_HIP_ECAPACITY, "kmc_hip_split_part: recs_capacity too small (size + 256 * (n_bins + 1) always suffices)");
+			return fail(KMC_HIP_ECAPACITY, "kmc_hip_split_part: recs_capacity too small, *recs_bytes holds what this part needs");
 		if (R.recs_bytes)
 			be.d2h(recs, R.d_recs, R.recs_bytes);
 	} catch (const S1BackendFailure &f) {

@@ -19,7 +19,7 @@ namespace {
 struct SplitApi {
 	int (*set_map)(kmc_hip_ctx *, int, const int32_t *, uint32_t) = nullptr;
 	int (*split_part)(kmc_hip_ctx *, int, int, const kmc_hip_split_params *, const uint8_t *, uint64_t, uint8_t *, uint64_t, uint64_t *, uint64_t *, uint64_t *,
-	                  uint64_t *, uint64_t *, uint64_t *) = nullptr;
+	                  uint64_t *, uint64_t *, uint64_t *, uint64_t *) = nullptr;
 	const char *(*last_error)(kmc_hip_ctx *) = nullptr;
 	kmc_hip_ctx *ctx = nullptr;
 	int n_dev = 1, n_slots = 1;
@@ -77,13 +77,18 @@ struct HipSplitEngine : KmcSplitEngine {
 		hp.both_strands = P.both_strands ? 1u : 0u;
 		hp.file_type = (uint32_t)P.file_type;
 		hp.line_cap = P.line_cap;
-		const uint64_t cap = size + 256ull * (P.n_bins + 1);
-		if (recs.size() < cap)
-			recs.resize(cap);
+		/* records of real reads take ~0.3 bytes per symbol; text whose k-mers are nearly all their own super-k-mer needs more: second call */
+		if (recs.size() < size + 256ull * (P.n_bins + 1))
+			recs.resize(size + 256ull * (P.n_bins + 1));
 		const size_t nb = P.n_bins;
-		uint64_t n_reads = 0;
-		const int rc = g_split.split_part(g_split.ctx, dev, slot, &hp, text, size, recs.data(), cap, &arrays[0], &arrays[nb], &arrays[2 * nb], &arrays[3 * nb], &arrays[4 * nb],
-		                                  &n_reads);
+		uint64_t n_reads = 0, need = 0;
+		int rc = g_split.split_part(g_split.ctx, dev, slot, &hp, text, size, recs.data(), recs.size(), &need, &arrays[0], &arrays[nb], &arrays[2 * nb], &arrays[3 * nb],
+		                            &arrays[4 * nb], &n_reads);
+		if (rc == KMC_HIP_ECAPACITY && need > recs.size()) {
+			recs.resize(need);
+			rc = g_split.split_part(g_split.ctx, dev, slot, &hp, text, size, recs.data(), recs.size(), &need, &arrays[0], &arrays[nb], &arrays[2 * nb], &arrays[3 * nb],
+			                        &arrays[4 * nb], &n_reads);
+		}
 		if (rc == KMC_HIP_UNCOVERED)
 			return KMC_SPLIT_UNCOVERED;
 		if (rc) {
