@@ -133,21 +133,32 @@ def test_splitter_plugin_falls_back_for_jobs_it_does_not_cover(tmp_path):
 
 
 @needs_ref
+@pytest.mark.parametrize("skewed", [False, True], ids=["reads", "one-bin-takes-parts"])
 @pytest.mark.parametrize("flags", [["-k27", "-ci1"], ["-k27", "-b"], ["-k21"], ["-k55"], ["-k28", "-ci1"]], ids=lambda f: "".join(f))
-def test_bin_descriptors_of_the_plugin_equal_the_reference_collectors(flags, tmp_path):
+def test_bin_descriptors_of_the_plugin_equal_the_reference_collectors(flags, skewed, tmp_path):
     """per bin, what stage 1 leaves in CBinDesc — bytes, k-mers and n_plus_x_recs (the (k+x)-mer records stage 2 will expand the bin into) —
     from the reference's collectors (kmc_oracle: reference stage 1) and from the plug-in over the oracle engine (kmc_oracle_all): the direct
-    pin of oracle_s1_kxmer_recs and of the worker's sums (canonical and -b counting take different branches, kb_collector.cpp:85-98)."""
+    pin of oracle_s1_kxmer_recs and of the worker's sums (canonical and -b counting take different branches, kb_collector.cpp:85-98). The skewed
+    input sends most of every part to one bin: there the worker cuts pieces record by record and counts with kmc_record_plus_x."""
     fq = str(tmp_path / "in.fq")
-    synth.make_fastq(fq, seed=21, genome_len=200_000, n_reads=20_000, read_len=150)
+    if skewed:
+        rng = np.random.default_rng(8)
+        with open(fq, "wb") as f:
+            for i in range(20_000):
+                r = [b"A" * 150, b"AC" * 75, _rnd(rng, 150), b"T" * 149 + b"G", b"ACGT" * 37][i % 5]
+                f.write(b"@r%d\n" % i + r + b"\n+\n" + b"I" * len(r) + b"\n")
+    else:
+        synth.make_fastq(fq, seed=21, genome_len=200_000, n_reads=20_000, read_len=150)
     out = {}
     for exe in ("kmc_oracle", "kmc_oracle_all"):
         dump = str(tmp_path / (exe + ".desc"))
-        _run(exe, flags + ["-m2", "-sf1", "-sp2", "-sr1"], fq, tmp_path, exe, env={"KMC_HIP_BINDESC_DUMP": dump})
+        _run(exe, flags + ["-m2", "-sf1", "-sp2", "-sr1"], fq, tmp_path, exe, env={"KMC_HIP_BINDESC_DUMP": dump, "KMC_HIP_VERBOSE": "1"})
         rows = sorted(tuple(int(x) for x in ln.split()) for ln in open(dump))
         out[exe] = rows
+    if skewed:
+        assert _report_sum("cut record by record") > 0
     assert out["kmc_oracle"] == out["kmc_oracle_all"]
-    assert len(out["kmc_oracle"]) >= 64 and sum(r[2] for r in out["kmc_oracle"]) > 1_000_000
+    assert sum(r[2] for r in out["kmc_oracle"]) > 1_000_000 and (skewed or len(out["kmc_oracle"]) >= 64)
     assert any(r[3] for r in out["kmc_oracle"]), "n_plus_x_recs is zero everywhere: the k+x-mer path was not exercised"
 
 
