@@ -140,6 +140,7 @@ struct Dev {
 	int *d_sig_map = nullptr; /* stage 1: the signature -> bin map of kmc_hip_split_set_map */
 	u32 sig_map_entries = 0;
 	std::mutex map_mtx;
+	DBuf s1_arena[N_SLOTS]; /* stage 1: grow-only work area of kmc_hip_split_part, one per stream slot */
 };
 
 u32 counter_bytes(u64 cutoff_max, u64 counter_max) { return kmc_counter_bytes(cutoff_max, counter_max); }
@@ -792,17 +793,28 @@ struct S1BackendFailure {
 	hipError_t e;
 	const char *what;
 };
+/* Work memory comes from a grow-only arena of the slot (hipMalloc / hipFree per part would cost more than the kernels: hipFree synchronises
+ * the device); what does not fit — the arena was sized from the part's size before anything about its content was known — is a separate
+ * allocation, freed when the call ends. */
 struct S1HipBackend {
 	hipStream_t stream;
-	std::vector<void *> blocks;
+	DBuf *arena = nullptr;
+	size_t used = 0;
+	std::vector<void *> extra;
 	void *alloc(size_t bytes)
 	{
+		const size_t want = ((bytes ? bytes : 1) + 255) & ~(size_t)255;
 		void *p = nullptr;
-		hipError_t e = hipMalloc(&p, bytes ? bytes : 1);
-		if (e != hipSuccess)
-			throw S1BackendFailure{e, "hipMalloc"};
-		blocks.push_back(p);
-		e = hipMemsetAsync(p, 0, bytes ? bytes : 1, stream);
+		if (arena && used + want <= arena->cap) {
+			p = static_cast<char *>(arena->p) + used;
+			used += want;
+		} else {
+			hipError_t e = hipMalloc(&p, want);
+			if (e != hipSuccess)
+				throw S1BackendFailure{e, "hipMalloc"};
+			extra.push_back(p);
+		}
+		hipError_t e = hipMemsetAsync(p, 0, want, stream);
 		if (e != hipSuccess)
 			throw S1BackendFailure{e, "hipMemsetAsync"};
 		return p;
@@ -826,9 +838,12 @@ struct S1HipBackend {
 	}
 	void release()
 	{
-		for (void *p : blocks)
+		if (!extra.empty())
+			(void)hipStreamSynchronize(stream);
+		for (void *p : extra)
 			(void)hipFree(p);
-		blocks.clear();
+		extra.clear();
+		used = 0;
 	}
 	~S1HipBackend() { release(); }
 };
@@ -910,6 +925,9 @@ void kmc_hip_destroy(kmc_hip_ctx *ctx)
 			(void)hipFree(d->rccl_buf.p);
 		if (d->d_sig_map)
 			(void)hipFree(d->d_sig_map);
+		for (auto &a : d->s1_arena)
+			if (a.p)
+				(void)hipFree(a.p);
 	}
 	if (ctx->comms_ready)
 		for (auto &c : ctx->comms)
@@ -1699,8 +1717,13 @@ int kmc_hip_split_part(kmc_hip_ctx *ctx, int dev, int slot, const kmc_hip_split_
 	*recs_bytes = 0;
 	Slot &s = d.slot[slot];
 	std::lock_guard<std::mutex> lck(s.mtx);
+	/* text + codes + line ends (2 B per byte of text at most, see stage1_chain.h) + super-k-mers (2 B per symbol at the first guess) +
+	 * records (~0.3 B per symbol) + per-bin arrays */
+	if (int rc = ensure(d.s1_arena[slot], (size_t)size * 8 + ((size_t)32 << 20)))
+		return rc;
 	S1HipBackend be;
 	be.stream = s.stream;
+	be.arena = &d.s1_arena[slot];
 	S1PartParams sp;
 	sp.k = p->kmer_len;
 	sp.m = p->signature_len;
