@@ -251,3 +251,46 @@ def test_hip_stage1_binary_fails_loudly_without_a_gpu(tmp_path):
     tmp.mkdir()
     r = subprocess.run([exe, "-k27", "-t2", fq, str(tmp_path / "outref"), str(tmp)], env=env, capture_output=True, text=True, timeout=120)
     assert r.returncode != 0 and "split engine" not in r.stdout + r.stderr
+
+
+def _random_text(seed):
+    """a FASTA or FASTQ file of random records: reads of a small genome and of a skewed alphabet (N, IUPAC, lower case), empty / homopolymer /
+    periodic reads, titles and quality strings of random printable characters ('@', '+', '>' anywhere), LF and CRLF mixed line by line"""
+    rng = np.random.default_rng(seed)
+    fmt = ["fq", "fa"][int(rng.integers(0, 2))]
+    k = int(rng.choice([11, 21, 27, 28, 32, 40, 55]))
+    alpha = np.frombuffer(b"ACGTacgtNnRY", dtype=np.uint8)
+    p = np.array([20, 20, 20, 20, 2, 2, 2, 2, 1, 0.5, 0.3, 0.2])
+    p = p / p.sum()
+    genome = np.frombuffer(b"ACGT", dtype=np.uint8)[rng.integers(0, 4, size=5000)]
+    out = []
+    for _ in range(int(rng.integers(1, 800))):
+        mode = rng.random()
+        if mode < 0.6:
+            a = int(rng.integers(0, 4800))
+            r = genome[a:a + int(rng.integers(0, 200))].tobytes()
+        elif mode < 0.9:
+            r = alpha[rng.choice(alpha.size, size=int(rng.integers(0, 300)), p=p)].tobytes()
+        else:
+            r = [b"", b"A" * int(rng.integers(1, 400)), b"ACGT" * int(rng.integers(1, 60)), b"N" * 5][int(rng.integers(0, 4))]
+        eol = b"\r\n" if rng.random() < 0.3 else b"\n"
+        title = (b"@" if fmt == "fq" else b">") + bytes(rng.integers(33, 127, size=int(rng.integers(0, 40)), dtype=np.uint8))
+        if fmt == "fq":
+            q = bytes(rng.integers(33, 127, size=len(r), dtype=np.uint8))
+            out.append(title + eol + r + eol + b"+" + (title[1:] if rng.random() < 0.2 else b"") + eol + q + eol)
+        else:
+            out.append(title + eol + r + eol)
+    return fmt, k, b"".join(out)
+
+
+@needs_emu
+@pytest.mark.parametrize("seed", range(8))
+def test_emulated_stage1_kernels_on_random_text(seed, tmp_path):
+    """seeded sweep (130 more seeds were run once while this was written: no difference): database and statistics of the reference pipeline
+    with the emulated stage-1 kernels vs the unmodified reference"""
+    fmt, k, text = _random_text(seed)
+    path = str(tmp_path / ("in." + fmt))
+    with open(path, "wb") as f:
+        f.write(text)
+    flags = ["-k%d" % k, "-ci1", "-m2", "-sf1", "-sr1"] + (["-fa"] if fmt == "fa" else [])
+    assert _run("kmc_emu_s1", flags + ["-sp1"], path, tmp_path, "emu") == _run("kmc", flags + ["-sp1"], path, tmp_path, "ref")
