@@ -33,6 +33,21 @@ def build(geometry="small", force=False) -> str:
     return so
 
 
+def build_mock(force=False) -> str:
+    """tests/hipemu/libkmc_hip_mock.so: the entry points the product's dlopen loaders bind, over the stage-2 oracle and the emulated stage-1
+    chain (see mock_hip_lib.cpp). Loaded only through an explicit KMC_HIP_LIB."""
+    so = os.path.join(EMU_DIR, "libkmc_hip_mock.so")
+    srcs = [os.path.join(EMU_DIR, "mock_hip_lib.cpp"), os.path.join(EMU_DIR, "include", "hip", "hip_runtime.h"), os.path.join(ROOT, "oracle", "stage2_oracle.c"),
+            os.path.join(ROOT, "oracle", "stage2_oracle.h"), os.path.join(ROOT, "include", "kmc_hip.h")] + [os.path.join(ROOT, "kmc_amd", "csrc", f) for f in
+                                                                                                       ("kernels.hip.h", "kmer_ops.h", "stage1_kernels.hip.h", "stage1_chain.h")]
+    if force or not os.path.exists(so) or any(os.path.getmtime(x) > os.path.getmtime(so) for x in srcs):
+        obj = os.path.join(EMU_DIR, "stage2_oracle_mock.o")
+        subprocess.check_call(["gcc", "-O2", "-std=c11", "-fPIC", "-c", srcs[2], "-o", obj])
+        subprocess.check_call(["g++", "-std=c++17", "-O1", "-g", "-fPIC", "-shared", "-pthread", "-w", "-fvisibility=hidden", "-I", os.path.join(EMU_DIR, "include"),
+                               srcs[0], obj, "-o", so])
+    return so
+
+
 def lib(geometry="small"):
     if geometry not in _LIBS:
         L = C.CDLL(build(geometry))

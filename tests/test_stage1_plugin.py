@@ -294,3 +294,26 @@ def test_emulated_stage1_kernels_on_random_text(seed, tmp_path):
         f.write(text)
     flags = ["-k%d" % k, "-ci1", "-m2", "-sf1", "-sr1"] + (["-fa"] if fmt == "fa" else [])
     assert _run("kmc_emu_s1", flags + ["-sp1"], path, tmp_path, "emu") == _run("kmc", flags + ["-sp1"], path, tmp_path, "ref")
+
+
+# ---- the PRODUCT binaries on the CPU: kmc_hip / kmc_hip_s1 (plug-ins + the dlopen loaders hip_loader.cpp / hip_split_loader.cpp) bound to a
+# mock of libkmc_hip.so (tests/hipemu/mock_hip_lib.cpp: stage-2 oracle per bin, emulated stage-1 chain per part) instead of the GPU library
+@pytest.mark.parametrize("exe,flags", [("kmc_hip_s1", ["-k27", "-ci1", "-sp3", "-sr3"]), ("kmc_hip_s1", ["-k55", "-b", "-sp2", "-sr1"]), ("kmc_hip", ["-k27", "-ci1", "-sp2", "-sr2"])],
+                         ids=lambda v: v if isinstance(v, str) else "".join(v))
+def test_product_binaries_over_a_mock_library_write_the_reference_database(exe, flags, tmp_path):
+    """everything between the reference pipeline and the C-ABI — worker plug-ins, ordered emission with several workers, loaders, argument
+    marshalling of kmc_hip_process_bin_submit/_wait and kmc_hip_split_set_map/_split_part, two configured devices — runs here as shipped; only the
+    library behind the C-ABI is a stand-in"""
+    if not os.path.exists(os.path.join(REF, exe)):
+        pytest.skip("oracle/_ref/%s not built" % exe)
+    import emu
+
+    mock = emu.build_mock()
+    fq = str(tmp_path / "in.fq")
+    synth.make_fastq(fq, seed=11, genome_len=50_000, n_reads=3_000, read_len=150)
+    common = [f for f in flags if not f.startswith(("-sp", "-sr"))] + ["-m2", "-sf1"]
+    want = _run("kmc", common + ["-sp1", "-sr1"], fq, tmp_path, "ref")
+    got = _run(exe, flags + ["-m2", "-sf1"], fq, tmp_path, "mock", env={"KMC_HIP_LIB": mock, "KMC_HIP_DEVICES": "0,1", "KMC_HIP_VERBOSE": "1"})
+    assert got == want
+    if exe == "kmc_hip_s1":
+        assert _report_sum("parts through the engine") > 0 and _report_sum("bin pieces") > 0
