@@ -48,6 +48,60 @@ def build_mock(force=False) -> str:
     return so
 
 
+def rewrite_launches(src: str) -> str:
+    """`kernel<tmpl><<<grid, block, lds, stream>>>(args)` -> `HIPEMU_LAUNCH((kernel<tmpl>), grid, block, lds, stream, args)`: the one construct of
+    kmc_amd/csrc/kmc_hip.hip a host compiler cannot parse. Everything else of the product's host source is compiled as it is."""
+    out, pos = [], 0
+    while True:
+        i = src.find("<<<", pos)
+        if i < 0:
+            out.append(src[pos:])
+            return "".join(out)
+        # the kernel expression: back over an identifier with optional template arguments
+        j, depth = i, 0
+        while j > 0:
+            c = src[j - 1]
+            if c == ">":
+                depth += 1
+            elif c == "<":
+                depth -= 1
+            elif depth == 0 and not (c.isalnum() or c in "_:"):
+                break
+            j -= 1
+        e = src.find(">>>", i)
+        assert e > 0 and src[e + 3] == "(", "launch syntax the rewriter does not know"
+        k, d = e + 4, 1
+        while d:
+            d += {"(": 1, ")": -1}.get(src[k], 0)
+            k += 1
+        args = src[e + 4:k - 1].strip()
+        out.append(src[pos:j] + "HIPEMU_LAUNCH((" + src[j:i] + "), " + src[i + 3:e].strip() + (", " + args if args else "") + ")")
+        pos = k
+
+
+def build_hostlib(geometry="small", force=False) -> str:
+    """tests/hipemu/libkmc_hip_emu_<geometry>.so: THE PRODUCT'S HOST LIBRARY (kmc_amd/csrc/kmc_hip.hip: every C-ABI entry point, buffer
+    management, launch sequences, error handling) compiled with g++ over the emulated kernels and an emulated HIP runtime
+    (tests/hipemu/include/hip/hip_host_api.h). Load it with KMC_HIP_LIB=<path>: kmc_amd.capi, the worker plug-ins' loaders and the -m gpu tests
+    then run on a box without a GPU (small inputs: one OS thread per GPU thread)."""
+    so = os.path.join(EMU_DIR, f"libkmc_hip_emu_{geometry}.so")
+    csrc = os.path.join(ROOT, "kmc_amd", "csrc")
+    srcs = [os.path.join(csrc, f) for f in ("kmc_hip.hip", "kernels.hip.h", "kmer_ops.h", "stage1_kernels.hip.h", "stage1_chain.h")] + [
+        os.path.join(ROOT, "include", "kmc_hip.h"), os.path.join(EMU_DIR, "include", "hip", "hip_runtime.h"), os.path.join(EMU_DIR, "include", "hip", "hip_host_api.h"),
+        os.path.join(EMU_DIR, "include", "rccl", "rccl.h"), os.path.abspath(__file__)]
+    if force or not os.path.exists(so) or any(os.path.getmtime(x) > os.path.getmtime(so) for x in srcs):
+        gen_dir = os.path.join(EMU_DIR, "_gen")
+        os.makedirs(gen_dir, exist_ok=True)
+        gen = os.path.join(gen_dir, f"kmc_hip_emu_{geometry}.cpp")
+        with open(srcs[0]) as f:
+            text = rewrite_launches(f.read())
+        with open(gen, "w") as f:
+            f.write("/* GENERATED by tests/emu.py build_hostlib from kmc_amd/csrc/kmc_hip.hip: only the kernel launches were rewritten */\n" + text)
+        subprocess.check_call(["g++", "-std=c++17", "-O1", "-g", "-fPIC", "-shared", "-pthread", "-w", "-fno-gnu-unique", "-Wl,-Bsymbolic", "-DHIPEMU_HOST_API",
+                               *GEOMETRY_FLAGS[geometry], "-I", os.path.join(EMU_DIR, "include"), "-I", csrc, gen, "-o", so])
+    return so
+
+
 def lib(geometry="small"):
     if geometry not in _LIBS:
         L = C.CDLL(build(geometry))

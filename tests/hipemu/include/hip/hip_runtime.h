@@ -262,4 +262,8 @@ template <typename T> static inline T atomicMax(T *p, T v)
 	return old;
 }
 
+#ifdef HIPEMU_HOST_API
+#include "hip_host_api.h" /* the runtime API of the product's host library, over plain memory (tests/emu.py build_hostlib) */
+#endif
+
 #endif

@@ -1,7 +1,9 @@
-"""-m gpu, OPT-IN: the stage-1 worker plug-in over kmc_hip_split_part inside the reference pipeline (oracle/_ref/kmc_hip_s1). The host glue behind
-that entry point (kmc_hip.hip S1HipBackend, hip_split_loader.cpp) was written after round 2's GPU budget was spent and has never run on a GPU;
-its launch sequence is the one tests/test_stage1_plugin.py proves under emulation. These tests therefore run only with KMC_TEST_UNVALIDATED=1,
-so that an unproven path cannot stop the validated suite; the first GPU session of the next round switches them on for good."""
+"""-m gpu: the stage-1 worker plug-in over kmc_hip_split_part inside the reference pipeline (oracle/_ref/kmc_hip_s1: stage 1 AND stage 2 on the
+GPU). Everything on this path has run on the CPU — the kernels and the launch sequence under emulation inside the reference pipeline
+(tests/test_stage1_plugin.py), the product binary over the product's host library compiled against an emulated HIP runtime
+(tests/test_hostlib_emulated.py) — but kmc_hip_split_part was written after round 2's GPU budget was spent and had not met a real GPU when this
+was committed. The tests are therefore marked xfail(strict=False): they RUN (in a child process: the binary), a pass is reported as XPASS, a
+failure as XFAIL, and neither can stop the validated suite. KMC_TEST_UNVALIDATED=0 skips them. Last file of the -m gpu collection on purpose."""
 import hashlib
 import os
 import subprocess
@@ -10,10 +12,14 @@ import pytest
 
 from kmc_amd import synth
 
-pytestmark = [pytest.mark.gpu, pytest.mark.skipif(os.environ.get("KMC_TEST_UNVALIDATED") != "1", reason="opt-in: set KMC_TEST_UNVALIDATED=1 (never run on a GPU yet)")]
+pytestmark = [pytest.mark.gpu, pytest.mark.skipif(os.environ.get("KMC_TEST_UNVALIDATED") == "0", reason="KMC_TEST_UNVALIDATED=0"),
+              pytest.mark.xfail(strict=False, reason="kmc_hip_split_part had not run on a real GPU when this was committed (emulation-validated only)")]
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 REF = os.path.join(ROOT, "oracle", "_ref")
+
+
+_state = {"broken": False}  # one failed or hung run is enough: the other parameter sets do not spend GPU time on the same problem
 
 
 def _run(exe, flags, inp, tmp_path, tag, env=None):
@@ -21,7 +27,13 @@ def _run(exe, flags, inp, tmp_path, tag, env=None):
     t.mkdir(exist_ok=True)
     db = str(tmp_path / ("db_" + tag))
     e = dict(os.environ, KMC_HIP_LIB=os.path.join(ROOT, "kmc_amd", "libkmc_hip.so"), **(env or {}))
-    r = subprocess.run([os.path.join(REF, exe), *flags, inp, db, str(t)], capture_output=True, text=True, env=e, timeout=600)
+    try:
+        r = subprocess.run([os.path.join(REF, exe), *flags, inp, db, str(t)], capture_output=True, text=True, env=e, timeout=120)
+    except subprocess.TimeoutExpired:
+        _state["broken"] = True
+        raise
+    if r.returncode != 0:
+        _state["broken"] = True
     assert r.returncode == 0, (exe, flags, (r.stdout + r.stderr)[-1500:])
     md5 = tuple(hashlib.md5(open(db + x, "rb").read()).hexdigest() for x in (".kmc_pre", ".kmc_suf"))
     stats = [ln.split(":")[1].strip() for ln in r.stdout.splitlines() if "No. of" in ln or "Total no." in ln]
@@ -30,6 +42,8 @@ def _run(exe, flags, inp, tmp_path, tag, env=None):
 
 @pytest.mark.parametrize("flags", [["-k27", "-ci1"], ["-k27", "-b"], ["-k55"], ["-k21", "-ci1"]], ids=lambda f: "".join(f))
 def test_kmc_with_hip_stage1_and_stage2_writes_the_reference_database(flags, tmp_path):
+    if _state["broken"]:
+        pytest.xfail("an earlier run of kmc_hip_s1 failed or hung")
     fq = str(tmp_path / "in.fq")
     synth.make_fastq(fq, seed=31, genome_len=2_000_000, n_reads=300_000, read_len=150)
     want = _run("kmc", flags + ["-m4", "-sf1", "-sp1", "-sr1"], fq, tmp_path, "ref")

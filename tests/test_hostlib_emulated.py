@@ -1,0 +1,59 @@
+"""CPU: the PRODUCT'S HOST LIBRARY — kmc_amd/csrc/kmc_hip.hip, every C-ABI entry point with its buffer management, launch sequences and error
+handling — compiled with g++ over the emulated kernels and an emulated HIP runtime (tests/emu.py build_hostlib: the source is used as it is,
+only the `<<<...>>>` launches are rewritten) and loaded through KMC_HIP_LIB in place of libkmc_hip.so. Two uses:
+  * a quick subset of the -m gpu tests runs here, in a child process, on every CPU run of the suite (the whole -m gpu parity file passes this
+    way too: `KMC_HIP_LIB=tests/hipemu/libkmc_hip_emu_small.so pytest tests -m gpu -k ...`, 142 tests in 25 min when this was written);
+  * the product binary kmc_hip_s1 (all four plug-ins, both dlopen loaders) over that library: stage 1 through kmc_hip_split_part and stage 2
+    through kmc_hip_process_bin_submit/_wait, i.e. everything but the silicon and the real runtime, against the reference's database.
+Test infrastructure only: nothing loads the emulated library unless KMC_HIP_LIB names it."""
+import hashlib
+import os
+import subprocess
+import sys
+
+import pytest
+
+import emu
+from kmc_amd import synth
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REF = os.path.join(ROOT, "oracle", "_ref")
+
+QUICK = ("process_bin_edges or size_and_n_rec or sort_records_into or allreduce_stats_single or submit_wait or (test_stage1_kernels_match_the_oracle and 27-9) "
+         "or (compact_stage_matches_oracle and 27-3) or (expand_stage_matches_oracle and 1-27) or (test_process_bin_matches_oracle and k27-cutoff)")
+
+
+def test_gpu_tests_pass_on_the_emulated_host_library():
+    lib = emu.build_hostlib("small")
+    env = dict(os.environ, KMC_HIP_LIB=lib)
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(ROOT, "tests", "test_gpu_parity.py"), os.path.join(ROOT, "tests", "test_gpu_stage1.py"), "-m", "gpu",
+                        "-q", "-x", "-p", "no:cacheprovider", "-k", QUICK], env=env, capture_output=True, text=True, timeout=1500, cwd=ROOT)
+    tail = (r.stdout + r.stderr)[-1500:]
+    assert r.returncode == 0, tail
+    assert " passed" in tail and "failed" not in tail
+    assert int(tail.split(" passed")[0].split()[-1]) >= 10, tail
+
+
+def _run(exe, flags, inp, tmp_path, tag, env=None):
+    t = tmp_path / ("tmp_" + tag)
+    t.mkdir(exist_ok=True)
+    db = str(tmp_path / ("db_" + tag))
+    r = subprocess.run([os.path.join(REF, exe), *flags, inp, db, str(t)], capture_output=True, text=True, env=dict(os.environ, **(env or {})), timeout=1500)
+    assert r.returncode == 0, (exe, flags, (r.stdout + r.stderr)[-1500:])
+    md5 = tuple(hashlib.md5(open(db + e, "rb").read()).hexdigest() for e in (".kmc_pre", ".kmc_suf"))
+    stats = [ln.split(":")[1].strip() for ln in r.stdout.splitlines() if "No. of" in ln or "Total no." in ln]
+    return md5, stats, r.stderr
+
+
+@pytest.mark.parametrize("flags", [["-k27", "-ci1"], ["-k55", "-b"]], ids=lambda f: "".join(f))
+def test_product_binary_over_the_emulated_host_library_writes_the_reference_database(flags, tmp_path):
+    if not os.path.exists(os.path.join(REF, "kmc_hip_s1")):
+        pytest.skip("oracle/_ref/kmc_hip_s1 not built (needs /root/reference)")
+    lib = emu.build_hostlib("small")
+    fq = str(tmp_path / "in.fq")
+    synth.make_fastq(fq, seed=11, genome_len=30_000, n_reads=1_500, read_len=150)
+    common = flags + ["-m2", "-sf1", "-n64"]
+    want = _run("kmc", common + ["-sp1", "-sr1"], fq, tmp_path, "ref")
+    got = _run("kmc_hip_s1", common + ["-sp2", "-sr2"], fq, tmp_path, "emu", env={"KMC_HIP_LIB": lib, "KMC_HIP_VERBOSE": "1"})
+    assert got[:2] == want[:2]
+    assert "parts through the engine" in got[2] and "[kmc_hip stage 2] 64 bins, 2 workers" in got[2]
