@@ -57,3 +57,20 @@ def test_product_binary_over_the_emulated_host_library_writes_the_reference_data
     got = _run("kmc_hip_s1", common + ["-sp2", "-sr2"], fq, tmp_path, "emu", env={"KMC_HIP_LIB": lib, "KMC_HIP_VERBOSE": "1"})
     assert got[:2] == want[:2]
     assert "parts through the engine" in got[2] and "[kmc_hip stage 2] 64 bins, 2 workers" in got[2]
+
+
+def test_two_emulated_devices_context_wide_records_allreduce_and_dropin(tmp_path):
+    """the multi-device code of the host library and of the worker loader on TWO emulated devices (HIPEMU_DEVICES=2) — no box this repo has seen
+    had two GPUs, so this is where `KMC_HIP_DEVICES=0,1`, the per-device function attributes and kmc_hip_allreduce_stats over two devices run
+    (the -m gpu original, test_two_devices_worker_allreduce_and_wide_records, passes on the emulated library as well: 230 s)"""
+    lib = emu.build_hostlib("small")
+    env = dict(os.environ, KMC_HIP_LIB=lib, HIPEMU_DEVICES="2")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "hostlib_two_devices.py")], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and "two devices ok" in r.stdout, (r.stdout + r.stderr)[-1500:]
+    if not os.path.exists(os.path.join(REF, "kmc_hip")):
+        return
+    fq = str(tmp_path / "in.fq")
+    synth.make_fastq(fq, seed=5, genome_len=20_000, n_reads=800, read_len=150)
+    want = _run("kmc", ["-k27", "-ci1", "-m2", "-sf1", "-n64", "-sp1", "-sr1"], fq, tmp_path, "ref")
+    got = _run("kmc_hip", ["-k27", "-ci1", "-m2", "-sf1", "-n64", "-sp1", "-sr4"], fq, tmp_path, "emu", env={"KMC_HIP_LIB": lib, "HIPEMU_DEVICES": "2", "KMC_HIP_DEVICES": "0,1"})
+    assert got[:2] == want[:2]
