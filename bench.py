@@ -428,6 +428,7 @@ def main():
     is_main = not args.leg
     name = args.leg or next((n for n, c in CONFIGS.items() if (c["reads"], c["genome"], c["bins"]) == (args.reads, args.genome, args.bins)), "custom")
     k = args.k
+    capi.require_gpu_backend()
     ctx = capi.Context((dev_index,))
     pl = args.lut_prefix if args.lut_prefix >= 0 else kmc_lut_prefix_len(k, args.reads, args.bins)
     p = capi.make_params(k, lut_prefix_len=pl)

@@ -62,6 +62,9 @@ int kmc_hip_init(const int *device_ids, int n_dev, kmc_hip_ctx **out);
 void kmc_hip_destroy(kmc_hip_ctx *ctx);
 const char *kmc_hip_last_error(kmc_hip_ctx *ctx); /* thread-local message of the calling thread's last failure */
 int kmc_hip_abi_version(void);
+/* 0 = HIP on a GPU (the product). Test builds say otherwise — 1: this library's source over the CPU emulation of tests/hipemu, 2: the mock of
+ * tests/hipemu/mock_hip_lib.cpp — so that whatever measures or certifies (bench.py, __graft_entry__.smoke) can refuse them. */
+int kmc_hip_backend_kind(void);
 int kmc_hip_num_devices(kmc_hip_ctx *ctx);
 int kmc_hip_device_count(void); /* HIP devices visible to the process (0 when the runtime is unusable) */
 int kmc_hip_num_slots(void); /* stream slots per device usable with _submit/_wait (independent bins in flight) */

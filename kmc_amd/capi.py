@@ -62,7 +62,7 @@ def make_params(k, both_strands=1, cutoff_min=2, cutoff_max=10**9, counter_max=2
 
 # every symbol include/kmc_hip.h declares (tests check the library exports them all)
 SYMBOLS = [
-    "kmc_hip_init", "kmc_hip_destroy", "kmc_hip_last_error", "kmc_hip_abi_version", "kmc_hip_num_devices", "kmc_hip_num_slots",
+    "kmc_hip_init", "kmc_hip_destroy", "kmc_hip_last_error", "kmc_hip_abi_version", "kmc_hip_backend_kind", "kmc_hip_num_devices", "kmc_hip_num_slots",
     "kmc_hip_device_count",
     "kmc_hip_words", "kmc_hip_counter_size", "kmc_hip_out_rec_bytes", "kmc_hip_lut_entries",
     "kmc_hip_sort_records", "kmc_hip_sort_records_into", "kmc_hip_sort_records_device",
@@ -82,6 +82,14 @@ _LIB = None
 def lib_path() -> str:
     """In-tree libkmc_hip.so; $KMC_HIP_LIB overrides (tuning variants built by tools/build_variants.py)."""
     return os.environ.get("KMC_HIP_LIB") or _build.LIB_HIP
+
+
+def require_gpu_backend():
+    """bench.py / smoke(): refuse a test build of the library (CPU emulation or mock, see kmc_hip_backend_kind) — numbers and certificates are
+    for the GPU library only."""
+    kind = load().kmc_hip_backend_kind()
+    if kind != 0:
+        raise RuntimeError(f"{lib_path()} is a test build of libkmc_hip (backend kind {kind}: CPU emulation / mock), not the GPU library")
 
 
 def load():

@@ -854,6 +854,14 @@ struct S1HipBackend {
 extern "C" {
 
 int kmc_hip_abi_version(void) { return KMC_HIP_ABI_VERSION; }
+int kmc_hip_backend_kind(void)
+{
+#ifdef KMC_HIPEMU /* tests/hipemu: this source compiled for the CPU emulation (tests/emu.py build_hostlib) */
+	return 1;
+#else
+	return 0;
+#endif
+}
 const char *kmc_hip_last_error(kmc_hip_ctx *) { return g_err.c_str(); }
 uint32_t kmc_hip_words(uint32_t kmer_len) { return (kmer_len + 31) / 32; }
 uint32_t kmc_hip_counter_size(uint64_t cutoff_max, uint64_t counter_max) { return counter_bytes(cutoff_max, counter_max); }

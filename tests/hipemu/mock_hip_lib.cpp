@@ -73,6 +73,7 @@ MOCK_API int kmc_hip_init(const int *, int n_dev, kmc_hip_ctx **out)
 MOCK_API void kmc_hip_destroy(kmc_hip_ctx *ctx) { delete ctx; }
 MOCK_API const char *kmc_hip_last_error(kmc_hip_ctx *) { return g_err.c_str(); }
 MOCK_API int kmc_hip_abi_version(void) { return KMC_HIP_ABI_VERSION; }
+MOCK_API int kmc_hip_backend_kind(void) { return 2; }
 MOCK_API int kmc_hip_num_slots(void) { return 4; }
 MOCK_API int kmc_hip_sort_records_into(kmc_hip_ctx *, int, const void *recs, void *dst, uint64_t n, uint32_t words, uint32_t)
 {

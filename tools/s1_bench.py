@@ -35,6 +35,7 @@ def main():
     codes, n_reads = make_codes(a.symbols, 150, 1)
     smap = np.random.default_rng(2).integers(0, a.bins, size=(1 << (2 * a.m)) + 1).astype(np.int32)
     gen_s = time.time() - t
+    capi.require_gpu_backend()
     ctx = capi.Context((0,))
     L, h = ctx.L, ctx.h
     L.kmc_hip_split_reads_free.restype = None
