@@ -22,6 +22,7 @@ Extra keys of the N=1 line (each measured after the timed region, none inside it
   secondary.single_bin: configs[1] — 2 Gbp, all k-mers as ONE bin (the kernel-level datum of round 1)
   secondary.bins512_2gbp: the 2 Gbp sample cut into 512 bins (3.2 M k-mers per bin), tallies checked against the reference
   secondary.stage1_groundwork: NOT stage 2 — the splitter groundwork of DESIGN.md 9 (codes in HBM -> bins in HBM), timed by tools/s1_bench.py
+  e2e_stage1          : NOT stage 2 — "1st stage" seconds of the reference pipeline with the splitter worker swapped too (kmc_hip_s1)
   cpu_baseline / e2e  : the REAL reference (oracle/_ref/kmc, built from /root/reference by oracle/Makefile) and the drop-in
                         (oracle/_ref/kmc_hip = reference pipeline + this library) on a FASTQ of the SAME reads as the 2 Gbp sample:
                         "2nd stage" seconds of each, the five statistics compared.
@@ -298,10 +299,10 @@ _STAT_PATTERNS = {
 }
 
 
-def _run_kmc(exe, flags, fq, td, tag, env=None):
+def _run_kmc(exe, flags, fq, td, tag, env=None, timeout=None):
     tmp = os.path.join(td, "tmp_" + tag)
     os.makedirs(tmp, exist_ok=True)
-    r = subprocess.run([exe, *flags, fq, os.path.join(td, "db_" + tag), tmp], capture_output=True, text=True, env=env)
+    r = subprocess.run([exe, *flags, fq, os.path.join(td, "db_" + tag), tmp], capture_output=True, text=True, env=env, timeout=timeout)
     shutil.rmtree(tmp, ignore_errors=True)
     if r.returncode != 0:
         raise RuntimeError(f"{os.path.basename(exe)} failed: {(r.stdout + r.stderr)[-600:]}")
@@ -358,6 +359,22 @@ def reference_legs(k: int, reads: int, genome: int, runs: int = 2):
                           "ref_stage2_s": s2, "hip_stage2_s": h2, "speedup": s2 / h2, "hip_Gkmers_per_s": hst["total"] / h2 / 1e9,
                           "ref_Gkmers_per_s": st["total"] / s2 / 1e9, "stats_equal": hst == st, "hip_stats": hst, "hip_stage1_s": h1,
                           "all_hip_stage2_s": [x[1] for x in hip_runs], "all_ref_stage2_s": [x[1] for x in ref_runs], "worker_report": verbose}
+            # Stage 1 on the GPU as well: informative, in its own try — kmc_hip_split_part had run under emulation only when this
+            # was committed, and nothing here may cost the stage-2 line.
+            hip_s1 = os.path.join(ROOT, "oracle", "_ref", "kmc_hip_s1")
+            if os.path.exists(hip_s1):
+                try:
+                    g1, g2, gst, gverbose = _run_kmc(hip_s1, [f"-k{k}", f"-t{threads}", f"-m{mem}", "-sr16", "-hp"], fq, td, "hips1", env, timeout=300)
+                    out["e2e_stage1"] = {"what": "'1st stage' seconds of the same pipeline with the splitter worker swapped too (oracle/_ref/kmc_hip_s1: parts of "
+                                                 "FASTQ text through kmc_hip_split_part); readers, storer and bin files are the reference's",
+                                         "ref_stage1_s": s1, "hip_stage1_s": g1, "speedup": s1 / g1 if g1 else None, "hip_stage2_s": g2, "stats_equal": gst == st,
+                                         "workers": sum(1 for ln in gverbose if "stage 1" in ln),
+                                         "parts_through_the_engine": sum(int(m.group(1)) for ln in gverbose for m in [re.search(r"worker: (\d+) parts", ln)] if m),
+                                         "engine_s_summed_over_workers": sum(float(m.group(1)) for ln in gverbose for m in [re.search(r"\(([0-9.]+) s inside\)", ln)] if m),
+                                         "uncovered_parts": sum(int(m.group(1)) for ln in gverbose for m in [re.search(r"and (\d+) uncovered parts", ln)] if m),
+                                         "worker_report": [ln for ln in gverbose if "stage 1" in ln and "worker: 0 parts" not in ln][:3]}
+                except Exception as e:  # noqa: BLE001
+                    out["e2e_stage1"] = {"error": repr(e)[-600:]}
     return out
 
 
