@@ -225,7 +225,7 @@ int kmc_hip_split_reads_plan(kmc_hip_ctx *ctx, int dev, const int8_t *d_codes, u
 int kmc_hip_split_reads_emit(kmc_hip_ctx *ctx, kmc_hip_s1_plan *plan, uint8_t *d_bins, uint64_t *d_pack_start);
 void kmc_hip_split_reads_free(kmc_hip_ctx *ctx, kmc_hip_s1_plan *plan);
 
-/* ---- stage 1, one part of input text (the engine behind kmc_amd/host/kb_splitter_plugin.h; NOT YET RUN ON A GPU) ----
+/* ---- stage 1, one part of input text (the engine behind kmc_amd/host/kb_splitter_plugin.h; emulation-validated) ----
  * Replaces, for one part the reference's readers cut (fastq_reader.cpp), CSplitter::ProcessReads and the n_bins CKmerBinCollectors up to the
  * bin-part buffers (splitter.cpp:557-672, kb_collector.cpp:34-106): text (host) -> the part's bin records (host, bin b at recs + bin_off[b],
  * bin_bytes[b] bytes; bins are 256-byte aligned. *recs_bytes = bytes of `recs` the part needs: about 0.3 bytes per symbol + 256 per bin for

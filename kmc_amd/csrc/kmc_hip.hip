@@ -1685,7 +1685,8 @@ void kmc_hip_split_reads_free(kmc_hip_ctx *ctx, kmc_hip_s1_plan *p)
 }
 
 /* ---- stage 1, one part of input text: host text -> host records + collector sums (the engine of kb_splitter_plugin.h) ----
- * NOT YET RUN ON A GPU (written after the round's GPU budget was spent). The launch sequence itself is kmc_amd/csrc/stage1_chain.h, which
+ * Had not met a real GPU when round 2 ended (written after the GPU budget was spent); runs on the CPU over the emulated HIP runtime of
+ * tests/hipemu (tests/test_hostlib_emulated.py). The launch sequence itself is kmc_amd/csrc/stage1_chain.h, which
  * runs inside the real KMC pipeline under the CPU emulation (oracle/_ref/kmc_emu_s1); what is new here is the backend below. */
 
 int kmc_hip_split_set_map(kmc_hip_ctx *ctx, int dev, const int32_t *sig_to_bin, uint32_t signature_len)

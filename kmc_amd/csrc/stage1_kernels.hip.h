@@ -1,7 +1,9 @@
 /*
- * kmc_amd/csrc/stage1_kernels.hip.h — FIRST kernels of KMC's STAGE 1 on gfx950 (groundwork, not yet a drop-in:
- * no FASTQ parsing, the signature map is an input; reachable through kmc_hip_split_reads_plan/_emit, which leave bins in HBM in the layout
- * kmc_hip_process_bins_device takes, and through the test hook kmc_hip_debug_split_reads). DESIGN.md §9.
+ * kmc_amd/csrc/stage1_kernels.hip.h — the kernels of KMC's STAGE 1 on gfx950: text of a FASTA/FASTQ part ->
+ * codes -> minimizer signatures -> super-k-mers -> bin records + the collector's sums. Reachable through kmc_hip_split_part (one part, host
+ * text -> host records: the engine of the stage-1 worker plug-in), kmc_hip_split_reads_plan/_emit (codes in HBM -> bins in HBM in the layout
+ * kmc_hip_process_bins_device takes) and the test hook kmc_hip_debug_split_reads. The signature -> bin map is an input (stage 0 stays the
+ * reference's). GPU-validated: signatures, cut, bin totals / layout / emit; under emulation only so far: text -> codes, record check, k+x sums.
  *
  * What the reference does (kmc_core/splitter.cpp:557-672, CSplitter::ProcessReads) is a sequential scan per read with a two-variable state
  * (current signature, its position). Its RESULT has a data-parallel description, which oracle/stage1_oracle.c's line-by-line restatement

@@ -1,7 +1,8 @@
 /*
  * kmc_amd/host/hip_split_loader.cpp — the HIP split engine of the stage-1 worker (kb_splitter_plugin.h): kmc_hip_split_part of
- * include/kmc_hip.h through the library hip_loader.cpp already loaded. NOT YET RUN ON A GPU: the launch sequence behind
- * kmc_hip_split_part is proven under emulation inside the reference pipeline (oracle/_ref/kmc_emu_s1), this glue is compile-checked only.
+ * include/kmc_hip.h through the library hip_loader.cpp already loaded. Had not met a real GPU when round 2 ended; proven on the
+ * CPU twice: bound to a mock of the library and to the library's own source over an emulated HIP runtime (tests/test_stage1_plugin.py,
+ * tests/test_hostlib_emulated.py).
  * No CPU fallback: without the library or a GPU the engine reports the error and the worker raises it.
  */
 #include <dlfcn.h>

@@ -7,8 +7,9 @@
  * and pushes those to the storer exactly as the collectors would.
  *   - oracle engine: oracle/stage1_oracle.c (TEST ONLY: oracle/oracle_engine_s1.h -> oracle/_ref/kmc_oracle_s1; pins the worker's protocol
  *     and the oracle's parser and k+x-mer bookkeeping to the reference: the database must be byte-identical)
- *   - HIP engine   : not written yet (kmc_hip_split_reads_* produce the records on the device; the text -> codes step and the
- *     k+x-mer sums are the missing kernels)
+ *   - emulated engine: the stage-1 kernels under the CPU emulation (TEST ONLY: tests/hipemu/emu_split_engine.cpp -> oracle/_ref/kmc_emu_s1)
+ *   - HIP engine   : kmc_hip_split_part of include/kmc_hip.h through hip_split_loader.cpp -> oracle/_ref/kmc_hip_s1 (proven on the
+ *     CPU over an emulated HIP runtime; its first run on a GPU is the round-end bench / xfail-marked test of round 2)
  */
 #ifndef KMC_AMD_SPLIT_ENGINE_H
 #define KMC_AMD_SPLIT_ENGINE_H
