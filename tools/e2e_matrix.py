@@ -39,7 +39,13 @@ with tempfile.TemporaryDirectory(dir=base) as td:
             ("kmc_hip", ["-t128", "-m128", "-sr16", "-r"], {}),
             ("kmc_hip", ["-t128", "-m16", "-sr16"], {}),
             ("kmc_hip_sr", ["-t128", "-m128", "-sr16"], {}),
-            ("kmc", ["-t128", "-m128", "-r"], {})]
+            ("kmc", ["-t128", "-m128", "-r"], {}),
+            # indices 15..19: stage 1 on the GPU too (kmc_hip_s1)
+            ("kmc_hip_s1", ["-t32", "-m128", "-sr16"], {}),
+            ("kmc_hip_s1", ["-t128", "-m128", "-sr16"], {}),
+            ("kmc_hip_s1", ["-t128", "-m128", "-sr16", "-sp16"], {}),
+            ("kmc_hip_s1", ["-t128", "-m128", "-sr16", "-sp32", "-sf8"], {}),
+            ("kmc_hip_s1", ["-t32", "-m128", "-sr16"], {"KMC_HIP_SPLITTER_REF": "1"})]
     if len(sys.argv) > 4:  # a subset of the runs, by index
         runs = [runs[int(i)] for i in sys.argv[4].split(",")]
     for exe, flags, env in runs:

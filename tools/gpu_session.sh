@@ -13,6 +13,7 @@ for step in "$@"; do
     bench)   timeout 1200 python bench.py --cache /dev/shm/kmccache > $OUT/bench.json 2> $OUT/bench.err; tail -c 600 $OUT/bench.err ;;
     benchq)  timeout 900 python bench.py --no-cpu-baseline --no-secondary > $OUT/benchq.json 2> $OUT/benchq.err; tail -c 300 $OUT/benchq.err ;;
     e2e)     timeout 900 python tools/e2e_matrix.py > $OUT/e2e_matrix.jsonl 2> $OUT/e2e_matrix.err ;;
+    e2es1)   timeout 600 python tools/e2e_matrix.py 13300000 66000000 27 2,3,15,16,17,18,19 > $OUT/e2e_stage1.jsonl 2> $OUT/e2e_stage1.err; python tools/pj.py $OUT/e2e_stage1.jsonl 2>/dev/null | cut -c1-400 ;;
     e2eq)    timeout 600 python tools/e2e_matrix.py 13300000 66000000 27 3,3,6 > $OUT/e2e_quick.jsonl 2> $OUT/e2e_quick.err ;;
     streams:*) n=${step#streams:}; timeout 900 python bench.py --cache /dev/shm/kmccache --streams $n --no-cpu-baseline --no-secondary --no-host-boundary --no-digest --steps 3 > $OUT/c3_streams$n.json 2> $OUT/c3_streams$n.err ;;
     small)   timeout 600 python bench.py --leg custom --reads 2000000 --genome 10000000 --bins 512 --steps 5 --warmup 1 --no-digest > $OUT/bins512small.json 2> $OUT/bins512small.err ;;
