@@ -43,7 +43,7 @@ with tempfile.TemporaryDirectory(dir=base) as td:
             # indices 15..19: stage 1 on the GPU too (kmc_hip_s1)
             ("kmc_hip_s1", ["-t32", "-m128", "-sr16"], {}),
             ("kmc_hip_s1", ["-t128", "-m128", "-sr16"], {}),
-            ("kmc_hip_s1", ["-t128", "-m128", "-sr16", "-sp16"], {}),
+            ("kmc_hip_s1", ["-t128", "-m128", "-sr16", "-sp16", "-sf4"], {}),
             ("kmc_hip_s1", ["-t128", "-m128", "-sr16", "-sp32", "-sf8"], {}),
             ("kmc_hip_s1", ["-t32", "-m128", "-sr16"], {"KMC_HIP_SPLITTER_REF": "1"})]
     if len(sys.argv) > 4:  # a subset of the runs, by index
