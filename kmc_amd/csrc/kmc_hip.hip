@@ -788,6 +788,9 @@ int debug_compact_t(Slot &s, const DevParams &P, u64 n, u64 out_capacity, u64 lu
 /* ================================================================================================ C-ABI */
 
 /* stage 1, one part of text: the backend of kmc_amd/csrc/stage1_chain.h on a HIP stream (used by kmc_hip_split_part below) */
+extern "C" {
+static int sort_records_device_locked(Slot &s, void *d_recs, void *d_tmp, uint64_t n, uint32_t words, uint32_t key_bytes, void **d_result); /* defined below */
+}
 namespace {
 struct S1BackendFailure {
 	hipError_t e;
@@ -798,6 +801,7 @@ struct S1BackendFailure {
  * allocation, freed when the call ends. */
 struct S1HipBackend {
 	hipStream_t stream;
+	Slot *slot = nullptr; /* held by the caller: its stage-2 work areas are free for the sort of sort_by_low16 */
 	DBuf *arena = nullptr;
 	size_t used = 0;
 	std::vector<void *> extra;
@@ -835,6 +839,21 @@ struct S1HipBackend {
 		if (e != hipSuccess)
 			throw S1BackendFailure{e, "device to host copy"};
 		return true;
+	}
+	void h2d(void *dst, const void *src, size_t bytes)
+	{
+		hipError_t e = hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, stream);
+		if (e == hipSuccess)
+			e = hipStreamSynchronize(stream); /* the source may be reused */
+		if (e != hipSuccess)
+			throw S1BackendFailure{e, "host to device copy"};
+	}
+	u64 *sort_by_low16(u64 *keys, u64 *tmp, u64 n)
+	{
+		void *res = keys;
+		if (n > 1 && sort_records_device_locked(*slot, keys, tmp, n, 1, 2, &res) != 0)
+			throw S1BackendFailure{hipGetLastError(), "sort of the super-k-mer keys"};
+		return (u64 *)res;
 	}
 	void release()
 	{
@@ -1732,6 +1751,7 @@ int kmc_hip_split_part(kmc_hip_ctx *ctx, int dev, int slot, const kmc_hip_split_
 		return rc;
 	S1HipBackend be;
 	be.stream = s.stream;
+	be.slot = &s;
 	be.arena = &d.s1_arena[slot];
 	S1PartParams sp;
 	sp.k = p->kmer_len;
@@ -1742,6 +1762,7 @@ int kmc_hip_split_part(kmc_hip_ctx *ctx, int dev, int slot, const kmc_hip_split_
 	sp.lines_per_record = p->file_type == 1 ? 4u : 2u;
 	sp.line_cap = p->line_cap;
 	sp.d_sig_to_bin = d.d_sig_map;
+	sp.sorted_emit = getenv("KMC_HIP_S1_SORTED_EMIT") != nullptr; /* the alternative emit (stage1_kernels.hip.h): to be measured before it becomes the default */
 	S1PartResult R;
 	try {
 		uint8_t *d_text = (uint8_t *)be.alloc(size + 16);

@@ -11,7 +11,10 @@
  *   void *alloc(size_t bytes)                  zeroed device memory, owned by the backend until release()
  *   void  zero(void *p, size_t bytes)          (stream-ordered)
  *   bool  d2h(void *dst, const void *src, size_t bytes)   copies and waits for everything launched before; false = device failure
+ *   void  h2d(void *dst, const void *src, size_t bytes)   (the source may be reused when it returns)
  *   S1_LAUNCH(B, be, kernel, grid, block, args...)         launch `kernel` (a macro per backend: the emulator calls kernels as functions)
+ *   u64  *sort_by_low16(u64 *keys, u64 *tmp, u64 n)         stable sort of 8-byte records by their two low bytes; returns where the result is
+ *                                                           (the HIP backend runs the library's own radix passes, test backends sort on the host)
  */
 #ifndef KMC_AMD_STAGE1_CHAIN_H
 #define KMC_AMD_STAGE1_CHAIN_H
@@ -25,6 +28,7 @@ struct S1PartParams {
 	u64 line_cap;                                             /* mem_part_pmm_reads */
 	const int *d_sig_to_bin;                                  /* device: 4^m + 1 entries */
 	u64 sk_guess_div = 8;                                     /* first guess of the number of super-k-mers: symbols / this + 4096 */
+	bool sorted_emit = false;                                 /* records through a sort by bin (k_s1_emit_sorted) instead of k_s1_emit: bins in read order */
 };
 struct S1PartResult {
 	const uint8_t *d_recs = nullptr; /* device: bin b's records at d_recs + bin_off[b], bin_bytes[b] of them */
@@ -131,9 +135,27 @@ template <class B> int s1_split_part(B &be, const uint8_t *d_text, u64 size, boo
 	uint8_t *d_recs = (uint8_t *)be.alloc(recs_bytes + 16);
 	u64 *d_packs = (u64 *)be.alloc((n_packs + 1) * 8);
 	S1_LAUNCH(B, be, k_s1_bin_layout, dim3(1), dim3(256), (const u64 *)d_tot, nb, d_lay, d_lay + nb + 1, d_lay + 2 * nb + 2, d_packs);
-	if (sk_tiles)
+	if (sk_tiles && !P.sorted_emit)
 		S1_LAUNCH(B, be, k_s1_emit, dim3(sk_tiles), dim3(256), (const int8_t *)d_codes, (const u64 *)d_pos, (const u32 *)d_len, (const u32 *)d_sig, n_sk, P.k, P.d_sig_to_bin, nb,
 		          (const u64 *)d_lay, (const u64 *)(d_lay + nb + 1), d_lay + 2 * nb + 2, d_recs, d_packs);
+	if (sk_tiles && P.sorted_emit) {
+		/* bytes of all bins before each bin, from the sums already on the device */
+		std::vector<u64> cum(nb + 1, 0), bytes_now(nb);
+		if (!be.d2h(bytes_now.data(), d_tot, (size_t)nb * 8))
+			return S1_CHAIN_BACKEND_FAILURE;
+		for (u32 b = 0; b < nb; ++b)
+			cum[b + 1] = cum[b] + bytes_now[b];
+		u64 *d_cum = (u64 *)be.alloc((size_t)(nb + 1) * 8);
+		be.h2d(d_cum, cum.data(), (size_t)(nb + 1) * 8);
+		u64 *d_keys = (u64 *)be.alloc(n_sk * 8), *d_ktmp = (u64 *)be.alloc(n_sk * 8);
+		S1_LAUNCH(B, be, k_s1_sort_keys, dim3((u32)((n_sk + 255) / 256)), dim3(256), (const u32 *)d_sig, n_sk, P.d_sig_to_bin, nb, d_keys, d_err);
+		const u64 *d_sorted = be.sort_by_low16(d_keys, d_ktmp, n_sk);
+		const u32 et = (u32)((n_sk + S1_TILE - 1) / S1_TILE);
+		u64 *d_estat = (u64 *)be.alloc((size_t)et * 8);
+		be.zero(d_ticket, 4);
+		S1_LAUNCH(B, be, k_s1_emit_sorted, dim3(et), dim3(S1_BLOCK), d_sorted, n_sk, (const int8_t *)d_codes, (const u64 *)d_pos, (const u32 *)d_len, P.k, (const u64 *)d_lay,
+		          (const u64 *)(d_lay + nb + 1), (const u64 *)d_cum, d_estat, d_ticket, d_recs, d_packs, d_err);
+	}
 	std::vector<u64> tot(4 * (size_t)nb);
 	if (!be.d2h(tot.data(), d_tot, tot.size() * 8) || !be.d2h(small, d_small, sizeof small))
 		return S1_CHAIN_BACKEND_FAILURE;

@@ -695,4 +695,98 @@ __global__ void __launch_bounds__(256) k_s1_bin_plus_x(const int8_t *__restrict_
 			atomicAdd(&bin_plus_x[b], (u64)s_px[b]);
 }
 
+/* ------------------------------------------------------------------------------------------------ emit through a sort (alternative to k_s1_emit)
+ * k_s1_emit claims output space with atomics: 512 partial-line write streams, ~2 records per bin and tile, 2.9 of the 6.1 ms of a 300 M symbol
+ * part (profiles/r02/s1_bench_v3_*). The alternative orders the super-k-mers by bin first — k_s1_sort_keys makes 8-byte records
+ * (index << 16) | bin, the EXISTING k_onesweep sorts them by their two low bytes (stable: a bin keeps read order, like the reference with one
+ * splitter thread) — and k_s1_emit_sorted gives every record its final position from one exclusive scan of the record sizes in that order:
+ *   position = bin_base[bin] + (bytes of all records before it in sorted order) - (bytes of all bins before its bin),
+ * so consecutive threads write consecutive bytes. EMULATION-TESTED ONLY, not the default (S1PartParams::sorted_emit): to be measured first. */
+__global__ void __launch_bounds__(256) k_s1_sort_keys(const u32 *__restrict__ sk_sig, u64 n_sk, const int *__restrict__ sig_to_bin, u32 n_bins, u64 *__restrict__ keys, u32 *err)
+{
+	const u64 i = (u64)blockIdx.x * 256 + threadIdx.x;
+	if (i >= n_sk)
+		return;
+	const int b = sig_to_bin[sk_sig[i]];
+	if (b < 0 || (u32)b >= n_bins) {
+		atomicOr(err, KERR_CORRUPT);
+		keys[i] = (i << 16) | 0xFFFFu;
+	} else
+		keys[i] = (i << 16) | (u64)b;
+}
+
+/* sorted: the keys in bin-major order; cum_bytes[b] = bytes of the records of all bins < b (no alignment). status: one zeroed u64 per tile. */
+__global__ void __launch_bounds__(S1_BLOCK) k_s1_emit_sorted(const u64 *__restrict__ sorted, u64 n_sk, const int8_t *__restrict__ codes, const u64 *__restrict__ sk_pos,
+                                                              const u32 *__restrict__ sk_len, u32 k, const u64 *__restrict__ bin_base, const u64 *__restrict__ pack_base,
+                                                              const u64 *__restrict__ cum_bytes, u64 *status, u32 *ticket_ctr, uint8_t *__restrict__ out,
+                                                              u64 *__restrict__ pack_start, u32 *err)
+{
+	__shared__ u32 s_tmp[S1_BLOCK / 64 + 1];
+	__shared__ u64 s_carry;
+	__shared__ u32 s_ticket;
+	const u32 tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+	if (tid == 0)
+		s_ticket = atomicAdd(ticket_ctr, 1u);
+	__syncthreads();
+	const u32 tile = s_ticket;
+	const u32 num_tiles = (u32)((n_sk + S1_TILE - 1) / S1_TILE);
+	if (tile >= num_tiles)
+		return;
+	const u64 j0 = (u64)tile * S1_TILE + (u64)tid * S1_PER; /* this thread's S1_PER consecutive records of the sorted order */
+	u64 idx[S1_PER];
+	u32 bin[S1_PER], len[S1_PER], bytes[S1_PER], mine = 0;
+#pragma unroll
+	for (int t = 0; t < S1_PER; ++t) {
+		bytes[t] = 0;
+		if (j0 + t < n_sk) {
+			const u64 key = sorted[j0 + t];
+			idx[t] = key >> 16;
+			bin[t] = (u32)(key & 0xFFFFu);
+			len[t] = sk_len[idx[t]];
+			bytes[t] = 1u + (len[t] + 3u) / 4u;
+			mine += bytes[t];
+		}
+	}
+	u32 tile_bytes;
+	const u32 before = block_excl_sum<S1_BLOCK / 64, u32>(mine, s_tmp, tile_bytes);
+	if (wave == 0) {
+		const u64 excl = lookback64(status, tile, (u64)tile_bytes, lane, err, KERR_WATCHDOG);
+		if (lane == 0)
+			s_carry = excl;
+	}
+	__syncthreads();
+	u64 g = s_carry + before; /* bytes of all records before this one in sorted order */
+#pragma unroll
+	for (int t = 0; t < S1_PER; ++t) {
+		if (!bytes[t])
+			continue;
+		const u32 b = bin[t];
+		const u64 rel = g - cum_bytes[b]; /* offset inside the bin's stream */
+		g += bytes[t];
+		const u64 m = (rel + S1_PACK_BYTES - 1) / S1_PACK_BYTES;
+		if (m * S1_PACK_BYTES < rel + bytes[t]) /* the record that covers the m-th multiple of the pack size starts pack m */
+			pack_start[pack_base[b] + m] = rel;
+		uint8_t *dst = out + bin_base[b] + rel;
+		const int8_t *src = codes + sk_pos[idx[t]];
+		dst[0] = (uint8_t)(len[t] - k);
+		u32 q = 0;
+		for (; 4u * q + 8u <= len[t]; q += 2) {
+			u64 w8;
+			__builtin_memcpy(&w8, src + 4u * q, 8);
+			const u32 lo = (u32)w8, hi = (u32)(w8 >> 32);
+			dst[1 + q] = (uint8_t)(((lo & 3u) << 6) | (((lo >> 8) & 3u) << 4) | (((lo >> 16) & 3u) << 2) | ((lo >> 24) & 3u));
+			dst[2 + q] = (uint8_t)(((hi & 3u) << 6) | (((hi >> 8) & 3u) << 4) | (((hi >> 16) & 3u) << 2) | ((hi >> 24) & 3u));
+		}
+		for (; q < (len[t] + 3u) / 4u; ++q) {
+			u32 v = 0;
+#pragma unroll
+			for (u32 u = 0; u < 4; ++u) {
+				const u32 p = 4 * q + u;
+				v = (v << 2) | (p < len[t] ? (u32)(src[p] & 3) : 0u);
+			}
+			dst[1 + q] = (uint8_t)v;
+		}
+	}
+}
+
 #endif

@@ -120,6 +120,8 @@ def lib(geometry="small"):
         L.emu_s1_scatter.restype = C.c_int
         L.emu_s1_scatter.argtypes = [C.c_void_p] * 4 + [C.c_uint64, C.c_uint32, C.c_void_p, C.c_uint32] + [C.c_void_p] * 4 + [C.c_uint64, C.c_void_p, C.c_uint64]
         L.emu_s1_geometry.argtypes = [C.c_void_p]
+        L.emu_s1_scatter_sorted.restype = C.c_int
+        L.emu_s1_scatter_sorted.argtypes = L.emu_s1_scatter.argtypes
         L.emu_s1_text_to_codes.restype = C.c_int
         L.emu_s1_text_to_codes.argtypes = [C.c_void_p, C.c_uint64, C.c_uint32, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p]
         L.emu_s1_plus_x.restype = None
@@ -231,7 +233,7 @@ def s1_geometry(geometry="small"):
     return tuple(g)
 
 
-def s1_scatter(codes, sk_pos, sk_len, sk_sig, k: int, sig_to_bin: np.ndarray, n_bins: int, geometry="small"):
+def s1_scatter(codes, sk_pos, sk_len, sk_sig, k: int, sig_to_bin: np.ndarray, n_bins: int, geometry="small", through_sort=False):
     """stage-1 bin scatter on the super-k-mer list of s1_split. Returns dict(err, base uint64[n_bins+1], totals uint64[3][n_bins] = bytes /
     super-k-mers / k-mers, pack_base uint64[n_bins+1], out bytes, pack_start uint64[...])."""
     codes = np.ascontiguousarray(codes, dtype=np.int8)
@@ -249,7 +251,8 @@ def s1_scatter(codes, sk_pos, sk_len, sk_sig, k: int, sig_to_bin: np.ndarray, n_
     out = np.full(cap, 0xEE, dtype=np.uint8)
     pcap = payload // pack_bytes + 2 * n_bins + 2
     pack_start = np.full(pcap, 0xFFFFFFFFFFFFFFFF, dtype=np.uint64)
-    err = lib(geometry).emu_s1_scatter(codes.ctypes.data, sk_pos.ctypes.data, sk_len.ctypes.data, sk_sig.ctypes.data, n, k, m.ctypes.data, n_bins, base.ctypes.data,
+    fn = lib(geometry).emu_s1_scatter_sorted if through_sort else lib(geometry).emu_s1_scatter
+    err = fn(codes.ctypes.data, sk_pos.ctypes.data, sk_len.ctypes.data, sk_sig.ctypes.data, n, k, m.ctypes.data, n_bins, base.ctypes.data,
                                        pbase.ctypes.data, tot.ctypes.data, out.ctypes.data, cap, pack_start.ctypes.data, pcap)
     return dict(err=err, base=base, pack_base=pbase, totals=tot, out=out[: int(base[n_bins])].copy(), pack_start=pack_start[: int(pbase[n_bins])].copy())
 

@@ -488,4 +488,36 @@ EMU_API void emu_s1_plus_x(const int8_t *codes, const u64 *sk_pos, const u32 *sk
 	if (tiles)
 		hipemu::launch(dim3(tiles), dim3(256), 0, [&] { k_s1_bin_plus_x(codes, sk_pos, sk_len, sk_sig, n_sk, k, max_x, both_strands, sig_to_bin, n_bins, bin_plus_x); });
 }
+
+/* the alternative emit: keys -> (stable sort by bin, on the host here: the radix passes have their own tests) -> k_s1_emit_sorted */
+EMU_API int emu_s1_scatter_sorted(const int8_t *codes, const u64 *sk_pos, const u32 *sk_len, const u32 *sk_sig, u64 n_sk, unsigned k, const int *sig_to_bin, unsigned n_bins,
+                                  u64 *bin_base, u64 *pack_base, u64 *totals, uint8_t *out, u64 out_cap, u64 *pack_start, u64 pack_cap)
+{
+	u32 err = 0, ticket = 0;
+	std::vector<u64> cursor(n_bins, 0), cum(n_bins + 1, 0), keys(n_sk + 1, 0);
+	for (u64 i = 0; i < 3ull * n_bins; ++i)
+		totals[i] = 0;
+	const u32 tiles = (u32)((n_sk + S1_SK_TILE - 1) / S1_SK_TILE);
+	if (tiles)
+		hipemu::launch(dim3(tiles), dim3(256), 0,
+		               [&] { k_s1_bin_totals(sk_len, sk_sig, n_sk, k, sig_to_bin, n_bins, totals, totals + n_bins, totals + 2 * n_bins, &err); });
+	if (err)
+		return (int)err;
+	hipemu::launch(dim3(1), dim3(256), 0, [&] { k_s1_bin_layout(totals, n_bins, bin_base, pack_base, cursor.data(), (u64 *)nullptr); });
+	if (bin_base[n_bins] > out_cap || pack_base[n_bins] > pack_cap)
+		return -1;
+	hipemu::launch(dim3(1), dim3(256), 0, [&] { k_s1_bin_layout(totals, n_bins, bin_base, pack_base, cursor.data(), pack_start); });
+	if (!n_sk)
+		return 0;
+	for (unsigned b = 0; b < n_bins; ++b)
+		cum[b + 1] = cum[b] + totals[b];
+	hipemu::launch(dim3((u32)((n_sk + 255) / 256)), dim3(256), 0, [&] { k_s1_sort_keys(sk_sig, n_sk, sig_to_bin, n_bins, keys.data(), &err); });
+	std::stable_sort(keys.begin(), keys.begin() + n_sk, [](u64 a, u64 b) { return (a & 0xFFFFu) < (b & 0xFFFFu); });
+	const u32 et = (u32)((n_sk + S1_TILE - 1) / S1_TILE);
+	std::vector<u64> status(et, 0);
+	hipemu::launch(dim3(et), dim3(S1_BLOCK), 0, [&] {
+		k_s1_emit_sorted(keys.data(), n_sk, codes, sk_pos, sk_len, k, bin_base, pack_base, cum.data(), status.data(), &ticket, out, pack_start, &err);
+	});
+	return (int)err;
+}
 }

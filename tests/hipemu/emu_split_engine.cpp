@@ -8,6 +8,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdlib>
+#include <algorithm>
 #include <cstring>
 #include <memory>
 #include <mutex>
@@ -29,6 +30,12 @@ struct EmuBackend {
 	{
 		memcpy(dst, src, bytes);
 		return true;
+	}
+	void h2d(void *dst, const void *src, size_t bytes) { memcpy(dst, src, bytes); }
+	u64 *sort_by_low16(u64 *keys, u64 *, u64 n) /* the radix passes themselves are tested elsewhere (tests/test_kernels_emulated.py) */
+	{
+		std::stable_sort(keys, keys + n, [](u64 a, u64 b) { return (a & 0xFFFFu) < (b & 0xFFFFu); });
+		return keys;
 	}
 	void release() { blocks.clear(); }
 };
@@ -61,6 +68,7 @@ struct EmuSplitEngine : KmcSplitEngine {
 		sp.lines_per_record = P.file_type == 1 ? 4u : 2u;
 		sp.line_cap = P.line_cap;
 		sp.d_sig_to_bin = P.sig_to_bin;
+		sp.sorted_emit = getenv("KMC_HIP_S1_SORTED_EMIT") != nullptr;
 		if (const char *g = getenv("KMC_EMU_SK_GUESS_DIV"))
 			sp.sk_guess_div = strtoull(g, nullptr, 10);
 		const int rc = s1_split_part(be, text, size, size && text[size - 1] == '\n', sp, R);

@@ -9,6 +9,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdlib>
+#include <algorithm>
 #include <cstring>
 #include <memory>
 #include <mutex>
@@ -30,6 +31,12 @@ struct MockBackend {
 	{
 		memcpy(dst, src, bytes);
 		return true;
+	}
+	void h2d(void *dst, const void *src, size_t bytes) { memcpy(dst, src, bytes); }
+	u64 *sort_by_low16(u64 *keys, u64 *, u64 n) /* the radix passes themselves are tested elsewhere (tests/test_kernels_emulated.py) */
+	{
+		std::stable_sort(keys, keys + n, [](u64 a, u64 b) { return (a & 0xFFFFu) < (b & 0xFFFFu); });
+		return keys;
 	}
 };
 #define S1_LAUNCH(B, be, kernel, grid, block, ...) hipemu::launch(grid, block, 0, [&] { kernel(__VA_ARGS__); })
@@ -134,6 +141,7 @@ MOCK_API int kmc_hip_split_part(kmc_hip_ctx *ctx, int dev, int slot, const kmc_h
 	sp.lines_per_record = p->file_type == 1 ? 4u : 2u;
 	sp.line_cap = p->line_cap;
 	sp.d_sig_to_bin = ctx->sig_map.data();
+	sp.sorted_emit = getenv("KMC_HIP_S1_SORTED_EMIT") != nullptr;
 	S1PartResult R;
 	const int rc = s1_split_part(be, text, size, size && text[size - 1] == '\n', sp, R);
 	if (rc == S1_CHAIN_UNCOVERED)

@@ -45,8 +45,11 @@ def _run(exe, flags, inp, tmp_path, tag, env=None):
     return md5, stats, r.stderr
 
 
+@pytest.mark.parametrize("sorted_emit", [False, True], ids=["emit", "emit-through-a-sort"])
 @pytest.mark.parametrize("flags", [["-k27", "-ci1"], ["-k55", "-b"]], ids=lambda f: "".join(f))
-def test_product_binary_over_the_emulated_host_library_writes_the_reference_database(flags, tmp_path):
+def test_product_binary_over_the_emulated_host_library_writes_the_reference_database(flags, sorted_emit, tmp_path):
+    """sorted_emit: KMC_HIP_S1_SORTED_EMIT=1 — the alternative emit of stage 1, whose sort is the library's own radix path (k_hist, k_onesweep) on the
+    super-k-mer keys"""
     if not os.path.exists(os.path.join(REF, "kmc_hip_s1")):
         pytest.skip("oracle/_ref/kmc_hip_s1 not built (needs /root/reference)")
     lib = emu.build_hostlib("small")
@@ -54,7 +57,10 @@ def test_product_binary_over_the_emulated_host_library_writes_the_reference_data
     synth.make_fastq(fq, seed=11, genome_len=30_000, n_reads=1_500, read_len=150)
     common = flags + ["-m2", "-sf1", "-n64"]
     want = _run("kmc", common + ["-sp1", "-sr1"], fq, tmp_path, "ref")
-    got = _run("kmc_hip_s1", common + ["-sp2", "-sr2"], fq, tmp_path, "emu", env={"KMC_HIP_LIB": lib, "KMC_HIP_VERBOSE": "1"})
+    env = {"KMC_HIP_LIB": lib, "KMC_HIP_VERBOSE": "1"}
+    if sorted_emit:
+        env["KMC_HIP_S1_SORTED_EMIT"] = "1"
+    got = _run("kmc_hip_s1", common + ["-sp2", "-sr2"], fq, tmp_path, "emu", env=env)
     assert got[:2] == want[:2]
     assert "parts through the engine" in got[2] and "[kmc_hip stage 2] 64 bins, 2 workers" in got[2]
 

@@ -267,3 +267,34 @@ def test_emulated_kxmer_sums_match_the_oracle(k, max_x, both):
     for p, l, s in zip(pos, ln, sg):
         want[smap[s]] += S1.kxmer_recs(codes[int(p):int(p) + int(l)], k, max_x, both)
     assert np.array_equal(got, want) and (want.sum() > 0) == (max_x > 0)
+
+
+@pytest.mark.parametrize("k,m,n_bins", [(27, 9, 64), (21, 7, 512), (55, 9, 2000), (14, 7, 3), (200, 9, 1)])
+def test_emulated_emit_through_a_sort_writes_bins_in_read_order(k, m, n_bins):
+    """k_s1_sort_keys + a stable sort by bin + k_s1_emit_sorted: every bin image is EXACTLY the oracle's — the super-k-mers of the bin's signatures in
+    read order, which is what the reference's splitter writes with one thread — not just the same multiset; pack boundaries as for k_s1_emit"""
+    rng = np.random.default_rng(k + n_bins)
+    reads = _reads(rng, k, 60, max(150, 2 * k))
+    need_bytes = 4 * emu.s1_geometry()[1] * n_bins if n_bins <= 3 else 0
+    while len(S1.split(reads, k, m)[0]) <= 1100 or S1.split(reads, k, m)[2].size < need_bytes:
+        reads += _reads(rng, k, 60, max(150, 2 * k))
+    codes = _stream(reads)
+    err, _, pos, ln, sg = emu.s1_split(codes, k, m)
+    assert err == 0
+    smap = _sig_map(m, n_bins, 7)
+    r = emu.s1_scatter(codes, pos, ln, sg, k, smap, n_bins, through_sort=True)
+    assert r["err"] == 0
+    w_sig, w_off, w_recs = S1.split(reads, k, m)
+    _, pack_bytes, align = emu.s1_geometry()
+    bins_of = smap[w_sig]
+    for b in range(n_bins):
+        idx = np.flatnonzero(bins_of == b)
+        want = np.concatenate([w_recs[int(w_off[i]):int(w_off[i + 1])] for i in idx]) if idx.size else np.zeros(0, dtype=np.uint8)
+        lo, size = int(r["base"][b]), int(r["totals"][0, b])
+        assert lo % align == 0 and size == want.size
+        assert np.array_equal(r["out"][lo:lo + size], want), b
+        ps = r["pack_start"][int(r["pack_base"][b]):int(r["pack_base"][b + 1])].astype(np.int64)
+        assert ps.size == (size + pack_bytes - 1) // pack_bytes + 1 and ps[-1] == size and (size == 0 or ps[0] == 0)
+        assert np.all(np.diff(ps) > 0) if size else ps.tolist() == [0]
+        starts = np.concatenate([[0], np.cumsum([int(w_off[i + 1] - w_off[i]) for i in idx])]) if idx.size else np.zeros(1, dtype=np.int64)
+        assert np.all(np.isin(ps, starts))

@@ -317,3 +317,19 @@ def test_product_binaries_over_a_mock_library_write_the_reference_database(exe, 
     assert got == want
     if exe == "kmc_hip_s1":
         assert _report_sum("parts through the engine") > 0 and _report_sum("bin pieces") > 0
+
+
+@needs_emu
+@pytest.mark.parametrize("fmt,flags", [("fq", ["-k27", "-ci1"]), ("fa", ["-k55", "-b"]), ("fq", ["-k21", "-n64"])], ids=lambda v: v if isinstance(v, str) else "".join(v))
+def test_emit_through_a_sort_gives_the_same_database_and_bins_in_read_order(fmt, flags, tmp_path):
+    """the alternative emit (k_s1_sort_keys -> sort by bin -> k_s1_emit_sorted, KMC_HIP_S1_SORTED_EMIT=1): same database, and — because the sort is
+    stable — every bin holds its super-k-mers in read order, i.e. the bin DESCRIPTORS and the bin images equal those of the reference's splitter
+    run with one thread (checked through the database and through the per-bin descriptors)"""
+    k = int(flags[0][2:])
+    path = str(tmp_path / ("in." + fmt))
+    with open(path, "wb") as f:
+        f.write(_small_text(fmt, b"\n", k))
+    common = flags + ["-m2", "-sf1", "-sr1"] + (["-fa"] if fmt == "fa" else [])
+    want = _run("kmc", common + ["-sp1"], path, tmp_path, "ref")
+    got = _run("kmc_emu_s1", common + ["-sp2"], path, tmp_path, "emu", env={"KMC_HIP_S1_SORTED_EMIT": "1", "KMC_HIP_VERBOSE": "1"})
+    assert got == want and _report_sum("parts through the engine") > 0

@@ -38,6 +38,7 @@ t=time.time(); s=capi.synth_bins(seed=2026, genome_len=1000000000, n_reads=20000
     trace)   KMC_HIP_LIB=kmc_amd/variants/libkmc_hip_trace.so timeout 300 python tools/trace_run.py $TAG > $OUT/trace_run.txt 2>&1; python tools/trace_report.py gpurun_out/trace_$TAG.npy > $OUT/trace_report.txt 2>&1; rm -f gpurun_out/trace_$TAG.npy ;;
     s1prof)  cd /tmp; timeout 120 rocprofv3 --kernel-trace --stats -f csv -d $OLDPWD/$OUT/s1prof -o kt -- python $OLDPWD/tools/s1_bench.py > $OLDPWD/$OUT/s1_bench.json 2> $OLDPWD/$OUT/s1_bench.err; cd $OLDPWD; cat $OUT/s1_bench.json; tail -2 $OUT/s1_bench.err; find $OUT/s1prof -name "*kernel_trace.csv" -delete ;;
     s1part)  timeout 120 python tools/s1_part_bench.py > $OUT/s1_part_bench.json 2> $OUT/s1_part_bench.err; cat $OUT/s1_part_bench.json; tail -2 $OUT/s1_part_bench.err ;;
+    s1parts) KMC_HIP_S1_SORTED_EMIT=1 timeout 120 python tools/s1_part_bench.py > $OUT/s1_part_bench_sorted.json 2> $OUT/s1_part_bench_sorted.err; cat $OUT/s1_part_bench_sorted.json; tail -2 $OUT/s1_part_bench_sorted.err ;;
     s1)      timeout 120 python tools/s1_bench.py > $OUT/s1_bench_plain.json 2> $OUT/s1_bench_plain.err; cat $OUT/s1_bench_plain.json; tail -2 $OUT/s1_bench_plain.err ;;
     *) echo "unknown step $step" ;;
   esac
