@@ -129,8 +129,13 @@ template <class B> int s1_split_part(B &be, const uint8_t *d_text, u64 size, boo
 	}
 	S1_LAUNCH(B, be, k_s1_bin_layout, dim3(1), dim3(256), (const u64 *)d_tot, nb, d_lay, d_lay + nb + 1, d_lay + 2 * nb + 2, (u64 *)nullptr);
 	std::vector<u64> lay(2 * (size_t)nb + 2);
-	if (!be.d2h(lay.data(), d_lay, lay.size() * 8))
+	if (!be.d2h(lay.data(), d_lay, lay.size() * 8) || !be.d2h(small, d_small, sizeof small))
 		return S1_CHAIN_BACKEND_FAILURE;
+	err = (u32)(small[3] >> 32);
+	if (err) { /* a signature the map does not know (KERR_CORRUPT from k_s1_bin_totals): nothing is emitted */
+		R.device_error = err;
+		return S1_CHAIN_DEVICE_ERROR;
+	}
 	const u64 recs_bytes = lay[nb], n_packs = lay[2 * (size_t)nb + 1];
 	uint8_t *d_recs = (uint8_t *)be.alloc(recs_bytes + 16);
 	u64 *d_packs = (u64 *)be.alloc((n_packs + 1) * 8);
@@ -153,7 +158,7 @@ template <class B> int s1_split_part(B &be, const uint8_t *d_text, u64 size, boo
 		const u32 et = (u32)((n_sk + S1_TILE - 1) / S1_TILE);
 		u64 *d_estat = (u64 *)be.alloc((size_t)et * 8);
 		be.zero(d_ticket, 4);
-		S1_LAUNCH(B, be, k_s1_emit_sorted, dim3(et), dim3(S1_BLOCK), d_sorted, n_sk, (const int8_t *)d_codes, (const u64 *)d_pos, (const u32 *)d_len, P.k, (const u64 *)d_lay,
+		S1_LAUNCH(B, be, k_s1_emit_sorted, dim3(et), dim3(S1_BLOCK), d_sorted, n_sk, (const int8_t *)d_codes, (const u64 *)d_pos, (const u32 *)d_len, P.k, nb, (const u64 *)d_lay,
 		          (const u64 *)(d_lay + nb + 1), (const u64 *)d_cum, d_estat, d_ticket, d_recs, d_packs, d_err);
 	}
 	std::vector<u64> tot(4 * (size_t)nb);

@@ -717,9 +717,9 @@ __global__ void __launch_bounds__(256) k_s1_sort_keys(const u32 *__restrict__ sk
 
 /* sorted: the keys in bin-major order; cum_bytes[b] = bytes of the records of all bins < b (no alignment). status: one zeroed u64 per tile. */
 __global__ void __launch_bounds__(S1_BLOCK) k_s1_emit_sorted(const u64 *__restrict__ sorted, u64 n_sk, const int8_t *__restrict__ codes, const u64 *__restrict__ sk_pos,
-                                                              const u32 *__restrict__ sk_len, u32 k, const u64 *__restrict__ bin_base, const u64 *__restrict__ pack_base,
-                                                              const u64 *__restrict__ cum_bytes, u64 *status, u32 *ticket_ctr, uint8_t *__restrict__ out,
-                                                              u64 *__restrict__ pack_start, u32 *err)
+                                                              const u32 *__restrict__ sk_len, u32 k, u32 n_bins, const u64 *__restrict__ bin_base,
+                                                              const u64 *__restrict__ pack_base, const u64 *__restrict__ cum_bytes, u64 *status, u32 *ticket_ctr,
+                                                              uint8_t *__restrict__ out, u64 *__restrict__ pack_start, u32 *err)
 {
 	__shared__ u32 s_tmp[S1_BLOCK / 64 + 1];
 	__shared__ u64 s_carry;
@@ -742,6 +742,10 @@ __global__ void __launch_bounds__(S1_BLOCK) k_s1_emit_sorted(const u64 *__restri
 			const u64 key = sorted[j0 + t];
 			idx[t] = key >> 16;
 			bin[t] = (u32)(key & 0xFFFFu);
+			if (bin[t] >= n_bins) { /* k_s1_sort_keys marked a signature without a bin (and raised the error) */
+				atomicOr(err, KERR_CORRUPT);
+				continue;
+			}
 			len[t] = sk_len[idx[t]];
 			bytes[t] = 1u + (len[t] + 3u) / 4u;
 			mine += bytes[t];

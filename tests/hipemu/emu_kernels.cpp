@@ -516,7 +516,7 @@ EMU_API int emu_s1_scatter_sorted(const int8_t *codes, const u64 *sk_pos, const 
 	const u32 et = (u32)((n_sk + S1_TILE - 1) / S1_TILE);
 	std::vector<u64> status(et, 0);
 	hipemu::launch(dim3(et), dim3(S1_BLOCK), 0, [&] {
-		k_s1_emit_sorted(keys.data(), n_sk, codes, sk_pos, sk_len, k, bin_base, pack_base, cum.data(), status.data(), &ticket, out, pack_start, &err);
+		k_s1_emit_sorted(keys.data(), n_sk, codes, sk_pos, sk_len, k, n_bins, bin_base, pack_base, cum.data(), status.data(), &ticket, out, pack_start, &err);
 	});
 	return (int)err;
 }
