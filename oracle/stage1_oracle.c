@@ -266,20 +266,15 @@ typedef struct {
 	uint32_t curr_read_len;
 } oracle_s1_part;
 
-static const int8_t *s1_codes(void) /* splitter.cpp:41-47 */
+static int8_t s1_code(uint8_t c) /* splitter.cpp:41-47; a function, not a lazily filled table: several splitter threads parse at once */
 {
-	static int8_t codes[256];
-	static int init = 0;
-	if (!init) {
-		for (int i = 0; i < 256; ++i)
-			codes[i] = -1;
-		codes['A'] = codes['a'] = 0;
-		codes['C'] = codes['c'] = 1;
-		codes['G'] = codes['g'] = 2;
-		codes['T'] = codes['t'] = 3;
-		init = 1;
+	switch (c) {
+	case 'A': case 'a': return 0;
+	case 'C': case 'c': return 1;
+	case 'G': case 'g': return 2;
+	case 'T': case 't': return 3;
+	default: return -1;
 	}
-	return codes;
 }
 
 static int s1_is_eol(uint8_t c) { return c == '\n' || c == '\r'; }
@@ -287,7 +282,6 @@ static int s1_is_eol(uint8_t c) { return c == '\n' || c == '\r'; }
 static int s1_get_seq(oracle_s1_part *st, int file_type, uint32_t kmer_len, uint64_t line_cap, int8_t *seq, uint32_t *seq_size)
 {
 	const uint8_t *part = st->part;
-	const int8_t *codes = s1_codes();
 	if (st->part_pos >= st->part_size) /* :94 */
 		return 0;
 	uint8_t c = 0;
@@ -316,7 +310,7 @@ static int s1_get_seq(oracle_s1_part *st, int file_type, uint32_t kmer_len, uint
 		c = part[st->part_pos++];
 		if (s1_is_eol(c))
 			break;
-		seq[pos++] = codes[c];
+		seq[pos++] = s1_code(c);
 	}
 	if (file_type == 0) { /* FASTA: the part may end with the sequence, :134-137 / :160-163 */
 		*seq_size = pos;

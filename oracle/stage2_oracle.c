@@ -165,7 +165,7 @@ int oracle_expand(const oracle_params *p, const uint8_t *data, uint64_t size, ui
  * Contract of SortFunction (raduls.h:19-20, kb_sorter.h:757-780): ascending by the record's
  * unsigned value. The reference's algorithm (MSD radix, raduls_impl.h:546-754) is not
  * observable in the result because equal keys are bit-identical records. */
-static uint32_t g_cmp_words; /* single-threaded oracle; qsort has no context argument */
+static _Thread_local uint32_t g_cmp_words; /* per thread: several workers of the oracle-engine binaries sort at once */ /* qsort has no context argument */
 static int cmp_recs(const void *a, const void *b)
 {
 	const uint64_t *x = (const uint64_t *)a, *y = (const uint64_t *)b;
