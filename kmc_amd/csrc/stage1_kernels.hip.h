@@ -545,9 +545,19 @@ __global__ void __launch_bounds__(S1_BLOCK) k_s1_text_to_codes(const uint8_t *__
 		return;
 	const u64 p0 = (u64)tile * S1_TXT_TILE + (u64)tid * S1_TXT_PER;
 	uint8_t c[S1_TXT_PER + 1]; /* the thread's bytes and the one after them ('\r' looks ahead) */
+	static_assert(S1_TXT_PER == 16, "one 16-byte load per thread");
+	if (p0 + S1_TXT_PER <= n) {
+		u32 w[4];
+		__builtin_memcpy(w, text + p0, 16); /* one 16-byte load instead of sixteen byte loads */
 #pragma unroll
-	for (int j = 0; j <= S1_TXT_PER; ++j)
-		c[j] = p0 + j < n ? text[p0 + j] : (uint8_t)0;
+		for (int j = 0; j < S1_TXT_PER; ++j)
+			c[j] = (uint8_t)(w[j >> 2] >> (8 * (j & 3)));
+	} else {
+#pragma unroll
+		for (int j = 0; j < S1_TXT_PER; ++j)
+			c[j] = p0 + j < n ? text[p0 + j] : (uint8_t)0;
+	}
+	c[S1_TXT_PER] = p0 + S1_TXT_PER < n ? text[p0 + S1_TXT_PER] : (uint8_t)0;
 	u32 my_nl = 0;
 #pragma unroll
 	for (int j = 0; j < S1_TXT_PER; ++j)
