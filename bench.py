@@ -469,6 +469,7 @@ def main():
         dist.barrier()
     dt = time.perf_counter() - t0
     n_launch, sc_ms, sc_recs = ctx.scatter_totals(reset=True)
+    ls = ctx.local_sort_totals(reset=True)
     if dist:
         tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -533,6 +534,10 @@ def main():
                          "note": "consecutive bins of a stream share one sort (bins_per_sort: the bin's number inside the group rides in the spare bits of the "
                                  "top radix digit), so a launch covers that many bins; every 8th group of a stream carries the event pairs (an event costs "
                                  "stream time); big bins run on one stream, so launches do not overlap and the event durations are the kernel's own"},
+            "local_sort": {"kernel": "k_bucket_bounds + k_bucket_sort<%d> (the key bytes below the HBM passes, sorted inside LDS on bucket-aligned tiles)" % ((k + 31) // 32),
+                           "launches_timed": ls["launches"], "avg_launch_ms": ls["ms"] / max(ls["launches"], 1), "records_per_launch": ls["records"] / max(ls["launches"], 1),
+                           "GBs_read_plus_written": (2 * W * ls["records"]) / (ls["ms"] * 1e-3) / 1e9 if ls["launches"] else 0.0,
+                           "hybrid_groups": ls["hybrid_groups"], "redo_groups": ls["redo_groups"]},
             "phases_ms_last_bin_slot0": timings,
             "phases_note": "event intervals of the last timed GROUP of bins on stream slot 0 (bins_per_sort bins; one launch each of parse+index, expand, "
                            "the scatter passes, compaction + fold + gather)",

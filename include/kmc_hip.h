@@ -177,6 +177,12 @@ int kmc_hip_last_timings(kmc_hip_ctx *ctx, int dev, float ms[6]);
  * duration (HIP events around each launch, on the launch's own stream) and the records they moved — the roofline
  * input of bench.py. Waits for the device's streams. */
 int kmc_hip_scatter_totals(kmc_hip_ctx *ctx, int dev, int reset, uint64_t *n_launches, double *total_ms, uint64_t *total_records);
+/* The LDS half of the hybrid sort (k_bucket_bounds + k_bucket_sort, kmc_amd/csrc/bucket_sort.hip.h; replaces the small-bucket recursion and
+ * CSmallSort of raduls_impl.h:133-141,497-510 / small_sort.h:29-179): launches, summed duration (HIP events on the launch's stream) and records
+ * since the last reset; plus, process-wide, how many groups of bins took the hybrid sort and how many of them had to be sorted again with LSD
+ * passes over every byte because a bucket did not fit a tile. Any pointer may be NULL. Waits for the device's streams. */
+int kmc_hip_local_sort_totals(kmc_hip_ctx *ctx, int dev, int reset, uint64_t *n_launches, double *total_ms, uint64_t *total_records,
+                              uint64_t *n_hybrid_groups, uint64_t *n_redo_groups);
 /* Device memory helpers so non-HIP callers (ctypes tests, the C++ worker) need not link HIP themselves. */
 int kmc_hip_malloc(kmc_hip_ctx *ctx, int dev, uint64_t bytes, void **d_ptr);
 int kmc_hip_free(kmc_hip_ctx *ctx, int dev, void *d_ptr);

@@ -68,7 +68,7 @@ SYMBOLS = [
     "kmc_hip_sort_records", "kmc_hip_sort_records_into", "kmc_hip_sort_records_device",
     "kmc_hip_process_bin", "kmc_hip_process_bin_submit", "kmc_hip_process_bin_wait", "kmc_hip_process_bin_device",
     "kmc_hip_process_bins_device",
-    "kmc_hip_allreduce_stats", "kmc_hip_last_timings", "kmc_hip_scatter_totals",
+    "kmc_hip_allreduce_stats", "kmc_hip_last_timings", "kmc_hip_scatter_totals", "kmc_hip_local_sort_totals",
     "kmc_hip_malloc", "kmc_hip_free", "kmc_hip_memcpy_h2d", "kmc_hip_memcpy_d2h",
     "kmc_hip_host_register", "kmc_hip_host_unregister", "kmc_hip_host_alloc", "kmc_hip_host_free", "kmc_hip_synchronize",
     "kmc_hip_debug_expand", "kmc_hip_debug_compact", "kmc_hip_debug_split_reads",
@@ -129,6 +129,7 @@ def load():
     L.kmc_hip_allreduce_stats.argtypes = [vp, u64p]
     L.kmc_hip_last_timings.argtypes = [vp, C.c_int, C.POINTER(C.c_float)]
     L.kmc_hip_scatter_totals.argtypes = [vp, C.c_int, C.c_int, u64p, C.POINTER(C.c_double), u64p]
+    L.kmc_hip_local_sort_totals.argtypes = [vp, C.c_int, C.c_int, u64p, C.POINTER(C.c_double), u64p, u64p, u64p]
     L.kmc_hip_process_bins_device.argtypes = [vp, C.c_int, C.POINTER(BinParams), C.POINTER(BinDesc), C.c_uint64, C.c_int]
     L.kmc_hip_host_alloc.argtypes = [vp, C.c_uint64, C.POINTER(vp)]
     L.kmc_hip_host_free.argtypes = [vp, vp]
@@ -316,6 +317,12 @@ class Context:
         n, t, k = C.c_uint64(), C.c_double(), C.c_uint64()
         self._chk(self.L.kmc_hip_scatter_totals(self.h, dev, 1 if reset else 0, C.byref(n), C.byref(t), C.byref(k)))
         return n.value, t.value, k.value
+
+    def local_sort_totals(self, reset: bool = True, dev: int = 0):
+        """dict(launches, ms, records) of the LDS half of the hybrid sort on `dev` since the last reset + process-wide hybrid / redo group counts."""
+        n, t, k, h, r = C.c_uint64(), C.c_double(), C.c_uint64(), C.c_uint64(), C.c_uint64()
+        self._chk(self.L.kmc_hip_local_sort_totals(self.h, dev, 1 if reset else 0, C.byref(n), C.byref(t), C.byref(k), C.byref(h), C.byref(r)))
+        return dict(launches=n.value, ms=t.value, records=k.value, hybrid_groups=h.value, redo_groups=r.value)
 
     def process_bins_device(self, p: BinParams, descs, n_streams: int = 0, dev: int = 0):
         """Enqueue many device-resident bins (ctypes array of BinDesc); returns after enqueueing — call synchronize()."""

@@ -559,8 +559,10 @@ static_assert(EXP_CHUNK / 32 <= EXP_BLOCK && EXP_CHUNK <= 65536, "one bitmap wor
 static_assert(EXP_BLOCK >= 256, "the last workgroup scans 256 digits per pass, one per thread");
 template <int SIZE, bool FUSE_HIST>
 __global__ void __launch_bounds__(EXP_BLOCK) k_expand(const GrpExpand ge, u32 k, u32 both_strands, u32 n_pass, u64 *__restrict__ ghist, u32 *ticket_ctr,
-                                                 u32 *err, u64 *__restrict__ digit_base, u32 *done_ctr)
+                                                 u32 *err, u64 *__restrict__ digit_base, u32 *done_ctr, u32 pass_lo)
 {
+	/* n_pass histograms are fused: those of key bytes pass_lo .. pass_lo + n_pass - 1 (the hybrid sort of bucket_sort.hip.h only sends the top
+	 * bytes of the key through HBM passes; pass_lo = 0 and n_pass = ceil(k/4) is the plain LSD sort) */
 	/* The slices of all bins of the group form one ticket space. ge.tag[bin] is OR-ed into the record word that holds bit 2k — the spare
 	 * bits of the top radix digit (8 ceil(k/4) - 2k of them): bins expanded into one record array with tags 0, 1, 2 ... are sorted by ONE set
 	 * of passes into bin-major order (kmc_hip.hip run_group_device_t); 0 for a bin on its own. */
@@ -722,7 +724,7 @@ __global__ void __launch_bounds__(EXP_BLOCK) k_expand(const GrpExpand ge, u32 k,
 #ifndef EXP_NO_HIST /* tuning builds only (-DEXP_NO_HIST): what do the fused histograms cost? (the sort is garbage then) */
 					if (FUSE_HIST) {
 						for (u32 b = 0; b < n_pass; ++b)
-							atomicAdd(&s_h[b * 256 + kmc_get_byte<SIZE>(v, b)], 1u);
+							atomicAdd(&s_h[b * 256 + kmc_get_byte<SIZE>(v, pass_lo + b)], 1u);
 					}
 #endif
 				}
@@ -770,7 +772,7 @@ template <bool FUSE_HIST> constexpr size_t exp_lds_bytes(u32 n_pass, u32 k)
  * (u32 per workgroup), flushed with 64-bit global atomics. A wave whose lanes all hold the same digit value
  * (zero high bytes, poly-A bins) adds once instead of issuing a 64-way conflicting LDS atomic. */
 template <int SIZE>
-__global__ void __launch_bounds__(256) k_hist(const u64 *__restrict__ recs, u64 n, u32 n_pass, u64 *__restrict__ ghist)
+__global__ void __launch_bounds__(256) k_hist(const u64 *__restrict__ recs, u64 n, u32 n_pass, u64 *__restrict__ ghist, u32 pass_lo)
 {
 	KMC_DYN_LDS(u32, s_h); /* n_pass * 256 */
 	for (u32 i = threadIdx.x; i < n_pass * 256; i += 256)
@@ -791,7 +793,7 @@ __global__ void __launch_bounds__(256) k_hist(const u64 *__restrict__ recs, u64 
 			load_rec<SIZE>(recs + i * SIZE, x);
 		const u64 act = __ballot(valid); /* lane 0 is valid whenever any lane is */
 		for (u32 b = 0; b < n_pass; ++b) {
-			const u32 d = kmc_get_byte<SIZE>(x, b);
+			const u32 d = kmc_get_byte<SIZE>(x, pass_lo + b);
 			const u32 d0 = (u32)__builtin_amdgcn_readfirstlane((int)d);
 			if (__ballot(valid && d == d0) == act) {
 				if (lane == 0)

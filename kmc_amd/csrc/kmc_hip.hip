@@ -12,6 +12,7 @@
 #include <rccl/rccl.h>
 
 #include <algorithm>
+#include <atomic>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -23,6 +24,7 @@
 
 #include "../../include/kmc_hip.h"
 #include "kernels.hip.h"
+#include "bucket_sort.hip.h"
 #include "stage1_kernels.hip.h"
 
 namespace {
@@ -72,6 +74,7 @@ int ensure(DBuf &b, size_t bytes)
 constexpr size_t SM_STATS = 16;      /* u64[4]                           */
 constexpr size_t SM_OUTBYTES = 48;   /* u64                              */
 constexpr size_t SM_ERR = 56;        /* u32: copy of the slot's sticky error word, taken when a host-boundary bin ends */
+constexpr size_t SM_REDO = 60;       /* u32: set by k_bucket_sort when a tile of the hybrid sort did not fit: the host sorts the group again, LSD over all bytes */
 constexpr size_t SM_DBASE_WORK = 256; /* u64[2][256] per-portion digit bases (ping-pong) */
 constexpr size_t SM_COUNTERS = 256 + 2 * 256 * 8; /* u32[N_COUNTERS] ticket counters, one per launch (the tally shards of the compaction are per bin, BinPlan) */
 constexpr size_t N_COUNTERS = 4096;
@@ -94,7 +97,7 @@ struct HostRes {
 	u64 stats[4];
 	u64 out_bytes;
 	u32 err;
-	u32 pad;
+	u32 redo;
 };
 
 /* Everything a bin needs zeroed on the device lies in ONE region (one memset per bin instead of ~14: with 512 small bins
@@ -111,15 +114,17 @@ struct Slot {
 	u64 portion = PORTION_MAX;
 	DBuf in, pack_start;
 	DBuf recA, recB, zero, dbase, out, lut, sticky;
+	DBuf bounds;   /* hybrid sort: tile boundaries of k_bucket_bounds, u64[windows + 1] */
+	DBuf redo_log; /* hybrid sort: one "sort me again" word per asynchronous group since the last drain (drain_redo) */
 	HostRes *h_res = nullptr; /* pinned */
 	hipEvent_t ev[6] = {};
 	hipEvent_t done_ev = nullptr; /* blocking-sync event: _wait must not spin (stage-2 workers outnumber the cores a container may use) */
 	/* one event pair per scatter launch since the last harvest (roofline input) */
 	std::vector<hipEvent_t> sc_ev;
-	std::vector<u32> sc_cnt;
+	std::vector<u64> sc_cnt; /* records of the launch; bit 63: the pair brackets the LDS sort (k_bucket_bounds + k_bucket_sort), not a scatter pass */
 	u32 sc_used = 0;
-	double sc_ms_total = 0;
-	u64 sc_keys_total = 0, sc_launch_total = 0;
+	double sc_ms_total = 0, ls_ms_total = 0;
+	u64 sc_keys_total = 0, sc_launch_total = 0, ls_keys_total = 0, ls_launch_total = 0;
 	bool timed = false;
 	u32 async_seq = 0; /* asynchronous device-resident bins on this slot: every TIMING_SAMPLE-th one carries events */
 	/* pending async bin */
@@ -129,6 +134,16 @@ struct Slot {
 	u64 out_capacity = 0, lut_entries = 0;
 	bool without_output = false;
 	std::vector<u64> h_pack_start;
+	/* host-boundary bin in flight: what a redo needs */
+	DevParams sub_P = {};
+	u64 sub_size = 0, sub_n_rec = 0, sub_np = 0;
+	/* asynchronous device-resident groups since the last drain, in redo_log order */
+	struct PendingGroup {
+		DevParams P;
+		u64 lut_entries;
+		std::vector<kmc_hip_bin_desc> descs;
+	};
+	std::vector<PendingGroup> pending_groups;
 };
 
 struct Dev {
@@ -172,6 +187,8 @@ template <int SIZE> int set_func_attrs()
 	if (rs_lds_bytes<SIZE>() > 65536)
 		HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_onesweep<SIZE>), hipFuncAttributeMaxDynamicSharedMemorySize,
 		                           (int)rs_lds_bytes<SIZE>()));
+	if (bs_lds_bytes<SIZE>() > 65536)
+		HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_bucket_sort<SIZE>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bs_lds_bytes<SIZE>()));
 	if (exp_lds_bytes<true>(EXP_FUSE_MAX_PASS, 1) > 65536) /* worst case: the shortest records (smallest k) and 16 fused passes */
 		HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_expand<SIZE, true>), hipFuncAttributeMaxDynamicSharedMemorySize,
 		                           (int)exp_lds_bytes<true>(EXP_FUSE_MAX_PASS, 1)));
@@ -205,7 +222,7 @@ int slot_init(Slot &s, u64 portion)
 
 void slot_destroy(Slot &s)
 {
-	for (DBuf *b : {&s.in, &s.pack_start, &s.recA, &s.recB, &s.zero, &s.dbase, &s.out, &s.lut, &s.sticky})
+	for (DBuf *b : {&s.in, &s.pack_start, &s.recA, &s.recB, &s.zero, &s.dbase, &s.out, &s.lut, &s.sticky, &s.bounds, &s.redo_log})
 		if (b->p)
 			(void)hipFree(b->p);
 	if (s.h_res)
@@ -225,7 +242,7 @@ template <typename T> T *small_ptr(Slot &s, size_t off) { return reinterpret_cas
 template <typename T> T *zero_ptr(Slot &s, size_t off) { return reinterpret_cast<T *>(static_cast<char *>(s.zero.p) + off); }
 u32 *err_ptr(Slot &s) { return static_cast<u32 *>(s.sticky.p); }
 
-int sc_event_pair(Slot &s, hipEvent_t &e0, hipEvent_t &e1, u32 cnt)
+int sc_event_pair(Slot &s, hipEvent_t &e0, hipEvent_t &e1, u64 cnt)
 {
 	while (s.sc_ev.size() < (size_t)s.sc_used + 2) {
 		hipEvent_t ne;
@@ -239,15 +256,24 @@ int sc_event_pair(Slot &s, hipEvent_t &e0, hipEvent_t &e1, u32 cnt)
 	return 0;
 }
 
+int ls_event_pair(Slot &s, hipEvent_t &e0, hipEvent_t &e1, u64 cnt) { return sc_event_pair(s, e0, e1, cnt | (1ull << 63)); }
+
 /* after the slot's stream is idle: fold the recorded scatter launches into the slot's totals */
 int harvest(Slot &s)
 {
 	for (u32 i = 0; i + 1 < s.sc_used; i += 2) {
 		float t = 0;
 		HIPCHK(hipEventElapsedTime(&t, s.sc_ev[i], s.sc_ev[i + 1]));
-		s.sc_ms_total += t;
-		s.sc_keys_total += s.sc_cnt[i / 2];
-		++s.sc_launch_total;
+		const u64 c = s.sc_cnt[i / 2];
+		if (c >> 63) {
+			s.ls_ms_total += t;
+			s.ls_keys_total += c & ~(1ull << 63);
+			++s.ls_launch_total;
+		} else {
+			s.sc_ms_total += t;
+			s.sc_keys_total += c;
+			++s.sc_launch_total;
+		}
 	}
 	s.sc_used = 0;
 	s.sc_cnt.clear();
@@ -282,10 +308,64 @@ struct BinPlan {
 	u64 rec_off = 0; /* first record of the bin in the group's record arrays */
 };
 
+/* ---- the sort's shape ----------------------------------------------------------------------------------------------
+ * key_bytes = ceil(key bits / 8) byte positions; the TOP `top` of them are sorted by 8-bit LSD passes through HBM (k_onesweep), the rest
+ * inside LDS by k_bucket_sort on bucket-aligned tiles (bucket_sort.hip.h). top == key_bytes: the plain LSD sort of rounds 1-2. */
+struct SortPlan {
+	u32 key_bytes = 0, top = 0;
+	u32 key_bits = 0; /* significant bits of the key (2k + tag bits; 8 key_bytes when the caller cannot tell) */
+	u32 pass_lo() const { return key_bytes - top; }
+	bool local() const { return top < key_bytes; }
+	u32 hbits() const { return top ? 8 * top - (8 * key_bytes - key_bits) : 0; } /* top bits of the significant key that the HBM passes order (plan_sort: 8 top > spare bits) */
+};
+std::atomic<u64> g_hybrid_groups{0}, g_redo_groups{0}; /* process-wide: input whose buckets keep overflowing the tiles stops being tried */
+int hybrid_mode()
+{
+	static const int v = [] {
+		const char *e = getenv("KMC_HIP_HYBRID"); /* 0 = LSD passes over every byte (rounds 1-2); 1 = default; -h = force `h` top bytes (tuning) */
+		return e ? atoi(e) : 1;
+	}();
+	return v;
+}
+template <int SIZE> SortPlan plan_sort(u64 n, u32 key_bytes, u32 key_bits, bool classic)
+{
+	SortPlan sp;
+	sp.key_bytes = sp.top = key_bytes;
+	sp.key_bits = key_bits;
+	const int mode = hybrid_mode();
+	if (classic || mode == 0 || key_bytes < 3 || n < 2)
+		return sp;
+	const u64 redo = g_redo_groups.load(std::memory_order_relaxed);
+	if (redo > 4 && redo * 8 > g_hybrid_groups.load(std::memory_order_relaxed))
+		return sp; /* this input defeats the bucket tiles too often */
+	const u32 spare = 8 * key_bytes - key_bits;
+	if (mode < 0) {
+		const u32 h = (u32)(-mode);
+		if (h + 1 <= key_bytes && 8 * h > spare)
+			sp.top = h;
+		return sp;
+	}
+	/* the fewest top bytes that leave buckets of bs_target_bucket() records on average, and only if at least two passes are saved */
+	for (u32 h = 0; h + 2 <= key_bytes && h <= 4; ++h) {
+		bool ok;
+		if (h == 0)
+			ok = n <= (u64)BsCfg<SIZE>::CAP;
+		else {
+			const u32 eff = 8 * h > spare ? 8 * h - spare : 0;
+			ok = eff > 0 && (eff >= 63 || (n >> eff) <= bs_target_bucket<SIZE>());
+		}
+		if (ok) {
+			sp.top = h;
+			break;
+		}
+	}
+	return sp;
+}
+
 /* lays out the zero region of a group: small block | per bin: bitmap, expand look-back words, compaction look-back words, LUT shards, tally
  * shards | digit histograms | one scatter status area per onesweep launch over the group's `n_total` records */
 template <int SIZE>
-ZeroPlan plan_group(const Slot &s, std::vector<BinPlan> &bins, u64 n_total, u32 n_pass, bool front, bool sort, bool compact, u64 lut_shard_entries)
+ZeroPlan plan_group(const Slot &s, std::vector<BinPlan> &bins, u64 n_total, u32 n_pass /* passes through HBM */, bool front, bool sort, bool compact, u64 lut_shard_entries)
 {
 	ZeroPlan z;
 	size_t off = up256(SM_BYTES);
@@ -328,85 +408,114 @@ int apply_plan(Slot &s, const ZeroPlan &z)
 	return 0;
 }
 
-/* ---- the sort: histogram of every digit + n_pass onesweep launches (per portion) --------------------------- */
+/* ---- the sort: histograms of the digits that go through HBM + one onesweep launch per such digit (and portion), then — hybrid — the
+ * bucket-aligned LDS sort of the remaining bytes, in place. `d_flag`: where k_bucket_sort reports a tile it could not sort. ---- */
 template <int SIZE>
-int sort_device_t(Slot &s, const ZeroPlan &z, u64 *d_recs, u64 *d_tmp, u64 n, u32 n_pass, u64 **d_result, u32 &counter_idx, bool hist_done)
+int sort_device_t(Slot &s, const ZeroPlan &z, u64 *d_recs, u64 *d_tmp, u64 n, const SortPlan &sp, u64 **d_result, u32 &counter_idx, bool hist_done, u32 *d_flag)
 {
 	u64 *src = d_recs, *dst = d_tmp;
-	if (n < 2 || n_pass == 0) {
+	if (n < 2 || sp.key_bytes == 0) {
 		*d_result = src;
+		if (s.timed)
+			HIPCHK(hipEventRecord(s.ev[3], s.stream));
 		return 0;
 	}
-	if (int rc = ensure(s.dbase, (size_t)n_pass * 256 * 8))
-		return rc;
-	u64 *ghist = zero_ptr<u64>(s, z.ghist), *dbase = (u64 *)s.dbase.p;
+	const u32 n_pass = sp.top, pass_lo = sp.pass_lo();
 	u32 *err = err_ptr(s);
-	u32 *counters = small_ptr<u32>(s, SM_COUNTERS);
-	u64 *work = small_ptr<u64>(s, SM_DBASE_WORK);
+	if (n_pass) {
+		if (int rc = ensure(s.dbase, (size_t)n_pass * 256 * 8))
+			return rc;
+		u64 *ghist = zero_ptr<u64>(s, z.ghist), *dbase = (u64 *)s.dbase.p;
+		u32 *counters = small_ptr<u32>(s, SM_COUNTERS);
+		u64 *work = small_ptr<u64>(s, SM_DBASE_WORK);
 
-	if (!hist_done) { /* digit bases: the expansion's last workgroup made them when the histograms were fused into it */
-		u64 blocks = (n + 255) / 256;
-		if (blocks > 256 * 8)
-			blocks = 256 * 8; /* 8 workgroups per CU, grid-stride */
-		k_hist<SIZE><<<dim3((u32)blocks), dim3(256), (size_t)n_pass * 1024, s.stream>>>(src, n, n_pass, ghist);
-		k_hist_scan<<<dim3(n_pass), dim3(256), 0, s.stream>>>(ghist, dbase);
-	}
-	if (s.timed)
-		HIPCHK(hipEventRecord(s.ev[3], s.stream));
-	u32 launch = 0;
-	for (u32 pass = 0; pass < n_pass; ++pass) {
-		const u64 *base_in = dbase + (size_t)pass * 256;
-		int flip = 0;
-		for (u64 start = 0; start < n; start += s.portion) {
-			const u32 cnt = (u32)std::min(s.portion, n - start);
-			const u32 tiles = (cnt + RsCfg<SIZE>::TILE - 1) / RsCfg<SIZE>::TILE;
-			if (counter_idx >= N_COUNTERS)
-				return fail(KMC_HIP_EINVAL, "too many scatter launches for one bin");
-			u32 *status = zero_ptr<u32>(s, z.sc_status + (size_t)launch * z.sc_stride);
-			u64 *base_out = work + (size_t)flip * 256;
-			hipEvent_t e0 = nullptr, e1 = nullptr;
-			if (s.timed) {
-				if (int rc = sc_event_pair(s, e0, e1, cnt))
-					return rc;
-				HIPCHK(hipEventRecord(e0, s.stream));
-			}
-			k_onesweep<SIZE><<<dim3((tiles + RS_TPB - 1) / RS_TPB), dim3(RS_BLOCK), rs_lds_bytes<SIZE>(), s.stream>>>(
-			    src + start * SIZE, dst, cnt, pass, base_in, base_out, status, counters + counter_idx, tiles, err);
-			if (s.timed)
-				HIPCHK(hipEventRecord(e1, s.stream));
-			++counter_idx;
-			++launch;
-			base_in = base_out;
-			flip ^= 1;
+		if (!hist_done) { /* digit bases: the expansion's last workgroup made them when the histograms were fused into it */
+			u64 blocks = (n + 255) / 256;
+			if (blocks > 256 * 8)
+				blocks = 256 * 8; /* 8 workgroups per CU, grid-stride */
+			k_hist<SIZE><<<dim3((u32)blocks), dim3(256), (size_t)n_pass * 1024, s.stream>>>(src, n, n_pass, ghist, pass_lo);
+			k_hist_scan<<<dim3(n_pass), dim3(256), 0, s.stream>>>(ghist, dbase);
 		}
-		std::swap(src, dst);
+		if (s.timed)
+			HIPCHK(hipEventRecord(s.ev[3], s.stream));
+		u32 launch = 0;
+		for (u32 pass = 0; pass < n_pass; ++pass) {
+			const u64 *base_in = dbase + (size_t)pass * 256;
+			int flip = 0;
+			for (u64 start = 0; start < n; start += s.portion) {
+				const u32 cnt = (u32)std::min(s.portion, n - start);
+				const u32 tiles = (cnt + RsCfg<SIZE>::TILE - 1) / RsCfg<SIZE>::TILE;
+				if (counter_idx >= N_COUNTERS)
+					return fail(KMC_HIP_EINVAL, "too many scatter launches for one bin");
+				u32 *status = zero_ptr<u32>(s, z.sc_status + (size_t)launch * z.sc_stride);
+				u64 *base_out = work + (size_t)flip * 256;
+				hipEvent_t e0 = nullptr, e1 = nullptr;
+				if (s.timed) {
+					if (int rc = sc_event_pair(s, e0, e1, cnt))
+						return rc;
+					HIPCHK(hipEventRecord(e0, s.stream));
+				}
+				k_onesweep<SIZE><<<dim3((tiles + RS_TPB - 1) / RS_TPB), dim3(RS_BLOCK), rs_lds_bytes<SIZE>(), s.stream>>>(
+				    src + start * SIZE, dst, cnt, pass_lo + pass, base_in, base_out, status, counters + counter_idx, tiles, err);
+				if (s.timed)
+					HIPCHK(hipEventRecord(e1, s.stream));
+				++counter_idx;
+				++launch;
+				base_in = base_out;
+				flip ^= 1;
+			}
+			std::swap(src, dst);
+		}
+	} else if (s.timed)
+		HIPCHK(hipEventRecord(s.ev[3], s.stream));
+	if (sp.local()) {
+		constexpr u64 S = BsCfg<SIZE>::STRIDE;
+		const u64 n_win = (n + S - 1) / S;
+		if (n_win > 0x7FFFFFF0ull)
+			return fail(KMC_HIP_EINVAL, "bin too large");
+		if (int rc = ensure(s.bounds, (size_t)(n_win + 2) * 8))
+			return rc;
+		u64 *bounds = (u64 *)s.bounds.p;
+		hipEvent_t e0 = nullptr, e1 = nullptr;
+		if (s.timed) {
+			if (int rc = ls_event_pair(s, e0, e1, n))
+				return rc;
+			HIPCHK(hipEventRecord(e0, s.stream));
+		}
+		k_bucket_bounds<SIZE><<<dim3((u32)((n_win + 1 + 3) / 4)), dim3(256), 0, s.stream>>>(src, n, n_win, sp.key_bits, sp.hbits(), bounds);
+		k_bucket_sort<SIZE><<<dim3((u32)n_win), dim3(BsCfg<SIZE>::THREADS), bs_lds_bytes<SIZE>(), s.stream>>>(src, sp.key_bits, sp.hbits(), bounds, d_flag);
+		if (s.timed)
+			HIPCHK(hipEventRecord(e1, s.stream));
 	}
 	HIPCHK(hipGetLastError());
 	*d_result = src;
 	return 0;
 }
 
-template <int SIZE> int sort_only_t(Slot &s, u64 *d_recs, u64 *d_tmp, u64 n, u32 n_pass, u64 **d_result)
+/* sort-only calls (narrow boundary, stage 1's key sort). `stable_lsd`: the caller's records carry payload above the key and rely on the LSD
+ * passes' stability (kmc_hip_split_part sorts (index << 16) | bin by its low 2 bytes) — the hybrid sort compares whole records. */
+template <int SIZE> int sort_only_t(Slot &s, u64 *d_recs, u64 *d_tmp, u64 n, u32 key_bytes, u64 **d_result, bool stable_lsd)
 {
 	std::vector<BinPlan> none;
-	const ZeroPlan z = plan_group<SIZE>(s, none, n, n_pass, false, true, false, 0);
+	const SortPlan sp = plan_sort<SIZE>(n, key_bytes, 8 * key_bytes, stable_lsd);
+	const ZeroPlan z = plan_group<SIZE>(s, none, n, sp.top, false, true, false, 0);
 	if (int rc = apply_plan(s, z))
 		return rc;
 	u32 counter_idx = 0;
-	return sort_device_t<SIZE>(s, z, d_recs, d_tmp, n, n_pass, d_result, counter_idx, false);
+	return sort_device_t<SIZE>(s, z, d_recs, d_tmp, n, sp, d_result, counter_idx, false, small_ptr<u32>(s, SM_REDO));
 }
 
-int sort_device(Slot &s, u64 *d_recs, u64 *d_tmp, u64 n, u32 words, u32 n_pass, u64 **d_result)
+int sort_device(Slot &s, u64 *d_recs, u64 *d_tmp, u64 n, u32 words, u32 n_pass, u64 **d_result, bool stable_lsd)
 {
 	switch (words) {
-	case 1: return sort_only_t<1>(s, d_recs, d_tmp, n, n_pass, d_result);
-	case 2: return sort_only_t<2>(s, d_recs, d_tmp, n, n_pass, d_result);
-	case 3: return sort_only_t<3>(s, d_recs, d_tmp, n, n_pass, d_result);
-	case 4: return sort_only_t<4>(s, d_recs, d_tmp, n, n_pass, d_result);
-	case 5: return sort_only_t<5>(s, d_recs, d_tmp, n, n_pass, d_result);
-	case 6: return sort_only_t<6>(s, d_recs, d_tmp, n, n_pass, d_result);
-	case 7: return sort_only_t<7>(s, d_recs, d_tmp, n, n_pass, d_result);
-	case 8: return sort_only_t<8>(s, d_recs, d_tmp, n, n_pass, d_result);
+	case 1: return sort_only_t<1>(s, d_recs, d_tmp, n, n_pass, d_result, stable_lsd);
+	case 2: return sort_only_t<2>(s, d_recs, d_tmp, n, n_pass, d_result, stable_lsd);
+	case 3: return sort_only_t<3>(s, d_recs, d_tmp, n, n_pass, d_result, stable_lsd);
+	case 4: return sort_only_t<4>(s, d_recs, d_tmp, n, n_pass, d_result, stable_lsd);
+	case 5: return sort_only_t<5>(s, d_recs, d_tmp, n, n_pass, d_result, stable_lsd);
+	case 6: return sort_only_t<6>(s, d_recs, d_tmp, n, n_pass, d_result, stable_lsd);
+	case 7: return sort_only_t<7>(s, d_recs, d_tmp, n, n_pass, d_result, stable_lsd);
+	case 8: return sort_only_t<8>(s, d_recs, d_tmp, n, n_pass, d_result, stable_lsd);
 	}
 	return fail(KMC_HIP_EINVAL, "words must be 1..8");
 }
@@ -441,8 +550,8 @@ int check_params(const kmc_hip_bin_params *p, DevParams &P)
 /* ---- front end of a group: mark super-k-mer starts (one workgroup per pack of any bin), then expand slice-parallel (one ticket space over
  * the slices of all bins) with the sort's histograms fused in; the last workgroup turns the histograms into digit bases ---- */
 template <int SIZE>
-int front_end_group(Slot &s, const std::vector<BinPlan> &bins, size_t off_ghist, const DevParams &P, u32 n_pass, u32 &counter_idx, bool &hist_done,
-                    u64 *d_recs, bool fuse)
+int front_end_group(Slot &s, const std::vector<BinPlan> &bins, size_t off_ghist, const DevParams &P, u32 n_pass /* digits through HBM */, u32 pass_lo, u32 &counter_idx,
+                    bool &hist_done, u64 *d_recs, bool fuse)
 {
 	if (bins.empty())
 		return 0;
@@ -486,10 +595,10 @@ int front_end_group(Slot &s, const std::vector<BinPlan> &bins, size_t off_ghist,
 		if (int rc = ensure(s.dbase, (size_t)n_pass * 256 * 8))
 			return rc;
 		k_expand<SIZE, true><<<dim3(blocks), dim3(EXP_BLOCK), exp_lds_bytes<true>(n_pass, P.k), s.stream>>>(
-		    ge, P.k, P.both_strands, n_pass, ghist, counters + counter_idx, err, (u64 *)s.dbase.p, counters + counter_idx + 1);
+		    ge, P.k, P.both_strands, n_pass, ghist, counters + counter_idx, err, (u64 *)s.dbase.p, counters + counter_idx + 1, pass_lo);
 	} else
 		k_expand<SIZE, false><<<dim3(blocks), dim3(EXP_BLOCK), exp_lds_bytes<false>(n_pass, P.k), s.stream>>>(
-		    ge, P.k, P.both_strands, n_pass, ghist, counters + counter_idx, err, nullptr, counters + counter_idx + 1);
+		    ge, P.k, P.both_strands, n_pass, ghist, counters + counter_idx, err, nullptr, counters + counter_idx + 1, pass_lo);
 	counter_idx += 2;
 	hist_done = fuse;
 	if (s.timed)
@@ -600,7 +709,7 @@ constexpr u64 GROUP_MAX_RECORD_BYTES = 6ull << 30; /* per record array of a grou
 
 /* d_stats / d_out_bytes == NULL in a descriptor (groups of one only): the slot's own small block (host-boundary path) */
 template <int SIZE>
-int run_group_device_t(Slot &s, const DevParams &P, const kmc_hip_bin_desc *const *descs, u32 g, u64 lut_entries)
+int run_group_device_t(Slot &s, const DevParams &P, const kmc_hip_bin_desc *const *descs, u32 g, u64 lut_entries, bool classic, u32 *d_flag, bool *used_hybrid)
 {
 	const u32 k = P.k;
 	const bool use_lut = lut_entries && !P.without_output && !P.kff;
@@ -637,9 +746,14 @@ int run_group_device_t(Slot &s, const DevParams &P, const kmc_hip_bin_desc *cons
 		++tag_bits;
 	if (2 * k + tag_bits > 64u * SIZE)
 		return fail(KMC_HIP_EINVAL, "group too large for the record width");
-	const u32 n_pass = (2 * k + tag_bits + 7) / 8;
-	/* the sort's histograms are fused into the expansion up to 16 passes (k <= 64); a bin on its own with a single record has nothing to sort */
-	const bool fuse = n_pass <= EXP_FUSE_MAX_PASS && N >= 2;
+	const u32 key_bytes = (2 * k + tag_bits + 7) / 8;
+	/* hybrid: only the top bytes of the key go through HBM passes, the rest is sorted inside LDS (bucket_sort.hip.h) */
+	const SortPlan sp = plan_sort<SIZE>(N, key_bytes, 2 * k + tag_bits, classic);
+	const u32 n_pass = sp.top;
+	if (used_hybrid)
+		*used_hybrid = sp.local() && N >= 2;
+	/* the histograms of the HBM passes are fused into the expansion up to 16 of them (plain LSD: k <= 64); a bin on its own with a single record has nothing to sort */
+	const bool fuse = n_pass >= 1 && n_pass <= EXP_FUSE_MAX_PASS && N >= 2;
 	int rc = 0;
 	if (N && ((rc = ensure(s.recA, N * SIZE * 8 + 256)) || (rc = ensure(s.recB, N * SIZE * 8 + 256))))
 		return rc;
@@ -666,17 +780,19 @@ int run_group_device_t(Slot &s, const DevParams &P, const kmc_hip_bin_desc *cons
 		HIPCHK(hipEventRecord(s.ev[0], s.stream));
 	u32 counter_idx = 0;
 	bool hist_done = false;
-	if ((rc = front_end_group<SIZE>(s, bins, z.ghist, P, n_pass, counter_idx, hist_done, (u64 *)s.recA.p, fuse)))
+	if ((rc = front_end_group<SIZE>(s, bins, z.ghist, P, n_pass, sp.pass_lo(), counter_idx, hist_done, (u64 *)s.recA.p, fuse)))
 		return rc;
+	if (n_pass == 0)
+		hist_done = true; /* no HBM pass, no histogram */
 	if (s.timed && bins.empty()) {
 		HIPCHK(hipEventRecord(s.ev[1], s.stream));
 		HIPCHK(hipEventRecord(s.ev[2], s.stream));
 	}
 	u64 *sorted = (u64 *)s.recA.p;
-	if (N && (rc = sort_device_t<SIZE>(s, z, (u64 *)s.recA.p, (u64 *)s.recB.p, N, n_pass, &sorted, counter_idx, hist_done)))
+	if (N && (rc = sort_device_t<SIZE>(s, z, (u64 *)s.recA.p, (u64 *)s.recB.p, N, sp, &sorted, counter_idx, hist_done, d_flag ? d_flag : small_ptr<u32>(s, SM_REDO))))
 		return rc;
 	if (s.timed) {
-		if (N < 2)
+		if (!N)
 			HIPCHK(hipEventRecord(s.ev[3], s.stream));
 		HIPCHK(hipEventRecord(s.ev[4], s.stream));
 	}
@@ -688,25 +804,96 @@ int run_group_device_t(Slot &s, const DevParams &P, const kmc_hip_bin_desc *cons
 	return 0;
 }
 
-/* caller holds s.mtx and has set s.timed */
-int run_group_device(Slot &s, const DevParams &P, const kmc_hip_bin_desc *const *descs, u32 g, u64 lut_entries)
+/* caller holds s.mtx and has set s.timed. `classic`: LSD passes over every byte (the redo of a group whose hybrid sort reported a tile it could
+ * not handle). `d_flag`: the device word that report goes to — NULL = the slot's small block (SM_REDO), which the group's memset clears. */
+int run_group_device(Slot &s, const DevParams &P, const kmc_hip_bin_desc *const *descs, u32 g, u64 lut_entries, bool classic = false, u32 *d_flag = nullptr,
+                     bool *used_hybrid = nullptr)
 {
+	bool hyb = false;
+	int rc = KMC_HIP_EINVAL;
 	switch ((P.k + 31) / 32) {
-	case 1: return run_group_device_t<1>(s, P, descs, g, lut_entries);
-	case 2: return run_group_device_t<2>(s, P, descs, g, lut_entries);
-	case 3: return run_group_device_t<3>(s, P, descs, g, lut_entries);
-	case 4: return run_group_device_t<4>(s, P, descs, g, lut_entries);
-	case 5: return run_group_device_t<5>(s, P, descs, g, lut_entries);
-	case 6: return run_group_device_t<6>(s, P, descs, g, lut_entries);
-	case 7: return run_group_device_t<7>(s, P, descs, g, lut_entries);
-	case 8: return run_group_device_t<8>(s, P, descs, g, lut_entries);
+	case 1: rc = run_group_device_t<1>(s, P, descs, g, lut_entries, classic, d_flag, &hyb); break;
+	case 2: rc = run_group_device_t<2>(s, P, descs, g, lut_entries, classic, d_flag, &hyb); break;
+	case 3: rc = run_group_device_t<3>(s, P, descs, g, lut_entries, classic, d_flag, &hyb); break;
+	case 4: rc = run_group_device_t<4>(s, P, descs, g, lut_entries, classic, d_flag, &hyb); break;
+	case 5: rc = run_group_device_t<5>(s, P, descs, g, lut_entries, classic, d_flag, &hyb); break;
+	case 6: rc = run_group_device_t<6>(s, P, descs, g, lut_entries, classic, d_flag, &hyb); break;
+	case 7: rc = run_group_device_t<7>(s, P, descs, g, lut_entries, classic, d_flag, &hyb); break;
+	case 8: rc = run_group_device_t<8>(s, P, descs, g, lut_entries, classic, d_flag, &hyb); break;
+	default: return fail(KMC_HIP_EINVAL, "kmer_len out of range");
 	}
-	return fail(KMC_HIP_EINVAL, "kmer_len out of range");
+	if (!rc && hyb)
+		g_hybrid_groups.fetch_add(1, std::memory_order_relaxed);
+	if (used_hybrid)
+		*used_hybrid = hyb;
+	return rc;
+}
+
+/* ---- redo: asynchronous device-resident groups ---------------------------------------------------------------------
+ * A group enqueued without a synchronisation point of its own gets a word of the slot's redo log; once the stream is idle, drain_redo reads the
+ * log and sorts the flagged groups again with LSD passes over all bytes (their inputs — the bin images — are untouched, their outputs are
+ * simply written again). */
+constexpr u32 REDO_LOG_WORDS = 8192;
+int drain_redo(Slot &s); /* below */
+int run_group_async(Slot &s, const DevParams &P, const kmc_hip_bin_desc *const *descs, u32 g, u64 lut_entries)
+{
+	if (!s.redo_log.p) {
+		if (int rc = ensure(s.redo_log, REDO_LOG_WORDS * 4))
+			return rc;
+		HIPCHK(hipMemsetAsync(s.redo_log.p, 0, REDO_LOG_WORDS * 4, s.stream));
+	}
+	if (s.pending_groups.size() >= REDO_LOG_WORDS)
+		if (int rc = drain_redo(s))
+			return rc;
+	u32 *d_flag = (u32 *)s.redo_log.p + s.pending_groups.size();
+	bool hyb = false;
+	if (int rc = run_group_device(s, P, descs, g, lut_entries, false, d_flag, &hyb))
+		return rc;
+	Slot::PendingGroup pg;
+	pg.P = P;
+	pg.lut_entries = lut_entries;
+	if (hyb)
+		for (u32 i = 0; i < g; ++i)
+			pg.descs.push_back(*descs[i]);
+	s.pending_groups.push_back(std::move(pg)); /* a group sorted by LSD passes alone keeps its (never set) word, without descriptors */
+	return 0;
+}
+/* caller holds s.mtx */
+int drain_redo(Slot &s)
+{
+	if (s.pending_groups.empty())
+		return 0;
+	HIPCHK(hipStreamSynchronize(s.stream));
+	std::vector<u32> log(s.pending_groups.size());
+	HIPCHK(hipMemcpy(log.data(), s.redo_log.p, log.size() * 4, hipMemcpyDeviceToHost));
+	std::vector<Slot::PendingGroup> groups;
+	groups.swap(s.pending_groups);
+	bool any = false;
+	for (size_t i = 0; i < groups.size(); ++i) {
+		if (!log[i] || groups[i].descs.empty())
+			continue;
+		any = true;
+		g_redo_groups.fetch_add(1, std::memory_order_relaxed);
+		std::vector<const kmc_hip_bin_desc *> ptrs;
+		for (const auto &d : groups[i].descs)
+			ptrs.push_back(&d);
+		const bool timed = s.timed;
+		s.timed = false;
+		const int rc = run_group_device(s, groups[i].P, ptrs.data(), (u32)ptrs.size(), groups[i].lut_entries, true);
+		s.timed = timed;
+		if (rc)
+			return rc;
+	}
+	if (any) {
+		HIPCHK(hipMemsetAsync(s.redo_log.p, 0, log.size() * 4, s.stream));
+		HIPCHK(hipStreamSynchronize(s.stream));
+	}
+	return 0;
 }
 
 /* one bin = a group of one */
 int run_bin_device(Slot &s, const DevParams &P, const uint8_t *d_in, u64 size, u64 n_rec, const u64 *d_pack_start, u64 n_packs, uint8_t *d_out,
-                   u64 out_capacity, u64 *d_out_bytes, u64 *d_lut, u64 lut_entries, u64 *d_stats)
+                   u64 out_capacity, u64 *d_out_bytes, u64 *d_lut, u64 lut_entries, u64 *d_stats, bool classic = false, bool async = false)
 {
 	kmc_hip_bin_desc d;
 	d.d_superkmers = d_in;
@@ -720,7 +907,20 @@ int run_bin_device(Slot &s, const DevParams &P, const uint8_t *d_in, u64 size, u
 	d.d_lut = (uint64_t *)d_lut;
 	d.d_stats = (uint64_t *)d_stats;
 	const kmc_hip_bin_desc *p = &d;
-	return run_group_device(s, P, &p, 1, lut_entries);
+	if (async)
+		return run_group_async(s, P, &p, 1, lut_entries);
+	return run_group_device(s, P, &p, 1, lut_entries, classic);
+}
+
+/* the slot's stream is idle: did the hybrid sort of the group that just ran ask for a redo (small block, SM_REDO)? */
+int read_redo(Slot &s, bool &redo)
+{
+	u32 v = 0;
+	HIPCHK(hipMemcpy(&v, small_ptr<u32>(s, SM_REDO), 4, hipMemcpyDeviceToHost));
+	redo = v != 0;
+	if (redo)
+		g_redo_groups.fetch_add(1, std::memory_order_relaxed);
+	return 0;
 }
 
 int err_to_code(u32 err)
@@ -763,7 +963,7 @@ int debug_expand_t(Slot &s, const DevParams &P, u64 size, u64 n_rec, u64 np)
 		return rc;
 	u32 counter_idx = 0;
 	bool hist_done = false;
-	return front_end_group<SIZE>(s, bins, z.ghist, P, n_pass, counter_idx, hist_done, (u64 *)s.recA.p, n_pass <= EXP_FUSE_MAX_PASS && n_rec >= 2);
+	return front_end_group<SIZE>(s, bins, z.ghist, P, n_pass, 0, counter_idx, hist_done, (u64 *)s.recA.p, n_pass <= EXP_FUSE_MAX_PASS && n_rec >= 2);
 }
 template <int SIZE>
 int debug_compact_t(Slot &s, const DevParams &P, u64 n, u64 out_capacity, u64 lut_entries)
@@ -789,7 +989,7 @@ int debug_compact_t(Slot &s, const DevParams &P, u64 n, u64 out_capacity, u64 lu
 
 /* stage 1, one part of text: the backend of kmc_amd/csrc/stage1_chain.h on a HIP stream (used by kmc_hip_split_part below) */
 extern "C" {
-static int sort_records_device_locked(Slot &s, void *d_recs, void *d_tmp, uint64_t n, uint32_t words, uint32_t key_bytes, void **d_result); /* defined below */
+static int sort_records_device_locked(Slot &s, void *d_recs, void *d_tmp, uint64_t n, uint32_t words, uint32_t key_bytes, void **d_result, int stable_lsd); /* defined below */
 }
 namespace {
 struct S1BackendFailure {
@@ -851,7 +1051,7 @@ struct S1HipBackend {
 	u64 *sort_by_low16(u64 *keys, u64 *tmp, u64 n)
 	{
 		void *res = keys;
-		if (n > 1 && sort_records_device_locked(*slot, keys, tmp, n, 1, 2, &res) != 0)
+		if (n > 1 && sort_records_device_locked(*slot, keys, tmp, n, 1, 2, &res, 1 /* payload above the key: stable LSD passes */) != 0)
 			throw S1BackendFailure{hipGetLastError(), "sort of the super-k-mer keys"};
 		return (u64 *)res;
 	}
@@ -1031,6 +1231,8 @@ int kmc_hip_synchronize(kmc_hip_ctx *ctx, int dev)
 	for (auto &s : ctx->devs[dev]->slot) {
 		std::lock_guard<std::mutex> lck(s.mtx);
 		HIPCHK(hipStreamSynchronize(s.stream));
+		if (int rc = drain_redo(s))
+			return rc;
 		if (int rc = harvest(s))
 			return rc;
 		u32 e1 = 0;
@@ -1042,13 +1244,23 @@ int kmc_hip_synchronize(kmc_hip_ctx *ctx, int dev)
 }
 
 /* ---- narrow boundary ---- */
-static int sort_records_device_locked(Slot &s, void *d_recs, void *d_tmp, uint64_t n, uint32_t words, uint32_t key_bytes, void **d_result)
+static int sort_records_device_locked(Slot &s, void *d_recs, void *d_tmp, uint64_t n, uint32_t words, uint32_t key_bytes, void **d_result, int stable_lsd)
 {
 	s.timed = true;
 	u64 *res = nullptr;
-	if (int rc = sort_device(s, (u64 *)d_recs, (u64 *)d_tmp, n, words, key_bytes, &res))
+	if (int rc = sort_device(s, (u64 *)d_recs, (u64 *)d_tmp, n, words, key_bytes, &res, stable_lsd != 0))
 		return rc;
 	HIPCHK(hipStreamSynchronize(s.stream));
+	bool redo = false;
+	if (!stable_lsd && n >= 2)
+		if (int rc = read_redo(s, redo))
+			return rc;
+	if (redo) { /* a tile of the hybrid sort did not fit: the array is still a permutation of the input, LSD passes over all bytes sort it */
+		u64 *other = res == (u64 *)d_recs ? (u64 *)d_tmp : (u64 *)d_recs;
+		if (int rc = sort_device(s, res, other, n, words, key_bytes, &res, true))
+			return rc;
+		HIPCHK(hipStreamSynchronize(s.stream));
+	}
 	if (int rc = harvest(s))
 		return rc;
 	u32 err = 0;
@@ -1067,7 +1279,7 @@ int kmc_hip_sort_records_device(kmc_hip_ctx *ctx, int dev, void *d_recs, void *d
 		return fail(KMC_HIP_EINVAL, "kmc_hip_sort_records_device: bad arguments");
 	Slot &s = ctx->devs[dev]->slot[0];
 	std::lock_guard<std::mutex> lck(s.mtx);
-	return sort_records_device_locked(s, d_recs, d_tmp, n, words, key_bytes, d_result);
+	return sort_records_device_locked(s, d_recs, d_tmp, n, words, key_bytes, d_result, 0);
 }
 
 int kmc_hip_sort_records_into(kmc_hip_ctx *ctx, int dev, const void *recs, void *dst, uint64_t n, uint32_t words, uint32_t key_bytes)
@@ -1091,7 +1303,7 @@ int kmc_hip_sort_records_into(kmc_hip_ctx *ctx, int dev, const void *recs, void 
 		return rc;
 	HIPCHK(hipMemcpyAsync(s.recA.p, recs, bytes, hipMemcpyHostToDevice, s.stream));
 	void *res = nullptr;
-	if ((rc = sort_records_device_locked(s, s.recA.p, s.recB.p, n, words, key_bytes, &res)))
+	if ((rc = sort_records_device_locked(s, s.recA.p, s.recB.p, n, words, key_bytes, &res, 0)))
 		return rc;
 	HIPCHK(hipMemcpyAsync(dst, res, bytes, hipMemcpyDeviceToHost, s.stream));
 	HIPCHK(hipStreamSynchronize(s.stream));
@@ -1113,11 +1325,23 @@ static int process_bin_device_on(kmc_hip_ctx *ctx, int dev, Slot &s, const DevPa
 	std::lock_guard<std::mutex> lck(s.mtx);
 	s.timed = sync || (s.async_seq++ % TIMING_SAMPLE) == 0; /* async_seq restarts with kmc_hip_scatter_totals(reset) */
 	if (int rc = run_bin_device(s, P, d_superkmers, size, n_rec, (const u64 *)d_pack_start, n_packs, d_out, out_capacity, (u64 *)d_out_bytes,
-	                            (u64 *)d_lut, lut_entries, (u64 *)d_stats))
+	                            (u64 *)d_lut, lut_entries, (u64 *)d_stats, false, !sync))
 		return rc;
 	if (!sync)
 		return 0;
 	HIPCHK(hipStreamSynchronize(s.stream));
+	bool redo = false;
+	if (n_rec >= 2)
+		if (int rc = read_redo(s, redo))
+			return rc;
+	if (redo) {
+		if (int rc = run_bin_device(s, P, d_superkmers, size, n_rec, (const u64 *)d_pack_start, n_packs, d_out, out_capacity, (u64 *)d_out_bytes,
+		                            (u64 *)d_lut, lut_entries, (u64 *)d_stats, true))
+			return rc;
+		HIPCHK(hipStreamSynchronize(s.stream));
+	}
+	if (int rc = drain_redo(s)) /* asynchronous groups enqueued on this slot before */
+		return rc;
 	if (int rc = harvest(s))
 		return rc;
 	u32 err = 0;
@@ -1204,7 +1428,7 @@ int kmc_hip_process_bins_device(kmc_hip_ctx *ctx, int dev, const kmc_hip_bin_par
 				Slot &sl = d.slot[t];
 				std::lock_guard<std::mutex> lck(sl.mtx);
 				sl.timed = (sl.async_seq++ % TIMING_SAMPLE) == 0;
-				rc = run_group_device(sl, P, grp.data(), (u32)grp.size(), lut_entries);
+				rc = run_group_async(sl, P, grp.data(), (u32)grp.size(), lut_entries);
 			}
 			grp.clear();
 			grp_recs = 0;
@@ -1249,6 +1473,22 @@ int kmc_hip_process_bins_device(kmc_hip_ctx *ctx, int dev, const kmc_hip_bin_par
 	for (int t = 0; t < n_streams; ++t)
 		if (rcs[t])
 			return fail(rcs[t], msgs[t]);
+	return 0;
+}
+
+/* the kernels of the host-boundary bin whose image is in s.in, and the copy of its results block to pinned memory (caller holds s.mtx) */
+static int enqueue_host_bin(Slot &s, bool classic)
+{
+	const DevParams &P = s.sub_P;
+	if (int rc = run_bin_device(s, P, (const uint8_t *)s.in.p, s.sub_size, s.sub_n_rec, (const u64 *)s.pack_start.p, s.sub_np, (uint8_t *)s.out.p,
+	                            P.without_output ? 0 : s.out_capacity, nullptr /* out_bytes and stats: the slot's small block */, (u64 *)s.lut.p,
+	                            s.lut_entries, nullptr, classic))
+		return rc;
+	if (s.sub_n_rec == 0) /* the empty-bin path does not touch the small block */
+		HIPCHK(hipMemsetAsync(s.zero.p, 0, 64, s.stream));
+	HIPCHK(hipMemcpyAsync(small_ptr<u32>(s, SM_ERR), s.sticky.p, 4, hipMemcpyDeviceToDevice, s.stream));
+	HIPCHK(hipMemcpyAsync(s.h_res, s.zero.p, sizeof(HostRes), hipMemcpyDeviceToHost, s.stream));
+	HIPCHK(hipEventRecord(s.done_ev, s.stream));
 	return 0;
 }
 
@@ -1315,15 +1555,14 @@ int kmc_hip_process_bin_submit(kmc_hip_ctx *ctx, int dev, int slot, const kmc_hi
 		HIPCHK(hipMemcpyAsync(s.pack_start.p, ps.data(), (np + 1) * 8, hipMemcpyHostToDevice, s.stream));
 	}
 	s.timed = true;
-	if ((rc = run_bin_device(s, P, (const uint8_t *)s.in.p, size, n_rec, (const u64 *)s.pack_start.p, np, (uint8_t *)s.out.p,
-	                         P.without_output ? 0 : out_capacity, nullptr /* out_bytes and stats: the slot's small block */, (u64 *)s.lut.p,
-	                         lut_entries, nullptr)))
+	s.sub_P = P;
+	s.sub_size = size;
+	s.sub_n_rec = n_rec;
+	s.sub_np = np;
+	s.out_capacity = out_capacity;
+	s.lut_entries = lut_entries;
+	if ((rc = enqueue_host_bin(s, false)))
 		return rc;
-	if (n_rec == 0) /* the empty-bin path does not touch the small block */
-		HIPCHK(hipMemsetAsync(s.zero.p, 0, 64, s.stream));
-	HIPCHK(hipMemcpyAsync(small_ptr<u32>(s, SM_ERR), s.sticky.p, 4, hipMemcpyDeviceToDevice, s.stream));
-	HIPCHK(hipMemcpyAsync(s.h_res, s.zero.p, sizeof(HostRes), hipMemcpyDeviceToHost, s.stream));
-	HIPCHK(hipEventRecord(s.done_ev, s.stream));
 	s.pending = true;
 	s.h_out = out_suffix;
 	s.h_lut = (u64 *)lut;
@@ -1347,7 +1586,14 @@ int kmc_hip_process_bin_wait(kmc_hip_ctx *ctx, int dev, int slot, uint64_t *out_
 	HIPCHK(hipEventSynchronize(s.done_ev)); /* blocks in the kernel driver instead of spinning */
 	if (int rc = harvest(s))
 		return rc;
-	const HostRes r = *s.h_res;
+	HostRes r = *s.h_res;
+	if (r.redo && !r.err) { /* the hybrid sort met a tile it could not handle: the bin again (its image is still in s.in), LSD passes over every byte */
+		g_redo_groups.fetch_add(1, std::memory_order_relaxed);
+		if (int rc = enqueue_host_bin(s, true))
+			return rc;
+		HIPCHK(hipEventSynchronize(s.done_ev));
+		r = *s.h_res;
+	}
 	if (r.err) {
 		HIPCHK(hipMemset(s.sticky.p, 0, 4));
 		return err_to_code(r.err);
@@ -1896,6 +2142,40 @@ int kmc_hip_scatter_totals(kmc_hip_ctx *ctx, int dev, int reset, uint64_t *n_lau
 		*total_ms = ms;
 	if (total_records)
 		*total_records = keys;
+	return 0;
+}
+
+int kmc_hip_local_sort_totals(kmc_hip_ctx *ctx, int dev, int reset, uint64_t *n_launches, double *total_ms, uint64_t *total_records, uint64_t *n_hybrid_groups,
+                              uint64_t *n_redo_groups)
+{
+	if (int rc = set_dev(ctx, dev))
+		return rc;
+	u64 nl = 0, keys = 0;
+	double ms = 0;
+	for (auto &s : ctx->devs[dev]->slot) {
+		std::lock_guard<std::mutex> lck(s.mtx);
+		HIPCHK(hipStreamSynchronize(s.stream));
+		if (int rc = harvest(s))
+			return rc;
+		nl += s.ls_launch_total;
+		keys += s.ls_keys_total;
+		ms += s.ls_ms_total;
+		if (reset) {
+			s.ls_launch_total = 0;
+			s.ls_keys_total = 0;
+			s.ls_ms_total = 0;
+		}
+	}
+	if (n_launches)
+		*n_launches = nl;
+	if (total_ms)
+		*total_ms = ms;
+	if (total_records)
+		*total_records = keys;
+	if (n_hybrid_groups)
+		*n_hybrid_groups = g_hybrid_groups.load();
+	if (n_redo_groups)
+		*n_redo_groups = g_redo_groups.load();
 	return 0;
 }
 

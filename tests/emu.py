@@ -15,7 +15,7 @@ EMU_DIR = os.path.join(ROOT, "tests", "hipemu")
 # Two builds of the same kernel source: the product's tile geometry (512-thread workgroups: hundreds of OS threads per emulated workgroup,
 # slow) and a small one (128/256-thread workgroups, 4 KB expand slices) that runs the same code paths ~10x faster. Tests use the small one
 # unless they ask for "product".
-GEOMETRY_FLAGS = {"small": ["-DCP_BLOCK_THREADS=128", "-DEXP_BLOCK_THREADS=256", "-DEXP_CHUNK_BYTES=4096", "-DRS_BLOCK_THREADS=256", "-DCP_FOLD_CHUNK=256", "-DS1_SK_TILE_N=64", "-DS1_PACK_BYTES_N=16384", "-DS1_SUB_N=2"], "product": []}
+GEOMETRY_FLAGS = {"small": ["-DCP_BLOCK_THREADS=128", "-DEXP_BLOCK_THREADS=256", "-DEXP_CHUNK_BYTES=4096", "-DRS_BLOCK_THREADS=256", "-DCP_FOLD_CHUNK=256", "-DS1_SK_TILE_N=64", "-DS1_PACK_BYTES_N=16384", "-DS1_SUB_N=2", "-DBS_BLOCK_THREADS=128", "-DBS_LOG_NB=7"], "product": []}
 _LIBS = {}
 
 
@@ -86,7 +86,7 @@ def build_hostlib(geometry="small", force=False) -> str:
     then run on a box without a GPU (small inputs: one OS thread per GPU thread)."""
     so = os.path.join(EMU_DIR, f"libkmc_hip_emu_{geometry}.so")
     csrc = os.path.join(ROOT, "kmc_amd", "csrc")
-    srcs = [os.path.join(csrc, f) for f in ("kmc_hip.hip", "kernels.hip.h", "kmer_ops.h", "stage1_kernels.hip.h", "stage1_chain.h")] + [
+    srcs = [os.path.join(csrc, f) for f in ("kmc_hip.hip", "kernels.hip.h", "bucket_sort.hip.h", "kmer_ops.h", "stage1_kernels.hip.h", "stage1_chain.h")] + [
         os.path.join(ROOT, "include", "kmc_hip.h"), os.path.join(EMU_DIR, "include", "hip", "hip_runtime.h"), os.path.join(EMU_DIR, "include", "hip", "hip_host_api.h"),
         os.path.join(EMU_DIR, "include", "rccl", "rccl.h"), os.path.abspath(__file__)]
     if force or not os.path.exists(so) or any(os.path.getmtime(x) > os.path.getmtime(so) for x in srcs):

@@ -70,10 +70,10 @@ template <int SIZE> int expand_t(const DevParams &P, const uint8_t *img, u64 siz
 	const u32 blocks = (u32)std::min<u64>(n_chunks, 4); /* persistent workgroups pulling slice tickets */
 	if (fuse)
 		hipemu::launch(dim3(blocks), dim3(EXP_BLOCK), exp_lds_bytes<true>(n_pass, P.k),
-		               [&] { k_expand<SIZE, true>(ge, P.k, P.both_strands, n_pass, ghist.data(), &counters[0], err, dbase, &counters[1]); });
+		               [&] { k_expand<SIZE, true>(ge, P.k, P.both_strands, n_pass, ghist.data(), &counters[0], err, dbase, &counters[1], 0u); });
 	else
 		hipemu::launch(dim3(blocks), dim3(EXP_BLOCK), exp_lds_bytes<false>(n_pass, P.k),
-		               [&] { k_expand<SIZE, false>(ge, P.k, P.both_strands, n_pass, ghist.data(), &counters[0], err, nullptr, &counters[1]); });
+		               [&] { k_expand<SIZE, false>(ge, P.k, P.both_strands, n_pass, ghist.data(), &counters[0], err, nullptr, &counters[1], 0u); });
 	return fuse ? 1 : 0;
 }
 
@@ -85,7 +85,7 @@ template <int SIZE> u64 *sort_t(u64 *a, u64 *b, u64 n, u32 n_pass, const u64 *db
 	if (hist_done)
 		memcpy(dbase.data(), dbase_in, dbase.size() * 8);
 	else {
-		hipemu::launch(dim3((u32)std::min<u64>((n + 255) / 256, 4)), dim3(256), (size_t)n_pass * 1024, [&] { k_hist<SIZE>(a, n, n_pass, ghist.data()); });
+		hipemu::launch(dim3((u32)std::min<u64>((n + 255) / 256, 4)), dim3(256), (size_t)n_pass * 1024, [&] { k_hist<SIZE>(a, n, n_pass, ghist.data(), 0u); });
 		hipemu::launch(dim3(n_pass), dim3(256), 0, [&] { k_hist_scan(ghist.data(), dbase.data()); });
 	}
 	u64 *src = a, *dst = b;
@@ -218,7 +218,7 @@ int group_front_t(const DevParams &P, int g, const uint8_t *const *imgs, const u
 	hipemu::launch(dim3((u32)packs), dim3(256), 0, [&] { k_parse_packs(gp, P.k, err); });
 	const u32 blocks = (u32)std::min<u64>(chunks, 3);
 	hipemu::launch(dim3(blocks), dim3(EXP_BLOCK), exp_lds_bytes<true>(n_pass, P.k),
-	               [&] { k_expand<SIZE, true>(ge, P.k, P.both_strands, n_pass, ghist.data(), &counters[0], err, dbase.data(), &counters[1]); });
+	               [&] { k_expand<SIZE, true>(ge, P.k, P.both_strands, n_pass, ghist.data(), &counters[0], err, dbase.data(), &counters[1], 0u); });
 	/* the fused histograms must cover every record of the group, tag included: digit totals == records */
 	for (u32 b = 0; b < n_pass; ++b) {
 		u64 tot = 0;
