@@ -9,8 +9,8 @@
  *   k_bucket_bounds   cuts the array into tiles that start and end on bucket boundaries: tile j = the buckets that START in
  *                     window [j S, (j+1) S). One wave per window finds "first bucket boundary at or after j S".
  *   k_bucket_sort     one workgroup per tile: records -> registers -> LDS, grouped by an order-preserving sub-bucket number
- *                     (the tile's key range cut into NB equal slices: counting with returning LDS atomics, one scan, one
- *                     placement), then every sub-bucket (a few records, or the copies of one k-mer) is finished by one thread
+ *                     (every bucket of the tile cut into as many equal slices as it has records: counting with returning LDS
+ *                     atomics, one scan, one placement), then every sub-bucket (a few records, or the copies of one k-mer) is finished by one thread
  *                     with an insertion sort whose fast path is "not smaller than the last one" (duplicates cost one compare);
  *                     the sorted tile is written back in place, coalesced. 8 B read + 8 B written per record, once, whatever k.
  *
@@ -30,13 +30,10 @@
 #include "kernels.hip.h"
 
 #ifndef BS_BLOCK_THREADS
-#define BS_BLOCK_THREADS 768 /* 12 waves; two workgroups per CU at 56 KB of LDS each */
+#define BS_BLOCK_THREADS 768 /* 12 waves; two workgroups per CU at 72 KB of LDS each (records 48 KB + one counter per record slot) */
 #endif
 #ifndef BS_WORDS_PER_THREAD
 #define BS_WORDS_PER_THREAD 8 /* 8-byte words a thread holds while a tile is loaded */
-#endif
-#ifndef BS_LOG_NB
-#define BS_LOG_NB 11 /* sub-bucket counters per tile (2048): ~2-3 records per sub-bucket on distinct keys */
 #endif
 #ifndef BS_MOVE_LIMIT
 #define BS_MOVE_LIMIT 4096 /* record moves one thread may spend on its sub-buckets before the tile is handed back to the host */
@@ -47,13 +44,11 @@ template <int SIZE> struct BsCfg {
 	static constexpr int ITEMS = (BS_WORDS_PER_THREAD / SIZE) > 2 ? (BS_WORDS_PER_THREAD / SIZE) : 2;
 	static constexpr int CAP = THREADS * ITEMS;   /* records a tile may hold */
 	static constexpr int STRIDE = CAP / 3 * 2;    /* window length S: a tile is S records on average, CAP - S of slack for its last bucket */
-	static constexpr int LOG_NB = BS_LOG_NB, NB = 1 << LOG_NB;
 	static_assert(CAP < 65536, "tile-relative positions are kept in 16 bits");
-	static_assert(NB % 4 == 0 && NB / 4 <= THREADS, "the counter scan gives 4 counters to a thread");
 };
 template <int SIZE> constexpr size_t bs_lds_bytes()
 {
-	return (size_t)BsCfg<SIZE>::CAP * SIZE * 8 + ((size_t)BsCfg<SIZE>::NB + 1) * 4 + (BsCfg<SIZE>::THREADS / 64 + 2) * 4 + 16;
+	return (size_t)BsCfg<SIZE>::CAP * SIZE * 8 + ((size_t)BsCfg<SIZE>::CAP + 1) * 4 + (3 * (BsCfg<SIZE>::THREADS / 64) + 2) * 4 + 16;
 }
 /* average bucket size the host aims for when it picks H: two orders of magnitude below the slack, because k-mers that share a
  * minimizer are clustered (measured on the bench's bins: the largest of 2^22 buckets holds 100x the average) */
@@ -78,17 +73,29 @@ template <int SIZE> __device__ __forceinline__ u64 bs_p64(const u64 (&x)[SIZE], 
 	}
 }
 
-/* One wave per window j (0..n_win): bounds[j] = the first index i >= j S at which a bucket starts (i == 0, or the top `hbits`
+/* The arrays k_bucket_bounds cuts into tiles: the slices of up to GRP_MAX bins (a sort-only call: one array). Bin b has items
+ * item_prefix[b] .. item_prefix[b+1]-1 = its windows 0 .. n_win, one more than it has windows (bounds[n_win] = n). */
+struct GrpBounds {
+	u32 g, item_prefix[GRP_MAX + 1];
+	const u64 *S[GRP_MAX];
+	u64 n[GRP_MAX];
+	u64 *bounds[GRP_MAX];
+};
+
+/* One wave per window j (0..n_win) of a bin: bounds[j] = the first index i >= j stride at which a bucket starts (i == 0, or the top `hbits`
  * bits of record i differ from those of record i-1), n if there is none. hbits == 0: the whole array is one bucket. */
 template <int SIZE>
-__global__ void __launch_bounds__(256) k_bucket_bounds(const u64 *__restrict__ recs, u64 n, u64 n_win, u32 key_bits, u32 hbits, u64 *__restrict__ bounds)
+__global__ void __launch_bounds__(256) k_bucket_bounds(const GrpBounds gb, u32 stride, u32 key_bits, u32 hbits)
 {
-	constexpr u64 S = BsCfg<SIZE>::STRIDE;
 	const u32 lane = threadIdx.x & 63;
-	const u64 j = (u64)blockIdx.x * 4 + (threadIdx.x >> 6);
-	if (j > n_win)
+	const u32 item = blockIdx.x * 4 + (threadIdx.x >> 6);
+	if (item >= gb.item_prefix[gb.g])
 		return;
-	const u64 p = j * S;
+	const u32 bin = grp_find(gb.item_prefix, gb.g, item);
+	const u64 j = item - gb.item_prefix[bin];
+	const u64 *__restrict__ recs = gb.S[bin];
+	const u64 n = gb.n[bin];
+	const u64 p = j * stride;
 	u64 b;
 	if (j == 0)
 		b = 0;
@@ -121,11 +128,9 @@ __global__ void __launch_bounds__(256) k_bucket_bounds(const u64 *__restrict__ r
 			const bool t = in && bucket_at(q) != v;
 			const u64 m = __ballot(t), inm = __ballot(in);
 			if (m) {
-				const u64 f = (u64)(__ffsll((long long)m) - 1);
-				hi = lo + f * step;              /* the first probe in a different bucket: the answer is at or below it */
-				lo = f ? lo + (f - 1) * step + 1 : lo; /* f == 0: cannot happen (lo itself is probed and is still in bucket v or is the answer) */
-				if (f == 0)
-					hi = lo;
+				const u64 f = (u64)(__ffsll((long long)m) - 1); /* the first probe in a different bucket: the answer is at or below it, above the probe before it */
+				hi = lo + f * step;
+				lo = f ? hi - step + 1 : hi;
 			} else {
 				const u64 last = 63 - (u64)__clzll((long long)inm);
 				lo = lo + last * step + 1;
@@ -140,20 +145,30 @@ __global__ void __launch_bounds__(256) k_bucket_bounds(const u64 *__restrict__ r
 			b = lo;
 	}
 	if (lane == 0)
-		bounds[j] = b;
+		gb.bounds[bin][j] = b;
 }
 
-/* One workgroup per window j: sorts tile [bounds[j], bounds[j+1]) in place (empty when no bucket starts in the window). */
+/* One workgroup per window j: sorts tile [bounds[j], bounds[j+1]) in place (empty when no bucket starts in the window).
+ *
+ * Sub-buckets. K-mers of a signature bin are clustered (those that START with the bin's minimizers share 18+ bits: measured on the bench's
+ * bins, half of all records sit in buckets of more than 3x the average size), so cutting the tile's key range into equal slices leaves
+ * hundreds of distinct keys in one slice and none in most. Instead every bucket of the tile — a run of n_b records at tile positions
+ * [s, s + n_b), known from the bucket boundaries inside the tile — gets n_b counters of its own, [s, s + n_b), and a record goes to
+ *       id = s + floor(rem32 * n_b / 2^32)           rem32 = the 32 key bits below the bucket bits
+ * which is order-preserving, needs no table, and adapts to the density: one distinct key per counter on average wherever the bits below the
+ * bucket bits are uniform (they are: the clustering comes from the minimizer, and that sits in the bits above). */
 template <int SIZE>
 __global__ void __launch_bounds__(BsCfg<SIZE>::THREADS) k_bucket_sort(u64 *__restrict__ recs, u32 key_bits, u32 hbits, const u64 *__restrict__ bounds, u32 *flag)
 {
-	constexpr int THREADS = BsCfg<SIZE>::THREADS, ITEMS = BsCfg<SIZE>::ITEMS, CAP = BsCfg<SIZE>::CAP, NB = BsCfg<SIZE>::NB, LOG_NB = BsCfg<SIZE>::LOG_NB;
+	constexpr int THREADS = BsCfg<SIZE>::THREADS, ITEMS = BsCfg<SIZE>::ITEMS, CAP = BsCfg<SIZE>::CAP, NW = THREADS / 64;
 	constexpr u64 S = BsCfg<SIZE>::STRIDE;
+	constexpr u32 NONE = 0xFFFFFFFFu;
 	KMC_DYN_LDS(unsigned char, s_raw);
-	u64 *s_rec = reinterpret_cast<u64 *>(s_raw);                  /* [CAP * SIZE] record-major */
-	u32 *s_cnt = reinterpret_cast<u32 *>(s_rec + (size_t)CAP * SIZE); /* [NB + 1] counts -> first slot of each sub-bucket, [NB] = tile length */
-	u32 *s_tmp = s_cnt + NB + 1;                                  /* [THREADS/64 + 1] scan scratch, then [1] the "over budget" mark */
-	u32 *s_fail = s_tmp + THREADS / 64 + 1;
+	u64 *s_rec = reinterpret_cast<u64 *>(s_raw);                      /* [CAP * SIZE] record-major */
+	u32 *s_cnt = reinterpret_cast<u32 *>(s_rec + (size_t)CAP * SIZE); /* [CAP + 1] counts -> first slot of each sub-bucket */
+	u32 *s_tmp = s_cnt + CAP + 1;                                     /* [NW + 1] scan scratch */
+	u32 *s_wfirst = s_tmp + NW + 1, *s_wlast = s_wfirst + NW;         /* [NW] each: first / last bucket start inside wave w's rows */
+	u32 *s_fail = s_wlast + NW;
 
 	const u64 j = blockIdx.x;
 	const u64 b0 = bounds[j], b1 = bounds[j + 1];
@@ -165,31 +180,19 @@ __global__ void __launch_bounds__(BsCfg<SIZE>::THREADS) k_bucket_sort(u64 *__res
 		return;
 	}
 	const u32 len = (u32)(b1 - b0);
-	const u32 tid = threadIdx.x;
+	const u32 tid = threadIdx.x, lane = tid & 63;
+	const u32 wave = (u32)__builtin_amdgcn_readfirstlane((int)(tid >> 6));
 	u64 *__restrict__ T = recs + b0 * SIZE;
+	const u32 crel = wave * (ITEMS * 64); /* the wave owns ITEMS rows of 64 consecutive records */
 
-	/* the tile's key range, from its first and last bucket: [lo64, hi64] in units of the left-aligned top 64 key bits */
-	u64 lo64, hi64;
-	{
-		u64 f[SIZE], l[SIZE];
-		load_rec<SIZE>(T, f);
-		load_rec<SIZE>(T + (size_t)(len - 1) * SIZE, l);
-		const u64 hmask = hbits == 0 ? ~0ull : (hbits >= 64 ? 0ull : ((1ull << (64 - hbits)) - 1));
-		lo64 = bs_p64<SIZE>(f, key_bits) & ~hmask;
-		hi64 = bs_p64<SIZE>(l, key_bits) | hmask;
-	}
-	const u64 span = hi64 - lo64;
-	const u32 bits = span ? 64u - (u32)__clzll((long long)span) : 0u;
-	const u32 sh = bits > (u32)LOG_NB ? bits - LOG_NB : 0u; /* (span >> sh) < NB */
-
-	for (u32 i = tid; i <= (u32)NB; i += THREADS)
+	for (u32 i = tid; i <= (u32)CAP; i += THREADS)
 		s_cnt[i] = 0;
 	if (tid == 0)
 		*s_fail = 0;
 	u64 key[ITEMS][SIZE];
 #pragma unroll
 	for (int r = 0; r < ITEMS; ++r) {
-		const u32 idx = r * THREADS + tid;
+		const u32 idx = crel + r * 64 + lane;
 		if (idx < len)
 			load_rec<SIZE>(T + (size_t)idx * SIZE, key[r]);
 		else {
@@ -198,48 +201,103 @@ __global__ void __launch_bounds__(BsCfg<SIZE>::THREADS) k_bucket_sort(u64 *__res
 				key[r][w] = 0;
 		}
 	}
+	/* bucket starts ("heads") as one scalar mask per row */
+	const u32 bsh = 64 - hbits;
+	auto bucket_of = [&](const u64(&x)[SIZE]) -> u64 { return hbits ? bs_p64<SIZE>(x, key_bits) >> bsh : 0ull; };
+	u64 prev_last = 0; /* bucket of the record in front of the row */
+	if (crel > 0 && crel - 1 < len) {
+		u64 x[SIZE];
+		load_rec<SIZE>(T + (size_t)(crel - 1) * SIZE, x);
+		prev_last = bucket_of(x);
+	}
+	u64 heads[ITEMS];
+	u32 wfirst = NONE, wlast = NONE;
+#pragma unroll
+	for (int r = 0; r < ITEMS; ++r) {
+		const u32 rowrel = crel + r * 64, idx = rowrel + lane;
+		const u64 bk = bucket_of(key[r]);
+		u64 pv = __shfl_up(bk, 1);
+		if (lane == 0)
+			pv = prev_last;
+		const u64 m = __ballot(idx < len && (idx == 0 || pv != bk));
+		heads[r] = m;
+		if (m) {
+			if (wfirst == NONE)
+				wfirst = rowrel + (u32)__ffsll((long long)m) - 1;
+			wlast = rowrel + 63 - (u32)__clzll((long long)m);
+		}
+		prev_last = __shfl(bk, 63); /* lane 63's bucket in every lane */
+	}
+	if (lane == 0) {
+		s_wfirst[wave] = wfirst;
+		s_wlast[wave] = wlast;
+	}
 	__syncthreads();
-	/* sub-bucket number (order-preserving) and arrival rank inside the sub-bucket */
+	u32 carry_f = 0, carry_b = len; /* start of the bucket open at the wave's first record; first bucket start after the wave's last record */
+#pragma unroll
+	for (int w = 0; w < NW; ++w) {
+		const u32 l = s_wlast[w], f = s_wfirst[NW - 1 - w];
+		if (w < (int)wave && l != NONE)
+			carry_f = l;
+		if (NW - 1 - w > (int)wave && f != NONE)
+			carry_b = f;
+	}
+	carry_f = (u32)__builtin_amdgcn_readfirstlane((int)carry_f);
+	carry_b = (u32)__builtin_amdgcn_readfirstlane((int)carry_b);
+	/* end of every record's bucket (rows backwards), then its start (rows forwards) -> sub-bucket and arrival rank */
+	u32 bend[ITEMS];
+#pragma unroll
+	for (int r = ITEMS - 1; r >= 0; --r) {
+		const u32 rowrel = crel + r * 64;
+		const u64 m = heads[r];
+		const u64 above = m & ~(((2ull << lane) - 1)); /* heads at higher lanes (lane 63: none) */
+		bend[r] = above ? rowrel + (u32)__ffsll((long long)above) - 1 : carry_b;
+		if (m)
+			carry_b = rowrel + (u32)__ffsll((long long)m) - 1;
+	}
 	u32 ir[ITEMS]; /* [15:0] sub-bucket, [31:16] rank */
 #pragma unroll
 	for (int r = 0; r < ITEMS; ++r) {
-		const u32 idx = r * THREADS + tid;
+		const u32 rowrel = crel + r * 64, idx = rowrel + lane;
+		const u64 m = heads[r];
+		const u64 upto = m & ((2ull << lane) - 1); /* heads at this lane or below */
+		const u32 bstart = upto ? rowrel + 63 - (u32)__clzll((long long)upto) : carry_f;
+		if (m)
+			carry_f = rowrel + 63 - (u32)__clzll((long long)m);
 		ir[r] = 0;
 		if (idx < len) {
-			const u64 rel = (bs_p64<SIZE>(key[r], key_bits) - lo64) >> sh;
-			const u32 id = rel < (u64)NB ? (u32)rel : (u32)NB - 1; /* in range by construction; the clamp is for records of a corrupt bin (bits above the
-			                                                          * key, a count that disagrees with the stream: the error word is already set) */
+			const u64 p = bs_p64<SIZE>(key[r], key_bits);
+			const u32 rem32 = (u32)((hbits ? (p << hbits) : p) >> 32);
+			u32 id = bstart + __umulhi(rem32, bend[r] - bstart);
+			id = id < len ? id : len - 1; /* in range by construction; the clamp is for records of a corrupt bin (bits above the key, a count that
+			                               * disagrees with the stream: the error word is already set) */
 			const u32 rk = __hip_atomic_fetch_add(&s_cnt[id], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 			ir[r] = id | (rk << 16);
 		}
 	}
 	__syncthreads();
-	/* counts -> first slots: thread t < NB/4 owns counters 4t .. 4t+3 */
+	/* counts -> first slots: thread t owns counters ITEMS t .. ITEMS t + ITEMS - 1 */
 	{
-		u32 c[4] = {0, 0, 0, 0}, sum = 0;
-		if (tid < (u32)NB / 4) {
+		u32 c[ITEMS], sum = 0;
 #pragma unroll
-			for (int q = 0; q < 4; ++q) {
-				c[q] = s_cnt[tid * 4 + q];
-				sum += c[q];
-			}
+		for (int q = 0; q < ITEMS; ++q) {
+			c[q] = s_cnt[tid * ITEMS + q];
+			sum += c[q];
 		}
 		u32 total;
-		u32 run = block_excl_sum<THREADS / 64, u32>(sum, s_tmp, total);
-		if (tid < (u32)NB / 4) {
+		u32 run = block_excl_sum<NW, u32>(sum, s_tmp, total);
 #pragma unroll
-			for (int q = 0; q < 4; ++q) {
-				s_cnt[tid * 4 + q] = run;
-				run += c[q];
-			}
+		for (int q = 0; q < ITEMS; ++q) {
+			s_cnt[tid * ITEMS + q] = run;
+			run += c[q];
 		}
 		if (tid == 0)
-			s_cnt[NB] = total; /* == len */
+			s_cnt[CAP] = total; /* == len */
 	}
 	__syncthreads();
 #pragma unroll
 	for (int r = 0; r < ITEMS; ++r) {
-		const u32 idx = r * THREADS + tid;
+		const u32 idx = crel + r * 64 + lane;
 		if (idx < len) {
 			const u32 pos = s_cnt[ir[r] & 0xFFFFu] + (ir[r] >> 16);
 			store_rec<SIZE>(s_rec + (size_t)pos * SIZE, key[r]);
@@ -249,9 +307,8 @@ __global__ void __launch_bounds__(BsCfg<SIZE>::THREADS) k_bucket_sort(u64 *__res
 	/* every sub-bucket is finished by one thread. The common shapes — one or two distinct k-mers, each with all its copies — cost one
 	 * compare per record ("not smaller than the largest so far"). */
 	{
-		const u32 n_ids = (u32)(span >> sh) + 1; /* <= NB */
 		u32 moves = 0;
-		for (u32 id = tid; id < n_ids; id += THREADS) {
+		for (u32 id = tid; id < len; id += THREADS) {
 			const u32 a = s_cnt[id], b = s_cnt[id + 1];
 			if (b - a < 2)
 				continue;
@@ -289,14 +346,389 @@ __global__ void __launch_bounds__(BsCfg<SIZE>::THREADS) k_bucket_sort(u64 *__res
 	}
 	__syncthreads();
 	if (*s_fail && tid == 0)
-		atomicOr(flag, 1u); /* many distinct keys that the tile's NB slices do not separate: LSD passes will sort them (the tile stays a permutation) */
+		atomicOr(flag, 1u); /* many distinct keys that the sub-buckets do not separate: LSD passes will sort them (the tile stays a permutation) */
+	for (u32 idx = tid; idx < len; idx += THREADS) {
+		u64 x[SIZE];
+		load_rec<SIZE>(s_rec + (size_t)idx * SIZE, x);
+		store_rec<SIZE>(T + (size_t)idx * SIZE, x);
+	}
+}
+
+/* ================================================================================================ fused: tile -> (k-mer, count) records
+ * What stage 2 wants from the sort is not the sorted records but the RUNS of equal k-mers: ascending distinct k-mers with their counts
+ * (kb_sorter.h:1128-1281). All copies of a k-mer share their bucket, hence their tile, hence their sub-bucket — so a tile can be counted
+ * without ever being sorted:
+ *   1  records -> registers and, in arrival order, LDS; bucket boundaries -> sub-bucket id as in k_bucket_sort; count per sub-bucket (LDS
+ *      atomics, nothing returned); scan: sub-bucket i owns slots [base[i], base[i+1]) of a tag array — as many slots as it has records
+ *   2  every record looks for its k-mer in its sub-bucket's slots, open addressing from a hashed start: an empty slot is claimed with a
+ *      compare-and-swap (tag = the claiming record's position, count 1), a slot whose owner holds the same k-mer gets its count bumped.
+ *      This is the run-length counting, parallel over RECORDS: 30x coverage costs one probe and one add per copy.
+ *   3  one thread per sub-bucket packs the claimed slots to the front of the region, orders them by their owners' k-mers (one or two
+ *      distinct k-mers per sub-bucket on average, bucket_sort's id function) and applies the cutoffs and the clamp (kb_sorter.h:1174-1192)
+ *   4  the tag array now lists the tile's distinct k-mers in ascending order: ranks of the counted ones by ballot + mbcnt, records assembled in
+ *      LDS and written to the tile's span of the free record array, the tile's count to status[tile] (two-phase output: k_compact_fold turns the
+ *      counts into offsets, k_compact_gather moves the records), per-tile aggregated LUT atomics and sharded tallies exactly as k_compact.
+ * HBM traffic per record: the 8 SIZE bytes of its one read. A tile longer than `max_len` (LDS capacity, or what its span can hold at
+ * cutoff_min 1) or a sub-bucket with too many distinct k-mers out of order sets *flag: the host runs the group again with LSD passes over every
+ * byte and k_compact. */
+#ifndef BC_BLOCK_THREADS
+#define BC_BLOCK_THREADS 512 /* 8 waves, 4096-record tiles of one-word records: 64 KB of LDS, two workgroups per CU */
+#endif
+template <int SIZE> struct BcCfg {
+	static constexpr int THREADS = BC_BLOCK_THREADS;
+	static constexpr int ITEMS = (BS_WORDS_PER_THREAD / SIZE) > 2 ? (BS_WORDS_PER_THREAD / SIZE) : 2;
+	static constexpr int CAP = THREADS * ITEMS;
+	static constexpr int STRIDE = CAP / 4 * 3; /* window length; CAP / STRIDE = 4/3 so that a full tile's records fit its span even when every k-mer is counted */
+	static_assert(CAP < 65535, "positions + 1 are kept in 16 bits");
+};
+template <int SIZE> constexpr size_t bc_lds_bytes()
+{
+	return (size_t)BcCfg<SIZE>::CAP * SIZE * 8 + ((size_t)2 * BcCfg<SIZE>::CAP + 2) * 4 + (7 * (BcCfg<SIZE>::THREADS / 64) + 4) * 4 + 16;
+}
+template <int SIZE> constexpr u64 bc_target_bucket() { return (BcCfg<SIZE>::CAP - BcCfg<SIZE>::STRIDE) / 64 > 4 ? (BcCfg<SIZE>::CAP - BcCfg<SIZE>::STRIDE) / 64 : 4; }
+
+struct GrpBucket {
+	u32 g, win_prefix[GRP_MAX + 1]; /* windows (= tiles) of bin b */
+	const u64 *S[GRP_MAX];          /* the bin's slice of the record array, ordered by the top `hbits` key bits */
+	const u64 *bounds[GRP_MAX];     /* [windows + 1] tile boundaries (k_bucket_bounds) */
+	uint8_t *scratch[GRP_MAX];      /* tile t's records go to scratch + t * pitch */
+	u64 *status[GRP_MAX];           /* tile t's number of counted k-mers */
+	u64 *lut_base[GRP_MAX];
+	u64 *tally[GRP_MAX];            /* [CP_SHARDS][4] */
+};
+
+template <int SIZE>
+__global__ void __launch_bounds__(BcCfg<SIZE>::THREADS) k_bucket_count(const GrpBucket gb, DevParams P, u32 key_bits, u32 hbits, u32 max_len, u32 lut_shards, u64 lut_stride,
+                                                                    u32 lut_mask, u64 pitch, u32 *flag)
+{
+	constexpr int THREADS = BcCfg<SIZE>::THREADS, ITEMS = BcCfg<SIZE>::ITEMS, CAP = BcCfg<SIZE>::CAP, NW = THREADS / 64;
+	constexpr u64 S = BcCfg<SIZE>::STRIDE;
+	constexpr u32 NONE = 0xFFFFFFFFu;
+	KMC_DYN_LDS(unsigned char, s_raw);
+	u64 *s_rec = reinterpret_cast<u64 *>(s_raw);                      /* [CAP * SIZE] records in arrival order; later the output staging area */
+	u32 *s_cnt = reinterpret_cast<u32 *>(s_rec + (size_t)CAP * SIZE); /* [CAP + 1] records per sub-bucket -> first slot; later the LUT prefixes of the counted k-mers */
+	u32 *s_tag = s_cnt + CAP + 1;                                     /* [CAP] [15:0] owner position + 1 (0 = free), [31:16] count */
+	u32 *s_tmp = s_tag + CAP;                                         /* [NW + 1] */
+	u32 *s_wfirst = s_tmp + NW + 1, *s_wlast = s_wfirst + NW;         /* [NW] each */
+	u32 *s_wcnt = s_wlast + NW;                                       /* [NW] counted k-mers of wave w */
+	u32 *s_wtal = s_wcnt + NW;                                        /* [NW][3] distinct / below min / above max */
+	u32 *s_fail = s_wtal + 3 * NW;
+
+	const u32 gtile = blockIdx.x;
+	const u32 bin = (u32)__builtin_amdgcn_readfirstlane((int)grp_find(gb.win_prefix, gb.g, gtile));
+	const u32 tile = gtile - gb.win_prefix[bin];
+	const u64 *__restrict__ bounds = gb.bounds[bin];
+	const u64 b0 = bounds[tile], b1 = bounds[tile + 1];
+	if (b0 >= ((u64)tile + 1) * S || b0 >= b1)
+		return; /* no bucket starts in this window: status[tile] stays 0 */
+	if (b1 - b0 > (u64)max_len) {
+		if (threadIdx.x == 0)
+			atomicOr(flag, 1u);
+		return;
+	}
+	const u32 len = (u32)(b1 - b0);
+	const u32 tid = threadIdx.x, lane = tid & 63;
+	const u32 wave = (u32)__builtin_amdgcn_readfirstlane((int)(tid >> 6));
+	const u64 *__restrict__ T = gb.S[bin] + b0 * SIZE;
+	const u32 crel = wave * (ITEMS * 64);
+	const u32 rec_bytes = P.sbytes + P.cbytes;
+	const bool use_lut = P.lut_prefix_len != 0 && !P.kff && !P.without_output;
+
+	for (u32 i = tid; i <= (u32)CAP; i += THREADS)
+		s_cnt[i] = 0;
+	for (u32 i = tid; i < (u32)CAP; i += THREADS)
+		s_tag[i] = 0;
+	if (tid == 0)
+		*s_fail = 0;
+	u64 key[ITEMS][SIZE];
 #pragma unroll
 	for (int r = 0; r < ITEMS; ++r) {
-		const u32 idx = r * THREADS + tid;
+		const u32 idx = crel + r * 64 + lane;
 		if (idx < len) {
-			u64 x[SIZE];
-			load_rec<SIZE>(s_rec + (size_t)idx * SIZE, x);
-			store_rec<SIZE>(T + (size_t)idx * SIZE, x);
+			load_rec<SIZE>(T + (size_t)idx * SIZE, key[r]);
+			store_rec<SIZE>(s_rec + (size_t)idx * SIZE, key[r]);
+		} else {
+#pragma unroll
+			for (int w = 0; w < SIZE; ++w)
+				key[r][w] = 0;
+		}
+	}
+	/* ---- 1: bucket starts, one scalar mask per row */
+	const u32 bsh = 64 - hbits;
+	auto bucket_of = [&](const u64(&x)[SIZE]) -> u64 { return hbits ? bs_p64<SIZE>(x, key_bits) >> bsh : 0ull; };
+	u64 prev_last = 0;
+	if (crel > 0 && crel - 1 < len) {
+		u64 x[SIZE];
+		load_rec<SIZE>(T + (size_t)(crel - 1) * SIZE, x);
+		prev_last = bucket_of(x);
+	}
+	u64 heads[ITEMS];
+	u32 wfirst = NONE, wlast = NONE;
+#pragma unroll
+	for (int r = 0; r < ITEMS; ++r) {
+		const u32 rowrel = crel + r * 64, idx = rowrel + lane;
+		const u64 bk = bucket_of(key[r]);
+		u64 pv = __shfl_up(bk, 1);
+		if (lane == 0)
+			pv = prev_last;
+		const u64 m = __ballot(idx < len && (idx == 0 || pv != bk));
+		heads[r] = m;
+		if (m) {
+			if (wfirst == NONE)
+				wfirst = rowrel + (u32)__ffsll((long long)m) - 1;
+			wlast = rowrel + 63 - (u32)__clzll((long long)m);
+		}
+		prev_last = __shfl(bk, 63);
+	}
+	if (lane == 0) {
+		s_wfirst[wave] = wfirst;
+		s_wlast[wave] = wlast;
+	}
+	__syncthreads();
+	u32 carry_f = 0, carry_b = len;
+#pragma unroll
+	for (int w = 0; w < NW; ++w) {
+		const u32 l = s_wlast[w], f = s_wfirst[NW - 1 - w];
+		if (w < (int)wave && l != NONE)
+			carry_f = l;
+		if (NW - 1 - w > (int)wave && f != NONE)
+			carry_b = f;
+	}
+	carry_f = (u32)__builtin_amdgcn_readfirstlane((int)carry_f);
+	carry_b = (u32)__builtin_amdgcn_readfirstlane((int)carry_b);
+	u32 bend[ITEMS];
+#pragma unroll
+	for (int r = ITEMS - 1; r >= 0; --r) {
+		const u32 rowrel = crel + r * 64;
+		const u64 m = heads[r];
+		const u64 above = m & ~(((2ull << lane) - 1));
+		bend[r] = above ? rowrel + (u32)__ffsll((long long)above) - 1 : carry_b;
+		if (m)
+			carry_b = rowrel + (u32)__ffsll((long long)m) - 1;
+	}
+	u32 sub[ITEMS]; /* the record's sub-bucket */
+#pragma unroll
+	for (int r = 0; r < ITEMS; ++r) {
+		const u32 rowrel = crel + r * 64, idx = rowrel + lane;
+		const u64 m = heads[r];
+		const u64 upto = m & ((2ull << lane) - 1);
+		const u32 bstart = upto ? rowrel + 63 - (u32)__clzll((long long)upto) : carry_f;
+		if (m)
+			carry_f = rowrel + 63 - (u32)__clzll((long long)m);
+		sub[r] = 0;
+		if (idx < len) {
+			const u64 p = bs_p64<SIZE>(key[r], key_bits);
+			const u32 rem32 = (u32)((hbits ? (p << hbits) : p) >> 32);
+			u32 id = bstart + __umulhi(rem32, bend[r] - bstart);
+			id = id < len ? id : len - 1; /* in range by construction; the clamp is for records of a corrupt bin (the error word is already set) */
+			sub[r] = id;
+			(void)__hip_atomic_fetch_add(&s_cnt[id], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+		}
+	}
+	__syncthreads();
+	{
+		u32 c[ITEMS], sum = 0;
+#pragma unroll
+		for (int q = 0; q < ITEMS; ++q) {
+			c[q] = s_cnt[tid * ITEMS + q];
+			sum += c[q];
+		}
+		u32 total;
+		u32 run = block_excl_sum<NW, u32>(sum, s_tmp, total);
+#pragma unroll
+		for (int q = 0; q < ITEMS; ++q) {
+			s_cnt[tid * ITEMS + q] = run;
+			run += c[q];
+		}
+		if (tid == 0)
+			s_cnt[CAP] = total;
+	}
+	__syncthreads();
+	/* ---- 2: count the copies. Region of sub-bucket i: slots [s_cnt[i], s_cnt[i+1]) — one slot per record, so a free slot always exists. */
+#pragma unroll
+	for (int r = 0; r < ITEMS; ++r) {
+		const u32 idx = crel + r * 64 + lane;
+		if (idx < len) {
+			const u32 a = s_cnt[sub[r]], nreg = s_cnt[sub[r] + 1] - a;
+			u32 h = 0;
+#pragma unroll
+			for (int w = 0; w < SIZE; ++w)
+				h = (h ^ (u32)key[r][w] ^ (u32)(key[r][w] >> 32)) * 0x9E3779B1u;
+			h ^= h >> 15;
+			u32 slot = a + __umulhi(h * 0x85EBCA6Bu, nreg);
+			for (u32 probe = 0; probe < nreg; ++probe) {
+				u32 w = __hip_atomic_load(&s_tag[slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+				if (w == 0) {
+					w = atomicCAS(&s_tag[slot], 0u, (1u << 16) | (idx + 1));
+					if (w == 0)
+						break; /* claimed: this record represents its k-mer */
+				}
+				u64 o[SIZE];
+				load_rec<SIZE>(s_rec + (size_t)((w & 0xFFFFu) - 1) * SIZE, o);
+				if (kmc_equal<SIZE>(o, key[r])) {
+					(void)__hip_atomic_fetch_add(&s_tag[slot], 1u << 16, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+					break;
+				}
+				slot = slot + 1 == a + nreg ? a : slot + 1;
+			}
+		}
+	}
+	__syncthreads();
+	/* ---- 3: per sub-bucket: claimed slots to the front, ordered by k-mer, cutoffs and clamp. Dropped k-mers keep their slot with count 0. */
+	u32 nu = 0, nb = 0, na = 0;
+	{
+		u32 moves = 0;
+		for (u32 id = tid; id < len; id += THREADS) {
+			const u32 a = s_cnt[id], b = s_cnt[id + 1];
+			if (a == b)
+				continue;
+			u32 d = 0;
+			for (u32 i = a; i < b; ++i) {
+				const u32 w = s_tag[i];
+				if (w) {
+					if (i != a + d) {
+						s_tag[a + d] = w;
+						s_tag[i] = 0;
+					}
+					++d;
+				}
+			}
+			for (u32 i = a + 1; i < a + d; ++i) {
+				const u32 w = s_tag[i];
+				u64 x[SIZE];
+				load_rec<SIZE>(s_rec + (size_t)((w & 0xFFFFu) - 1) * SIZE, x);
+				u32 q = i;
+				while (q > a) {
+					const u32 wy = s_tag[q - 1];
+					u64 y[SIZE];
+					load_rec<SIZE>(s_rec + (size_t)((wy & 0xFFFFu) - 1) * SIZE, y);
+					if (!kmc_less<SIZE>(x, y))
+						break;
+					s_tag[q] = wy;
+					--q;
+					++moves;
+				}
+				s_tag[q] = w;
+			}
+			for (u32 i = a; i < a + d; ++i) {
+				u32 w = s_tag[i];
+				const u32 c = w >> 16;
+				++nu;
+				if (c < P.cutoff_min) {
+					++nb;
+					w &= 0xFFFFu;
+				} else if (c > P.cutoff_max) {
+					++na;
+					w &= 0xFFFFu;
+				} else
+					w = (w & 0xFFFFu) | ((c > P.counter_max ? P.counter_max : c) << 16);
+				s_tag[i] = w;
+			}
+			if (moves > (u32)BS_MOVE_LIMIT) {
+				*s_fail = 1;
+				break;
+			}
+		}
+	}
+	nu = wave_sum<u32>(nu);
+	nb = wave_sum<u32>(nb);
+	na = wave_sum<u32>(na);
+	if (lane == 0) {
+		s_wtal[wave * 3 + 0] = nu;
+		s_wtal[wave * 3 + 1] = nb;
+		s_wtal[wave * 3 + 2] = na;
+	}
+	__syncthreads();
+	if (*s_fail) {
+		if (tid == 0)
+			atomicOr(flag, 1u);
+		return; /* the group is run again by the host; nothing of this tile was published */
+	}
+	/* ---- 4: the tag array in position order = the distinct k-mers in ascending order */
+	u32 wv[ITEMS], rk[ITEMS], nc = 0;
+	u64 kx[ITEMS][SIZE];
+#pragma unroll
+	for (int r = 0; r < ITEMS; ++r) {
+		const u32 pos = crel + r * 64 + lane;
+		const u32 w = pos < len ? s_tag[pos] : 0u;
+		const bool em = (w >> 16) != 0;
+		const u64 m = __ballot(em);
+		wv[r] = em ? w : 0u;
+		rk[r] = __builtin_amdgcn_mbcnt_hi((u32)(m >> 32), __builtin_amdgcn_mbcnt_lo((u32)m, nc));
+		nc += (u32)__popcll(m);
+		if (em) {
+			load_rec<SIZE>(s_rec + (size_t)((w & 0xFFFFu) - 1) * SIZE, kx[r]);
+			kmc_mask_low<SIZE>(kx[r], 2 * P.k); /* drops a group tag above the k-mer (KFF records carry the top bytes) */
+		} else {
+#pragma unroll
+			for (int q = 0; q < SIZE; ++q)
+				kx[r][q] = 0;
+		}
+	}
+	if (lane == 0)
+		s_wcnt[wave] = nc;
+	__syncthreads(); /* every k-mer this tile emits is in registers: s_rec becomes the staging area, s_cnt the prefix list */
+	u32 wave_off = 0, tile_counted = 0;
+#pragma unroll
+	for (int w = 0; w < NW; ++w) {
+		const u32 x = s_wcnt[w];
+		if (w < (int)wave)
+			wave_off += x;
+		tile_counted += x;
+	}
+	if (tid == 0) {
+		u32 tu = 0, tb = 0, ta = 0;
+#pragma unroll
+		for (int w = 0; w < NW; ++w) {
+			tu += s_wtal[w * 3 + 0];
+			tb += s_wtal[w * 3 + 1];
+			ta += s_wtal[w * 3 + 2];
+		}
+		u64 *sh = gb.tally[bin] + (size_t)(tile % CP_SHARDS) * 4;
+		if (tu)
+			atomicAdd(&sh[0], (u64)tu);
+		if (tb)
+			atomicAdd(&sh[1], (u64)tb);
+		if (ta)
+			atomicAdd(&sh[2], (u64)ta);
+		if (!P.without_output)
+			gb.status[bin][tile] = tile_counted;
+	}
+	if (P.without_output || tile_counted == 0)
+		return;
+	uint8_t *s_stage = reinterpret_cast<uint8_t *>(s_rec);
+	u32 *s_pref = s_cnt;
+	const u32 pshift = 2 * (P.k - P.lut_prefix_len);
+#pragma unroll
+	for (int r = 0; r < ITEMS; ++r) {
+		if (wv[r]) {
+			const u32 rank = wave_off + rk[r];
+			const u32 cntv = wv[r] >> 16;
+			if (use_lut)
+				s_pref[rank] = (u32)kmc_remove_suffix<SIZE>(kx[r], pshift) & lut_mask;
+			uint8_t *dstb = s_stage + (size_t)rank * rec_bytes;
+			for (u32 q = 0; q < P.sbytes; ++q)
+				dstb[q] = (uint8_t)kmc_get_byte<SIZE>(kx[r], P.sbytes - 1 - q); /* suffix bytes high -> low (kb_sorter.h:1198-1199) */
+			for (u32 q = 0; q < P.cbytes; ++q)
+				dstb[P.sbytes + q] = (uint8_t)(cntv >> (8 * (P.kff ? (P.cbytes - 1 - q) : q))); /* :1200-1201 / KFF :1210-1211 */
+		}
+	}
+	__syncthreads();
+	{
+		const u32 tile_bytes = tile_counted * rec_bytes; /* <= pitch: the host checked max_len against the span */
+		u32 *dst32 = reinterpret_cast<u32 *>(gb.scratch[bin] + (u64)tile * pitch);
+		const u32 *src32 = reinterpret_cast<const u32 *>(s_stage);
+		for (u32 wd = tid; wd < (tile_bytes + 3) / 4; wd += THREADS)
+			dst32[wd] = src32[wd];
+	}
+	if (use_lut) {
+		u64 *lut = gb.lut_base[bin] + (size_t)(tile % lut_shards) * lut_stride;
+		for (u32 q = tid; q < tile_counted; q += THREADS) {
+			const u32 pf = s_pref[q];
+			if (q + 1 == tile_counted || s_pref[q + 1] != pf)
+				atomicAdd(&lut[pf], (u64)(q + 1));
+			if (q > 0 && s_pref[q - 1] != pf)
+				atomicAdd(&lut[pf], (u64)0 - (u64)q);
 		}
 	}
 }

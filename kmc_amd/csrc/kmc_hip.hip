@@ -187,6 +187,8 @@ template <int SIZE> int set_func_attrs()
 	if (rs_lds_bytes<SIZE>() > 65536)
 		HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_onesweep<SIZE>), hipFuncAttributeMaxDynamicSharedMemorySize,
 		                           (int)rs_lds_bytes<SIZE>()));
+	if (bc_lds_bytes<SIZE>() > 65536)
+		HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_bucket_count<SIZE>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bc_lds_bytes<SIZE>()));
 	if (bs_lds_bytes<SIZE>() > 65536)
 		HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_bucket_sort<SIZE>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bs_lds_bytes<SIZE>()));
 	if (exp_lds_bytes<true>(EXP_FUSE_MAX_PASS, 1) > 65536) /* worst case: the shortest records (smallest k) and 16 fused passes */
@@ -327,7 +329,7 @@ int hybrid_mode()
 	}();
 	return v;
 }
-template <int SIZE> SortPlan plan_sort(u64 n, u32 key_bytes, u32 key_bits, bool classic)
+template <int SIZE> SortPlan plan_sort(u64 n, u32 key_bytes, u32 key_bits, bool classic, bool fused = false /* k_bucket_count's tiles, not k_bucket_sort's */)
 {
 	SortPlan sp;
 	sp.key_bytes = sp.top = key_bytes;
@@ -349,10 +351,10 @@ template <int SIZE> SortPlan plan_sort(u64 n, u32 key_bytes, u32 key_bits, bool 
 	for (u32 h = 0; h + 2 <= key_bytes && h <= 4; ++h) {
 		bool ok;
 		if (h == 0)
-			ok = n <= (u64)BsCfg<SIZE>::CAP;
+			ok = !fused && n <= (u64)BsCfg<SIZE>::CAP; /* groups always take one pass at least: the bins' tags must be ordered */
 		else {
 			const u32 eff = 8 * h > spare ? 8 * h - spare : 0;
-			ok = eff > 0 && (eff >= 63 || (n >> eff) <= bs_target_bucket<SIZE>());
+			ok = eff > 0 && (eff >= 63 || (n >> eff) <= (fused ? bc_target_bucket<SIZE>() : bs_target_bucket<SIZE>()));
 		}
 		if (ok) {
 			sp.top = h;
@@ -365,7 +367,8 @@ template <int SIZE> SortPlan plan_sort(u64 n, u32 key_bytes, u32 key_bits, bool 
 /* lays out the zero region of a group: small block | per bin: bitmap, expand look-back words, compaction look-back words, LUT shards, tally
  * shards | digit histograms | one scatter status area per onesweep launch over the group's `n_total` records */
 template <int SIZE>
-ZeroPlan plan_group(const Slot &s, std::vector<BinPlan> &bins, u64 n_total, u32 n_pass /* passes through HBM */, bool front, bool sort, bool compact, u64 lut_shard_entries)
+ZeroPlan plan_group(const Slot &s, std::vector<BinPlan> &bins, u64 n_total, u32 n_pass /* passes through HBM */, bool front, bool sort, bool compact, u64 lut_shard_entries,
+                    u64 cp_tile = CpCfg<SIZE>::TILE /* records per compaction tile: k_compact's, or the window of k_bucket_count */)
 {
 	ZeroPlan z;
 	size_t off = up256(SM_BYTES);
@@ -378,7 +381,7 @@ ZeroPlan plan_group(const Slot &s, std::vector<BinPlan> &bins, u64 n_total, u32 
 		}
 		if (compact) {
 			b.off_cp_status = off;
-			off += up256(((b.n_rec + CpCfg<SIZE>::TILE - 1) / CpCfg<SIZE>::TILE) * 8 + 8);
+			off += up256(((b.n_rec + cp_tile - 1) / cp_tile) * 8 + 8);
 			b.off_lutsh = off;
 			off += up256(lut_shard_entries * 8); /* n_shards x entries when the LUT is sharded */
 			b.off_tally = off;
@@ -411,7 +414,8 @@ int apply_plan(Slot &s, const ZeroPlan &z)
 /* ---- the sort: histograms of the digits that go through HBM + one onesweep launch per such digit (and portion), then — hybrid — the
  * bucket-aligned LDS sort of the remaining bytes, in place. `d_flag`: where k_bucket_sort reports a tile it could not sort. ---- */
 template <int SIZE>
-int sort_device_t(Slot &s, const ZeroPlan &z, u64 *d_recs, u64 *d_tmp, u64 n, const SortPlan &sp, u64 **d_result, u32 &counter_idx, bool hist_done, u32 *d_flag)
+int sort_device_t(Slot &s, const ZeroPlan &z, u64 *d_recs, u64 *d_tmp, u64 n, const SortPlan &sp, u64 **d_result, u32 &counter_idx, bool hist_done, u32 *d_flag,
+                  bool local_by_caller = false /* the caller finishes the low bytes itself (count_group: k_bucket_count) */)
 {
 	u64 *src = d_recs, *dst = d_tmp;
 	if (n < 2 || sp.key_bytes == 0) {
@@ -468,7 +472,7 @@ int sort_device_t(Slot &s, const ZeroPlan &z, u64 *d_recs, u64 *d_tmp, u64 n, co
 		}
 	} else if (s.timed)
 		HIPCHK(hipEventRecord(s.ev[3], s.stream));
-	if (sp.local()) {
+	if (sp.local() && !local_by_caller) {
 		constexpr u64 S = BsCfg<SIZE>::STRIDE;
 		const u64 n_win = (n + S - 1) / S;
 		if (n_win > 0x7FFFFFF0ull)
@@ -482,7 +486,13 @@ int sort_device_t(Slot &s, const ZeroPlan &z, u64 *d_recs, u64 *d_tmp, u64 n, co
 				return rc;
 			HIPCHK(hipEventRecord(e0, s.stream));
 		}
-		k_bucket_bounds<SIZE><<<dim3((u32)((n_win + 1 + 3) / 4)), dim3(256), 0, s.stream>>>(src, n, n_win, sp.key_bits, sp.hbits(), bounds);
+		GrpBounds gbn = {};
+		gbn.g = 1;
+		gbn.item_prefix[1] = (u32)(n_win + 1);
+		gbn.S[0] = src;
+		gbn.n[0] = n;
+		gbn.bounds[0] = bounds;
+		k_bucket_bounds<SIZE><<<dim3((u32)((n_win + 1 + 3) / 4)), dim3(256), 0, s.stream>>>(gbn, (u32)S, sp.key_bits, sp.hbits());
 		k_bucket_sort<SIZE><<<dim3((u32)n_win), dim3(BsCfg<SIZE>::THREADS), bs_lds_bytes<SIZE>(), s.stream>>>(src, sp.key_bits, sp.hbits(), bounds, d_flag);
 		if (s.timed)
 			HIPCHK(hipEventRecord(e1, s.stream));
@@ -681,6 +691,104 @@ int compact_group(Slot &s, const std::vector<BinPlan> &bins, const u64 *sorted, 
 	return 0;
 }
 
+/* ---- hybrid groups: the array is ordered by its top bytes only; k_bucket_count turns bucket-aligned tiles straight into (k-mer, count) records in the
+ * tiles' spans of the free record array (kernels: bucket_sort.hip.h), then the fold and the gather of the two-phase output as after k_compact. ---- */
+template <int SIZE> u32 count_max_len(const DevParams &P)
+{
+	const u64 pitch = (u64)BcCfg<SIZE>::STRIDE * SIZE * 8;
+	const u32 rec_bytes = P.sbytes + P.cbytes;
+	u64 m = BcCfg<SIZE>::CAP;
+	if (!P.without_output && rec_bytes) /* a tile of L records counts at most L / cutoff_min k-mers: they must fit the tile's span */
+		m = std::min<u64>(m, (u64)std::max<u32>(P.cutoff_min, 1) * (pitch / rec_bytes));
+	return (u32)m;
+}
+template <int SIZE> bool count_applicable(const DevParams &P)
+{
+	static const bool allow_two_phase = [] {
+		const char *e = getenv("KMC_HIP_TWO_PHASE");
+		return !e || atoi(e) != 0;
+	}();
+	/* room for the last bucket of a tile: at least a quarter of the nominal slack */
+	return allow_two_phase && count_max_len<SIZE>(P) >= (u32)BcCfg<SIZE>::STRIDE + (u32)(BcCfg<SIZE>::CAP - BcCfg<SIZE>::STRIDE) / 4;
+}
+template <int SIZE>
+int count_group(Slot &s, const std::vector<BinPlan> &bins, const u64 *sorted, u64 *scratch, const DevParams &P, u64 lut_entries, const SortPlan &sp, u64 n_total, u32 *d_flag)
+{
+	if (bins.empty())
+		return 0;
+	u32 *err = err_ptr(s);
+	const bool use_lut = lut_entries && !P.without_output && !P.kff;
+	const u32 n_sh = !use_lut ? 1u : lut_shards_for(lut_entries);
+	const u32 rec_bytes = P.sbytes + P.cbytes;
+	constexpr u64 S = BcCfg<SIZE>::STRIDE;
+	const u64 pitch = S * SIZE * 8;
+	GrpBounds gbn = {};
+	GrpBucket gb = {};
+	GrpFold gf = {};
+	GrpGather gg = {};
+	gbn.g = gb.g = gg.g = (u32)bins.size();
+	u64 wins = 0, items = 0;
+	for (const BinPlan &b : bins)
+		items += (b.n_rec + S - 1) / S + 1;
+	if (items > 0x7FFFFFF0ull)
+		return fail(KMC_HIP_EINVAL, "bin too large");
+	if (int rc = ensure(s.bounds, (size_t)(items + 2) * 8))
+		return rc;
+	u64 *bounds = (u64 *)s.bounds.p;
+	items = 0;
+	for (size_t i = 0; i < bins.size(); ++i) {
+		const BinPlan &b = bins[i];
+		const u64 bin_wins = (b.n_rec + S - 1) / S;
+		gbn.item_prefix[i] = (u32)items;
+		gb.win_prefix[i] = gg.tile_prefix[i] = (u32)wins;
+		u64 *lut_base = b.d_lut;
+		if (use_lut && n_sh > 1)
+			lut_base = zero_ptr<u64>(s, b.off_lutsh);
+		else if (use_lut)
+			HIPCHK(hipMemsetAsync(b.d_lut, 0, lut_entries * 8, s.stream));
+		gbn.S[i] = gb.S[i] = sorted + b.rec_off * SIZE;
+		gbn.n[i] = gf.n[i] = b.n_rec;
+		gbn.bounds[i] = bounds + items;
+		gb.bounds[i] = bounds + items;
+		gb.scratch[i] = (uint8_t *)(scratch + b.rec_off * SIZE);
+		gb.status[i] = zero_ptr<u64>(s, b.off_cp_status);
+		gb.lut_base[i] = lut_base;
+		gb.tally[i] = zero_ptr<u64>(s, b.off_tally);
+		gf.tally[i] = gb.tally[i];
+		gf.stats[i] = b.d_stats;
+		gf.lut_base[i] = lut_base;
+		gf.lut_out[i] = b.d_lut;
+		gf.status[i] = gb.status[i];
+		gf.n_tiles[i] = (u32)bin_wins;
+		gf.out_bytes[i] = b.d_out_bytes;
+		gf.out_capacity[i] = b.out_capacity;
+		gg.scratch[i] = gb.scratch[i];
+		gg.prefix[i] = gb.status[i];
+		gg.out[i] = b.d_out;
+		gg.out_capacity[i] = b.out_capacity;
+		items += bin_wins + 1;
+		wins += bin_wins;
+	}
+	gbn.item_prefix[bins.size()] = (u32)items;
+	gb.win_prefix[bins.size()] = gg.tile_prefix[bins.size()] = (u32)wins;
+	hipEvent_t e0 = nullptr, e1 = nullptr;
+	if (s.timed) {
+		if (int rc = ls_event_pair(s, e0, e1, n_total))
+			return rc;
+		HIPCHK(hipEventRecord(e0, s.stream));
+	}
+	k_bucket_bounds<SIZE><<<dim3((u32)((items + 3) / 4)), dim3(256), 0, s.stream>>>(gbn, (u32)S, sp.key_bits, sp.hbits());
+	k_bucket_count<SIZE><<<dim3((u32)wins), dim3(BcCfg<SIZE>::THREADS), bc_lds_bytes<SIZE>(), s.stream>>>(
+	    gb, P, sp.key_bits, sp.hbits(), count_max_len<SIZE>(P), n_sh, lut_entries, P.lut_prefix_len ? (u32)((1ull << (2 * P.lut_prefix_len)) - 1) : 0u, pitch, d_flag);
+	if (s.timed)
+		HIPCHK(hipEventRecord(e1, s.stream));
+	k_compact_fold<<<dim3((u32)bins.size()), dim3(256), 0, s.stream>>>(gf, use_lut ? n_sh : 1u, lut_entries, 1u, rec_bytes, err);
+	if (!P.without_output)
+		k_compact_gather<<<dim3((u32)((wins + 3) / 4)), dim3(256), 0, s.stream>>>(gg, rec_bytes, pitch);
+	HIPCHK(hipGetLastError());
+	return 0;
+}
+
 /* ---- a group of bins, everything device resident -------------------------------------------------------------------
  * The top radix digit of a k-mer has 8 ceil(k/4) - 2k spare bits (2 at k = 27, 55, 127). Bins expanded into one record array with the bin's
  * number inside the group in those bits are put into bin-major order by the SAME number of passes one bin needs — as launches 2^spare times
@@ -748,7 +856,8 @@ int run_group_device_t(Slot &s, const DevParams &P, const kmc_hip_bin_desc *cons
 		return fail(KMC_HIP_EINVAL, "group too large for the record width");
 	const u32 key_bytes = (2 * k + tag_bits + 7) / 8;
 	/* hybrid: only the top bytes of the key go through HBM passes, the rest is sorted inside LDS (bucket_sort.hip.h) */
-	const SortPlan sp = plan_sort<SIZE>(N, key_bytes, 2 * k + tag_bits, classic);
+	/* ... and then the tiles are counted where they lie (k_bucket_count): possible whenever a tile's records fit its span of the free array */
+	const SortPlan sp = plan_sort<SIZE>(N, key_bytes, 2 * k + tag_bits, classic || !count_applicable<SIZE>(P), true);
 	const u32 n_pass = sp.top;
 	if (used_hybrid)
 		*used_hybrid = sp.local() && N >= 2;
@@ -757,7 +866,8 @@ int run_group_device_t(Slot &s, const DevParams &P, const kmc_hip_bin_desc *cons
 	int rc = 0;
 	if (N && ((rc = ensure(s.recA, N * SIZE * 8 + 256)) || (rc = ensure(s.recB, N * SIZE * 8 + 256))))
 		return rc;
-	const ZeroPlan z = plan_group<SIZE>(s, bins, N, n_pass, true, true, true, n_sh > 1 ? (u64)n_sh * lut_entries : 0);
+	const ZeroPlan z = plan_group<SIZE>(s, bins, N, n_pass, true, true, true, n_sh > 1 ? (u64)n_sh * lut_entries : 0,
+	                                    sp.local() ? (u64)BcCfg<SIZE>::STRIDE : (u64)CpCfg<SIZE>::TILE);
 	if ((rc = apply_plan(s, z))) /* ONE memset per group: small block, bitmaps, look-back words, histograms, LUT and tally shards, scatter status */
 		return rc;
 	for (BinPlan &b : bins) { /* resolved only AFTER apply_plan: growing the zero region moves the small block */
@@ -789,14 +899,20 @@ int run_group_device_t(Slot &s, const DevParams &P, const kmc_hip_bin_desc *cons
 		HIPCHK(hipEventRecord(s.ev[2], s.stream));
 	}
 	u64 *sorted = (u64 *)s.recA.p;
-	if (N && (rc = sort_device_t<SIZE>(s, z, (u64 *)s.recA.p, (u64 *)s.recB.p, N, sp, &sorted, counter_idx, hist_done, d_flag ? d_flag : small_ptr<u32>(s, SM_REDO))))
+	u32 *const flag = d_flag ? d_flag : small_ptr<u32>(s, SM_REDO);
+	if (N && (rc = sort_device_t<SIZE>(s, z, (u64 *)s.recA.p, (u64 *)s.recB.p, N, sp, &sorted, counter_idx, hist_done, flag, true)))
 		return rc;
 	if (s.timed) {
 		if (!N)
 			HIPCHK(hipEventRecord(s.ev[3], s.stream));
 		HIPCHK(hipEventRecord(s.ev[4], s.stream));
 	}
-	if ((rc = compact_group<SIZE>(s, bins, sorted, N ? (sorted == (u64 *)s.recA.p ? (u64 *)s.recB.p : (u64 *)s.recA.p) : nullptr, P, lut_entries, counter_idx)))
+	u64 *const free_array = N ? (sorted == (u64 *)s.recA.p ? (u64 *)s.recB.p : (u64 *)s.recA.p) : nullptr;
+	if (sp.local() && N >= 2)
+		rc = count_group<SIZE>(s, bins, sorted, free_array, P, lut_entries, sp, N, flag);
+	else
+		rc = compact_group<SIZE>(s, bins, sorted, free_array, P, lut_entries, counter_idx);
+	if (rc)
 		return rc;
 	if (s.timed)
 		HIPCHK(hipEventRecord(s.ev[5], s.stream));
