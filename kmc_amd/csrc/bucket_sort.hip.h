@@ -361,16 +361,18 @@ __global__ void __launch_bounds__(BsCfg<SIZE>::THREADS) k_bucket_sort(u64 *__res
  *   1  records -> registers and, in arrival order, LDS; bucket boundaries -> sub-bucket id as in k_bucket_sort; count per sub-bucket (LDS
  *      atomics, nothing returned); scan: sub-bucket i owns slots [base[i], base[i+1]) of a tag array — as many slots as it has records
  *   2  every record looks for its k-mer in its sub-bucket's slots, open addressing from a hashed start: an empty slot is claimed with a
- *      compare-and-swap (tag = the claiming record's position, count 1), a slot whose owner holds the same k-mer gets its count bumped.
- *      This is the run-length counting, parallel over RECORDS: 30x coverage costs one probe and one add per copy.
- *   3  one thread per sub-bucket packs the claimed slots to the front of the region, orders them by their owners' k-mers (one or two
- *      distinct k-mers per sub-bucket on average, bucket_sort's id function) and applies the cutoffs and the clamp (kb_sorter.h:1174-1192)
- *   4  the tag array now lists the tile's distinct k-mers in ascending order: ranks of the counted ones by ballot + mbcnt, records assembled in
- *      LDS and written to the tile's span of the free record array, the tile's count to status[tile] (two-phase output: k_compact_fold turns the
- *      counts into offsets, k_compact_gather moves the records), per-tile aggregated LUT atomics and sharded tallies exactly as k_compact.
- * HBM traffic per record: the 8 SIZE bytes of its one read. A tile longer than `max_len` (LDS capacity, or what its span can hold at
- * cutoff_min 1) or a sub-bucket with too many distinct k-mers out of order sets *flag: the host runs the group again with LSD passes over every
- * byte and k_compact. */
+ *      compare-and-swap (tag = the claiming record's position, count 1: the record now OWNS its k-mer), a slot whose owner holds the same
+ *      k-mer gets its count bumped. This is the run-length counting, parallel over RECORDS: 30x coverage costs one probe and one add per copy.
+ *   3  every owner applies the cutoffs and the clamp to its slot's count (kb_sorter.h:1174-1192); an owner whose k-mer is counted scans its
+ *      sub-bucket's slots for counted k-mers smaller than its own (one or two distinct k-mers per sub-bucket on average) and adds itself to
+ *      its sub-bucket's number of counted k-mers; a scan of those numbers gives every counted k-mer its rank in the tile
+ *   4  records assembled in LDS at their ranks and written to the tile's span of the free record array, the tile's count to status[tile]
+ *      (two-phase output: k_compact_fold turns the counts into offsets, k_compact_gather moves the records), per-tile aggregated LUT atomics
+ *      and sharded tallies exactly as k_compact. Nothing is ever sorted.
+ * HBM traffic per record: the 8 SIZE bytes of its one read. The span of a tile starts at the byte offset of its first record in the free
+ * array (8 SIZE bytes per record of room), so a tile of any length has room for its output. A tile longer than the LDS capacity is counted in
+ * bucket-aligned chunks; only a single BUCKET beyond the capacity (one k-mer repeated thousands of times) sets *flag: the host runs the group
+ * again with LSD passes over every byte and k_compact. */
 #ifndef BC_BLOCK_THREADS
 #define BC_BLOCK_THREADS 512 /* 8 waves, 4096-record tiles of one-word records: 64 KB of LDS, two workgroups per CU */
 #endif
@@ -378,12 +380,12 @@ template <int SIZE> struct BcCfg {
 	static constexpr int THREADS = BC_BLOCK_THREADS;
 	static constexpr int ITEMS = (BS_WORDS_PER_THREAD / SIZE) > 2 ? (BS_WORDS_PER_THREAD / SIZE) : 2;
 	static constexpr int CAP = THREADS * ITEMS;
-	static constexpr int STRIDE = CAP / 4 * 3; /* window length; CAP / STRIDE = 4/3 so that a full tile's records fit its span even when every k-mer is counted */
+	static constexpr int STRIDE = CAP / 4 * 3; /* window length: a tile is STRIDE records on average; one that outgrows CAP takes a second chunk */
 	static_assert(CAP < 65535, "positions + 1 are kept in 16 bits");
 };
 template <int SIZE> constexpr size_t bc_lds_bytes()
 {
-	return (size_t)BcCfg<SIZE>::CAP * SIZE * 8 + ((size_t)2 * BcCfg<SIZE>::CAP + 2) * 4 + (7 * (BcCfg<SIZE>::THREADS / 64) + 4) * 4 + 16;
+	return (size_t)BcCfg<SIZE>::CAP * SIZE * 8 + ((size_t)2 * BcCfg<SIZE>::CAP + 2) * 4 + (6 * (BcCfg<SIZE>::THREADS / 64) + 4) * 4 + 16;
 }
 template <int SIZE> constexpr u64 bc_target_bucket() { return (BcCfg<SIZE>::CAP - BcCfg<SIZE>::STRIDE) / 64 > 4 ? (BcCfg<SIZE>::CAP - BcCfg<SIZE>::STRIDE) / 64 : 4; }
 
@@ -391,28 +393,26 @@ struct GrpBucket {
 	u32 g, win_prefix[GRP_MAX + 1]; /* windows (= tiles) of bin b */
 	const u64 *S[GRP_MAX];          /* the bin's slice of the record array, ordered by the top `hbits` key bits */
 	const u64 *bounds[GRP_MAX];     /* [windows + 1] tile boundaries (k_bucket_bounds) */
-	uint8_t *scratch[GRP_MAX];      /* tile t's records go to scratch + t * pitch */
+	uint8_t *scratch[GRP_MAX];      /* the bin's slice of the free record array: tile t's records go to scratch + bounds[t] * 8 SIZE */
 	u64 *status[GRP_MAX];           /* tile t's number of counted k-mers */
 	u64 *lut_base[GRP_MAX];
 	u64 *tally[GRP_MAX];            /* [CP_SHARDS][4] */
 };
 
 template <int SIZE>
-__global__ void __launch_bounds__(BcCfg<SIZE>::THREADS) k_bucket_count(const GrpBucket gb, DevParams P, u32 key_bits, u32 hbits, u32 max_len, u32 lut_shards, u64 lut_stride,
-                                                                    u32 lut_mask, u64 pitch, u32 *flag)
+__global__ void __launch_bounds__(BcCfg<SIZE>::THREADS) k_bucket_count(const GrpBucket gb, DevParams P, u32 key_bits, u32 hbits, u32 lut_shards, u64 lut_stride, u32 lut_mask,
+                                                                    u32 *flag)
 {
 	constexpr int THREADS = BcCfg<SIZE>::THREADS, ITEMS = BcCfg<SIZE>::ITEMS, CAP = BcCfg<SIZE>::CAP, NW = THREADS / 64;
 	constexpr u64 S = BcCfg<SIZE>::STRIDE;
 	constexpr u32 NONE = 0xFFFFFFFFu;
 	KMC_DYN_LDS(unsigned char, s_raw);
 	u64 *s_rec = reinterpret_cast<u64 *>(s_raw);                      /* [CAP * SIZE] records in arrival order; later the output staging area */
-	u32 *s_cnt = reinterpret_cast<u32 *>(s_rec + (size_t)CAP * SIZE); /* [CAP + 1] records per sub-bucket -> first slot; later the LUT prefixes of the counted k-mers */
-	u32 *s_tag = s_cnt + CAP + 1;                                     /* [CAP] [15:0] owner position + 1 (0 = free), [31:16] count */
+	u32 *s_cnt = reinterpret_cast<u32 *>(s_rec + (size_t)CAP * SIZE); /* [CAP + 1] records per sub-bucket -> first slot; later counted k-mers per sub-bucket -> first rank */
+	u32 *s_tag = s_cnt + CAP + 1;                                     /* [CAP] [15:0] owner position + 1 (0 = free), [31:16] count; later the LUT prefixes of the counted k-mers */
 	u32 *s_tmp = s_tag + CAP;                                         /* [NW + 1] */
 	u32 *s_wfirst = s_tmp + NW + 1, *s_wlast = s_wfirst + NW;         /* [NW] each */
-	u32 *s_wcnt = s_wlast + NW;                                       /* [NW] counted k-mers of wave w */
-	u32 *s_wtal = s_wcnt + NW;                                        /* [NW][3] distinct / below min / above max */
-	u32 *s_fail = s_wtal + 3 * NW;
+	u32 *s_wtal = s_wlast + NW;                                       /* [NW][3] distinct / below min / above max */
 
 	const u32 gtile = blockIdx.x;
 	const u32 bin = (u32)__builtin_amdgcn_readfirstlane((int)grp_find(gb.win_prefix, gb.g, gtile));
@@ -421,214 +421,297 @@ __global__ void __launch_bounds__(BcCfg<SIZE>::THREADS) k_bucket_count(const Grp
 	const u64 b0 = bounds[tile], b1 = bounds[tile + 1];
 	if (b0 >= ((u64)tile + 1) * S || b0 >= b1)
 		return; /* no bucket starts in this window: status[tile] stays 0 */
-	if (b1 - b0 > (u64)max_len) {
-		if (threadIdx.x == 0)
-			atomicOr(flag, 1u);
-		return;
-	}
-	const u32 len = (u32)(b1 - b0);
 	const u32 tid = threadIdx.x, lane = tid & 63;
 	const u32 wave = (u32)__builtin_amdgcn_readfirstlane((int)(tid >> 6));
-	const u64 *__restrict__ T = gb.S[bin] + b0 * SIZE;
 	const u32 crel = wave * (ITEMS * 64);
 	const u32 rec_bytes = P.sbytes + P.cbytes;
 	const bool use_lut = P.lut_prefix_len != 0 && !P.kff && !P.without_output;
-
-	for (u32 i = tid; i <= (u32)CAP; i += THREADS)
-		s_cnt[i] = 0;
-	for (u32 i = tid; i < (u32)CAP; i += THREADS)
-		s_tag[i] = 0;
-	if (tid == 0)
-		*s_fail = 0;
-	u64 key[ITEMS][SIZE];
-#pragma unroll
-	for (int r = 0; r < ITEMS; ++r) {
-		const u32 idx = crel + r * 64 + lane;
-		if (idx < len) {
-			load_rec<SIZE>(T + (size_t)idx * SIZE, key[r]);
-			store_rec<SIZE>(s_rec + (size_t)idx * SIZE, key[r]);
-		} else {
-#pragma unroll
-			for (int w = 0; w < SIZE; ++w)
-				key[r][w] = 0;
-		}
-	}
-	/* ---- 1: bucket starts, one scalar mask per row */
 	const u32 bsh = 64 - hbits;
+	const u64 lane_le = (2ull << lane) - 1; /* this lane and the ones below */
 	auto bucket_of = [&](const u64(&x)[SIZE]) -> u64 { return hbits ? bs_p64<SIZE>(x, key_bits) >> bsh : 0ull; };
-	u64 prev_last = 0;
-	if (crel > 0 && crel - 1 < len) {
-		u64 x[SIZE];
-		load_rec<SIZE>(T + (size_t)(crel - 1) * SIZE, x);
-		prev_last = bucket_of(x);
-	}
-	u64 heads[ITEMS];
-	u32 wfirst = NONE, wlast = NONE;
+	uint8_t *const span = gb.scratch[bin] + b0 * (u64)(SIZE * 8); /* this tile's output: room for 8 SIZE bytes per record */
+	u32 nu = 0, nb = 0, na = 0;                                    /* this thread's owners: distinct / below min / above max */
+	u32 counted_done = 0;                                          /* counted k-mers of the chunks before this one */
+
+	for (u64 c0 = b0; c0 < b1;) { /* chunks of whole buckets; nearly always one */
+		const u64 *__restrict__ T = gb.S[bin] + c0 * SIZE;
+		const u32 avail = (b1 - c0) > (u64)CAP ? (u32)CAP : (u32)(b1 - c0);
+		for (u32 i = tid; i <= (u32)CAP; i += THREADS)
+			s_cnt[i] = 0;
+		for (u32 i = tid; i < (u32)CAP; i += THREADS)
+			s_tag[i] = 0;
+		u64 key[ITEMS][SIZE];
 #pragma unroll
-	for (int r = 0; r < ITEMS; ++r) {
-		const u32 rowrel = crel + r * 64, idx = rowrel + lane;
-		const u64 bk = bucket_of(key[r]);
-		u64 pv = __shfl_up(bk, 1);
-		if (lane == 0)
-			pv = prev_last;
-		const u64 m = __ballot(idx < len && (idx == 0 || pv != bk));
-		heads[r] = m;
-		if (m) {
-			if (wfirst == NONE)
-				wfirst = rowrel + (u32)__ffsll((long long)m) - 1;
-			wlast = rowrel + 63 - (u32)__clzll((long long)m);
-		}
-		prev_last = __shfl(bk, 63);
-	}
-	if (lane == 0) {
-		s_wfirst[wave] = wfirst;
-		s_wlast[wave] = wlast;
-	}
-	__syncthreads();
-	u32 carry_f = 0, carry_b = len;
+		for (int r = 0; r < ITEMS; ++r) {
+			const u32 idx = crel + r * 64 + lane;
+			if (idx < avail) {
+				load_rec<SIZE>(T + (size_t)idx * SIZE, key[r]);
+				store_rec<SIZE>(s_rec + (size_t)idx * SIZE, key[r]);
+			} else {
 #pragma unroll
-	for (int w = 0; w < NW; ++w) {
-		const u32 l = s_wlast[w], f = s_wfirst[NW - 1 - w];
-		if (w < (int)wave && l != NONE)
-			carry_f = l;
-		if (NW - 1 - w > (int)wave && f != NONE)
-			carry_b = f;
-	}
-	carry_f = (u32)__builtin_amdgcn_readfirstlane((int)carry_f);
-	carry_b = (u32)__builtin_amdgcn_readfirstlane((int)carry_b);
-	u32 bend[ITEMS];
-#pragma unroll
-	for (int r = ITEMS - 1; r >= 0; --r) {
-		const u32 rowrel = crel + r * 64;
-		const u64 m = heads[r];
-		const u64 above = m & ~(((2ull << lane) - 1));
-		bend[r] = above ? rowrel + (u32)__ffsll((long long)above) - 1 : carry_b;
-		if (m)
-			carry_b = rowrel + (u32)__ffsll((long long)m) - 1;
-	}
-	u32 sub[ITEMS]; /* the record's sub-bucket */
-#pragma unroll
-	for (int r = 0; r < ITEMS; ++r) {
-		const u32 rowrel = crel + r * 64, idx = rowrel + lane;
-		const u64 m = heads[r];
-		const u64 upto = m & ((2ull << lane) - 1);
-		const u32 bstart = upto ? rowrel + 63 - (u32)__clzll((long long)upto) : carry_f;
-		if (m)
-			carry_f = rowrel + 63 - (u32)__clzll((long long)m);
-		sub[r] = 0;
-		if (idx < len) {
-			const u64 p = bs_p64<SIZE>(key[r], key_bits);
-			const u32 rem32 = (u32)((hbits ? (p << hbits) : p) >> 32);
-			u32 id = bstart + __umulhi(rem32, bend[r] - bstart);
-			id = id < len ? id : len - 1; /* in range by construction; the clamp is for records of a corrupt bin (the error word is already set) */
-			sub[r] = id;
-			(void)__hip_atomic_fetch_add(&s_cnt[id], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-		}
-	}
-	__syncthreads();
-	{
-		u32 c[ITEMS], sum = 0;
-#pragma unroll
-		for (int q = 0; q < ITEMS; ++q) {
-			c[q] = s_cnt[tid * ITEMS + q];
-			sum += c[q];
-		}
-		u32 total;
-		u32 run = block_excl_sum<NW, u32>(sum, s_tmp, total);
-#pragma unroll
-		for (int q = 0; q < ITEMS; ++q) {
-			s_cnt[tid * ITEMS + q] = run;
-			run += c[q];
-		}
-		if (tid == 0)
-			s_cnt[CAP] = total;
-	}
-	__syncthreads();
-	/* ---- 2: count the copies. Region of sub-bucket i: slots [s_cnt[i], s_cnt[i+1]) — one slot per record, so a free slot always exists. */
-#pragma unroll
-	for (int r = 0; r < ITEMS; ++r) {
-		const u32 idx = crel + r * 64 + lane;
-		if (idx < len) {
-			const u32 a = s_cnt[sub[r]], nreg = s_cnt[sub[r] + 1] - a;
-			u32 h = 0;
-#pragma unroll
-			for (int w = 0; w < SIZE; ++w)
-				h = (h ^ (u32)key[r][w] ^ (u32)(key[r][w] >> 32)) * 0x9E3779B1u;
-			h ^= h >> 15;
-			u32 slot = a + __umulhi(h * 0x85EBCA6Bu, nreg);
-			for (u32 probe = 0; probe < nreg; ++probe) {
-				u32 w = __hip_atomic_load(&s_tag[slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-				if (w == 0) {
-					w = atomicCAS(&s_tag[slot], 0u, (1u << 16) | (idx + 1));
-					if (w == 0)
-						break; /* claimed: this record represents its k-mer */
-				}
-				u64 o[SIZE];
-				load_rec<SIZE>(s_rec + (size_t)((w & 0xFFFFu) - 1) * SIZE, o);
-				if (kmc_equal<SIZE>(o, key[r])) {
-					(void)__hip_atomic_fetch_add(&s_tag[slot], 1u << 16, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-					break;
-				}
-				slot = slot + 1 == a + nreg ? a : slot + 1;
+				for (int w = 0; w < SIZE; ++w)
+					key[r][w] = 0;
 			}
 		}
-	}
-	__syncthreads();
-	/* ---- 3: per sub-bucket: claimed slots to the front, ordered by k-mer, cutoffs and clamp. Dropped k-mers keep their slot with count 0. */
-	u32 nu = 0, nb = 0, na = 0;
-	{
-		u32 moves = 0;
-		for (u32 id = tid; id < len; id += THREADS) {
-			const u32 a = s_cnt[id], b = s_cnt[id + 1];
-			if (a == b)
-				continue;
-			u32 d = 0;
-			for (u32 i = a; i < b; ++i) {
-				const u32 w = s_tag[i];
-				if (w) {
-					if (i != a + d) {
-						s_tag[a + d] = w;
-						s_tag[i] = 0;
+		/* ---- 1: bucket starts, one scalar mask per row */
+		u64 prev_last = 0;
+		if (crel > 0 && crel - 1 < avail) {
+			u64 x[SIZE];
+			load_rec<SIZE>(T + (size_t)(crel - 1) * SIZE, x);
+			prev_last = bucket_of(x);
+		}
+		u64 heads[ITEMS];
+		u32 wfirst = NONE, wlast = NONE;
+#pragma unroll
+		for (int r = 0; r < ITEMS; ++r) {
+			const u32 rowrel = crel + r * 64, idx = rowrel + lane;
+			const u64 bk = bucket_of(key[r]);
+			u64 pv = __shfl_up(bk, 1);
+			if (lane == 0)
+				pv = prev_last;
+			const u64 m = __ballot(idx < avail && (idx == 0 || pv != bk));
+			heads[r] = m;
+			if (m) {
+				if (wfirst == NONE)
+					wfirst = rowrel + (u32)__ffsll((long long)m) - 1;
+				wlast = rowrel + 63 - (u32)__clzll((long long)m);
+			}
+			prev_last = __shfl(bk, 63);
+		}
+		if (lane == 0) {
+			s_wfirst[wave] = wfirst;
+			s_wlast[wave] = wlast;
+		}
+		__syncthreads();
+		/* the chunk: everything that was loaded, or — when the tile has more — up to the start of the last bucket that began inside it */
+		u32 len = avail;
+		if ((b1 - c0) > (u64)CAP) {
+			u32 last_head = 0;
+#pragma unroll
+			for (int w = 0; w < NW; ++w) {
+				const u32 l = s_wlast[w];
+				if (l != NONE)
+					last_head = l; /* ascending over waves */
+			}
+			if (last_head == 0) { /* one bucket beyond the LDS capacity (uniform over the workgroup) */
+				if (tid == 0)
+					atomicOr(flag, 1u);
+				return;
+			}
+			len = last_head;
+		}
+		u32 carry_f = 0, carry_b = len;
+#pragma unroll
+		for (int w = 0; w < NW; ++w) {
+			const u32 l = s_wlast[w], f = s_wfirst[NW - 1 - w];
+			if (w < (int)wave && l != NONE)
+				carry_f = l;
+			if (NW - 1 - w > (int)wave && f != NONE && f < len)
+				carry_b = f;
+		}
+		carry_f = (u32)__builtin_amdgcn_readfirstlane((int)carry_f);
+		carry_b = (u32)__builtin_amdgcn_readfirstlane((int)carry_b);
+		u32 bend[ITEMS];
+#pragma unroll
+		for (int r = ITEMS - 1; r >= 0; --r) {
+			const u32 rowrel = crel + r * 64;
+			u64 m = heads[r];
+			if (rowrel + 63 >= len) /* heads at or beyond the cut do not belong to this chunk */
+				m = rowrel >= len ? 0ull : (m & (((u64)1 << (len - rowrel)) - 1));
+			heads[r] = m;
+			const u64 above = m & ~lane_le;
+			bend[r] = above ? rowrel + (u32)__ffsll((long long)above) - 1 : carry_b;
+			if (m)
+				carry_b = rowrel + (u32)__ffsll((long long)m) - 1;
+		}
+		u32 sub[ITEMS]; /* the record's sub-bucket */
+#pragma unroll
+		for (int r = 0; r < ITEMS; ++r) {
+			const u32 rowrel = crel + r * 64, idx = rowrel + lane;
+			const u64 m = heads[r];
+			const u64 upto = m & lane_le;
+			const u32 bstart = upto ? rowrel + 63 - (u32)__clzll((long long)upto) : carry_f;
+			if (m)
+				carry_f = rowrel + 63 - (u32)__clzll((long long)m);
+			sub[r] = 0;
+			if (idx < len) {
+				const u64 p = bs_p64<SIZE>(key[r], key_bits);
+				const u32 rem32 = (u32)((hbits ? (p << hbits) : p) >> 32);
+				u32 id = bstart + __umulhi(rem32, bend[r] - bstart);
+				id = id < len ? id : len - 1; /* in range by construction; the clamp is for records of a corrupt bin (the error word is already set) */
+				sub[r] = id;
+				(void)__hip_atomic_fetch_add(&s_cnt[id], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+			}
+		}
+		__syncthreads();
+		{
+			u32 c[ITEMS], sum = 0;
+#pragma unroll
+			for (int q = 0; q < ITEMS; ++q) {
+				c[q] = s_cnt[tid * ITEMS + q];
+				sum += c[q];
+			}
+			u32 total;
+			u32 run = block_excl_sum<NW, u32>(sum, s_tmp, total);
+#pragma unroll
+			for (int q = 0; q < ITEMS; ++q) {
+				s_cnt[tid * ITEMS + q] = run;
+				run += c[q];
+			}
+			if (tid == 0)
+				s_cnt[CAP] = total;
+		}
+		__syncthreads();
+#if defined(BC_STOP_AFTER) && BC_STOP_AFTER <= 1 /* tuning builds only: what does each phase cost? (the output is garbage) */
+		return;
+#endif
+		/* ---- 2: count the copies. Region of sub-bucket i: slots [s_cnt[i], s_cnt[i+1]) — one slot per record, so a free slot always exists. */
+		u32 areg[ITEMS];   /* [15:0] first slot of the record's region, [31:16] its length */
+		u32 myslot[ITEMS]; /* the slot this record owns, NONE if it is a copy */
+#pragma unroll
+		for (int r = 0; r < ITEMS; ++r) {
+			const u32 idx = crel + r * 64 + lane;
+			areg[r] = 0;
+			myslot[r] = NONE;
+			if (idx < len) {
+				const u32 a = s_cnt[sub[r]], nreg = s_cnt[sub[r] + 1] - a;
+				areg[r] = a | (nreg << 16);
+				u32 h = 0;
+#pragma unroll
+				for (int w = 0; w < SIZE; ++w)
+					h = (h ^ (u32)key[r][w] ^ (u32)(key[r][w] >> 32)) * 0x9E3779B1u;
+				h ^= h >> 15;
+				u32 slot = a + __umulhi(h * 0x85EBCA6Bu, nreg);
+				for (u32 probe = 0; probe < nreg; ++probe) {
+					u32 w = __hip_atomic_load(&s_tag[slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+					if (w == 0) {
+						w = atomicCAS(&s_tag[slot], 0u, (1u << 16) | (idx + 1));
+						if (w == 0) {
+							myslot[r] = slot;
+							break;
+						}
 					}
-					++d;
-				}
-			}
-			for (u32 i = a + 1; i < a + d; ++i) {
-				const u32 w = s_tag[i];
-				u64 x[SIZE];
-				load_rec<SIZE>(s_rec + (size_t)((w & 0xFFFFu) - 1) * SIZE, x);
-				u32 q = i;
-				while (q > a) {
-					const u32 wy = s_tag[q - 1];
-					u64 y[SIZE];
-					load_rec<SIZE>(s_rec + (size_t)((wy & 0xFFFFu) - 1) * SIZE, y);
-					if (!kmc_less<SIZE>(x, y))
+					u64 o[SIZE];
+					load_rec<SIZE>(s_rec + (size_t)((w & 0xFFFFu) - 1) * SIZE, o);
+					if (kmc_equal<SIZE>(o, key[r])) {
+						(void)__hip_atomic_fetch_add(&s_tag[slot], 1u << 16, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 						break;
-					s_tag[q] = wy;
-					--q;
-					++moves;
+					}
+					slot = slot + 1 == a + nreg ? a : slot + 1;
 				}
-				s_tag[q] = w;
-			}
-			for (u32 i = a; i < a + d; ++i) {
-				u32 w = s_tag[i];
-				const u32 c = w >> 16;
-				++nu;
-				if (c < P.cutoff_min) {
-					++nb;
-					w &= 0xFFFFu;
-				} else if (c > P.cutoff_max) {
-					++na;
-					w &= 0xFFFFu;
-				} else
-					w = (w & 0xFFFFu) | ((c > P.counter_max ? P.counter_max : c) << 16);
-				s_tag[i] = w;
-			}
-			if (moves > (u32)BS_MOVE_LIMIT) {
-				*s_fail = 1;
-				break;
 			}
 		}
+		__syncthreads();
+#if defined(BC_STOP_AFTER) && BC_STOP_AFTER <= 2
+		return;
+#endif
+		/* ---- 3: owners classify their k-mer; a counted one finds how many counted k-mers of its sub-bucket are smaller */
+		for (u32 i = tid; i <= (u32)CAP; i += THREADS)
+			s_cnt[i] = 0; /* every reader of the region table is past the barrier: it becomes "counted k-mers per sub-bucket" */
+		u32 ec[ITEMS]; /* counted owners: [15:0] smaller counted k-mers in the region, [31:16] the count to store; else 0 */
+#pragma unroll
+		for (int r = 0; r < ITEMS; ++r) {
+			ec[r] = 0;
+			if (myslot[r] != NONE) {
+				const u32 c = s_tag[myslot[r]] >> 16;
+				++nu;
+				if (c < P.cutoff_min)
+					++nb;
+				else if (c > P.cutoff_max)
+					++na;
+				else {
+					const u32 a = areg[r] & 0xFFFFu, e = a + (areg[r] >> 16);
+					u32 smaller = 0;
+					for (u32 q = a; q < e; ++q) {
+						const u32 wq = s_tag[q];
+						const u32 cq = wq >> 16;
+						if (q != myslot[r] && wq && cq >= P.cutoff_min && cq <= P.cutoff_max) {
+							u64 o[SIZE];
+							load_rec<SIZE>(s_rec + (size_t)((wq & 0xFFFFu) - 1) * SIZE, o);
+							smaller += kmc_less<SIZE>(o, key[r]) ? 1u : 0u;
+						}
+					}
+					ec[r] = smaller | ((c > P.counter_max ? P.counter_max : c) << 16);
+				}
+			}
+		}
+		__syncthreads();
+#pragma unroll
+		for (int r = 0; r < ITEMS; ++r)
+			if (ec[r])
+				(void)__hip_atomic_fetch_add(&s_cnt[sub[r]], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+		__syncthreads();
+		u32 chunk_counted;
+		{
+			u32 c[ITEMS], sum = 0;
+#pragma unroll
+			for (int q = 0; q < ITEMS; ++q) {
+				c[q] = s_cnt[tid * ITEMS + q];
+				sum += c[q];
+			}
+			u32 run = block_excl_sum<NW, u32>(sum, s_tmp, chunk_counted);
+#pragma unroll
+			for (int q = 0; q < ITEMS; ++q) {
+				s_cnt[tid * ITEMS + q] = run;
+				run += c[q];
+			}
+		}
+		__syncthreads();
+#if defined(BC_STOP_AFTER) && BC_STOP_AFTER <= 3
+		return;
+#endif
+		/* ---- 4: records at their ranks. s_rec is free (the region scans are behind the barriers above): it is the staging area now, s_tag the
+		 * list of LUT prefixes */
+		if (!P.without_output && chunk_counted) {
+			uint8_t *s_stage = reinterpret_cast<uint8_t *>(s_rec);
+			u32 *s_pref = s_tag;
+			const u32 pshift = 2 * (P.k - P.lut_prefix_len);
+#pragma unroll
+			for (int r = 0; r < ITEMS; ++r) {
+				if (ec[r]) {
+					const u32 rank = s_cnt[sub[r]] + (ec[r] & 0xFFFFu);
+					const u32 cntv = ec[r] >> 16;
+					u64 kx[SIZE];
+#pragma unroll
+					for (int w = 0; w < SIZE; ++w)
+						kx[w] = key[r][w];
+					kmc_mask_low<SIZE>(kx, 2 * P.k); /* drops a group tag above the k-mer (KFF records carry the top bytes) */
+					if (use_lut)
+						s_pref[rank] = (u32)kmc_remove_suffix<SIZE>(kx, pshift) & lut_mask;
+					uint8_t *dstb = s_stage + (size_t)rank * rec_bytes;
+					for (u32 q = 0; q < P.sbytes; ++q)
+						dstb[q] = (uint8_t)kmc_get_byte<SIZE>(kx, P.sbytes - 1 - q); /* suffix bytes high -> low (kb_sorter.h:1198-1199) */
+					for (u32 q = 0; q < P.cbytes; ++q)
+						dstb[P.sbytes + q] = (uint8_t)(cntv >> (8 * (P.kff ? (P.cbytes - 1 - q) : q))); /* :1200-1201 / KFF :1210-1211 */
+				}
+			}
+			__syncthreads();
+			const u32 chunk_bytes = chunk_counted * rec_bytes;
+			uint8_t *dst = span + (u64)counted_done * rec_bytes;
+			if ((counted_done * rec_bytes & 3u) == 0) { /* the span is 8-byte aligned: whole dwords (the bytes behind the last record are the span's own) */
+				u32 *dst32 = reinterpret_cast<u32 *>(dst);
+				const u32 *src32 = reinterpret_cast<const u32 *>(s_stage);
+				for (u32 wd = tid; wd < (chunk_bytes + 3) / 4; wd += THREADS)
+					dst32[wd] = src32[wd];
+			} else {
+				for (u32 q = tid; q < chunk_bytes; q += THREADS)
+					dst[q] = s_stage[q];
+			}
+			if (use_lut) {
+				u64 *lut = gb.lut_base[bin] + (size_t)(tile % lut_shards) * lut_stride;
+				for (u32 q = tid; q < chunk_counted; q += THREADS) {
+					const u32 pf = s_pref[q];
+					if (q + 1 == chunk_counted || s_pref[q + 1] != pf)
+						atomicAdd(&lut[pf], (u64)(q + 1));
+					if (q > 0 && s_pref[q - 1] != pf)
+						atomicAdd(&lut[pf], (u64)0 - (u64)q);
+				}
+			}
+		}
+		counted_done += chunk_counted;
+		c0 += len;
+		if (c0 < b1)
+			__syncthreads(); /* the next chunk clears what this one still reads */
 	}
 	nu = wave_sum<u32>(nu);
 	nb = wave_sum<u32>(nb);
@@ -639,43 +722,6 @@ __global__ void __launch_bounds__(BcCfg<SIZE>::THREADS) k_bucket_count(const Grp
 		s_wtal[wave * 3 + 2] = na;
 	}
 	__syncthreads();
-	if (*s_fail) {
-		if (tid == 0)
-			atomicOr(flag, 1u);
-		return; /* the group is run again by the host; nothing of this tile was published */
-	}
-	/* ---- 4: the tag array in position order = the distinct k-mers in ascending order */
-	u32 wv[ITEMS], rk[ITEMS], nc = 0;
-	u64 kx[ITEMS][SIZE];
-#pragma unroll
-	for (int r = 0; r < ITEMS; ++r) {
-		const u32 pos = crel + r * 64 + lane;
-		const u32 w = pos < len ? s_tag[pos] : 0u;
-		const bool em = (w >> 16) != 0;
-		const u64 m = __ballot(em);
-		wv[r] = em ? w : 0u;
-		rk[r] = __builtin_amdgcn_mbcnt_hi((u32)(m >> 32), __builtin_amdgcn_mbcnt_lo((u32)m, nc));
-		nc += (u32)__popcll(m);
-		if (em) {
-			load_rec<SIZE>(s_rec + (size_t)((w & 0xFFFFu) - 1) * SIZE, kx[r]);
-			kmc_mask_low<SIZE>(kx[r], 2 * P.k); /* drops a group tag above the k-mer (KFF records carry the top bytes) */
-		} else {
-#pragma unroll
-			for (int q = 0; q < SIZE; ++q)
-				kx[r][q] = 0;
-		}
-	}
-	if (lane == 0)
-		s_wcnt[wave] = nc;
-	__syncthreads(); /* every k-mer this tile emits is in registers: s_rec becomes the staging area, s_cnt the prefix list */
-	u32 wave_off = 0, tile_counted = 0;
-#pragma unroll
-	for (int w = 0; w < NW; ++w) {
-		const u32 x = s_wcnt[w];
-		if (w < (int)wave)
-			wave_off += x;
-		tile_counted += x;
-	}
 	if (tid == 0) {
 		u32 tu = 0, tb = 0, ta = 0;
 #pragma unroll
@@ -692,44 +738,7 @@ __global__ void __launch_bounds__(BcCfg<SIZE>::THREADS) k_bucket_count(const Grp
 		if (ta)
 			atomicAdd(&sh[2], (u64)ta);
 		if (!P.without_output)
-			gb.status[bin][tile] = tile_counted;
-	}
-	if (P.without_output || tile_counted == 0)
-		return;
-	uint8_t *s_stage = reinterpret_cast<uint8_t *>(s_rec);
-	u32 *s_pref = s_cnt;
-	const u32 pshift = 2 * (P.k - P.lut_prefix_len);
-#pragma unroll
-	for (int r = 0; r < ITEMS; ++r) {
-		if (wv[r]) {
-			const u32 rank = wave_off + rk[r];
-			const u32 cntv = wv[r] >> 16;
-			if (use_lut)
-				s_pref[rank] = (u32)kmc_remove_suffix<SIZE>(kx[r], pshift) & lut_mask;
-			uint8_t *dstb = s_stage + (size_t)rank * rec_bytes;
-			for (u32 q = 0; q < P.sbytes; ++q)
-				dstb[q] = (uint8_t)kmc_get_byte<SIZE>(kx[r], P.sbytes - 1 - q); /* suffix bytes high -> low (kb_sorter.h:1198-1199) */
-			for (u32 q = 0; q < P.cbytes; ++q)
-				dstb[P.sbytes + q] = (uint8_t)(cntv >> (8 * (P.kff ? (P.cbytes - 1 - q) : q))); /* :1200-1201 / KFF :1210-1211 */
-		}
-	}
-	__syncthreads();
-	{
-		const u32 tile_bytes = tile_counted * rec_bytes; /* <= pitch: the host checked max_len against the span */
-		u32 *dst32 = reinterpret_cast<u32 *>(gb.scratch[bin] + (u64)tile * pitch);
-		const u32 *src32 = reinterpret_cast<const u32 *>(s_stage);
-		for (u32 wd = tid; wd < (tile_bytes + 3) / 4; wd += THREADS)
-			dst32[wd] = src32[wd];
-	}
-	if (use_lut) {
-		u64 *lut = gb.lut_base[bin] + (size_t)(tile % lut_shards) * lut_stride;
-		for (u32 q = tid; q < tile_counted; q += THREADS) {
-			const u32 pf = s_pref[q];
-			if (q + 1 == tile_counted || s_pref[q + 1] != pf)
-				atomicAdd(&lut[pf], (u64)(q + 1));
-			if (q > 0 && s_pref[q - 1] != pf)
-				atomicAdd(&lut[pf], (u64)0 - (u64)q);
-		}
+			gb.status[bin][tile] = counted_done;
 	}
 }
 

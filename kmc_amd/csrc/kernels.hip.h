@@ -143,6 +143,7 @@ struct GrpGather { /* two-phase output: tile t's records move from scratch + t *
 	const u64 *prefix[GRP_MAX]; /* [n_tiles + 1] */
 	uint8_t *out[GRP_MAX];
 	u64 out_capacity[GRP_MAX];
+	const u64 *src_rec[GRP_MAX]; /* NULL, or (k_bucket_count's tiles) the first record of every tile: tile t's records lie at scratch + src_rec[t] * tile_pitch */
 };
 /* bin of work item `item` (wave-uniform) */
 __device__ __forceinline__ u32 grp_find(const u32 (&prefix)[GRP_MAX + 1], u32 g, u32 item)
@@ -1664,7 +1665,7 @@ __global__ void __launch_bounds__(256) k_compact_gather(const GrpGather gg, u32 
 	const u32 len = (u32)(prefix[tile + 1] - first) * rec_bytes;
 	if (!len)
 		return;
-	const uint8_t *__restrict__ src = gg.scratch[bin] + (u64)tile * tile_pitch;
+	const uint8_t *__restrict__ src = gg.scratch[bin] + (gg.src_rec[bin] ? gg.src_rec[bin][tile] : (u64)tile) * tile_pitch;
 	uint8_t *__restrict__ dst = gg.out[bin] + first * rec_bytes;
 	u32 head = (u32)((4 - ((uintptr_t)dst & 3)) & 3);
 	if (head > len)

@@ -337,9 +337,6 @@ template <int SIZE> SortPlan plan_sort(u64 n, u32 key_bytes, u32 key_bits, bool 
 	const int mode = hybrid_mode();
 	if (classic || mode == 0 || key_bytes < 3 || n < 2)
 		return sp;
-	const u64 redo = g_redo_groups.load(std::memory_order_relaxed);
-	if (redo > 4 && redo * 8 > g_hybrid_groups.load(std::memory_order_relaxed))
-		return sp; /* this input defeats the bucket tiles too often */
 	const u32 spare = 8 * key_bytes - key_bits;
 	if (mode < 0) {
 		const u32 h = (u32)(-mode);
@@ -347,6 +344,9 @@ template <int SIZE> SortPlan plan_sort(u64 n, u32 key_bytes, u32 key_bits, bool 
 			sp.top = h;
 		return sp;
 	}
+	const u64 redo = g_redo_groups.load(std::memory_order_relaxed);
+	if (redo > 4 && redo * 8 > g_hybrid_groups.load(std::memory_order_relaxed))
+		return sp; /* this input defeats the bucket tiles too often */
 	/* the fewest top bytes that leave buckets of bs_target_bucket() records on average, and only if at least two passes are saved */
 	for (u32 h = 0; h + 2 <= key_bytes && h <= 4; ++h) {
 		bool ok;
@@ -693,23 +693,16 @@ int compact_group(Slot &s, const std::vector<BinPlan> &bins, const u64 *sorted, 
 
 /* ---- hybrid groups: the array is ordered by its top bytes only; k_bucket_count turns bucket-aligned tiles straight into (k-mer, count) records in the
  * tiles' spans of the free record array (kernels: bucket_sort.hip.h), then the fold and the gather of the two-phase output as after k_compact. ---- */
-template <int SIZE> u32 count_max_len(const DevParams &P)
-{
-	const u64 pitch = (u64)BcCfg<SIZE>::STRIDE * SIZE * 8;
-	const u32 rec_bytes = P.sbytes + P.cbytes;
-	u64 m = BcCfg<SIZE>::CAP;
-	if (!P.without_output && rec_bytes) /* a tile of L records counts at most L / cutoff_min k-mers: they must fit the tile's span */
-		m = std::min<u64>(m, (u64)std::max<u32>(P.cutoff_min, 1) * (pitch / rec_bytes));
-	return (u32)m;
-}
 template <int SIZE> bool count_applicable(const DevParams &P)
 {
 	static const bool allow_two_phase = [] {
 		const char *e = getenv("KMC_HIP_TWO_PHASE");
 		return !e || atoi(e) != 0;
 	}();
-	/* room for the last bucket of a tile: at least a quarter of the nominal slack */
-	return allow_two_phase && count_max_len<SIZE>(P) >= (u32)BcCfg<SIZE>::STRIDE + (u32)(BcCfg<SIZE>::CAP - BcCfg<SIZE>::STRIDE) / 4;
+	/* a tile of L records counts at most L / cutoff_min k-mers, and its span of the free array has 8 SIZE bytes per record (+ 3 bytes of dword padding,
+	 * inside the span as long as a stored record is not longer than that) */
+	const u32 rec_bytes = P.sbytes + P.cbytes;
+	return allow_two_phase && (P.without_output || rec_bytes <= (u32)(SIZE * 8));
 }
 template <int SIZE>
 int count_group(Slot &s, const std::vector<BinPlan> &bins, const u64 *sorted, u64 *scratch, const DevParams &P, u64 lut_entries, const SortPlan &sp, u64 n_total, u32 *d_flag)
@@ -721,7 +714,6 @@ int count_group(Slot &s, const std::vector<BinPlan> &bins, const u64 *sorted, u6
 	const u32 n_sh = !use_lut ? 1u : lut_shards_for(lut_entries);
 	const u32 rec_bytes = P.sbytes + P.cbytes;
 	constexpr u64 S = BcCfg<SIZE>::STRIDE;
-	const u64 pitch = S * SIZE * 8;
 	GrpBounds gbn = {};
 	GrpBucket gb = {};
 	GrpFold gf = {};
@@ -766,6 +758,7 @@ int count_group(Slot &s, const std::vector<BinPlan> &bins, const u64 *sorted, u6
 		gg.prefix[i] = gb.status[i];
 		gg.out[i] = b.d_out;
 		gg.out_capacity[i] = b.out_capacity;
+		gg.src_rec[i] = bounds + items;
 		items += bin_wins + 1;
 		wins += bin_wins;
 	}
@@ -779,12 +772,12 @@ int count_group(Slot &s, const std::vector<BinPlan> &bins, const u64 *sorted, u6
 	}
 	k_bucket_bounds<SIZE><<<dim3((u32)((items + 3) / 4)), dim3(256), 0, s.stream>>>(gbn, (u32)S, sp.key_bits, sp.hbits());
 	k_bucket_count<SIZE><<<dim3((u32)wins), dim3(BcCfg<SIZE>::THREADS), bc_lds_bytes<SIZE>(), s.stream>>>(
-	    gb, P, sp.key_bits, sp.hbits(), count_max_len<SIZE>(P), n_sh, lut_entries, P.lut_prefix_len ? (u32)((1ull << (2 * P.lut_prefix_len)) - 1) : 0u, pitch, d_flag);
+	    gb, P, sp.key_bits, sp.hbits(), n_sh, lut_entries, P.lut_prefix_len ? (u32)((1ull << (2 * P.lut_prefix_len)) - 1) : 0u, d_flag);
 	if (s.timed)
 		HIPCHK(hipEventRecord(e1, s.stream));
 	k_compact_fold<<<dim3((u32)bins.size()), dim3(256), 0, s.stream>>>(gf, use_lut ? n_sh : 1u, lut_entries, 1u, rec_bytes, err);
 	if (!P.without_output)
-		k_compact_gather<<<dim3((u32)((wins + 3) / 4)), dim3(256), 0, s.stream>>>(gg, rec_bytes, pitch);
+		k_compact_gather<<<dim3((u32)((wins + 3) / 4)), dim3(256), 0, s.stream>>>(gg, rec_bytes, (u64)SIZE * 8);
 	HIPCHK(hipGetLastError());
 	return 0;
 }
@@ -985,9 +978,15 @@ int drain_redo(Slot &s)
 	std::vector<Slot::PendingGroup> groups;
 	groups.swap(s.pending_groups);
 	bool any = false;
+	static const bool no_redo = getenv("KMC_HIP_NO_REDO") != nullptr; /* timing experiments only: flagged groups keep their (wrong) output */
 	for (size_t i = 0; i < groups.size(); ++i) {
 		if (!log[i] || groups[i].descs.empty())
 			continue;
+		if (no_redo) {
+			g_redo_groups.fetch_add(1, std::memory_order_relaxed);
+			any = true;
+			continue;
+		}
 		any = true;
 		g_redo_groups.fetch_add(1, std::memory_order_relaxed);
 		std::vector<const kmc_hip_bin_desc *> ptrs;

@@ -40,6 +40,9 @@ VARIANTS = {
     "cp_bidx": ["-DCP_TILE_FROM_BLOCKIDX=1"],  # compaction tiles in blockIdx order (no ticket atomic)
     "rs_bidx": ["-DRS_TILE_FROM_BLOCKIDX=1"],  # scatter tiles in blockIdx order
     "bidx2": ["-DCP_TILE_FROM_BLOCKIDX=1", "-DRS_TILE_FROM_BLOCKIDX=1"],
+    "bc1": ["-DBC_STOP_AFTER=1"],  # k_bucket_count cut after its phase 1 / 2 / 3 (garbage output): phase costs
+    "bc2": ["-DBC_STOP_AFTER=2"],
+    "bc3": ["-DBC_STOP_AFTER=3"],
 }
 
 
