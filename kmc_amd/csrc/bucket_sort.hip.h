@@ -363,29 +363,38 @@ __global__ void __launch_bounds__(BsCfg<SIZE>::THREADS) k_bucket_sort(u64 *__res
  *   2  every record looks for its k-mer in its sub-bucket's slots, open addressing from a hashed start: an empty slot is claimed with a
  *      compare-and-swap (tag = the claiming record's position, count 1: the record now OWNS its k-mer), a slot whose owner holds the same
  *      k-mer gets its count bumped. This is the run-length counting, parallel over RECORDS: 30x coverage costs one probe and one add per copy.
- *   3  every owner applies the cutoffs and the clamp to its slot's count (kb_sorter.h:1174-1192); an owner whose k-mer is counted scans its
- *      sub-bucket's slots for counted k-mers smaller than its own (one or two distinct k-mers per sub-bucket on average) and adds itself to
- *      its sub-bucket's number of counted k-mers; a scan of those numbers gives every counted k-mer its rank in the tile
- *   4  records assembled in LDS at their ranks and written to the tile's span of the free record array, the tile's count to status[tile]
- *      (two-phase output: k_compact_fold turns the counts into offsets, k_compact_gather moves the records), per-tile aggregated LUT atomics
- *      and sharded tallies exactly as k_compact. Nothing is ever sorted.
+ *   3  the slots are in k-mer order sub-bucket by sub-bucket, so the number of counted k-mers (count inside the cutoffs, kb_sorter.h:1174-1192) in
+ *      the slots in front of a sub-bucket is one scan over the tag array; an owner whose k-mer is counted adds the counted k-mers of its own
+ *      sub-bucket that are smaller than its own (one or two distinct k-mers per sub-bucket on average): its rank in the tile. Nothing is sorted.
+ *   4  the owner writes its record at that rank into the tile's span of the free record array (counted k-mers are ~4 % of the records at the
+ *      default cutoff: byte stores, merged in L2) and counts its LUT prefix in a small LDS histogram (flushed with one global atomic per
+ *      prefix); the tile's count goes to status[tile] (two-phase output: k_compact_fold turns the counts into offsets, k_compact_gather moves
+ *      the records), tallies are sharded exactly as in k_compact.
  * HBM traffic per record: the 8 SIZE bytes of its one read. The span of a tile starts at the byte offset of its first record in the free
  * array (8 SIZE bytes per record of room), so a tile of any length has room for its output. A tile longer than the LDS capacity is counted in
  * bucket-aligned chunks; only a single BUCKET beyond the capacity (one k-mer repeated thousands of times) sets *flag: the host runs the group
  * again with LSD passes over every byte and k_compact. */
 #ifndef BC_BLOCK_THREADS
-#define BC_BLOCK_THREADS 512 /* 8 waves, 4096-record tiles of one-word records: 64 KB of LDS, two workgroups per CU */
+#define BC_BLOCK_THREADS 1024 /* 16 waves x 4 rows of 64 records: 4096-record tiles of one-word records, 64 KB of LDS, two workgroups per CU */
 #endif
+#ifndef BC_WORDS_PER_THREAD
+#define BC_WORDS_PER_THREAD 4
+#endif
+#ifndef BC_MIN_WAVES
+#define BC_MIN_WAVES 8 /* waves per SIMD the register allocator must leave room for: two workgroups of 1024 per CU */
+#endif
+constexpr int BC_LUT_HIST = 1024; /* LUT prefixes a tile aggregates in LDS; a tile that spans more of them adds to the LUT directly */
 template <int SIZE> struct BcCfg {
 	static constexpr int THREADS = BC_BLOCK_THREADS;
-	static constexpr int ITEMS = (BS_WORDS_PER_THREAD / SIZE) > 2 ? (BS_WORDS_PER_THREAD / SIZE) : 2;
+	static constexpr int ITEMS = (BC_WORDS_PER_THREAD / SIZE) > 2 ? (BC_WORDS_PER_THREAD / SIZE) : 2;
 	static constexpr int CAP = THREADS * ITEMS;
 	static constexpr int STRIDE = CAP / 4 * 3; /* window length: a tile is STRIDE records on average; one that outgrows CAP takes a second chunk */
 	static_assert(CAP < 65535, "positions + 1 are kept in 16 bits");
 };
 template <int SIZE> constexpr size_t bc_lds_bytes()
 {
-	return (size_t)BcCfg<SIZE>::CAP * SIZE * 8 + ((size_t)2 * BcCfg<SIZE>::CAP + 2) * 4 + (6 * (BcCfg<SIZE>::THREADS / 64) + 4) * 4 + 16;
+	return (size_t)BcCfg<SIZE>::CAP * SIZE * 8 + ((size_t)2 * BcCfg<SIZE>::CAP + 2) * 4 + (size_t)(BcCfg<SIZE>::THREADS + BC_LUT_HIST) * 4 +
+	       (6 * (BcCfg<SIZE>::THREADS / 64) + 4) * 4 + 16;
 }
 template <int SIZE> constexpr u64 bc_target_bucket() { return (BcCfg<SIZE>::CAP - BcCfg<SIZE>::STRIDE) / 64 > 4 ? (BcCfg<SIZE>::CAP - BcCfg<SIZE>::STRIDE) / 64 : 4; }
 
@@ -400,17 +409,20 @@ struct GrpBucket {
 };
 
 template <int SIZE>
-__global__ void __launch_bounds__(BcCfg<SIZE>::THREADS) k_bucket_count(const GrpBucket gb, DevParams P, u32 key_bits, u32 hbits, u32 lut_shards, u64 lut_stride, u32 lut_mask,
-                                                                    u32 *flag)
+__global__ void __launch_bounds__(BcCfg<SIZE>::THREADS, (SIZE <= 2 ? BC_MIN_WAVES : BC_MIN_WAVES / 2)) k_bucket_count(const GrpBucket gb, DevParams P, u32 key_bits, u32 hbits, u32 lut_shards,
+                                                                                                             u64 lut_stride, u32 lut_mask, u32 *flag)
 {
 	constexpr int THREADS = BcCfg<SIZE>::THREADS, ITEMS = BcCfg<SIZE>::ITEMS, CAP = BcCfg<SIZE>::CAP, NW = THREADS / 64;
 	constexpr u64 S = BcCfg<SIZE>::STRIDE;
 	constexpr u32 NONE = 0xFFFFFFFFu;
+	static_assert(CAP == THREADS * ITEMS, "a thread scans ITEMS consecutive counters / slots");
 	KMC_DYN_LDS(unsigned char, s_raw);
-	u64 *s_rec = reinterpret_cast<u64 *>(s_raw);                      /* [CAP * SIZE] records in arrival order; later the output staging area */
-	u32 *s_cnt = reinterpret_cast<u32 *>(s_rec + (size_t)CAP * SIZE); /* [CAP + 1] records per sub-bucket -> first slot; later counted k-mers per sub-bucket -> first rank */
-	u32 *s_tag = s_cnt + CAP + 1;                                     /* [CAP] [15:0] owner position + 1 (0 = free), [31:16] count; later the LUT prefixes of the counted k-mers */
-	u32 *s_tmp = s_tag + CAP;                                         /* [NW + 1] */
+	u64 *s_rec = reinterpret_cast<u64 *>(s_raw);                      /* [CAP * SIZE] records in arrival order */
+	u32 *s_cnt = reinterpret_cast<u32 *>(s_rec + (size_t)CAP * SIZE); /* [CAP + 1] records per sub-bucket -> first slot of its region */
+	u32 *s_tag = s_cnt + CAP + 1;                                     /* [CAP] [15:0] owner position + 1 (0 = free), [31:16] count */
+	u32 *s_pre = s_tag + CAP;                                         /* [THREADS] counted k-mers in the slots before slot ITEMS * t */
+	u32 *s_lut = s_pre + THREADS;                                     /* [BC_LUT_HIST] counted k-mers per LUT prefix, relative to the tile's first */
+	u32 *s_tmp = s_lut + BC_LUT_HIST;                                 /* [NW + 1] */
 	u32 *s_wfirst = s_tmp + NW + 1, *s_wlast = s_wfirst + NW;         /* [NW] each */
 	u32 *s_wtal = s_wlast + NW;                                       /* [NW][3] distinct / below min / above max */
 
@@ -429,17 +441,24 @@ __global__ void __launch_bounds__(BcCfg<SIZE>::THREADS) k_bucket_count(const Grp
 	const u32 bsh = 64 - hbits;
 	const u64 lane_le = (2ull << lane) - 1; /* this lane and the ones below */
 	auto bucket_of = [&](const u64(&x)[SIZE]) -> u64 { return hbits ? bs_p64<SIZE>(x, key_bits) >> bsh : 0ull; };
+	auto counted = [&](u32 w) -> bool { const u32 c = w >> 16; return w != 0 && c >= P.cutoff_min && c <= P.cutoff_max; };
 	uint8_t *const span = gb.scratch[bin] + b0 * (u64)(SIZE * 8); /* this tile's output: room for 8 SIZE bytes per record */
 	u32 nu = 0, nb = 0, na = 0;                                    /* this thread's owners: distinct / below min / above max */
 	u32 counted_done = 0;                                          /* counted k-mers of the chunks before this one */
+	const u32 pshift = 2 * (P.k - P.lut_prefix_len);
 
 	for (u64 c0 = b0; c0 < b1;) { /* chunks of whole buckets; nearly always one */
 		const u64 *__restrict__ T = gb.S[bin] + c0 * SIZE;
 		const u32 avail = (b1 - c0) > (u64)CAP ? (u32)CAP : (u32)(b1 - c0);
-		for (u32 i = tid; i <= (u32)CAP; i += THREADS)
-			s_cnt[i] = 0;
-		for (u32 i = tid; i < (u32)CAP; i += THREADS)
-			s_tag[i] = 0;
+#pragma unroll
+		for (int q = 0; q < ITEMS; ++q) {
+			s_cnt[q * THREADS + tid] = 0;
+			s_tag[q * THREADS + tid] = 0;
+		}
+		if (tid == 0)
+			s_cnt[CAP] = 0;
+		for (u32 i = tid; i < (u32)BC_LUT_HIST; i += THREADS)
+			s_lut[i] = 0;
 		u64 key[ITEMS][SIZE];
 #pragma unroll
 		for (int r = 0; r < ITEMS; ++r) {
@@ -566,16 +585,13 @@ __global__ void __launch_bounds__(BcCfg<SIZE>::THREADS) k_bucket_count(const Grp
 		return;
 #endif
 		/* ---- 2: count the copies. Region of sub-bucket i: slots [s_cnt[i], s_cnt[i+1]) — one slot per record, so a free slot always exists. */
-		u32 areg[ITEMS];   /* [15:0] first slot of the record's region, [31:16] its length */
 		u32 myslot[ITEMS]; /* the slot this record owns, NONE if it is a copy */
 #pragma unroll
 		for (int r = 0; r < ITEMS; ++r) {
 			const u32 idx = crel + r * 64 + lane;
-			areg[r] = 0;
 			myslot[r] = NONE;
 			if (idx < len) {
 				const u32 a = s_cnt[sub[r]], nreg = s_cnt[sub[r] + 1] - a;
-				areg[r] = a | (nreg << 16);
 				u32 h = 0;
 #pragma unroll
 				for (int w = 0; w < SIZE; ++w)
@@ -605,13 +621,46 @@ __global__ void __launch_bounds__(BcCfg<SIZE>::THREADS) k_bucket_count(const Grp
 #if defined(BC_STOP_AFTER) && BC_STOP_AFTER <= 2
 		return;
 #endif
-		/* ---- 3: owners classify their k-mer; a counted one finds how many counted k-mers of its sub-bucket are smaller */
-		for (u32 i = tid; i <= (u32)CAP; i += THREADS)
-			s_cnt[i] = 0; /* every reader of the region table is past the barrier: it becomes "counted k-mers per sub-bucket" */
-		u32 ec[ITEMS]; /* counted owners: [15:0] smaller counted k-mers in the region, [31:16] the count to store; else 0 */
+		/* ---- 3: counted k-mers in front of every group of ITEMS slots */
+		u32 chunk_counted;
+		{
+			u32 n = 0;
+#pragma unroll
+			for (int q = 0; q < ITEMS; ++q)
+				n += counted(s_tag[tid * ITEMS + q]) ? 1u : 0u;
+			s_pre[tid] = block_excl_sum<NW, u32>(n, s_tmp, chunk_counted);
+		}
+		__syncthreads();
+#if defined(BC_STOP_AFTER) && BC_STOP_AFTER <= 3
+		return;
+#endif
+		/* the LUT prefixes this chunk can hold: those of its first bucket's smallest and its last bucket's largest k-mer */
+		u32 pf_lo = 0, pf_span = 0;
+		if (use_lut) {
+			u64 f[SIZE], l[SIZE];
+			load_rec<SIZE>(s_rec, f);
+			load_rec<SIZE>(s_rec + (size_t)(len - 1) * SIZE, l);
+			kmc_mask_low<SIZE>(f, 2 * P.k);
+			kmc_mask_low<SIZE>(l, 2 * P.k);
+			/* below the bucket bits everything is possible: clear them in the first record, set them in the last */
+			const u32 low = key_bits > hbits ? key_bits - hbits : 0; /* key bits below the bucket bits (tag bits above 2k are masked off already) */
+			u64 fl[SIZE], lh[SIZE];
+#pragma unroll
+			for (int w = 0; w < SIZE; ++w) {
+				const u32 lo_bit = 64u * w;
+				const u64 mask = low <= lo_bit ? 0ull : (low - lo_bit >= 64 ? ~0ull : ((1ull << (low - lo_bit)) - 1));
+				fl[w] = f[w] & ~mask;
+				lh[w] = l[w] | mask;
+			}
+			kmc_mask_low<SIZE>(lh, 2 * P.k);
+			pf_lo = (u32)kmc_remove_suffix<SIZE>(fl, pshift) & lut_mask;
+			const u32 pf_hi = (u32)kmc_remove_suffix<SIZE>(lh, pshift) & lut_mask;
+			pf_span = pf_hi >= pf_lo ? pf_hi - pf_lo + 1 : 0xFFFFFFFFu;
+		}
+		u64 *const lut = use_lut ? gb.lut_base[bin] + (size_t)(tile % lut_shards) * lut_stride : nullptr;
+		/* ---- 4: owners: tallies; a counted k-mer finds its rank and writes its record */
 #pragma unroll
 		for (int r = 0; r < ITEMS; ++r) {
-			ec[r] = 0;
 			if (myslot[r] != NONE) {
 				const u32 c = s_tag[myslot[r]] >> 16;
 				++nu;
@@ -619,93 +668,46 @@ __global__ void __launch_bounds__(BcCfg<SIZE>::THREADS) k_bucket_count(const Grp
 					++nb;
 				else if (c > P.cutoff_max)
 					++na;
-				else {
-					const u32 a = areg[r] & 0xFFFFu, e = a + (areg[r] >> 16);
-					u32 smaller = 0;
+				else if (!P.without_output) {
+					const u32 a = s_cnt[sub[r]], e = s_cnt[sub[r] + 1];
+					u32 rank = s_pre[a / ITEMS];
+					for (u32 q = a - a % ITEMS; q < a; ++q)
+						rank += counted(s_tag[q]) ? 1u : 0u;
 					for (u32 q = a; q < e; ++q) {
 						const u32 wq = s_tag[q];
-						const u32 cq = wq >> 16;
-						if (q != myslot[r] && wq && cq >= P.cutoff_min && cq <= P.cutoff_max) {
+						if (q != myslot[r] && counted(wq)) {
 							u64 o[SIZE];
 							load_rec<SIZE>(s_rec + (size_t)((wq & 0xFFFFu) - 1) * SIZE, o);
-							smaller += kmc_less<SIZE>(o, key[r]) ? 1u : 0u;
+							rank += kmc_less<SIZE>(o, key[r]) ? 1u : 0u;
 						}
 					}
-					ec[r] = smaller | ((c > P.counter_max ? P.counter_max : c) << 16);
-				}
-			}
-		}
-		__syncthreads();
-#pragma unroll
-		for (int r = 0; r < ITEMS; ++r)
-			if (ec[r])
-				(void)__hip_atomic_fetch_add(&s_cnt[sub[r]], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-		__syncthreads();
-		u32 chunk_counted;
-		{
-			u32 c[ITEMS], sum = 0;
-#pragma unroll
-			for (int q = 0; q < ITEMS; ++q) {
-				c[q] = s_cnt[tid * ITEMS + q];
-				sum += c[q];
-			}
-			u32 run = block_excl_sum<NW, u32>(sum, s_tmp, chunk_counted);
-#pragma unroll
-			for (int q = 0; q < ITEMS; ++q) {
-				s_cnt[tid * ITEMS + q] = run;
-				run += c[q];
-			}
-		}
-		__syncthreads();
-#if defined(BC_STOP_AFTER) && BC_STOP_AFTER <= 3
-		return;
-#endif
-		/* ---- 4: records at their ranks. s_rec is free (the region scans are behind the barriers above): it is the staging area now, s_tag the
-		 * list of LUT prefixes */
-		if (!P.without_output && chunk_counted) {
-			uint8_t *s_stage = reinterpret_cast<uint8_t *>(s_rec);
-			u32 *s_pref = s_tag;
-			const u32 pshift = 2 * (P.k - P.lut_prefix_len);
-#pragma unroll
-			for (int r = 0; r < ITEMS; ++r) {
-				if (ec[r]) {
-					const u32 rank = s_cnt[sub[r]] + (ec[r] & 0xFFFFu);
-					const u32 cntv = ec[r] >> 16;
+					const u32 cntv = c > P.counter_max ? P.counter_max : c;
 					u64 kx[SIZE];
 #pragma unroll
 					for (int w = 0; w < SIZE; ++w)
 						kx[w] = key[r][w];
 					kmc_mask_low<SIZE>(kx, 2 * P.k); /* drops a group tag above the k-mer (KFF records carry the top bytes) */
-					if (use_lut)
-						s_pref[rank] = (u32)kmc_remove_suffix<SIZE>(kx, pshift) & lut_mask;
-					uint8_t *dstb = s_stage + (size_t)rank * rec_bytes;
+					uint8_t *dstb = span + (u64)(counted_done + rank) * rec_bytes;
 					for (u32 q = 0; q < P.sbytes; ++q)
 						dstb[q] = (uint8_t)kmc_get_byte<SIZE>(kx, P.sbytes - 1 - q); /* suffix bytes high -> low (kb_sorter.h:1198-1199) */
 					for (u32 q = 0; q < P.cbytes; ++q)
 						dstb[P.sbytes + q] = (uint8_t)(cntv >> (8 * (P.kff ? (P.cbytes - 1 - q) : q))); /* :1200-1201 / KFF :1210-1211 */
+					if (use_lut) {
+						const u32 pf = (u32)kmc_remove_suffix<SIZE>(kx, pshift) & lut_mask;
+						if (pf_span <= (u32)BC_LUT_HIST && pf - pf_lo < (u32)BC_LUT_HIST)
+							(void)__hip_atomic_fetch_add(&s_lut[pf - pf_lo], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+						else
+							atomicAdd(&lut[pf], 1ull);
+					}
 				}
 			}
-			__syncthreads();
-			const u32 chunk_bytes = chunk_counted * rec_bytes;
-			uint8_t *dst = span + (u64)counted_done * rec_bytes;
-			if ((counted_done * rec_bytes & 3u) == 0) { /* the span is 8-byte aligned: whole dwords (the bytes behind the last record are the span's own) */
-				u32 *dst32 = reinterpret_cast<u32 *>(dst);
-				const u32 *src32 = reinterpret_cast<const u32 *>(s_stage);
-				for (u32 wd = tid; wd < (chunk_bytes + 3) / 4; wd += THREADS)
-					dst32[wd] = src32[wd];
-			} else {
-				for (u32 q = tid; q < chunk_bytes; q += THREADS)
-					dst[q] = s_stage[q];
-			}
-			if (use_lut) {
-				u64 *lut = gb.lut_base[bin] + (size_t)(tile % lut_shards) * lut_stride;
-				for (u32 q = tid; q < chunk_counted; q += THREADS) {
-					const u32 pf = s_pref[q];
-					if (q + 1 == chunk_counted || s_pref[q + 1] != pf)
-						atomicAdd(&lut[pf], (u64)(q + 1));
-					if (q > 0 && s_pref[q - 1] != pf)
-						atomicAdd(&lut[pf], (u64)0 - (u64)q);
-				}
+		}
+		__syncthreads();
+		if (use_lut && pf_span <= (u32)BC_LUT_HIST) {
+			for (u32 i = tid; i < pf_span; i += THREADS) {
+				const u32 v = s_lut[i];
+				if (v)
+					atomicAdd(&lut[pf_lo + i], (u64)v);
 			}
 		}
 		counted_done += chunk_counted;
