@@ -383,6 +383,11 @@ __global__ void __launch_bounds__(BsCfg<SIZE>::THREADS) k_bucket_sort(u64 *__res
 #ifndef BC_MIN_WAVES
 #define BC_MIN_WAVES 8 /* waves per SIMD the register allocator must leave room for: two workgroups of 1024 per CU */
 #endif
+#ifndef BC_HASH_CAP
+#define BC_HASH_CAP 8 /* a k-mer's probe sequence starts in the first BC_HASH_CAP slots of its region: a region has one slot per RECORD (25 copies of
+                       * one k-mer: 25 slots, one of them claimed), and whoever scans a region for its claimed slots (step 4) can stop at the first
+                       * free slot behind those — a slot further back is only ever claimed by a probe that found the slot before it taken */
+#endif
 constexpr int BC_LUT_HIST = 1024; /* LUT prefixes a tile aggregates in LDS; a tile that spans more of them adds to the LUT directly */
 template <int SIZE> struct BcCfg {
 	static constexpr int THREADS = BC_BLOCK_THREADS;
@@ -440,7 +445,7 @@ __global__ void __launch_bounds__(BcCfg<SIZE>::THREADS, (SIZE <= 2 ? BC_MIN_WAVE
 	const bool use_lut = P.lut_prefix_len != 0 && !P.kff && !P.without_output;
 	const u32 bsh = 64 - hbits;
 	const u64 lane_le = (2ull << lane) - 1; /* this lane and the ones below */
-	auto bucket_of = [&](const u64(&x)[SIZE]) -> u64 { return hbits ? bs_p64<SIZE>(x, key_bits) >> bsh : 0ull; };
+	auto bucket_of = [&](const u64(&x)[SIZE]) -> u32 { return hbits ? (u32)(bs_p64<SIZE>(x, key_bits) >> bsh) : 0u; }; /* hbits <= 32 (kmc_hip.hip plan_sort) */
 	auto counted = [&](u32 w) -> bool { const u32 c = w >> 16; return w != 0 && c >= P.cutoff_min && c <= P.cutoff_max; };
 	uint8_t *const span = gb.scratch[bin] + b0 * (u64)(SIZE * 8); /* this tile's output: room for 8 SIZE bytes per record */
 	u32 nu = 0, nb = 0, na = 0;                                    /* this thread's owners: distinct / below min / above max */
@@ -473,7 +478,7 @@ __global__ void __launch_bounds__(BcCfg<SIZE>::THREADS, (SIZE <= 2 ? BC_MIN_WAVE
 			}
 		}
 		/* ---- 1: bucket starts, one scalar mask per row */
-		u64 prev_last = 0;
+		u32 prev_last = 0;
 		if (crel > 0 && crel - 1 < avail) {
 			u64 x[SIZE];
 			load_rec<SIZE>(T + (size_t)(crel - 1) * SIZE, x);
@@ -484,8 +489,8 @@ __global__ void __launch_bounds__(BcCfg<SIZE>::THREADS, (SIZE <= 2 ? BC_MIN_WAVE
 #pragma unroll
 		for (int r = 0; r < ITEMS; ++r) {
 			const u32 rowrel = crel + r * 64, idx = rowrel + lane;
-			const u64 bk = bucket_of(key[r]);
-			u64 pv = __shfl_up(bk, 1);
+			const u32 bk = bucket_of(key[r]);
+			u32 pv = __shfl_up(bk, 1);
 			if (lane == 0)
 				pv = prev_last;
 			const u64 m = __ballot(idx < avail && (idx == 0 || pv != bk));
@@ -597,7 +602,7 @@ __global__ void __launch_bounds__(BcCfg<SIZE>::THREADS, (SIZE <= 2 ? BC_MIN_WAVE
 				for (int w = 0; w < SIZE; ++w)
 					h = (h ^ (u32)key[r][w] ^ (u32)(key[r][w] >> 32)) * 0x9E3779B1u;
 				h ^= h >> 15;
-				u32 slot = a + __umulhi(h * 0x85EBCA6Bu, nreg);
+				u32 slot = a + __umulhi(h * 0x85EBCA6Bu, nreg < (u32)BC_HASH_CAP ? nreg : (u32)BC_HASH_CAP);
 				for (u32 probe = 0; probe < nreg; ++probe) {
 					u32 w = __hip_atomic_load(&s_tag[slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 					if (w == 0) {
@@ -675,6 +680,8 @@ __global__ void __launch_bounds__(BcCfg<SIZE>::THREADS, (SIZE <= 2 ? BC_MIN_WAVE
 						rank += counted(s_tag[q]) ? 1u : 0u;
 					for (u32 q = a; q < e; ++q) {
 						const u32 wq = s_tag[q];
+						if (wq == 0 && q >= a + (u32)BC_HASH_CAP)
+							break; /* nothing is claimed behind a free slot out here (BC_HASH_CAP) */
 						if (q != myslot[r] && counted(wq)) {
 							u64 o[SIZE];
 							load_rec<SIZE>(s_rec + (size_t)((wq & 0xFFFFu) - 1) * SIZE, o);
