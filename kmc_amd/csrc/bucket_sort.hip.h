@@ -363,9 +363,9 @@ __global__ void __launch_bounds__(BsCfg<SIZE>::THREADS) k_bucket_sort(u64 *__res
  *   2  every record looks for its k-mer in its sub-bucket's slots, open addressing from a hashed start: an empty slot is claimed with a
  *      compare-and-swap (tag = the claiming record's position, count 1: the record now OWNS its k-mer), a slot whose owner holds the same
  *      k-mer gets its count bumped. This is the run-length counting, parallel over RECORDS: 30x coverage costs one probe and one add per copy.
- *   3  the slots are in k-mer order sub-bucket by sub-bucket, so the number of counted k-mers (count inside the cutoffs, kb_sorter.h:1174-1192) in
- *      the slots in front of a sub-bucket is one scan over the tag array; an owner whose k-mer is counted adds the counted k-mers of its own
- *      sub-bucket that are smaller than its own (one or two distinct k-mers per sub-bucket on average): its rank in the tile. Nothing is sorted.
+ *   3  owners apply the cutoffs (kb_sorter.h:1174-1192); a counted k-mer adds one to its sub-bucket's number of counted k-mers, one scan over the
+ *      sub-buckets turns those into "counted k-mers before this sub-bucket" = the rank in the tile of a counted k-mer that is alone in its
+ *      sub-bucket; the rare one that is not adds the smaller counted k-mers of its sub-bucket (a scan of a few slots). Nothing is sorted.
  *   4  the owner writes its record at that rank into the tile's span of the free record array (counted k-mers are ~4 % of the records at the
  *      default cutoff: byte stores, merged in L2) and counts its LUT prefix in a small LDS histogram (flushed with one global atomic per
  *      prefix); the tile's count goes to status[tile] (two-phase output: k_compact_fold turns the counts into offsets, k_compact_gather moves
@@ -398,7 +398,7 @@ template <int SIZE> struct BcCfg {
 };
 template <int SIZE> constexpr size_t bc_lds_bytes()
 {
-	return (size_t)BcCfg<SIZE>::CAP * SIZE * 8 + ((size_t)2 * BcCfg<SIZE>::CAP + 2) * 4 + (size_t)(BcCfg<SIZE>::THREADS + BC_LUT_HIST) * 4 +
+	return (size_t)BcCfg<SIZE>::CAP * SIZE * 8 + ((size_t)2 * BcCfg<SIZE>::CAP + 2) * 4 + (size_t)BC_LUT_HIST * 4 +
 	       (6 * (BcCfg<SIZE>::THREADS / 64) + 4) * 4 + 16;
 }
 template <int SIZE> constexpr u64 bc_target_bucket() { return (BcCfg<SIZE>::CAP - BcCfg<SIZE>::STRIDE) / 64 > 4 ? (BcCfg<SIZE>::CAP - BcCfg<SIZE>::STRIDE) / 64 : 4; }
@@ -423,10 +423,9 @@ __global__ void __launch_bounds__(BcCfg<SIZE>::THREADS, (SIZE <= 2 ? BC_MIN_WAVE
 	static_assert(CAP == THREADS * ITEMS, "a thread scans ITEMS consecutive counters / slots");
 	KMC_DYN_LDS(unsigned char, s_raw);
 	u64 *s_rec = reinterpret_cast<u64 *>(s_raw);                      /* [CAP * SIZE] records in arrival order */
-	u32 *s_cnt = reinterpret_cast<u32 *>(s_rec + (size_t)CAP * SIZE); /* [CAP + 1] records per sub-bucket -> first slot of its region */
+	u32 *s_cnt = reinterpret_cast<u32 *>(s_rec + (size_t)CAP * SIZE); /* [CAP + 1] records per sub-bucket -> [15:0] first slot of its region, [31:16] (step 3) counted k-mers in front of it */
 	u32 *s_tag = s_cnt + CAP + 1;                                     /* [CAP] [15:0] owner position + 1 (0 = free), [31:16] count */
-	u32 *s_pre = s_tag + CAP;                                         /* [THREADS] counted k-mers in the slots before slot ITEMS * t */
-	u32 *s_lut = s_pre + THREADS;                                     /* [BC_LUT_HIST] counted k-mers per LUT prefix, relative to the tile's first */
+	u32 *s_lut = s_tag + CAP;                                     /* [BC_LUT_HIST] counted k-mers per LUT prefix, relative to the tile's first */
 	u32 *s_tmp = s_lut + BC_LUT_HIST;                                 /* [NW + 1] */
 	u32 *s_wfirst = s_tmp + NW + 1, *s_wlast = s_wfirst + NW;         /* [NW] each */
 	u32 *s_wtal = s_wlast + NW;                                       /* [NW][3] distinct / below min / above max */
@@ -626,14 +625,43 @@ __global__ void __launch_bounds__(BcCfg<SIZE>::THREADS, (SIZE <= 2 ? BC_MIN_WAVE
 #if defined(BC_STOP_AFTER) && BC_STOP_AFTER <= 2
 		return;
 #endif
-		/* ---- 3: counted k-mers in front of every group of ITEMS slots */
+		/* ---- 3: owners apply the cutoffs (kb_sorter.h:1174-1192); every counted k-mer adds one to its sub-bucket's entry of the region table
+		 * (upper half of the word; the first slot stays in the lower half), and a scan of those numbers replaces them by "counted k-mers in the
+		 * sub-buckets before this one" — which is the rank of a counted k-mer that is alone in its sub-bucket (nearly all are) */
+		u32 mycount[ITEMS]; /* a counted owner's count; 0 for everybody else */
+#pragma unroll
+		for (int r = 0; r < ITEMS; ++r) {
+			mycount[r] = 0;
+			if (myslot[r] != NONE) {
+				const u32 c = s_tag[myslot[r]] >> 16;
+				++nu;
+				if (c < P.cutoff_min)
+					++nb;
+				else if (c > P.cutoff_max)
+					++na;
+				else {
+					mycount[r] = c;
+					(void)__hip_atomic_fetch_add(&s_cnt[sub[r]], 1u << 16, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+				}
+			}
+		}
+		__syncthreads();
 		u32 chunk_counted;
 		{
-			u32 n = 0;
+			u32 w[ITEMS], sum = 0;
 #pragma unroll
-			for (int q = 0; q < ITEMS; ++q)
-				n += counted(s_tag[tid * ITEMS + q]) ? 1u : 0u;
-			s_pre[tid] = block_excl_sum<NW, u32>(n, s_tmp, chunk_counted);
+			for (int q = 0; q < ITEMS; ++q) {
+				w[q] = s_cnt[tid * ITEMS + q];
+				sum += w[q] >> 16;
+			}
+			u32 run = block_excl_sum<NW, u32>(sum, s_tmp, chunk_counted);
+#pragma unroll
+			for (int q = 0; q < ITEMS; ++q) {
+				s_cnt[tid * ITEMS + q] = (w[q] & 0xFFFFu) | (run << 16);
+				run += w[q] >> 16;
+			}
+			if (tid == 0)
+				s_cnt[CAP] = (s_cnt[CAP] & 0xFFFFu) | (chunk_counted << 16);
 		}
 		__syncthreads();
 #if defined(BC_STOP_AFTER) && BC_STOP_AFTER <= 3
@@ -663,32 +691,27 @@ __global__ void __launch_bounds__(BcCfg<SIZE>::THREADS, (SIZE <= 2 ? BC_MIN_WAVE
 			pf_span = pf_hi >= pf_lo ? pf_hi - pf_lo + 1 : 0xFFFFFFFFu;
 		}
 		u64 *const lut = use_lut ? gb.lut_base[bin] + (size_t)(tile % lut_shards) * lut_stride : nullptr;
-		/* ---- 4: owners: tallies; a counted k-mer finds its rank and writes its record */
+		/* ---- 4: a counted k-mer writes its record at its rank */
+		if (!P.without_output) {
 #pragma unroll
-		for (int r = 0; r < ITEMS; ++r) {
-			if (myslot[r] != NONE) {
-				const u32 c = s_tag[myslot[r]] >> 16;
-				++nu;
-				if (c < P.cutoff_min)
-					++nb;
-				else if (c > P.cutoff_max)
-					++na;
-				else if (!P.without_output) {
-					const u32 a = s_cnt[sub[r]], e = s_cnt[sub[r] + 1];
-					u32 rank = s_pre[a / ITEMS];
-					for (u32 q = a - a % ITEMS; q < a; ++q)
-						rank += counted(s_tag[q]) ? 1u : 0u;
-					for (u32 q = a; q < e; ++q) {
-						const u32 wq = s_tag[q];
-						if (wq == 0 && q >= a + (u32)BC_HASH_CAP)
-							break; /* nothing is claimed behind a free slot out here (BC_HASH_CAP) */
-						if (q != myslot[r] && counted(wq)) {
-							u64 o[SIZE];
-							load_rec<SIZE>(s_rec + (size_t)((wq & 0xFFFFu) - 1) * SIZE, o);
-							rank += kmc_less<SIZE>(o, key[r]) ? 1u : 0u;
+			for (int r = 0; r < ITEMS; ++r) {
+				if (mycount[r]) {
+					const u32 w0 = s_cnt[sub[r]], w1 = s_cnt[sub[r] + 1];
+					u32 rank = w0 >> 16;
+					if ((w1 >> 16) - rank > 1) { /* several counted k-mers share the sub-bucket: this one goes behind the smaller ones */
+						const u32 a = w0 & 0xFFFFu, e = w1 & 0xFFFFu;
+						for (u32 q = a; q < e; ++q) {
+							const u32 wq = s_tag[q];
+							if (wq == 0 && q >= a + (u32)BC_HASH_CAP)
+								break; /* nothing is claimed behind a free slot out here (BC_HASH_CAP) */
+							if (q != myslot[r] && counted(wq)) {
+								u64 o[SIZE];
+								load_rec<SIZE>(s_rec + (size_t)((wq & 0xFFFFu) - 1) * SIZE, o);
+								rank += kmc_less<SIZE>(o, key[r]) ? 1u : 0u;
+							}
 						}
 					}
-					const u32 cntv = c > P.counter_max ? P.counter_max : c;
+					const u32 cntv = mycount[r] > P.counter_max ? P.counter_max : mycount[r];
 					u64 kx[SIZE];
 #pragma unroll
 					for (int w = 0; w < SIZE; ++w)
