@@ -691,8 +691,8 @@ __global__ void __launch_bounds__(BcCfg<SIZE>::THREADS, (SIZE <= 2 ? BC_MIN_WAVE
 			pf_span = pf_hi >= pf_lo ? pf_hi - pf_lo + 1 : 0xFFFFFFFFu;
 		}
 		u64 *const lut = use_lut ? gb.lut_base[bin] + (size_t)(tile % lut_shards) * lut_stride : nullptr;
-		/* ---- 4: a counted k-mer writes its record at its rank */
-		if (!P.without_output) {
+		/* ---- 4: a counted k-mer finds its rank ... */
+		if (!P.without_output && chunk_counted) { /* uniform over the workgroup */
 #pragma unroll
 			for (int r = 0; r < ITEMS; ++r) {
 				if (mycount[r]) {
@@ -711,17 +711,37 @@ __global__ void __launch_bounds__(BcCfg<SIZE>::THREADS, (SIZE <= 2 ? BC_MIN_WAVE
 							}
 						}
 					}
-					const u32 cntv = mycount[r] > P.counter_max ? P.counter_max : mycount[r];
+					mycount[r] = (mycount[r] > P.counter_max ? P.counter_max : mycount[r]) | (rank << 16); /* count <= chunk length < 2^16 */
+				}
+			}
+			__syncthreads(); /* ... and, the region scans being over, assembles its record in LDS where the records were: per-lane byte stores straight
+			                  * to HBM cost more than everything else in this kernel together (2.6 of 4.7 ms per 190 M records) */
+			const bool fast = rec_bytes <= 8; /* a record is one 64-bit value in output byte order, one 8-byte slot per record */
+			u64 *s_rec64 = s_rec;
+			uint8_t *s_stage = reinterpret_cast<uint8_t *>(s_rec);
+#pragma unroll
+			for (int r = 0; r < ITEMS; ++r) {
+				if (mycount[r]) {
+					const u32 rank = mycount[r] >> 16, cntv = mycount[r] & 0xFFFFu;
 					u64 kx[SIZE];
 #pragma unroll
 					for (int w = 0; w < SIZE; ++w)
 						kx[w] = key[r][w];
 					kmc_mask_low<SIZE>(kx, 2 * P.k); /* drops a group tag above the k-mer (KFF records carry the top bytes) */
-					uint8_t *dstb = span + (u64)(counted_done + rank) * rec_bytes;
-					for (u32 q = 0; q < P.sbytes; ++q)
-						dstb[q] = (uint8_t)kmc_get_byte<SIZE>(kx, P.sbytes - 1 - q); /* suffix bytes high -> low (kb_sorter.h:1198-1199) */
-					for (u32 q = 0; q < P.cbytes; ++q)
-						dstb[P.sbytes + q] = (uint8_t)(cntv >> (8 * (P.kff ? (P.cbytes - 1 - q) : q))); /* :1200-1201 / KFF :1210-1211 */
+					if (fast) {
+						u64 rv = P.sbytes ? __builtin_bswap64(kx[0] << (8 * (8 - P.sbytes))) : 0ull; /* suffix bytes high -> low (kb_sorter.h:1198-1199) */
+						if (P.cbytes) {
+							const u32 cv = P.kff ? (__builtin_bswap32(cntv) >> (8 * (4 - P.cbytes))) : cntv; /* :1200-1201 / KFF :1210-1211 */
+							rv |= (u64)cv << (8 * P.sbytes);
+						}
+						s_rec64[rank] = rv;
+					} else {
+						uint8_t *dstb = s_stage + (size_t)rank * rec_bytes;
+						for (u32 q = 0; q < P.sbytes; ++q)
+							dstb[q] = (uint8_t)kmc_get_byte<SIZE>(kx, P.sbytes - 1 - q);
+						for (u32 q = 0; q < P.cbytes; ++q)
+							dstb[P.sbytes + q] = (uint8_t)(cntv >> (8 * (P.kff ? (P.cbytes - 1 - q) : q)));
+					}
 					if (use_lut) {
 						const u32 pf = (u32)kmc_remove_suffix<SIZE>(kx, pshift) & lut_mask;
 						if (pf_span <= (u32)BC_LUT_HIST && pf - pf_lo < (u32)BC_LUT_HIST)
@@ -731,13 +751,50 @@ __global__ void __launch_bounds__(BcCfg<SIZE>::THREADS, (SIZE <= 2 ? BC_MIN_WAVE
 					}
 				}
 			}
-		}
-		__syncthreads();
-		if (use_lut && pf_span <= (u32)BC_LUT_HIST) {
-			for (u32 i = tid; i < pf_span; i += THREADS) {
-				const u32 v = s_lut[i];
-				if (v)
-					atomicAdd(&lut[pf_lo + i], (u64)v);
+			__syncthreads();
+			/* the chunk's bytes, coalesced. Byte i of the chunk is byte i % rec_bytes of record i / rec_bytes (fast: of its 8-byte slot). */
+			const u32 chunk_bytes = chunk_counted * rec_bytes;
+			const u32 inv = rec_bytes > 1 ? (u32)(((1ull << 32) + rec_bytes - 1) / rec_bytes) : 0u; /* x / rec_bytes = umulhi(x, inv), exact for x < 2^29 */
+			auto stage_byte = [&](u32 i) -> u32 {
+				if (!fast)
+					return s_stage[i];
+				const u32 ri = rec_bytes > 1 ? __umulhi(i, inv) : i;
+				return (u32)(s_rec64[ri] >> (8 * (i - ri * rec_bytes))) & 0xFFu;
+			};
+			uint8_t *dst = span + (u64)counted_done * rec_bytes;
+			if ((counted_done * rec_bytes & 3u) == 0) { /* the span is 8-byte aligned: whole dwords (the bytes behind the last record are the span's own) */
+				u32 *dst32 = reinterpret_cast<u32 *>(dst);
+				for (u32 wd = tid; wd < (chunk_bytes + 3) / 4; wd += THREADS) {
+					u32 word;
+					if (!fast)
+						word = reinterpret_cast<const u32 *>(s_stage)[wd];
+					else {
+						const u32 i0 = wd * 4;
+						u32 ri = rec_bytes > 1 ? __umulhi(i0, inv) : i0, q = i0 - ri * rec_bytes;
+						u64 cur = s_rec64[ri];
+						word = 0;
+#pragma unroll
+						for (int t = 0; t < 4; ++t) {
+							word |= ((u32)(cur >> (8 * q)) & 0xFFu) << (8 * t);
+							if (++q == rec_bytes) {
+								q = 0;
+								++ri;
+								cur = s_rec64[ri < (u32)CAP ? ri : (u32)CAP - 1];
+							}
+						}
+					}
+					dst32[wd] = word;
+				}
+			} else { /* a later chunk of a long tile */
+				for (u32 i = tid; i < chunk_bytes; i += THREADS)
+					dst[i] = (uint8_t)stage_byte(i);
+			}
+			if (use_lut && pf_span <= (u32)BC_LUT_HIST) {
+				for (u32 i = tid; i < pf_span; i += THREADS) {
+					const u32 v = s_lut[i];
+					if (v)
+						atomicAdd(&lut[pf_lo + i], (u64)v);
+				}
 			}
 		}
 		counted_done += chunk_counted;
