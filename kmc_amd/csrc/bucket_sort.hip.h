@@ -398,10 +398,23 @@ template <int SIZE> struct BcCfg {
 };
 template <int SIZE> constexpr size_t bc_lds_bytes()
 {
-	return (size_t)BcCfg<SIZE>::CAP * SIZE * 8 + ((size_t)2 * BcCfg<SIZE>::CAP + 2) * 4 + (size_t)BC_LUT_HIST * 4 +
+	return (size_t)BcCfg<SIZE>::CAP * SIZE * 8 + ((size_t)2 * BcCfg<SIZE>::CAP + 3) * 4 + (size_t)BC_LUT_HIST * 4 +
 	       (6 * (BcCfg<SIZE>::THREADS / 64) + 4) * 4 + 16;
 }
 template <int SIZE> constexpr u64 bc_target_bucket() { return (BcCfg<SIZE>::CAP - BcCfg<SIZE>::STRIDE) / 64 > 4 ? (BcCfg<SIZE>::CAP - BcCfg<SIZE>::STRIDE) / 64 : 4; }
+
+#ifdef KMC_TRACE /* tuning builds: thread 0 of every tile adds the time since its previous stamp to phase counter j (tools/trace_bc.py) */
+#define BC_STAMP(j)                                                                                                             \
+	do {                                                                                                                        \
+		if (threadIdx.x == 0) {                                                                                                 \
+			const unsigned long long now__ = wall_clock64();                                                                   \
+			atomicAdd(&g_trace[(3 * (TRACE_SLOTS / 4)) * 8 + (j)], now__ - bc_t_prev);                                           \
+			bc_t_prev = now__;                                                                                                  \
+		}                                                                                                                       \
+	} while (0)
+#else
+#define BC_STAMP(j) do { } while (0)
+#endif
 
 struct GrpBucket {
 	u32 g, win_prefix[GRP_MAX + 1]; /* windows (= tiles) of bin b */
@@ -424,11 +437,11 @@ __global__ void __launch_bounds__(BcCfg<SIZE>::THREADS, (SIZE <= 2 ? BC_MIN_WAVE
 	KMC_DYN_LDS(unsigned char, s_raw);
 	u64 *s_rec = reinterpret_cast<u64 *>(s_raw);                      /* [CAP * SIZE] records in arrival order */
 	u32 *s_cnt = reinterpret_cast<u32 *>(s_rec + (size_t)CAP * SIZE); /* [CAP + 1] records per sub-bucket -> [15:0] first slot of its region, [31:16] (step 3) counted k-mers in front of it */
-	u32 *s_tag = s_cnt + CAP + 1;                                     /* [CAP] [15:0] owner position + 1 (0 = free), [31:16] count */
-	u32 *s_lut = s_tag + CAP;                                     /* [BC_LUT_HIST] counted k-mers per LUT prefix, relative to the tile's first */
+	u32 *s_tag = s_cnt + CAP + 1;                                     /* [CAP + 1] [15:0] owner position + 1 (0 = free), [31:16] count; before that, the table of bucket starts */
+	u32 *s_lut = s_tag + CAP + 1;                                     /* [BC_LUT_HIST] counted k-mers per LUT prefix, relative to the tile's first */
 	u32 *s_tmp = s_lut + BC_LUT_HIST;                                 /* [NW + 1] */
-	u32 *s_wfirst = s_tmp + NW + 1, *s_wlast = s_wfirst + NW;         /* [NW] each */
-	u32 *s_wtal = s_wlast + NW;                                       /* [NW][3] distinct / below min / above max */
+	u32 *s_wfirst = s_tmp + NW + 1;                                   /* [NW] bucket starts in wave w's rows */
+	u32 *s_wtal = s_wfirst + NW;                                       /* [NW][3] distinct / below min / above max */
 
 	const u32 gtile = blockIdx.x;
 	const u32 bin = (u32)__builtin_amdgcn_readfirstlane((int)grp_find(gb.win_prefix, gb.g, gtile));
@@ -443,22 +456,22 @@ __global__ void __launch_bounds__(BcCfg<SIZE>::THREADS, (SIZE <= 2 ? BC_MIN_WAVE
 	const u32 rec_bytes = P.sbytes + P.cbytes;
 	const bool use_lut = P.lut_prefix_len != 0 && !P.kff && !P.without_output;
 	const u32 bsh = 64 - hbits;
-	const u64 lane_le = (2ull << lane) - 1; /* this lane and the ones below */
 	auto bucket_of = [&](const u64(&x)[SIZE]) -> u32 { return hbits ? (u32)(bs_p64<SIZE>(x, key_bits) >> bsh) : 0u; }; /* hbits <= 32 (kmc_hip.hip plan_sort) */
 	auto counted = [&](u32 w) -> bool { const u32 c = w >> 16; return w != 0 && c >= P.cutoff_min && c <= P.cutoff_max; };
 	uint8_t *const span = gb.scratch[bin] + b0 * (u64)(SIZE * 8); /* this tile's output: room for 8 SIZE bytes per record */
 	u32 nu = 0, nb = 0, na = 0;                                    /* this thread's owners: distinct / below min / above max */
 	u32 counted_done = 0;                                          /* counted k-mers of the chunks before this one */
 	const u32 pshift = 2 * (P.k - P.lut_prefix_len);
+#ifdef KMC_TRACE
+	unsigned long long bc_t_prev = wall_clock64();
+#endif
 
 	for (u64 c0 = b0; c0 < b1;) { /* chunks of whole buckets; nearly always one */
 		const u64 *__restrict__ T = gb.S[bin] + c0 * SIZE;
 		const u32 avail = (b1 - c0) > (u64)CAP ? (u32)CAP : (u32)(b1 - c0);
 #pragma unroll
-		for (int q = 0; q < ITEMS; ++q) {
+		for (int q = 0; q < ITEMS; ++q)
 			s_cnt[q * THREADS + tid] = 0;
-			s_tag[q * THREADS + tid] = 0;
-		}
 		if (tid == 0)
 			s_cnt[CAP] = 0;
 		for (u32 i = tid; i < (u32)BC_LUT_HIST; i += THREADS)
@@ -476,103 +489,85 @@ __global__ void __launch_bounds__(BcCfg<SIZE>::THREADS, (SIZE <= 2 ? BC_MIN_WAVE
 					key[r][w] = 0;
 			}
 		}
-		/* ---- 1: bucket starts, one scalar mask per row */
+		/* ---- 1: bucket starts ("heads"). A record's bucket is known by its ORDINAL among the chunk's buckets = heads at or before the record - 1:
+		 * a popcount of the row's head mask below the lane (mbcnt) + the heads of the rows and waves before. The start positions go into a table
+		 * indexed by that ordinal (it lives where the tag array will be: nothing probes yet), so a record finds the start and the end of its bucket
+		 * with two LDS reads — no per-lane 64-bit mask arithmetic. */
+		u32 *s_start = s_tag;
 		u32 prev_last = 0;
 		if (crel > 0 && crel - 1 < avail) {
 			u64 x[SIZE];
 			load_rec<SIZE>(T + (size_t)(crel - 1) * SIZE, x);
 			prev_last = bucket_of(x);
 		}
-		u64 heads[ITEMS];
-		u32 wfirst = NONE, wlast = NONE;
+		u32 headbits = 0, below[ITEMS], wheads = 0; /* bit r: this lane's record of row r starts a bucket; heads of the wave's earlier rows + lower lanes */
 #pragma unroll
 		for (int r = 0; r < ITEMS; ++r) {
-			const u32 rowrel = crel + r * 64, idx = rowrel + lane;
+			const u32 idx = crel + r * 64 + lane;
 			const u32 bk = bucket_of(key[r]);
 			u32 pv = __shfl_up(bk, 1);
 			if (lane == 0)
 				pv = prev_last;
-			const u64 m = __ballot(idx < avail && (idx == 0 || pv != bk));
-			heads[r] = m;
-			if (m) {
-				if (wfirst == NONE)
-					wfirst = rowrel + (u32)__ffsll((long long)m) - 1;
-				wlast = rowrel + 63 - (u32)__clzll((long long)m);
-			}
+			const bool head = idx < avail && (idx == 0 || pv != bk);
+			const u64 m = __ballot(head);
+			headbits |= head ? 1u << r : 0u;
+			below[r] = __builtin_amdgcn_mbcnt_hi((u32)(m >> 32), __builtin_amdgcn_mbcnt_lo((u32)m, wheads));
+			wheads += (u32)__popcll(m);
 			prev_last = __shfl(bk, 63);
 		}
-		if (lane == 0) {
-			s_wfirst[wave] = wfirst;
-			s_wlast[wave] = wlast;
-		}
+		if (lane == 0)
+			s_wfirst[wave] = wheads;
 		__syncthreads();
+		u32 wave_heads_before, total_heads;
+		{
+			const u32 v = lane < (u32)NW ? s_wfirst[lane] : 0u;
+			const u32 inc = wave_incl_sum<u32>(v, lane);
+			total_heads = __shfl(inc, NW - 1);
+			wave_heads_before = __shfl(inc - v, (int)wave);
+		}
+#pragma unroll
+		for (int r = 0; r < ITEMS; ++r)
+			if ((headbits >> r) & 1u)
+				s_start[wave_heads_before + below[r]] = crel + r * 64 + lane; /* ordinal of this head = heads before it */
+		if (tid == 0)
+			s_start[total_heads] = avail;
+		__syncthreads();
+		BC_STAMP(0); /* clear, load, bucket starts */
 		/* the chunk: everything that was loaded, or — when the tile has more — up to the start of the last bucket that began inside it */
 		u32 len = avail;
 		if ((b1 - c0) > (u64)CAP) {
-			u32 last_head = 0;
-#pragma unroll
-			for (int w = 0; w < NW; ++w) {
-				const u32 l = s_wlast[w];
-				if (l != NONE)
-					last_head = l; /* ascending over waves */
-			}
-			if (last_head == 0) { /* one bucket beyond the LDS capacity (uniform over the workgroup) */
+			len = s_start[total_heads - 1];
+			if (len == 0) { /* one bucket beyond the LDS capacity (uniform over the workgroup) */
 				if (tid == 0)
 					atomicOr(flag, 1u);
 				return;
 			}
-			len = last_head;
-		}
-		u32 carry_f = 0, carry_b = len;
-#pragma unroll
-		for (int w = 0; w < NW; ++w) {
-			const u32 l = s_wlast[w], f = s_wfirst[NW - 1 - w];
-			if (w < (int)wave && l != NONE)
-				carry_f = l;
-			if (NW - 1 - w > (int)wave && f != NONE && f < len)
-				carry_b = f;
-		}
-		carry_f = (u32)__builtin_amdgcn_readfirstlane((int)carry_f);
-		carry_b = (u32)__builtin_amdgcn_readfirstlane((int)carry_b);
-		u32 bend[ITEMS];
-#pragma unroll
-		for (int r = ITEMS - 1; r >= 0; --r) {
-			const u32 rowrel = crel + r * 64;
-			u64 m = heads[r];
-			if (rowrel + 63 >= len) /* heads at or beyond the cut do not belong to this chunk */
-				m = rowrel >= len ? 0ull : (m & (((u64)1 << (len - rowrel)) - 1));
-			heads[r] = m;
-			const u64 above = m & ~lane_le;
-			bend[r] = above ? rowrel + (u32)__ffsll((long long)above) - 1 : carry_b;
-			if (m)
-				carry_b = rowrel + (u32)__ffsll((long long)m) - 1;
 		}
 		u32 sub[ITEMS]; /* the record's sub-bucket */
 #pragma unroll
 		for (int r = 0; r < ITEMS; ++r) {
-			const u32 rowrel = crel + r * 64, idx = rowrel + lane;
-			const u64 m = heads[r];
-			const u64 upto = m & lane_le;
-			const u32 bstart = upto ? rowrel + 63 - (u32)__clzll((long long)upto) : carry_f;
-			if (m)
-				carry_f = rowrel + 63 - (u32)__clzll((long long)m);
+			const u32 idx = crel + r * 64 + lane;
 			sub[r] = 0;
 			if (idx < len) {
+				const u32 ord = wave_heads_before + below[r] + ((headbits >> r) & 1u) - 1;
+				const u32 bstart = s_start[ord], bend = s_start[ord + 1];
 				const u64 p = bs_p64<SIZE>(key[r], key_bits);
 				const u32 rem32 = (u32)((hbits ? (p << hbits) : p) >> 32);
-				u32 id = bstart + __umulhi(rem32, bend[r] - bstart);
+				u32 id = bstart + __umulhi(rem32, bend - bstart);
 				id = id < len ? id : len - 1; /* in range by construction; the clamp is for records of a corrupt bin (the error word is already set) */
 				sub[r] = id;
 				(void)__hip_atomic_fetch_add(&s_cnt[id], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 			}
 		}
 		__syncthreads();
+		BC_STAMP(1); /* sub-buckets, counting */
 		{
 			u32 c[ITEMS], sum = 0;
 #pragma unroll
 			for (int q = 0; q < ITEMS; ++q) {
 				c[q] = s_cnt[tid * ITEMS + q];
 				sum += c[q];
+				s_tag[q * THREADS + tid] = 0; /* the table of bucket starts has been read: the tag array starts empty */
 			}
 			u32 total;
 			u32 run = block_excl_sum<NW, u32>(sum, s_tmp, total);
@@ -581,10 +576,13 @@ __global__ void __launch_bounds__(BcCfg<SIZE>::THREADS, (SIZE <= 2 ? BC_MIN_WAVE
 				s_cnt[tid * ITEMS + q] = run;
 				run += c[q];
 			}
-			if (tid == 0)
+			if (tid == 0) {
 				s_cnt[CAP] = total;
+				s_tag[CAP] = 0;
+			}
 		}
 		__syncthreads();
+		BC_STAMP(2); /* region table scan */
 #if defined(BC_STOP_AFTER) && BC_STOP_AFTER <= 1 /* tuning builds only: what does each phase cost? (the output is garbage) */
 		return;
 #endif
@@ -622,6 +620,7 @@ __global__ void __launch_bounds__(BcCfg<SIZE>::THREADS, (SIZE <= 2 ? BC_MIN_WAVE
 			}
 		}
 		__syncthreads();
+		BC_STAMP(3); /* probing */
 #if defined(BC_STOP_AFTER) && BC_STOP_AFTER <= 2
 		return;
 #endif
@@ -646,6 +645,7 @@ __global__ void __launch_bounds__(BcCfg<SIZE>::THREADS, (SIZE <= 2 ? BC_MIN_WAVE
 			}
 		}
 		__syncthreads();
+		BC_STAMP(4); /* owners classify + count per sub-bucket */
 		u32 chunk_counted;
 		{
 			u32 w[ITEMS], sum = 0;
@@ -664,6 +664,7 @@ __global__ void __launch_bounds__(BcCfg<SIZE>::THREADS, (SIZE <= 2 ? BC_MIN_WAVE
 				s_cnt[CAP] = (s_cnt[CAP] & 0xFFFFu) | (chunk_counted << 16);
 		}
 		__syncthreads();
+		BC_STAMP(5); /* scan of counted per sub-bucket */
 #if defined(BC_STOP_AFTER) && BC_STOP_AFTER <= 3
 		return;
 #endif
@@ -714,34 +715,20 @@ __global__ void __launch_bounds__(BcCfg<SIZE>::THREADS, (SIZE <= 2 ? BC_MIN_WAVE
 					mycount[r] = (mycount[r] > P.counter_max ? P.counter_max : mycount[r]) | (rank << 16); /* count <= chunk length < 2^16 */
 				}
 			}
-			__syncthreads(); /* ... and, the region scans being over, assembles its record in LDS where the records were: per-lane byte stores straight
-			                  * to HBM cost more than everything else in this kernel together (2.6 of 4.7 ms per 190 M records) */
-			const bool fast = rec_bytes <= 8; /* a record is one 64-bit value in output byte order, one 8-byte slot per record */
-			u64 *s_rec64 = s_rec;
-			uint8_t *s_stage = reinterpret_cast<uint8_t *>(s_rec);
+			__syncthreads(); /* ... and, the region scans being over, assembles its record in LDS where the records were */
+			BC_STAMP(6); /* ranks */
+			/* staged: the k-mer (tag bits cleared) where the records were, at its rank; its count where the tags were */
 #pragma unroll
 			for (int r = 0; r < ITEMS; ++r) {
 				if (mycount[r]) {
-					const u32 rank = mycount[r] >> 16, cntv = mycount[r] & 0xFFFFu;
+					const u32 rank = mycount[r] >> 16;
 					u64 kx[SIZE];
 #pragma unroll
 					for (int w = 0; w < SIZE; ++w)
 						kx[w] = key[r][w];
 					kmc_mask_low<SIZE>(kx, 2 * P.k); /* drops a group tag above the k-mer (KFF records carry the top bytes) */
-					if (fast) {
-						u64 rv = P.sbytes ? __builtin_bswap64(kx[0] << (8 * (8 - P.sbytes))) : 0ull; /* suffix bytes high -> low (kb_sorter.h:1198-1199) */
-						if (P.cbytes) {
-							const u32 cv = P.kff ? (__builtin_bswap32(cntv) >> (8 * (4 - P.cbytes))) : cntv; /* :1200-1201 / KFF :1210-1211 */
-							rv |= (u64)cv << (8 * P.sbytes);
-						}
-						s_rec64[rank] = rv;
-					} else {
-						uint8_t *dstb = s_stage + (size_t)rank * rec_bytes;
-						for (u32 q = 0; q < P.sbytes; ++q)
-							dstb[q] = (uint8_t)kmc_get_byte<SIZE>(kx, P.sbytes - 1 - q);
-						for (u32 q = 0; q < P.cbytes; ++q)
-							dstb[P.sbytes + q] = (uint8_t)(cntv >> (8 * (P.kff ? (P.cbytes - 1 - q) : q)));
-					}
+					store_rec<SIZE>(s_rec + (size_t)rank * SIZE, kx);
+					s_tag[rank] = mycount[r] & 0xFFFFu;
 					if (use_lut) {
 						const u32 pf = (u32)kmc_remove_suffix<SIZE>(kx, pshift) & lut_mask;
 						if (pf_span <= (u32)BC_LUT_HIST && pf - pf_lo < (u32)BC_LUT_HIST)
@@ -752,42 +739,36 @@ __global__ void __launch_bounds__(BcCfg<SIZE>::THREADS, (SIZE <= 2 ? BC_MIN_WAVE
 				}
 			}
 			__syncthreads();
-			/* the chunk's bytes, coalesced. Byte i of the chunk is byte i % rec_bytes of record i / rec_bytes (fast: of its 8-byte slot). */
+			BC_STAMP(7); /* k-mers staged */
+			/* the chunk's bytes, coalesced: byte i of the chunk is byte i % rec_bytes of record i / rec_bytes — suffix bytes high -> low
+			 * (kb_sorter.h:1198-1199), then the counter, little-endian for KMC (:1200-1201), big-endian for KFF (:1210-1211) */
 			const u32 chunk_bytes = chunk_counted * rec_bytes;
 			const u32 inv = rec_bytes > 1 ? (u32)(((1ull << 32) + rec_bytes - 1) / rec_bytes) : 0u; /* x / rec_bytes = umulhi(x, inv), exact for x < 2^29 */
-			auto stage_byte = [&](u32 i) -> u32 {
-				if (!fast)
-					return s_stage[i];
-				const u32 ri = rec_bytes > 1 ? __umulhi(i, inv) : i;
-				return (u32)(s_rec64[ri] >> (8 * (i - ri * rec_bytes))) & 0xFFu;
+			auto out_byte = [&](u32 i) -> u32 {
+				const u32 ri = rec_bytes > 1 ? __umulhi(i, inv) : i, q = i - ri * rec_bytes;
+				if (q < P.sbytes) {
+					const u32 pbyte = P.sbytes - 1 - q;
+					return (u32)(s_rec[(size_t)ri * SIZE + (pbyte >> 3)] >> ((pbyte & 7) * 8)) & 0xFFu;
+				}
+				const u32 cq = q - P.sbytes;
+				return (s_tag[ri] >> (8 * (P.kff ? (P.cbytes - 1 - cq) : cq))) & 0xFFu;
 			};
 			uint8_t *dst = span + (u64)counted_done * rec_bytes;
 			if ((counted_done * rec_bytes & 3u) == 0) { /* the span is 8-byte aligned: whole dwords (the bytes behind the last record are the span's own) */
 				u32 *dst32 = reinterpret_cast<u32 *>(dst);
+#pragma clang loop unroll(disable) vectorize(disable)
 				for (u32 wd = tid; wd < (chunk_bytes + 3) / 4; wd += THREADS) {
-					u32 word;
-					if (!fast)
-						word = reinterpret_cast<const u32 *>(s_stage)[wd];
-					else {
-						const u32 i0 = wd * 4;
-						u32 ri = rec_bytes > 1 ? __umulhi(i0, inv) : i0, q = i0 - ri * rec_bytes;
-						u64 cur = s_rec64[ri];
-						word = 0;
-#pragma unroll
-						for (int t = 0; t < 4; ++t) {
-							word |= ((u32)(cur >> (8 * q)) & 0xFFu) << (8 * t);
-							if (++q == rec_bytes) {
-								q = 0;
-								++ri;
-								cur = s_rec64[ri < (u32)CAP ? ri : (u32)CAP - 1];
-							}
-						}
-					}
+					const u32 i0 = wd * 4;
+					u32 word = out_byte(i0);
+					word |= (i0 + 1 < chunk_bytes ? out_byte(i0 + 1) : 0u) << 8;
+					word |= (i0 + 2 < chunk_bytes ? out_byte(i0 + 2) : 0u) << 16;
+					word |= (i0 + 3 < chunk_bytes ? out_byte(i0 + 3) : 0u) << 24;
 					dst32[wd] = word;
 				}
 			} else { /* a later chunk of a long tile */
+#pragma clang loop unroll(disable) vectorize(disable)
 				for (u32 i = tid; i < chunk_bytes; i += THREADS)
-					dst[i] = (uint8_t)stage_byte(i);
+					dst[i] = (uint8_t)out_byte(i);
 			}
 			if (use_lut && pf_span <= (u32)BC_LUT_HIST) {
 				for (u32 i = tid; i < pf_span; i += THREADS) {
@@ -797,6 +778,7 @@ __global__ void __launch_bounds__(BcCfg<SIZE>::THREADS, (SIZE <= 2 ? BC_MIN_WAVE
 				}
 			}
 		}
+		BC_STAMP(8); /* copy-out, LUT flush */
 		counted_done += chunk_counted;
 		c0 += len;
 		if (c0 < b1)
@@ -829,6 +811,7 @@ __global__ void __launch_bounds__(BcCfg<SIZE>::THREADS, (SIZE <= 2 ? BC_MIN_WAVE
 		if (!P.without_output)
 			gb.status[bin][tile] = counted_done;
 	}
+	BC_STAMP(9); /* tallies */
 }
 
 #endif
