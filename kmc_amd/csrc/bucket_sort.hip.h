@@ -401,7 +401,10 @@ template <int SIZE> constexpr size_t bc_lds_bytes()
 	return (size_t)BcCfg<SIZE>::CAP * SIZE * 8 + ((size_t)2 * BcCfg<SIZE>::CAP + 3) * 4 + (size_t)BC_LUT_HIST * 4 +
 	       (6 * (BcCfg<SIZE>::THREADS / 64) + 4) * 4 + 16;
 }
-template <int SIZE> constexpr u64 bc_target_bucket() { return (BcCfg<SIZE>::CAP - BcCfg<SIZE>::STRIDE) / 64 > 4 ? (BcCfg<SIZE>::CAP - BcCfg<SIZE>::STRIDE) / 64 : 4; }
+/* average bucket size the host aims for when it picks the number of HBM passes. What must not happen is ONE bucket beyond CAP (a longer TILE is only a
+ * second chunk), and the k-mers of a signature bin are clustered: on the bench's bins the largest of 2^22 buckets holds 100x the average at k = 27 and
+ * more at k = 55 (measured: averages of 9 with CAP 2048 sent half of the groups back to the host). So: CAP / 256 for one-word records, CAP / 512 beyond. */
+template <int SIZE> constexpr u64 bc_target_bucket() { return SIZE == 1 ? BcCfg<SIZE>::CAP / 256 : (BcCfg<SIZE>::CAP / 512 > 1 ? BcCfg<SIZE>::CAP / 512 : 1); }
 
 #ifdef KMC_TRACE /* tuning builds: thread 0 of every tile adds the time since its previous stamp to phase counter j (tools/trace_bc.py) */
 #define BC_STAMP(j)                                                                                                             \

@@ -324,7 +324,10 @@ std::atomic<u64> g_hybrid_groups{0}, g_redo_groups{0}; /* process-wide: input wh
 int hybrid_mode()
 {
 	static const int v = [] {
-		const char *e = getenv("KMC_HIP_HYBRID"); /* 0 = LSD passes over every byte (rounds 1-2); 1 = default; -h = force `h` top bytes (tuning) */
+		/* 0 = LSD passes over every byte (rounds 1-2); 1 = default: hybrid where it wins (groups of bins with records of 2+ words, k >= 33: 4 HBM passes
+		 * instead of 14 at k = 55, 3 instead of 32 at k = 127 — at k <= 32 the fused counting kernel costs what the passes it replaces cost);
+		 * 2 = hybrid for every record width and for sort-only calls; -h = force `h` top bytes (tuning) */
+		const char *e = getenv("KMC_HIP_HYBRID");
 		return e ? atoi(e) : 1;
 	}();
 	return v;
@@ -336,6 +339,8 @@ template <int SIZE> SortPlan plan_sort(u64 n, u32 key_bytes, u32 key_bits, bool 
 	sp.key_bits = key_bits;
 	const int mode = hybrid_mode();
 	if (classic || mode == 0 || key_bytes < 3 || n < 2)
+		return sp;
+	if (mode == 1 && (SIZE == 1 || !fused))
 		return sp;
 	const u32 spare = 8 * key_bytes - key_bits;
 	if (mode < 0) {
@@ -982,6 +987,12 @@ int drain_redo(Slot &s)
 	for (size_t i = 0; i < groups.size(); ++i) {
 		if (!log[i] || groups[i].descs.empty())
 			continue;
+		if (getenv("KMC_HIP_VERBOSE")) {
+			fprintf(stderr, "[kmc_hip] group %zu of %zu on this stream asked for a redo (flag %u): bins", i, groups.size(), log[i]);
+			for (const auto &d : groups[i].descs)
+				fprintf(stderr, " %llu", (unsigned long long)d.n_rec);
+			fprintf(stderr, "\n");
+		}
 		if (no_redo) {
 			g_redo_groups.fetch_add(1, std::memory_order_relaxed);
 			any = true;

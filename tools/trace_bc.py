@@ -12,9 +12,11 @@ sys.path.insert(0, ROOT)
 from kmc_amd import capi  # noqa: E402
 
 n_bins = int(sys.argv[1]) if len(sys.argv) > 1 else 8
+K = int(sys.argv[2]) if len(sys.argv) > 2 else 27
+PL = int(sys.argv[3]) if len(sys.argv) > 3 else 7
 ctx = capi.Context((0,))
-bins = capi.synth_bins(seed=2026, genome_len=1_000_000_000 * n_bins // 512, n_reads=200_000_000 * n_bins // 512, k=27, n_bins=n_bins)
-p = capi.make_params(27, lut_prefix_len=7)
+bins = capi.synth_bins(seed=2026, genome_len=1_000_000_000 * n_bins // 512, n_reads=200_000_000 * n_bins // 512, k=K, n_bins=n_bins)
+p = capi.make_params(K, lut_prefix_len=PL)
 rec, nl = ctx.out_rec_bytes(p), ctx.lut_entries(p)
 descs = (capi.BinDesc * n_bins)()
 for i, (img, nrec, packs, _) in enumerate(bins):
@@ -25,6 +27,12 @@ for i, (img, nrec, packs, _) in enumerate(bins):
     ctx.h2d(d_ps, ps)
     descs[i] = capi.BinDesc(d_in, img.size, nrec, d_ps, packs.size, d_out, cap, d_small + 32, d_lut, d_small)
 L = ctx.L
+if not hasattr(L, "kmc_hip_debug_read_trace"):
+    for it in range(2):
+        ctx.process_bins_device(p, descs, 1)
+        ctx.synchronize()
+    print("k", K, "bins", n_bins, "local sort", ctx.local_sort_totals())
+    sys.exit(0)
 L.kmc_hip_debug_read_trace.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_uint64, C.c_int]
 buf = np.zeros((1 << 17) * 8, dtype=np.uint64)
 for it in range(2):
