@@ -24,7 +24,7 @@ Extra keys of the N=1 line (each measured after the timed region, none inside it
   secondary.stage1_groundwork: NOT stage 2 — the splitter groundwork of DESIGN.md 9 (codes in HBM -> bins in HBM), timed by tools/s1_bench.py
   e2e_stage1          : NOT stage 2 — "1st stage" seconds of the reference pipeline with the splitter worker swapped too (kmc_hip_s1)
   cpu_baseline / e2e  : the REAL reference (oracle/_ref/kmc, built from /root/reference by oracle/Makefile) and the drop-in
-                        (oracle/_ref/kmc_hip = reference pipeline + this library) on a FASTQ of the SAME reads as the 2 Gbp sample:
+                        (kmc_amd/bin/kmc_hip = reference pipeline + this library) on a FASTQ of the SAME reads as the 2 Gbp sample:
                         "2nd stage" seconds of each, the five statistics compared.
 `roofline`: dominant kernel k_onesweep (one launch = one 8-bit LSD pass over one bin); achieved = algorithmic bytes of the
 launches in the timed region (2*W = 16 B per record and pass) / their summed duration (HIP events around
@@ -144,6 +144,7 @@ def build_workload(ctx, args, k, p, rank, world, keep_host=False):
     d_small = ctx.malloc(64 * max(len(own), 1))
     w.allocs = [d_in, d_ps, d_out, d_lut, d_small]
     w.d_small, w.d_out, w.d_lut, w.out_off, w.lut_n, w.rec_bytes = d_small, d_out, d_lut, out_off, lut_n, rec_bytes
+    w.d_in, w.in_off = d_in, in_off
     descs = (capi.BinDesc * max(len(own), 1))()
     zeros = np.zeros(256, dtype=np.uint8)
     host_imgs = []
@@ -211,6 +212,43 @@ def output_digest(ctx, w, res):
                 idx = np.arange(1, arr.size + 1, dtype=np.uint64)
                 dig = (dig + int(arr.sum(dtype=np.uint64)) + int((arr * idx).sum(dtype=np.uint64)) * 31 + (w.bins[i][0] + 1) * arr.size) & ((1 << 64) - 1)
     return dig
+
+
+def oracle_check(ctx, w, res, n_check=3):
+    """The timed run's own output against the oracle, at the scale that was timed: the largest, the median and the smallest bin of this rank are copied
+    back (image, suffix records, LUT, tallies) and compared byte for byte with oracle/stage2_oracle.c's process_bin on the same image. The oracle is
+    the CHECKER here (tests/oracle_py.py, ctypes over oracle/liboracle_stage2.so); nothing of it is timed or shipped."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_py as O
+
+    order = sorted(range(w.n_own), key=lambda i: w.bins[i][2])
+    picks = sorted({order[-1], order[len(order) // 2], order[0]}, key=lambda i: -w.bins[i][2])[:n_check] if order else []
+    p = w.p
+    op = O.make_params(p.kmer_len, p.both_strands, p.cutoff_min, p.cutoff_max, p.counter_max, p.lut_prefix_len, p.output_type, p.without_output)
+    verdicts = [None] * len(picks)
+
+    def one(j, i):
+        b, size, n_rec = w.bins[i][0], w.bins[i][1], w.bins[i][2]
+        img = np.zeros(size, dtype=np.uint8)
+        ctx.d2h(img, w.d_in + w.in_off[i])
+        ob = int(res[i, 4])
+        out = np.zeros(ob, dtype=np.uint8)
+        if ob:
+            ctx.d2h(out, w.d_out + w.out_off[i])
+        lut = np.zeros(max(w.lut_n, 1), dtype=np.uint64)
+        if w.lut_n:
+            ctx.d2h(lut, w.d_lut + w.lut_n * 8 * i)
+        t = time.time()
+        w_out, w_lut, w_st = O.process_bin(op, img, n_rec)
+        verdicts[j] = {"bin": int(b), "kmers": int(n_rec), "out_bytes": ob, "oracle_s": round(time.time() - t, 2),
+                       "equal": bool(np.array_equal(out, w_out) and np.array_equal(lut[: w.lut_n], w_lut) and [int(x) for x in res[i, :4]] == [int(x) for x in w_st])}
+
+    th = [threading.Thread(target=one, args=(j, i)) for j, i in enumerate(picks)]  # the oracle is single-threaded C behind ctypes (the GIL is released)
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    return verdicts
 
 
 # ---------------------------------------------------------------------------------------------------------------- host boundary
@@ -316,7 +354,7 @@ def _run_kmc(exe, flags, fq, td, tag, env=None, timeout=None):
 def reference_legs(k: int, reads: int, genome: int, runs: int = 2):
     """cpu_baseline + e2e on a FASTQ of the SAME reads as the 2 Gbp sample (kmc_amd/csrc/synth_bins.cpp writes both)."""
     ref = os.path.join(ROOT, "oracle", "_ref", "kmc")
-    hip = os.path.join(ROOT, "oracle", "_ref", "kmc_hip")
+    hip = os.path.join(ROOT, "kmc_amd", "bin", "kmc_hip")
     cores = sharding.effective_cpus()  # what the container may really use (cgroup quota), not the hardware threads it shows
     threads = min(os.cpu_count() or 1, 128)
     ram_gb = os.sysconf("SC_PAGE_SIZE") * os.sysconf("SC_PHYS_PAGES") >> 30
@@ -354,18 +392,18 @@ def reference_legs(k: int, reads: int, genome: int, runs: int = 2):
             hip_runs = [_run_kmc(hip, [f"-k{k}", f"-t{threads}", f"-m{mem}", "-sr16", "-hp"], fq, td, f"hip{i}", env) for i in range(runs)]
             h1, h2, hst, verbose = min(hip_runs, key=lambda x: x[1])
             out["e2e"] = {"what": "'2nd stage' seconds of the reference's own pipeline on the same FASTQ: unmodified (oracle/_ref/kmc) vs with the "
-                                  "stage-2 worker and bin reader swapped for this library (oracle/_ref/kmc_hip -sr16); stage 1, arena, completer and "
+                                  "stage-2 worker and bin reader swapped for this library (kmc_amd/bin/kmc_hip -sr16); stage 1, arena, completer and "
                                   "database writer are the reference's in both",
                           "ref_stage2_s": s2, "hip_stage2_s": h2, "speedup": s2 / h2, "hip_Gkmers_per_s": hst["total"] / h2 / 1e9,
                           "ref_Gkmers_per_s": st["total"] / s2 / 1e9, "stats_equal": hst == st, "hip_stats": hst, "hip_stage1_s": h1,
                           "all_hip_stage2_s": [x[1] for x in hip_runs], "all_ref_stage2_s": [x[1] for x in ref_runs], "worker_report": verbose}
             # Stage 1 on the GPU as well: informative, in its own try — kmc_hip_split_part had run under emulation only when this
             # was committed, and nothing here may cost the stage-2 line.
-            hip_s1 = os.path.join(ROOT, "oracle", "_ref", "kmc_hip_s1")
+            hip_s1 = os.path.join(ROOT, "kmc_amd", "bin", "kmc_hip_s1")
             if os.path.exists(hip_s1):
                 try:
                     g1, g2, gst, gverbose = _run_kmc(hip_s1, [f"-k{k}", f"-t{threads}", f"-m{mem}", "-sr16", "-hp"], fq, td, "hips1", env, timeout=300)
-                    out["e2e_stage1"] = {"what": "'1st stage' seconds of the same pipeline with the splitter worker swapped too (oracle/_ref/kmc_hip_s1: parts of "
+                    out["e2e_stage1"] = {"what": "'1st stage' seconds of the same pipeline with the splitter worker swapped too (kmc_amd/bin/kmc_hip_s1: parts of "
                                                  "FASTQ text through kmc_hip_split_part); readers, storer and bin files are the reference's",
                                          "ref_stage1_s": s1, "hip_stage1_s": g1, "speedup": s1 / g1 if g1 else None, "hip_stage2_s": g2, "stats_equal": gst == st,
                                          "workers": sum(1 for ln in gverbose if "stage 1" in ln),
@@ -421,13 +459,44 @@ def main():
     ap.add_argument("--no-secondary", action="store_true")
     ap.add_argument("--no-two-streams", action="store_true", help="skip the value_two_streams leg (profiling runs: keeps overlapped launches out of the kernel statistics)")
     ap.add_argument("--no-digest", action="store_true")
+    ap.add_argument("--no-oracle-check", action="store_true", help="skip the byte-for-byte comparison of three of the timed run's bins with the oracle")
     ap.add_argument("--cache", default="", help="directory for the generated bin set (tuning sessions: generate once, reuse)")
+    ap.add_argument("--dry-launch", action="store_true", help="launcher check (runs without a GPU): start the ranks --gpus asks for, rendezvous over gloo, print what they see")
     args = ap.parse_args()
 
+    # `python bench.py --gpus N` with no launcher around it starts its own N ranks (one process per GPU, rendezvous on 127.0.0.1): the same command
+    # line re-executed under torch.distributed.run. Under a launcher (the driver's `python -m torch.distributed.run ... bench.py --gpus N`) WORLD_SIZE
+    # is already there — and must agree with --gpus: a line that says n_gpus = N after timing fewer ranks would be a wrong number.
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        import socket
+
+        with socket.socket() as so:
+            so.bind(("127.0.0.1", 0))
+            port = so.getsockname()[1]
+        os.execv(sys.executable, [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+                                  "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:])
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"bench.py --gpus {args.gpus} was started with WORLD_SIZE={world}: the launcher's ranks and --gpus must agree")
     import torch
+
+    if args.dry_launch:
+        import torch.distributed as dist
+
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29531")
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        seen = torch.tensor([1], dtype=torch.int64)
+        dist.all_reduce(seen)
+        if rank == 0:
+            print(json.dumps({"dry_launch": True, "gpus_requested": args.gpus, "world_size_env": world, "ranks_seen_by_all_reduce": int(seen.item()),
+                              "n_gpus": dist.get_world_size()}))
+        dist.destroy_process_group()
+        return
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (torch.cuda.is_available() is False); there is no CPU path")
@@ -493,6 +562,12 @@ def main():
             dist.all_gather_object(parts, dg)
             dg = sum(parts) & ((1 << 64) - 1)
         digest = "%016x" % dg
+    oracle_bins = None
+    if rank == 0 and not args.no_oracle_check and not args.leg:
+        try:
+            oracle_bins = oracle_check(ctx, w, res)
+        except Exception as e:  # noqa: BLE001 — the checker must not take the measurement down with it
+            oracle_bins = [{"error": repr(e)}]
     if dist:
         okt = torch.tensor([1 if ok else 0], dtype=torch.int64, device=dev)
         dist.all_reduce(okt, op=dist.ReduceOp.MIN)
@@ -511,7 +586,7 @@ def main():
         desc = (CONFIGS[name]["desc"] % k) if name in CONFIGS else f"custom: k={k}, {args.reads} reads of a {args.genome} bp genome, {args.bins} bins"
         out = {
             "metric": "stage-2 Gk-mers/s, k=%d (bin sort & count: parse + expand + 8-bit LSD radix sort + compaction over all signature bins)" % k,
-            "value": value, "unit": "Gk-mers/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "value": value, "unit": "Gk-mers/s", "n_gpus": dist.get_world_size() if dist else 1, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": "u64", "data": "synthetic",
             "config": {"workload": desc + (" on 1 MI355X" if world == 1 else f", sharded over {world} MI355X by LPT (per-GPU bin queues, RCCL tally reduce)"),
@@ -522,7 +597,8 @@ def main():
                        "parallelism": "bins sharded over ranks (LPT), 1 process/GPU, tallies all-reduced (RCCL)" if world > 1 else "1 GPU"},
             "unique_kmers_per_s": float(tallies[0]) * args.steps / dt,
             "tallies": {"n_unique": int(tallies[0]), "n_cutoff_min": int(tallies[1]), "n_cutoff_max": int(tallies[2]), "n_total": int(tallies[3])},
-            "self_check": {"per_bin_total_and_out_bytes_consistent": bool(ok), "output_digest": digest},
+            "self_check": {"per_bin_total_and_out_bytes_consistent": bool(ok), "output_digest": digest,
+                           "oracle_bins_equal": (all(v.get("equal") for v in oracle_bins) if oracle_bins else None), "oracle_bins": oracle_bins},
             "stage2_algorithmic_bytes_per_kmer": W * (2 * P + 3),
             "stage2_algorithmic_GBs": W * (2 * P + 3) * value,
             "stage2_frac_of_hbm_peak": W * (2 * P + 3) * value / HBM_PEAK_GBS,

@@ -45,7 +45,17 @@ def build_oracle(with_reference: bool = True) -> None:
         subprocess.check_call(["make", "-s", "-j8", "-C", od, "ref"])
 
 
+BIN_DIR = os.path.join(PKG, "bin")  # the product drop-in binaries: kmc_hip, kmc_hip_s1, kmc_hip_sr, kmc_hipsort (kmc_amd/host/Makefile)
+
+
+def build_dropin() -> None:
+    """kmc_amd/bin/: the reference's own pipeline linked with the plug-ins of kmc_amd/host/ over libkmc_hip.so (needs the reference tree)."""
+    if os.path.exists("/root/reference/kmc_core/kmc_runner.cpp"):
+        subprocess.check_call(["make", "-s", "-j8", "-C", os.path.join(PKG, "host")])
+
+
 def build_all() -> None:
     build_hip()
     build_synth()
     build_oracle()
+    build_dropin()

@@ -1447,7 +1447,9 @@ __global__ void __launch_bounds__(CP_BLOCK, CpCfg<SIZE>::MIN_WAVES) k_compact(co
 							if (use_lut && r0 == 0)
 								s_pref[rank] = (u32)kmc_remove_suffix<SIZE>(key[r], pshift) & lut_mask;
 							if (rank >= r0 && rank < r1) {
-								u64 rv = P.sbytes ? __builtin_bswap64(key[r][0] << (8 * (8 - P.sbytes))) : 0ull;
+								/* without a LUT prefix (KFF) the suffix bytes reach up to the top of the k-mer: a group tag above bit 2k must not get into them */
+								const u64 k0 = (2 * P.k < 64) ? (key[r][0] & ((1ull << (2 * P.k)) - 1)) : key[r][0];
+								u64 rv = P.sbytes ? __builtin_bswap64(k0 << (8 * (8 - P.sbytes))) : 0ull;
 								if (P.cbytes) {
 									const u32 cv = P.kff ? (__builtin_bswap32(cnt[r]) >> (8 * (4 - P.cbytes))) : cnt[r];
 									rv |= (u64)cv << (8 * P.sbytes);
@@ -1507,12 +1509,17 @@ __global__ void __launch_bounds__(CP_BLOCK, CpCfg<SIZE>::MIN_WAVES) k_compact(co
 								s_pref[rank] = (u32)kmc_remove_suffix<SIZE>(key[r], pshift) & lut_mask;
 							const u32 bb = rank * rec_bytes;
 							if (bb < c1 && bb + rec_bytes > c0) {
+								u64 km[SIZE]; /* the k-mer without a group tag above bit 2k (see the fast path) */
+#pragma unroll
+								for (int w = 0; w < SIZE; ++w)
+									km[w] = key[r][w];
+								kmc_mask_low<SIZE>(km, 2 * P.k);
 								for (u32 q = 0; q < rec_bytes; ++q) {
 									const u32 bpos = bb + q;
 									if (bpos >= c0 && bpos < c1) {
 										u32 val;
 										if (q < P.sbytes)
-											val = kmc_get_byte<SIZE>(key[r], P.sbytes - 1 - q);
+											val = kmc_get_byte<SIZE>(km, P.sbytes - 1 - q);
 										else {
 											const u32 cq = q - P.sbytes;
 											val = cnt[r] >> (8 * (P.kff ? (P.cbytes - 1 - cq) : cq));

@@ -88,6 +88,7 @@ void load_api_impl()
 	std::vector<std::string> cands;
 	if (const char *e = getenv("KMC_HIP_LIB"))
 		cands.push_back(e);
+	cands.push_back(exe_dir() + "/../libkmc_hip.so");          /* kmc_amd/bin/<exe> -> kmc_amd/libkmc_hip.so */
 	cands.push_back(exe_dir() + "/../../kmc_amd/libkmc_hip.so");
 	cands.push_back("libkmc_hip.so");
 	for (auto &c : cands) {
@@ -111,17 +112,28 @@ void load_api_impl()
 		a.so = nullptr;
 		return;
 	}
+	/* devices: $KMC_HIP_DEVICES ("0,1,..."), by default EVERY visible device — the stage-2 workers are spread over them (worker i drives device
+	 * i mod n_dev), as the reference hands its bins to n_sorters threads (kmc.h:1576-1584, queues.h:2087-2128); HIP_VISIBLE_DEVICES narrows the set
+	 * from outside */
 	std::vector<int> devs;
 	const char *e = getenv("KMC_HIP_DEVICES");
-	std::string s = e ? e : "0";
-	size_t pos = 0;
-	while (pos <= s.size()) {
-		size_t q = s.find(',', pos);
-		if (q == std::string::npos)
-			q = s.size();
-		if (q > pos)
-			devs.push_back(atoi(s.substr(pos, q - pos).c_str()));
-		pos = q + 1;
+	if (e && *e) {
+		std::string s = e;
+		size_t pos = 0;
+		while (pos <= s.size()) {
+			size_t q = s.find(',', pos);
+			if (q == std::string::npos)
+				q = s.size();
+			if (q > pos)
+				devs.push_back(atoi(s.substr(pos, q - pos).c_str()));
+			pos = q + 1;
+		}
+	} else {
+		int (*device_count)() = nullptr;
+		std::string ignore;
+		const int n = sym(a.so, "kmc_hip_device_count", device_count, ignore) ? device_count() : 1;
+		for (int i = 0; i < (n > 0 ? n : 1); ++i)
+			devs.push_back(i);
 	}
 	if (devs.empty())
 		devs.push_back(0);

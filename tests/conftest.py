@@ -25,9 +25,11 @@ def ctx():
 
 @pytest.fixture(scope="session")
 def ref_bins():
-    """Paths of the prebuilt reference binaries (oracle/_ref), or None where they were never built."""
+    """Paths of the prebuilt reference binaries (oracle/_ref: the checkers) and of the product drop-in (kmc_amd/bin/kmc_hip), or None where they
+    were never built."""
     d = os.path.join(ROOT, "oracle", "_ref")
-    need = ["kmc", "kmc_oracle", "kmc_hip", "kmc_tools"]
-    if all(os.path.exists(os.path.join(d, n)) for n in need):
-        return {n: os.path.join(d, n) for n in need}
+    paths = {n: os.path.join(d, n) for n in ("kmc", "kmc_oracle", "kmc_tools")}
+    paths["kmc_hip"] = os.path.join(ROOT, "kmc_amd", "bin", "kmc_hip")
+    if all(os.path.exists(p) for p in paths.values()):
+        return paths
     return None

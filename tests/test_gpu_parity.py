@@ -309,7 +309,7 @@ def _md5(p):
 
 @pytest.mark.parametrize("flags", [["-k27"], ["-k55"], ["-k127"], ["-k27", "-b", "-ci1", "-cs3"]], ids=lambda f: "".join(f))
 def test_kmc_with_hip_sorter_writes_the_reference_database(flags, ref_bins, tmp_path):
-    """oracle/_ref/kmc_hip = the reference's own pipeline (stage 1, bin reader, completer, CLI) with
+    """kmc_amd/bin/kmc_hip = the reference's own pipeline (stage 1, bin reader, completer, CLI) with
     CWKmerBinSorter swapped for the HIP worker (kb_sorter_plugin.h + libkmc_hip.so). Its .kmc_pre/.kmc_suf must be
     byte-identical to the unmodified reference run with -sr1."""
     if ref_bins is None:
@@ -412,14 +412,15 @@ def _run_batch(ctx, p, bins, n_streams=0, shrink_cap_of=None):
 
 @pytest.mark.parametrize("n_bins,reads,genome,pl,streams,k", [(512, 400_000, 2_000_000, 7, 0, 27), (16, 400_000, 2_000_000, 7, 3, 27), (64, 60_000, 300_000, 3, 16, 27),
                                                               (23, 300_000, 1_500_000, 7, 1, 27), (40, 100_000, 500_000, 5, 2, 25), (21, 100_000, 500_000, 3, 2, 55),
-                                                              (10, 100_000, 500_000, 4, 1, 32), (9, 40_000, 200_000, 3, 1, 127)])
+                                                              (10, 100_000, 500_000, 4, 1, 32), (9, 40_000, 200_000, 3, 1, 127),
+                                                              (8, 100_000, 500_000, 0, 1, 27), (8, 60_000, 300_000, 0, 1, 55)])  # pl 0: KFF records, bins grouped
 def test_many_bins_in_one_call_match_the_oracle_per_bin(ctx, n_bins, reads, genome, pl, streams, k):
     """configs[2]'s shape in small: one read set cut into signature bins (30x coverage, lut_prefix_len 7 as KMC picks for 30 Gbp),
     ALL bins through ONE kmc_hip_process_bins_device call (bin i on stream i mod n_streams, several host threads enqueueing; consecutive
     bins of a stream share one sort, tagged in the spare bits of the top radix digit: groups of 4 at k = 27, 55, 127, of 16 at k = 25, none
     at k = 32), every bin compared with the oracle bit for bit — suffix records, LUT, tallies."""
     bins = capi.synth_bins(seed=2026, genome_len=genome, n_reads=reads, k=k, n_bins=n_bins)
-    p = hp(k, lut_prefix_len=pl)
+    p = hp(k, lut_prefix_len=pl, output_type=0 if pl else 1)
     got, err = _run_batch(ctx, p, bins, streams)
     assert err is None, err
     tot = np.zeros(4, dtype=np.uint64)
@@ -510,12 +511,12 @@ def test_dropin_database_at_bench_scale(k, reads, genome, ref_bins, tmp_path):
 
 @pytest.mark.parametrize("flags", [["-k27"], ["-k21"], ["-k55"], ["-k127"]], ids=lambda f: "".join(f))
 def test_narrow_boundary_sortfunction_adapter(flags, ref_bins, tmp_path):
-    """oracle/_ref/kmc_hipsort = the reference with ONLY its SortFunction replaced by the GPU sort (hip_sort_function.h; the
+    """kmc_amd/bin/kmc_hipsort = the reference with ONLY its SortFunction replaced by the GPU sort (hip_sort_function.h; the
     reference's own CKmerBinSorter expands and compacts on the CPU): rec_len even (k=27: 8, k=127: 32 -> result in place) and
     odd (k=21: 7, k=55: 15 -> result in tmp). Database byte-identical to the unmodified reference, both with one sorter."""
-    exe = os.path.join(ROOT, "oracle", "_ref", "kmc_hipsort")
+    exe = os.path.join(ROOT, "kmc_amd", "bin", "kmc_hipsort")
     if ref_bins is None or not os.path.exists(exe):
-        pytest.skip("oracle/_ref/kmc_hipsort was not shipped")
+        pytest.skip("kmc_amd/bin/kmc_hipsort was not shipped")
     from kmc_amd import synth
 
     fq = str(tmp_path / "in.fq")
@@ -554,7 +555,7 @@ def test_reader_plugin_with_the_hip_worker(readers, flags, ref_bins, tmp_path):
     ram = [f for f in flags if f == "-r"]
     _kmc(ref_bins["kmc"], ["-k27", "-sr1", *ram], fq, str(tmp_path / "ref"), str(tmp_path / "t_ref"))
     _kmc(ref_bins["kmc_hip"], ["-k27", *flags], fq, str(tmp_path / "hip"), str(tmp_path / "t_hip"), env=_hip_env(KMC_HIP_READERS=readers))
-    sr = os.path.join(ROOT, "oracle", "_ref", "kmc_hip_sr")
+    sr = os.path.join(ROOT, "kmc_amd", "bin", "kmc_hip_sr")
     outs = ["hip"]
     if os.path.exists(sr):
         _kmc(sr, ["-k27", *flags], fq, str(tmp_path / "hipsr"), str(tmp_path / "t_hipsr"), env=_hip_env())

@@ -1,9 +1,7 @@
-"""-m gpu: the stage-1 worker plug-in over kmc_hip_split_part inside the reference pipeline (oracle/_ref/kmc_hip_s1: stage 1 AND stage 2 on the
-GPU). Everything on this path has run on the CPU — the kernels and the launch sequence under emulation inside the reference pipeline
-(tests/test_stage1_plugin.py), the product binary over the product's host library compiled against an emulated HIP runtime
-(tests/test_hostlib_emulated.py) — but kmc_hip_split_part was written after round 2's GPU budget was spent and had not met a real GPU when this
-was committed. The tests are therefore marked xfail(strict=False): they RUN (in a child process: the binary), a pass is reported as XPASS, a
-failure as XFAIL, and neither can stop the validated suite. KMC_TEST_UNVALIDATED=0 skips them. Last file of the -m gpu collection on purpose."""
+"""-m gpu: the stage-1 worker plug-in over kmc_hip_split_part inside the reference pipeline (kmc_amd/bin/kmc_hip_s1: stage 1 AND stage 2 on the
+GPU). The kernels and the launch sequence also run on the CPU under emulation inside the reference pipeline (tests/test_stage1_plugin.py), the
+product binary over the product's host library compiled against an emulated HIP runtime (tests/test_hostlib_emulated.py). First met a real GPU in
+the driver's round-2 run (GPUTEST_r02: 4 xpassed); ordinary tests since round 3. Last file of the -m gpu collection."""
 import hashlib
 import os
 import subprocess
@@ -12,11 +10,15 @@ import pytest
 
 from kmc_amd import synth
 
-pytestmark = [pytest.mark.gpu, pytest.mark.skipif(os.environ.get("KMC_TEST_UNVALIDATED") == "0", reason="KMC_TEST_UNVALIDATED=0"),
-              pytest.mark.xfail(strict=False, reason="kmc_hip_split_part had not run on a real GPU when this was committed (emulation-validated only)")]
+pytestmark = [pytest.mark.gpu]
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 REF = os.path.join(ROOT, "oracle", "_ref")
+
+
+def _exe(name):
+    """oracle/_ref/<name> for the reference and the oracle builds (checkers), kmc_amd/bin/<name> for the product drop-in binaries"""
+    return os.path.join(ROOT, "kmc_amd", "bin", name) if name.startswith("kmc_hip") else os.path.join(REF, name)
 
 
 _state = {"broken": False}  # one failed or hung run is enough: the other parameter sets do not spend GPU time on the same problem
@@ -28,7 +30,7 @@ def _run(exe, flags, inp, tmp_path, tag, env=None):
     db = str(tmp_path / ("db_" + tag))
     e = dict(os.environ, KMC_HIP_LIB=os.path.join(ROOT, "kmc_amd", "libkmc_hip.so"), **(env or {}))
     try:
-        r = subprocess.run([os.path.join(REF, exe), *flags, inp, db, str(t)], capture_output=True, text=True, env=e, timeout=120)
+        r = subprocess.run([_exe(exe), *flags, inp, db, str(t)], capture_output=True, text=True, env=e, timeout=120)
     except subprocess.TimeoutExpired:
         _state["broken"] = True
         raise
@@ -43,7 +45,7 @@ def _run(exe, flags, inp, tmp_path, tag, env=None):
 @pytest.mark.parametrize("flags", [["-k27", "-ci1"], ["-k27", "-b"], ["-k55"], ["-k21", "-ci1"]], ids=lambda f: "".join(f))
 def test_kmc_with_hip_stage1_and_stage2_writes_the_reference_database(flags, tmp_path):
     if _state["broken"]:
-        pytest.xfail("an earlier run of kmc_hip_s1 failed or hung")
+        pytest.fail("an earlier run of kmc_hip_s1 failed or hung")
     fq = str(tmp_path / "in.fq")
     synth.make_fastq(fq, seed=31, genome_len=2_000_000, n_reads=300_000, read_len=150)
     want = _run("kmc", flags + ["-m4", "-sf1", "-sp1", "-sr1"], fq, tmp_path, "ref")

@@ -19,6 +19,11 @@ from kmc_amd import synth
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 REF = os.path.join(ROOT, "oracle", "_ref")
 
+
+def _exe(name):
+    """oracle/_ref/<name> for the reference and the oracle builds (checkers), kmc_amd/bin/<name> for the product drop-in binaries"""
+    return os.path.join(ROOT, "kmc_amd", "bin", name) if name.startswith("kmc_hip") else os.path.join(REF, name)
+
 QUICK = ("process_bin_edges or size_and_n_rec or sort_records_into or allreduce_stats_single or submit_wait or (test_stage1_kernels_match_the_oracle and 27-9) "
          "or (compact_stage_matches_oracle and 27-3) or (expand_stage_matches_oracle and 1-27) or (test_process_bin_matches_oracle and k27-cutoff)")
 
@@ -38,7 +43,7 @@ def _run(exe, flags, inp, tmp_path, tag, env=None):
     t = tmp_path / ("tmp_" + tag)
     t.mkdir(exist_ok=True)
     db = str(tmp_path / ("db_" + tag))
-    r = subprocess.run([os.path.join(REF, exe), *flags, inp, db, str(t)], capture_output=True, text=True, env=dict(os.environ, **(env or {})), timeout=1500)
+    r = subprocess.run([_exe(exe), *flags, inp, db, str(t)], capture_output=True, text=True, env=dict(os.environ, **(env or {})), timeout=1500)
     assert r.returncode == 0, (exe, flags, (r.stdout + r.stderr)[-1500:])
     md5 = tuple(hashlib.md5(open(db + e, "rb").read()).hexdigest() for e in (".kmc_pre", ".kmc_suf"))
     stats = [ln.split(":")[1].strip() for ln in r.stdout.splitlines() if "No. of" in ln or "Total no." in ln]
@@ -50,8 +55,8 @@ def _run(exe, flags, inp, tmp_path, tag, env=None):
 def test_product_binary_over_the_emulated_host_library_writes_the_reference_database(flags, sorted_emit, tmp_path):
     """sorted_emit: KMC_HIP_S1_SORTED_EMIT=1 — the alternative emit of stage 1, whose sort is the library's own radix path (k_hist, k_onesweep) on the
     super-k-mer keys"""
-    if not os.path.exists(os.path.join(REF, "kmc_hip_s1")):
-        pytest.skip("oracle/_ref/kmc_hip_s1 not built (needs /root/reference)")
+    if not os.path.exists(_exe("kmc_hip_s1")):
+        pytest.skip("kmc_amd/bin/kmc_hip_s1 not built (needs /root/reference)")
     lib = emu.build_hostlib("small")
     fq = str(tmp_path / "in.fq")
     synth.make_fastq(fq, seed=11, genome_len=30_000, n_reads=1_500, read_len=150)
@@ -73,7 +78,7 @@ def test_two_emulated_devices_context_wide_records_allreduce_and_dropin(tmp_path
     env = dict(os.environ, KMC_HIP_LIB=lib, HIPEMU_DEVICES="2")
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "hostlib_two_devices.py")], env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0 and "two devices ok" in r.stdout, (r.stdout + r.stderr)[-1500:]
-    if not os.path.exists(os.path.join(REF, "kmc_hip")):
+    if not os.path.exists(_exe("kmc_hip")):
         return
     fq = str(tmp_path / "in.fq")
     synth.make_fastq(fq, seed=5, genome_len=20_000, n_reads=800, read_len=150)

@@ -227,7 +227,7 @@ def test_dropin_binary_fails_loudly_without_a_gpu(ref_bins, tmp_path):
     (CCriticalErrorHandler), not count on the host. Covers the eager background initialisation of hip_loader.cpp too
     (it must neither crash at start-up nor at exit when HIP cannot initialise)."""
     if ref_bins is None or "kmc_hip" not in ref_bins or not os.path.exists(ref_bins["kmc_hip"]):
-        pytest.skip("oracle/_ref/kmc_hip not built")
+        pytest.skip("kmc_amd/bin/kmc_hip not built")
     if os.path.exists("/dev/kfd"):
         pytest.skip("a GPU is present: the drop-in runs for real here (see the -m gpu suite)")
     from kmc_amd import synth

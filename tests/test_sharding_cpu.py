@@ -129,3 +129,21 @@ def test_sharded_generation_reassembles_the_single_process_bin_set(world, tmp_pa
     loads = [sum(v[2] for v in own.values()) for _, own, _ in res]
     assert max(loads) <= sum(loads) / world + max(b[1] for b in bins)
     assert not [f for f in os.listdir(tmp_path) if f.startswith("kmcbins_")], "the exchange directory must be removed"
+
+
+def test_bench_gpus_n_launches_its_own_ranks(tmp_path):
+    """`python bench.py --gpus 2` with no launcher around it must start two ranks itself (re-exec under torch.distributed.run, rendezvous on 127.0.0.1)
+    and must refuse a world size that disagrees with --gpus. --dry-launch stops after the rendezvous (gloo): no GPU needed."""
+    import json
+    import subprocess
+    import sys
+
+    bench = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "bench.py")
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, bench, "--gpus", "2", "--dry-launch"], capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode == 0, r.stderr[-800:]
+    line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1]
+    d = json.loads(line)
+    assert d["gpus_requested"] == 2 and d["world_size_env"] == 2 and d["ranks_seen_by_all_reduce"] == 2 and d["n_gpus"] == 2
+    r = subprocess.run([sys.executable, bench, "--gpus", "2", "--dry-launch"], capture_output=True, text=True, timeout=120, env=dict(env, WORLD_SIZE="3", RANK="0"))
+    assert r.returncode != 0 and "must agree" in (r.stderr + r.stdout)

@@ -14,6 +14,11 @@ from kmc_amd import synth
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 REF = os.path.join(ROOT, "oracle", "_ref")
+
+
+def _exe(name):
+    """oracle/_ref/<name> for the reference and the oracle builds (checkers), kmc_amd/bin/<name> for the product drop-in binaries"""
+    return os.path.join(ROOT, "kmc_amd", "bin", name) if name.startswith("kmc_hip") else os.path.join(REF, name)
 needs_ref = pytest.mark.skipif(not os.path.exists(os.path.join(REF, "kmc_oracle_s1")), reason="oracle/_ref not built (needs /root/reference)")
 
 
@@ -21,7 +26,7 @@ def _run(exe, flags, inp, tmp_path, tag, env=None):
     t = tmp_path / ("tmp_" + tag)
     t.mkdir(exist_ok=True)
     db = str(tmp_path / ("db_" + tag))
-    r = subprocess.run([os.path.join(REF, exe), *flags, inp, db, str(t)], capture_output=True, text=True, env=dict(os.environ, **(env or {})))
+    r = subprocess.run([_exe(exe), *flags, inp, db, str(t)], capture_output=True, text=True, env=dict(os.environ, **(env or {})))
     assert r.returncode == 0, (exe, flags, (r.stdout + r.stderr)[-800:])
     md5 = tuple(hashlib.md5(open(db + e, "rb").read()).hexdigest() for e in (".kmc_pre", ".kmc_suf"))
     stats = [ln.split(":")[1].strip() for ln in r.stdout.splitlines() if "No. of" in ln or "Total no." in ln]
@@ -231,9 +236,9 @@ def test_emulated_chain_retries_the_cut_when_its_first_guess_is_short(tmp_path):
 def test_hip_stage1_binary_fails_loudly_without_a_gpu(tmp_path):
     """kmc_hip_s1 (every plug-in over libkmc_hip.so, the splitter over kmc_hip_split_part) has no CPU fallback either: without a GPU the first
     part must stop the run with the engine's error, not be split on the host"""
-    exe = os.path.join(REF, "kmc_hip_s1")
+    exe = _exe("kmc_hip_s1")
     if not os.path.exists(exe):
-        pytest.skip("oracle/_ref/kmc_hip_s1 not built")
+        pytest.skip("kmc_amd/bin/kmc_hip_s1 not built")
     if os.path.exists("/dev/kfd"):
         pytest.skip("a GPU is present")
     fq = str(tmp_path / "in.fq")
@@ -304,7 +309,7 @@ def test_product_binaries_over_a_mock_library_write_the_reference_database(exe, 
     """everything between the reference pipeline and the C-ABI — worker plug-ins, ordered emission with several workers, loaders, argument
     marshalling of kmc_hip_process_bin_submit/_wait and kmc_hip_split_set_map/_split_part, two configured devices — runs here as shipped; only the
     library behind the C-ABI is a stand-in"""
-    if not os.path.exists(os.path.join(REF, exe)):
+    if not os.path.exists(_exe(exe)):
         pytest.skip("oracle/_ref/%s not built" % exe)
     import emu
 

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Where does the drop-in's stage 2 spend its time? Runs oracle/_ref/kmc_hip (worker + reader plug-ins), kmc_hip_sr (worker plug-in,
+"""Where does the drop-in's stage 2 spend its time? Runs kmc_amd/bin/kmc_hip (worker + reader plug-ins), kmc_hip_sr (worker plug-in,
 reference reader) and the unmodified reference on ONE FASTQ (the 2 Gbp sample of bench.py) for several -sr / KMC_HIP_READERS /
 -r settings and prints one JSON line per run: stage times, the five statistics, the plug-ins' KMC_HIP_VERBOSE report."""
 import json
@@ -49,7 +49,7 @@ with tempfile.TemporaryDirectory(dir=base) as td:
     if len(sys.argv) > 4:  # a subset of the runs, by index
         runs = [runs[int(i)] for i in sys.argv[4].split(",")]
     for exe, flags, env in runs:
-        p = os.path.join(REF, exe)
+        p = os.path.join(ROOT, "kmc_amd", "bin", exe) if exe.startswith("kmc_hip") else os.path.join(REF, exe)
         if not os.path.exists(p):
             continue
         tmp = os.path.join(td, "tmp")

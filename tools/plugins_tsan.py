@@ -47,8 +47,8 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 import emu  # noqa: E402
 
 mock = emu.build_mock()
-subprocess.check_call(["make", "-s", "-j8", "-C", os.path.join(ROOT, "oracle"), f"OUT={OUT}", f"OBJ={OUT}/obj", "CXX=g++ -fsanitize=thread -g", "CC=gcc -fsanitize=thread -g",
-                       f"{OUT}/kmc_hip_s1"])
+subprocess.check_call(["make", "-s", "-j8", "-C", os.path.join(ROOT, "kmc_amd", "host"), f"OUT={OUT}/bin", f"OBJ={OUT}/bin/obj", f"ROBJ={OUT}/obj",
+                       "CXX=g++ -fsanitize=thread -g", "CC=gcc -fsanitize=thread -g", f"{OUT}/bin/kmc_hip_s1"])
 small = os.path.join(td, "small.fq")
 synth.make_fastq(small, seed=11, genome_len=50_000, n_reads=3_000, read_len=150)
 for flags, extra in [(["-k27", "-sf2", "-sp3", "-sr4"], {}), (["-k27", "-sf1", "-sp2", "-sr6"], {"KMC_HIP_EAGER_INIT": "0", "KMC_HIP_DEVICES": "0,1"})]:
@@ -57,7 +57,7 @@ for flags, extra in [(["-k27", "-sf2", "-sp3", "-sr4"], {}), (["-k27", "-sf1", "
     os.makedirs(t)
     env = dict(os.environ, TSAN_OPTIONS="halt_on_error=0 report_signal_unsafe=0 history_size=3", KMC_HIP_LIB=mock)
     env.update(extra)
-    r = subprocess.run([os.path.join(OUT, "kmc_hip_s1"), *flags, "-ci1", "-m2", small, os.path.join(td, "db"), t], capture_output=True, text=True, env=env)
+    r = subprocess.run([os.path.join(OUT, "bin", "kmc_hip_s1"), *flags, "-ci1", "-m2", small, os.path.join(td, "db"), t], capture_output=True, text=True, env=env)
     n = r.stderr.count("WARNING: ThreadSanitizer")
     total += n
     print("kmc_hip_s1 over the mock library", flags, extra, "rc", r.returncode, "reports", n)
