@@ -86,7 +86,10 @@ template <int SIZE> struct CpCfg {
 	static constexpr int WORDS = SIZE == 1 ? CP_WORDS_PER_THREAD_1 : CP_WORDS_PER_THREAD;
 	static constexpr int ITEMS = (WORDS / SIZE) > 2 ? (WORDS / SIZE) : 2; /* rows of 64 records per wave */
 	static constexpr int TILE = CP_BLOCK * ITEMS;
-	static constexpr int MIN_WAVES = SIZE == 1 ? 8 : 4; /* waves per SIMD the register allocator must leave room for */
+#ifndef CP_MIN_WAVES_1
+#define CP_MIN_WAVES_1 8
+#endif
+	static constexpr int MIN_WAVES = SIZE == 1 ? CP_MIN_WAVES_1 : 4; /* waves per SIMD the register allocator must leave room for */
 };
 
 /* per-run constants handed to the kernels by value */
@@ -1509,17 +1512,18 @@ __global__ void __launch_bounds__(CP_BLOCK, CpCfg<SIZE>::MIN_WAVES) k_compact(co
 								s_pref[rank] = (u32)kmc_remove_suffix<SIZE>(key[r], pshift) & lut_mask;
 							const u32 bb = rank * rec_bytes;
 							if (bb < c1 && bb + rec_bytes > c0) {
-								u64 km[SIZE]; /* the k-mer without a group tag above bit 2k (see the fast path) */
-#pragma unroll
-								for (int w = 0; w < SIZE; ++w)
-									km[w] = key[r][w];
-								kmc_mask_low<SIZE>(km, 2 * P.k);
 								for (u32 q = 0; q < rec_bytes; ++q) {
 									const u32 bpos = bb + q;
 									if (bpos >= c0 && bpos < c1) {
 										u32 val;
 										if (q < P.sbytes)
-											val = kmc_get_byte<SIZE>(km, P.sbytes - 1 - q);
+											{
+												/* (a group tag above bit 2k must not get into the top suffix byte: see the fast path) */
+												const u32 pb = P.sbytes - 1 - q, top = 2 * P.k;
+												val = kmc_get_byte<SIZE>(key[r], pb);
+												if (8 * pb + 8 > top)
+													val = top > 8 * pb ? (val & ((1u << (top - 8 * pb)) - 1)) : 0u;
+											}
 										else {
 											const u32 cq = q - P.sbytes;
 											val = cnt[r] >> (8 * (P.kff ? (P.cbytes - 1 - cq) : cq));

@@ -40,6 +40,8 @@ VARIANTS = {
     "cp_bidx": ["-DCP_TILE_FROM_BLOCKIDX=1"],  # compaction tiles in blockIdx order (no ticket atomic)
     "rs_bidx": ["-DRS_TILE_FROM_BLOCKIDX=1"],  # scatter tiles in blockIdx order
     "bidx2": ["-DCP_TILE_FROM_BLOCKIDX=1", "-DRS_TILE_FROM_BLOCKIDX=1"],
+    "cpmw6": ["-DCP_MIN_WAVES_1=6"],  # k_compact<1> with 80 VGPRs (no spills?) instead of 64 + 30 spilled
+    "cpmw5": ["-DCP_MIN_WAVES_1=5"],
     "bcmw4": ["-DBC_MIN_WAVES=4"],  # k_bucket_count with 128 VGPRs: one workgroup of 1024 per CU, nothing spilled
     "bc512": ["-DBC_BLOCK_THREADS=512", "-DBC_WORDS_PER_THREAD=8", "-DBC_MIN_WAVES=4"],  # 8 waves x 8 rows, two workgroups per CU at 128 VGPRs
     "bc1": ["-DBC_STOP_AFTER=1"],  # k_bucket_count cut after its phase 1 / 2 / 3 (garbage output): phase costs
