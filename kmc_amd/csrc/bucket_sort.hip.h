@@ -356,30 +356,24 @@ __global__ void __launch_bounds__(BsCfg<SIZE>::THREADS) k_bucket_sort(u64 *__res
 
 /* ================================================================================================ fused: tile -> (k-mer, count) records
  * What stage 2 wants from the sort is not the sorted records but the RUNS of equal k-mers: ascending distinct k-mers with their counts
- * (kb_sorter.h:1128-1281). All copies of a k-mer share their bucket, hence their tile — so a tile can be counted without ever being sorted:
- *   1  records -> registers and, in arrival order, LDS. Bucket starts ("heads": the top hbits differ from the record before) are found with one
- *      shuffle and one ballot per row; a record knows its bucket by its ORDINAL (heads at or before it: mbcnt + the heads of the rows and waves
- *      before), and a table START[ordinal] gives it the tile positions [s, s + n) its bucket occupies.
- *   2  the tag array has TWO slots per record, and bucket [s, s + n) owns slots [2s, 2s + 2n). A record starts probing at
- *            slot = 2s + floor(rem32 * 2n / 2^32)          rem32 = the 32 key bits below the bucket bits
- *      — order-preserving (a larger k-mer never starts before a smaller one) and adaptive (k-mers of a signature bin are clustered: half of all
- *      records sit in buckets of more than 3x the average size; equal slices of the tile's key range would put hundreds of distinct k-mers into
- *      one slice) — and walks forward: a free slot is claimed with a compare-and-swap (tag = the claiming record's position, count 1: the record
- *      now OWNS its k-mer), a slot whose owner holds the same k-mer gets its count bumped. This is the run-length counting, parallel over RECORDS:
- *      30x coverage costs one probe and one add per copy. The table is at most half full, so probe runs stay short whatever the data.
- *   3  owners apply the cutoffs (kb_sorter.h:1174-1192) and mark their slot "counted"; one scan over the tag array counts the marks in front of
- *      every group of 8 slots.
- *   4  rank of a counted k-mer = counted k-mers with a smaller key. Because start slots are monotone in the key and a k-mer only ever moves
- *      forward over OCCUPIED slots, every k-mer in front of the maximal occupied run ("cluster") around a slot is smaller than the one in it and
- *      every k-mer behind that cluster is larger: rank = marks in front of the cluster (step 3) + smaller counted k-mers inside the cluster (a
- *      walk over a few slots). Nothing is sorted.
- *   5  the owner's k-mer goes to its rank in LDS, the bytes of the stored records are composed from there and written, coalesced, to the tile's span
- *      of the free record array; the tile's count goes to status[tile] (two-phase output: k_compact_fold turns the counts into offsets,
- *      k_compact_gather moves the records); LUT prefixes through a small LDS histogram, tallies sharded exactly as in k_compact.
- * HBM traffic per record: the 8 SIZE bytes of its one read. The span of a tile starts at the byte offset of its first record in the free array
- * (8 SIZE bytes per record of room), so a tile of any length has room for its output. A tile longer than the LDS capacity is counted in
- * bucket-aligned chunks; a single BUCKET beyond the capacity (one k-mer repeated thousands of times) or a probe run that reaches the end of the
- * table sets *flag: the host runs the group again with LSD passes over every byte and k_compact. */
+ * (kb_sorter.h:1128-1281). All copies of a k-mer share their bucket, hence their tile, hence their sub-bucket — so a tile can be counted
+ * without ever being sorted:
+ *   1  records -> registers and, in arrival order, LDS; bucket boundaries -> sub-bucket id as in k_bucket_sort; count per sub-bucket (LDS
+ *      atomics, nothing returned); scan: sub-bucket i owns slots [base[i], base[i+1]) of a tag array — as many slots as it has records
+ *   2  every record looks for its k-mer in its sub-bucket's slots, open addressing from a hashed start: an empty slot is claimed with a
+ *      compare-and-swap (tag = the claiming record's position, count 1: the record now OWNS its k-mer), a slot whose owner holds the same
+ *      k-mer gets its count bumped. This is the run-length counting, parallel over RECORDS: 30x coverage costs one probe and one add per copy.
+ *   3  owners apply the cutoffs (kb_sorter.h:1174-1192); a counted k-mer adds one to its sub-bucket's number of counted k-mers, one scan over the
+ *      sub-buckets turns those into "counted k-mers before this sub-bucket" = the rank in the tile of a counted k-mer that is alone in its
+ *      sub-bucket; the rare one that is not adds the smaller counted k-mers of its sub-bucket (a scan of a few slots). Nothing is sorted.
+ *   4  the owner writes its record at that rank into the tile's span of the free record array (counted k-mers are ~4 % of the records at the
+ *      default cutoff: byte stores, merged in L2) and counts its LUT prefix in a small LDS histogram (flushed with one global atomic per
+ *      prefix); the tile's count goes to status[tile] (two-phase output: k_compact_fold turns the counts into offsets, k_compact_gather moves
+ *      the records), tallies are sharded exactly as in k_compact.
+ * HBM traffic per record: the 8 SIZE bytes of its one read. The span of a tile starts at the byte offset of its first record in the free
+ * array (8 SIZE bytes per record of room), so a tile of any length has room for its output. A tile longer than the LDS capacity is counted in
+ * bucket-aligned chunks; only a single BUCKET beyond the capacity (one k-mer repeated thousands of times) sets *flag: the host runs the group
+ * again with LSD passes over every byte and k_compact. */
 #ifndef BC_BLOCK_THREADS
 #define BC_BLOCK_THREADS 1024 /* 16 waves x 4 rows of 64 records: 4096-record tiles of one-word records, 64 KB of LDS, two workgroups per CU */
 #endif
@@ -400,14 +394,12 @@ template <int SIZE> struct BcCfg {
 	static constexpr int ITEMS = (BC_WORDS_PER_THREAD / SIZE) > 2 ? (BC_WORDS_PER_THREAD / SIZE) : 2;
 	static constexpr int CAP = THREADS * ITEMS;
 	static constexpr int STRIDE = CAP / 4 * 3; /* window length: a tile is STRIDE records on average; one that outgrows CAP takes a second chunk */
-	static_assert(CAP <= 4096, "a tag holds position + 1 and a count in 13 bits each");
+	static_assert(CAP < 65535, "positions + 1 are kept in 16 bits");
 };
 template <int SIZE> constexpr size_t bc_lds_bytes()
 {
-	/* records | tags (2 per record) | bucket starts (16 bit) / scan results | LUT histogram | small */
-	return (size_t)BcCfg<SIZE>::CAP * SIZE * 8 + (size_t)2 * BcCfg<SIZE>::CAP * 4 +
-	       (((size_t)BcCfg<SIZE>::CAP + 2) * 2 > (size_t)BcCfg<SIZE>::THREADS * 4 ? ((size_t)BcCfg<SIZE>::CAP + 2) * 2 : (size_t)BcCfg<SIZE>::THREADS * 4) + (size_t)BC_LUT_HIST * 4 +
-	       (5 * (BcCfg<SIZE>::THREADS / 64) + 8) * 4 + 16;
+	return (size_t)BcCfg<SIZE>::CAP * SIZE * 8 + ((size_t)2 * BcCfg<SIZE>::CAP + 3) * 4 + (size_t)BC_LUT_HIST * 4 +
+	       (6 * (BcCfg<SIZE>::THREADS / 64) + 4) * 4 + 16;
 }
 /* average bucket size the host aims for when it picks the number of HBM passes. What must not happen is ONE bucket beyond CAP (a longer TILE is only a
  * second chunk), and the k-mers of a signature bin are clustered: on the bench's bins the largest of 2^22 buckets holds 100x the average at k = 27 and
@@ -446,18 +438,13 @@ __global__ void __launch_bounds__(BcCfg<SIZE>::THREADS, (SIZE <= 2 ? BC_MIN_WAVE
 	constexpr u32 NONE = 0xFFFFFFFFu;
 	static_assert(CAP == THREADS * ITEMS, "a thread scans ITEMS consecutive counters / slots");
 	KMC_DYN_LDS(unsigned char, s_raw);
-	constexpr u32 TS = 2 * CAP;                /* tag slots */
-	constexpr u32 T_OWNER = 0x1FFFu, T_ONE = 1u << 13, T_COUNTED = 1u << 31; /* tag: [12:0] owner position + 1 (0 = free), [25:13] count, [31] counted */
-	constexpr size_t START_BYTES = ((size_t)CAP + 2) * 2 > (size_t)THREADS * 4 ? ((size_t)CAP + 2) * 2 : (size_t)THREADS * 4;
-	u64 *s_rec = reinterpret_cast<u64 *>(s_raw);                         /* [CAP * SIZE] records in arrival order; later the counted k-mers at their ranks */
-	u32 *s_tag = reinterpret_cast<u32 *>(s_rec + (size_t)CAP * SIZE);    /* [TS]; later the counts of the counted k-mers at their ranks */
-	unsigned short *s_start = reinterpret_cast<unsigned short *>(s_tag + TS); /* [CAP + 1] first position of the chunk's i-th bucket */
-	u32 *s_pre = reinterpret_cast<u32 *>(s_tag + TS);                    /* [THREADS] (after the probing) counted k-mers in the slots before slot 2 ITEMS t */
-	u32 *s_lut = reinterpret_cast<u32 *>(reinterpret_cast<unsigned char *>(s_tag + TS) + ((START_BYTES + 15) & ~(size_t)15)); /* [BC_LUT_HIST] */
-	u32 *s_tmp = s_lut + BC_LUT_HIST;                                    /* [NW + 1] */
-	u32 *s_wheads = s_tmp + NW + 1;                                      /* [NW] bucket starts in wave w's rows */
-	u32 *s_wtal = s_wheads + NW;                                         /* [NW][3] distinct / below min / above max */
-	u32 *s_fail = s_wtal + 3 * NW;
+	u64 *s_rec = reinterpret_cast<u64 *>(s_raw);                      /* [CAP * SIZE] records in arrival order */
+	u32 *s_cnt = reinterpret_cast<u32 *>(s_rec + (size_t)CAP * SIZE); /* [CAP + 1] records per sub-bucket -> [15:0] first slot of its region, [31:16] (step 3) counted k-mers in front of it */
+	u32 *s_tag = s_cnt + CAP + 1;                                     /* [CAP + 1] [15:0] owner position + 1 (0 = free), [31:16] count; before that, the table of bucket starts */
+	u32 *s_lut = s_tag + CAP + 1;                                     /* [BC_LUT_HIST] counted k-mers per LUT prefix, relative to the tile's first */
+	u32 *s_tmp = s_lut + BC_LUT_HIST;                                 /* [NW + 1] */
+	u32 *s_wfirst = s_tmp + NW + 1;                                   /* [NW] bucket starts in wave w's rows */
+	u32 *s_wtal = s_wfirst + NW;                                       /* [NW][3] distinct / below min / above max */
 
 	const u32 gtile = blockIdx.x;
 	const u32 bin = (u32)__builtin_amdgcn_readfirstlane((int)grp_find(gb.win_prefix, gb.g, gtile));
@@ -473,7 +460,7 @@ __global__ void __launch_bounds__(BcCfg<SIZE>::THREADS, (SIZE <= 2 ? BC_MIN_WAVE
 	const bool use_lut = P.lut_prefix_len != 0 && !P.kff && !P.without_output;
 	const u32 bsh = 64 - hbits;
 	auto bucket_of = [&](const u64(&x)[SIZE]) -> u32 { return hbits ? (u32)(bs_p64<SIZE>(x, key_bits) >> bsh) : 0u; }; /* hbits <= 32 (kmc_hip.hip plan_sort) */
-	auto owner_key = [&](u32 w, u64(&o)[SIZE]) { load_rec<SIZE>(s_rec + (size_t)((w & T_OWNER) - 1) * SIZE, o); };
+	auto counted = [&](u32 w) -> bool { const u32 c = w >> 16; return w != 0 && c >= P.cutoff_min && c <= P.cutoff_max; };
 	uint8_t *const span = gb.scratch[bin] + b0 * (u64)(SIZE * 8); /* this tile's output: room for 8 SIZE bytes per record */
 	u32 nu = 0, nb = 0, na = 0;                                    /* this thread's owners: distinct / below min / above max */
 	u32 counted_done = 0;                                          /* counted k-mers of the chunks before this one */
@@ -485,15 +472,13 @@ __global__ void __launch_bounds__(BcCfg<SIZE>::THREADS, (SIZE <= 2 ? BC_MIN_WAVE
 	for (u64 c0 = b0; c0 < b1;) { /* chunks of whole buckets; nearly always one */
 		const u64 *__restrict__ T = gb.S[bin] + c0 * SIZE;
 		const u32 avail = (b1 - c0) > (u64)CAP ? (u32)CAP : (u32)(b1 - c0);
-		{
-			uint4 *z = reinterpret_cast<uint4 *>(s_tag); /* TS words = TS / 4 vectors */
-			for (u32 i = tid; i < TS / 4; i += THREADS)
-				z[i] = make_uint4(0, 0, 0, 0);
-		}
+#pragma unroll
+		for (int q = 0; q < ITEMS; ++q)
+			s_cnt[q * THREADS + tid] = 0;
+		if (tid == 0)
+			s_cnt[CAP] = 0;
 		for (u32 i = tid; i < (u32)BC_LUT_HIST; i += THREADS)
 			s_lut[i] = 0;
-		if (tid == 0)
-			*s_fail = 0;
 		u64 key[ITEMS][SIZE];
 #pragma unroll
 		for (int r = 0; r < ITEMS; ++r) {
@@ -507,7 +492,11 @@ __global__ void __launch_bounds__(BcCfg<SIZE>::THREADS, (SIZE <= 2 ? BC_MIN_WAVE
 					key[r][w] = 0;
 			}
 		}
-		/* ---- 1: bucket starts -> ordinals -> table of bucket positions */
+		/* ---- 1: bucket starts ("heads"). A record's bucket is known by its ORDINAL among the chunk's buckets = heads at or before the record - 1:
+		 * a popcount of the row's head mask below the lane (mbcnt) + the heads of the rows and waves before. The start positions go into a table
+		 * indexed by that ordinal (it lives where the tag array will be: nothing probes yet), so a record finds the start and the end of its bucket
+		 * with two LDS reads — no per-lane 64-bit mask arithmetic. */
+		u32 *s_start = s_tag;
 		u32 prev_last = 0;
 		if (crel > 0 && crel - 1 < avail) {
 			u64 x[SIZE];
@@ -530,11 +519,11 @@ __global__ void __launch_bounds__(BcCfg<SIZE>::THREADS, (SIZE <= 2 ? BC_MIN_WAVE
 			prev_last = __shfl(bk, 63);
 		}
 		if (lane == 0)
-			s_wheads[wave] = wheads;
+			s_wfirst[wave] = wheads;
 		__syncthreads();
 		u32 wave_heads_before, total_heads;
 		{
-			const u32 v = lane < (u32)NW ? s_wheads[lane] : 0u;
+			const u32 v = lane < (u32)NW ? s_wfirst[lane] : 0u;
 			const u32 inc = wave_incl_sum<u32>(v, lane);
 			total_heads = __shfl(inc, NW - 1);
 			wave_heads_before = __shfl(inc - v, (int)wave);
@@ -542,9 +531,9 @@ __global__ void __launch_bounds__(BcCfg<SIZE>::THREADS, (SIZE <= 2 ? BC_MIN_WAVE
 #pragma unroll
 		for (int r = 0; r < ITEMS; ++r)
 			if ((headbits >> r) & 1u)
-				s_start[wave_heads_before + below[r]] = (unsigned short)(crel + r * 64 + lane); /* ordinal of this head = heads before it */
+				s_start[wave_heads_before + below[r]] = crel + r * 64 + lane; /* ordinal of this head = heads before it */
 		if (tid == 0)
-			s_start[total_heads] = (unsigned short)avail;
+			s_start[total_heads] = avail;
 		__syncthreads();
 		BC_STAMP(0); /* clear, load, bucket starts */
 		/* the chunk: everything that was loaded, or — when the tile has more — up to the start of the last bucket that began inside it */
@@ -557,66 +546,96 @@ __global__ void __launch_bounds__(BcCfg<SIZE>::THREADS, (SIZE <= 2 ? BC_MIN_WAVE
 				return;
 			}
 		}
-#if defined(BC_STOP_AFTER) && BC_STOP_AFTER <= 1 /* tuning builds only: what does each phase cost? (the output is garbage) */
-		return;
-#endif
-		/* ---- 2: count the copies */
-		const u32 last_start = 2 * len > 33 ? 2 * len - 33 : 0; /* no probe run starts in the last 32 slots of the chunk's part of the table */
-		u32 myslot[ITEMS];                                      /* the slot this record owns, NONE if it is a copy */
-		bool gave_up = false;
+		u32 sub[ITEMS]; /* the record's sub-bucket */
 #pragma unroll
 		for (int r = 0; r < ITEMS; ++r) {
 			const u32 idx = crel + r * 64 + lane;
-			myslot[r] = NONE;
+			sub[r] = 0;
 			if (idx < len) {
 				const u32 ord = wave_heads_before + below[r] + ((headbits >> r) & 1u) - 1;
 				const u32 bstart = s_start[ord], bend = s_start[ord + 1];
 				const u64 p = bs_p64<SIZE>(key[r], key_bits);
 				const u32 rem32 = (u32)((hbits ? (p << hbits) : p) >> 32);
-				u32 slot = 2 * bstart + __umulhi(rem32, 2 * (bend - bstart));
-				slot = slot < last_start ? slot : last_start; /* also keeps the records of a corrupt bin (error word already set) inside the table */
-				while (true) {
+				u32 id = bstart + __umulhi(rem32, bend - bstart);
+				id = id < len ? id : len - 1; /* in range by construction; the clamp is for records of a corrupt bin (the error word is already set) */
+				sub[r] = id;
+				(void)__hip_atomic_fetch_add(&s_cnt[id], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+			}
+		}
+		__syncthreads();
+		BC_STAMP(1); /* sub-buckets, counting */
+		{
+			u32 c[ITEMS], sum = 0;
+#pragma unroll
+			for (int q = 0; q < ITEMS; ++q) {
+				c[q] = s_cnt[tid * ITEMS + q];
+				sum += c[q];
+				s_tag[q * THREADS + tid] = 0; /* the table of bucket starts has been read: the tag array starts empty */
+			}
+			u32 total;
+			u32 run = block_excl_sum<NW, u32>(sum, s_tmp, total);
+#pragma unroll
+			for (int q = 0; q < ITEMS; ++q) {
+				s_cnt[tid * ITEMS + q] = run;
+				run += c[q];
+			}
+			if (tid == 0) {
+				s_cnt[CAP] = total;
+				s_tag[CAP] = 0;
+			}
+		}
+		__syncthreads();
+		BC_STAMP(2); /* region table scan */
+#if defined(BC_STOP_AFTER) && BC_STOP_AFTER <= 1 /* tuning builds only: what does each phase cost? (the output is garbage) */
+		return;
+#endif
+		/* ---- 2: count the copies. Region of sub-bucket i: slots [s_cnt[i], s_cnt[i+1]) — one slot per record, so a free slot always exists. */
+		u32 myslot[ITEMS]; /* the slot this record owns, NONE if it is a copy */
+#pragma unroll
+		for (int r = 0; r < ITEMS; ++r) {
+			const u32 idx = crel + r * 64 + lane;
+			myslot[r] = NONE;
+			if (idx < len) {
+				const u32 a = s_cnt[sub[r]], nreg = s_cnt[sub[r] + 1] - a;
+				u32 h = 0;
+#pragma unroll
+				for (int w = 0; w < SIZE; ++w)
+					h = (h ^ (u32)key[r][w] ^ (u32)(key[r][w] >> 32)) * 0x9E3779B1u;
+				h ^= h >> 15;
+				u32 slot = a + __umulhi(h * 0x85EBCA6Bu, nreg < (u32)BC_HASH_CAP ? nreg : (u32)BC_HASH_CAP);
+				for (u32 probe = 0; probe < nreg; ++probe) {
 					u32 w = __hip_atomic_load(&s_tag[slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 					if (w == 0) {
-						w = atomicCAS(&s_tag[slot], 0u, T_ONE | (idx + 1));
+						w = atomicCAS(&s_tag[slot], 0u, (1u << 16) | (idx + 1));
 						if (w == 0) {
 							myslot[r] = slot;
 							break;
 						}
 					}
 					u64 o[SIZE];
-					owner_key(w, o);
+					load_rec<SIZE>(s_rec + (size_t)((w & 0xFFFFu) - 1) * SIZE, o);
 					if (kmc_equal<SIZE>(o, key[r])) {
-						(void)__hip_atomic_fetch_add(&s_tag[slot], T_ONE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+						(void)__hip_atomic_fetch_add(&s_tag[slot], 1u << 16, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 						break;
 					}
-					if (++slot == TS) { /* 32+ occupied slots in a row at the very end of the table */
-						gave_up = true;
-						break;
-					}
+					slot = slot + 1 == a + nreg ? a : slot + 1;
 				}
 			}
 		}
-		if (gave_up)
-			*s_fail = 1;
 		__syncthreads();
 		BC_STAMP(3); /* probing */
-		if (*s_fail) {
-			if (tid == 0)
-				atomicOr(flag, 1u);
-			return;
-		}
 #if defined(BC_STOP_AFTER) && BC_STOP_AFTER <= 2
 		return;
 #endif
-		/* ---- 3: owners apply the cutoffs (kb_sorter.h:1174-1192) and mark their slot */
+		/* ---- 3: owners apply the cutoffs (kb_sorter.h:1174-1192); every counted k-mer adds one to its sub-bucket's entry of the region table
+		 * (upper half of the word; the first slot stays in the lower half), and a scan of those numbers replaces them by "counted k-mers in the
+		 * sub-buckets before this one" — which is the rank of a counted k-mer that is alone in its sub-bucket (nearly all are) */
 		u32 mycount[ITEMS]; /* a counted owner's count; 0 for everybody else */
 #pragma unroll
 		for (int r = 0; r < ITEMS; ++r) {
 			mycount[r] = 0;
 			if (myslot[r] != NONE) {
-				const u32 w = s_tag[myslot[r]];
-				const u32 c = (w >> 13) & 0x1FFFu;
+				const u32 c = s_tag[myslot[r]] >> 16;
 				++nu;
 				if (c < P.cutoff_min)
 					++nb;
@@ -624,25 +643,31 @@ __global__ void __launch_bounds__(BcCfg<SIZE>::THREADS, (SIZE <= 2 ? BC_MIN_WAVE
 					++na;
 				else {
 					mycount[r] = c;
-					s_tag[myslot[r]] = w | T_COUNTED; /* the probing is over: nobody else writes this slot */
+					(void)__hip_atomic_fetch_add(&s_cnt[sub[r]], 1u << 16, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 				}
 			}
 		}
 		__syncthreads();
-		BC_STAMP(4); /* owners classify */
+		BC_STAMP(4); /* owners classify + count per sub-bucket */
 		u32 chunk_counted;
 		{
-			const uint4 *t4 = reinterpret_cast<const uint4 *>(s_tag) + (size_t)tid * (2 * ITEMS / 4);
-			u32 n = 0;
+			u32 w[ITEMS], sum = 0;
 #pragma unroll
-			for (int q = 0; q < 2 * ITEMS / 4; ++q) {
-				const uint4 v = t4[q];
-				n += (v.x >> 31) + (v.y >> 31) + (v.z >> 31) + (v.w >> 31);
+			for (int q = 0; q < ITEMS; ++q) {
+				w[q] = s_cnt[tid * ITEMS + q];
+				sum += w[q] >> 16;
 			}
-			s_pre[tid] = block_excl_sum<NW, u32>(n, s_tmp, chunk_counted); /* the table of bucket starts is not read any more */
+			u32 run = block_excl_sum<NW, u32>(sum, s_tmp, chunk_counted);
+#pragma unroll
+			for (int q = 0; q < ITEMS; ++q) {
+				s_cnt[tid * ITEMS + q] = (w[q] & 0xFFFFu) | (run << 16);
+				run += w[q] >> 16;
+			}
+			if (tid == 0)
+				s_cnt[CAP] = (s_cnt[CAP] & 0xFFFFu) | (chunk_counted << 16);
 		}
 		__syncthreads();
-		BC_STAMP(5); /* scan of the marks */
+		BC_STAMP(5); /* scan of counted per sub-bucket */
 #if defined(BC_STOP_AFTER) && BC_STOP_AFTER <= 3
 		return;
 #endif
@@ -670,43 +695,32 @@ __global__ void __launch_bounds__(BcCfg<SIZE>::THREADS, (SIZE <= 2 ? BC_MIN_WAVE
 			pf_span = pf_hi >= pf_lo ? pf_hi - pf_lo + 1 : 0xFFFFFFFFu;
 		}
 		u64 *const lut = use_lut ? gb.lut_base[bin] + (size_t)(tile % lut_shards) * lut_stride : nullptr;
+		/* ---- 4: a counted k-mer finds its rank ... */
 		if (!P.without_output && chunk_counted) { /* uniform over the workgroup */
-			/* ---- 4: ranks */
 #pragma unroll
 			for (int r = 0; r < ITEMS; ++r) {
 				if (mycount[r]) {
-					const u32 p = myslot[r];
-					u32 rin = 0, q = p;
-					while (q > 0) { /* to the start of the cluster */
-						const u32 w = s_tag[q - 1];
-						if (w == 0)
-							break;
-						--q;
-						if (w >> 31) {
-							u64 o[SIZE];
-							owner_key(w, o);
-							rin += kmc_less<SIZE>(o, key[r]) ? 1u : 0u;
+					const u32 w0 = s_cnt[sub[r]], w1 = s_cnt[sub[r] + 1];
+					u32 rank = w0 >> 16;
+					if ((w1 >> 16) - rank > 1) { /* several counted k-mers share the sub-bucket: this one goes behind the smaller ones */
+						const u32 a = w0 & 0xFFFFu, e = w1 & 0xFFFFu;
+						for (u32 q = a; q < e; ++q) {
+							const u32 wq = s_tag[q];
+							if (wq == 0 && q >= a + (u32)BC_HASH_CAP)
+								break; /* nothing is claimed behind a free slot out here (BC_HASH_CAP) */
+							if (q != myslot[r] && counted(wq)) {
+								u64 o[SIZE];
+								load_rec<SIZE>(s_rec + (size_t)((wq & 0xFFFFu) - 1) * SIZE, o);
+								rank += kmc_less<SIZE>(o, key[r]) ? 1u : 0u;
+							}
 						}
 					}
-					u32 rank = s_pre[q / (2 * ITEMS)];
-					for (u32 g = q - q % (2 * ITEMS); g < q; ++g)
-						rank += s_tag[g] >> 31;
-					for (q = p + 1; q < TS; ++q) { /* to its end */
-						const u32 w = s_tag[q];
-						if (w == 0)
-							break;
-						if (w >> 31) {
-							u64 o[SIZE];
-							owner_key(w, o);
-							rin += kmc_less<SIZE>(o, key[r]) ? 1u : 0u;
-						}
-					}
-					mycount[r] = (mycount[r] > P.counter_max ? P.counter_max : mycount[r]) | ((rank + rin) << 16); /* count <= chunk length <= 2^12 */
+					mycount[r] = (mycount[r] > P.counter_max ? P.counter_max : mycount[r]) | (rank << 16); /* count <= chunk length < 2^16 */
 				}
 			}
-			__syncthreads(); /* the walks are over: the records' and the tags' places are free */
+			__syncthreads(); /* ... and, the region scans being over, assembles its record in LDS where the records were */
 			BC_STAMP(6); /* ranks */
-			/* ---- 5: staged: the k-mer (tag bits cleared) where the records were, at its rank; its count where the tags were */
+			/* staged: the k-mer (tag bits cleared) where the records were, at its rank; its count where the tags were */
 #pragma unroll
 			for (int r = 0; r < ITEMS; ++r) {
 				if (mycount[r]) {
