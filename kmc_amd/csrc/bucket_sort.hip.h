@@ -715,43 +715,23 @@ __global__ void __launch_bounds__(BcCfg<SIZE>::THREADS, (SIZE <= 2 ? BC_MIN_WAVE
 							}
 						}
 					}
-					/* ... and writes its record there. Counted k-mers are few (4 % of the records at the default cutoff, 30x coverage): straight to
-					 * the span, 16 bits at a time where the record length allows (staging them in LDS for a coalesced copy-out was measured: two more
-					 * barriers per tile cost more than these stores) */
-					const u32 cntv = mycount[r] > P.counter_max ? P.counter_max : mycount[r];
+					mycount[r] = (mycount[r] > P.counter_max ? P.counter_max : mycount[r]) | (rank << 16); /* count <= chunk length < 2^16 */
+				}
+			}
+			__syncthreads(); /* ... and, the region scans being over, assembles its record in LDS where the records were */
+			BC_STAMP(6); /* ranks */
+			/* staged: the k-mer (tag bits cleared) where the records were, at its rank; its count where the tags were */
+#pragma unroll
+			for (int r = 0; r < ITEMS; ++r) {
+				if (mycount[r]) {
+					const u32 rank = mycount[r] >> 16;
 					u64 kx[SIZE];
 #pragma unroll
 					for (int w = 0; w < SIZE; ++w)
 						kx[w] = key[r][w];
 					kmc_mask_low<SIZE>(kx, 2 * P.k); /* drops a group tag above the k-mer (KFF records carry the top bytes) */
-					uint8_t *dstb = span + (u64)(counted_done + rank) * rec_bytes;
-					if (rec_bytes <= 8 && (rec_bytes & 1u) == 0) { /* one 64-bit value in output byte order; the span is 8-byte aligned, so dstb is 2-byte aligned */
-						u64 rv = P.sbytes ? __builtin_bswap64(kx[0] << (8 * (8 - P.sbytes))) : 0ull; /* suffix bytes high -> low (kb_sorter.h:1198-1199) */
-						if (P.cbytes) {
-							const u32 cv = P.kff ? (__builtin_bswap32(cntv) >> (8 * (4 - P.cbytes))) : cntv; /* :1200-1201 / KFF :1210-1211 */
-							rv |= (u64)cv << (8 * P.sbytes);
-						}
-						unsigned short *d16 = reinterpret_cast<unsigned short *>(dstb);
-						for (u32 q = 0; q < rec_bytes / 2; ++q)
-							d16[q] = (unsigned short)(rv >> (16 * q));
-					} else {
-#pragma clang loop unroll(disable) vectorize(disable)
-						for (u32 q = 0; q < rec_bytes; ++q) {
-							u32 val;
-							if (q < P.sbytes) {
-								const u32 pbyte = P.sbytes - 1 - q;
-								u64 word = kx[0];
-#pragma unroll
-								for (int w = 1; w < SIZE; ++w)
-									word = (pbyte >> 3) == (u32)w ? kx[w] : word;
-								val = (u32)(word >> ((pbyte & 7) * 8));
-							} else {
-								const u32 cq = q - P.sbytes;
-								val = cntv >> (8 * (P.kff ? (P.cbytes - 1 - cq) : cq));
-							}
-							dstb[q] = (uint8_t)val;
-						}
-					}
+					store_rec<SIZE>(s_rec + (size_t)rank * SIZE, kx);
+					s_tag[rank] = mycount[r] & 0xFFFFu;
 					if (use_lut) {
 						const u32 pf = (u32)kmc_remove_suffix<SIZE>(kx, pshift) & lut_mask;
 						if (pf_span <= (u32)BC_LUT_HIST && pf - pf_lo < (u32)BC_LUT_HIST)
@@ -762,7 +742,37 @@ __global__ void __launch_bounds__(BcCfg<SIZE>::THREADS, (SIZE <= 2 ? BC_MIN_WAVE
 				}
 			}
 			__syncthreads();
-			BC_STAMP(6); /* ranks, records */
+			BC_STAMP(7); /* k-mers staged */
+			/* the chunk's bytes, coalesced: byte i of the chunk is byte i % rec_bytes of record i / rec_bytes — suffix bytes high -> low
+			 * (kb_sorter.h:1198-1199), then the counter, little-endian for KMC (:1200-1201), big-endian for KFF (:1210-1211) */
+			const u32 chunk_bytes = chunk_counted * rec_bytes;
+			const u32 inv = rec_bytes > 1 ? (u32)(((1ull << 32) + rec_bytes - 1) / rec_bytes) : 0u; /* x / rec_bytes = umulhi(x, inv), exact for x < 2^29 */
+			auto out_byte = [&](u32 i) -> u32 {
+				const u32 ri = rec_bytes > 1 ? __umulhi(i, inv) : i, q = i - ri * rec_bytes;
+				if (q < P.sbytes) {
+					const u32 pbyte = P.sbytes - 1 - q;
+					return (u32)(s_rec[(size_t)ri * SIZE + (pbyte >> 3)] >> ((pbyte & 7) * 8)) & 0xFFu;
+				}
+				const u32 cq = q - P.sbytes;
+				return (s_tag[ri] >> (8 * (P.kff ? (P.cbytes - 1 - cq) : cq))) & 0xFFu;
+			};
+			uint8_t *dst = span + (u64)counted_done * rec_bytes;
+			if ((counted_done * rec_bytes & 3u) == 0) { /* the span is 8-byte aligned: whole dwords (the bytes behind the last record are the span's own) */
+				u32 *dst32 = reinterpret_cast<u32 *>(dst);
+#pragma clang loop unroll(disable) vectorize(disable)
+				for (u32 wd = tid; wd < (chunk_bytes + 3) / 4; wd += THREADS) {
+					const u32 i0 = wd * 4;
+					u32 word = out_byte(i0);
+					word |= (i0 + 1 < chunk_bytes ? out_byte(i0 + 1) : 0u) << 8;
+					word |= (i0 + 2 < chunk_bytes ? out_byte(i0 + 2) : 0u) << 16;
+					word |= (i0 + 3 < chunk_bytes ? out_byte(i0 + 3) : 0u) << 24;
+					dst32[wd] = word;
+				}
+			} else { /* a later chunk of a long tile */
+#pragma clang loop unroll(disable) vectorize(disable)
+				for (u32 i = tid; i < chunk_bytes; i += THREADS)
+					dst[i] = (uint8_t)out_byte(i);
+			}
 			if (use_lut && pf_span <= (u32)BC_LUT_HIST) {
 				for (u32 i = tid; i < pf_span; i += THREADS) {
 					const u32 v = s_lut[i];
