@@ -183,6 +183,11 @@ int kmc_hip_scatter_totals(kmc_hip_ctx *ctx, int dev, int reset, uint64_t *n_lau
  * passes over every byte because a bucket did not fit a tile. Any pointer may be NULL. Waits for the device's streams. */
 int kmc_hip_local_sort_totals(kmc_hip_ctx *ctx, int dev, int reset, uint64_t *n_launches, double *total_ms, uint64_t *total_records,
                               uint64_t *n_hybrid_groups, uint64_t *n_redo_groups);
+/* Which sort stage 2 runs (process-wide; overrides $KMC_HIP_HYBRID; tests and tuning): 0 = 8-bit LSD passes over every key byte + k_compact (rounds 1-2);
+ * 1 = default: groups of bins with records of 2+ words (k >= 33) take the hybrid path — LSD passes over the top key bytes only, then k_bucket_count on
+ * bucket-aligned tiles in LDS —, one-word records the LSD path; 2 = hybrid for every record width, and the LDS sort for sort-only calls; -h = `h` top
+ * bytes forced. Also clears the hybrid / redo group counters of kmc_hip_local_sort_totals. Returns the mode that was in force. */
+int kmc_hip_set_hybrid(int mode);
 /* Device memory helpers so non-HIP callers (ctypes tests, the C++ worker) need not link HIP themselves. */
 int kmc_hip_malloc(kmc_hip_ctx *ctx, int dev, uint64_t bytes, void **d_ptr);
 int kmc_hip_free(kmc_hip_ctx *ctx, int dev, void *d_ptr);

@@ -68,7 +68,7 @@ SYMBOLS = [
     "kmc_hip_sort_records", "kmc_hip_sort_records_into", "kmc_hip_sort_records_device",
     "kmc_hip_process_bin", "kmc_hip_process_bin_submit", "kmc_hip_process_bin_wait", "kmc_hip_process_bin_device",
     "kmc_hip_process_bins_device",
-    "kmc_hip_allreduce_stats", "kmc_hip_last_timings", "kmc_hip_scatter_totals", "kmc_hip_local_sort_totals",
+    "kmc_hip_allreduce_stats", "kmc_hip_last_timings", "kmc_hip_scatter_totals", "kmc_hip_local_sort_totals", "kmc_hip_set_hybrid",
     "kmc_hip_malloc", "kmc_hip_free", "kmc_hip_memcpy_h2d", "kmc_hip_memcpy_d2h",
     "kmc_hip_host_register", "kmc_hip_host_unregister", "kmc_hip_host_alloc", "kmc_hip_host_free", "kmc_hip_synchronize",
     "kmc_hip_debug_expand", "kmc_hip_debug_compact", "kmc_hip_debug_split_reads",
@@ -317,6 +317,11 @@ class Context:
         n, t, k = C.c_uint64(), C.c_double(), C.c_uint64()
         self._chk(self.L.kmc_hip_scatter_totals(self.h, dev, 1 if reset else 0, C.byref(n), C.byref(t), C.byref(k)))
         return n.value, t.value, k.value
+
+    def set_hybrid(self, mode: int) -> int:
+        """process-wide sort selection (see include/kmc_hip.h kmc_hip_set_hybrid); returns the previous mode"""
+        self.L.kmc_hip_set_hybrid.restype = C.c_int
+        return int(self.L.kmc_hip_set_hybrid(C.c_int(mode)))
 
     def local_sort_totals(self, reset: bool = True, dev: int = 0):
         """dict(launches, ms, records) of the LDS half of the hybrid sort on `dev` since the last reset + process-wide hybrid / redo group counts."""

@@ -13,6 +13,7 @@
 
 #include <algorithm>
 #include <atomic>
+#include <cstdint>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -321,8 +322,12 @@ struct SortPlan {
 	u32 hbits() const { return top ? 8 * top - (8 * key_bytes - key_bits) : 0; } /* top bits of the significant key that the HBM passes order (plan_sort: 8 top > spare bits) */
 };
 std::atomic<u64> g_hybrid_groups{0}, g_redo_groups{0}; /* process-wide: input whose buckets keep overflowing the tiles stops being tried */
+std::atomic<int> g_hybrid_override{INT32_MIN}; /* kmc_hip_set_hybrid */
 int hybrid_mode()
 {
+	const int o = g_hybrid_override.load(std::memory_order_relaxed);
+	if (o != INT32_MIN)
+		return o;
 	static const int v = [] {
 		/* 0 = LSD passes over every byte (rounds 1-2); 1 = default: hybrid where it wins (groups of bins with records of 2+ words, k >= 33: 4 HBM passes
 		 * instead of 14 at k = 55, 3 instead of 32 at k = 127 — at k <= 32 the fused counting kernel costs what the passes it replaces cost);
@@ -661,7 +666,7 @@ int compact_group(Slot &s, const std::vector<BinPlan> &bins, const u64 *sorted, 
 		u64 *lut_base = b.d_lut;
 		if (use_lut && n_sh > 1)
 			lut_base = zero_ptr<u64>(s, b.off_lutsh); /* zeroed with the rest of the zero region */
-		else if (use_lut)
+		else if (lut_entries && !P.kff && b.d_lut) /* also without output: the caller's LUT is zero-filled by the callee (include/kmc_hip.h) */
 			HIPCHK(hipMemsetAsync(b.d_lut, 0, lut_entries * 8, s.stream));
 		gc.S[i] = sorted + b.rec_off * SIZE;
 		gc.n[i] = gf.n[i] = b.n_rec;
@@ -741,7 +746,7 @@ int count_group(Slot &s, const std::vector<BinPlan> &bins, const u64 *sorted, u6
 		u64 *lut_base = b.d_lut;
 		if (use_lut && n_sh > 1)
 			lut_base = zero_ptr<u64>(s, b.off_lutsh);
-		else if (use_lut)
+		else if (lut_entries && !P.kff && b.d_lut) /* also without output: the caller's LUT is zero-filled by the callee (include/kmc_hip.h) */
 			HIPCHK(hipMemsetAsync(b.d_lut, 0, lut_entries * 8, s.stream));
 		gbn.S[i] = gb.S[i] = sorted + b.rec_off * SIZE;
 		gbn.n[i] = gf.n[i] = b.n_rec;
@@ -2269,6 +2274,15 @@ int kmc_hip_scatter_totals(kmc_hip_ctx *ctx, int dev, int reset, uint64_t *n_lau
 	if (total_records)
 		*total_records = keys;
 	return 0;
+}
+
+int kmc_hip_set_hybrid(int mode)
+{
+	const int before = hybrid_mode();
+	g_hybrid_override.store(mode, std::memory_order_relaxed);
+	g_hybrid_groups.store(0);
+	g_redo_groups.store(0);
+	return before;
 }
 
 int kmc_hip_local_sort_totals(kmc_hip_ctx *ctx, int dev, int reset, uint64_t *n_launches, double *total_ms, uint64_t *total_records, uint64_t *n_hybrid_groups,

@@ -603,3 +603,73 @@ def test_two_devices_worker_allreduce_and_wide_records(ref_bins, tmp_path):
     _kmc(ref_bins["kmc_hip"], ["-k27", "-t8", "-sr6"], fq, str(tmp_path / "hip"), str(tmp_path / "t_hip"), env=_hip_env(KMC_HIP_DEVICES="0,1"))
     for ext in (".kmc_pre", ".kmc_suf"):
         assert _md5(str(tmp_path / ("ref" + ext))) == _md5(str(tmp_path / ("hip" + ext))), ext
+
+
+# ------------------------------------------------------------------------------------------------ hybrid sort (bucket_sort.hip.h)
+@pytest.fixture
+def hybrid_everywhere(ctx):
+    """the hybrid path for every record width (by default one-word records take the LSD passes), counters cleared; restored afterwards"""
+    before = ctx.set_hybrid(2)
+    yield ctx
+    ctx.set_hybrid(before)
+
+
+@pytest.mark.parametrize("k,pl,reads,genome,n_bins,kw", [(27, 7, 400_000, 2_000_000, 16, {}), (27, 3, 120_000, 600_000, 5, {"cutoff_min": 1}), (32, 4, 100_000, 500_000, 8, {}),
+                                                         (33, 5, 100_000, 500_000, 8, {}), (55, 7, 200_000, 1_000_000, 8, {}), (127, 3, 60_000, 300_000, 4, {"cutoff_min": 1, "counter_max": 3}),
+                                                         (27, 0, 100_000, 500_000, 8, {"output_type": 1}), (55, 0, 60_000, 300_000, 4, {"output_type": 1}), (27, 3, 100_000, 500_000, 4, {"without_output": 1}),
+                                                         (200, 4, 20_000, 100_000, 3, {"cutoff_min": 1})])
+def test_hybrid_sort_groups_match_the_oracle_per_bin(hybrid_everywhere, k, pl, reads, genome, n_bins, kw):
+    """LSD passes over the TOP key bytes only, then k_bucket_count on bucket-aligned tiles in LDS (no sorted records ever reach HBM): every bin of
+    every group byte for byte against the oracle — suffix records, LUT, tallies — and no group may have been handed back to the host."""
+    ctx = hybrid_everywhere
+    bins = capi.synth_bins(seed=99, genome_len=genome, n_reads=reads, k=k, n_bins=n_bins, read_len=150 if k < 140 else 300)
+    p = hp(k, lut_prefix_len=pl, **kw)
+    got, err = _run_batch(ctx, p, bins, 1)
+    assert err is None, err
+    for i, (img, nrec, packs, _) in enumerate(bins):
+        w_out, w_lut, w_st = O.process_bin(op(p), img, nrec)
+        assert np.array_equal(got[i][2], w_st), (i, got[i][2], w_st)
+        assert np.array_equal(got[i][0], w_out), (i, _first_diff(got[i][0], w_out))
+        assert np.array_equal(got[i][1], w_lut), i
+    t = ctx.local_sort_totals()
+    assert t["hybrid_groups"] >= 1 and t["redo_groups"] == 0, t
+
+
+@pytest.mark.parametrize("k", [27, 55])
+def test_hybrid_sort_hands_a_group_with_a_huge_bucket_back_to_the_lsd_passes(hybrid_everywhere, k):
+    """one k-mer repeated more often than a tile holds records (a 300 bp 'genome' read 20 000 times): k_bucket_count must say so (redo), the host
+    must sort the group again with LSD passes over every byte, and the result must be the oracle's — through the asynchronous device-resident
+    entry and through the host-buffer entry."""
+    ctx = hybrid_everywhere
+    bins = capi.synth_bins(seed=5, genome_len=300, n_reads=20_000, k=k, n_bins=2, read_len=150, err=0.0)
+    p = hp(k, lut_prefix_len=3)
+    got, err = _run_batch(ctx, p, bins, 1)
+    assert err is None, err
+    for i, (img, nrec, packs, _) in enumerate(bins):
+        w = O.process_bin(op(p), img, nrec)
+        assert np.array_equal(got[i][0], w[0]) and np.array_equal(got[i][1], w[1]) and np.array_equal(got[i][2], w[2]), i
+    t = ctx.local_sort_totals()
+    assert t["redo_groups"] >= 1, t
+    img, nrec, packs, _ = max(bins, key=lambda b: b[1])
+    out, lut, st = ctx.process_bin(p, img, nrec, packs)
+    w = O.process_bin(op(p), img, nrec)
+    assert np.array_equal(out, w[0]) and np.array_equal(lut, w[1]) and np.array_equal(st, w[2])
+    assert ctx.local_sort_totals()["redo_groups"] >= 1
+
+
+def test_hybrid_sort_only_calls_match_the_oracle(hybrid_everywhere):
+    """kmc_hip_sort_records under the hybrid mode: k_bucket_sort finishes the low bytes in LDS; skewed input goes back to the LSD passes"""
+    ctx = hybrid_everywhere
+    rng = np.random.default_rng(17)
+    for words, kb, n in ((1, 7, 300_001), (2, 14, 100_003), (4, 32, 50_000)):
+        recs = rng.integers(0, 2**63, size=(n, words), dtype=np.uint64)
+        for w in range(words):
+            lo = 8 * w
+            if kb <= lo:
+                recs[:, w] = 0
+            elif kb - lo < 8:
+                recs[:, w] &= np.uint64((1 << (8 * (kb - lo))) - 1)
+        got = ctx.sort_records(recs, kb)
+        assert np.array_equal(got, O.sort(recs))
+    a = np.where(rng.random(200_000) < 0.5, np.uint64(5), np.uint64(0x0011223344556677))
+    assert np.array_equal(ctx.sort_records(a.reshape(-1, 1), 7)[:, 0], np.sort(a))

@@ -85,3 +85,49 @@ def test_two_emulated_devices_context_wide_records_allreduce_and_dropin(tmp_path
     want = _run("kmc", ["-k27", "-ci1", "-m2", "-sf1", "-n64", "-sp1", "-sr1"], fq, tmp_path, "ref")
     got = _run("kmc_hip", ["-k27", "-ci1", "-m2", "-sf1", "-n64", "-sp1", "-sr4"], fq, tmp_path, "emu", env={"KMC_HIP_LIB": lib, "HIPEMU_DEVICES": "2", "KMC_HIP_DEVICES": "0,1"})
     assert got[:2] == want[:2]
+
+
+_HYBRID_CASE = r'''
+import sys
+import numpy as np
+sys.path.insert(0, r"%(root)s"); sys.path.insert(0, r"%(root)s/tests")
+import oracle_py as O
+from kmc_amd import capi
+from test_gpu_parity import _run_batch
+
+ctx = capi.Context((0,))
+ctx.set_hybrid(2)  # the hybrid sort for every record width
+for k, pl, kw in ((27, 3, {}), (55, 3, {"cutoff_min": 1}), (27, 0, {"output_type": 1})):
+    bins = capi.synth_bins(seed=7, genome_len=6000, n_reads=1200, k=k, n_bins=5, n_threads=1)
+    p = capi.make_params(k, lut_prefix_len=pl, **kw)
+    op = O.make_params(p.kmer_len, p.both_strands, p.cutoff_min, p.cutoff_max, p.counter_max, p.lut_prefix_len, p.output_type, p.without_output)
+    got, err = _run_batch(ctx, p, bins, 1)
+    assert err is None, err
+    for i, (img, nrec, packs, _) in enumerate(bins):
+        w = O.process_bin(op, img, nrec)
+        assert np.array_equal(got[i][0], w[0]) and np.array_equal(got[i][1], w[1]) and np.array_equal(got[i][2], w[2]), (k, i)
+t = ctx.local_sort_totals()
+assert t["hybrid_groups"] >= 3 and t["redo_groups"] == 0, t
+# one k-mer repeated more often than a tile of the small geometry holds records: the group must come back through the LSD passes
+bins = capi.synth_bins(seed=5, genome_len=300, n_reads=1500, k=27, n_bins=2, err=0.0, n_threads=1)
+p = capi.make_params(27)
+op = O.make_params(27)
+got, err = _run_batch(ctx, p, bins, 1)
+assert err is None, err
+for i, (img, nrec, packs, _) in enumerate(bins):
+    w = O.process_bin(op, img, nrec)
+    assert np.array_equal(got[i][0], w[0]) and np.array_equal(got[i][1], w[1]) and np.array_equal(got[i][2], w[2]), i
+assert ctx.local_sort_totals()["redo_groups"] >= 1
+rng = np.random.default_rng(3)
+a = rng.integers(0, 2**54, size=(5000, 1), dtype=np.uint64)
+assert np.array_equal(ctx.sort_records(a, 7), O.sort(a))
+print("HYBRID-OK")
+'''
+
+
+def test_hybrid_sort_on_the_emulated_host_library():
+    """bucket_sort.hip.h on the CPU: k_bucket_bounds + k_bucket_count (groups of bins, k = 27 / 55, KFF records) and k_bucket_sort (sort-only call)
+    against the oracle, and the redo of a group whose tile does not fit — through the product's host library over the emulated runtime."""
+    lib = emu.build_hostlib("small")
+    r = subprocess.run([sys.executable, "-c", _HYBRID_CASE % {"root": ROOT}], env=dict(os.environ, KMC_HIP_LIB=lib), capture_output=True, text=True, timeout=1500, cwd=ROOT)
+    assert r.returncode == 0 and "HYBRID-OK" in r.stdout, (r.stdout + r.stderr)[-1500:]

@@ -27,6 +27,7 @@ t=time.time(); s=capi.synth_bins(seed=2026, genome_len=1000000000, n_reads=20000
     host)    timeout 600 python tools/ubench_host.py > $OUT/ubench_host.json 2> $OUT/ubench_host.err ;;
     var:*)   v=${step#var:}; KMC_HIP_LIB=kmc_amd/variants/libkmc_hip_$v.so timeout 600 python bench.py $one_bin > $OUT/onebin_$v.json 2> $OUT/onebin_$v.err ;;
     var512:*) v=${step#var512:}; KMC_HIP_LIB=kmc_amd/variants/libkmc_hip_$v.so timeout 600 python bench.py $bins512 > $OUT/bins512_$v.json 2> $OUT/bins512_$v.err ;;
+    qs:*)    a=${step#qs:}; n=${a%%:*}; e=${a#*:}; env $e timeout 600 python bench.py --cache /dev/shm/kmccache --leg quarter --reads 50000000 --genome 250000000 --bins 128 --steps 3 --warmup 1 --streams $n > $OUT/qs_${n}_$e.json 2> $OUT/qs_${n}_$e.err; python tools/pj.py $OUT/qs_${n}_$e.json 2>&1 | cut -c1-120 ;;
     kq:*)    a=${step#kq:}; k=${a%%:*}; e=${a#*:}; env $e timeout 900 python bench.py --k $k --leg quarter --reads 50000000 --genome 250000000 --bins 128 --steps 3 --warmup 1 --no-digest > $OUT/kq_${k}_$e.json 2> $OUT/kq_${k}_$e.err; python tools/pj.py $OUT/kq_${k}_$e.json 2>&1 | cut -c1-700 ;;
     k:*)     k=${step#k:}; timeout 900 python bench.py --k $k --no-cpu-baseline --no-secondary --no-host-boundary --steps 3 > $OUT/bench_k$k.json 2> $OUT/bench_k$k.err ;;
     prof)    cd /tmp; timeout 1500 rocprofv3 --kernel-trace --stats -f csv -d $OLDPWD/$OUT/prof -o kt -- python $OLDPWD/bench.py --cache /dev/shm/kmccache --no-cpu-baseline --no-secondary --no-host-boundary --no-two-streams --no-digest --steps 3 > $OLDPWD/$OUT/prof_bench.json 2> $OLDPWD/$OUT/prof.err; cd $OLDPWD ;;
