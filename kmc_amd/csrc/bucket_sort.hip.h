@@ -402,9 +402,11 @@ template <int SIZE> constexpr size_t bc_lds_bytes()
 	       (6 * (BcCfg<SIZE>::THREADS / 64) + 4) * 4 + 16;
 }
 /* average bucket size the host aims for when it picks the number of HBM passes. What must not happen is ONE bucket beyond CAP (a longer TILE is only a
- * second chunk), and the k-mers of a signature bin are clustered: on the bench's bins the largest of 2^22 buckets holds 100x the average at k = 27 and
- * more at k = 55 (measured: averages of 9 with CAP 2048 sent half of the groups back to the host). So: CAP / 256 for one-word records, CAP / 512 beyond. */
-template <int SIZE> constexpr u64 bc_target_bucket() { return SIZE == 1 ? BcCfg<SIZE>::CAP / 256 : (BcCfg<SIZE>::CAP / 512 > 1 ? BcCfg<SIZE>::CAP / 512 : 1); }
+ * second chunk), and the k-mers of a signature bin are clustered — the longer the k-mer, the more: on the bench's bins the largest of 2^22 buckets holds
+ * 100x the average at k = 27, 600-1200x at k = 127 (a 9.4 M k-mer bin: average 2.2, largest 3072 > CAP 2048: nearly every group went back to the host).
+ * So: CAP / 256 for one-word records, 1 beyond (k = 55 and k = 127 on 30 Gbp: 4 passes); a group that still comes back raises the number of passes for
+ * the groups after it (kmc_hip.hip plan_sort). */
+template <int SIZE> constexpr u64 bc_target_bucket() { return SIZE == 1 ? BcCfg<SIZE>::CAP / 256 : 1; }
 
 #ifdef KMC_TRACE /* tuning builds: thread 0 of every tile adds the time since its previous stamp to phase counter j (tools/trace_bc.py) */
 #define BC_STAMP(j)                                                                                                             \

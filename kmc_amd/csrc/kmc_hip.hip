@@ -322,6 +322,14 @@ struct SortPlan {
 	u32 hbits() const { return top ? 8 * top - (8 * key_bytes - key_bits) : 0; } /* top bits of the significant key that the HBM passes order (plan_sort: 8 top > spare bits) */
 };
 std::atomic<u64> g_hybrid_groups{0}, g_redo_groups{0}; /* process-wide: input whose buckets keep overflowing the tiles stops being tried */
+std::atomic<u32> g_extra_top{0}; /* HBM passes added to the plan after a group came back (finer buckets for the groups after it) */
+void note_redo() { g_redo_groups.fetch_add(1, std::memory_order_relaxed); }
+void raise_top() /* once per drained stream / synchronous redo: the groups of one asynchronous call all come back at its end and must count once */
+{
+	u32 e = g_extra_top.load(std::memory_order_relaxed);
+	if (e < 2)
+		g_extra_top.compare_exchange_strong(e, e + 1, std::memory_order_relaxed);
+}
 std::atomic<int> g_hybrid_override{INT32_MIN}; /* kmc_hip_set_hybrid */
 int hybrid_mode()
 {
@@ -355,8 +363,8 @@ template <int SIZE> SortPlan plan_sort(u64 n, u32 key_bytes, u32 key_bits, bool 
 		return sp;
 	}
 	const u64 redo = g_redo_groups.load(std::memory_order_relaxed);
-	if (redo > 4 && redo * 8 > g_hybrid_groups.load(std::memory_order_relaxed))
-		return sp; /* this input defeats the bucket tiles too often */
+	if (g_extra_top.load(std::memory_order_relaxed) >= 2 && redo > 128 && redo * 8 > g_hybrid_groups.load(std::memory_order_relaxed))
+		return sp; /* this input defeats the bucket tiles even with two passes more */
 	/* the fewest top bytes that leave buckets of bs_target_bucket() records on average, and only if at least two passes are saved */
 	for (u32 h = 0; h + 2 <= key_bytes && h <= 4; ++h) {
 		bool ok;
@@ -370,6 +378,12 @@ template <int SIZE> SortPlan plan_sort(u64 n, u32 key_bytes, u32 key_bits, bool 
 			sp.top = h;
 			break;
 		}
+	}
+	if (sp.top < key_bytes && sp.top >= 1) { /* finer buckets after a redo, while that still saves passes and the bucket number fits 32 bits */
+		const u32 extra = g_extra_top.load(std::memory_order_relaxed);
+		sp.top = std::min(std::min(sp.top + extra, 4u), key_bytes);
+		if (sp.top + 2 > key_bytes)
+			sp.top = key_bytes;
 	}
 	return sp;
 }
@@ -999,12 +1013,12 @@ int drain_redo(Slot &s)
 			fprintf(stderr, "\n");
 		}
 		if (no_redo) {
-			g_redo_groups.fetch_add(1, std::memory_order_relaxed);
+			note_redo();
 			any = true;
 			continue;
 		}
 		any = true;
-		g_redo_groups.fetch_add(1, std::memory_order_relaxed);
+		note_redo();
 		std::vector<const kmc_hip_bin_desc *> ptrs;
 		for (const auto &d : groups[i].descs)
 			ptrs.push_back(&d);
@@ -1016,6 +1030,7 @@ int drain_redo(Slot &s)
 			return rc;
 	}
 	if (any) {
+		raise_top();
 		HIPCHK(hipMemsetAsync(s.redo_log.p, 0, log.size() * 4, s.stream));
 		HIPCHK(hipStreamSynchronize(s.stream));
 	}
@@ -1049,8 +1064,10 @@ int read_redo(Slot &s, bool &redo)
 	u32 v = 0;
 	HIPCHK(hipMemcpy(&v, small_ptr<u32>(s, SM_REDO), 4, hipMemcpyDeviceToHost));
 	redo = v != 0;
-	if (redo)
-		g_redo_groups.fetch_add(1, std::memory_order_relaxed);
+	if (redo) {
+		note_redo();
+		raise_top();
+	}
 	return 0;
 }
 
@@ -1719,7 +1736,8 @@ int kmc_hip_process_bin_wait(kmc_hip_ctx *ctx, int dev, int slot, uint64_t *out_
 		return rc;
 	HostRes r = *s.h_res;
 	if (r.redo && !r.err) { /* the hybrid sort met a tile it could not handle: the bin again (its image is still in s.in), LSD passes over every byte */
-		g_redo_groups.fetch_add(1, std::memory_order_relaxed);
+		note_redo();
+		raise_top();
 		if (int rc = enqueue_host_bin(s, true))
 			return rc;
 		HIPCHK(hipEventSynchronize(s.done_ev));
@@ -2282,6 +2300,7 @@ int kmc_hip_set_hybrid(int mode)
 	g_hybrid_override.store(mode, std::memory_order_relaxed);
 	g_hybrid_groups.store(0);
 	g_redo_groups.store(0);
+	g_extra_top.store(0);
 	return before;
 }
 
