@@ -583,6 +583,11 @@ def main():
         rpl = sc_recs / max(n_launch, 1)
         achieved = (2 * W * sc_recs) / (sc_ms * 1e-3) / 1e9 if n_launch else 0.0
         value = w.total_kmers_all * args.steps / dt / 1e9
+        # which sort ran: LSD passes over every key byte (P of them), or — hybrid — over the top bytes only + k_bucket_count in LDS. The sampled groups carry
+        # both kinds of event pairs, so passes per record = scatter records / LDS-sorted records.
+        hyb = ls["launches"] > 0 and ls["records"] > 0
+        hbm_passes = (sc_recs / ls["records"]) if hyb else float(P)
+        moved = W * (1 + 2 * hbm_passes + 1) + 1.2  # expand write + passes (read + write) + one read by k_bucket_count / k_compact + the bin image
         desc = (CONFIGS[name]["desc"] % k) if name in CONFIGS else f"custom: k={k}, {args.reads} reads of a {args.genome} bp genome, {args.bins} bins"
         out = {
             "metric": "stage-2 Gk-mers/s, k=%d (bin sort & count: parse + expand + 8-bit LSD radix sort + compaction over all signature bins)" % k,
@@ -599,6 +604,12 @@ def main():
             "tallies": {"n_unique": int(tallies[0]), "n_cutoff_min": int(tallies[1]), "n_cutoff_max": int(tallies[2]), "n_total": int(tallies[3])},
             "self_check": {"per_bin_total_and_out_bytes_consistent": bool(ok), "output_digest": digest,
                            "oracle_bins_equal": (all(v.get("equal") for v in oracle_bins) if oracle_bins else None), "oracle_bins": oracle_bins},
+            "sort_path": {"what": ("hybrid: 8-bit LSD passes through HBM over the top key bytes only, the rest counted inside LDS on bucket-aligned tiles (k_bucket_count)" if hyb
+                                   else "8-bit LSD passes through HBM over every key byte, then k_compact"),
+                          "hbm_passes_per_record": hbm_passes, "hbm_bytes_per_kmer_moved_by_design": moved, "moved_GBs": moved * value, "moved_frac_of_hbm_peak": moved * value / HBM_PEAK_GBS,
+                          "note": "SURVEY 8d: an implementation with fewer passes moves fewer real bytes — stage2_algorithmic_* below is the NORMATIVE 8-bit-LSD figure W(2P+3) "
+                                  "(what the reference formulation would have to move for this throughput: it can exceed the HBM peak when passes are skipped), "
+                                  "moved_* is what this path is designed to move (PMC-checked per kernel in profiles/r03)"},
             "stage2_algorithmic_bytes_per_kmer": W * (2 * P + 3),
             "stage2_algorithmic_GBs": W * (2 * P + 3) * value,
             "stage2_frac_of_hbm_peak": W * (2 * P + 3) * value / HBM_PEAK_GBS,

@@ -42,6 +42,8 @@ VARIANTS = {
     "bidx2": ["-DCP_TILE_FROM_BLOCKIDX=1", "-DRS_TILE_FROM_BLOCKIDX=1"],
     "cpmw6": ["-DCP_MIN_WAVES_1=6"],  # k_compact<1> with 80 VGPRs (no spills?) instead of 64 + 30 spilled
     "cpmw5": ["-DCP_MIN_WAVES_1=5"],
+    "bc768": ["-DBC_BLOCK_THREADS=768", "-DBC_MIN_WAVES=6"],  # k_bucket_count: 12 waves x 4 rows, 80 VGPRs (nothing spilled), two workgroups per CU
+    "bc512mw6": ["-DBC_BLOCK_THREADS=512", "-DBC_MIN_WAVES=6"],  # 8 waves x 4 rows, 80 VGPRs, three workgroups per CU
     "bcmw4": ["-DBC_MIN_WAVES=4"],  # k_bucket_count with 128 VGPRs: one workgroup of 1024 per CU, nothing spilled
     "bc512": ["-DBC_BLOCK_THREADS=512", "-DBC_WORDS_PER_THREAD=8", "-DBC_MIN_WAVES=4"],  # 8 waves x 8 rows, two workgroups per CU at 128 VGPRs
     "bc1": ["-DBC_STOP_AFTER=1"],  # k_bucket_count cut after its phase 1 / 2 / 3 (garbage output): phase costs
