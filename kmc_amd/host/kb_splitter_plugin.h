@@ -42,6 +42,7 @@
 
 #include "critical_error_handler.h"
 #include "split_engine.h"
+#include "kmc_order.h" /* KmcTimeline: where does the wall clock go between the stages (KMC_HIP_VERBOSE=1) */
 
 /* n_plus_x_recs of one record (kb_collector.cpp:83-100, kb_collector.h:72-118), from the PACKED record: only needed when a bin's piece of a
  * part has to be cut (it does not fit an empty buffer), because then the engine's sum for the piece cannot be used. */
@@ -205,8 +206,10 @@ public:
 
 	void operator()()
 	{
+		KmcTimeline::mark_first_last("splitter: first worker started", nullptr);
 		if (ref) {
 			(*ref)();
+			KmcTimeline::mark_first_last(nullptr, "splitter: last worker done");
 			return;
 		}
 		while (!pq->completed()) {
@@ -251,6 +254,7 @@ public:
 		}
 		bpq->mark_completed();
 		engine.reset();
+		KmcTimeline::mark_first_last(nullptr, "splitter: last worker done");
 		if (getenv("KMC_HIP_VERBOSE"))
 			fprintf(stderr, "[kmc_hip stage 1] worker: %llu parts through the engine (%.3f s inside), %llu long-read parts and %llu uncovered parts to the reference splitter, "
 			                "%llu bin pieces (%llu cut record by record), %llu buffers / %.1f MB pushed\n",

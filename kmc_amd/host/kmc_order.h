@@ -46,10 +46,32 @@ struct KmcTimeline {
 		std::lock_guard<std::mutex> lck(t.m);
 		t.marks.emplace_back(what, now);
 	}
+	/* first / last of many events of one kind (the 100+ splitter workers of stage 1) */
+	static void mark_first_last(const char *first, const char *last)
+	{
+		KmcTimeline &t = inst();
+		if (!t.on)
+			return;
+		const long long now = std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now().time_since_epoch()).count();
+		std::lock_guard<std::mutex> lck(t.m);
+		bool have_first = false, have_last = false;
+		for (auto &e : t.marks) {
+			have_first = have_first || e.first == first;
+			if (e.first == last) {
+				e.second = now;
+				have_last = true;
+			}
+		}
+		if (first && !have_first)
+			t.marks.emplace_back(first, now);
+		if (last && !have_last)
+			t.marks.emplace_back(last, now);
+	}
 	~KmcTimeline()
 	{
 		if (!on || marks.empty())
 			return;
+		mark("process exit (static destructors)");
 		fprintf(stderr, "[kmc_hip timeline]");
 		for (auto &e : marks)
 			fprintf(stderr, " %s %.3f |", e.first, (e.second - marks[0].second) * 1e-9);
