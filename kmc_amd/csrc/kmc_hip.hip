@@ -1153,7 +1153,7 @@ struct S1HipBackend {
 	DBuf *arena = nullptr;
 	size_t used = 0;
 	std::vector<void *> extra;
-	void *alloc(size_t bytes)
+	void *alloc_uninit(size_t bytes)
 	{
 		const size_t want = ((bytes ? bytes : 1) + 255) & ~(size_t)255;
 		void *p = nullptr;
@@ -1166,7 +1166,12 @@ struct S1HipBackend {
 				throw S1BackendFailure{e, "hipMalloc"};
 			extra.push_back(p);
 		}
-		hipError_t e = hipMemsetAsync(p, 0, want, stream);
+		return p;
+	}
+	void *alloc(size_t bytes) /* zeroed: status words, tickets, totals, the text and code streams (read with slack behind their ends) */
+	{
+		void *p = alloc_uninit(bytes);
+		hipError_t e = hipMemsetAsync(p, 0, ((bytes ? bytes : 1) + 255) & ~(size_t)255, stream);
 		if (e != hipSuccess)
 			throw S1BackendFailure{e, "hipMemsetAsync"};
 		return p;

@@ -9,6 +9,7 @@
  *
  * A backend B provides:
  *   void *alloc(size_t bytes)                  zeroed device memory, owned by the backend until release()
+ *   void *alloc_uninit(size_t bytes)           the same without the zeroing: for arrays that are written before they are read (super-k-mer lists, sort keys)
  *   void  zero(void *p, size_t bytes)          (stream-ordered)
  *   bool  d2h(void *dst, const void *src, size_t bytes)   copies and waits for everything launched before; false = device failure
  *   void  h2d(void *dst, const void *src, size_t bytes)   (the source may be reused when it returns)
@@ -83,9 +84,9 @@ template <class B> int s1_split_part(B &be, const uint8_t *d_text, u64 size, boo
 		const u32 ct = (u32)s1_cut_tiles(n);
 		u64 *d_cstat = (u64 *)be.alloc((size_t)ct * 16);
 		for (int attempt = 0; attempt < 2; ++attempt) {
-			d_pos = (u64 *)be.alloc(cap * 8);
-			d_len = (u32 *)be.alloc(cap * 4);
-			d_sig = (u32 *)be.alloc(cap * 4);
+			d_pos = (u64 *)be.alloc_uninit(cap * 8);
+			d_len = (u32 *)be.alloc_uninit(cap * 4);
+			d_sig = (u32 *)be.alloc_uninit(cap * 4);
 			if (attempt) {
 				be.zero(d_cstat, (size_t)ct * 16);
 				be.zero(d_small + 2, 8);
@@ -152,7 +153,7 @@ template <class B> int s1_split_part(B &be, const uint8_t *d_text, u64 size, boo
 			cum[b + 1] = cum[b] + bytes_now[b];
 		u64 *d_cum = (u64 *)be.alloc((size_t)(nb + 1) * 8);
 		be.h2d(d_cum, cum.data(), (size_t)(nb + 1) * 8);
-		u64 *d_keys = (u64 *)be.alloc(n_sk * 8), *d_ktmp = (u64 *)be.alloc(n_sk * 8);
+		u64 *d_keys = (u64 *)be.alloc_uninit(n_sk * 8), *d_ktmp = (u64 *)be.alloc_uninit(n_sk * 8);
 		S1_LAUNCH(B, be, k_s1_sort_keys, dim3((u32)((n_sk + 255) / 256)), dim3(256), (const u32 *)d_sig, n_sk, P.d_sig_to_bin, nb, d_keys, d_err);
 		const u64 *d_sorted = be.sort_by_low16(d_keys, d_ktmp, n_sk);
 		const u32 et = (u32)((n_sk + S1_TILE - 1) / S1_TILE);

@@ -26,7 +26,7 @@ struct SplitApi {
 	int n_dev = 1, n_slots = 1;
 	std::string err;
 	std::mutex map_mtx;
-	std::vector<char> map_set; /* per device */
+	std::vector<uint64_t> map_hash; /* per device: hash of the signature -> bin map that was uploaded last (0 = none) */
 } g_split;
 std::once_flag g_split_once;
 
@@ -42,7 +42,7 @@ void bind()
 		g_split.err = "libkmc_hip.so lacks kmc_hip_split_set_map / kmc_hip_split_part";
 		g_split.ctx = nullptr;
 	}
-	g_split.map_set.assign((size_t)g_split.n_dev, 0);
+	g_split.map_hash.assign((size_t)g_split.n_dev, 0);
 }
 
 struct HipSplitEngine : KmcSplitEngine {
@@ -52,7 +52,16 @@ struct HipSplitEngine : KmcSplitEngine {
 	std::vector<uint8_t> recs;
 	std::vector<uint64_t> arrays; /* bin_off | bin_bytes | bin_kmers | bin_superkmers | bin_plus_x */
 
-	HipSplitEngine(const KmcSplitParams &p, int dev, int slot) : P(p), dev(dev), slot(slot) { arrays.assign((size_t)5 * p.n_bins, 0); }
+	uint64_t map_hash = 0; /* of this run's map: a second KMC run in the same process (library API) with another map must not split with the first one's */
+	HipSplitEngine(const KmcSplitParams &p, int dev, int slot) : P(p), dev(dev), slot(slot)
+	{
+		arrays.assign((size_t)5 * p.n_bins, 0);
+		uint64_t h = 1469598103934665603ull ^ p.signature_len; /* FNV-1a over the map's entries, once per engine */
+		const size_t n = ((size_t)1 << (2 * p.signature_len)) + 1;
+		for (size_t i = 0; i < n; ++i)
+			h = (h ^ (uint32_t)p.sig_to_bin[i]) * 1099511628211ull;
+		map_hash = h ? h : 1;
+	}
 	std::string last_error() override { return err; }
 	int split_part(const uint8_t *text, uint64_t size, KmcSplitResult &out) override
 	{
@@ -62,12 +71,12 @@ struct HipSplitEngine : KmcSplitEngine {
 		}
 		{
 			std::lock_guard<std::mutex> lck(g_split.map_mtx);
-			if (!g_split.map_set[dev]) {
+			if (g_split.map_hash[dev] != map_hash) {
 				if (int rc = g_split.set_map(g_split.ctx, dev, P.sig_to_bin, P.signature_len)) {
 					err = g_split.last_error(g_split.ctx);
 					return rc;
 				}
-				g_split.map_set[dev] = 1;
+				g_split.map_hash[dev] = map_hash;
 			}
 		}
 		kmc_hip_split_params hp;

@@ -153,16 +153,23 @@ class CWSplitter {
 			at += len;
 		}
 	}
-	/* the reference's own splitter for this part; its collectors reserve n_bins buffers, so ours go to the storer first */
+	/* the reference's own splitter for this part. Its collectors reserve n_bins pmm_bins buffers (one each, CKmerBinCollector's constructor), and the
+	 * pool is sized for n_splitters x n_bins buffers beyond the storer's share (kmc.h:491-501): a worker must never hold two sets. So ours go to the
+	 * storer first, and the reference splitter is completed (its collectors flushed and their buffers handed over) and dropped as soon as the part is
+	 * through — held until the end of the run, a memory-tight run with mixed parts (nanopore FASTQ) could leave every worker waiting in
+	 * pmm_bins->reserve with nothing left to free. */
 	void to_reference(uchar *part, uint64 size, ReadType read_type)
 	{
 		push_all();
-		if (!ref_splitter) {
-			ref_splitter = std::make_unique<CSplitter>(*params, *queues);
-			ref_splitter->InitBins(*params, *queues);
-		}
+		ref_splitter = std::make_unique<CSplitter>(*params, *queues);
+		ref_splitter->InitBins(*params, *queues);
 		ref_splitter->ProcessReads(part, size, read_type);
 		pmm_fastq->free(part);
+		ref_splitter->Complete();
+		uint64 n = 0;
+		ref_splitter->GetTotal(n);
+		n_reads += n;
+		ref_splitter.reset();
 	}
 	void push_all()
 	{

@@ -21,6 +21,7 @@
 
 struct MockBackend {
 	std::vector<std::unique_ptr<uint8_t[]>> blocks;
+	void *alloc_uninit(size_t bytes) { return alloc(bytes); }
 	void *alloc(size_t bytes)
 	{
 		blocks.emplace_back(new uint8_t[bytes + 64]());
