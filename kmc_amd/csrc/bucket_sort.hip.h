@@ -444,8 +444,8 @@ __global__ void __launch_bounds__(BcCfg<SIZE>::THREADS, (SIZE <= 2 ? BC_MIN_WAVE
 	u32 *s_cnt = reinterpret_cast<u32 *>(s_rec + (size_t)CAP * SIZE); /* [CAP + 1] records per sub-bucket -> [15:0] first slot of its region, [31:16] (step 3) counted k-mers in front of it */
 	u32 *s_tag = s_cnt + CAP + 1;                                     /* [CAP + 1] [15:0] owner position + 1 (0 = free), [31:16] count; before that, the table of bucket starts */
 	u32 *s_lut = s_tag + CAP + 1;                                     /* [BC_LUT_HIST] counted k-mers per LUT prefix, relative to the tile's first */
-	u32 *s_tmp = s_lut + BC_LUT_HIST;                                 /* [NW + 1] */
-	u32 *s_wfirst = s_tmp + NW + 1;                                   /* [NW] bucket starts in wave w's rows */
+	u32 *s_tmp = s_lut + BC_LUT_HIST;                                 /* [2 NW] wave totals of the two scans */
+	u32 *s_wfirst = s_tmp + 2 * NW;                                   /* [NW] bucket starts in wave w's rows */
 	u32 *s_wtal = s_wfirst + NW;                                       /* [NW][3] distinct / below min / above max */
 
 	const u32 gtile = blockIdx.x;
@@ -510,9 +510,7 @@ __global__ void __launch_bounds__(BcCfg<SIZE>::THREADS, (SIZE <= 2 ? BC_MIN_WAVE
 		for (int r = 0; r < ITEMS; ++r) {
 			const u32 idx = crel + r * 64 + lane;
 			const u32 bk = bucket_of(key[r]);
-			u32 pv = __shfl_up(bk, 1);
-			if (lane == 0)
-				pv = prev_last;
+			const u32 pv = wave_shift_up1(bk, prev_last, lane);
 			const bool head = idx < avail && (idx == 0 || pv != bk);
 			const u64 m = __ballot(head);
 			headbits |= head ? 1u << r : 0u;
@@ -526,7 +524,7 @@ __global__ void __launch_bounds__(BcCfg<SIZE>::THREADS, (SIZE <= 2 ? BC_MIN_WAVE
 		u32 wave_heads_before, total_heads;
 		{
 			const u32 v = lane < (u32)NW ? s_wfirst[lane] : 0u;
-			const u32 inc = wave_incl_sum<u32>(v, lane);
+			const u32 inc = wave_incl_sum_u32(v, lane);
 			total_heads = __shfl(inc, NW - 1);
 			wave_heads_before = __shfl(inc - v, (int)wave);
 		}
@@ -575,7 +573,7 @@ __global__ void __launch_bounds__(BcCfg<SIZE>::THREADS, (SIZE <= 2 ? BC_MIN_WAVE
 				s_tag[q * THREADS + tid] = 0; /* the table of bucket starts has been read: the tag array starts empty */
 			}
 			u32 total;
-			u32 run = block_excl_sum<NW, u32>(sum, s_tmp, total);
+			u32 run = block_excl_sum_1b<NW>(sum, s_tmp, total);
 #pragma unroll
 			for (int q = 0; q < ITEMS; ++q) {
 				s_cnt[tid * ITEMS + q] = run;
@@ -659,7 +657,7 @@ __global__ void __launch_bounds__(BcCfg<SIZE>::THREADS, (SIZE <= 2 ? BC_MIN_WAVE
 				w[q] = s_cnt[tid * ITEMS + q];
 				sum += w[q] >> 16;
 			}
-			u32 run = block_excl_sum<NW, u32>(sum, s_tmp, chunk_counted);
+			u32 run = block_excl_sum_1b<NW>(sum, s_tmp + NW, chunk_counted);
 #pragma unroll
 			for (int q = 0; q < ITEMS; ++q) {
 				s_cnt[tid * ITEMS + q] = (w[q] & 0xFFFFu) | (run << 16);

@@ -212,6 +212,49 @@ template <typename T> __device__ __forceinline__ T wave_sum(T v)
 	return v; /* lane 0 holds the sum */
 }
 
+/* inclusive wave scan of 32-bit values on the VALU's data-parallel primitives: four row shifts inside the rows of 16 lanes, then the last lane of row 0
+ * (and of row 2) broadcast into row 1 (3), then lane 31 into rows 2-3 — six v_add with DPP operands instead of six ds_bpermute round trips through the LDS
+ * pipeline (what __shfl_up compiles to). gfx9-family controls (row_bcast exists up to gfx950). The CPU emulation of tests/hipemu keeps the shuffles. */
+__device__ __forceinline__ u32 wave_incl_sum_u32(u32 v, u32 lane)
+{
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(KMC_HIPEMU)
+	(void)lane;
+	v += (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x111 /* row_shr:1 */, 0xf, 0xf, false);
+	v += (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x112 /* row_shr:2 */, 0xf, 0xf, false);
+	v += (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x114 /* row_shr:4 */, 0xf, 0xf, false);
+	v += (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x118 /* row_shr:8 */, 0xf, 0xf, false);
+	v += (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x142 /* row_bcast:15 */, 0xa, 0xf, false);
+	v += (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x143 /* row_bcast:31 */, 0xc, 0xf, false);
+	return v;
+#else
+	return wave_incl_sum<u32>(v, lane);
+#endif
+}
+/* lane i receives lane i-1's value, lane 0 receives `first` (one v_mov with a DPP wave shift instead of a ds_bpermute + select) */
+__device__ __forceinline__ u32 wave_shift_up1(u32 v, u32 first, u32 lane)
+{
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(KMC_HIPEMU)
+	(void)lane;
+	return (u32)__builtin_amdgcn_update_dpp((int)first, (int)v, 0x138 /* wave_shr:1 */, 0xf, 0xf, false);
+#else
+	const u32 t = __shfl_up(v, 1);
+	return lane == 0 ? first : t;
+#endif
+}
+/* Block-wide exclusive sum of one 32-bit value per thread with ONE barrier: every wave scans the NW wave totals itself (block_excl_sum below lets wave 0
+ * do it and needs two more barriers). `tmp` has NW entries and must not be written again before the caller's next barrier. */
+template <int NW> __device__ __forceinline__ u32 block_excl_sum_1b(u32 v, u32 *tmp, u32 &total)
+{
+	const u32 lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+	const u32 inc = wave_incl_sum_u32(v, lane);
+	if (lane == 63)
+		tmp[wave] = inc;
+	__syncthreads();
+	const u32 w = lane < (u32)NW ? tmp[lane] : 0u;
+	const u32 winc = wave_incl_sum_u32(w, lane);
+	total = __shfl(winc, NW - 1);
+	return __shfl(winc - w, (int)wave) + inc - v;
+}
 /* Block-wide exclusive scans over one value per thread (NW waves). `tmp` has NW+1 entries of T in LDS.
  * All threads must call; returns the exclusive prefix, `total` = sum/max over the block. */
 template <int NW, typename T> __device__ __forceinline__ T block_excl_sum(T v, T *tmp, T &total)
