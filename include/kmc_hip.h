@@ -159,6 +159,18 @@ typedef struct kmc_hip_bin_desc {
 int kmc_hip_process_bins_device(kmc_hip_ctx *ctx, int dev, const kmc_hip_bin_params *params, const kmc_hip_bin_desc *bins,
                                 uint64_t n_bins, int n_streams);
 
+/* ---- a globally ordered database ---------------------------------------------
+ * The bins of a run — as kmc_hip_process_bin[s]_device left them: per bin `d_out` (suffix records, ascending inside the bin), `d_out_bytes`, `d_lut`
+ * (records per lut_prefix_len-symbol prefix) — merged into ONE ascending sequence of all counted k-mers: records of (kmer_len - out_lut_prefix_len) / 4
+ * suffix bytes (most significant first) + counter bytes (least significant first) into d_out, and into d_lut_out[4^out_lut_prefix_len] the number of
+ * records with a prefix BELOW each entry — the body of the database `kmc_tools transform <db> sort <out>` writes (kmc_tools/kmc1_db_writer.h:368-395;
+ * the header and the 'KMCP'/'KMCS' markers around it are the caller's, :309-370). Every k-mer is in exactly one bin (bins partition by signature), so
+ * this is a sort, not a merge of counts: records unpacked to (k-mer, count), ordered by the library's LSD passes, packed again. Synchronous; *n_kmers =
+ * records written. params: the parameters the bins were made with (KMC output, lut_prefix_len > 0); kmer_len <= 224.
+ * Replaces: kmc_tools' sort operation on the CPU (CKMC1DbWriter fed by a priority queue over the bins). */
+int kmc_hip_order_database_device(kmc_hip_ctx *ctx, int dev, const kmc_hip_bin_params *params, const kmc_hip_bin_desc *bins, uint64_t n_bins,
+                                  uint32_t out_lut_prefix_len, uint8_t *d_out, uint64_t out_capacity, uint64_t *d_lut_out, uint64_t *n_kmers);
+
 /* ---- end-of-run tallies ---------------------------------------------------------------------- */
 
 /* Sum stats[4] over the context's devices with one RCCL all-reduce (ncclUint64 x 4, ncclSum) over xGMI.

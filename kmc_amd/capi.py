@@ -67,7 +67,7 @@ SYMBOLS = [
     "kmc_hip_words", "kmc_hip_counter_size", "kmc_hip_out_rec_bytes", "kmc_hip_lut_entries",
     "kmc_hip_sort_records", "kmc_hip_sort_records_into", "kmc_hip_sort_records_device",
     "kmc_hip_process_bin", "kmc_hip_process_bin_submit", "kmc_hip_process_bin_wait", "kmc_hip_process_bin_device",
-    "kmc_hip_process_bins_device",
+    "kmc_hip_process_bins_device", "kmc_hip_order_database_device",
     "kmc_hip_allreduce_stats", "kmc_hip_last_timings", "kmc_hip_scatter_totals", "kmc_hip_local_sort_totals", "kmc_hip_set_hybrid",
     "kmc_hip_malloc", "kmc_hip_free", "kmc_hip_memcpy_h2d", "kmc_hip_memcpy_d2h",
     "kmc_hip_host_register", "kmc_hip_host_unregister", "kmc_hip_host_alloc", "kmc_hip_host_free", "kmc_hip_synchronize",
@@ -131,6 +131,7 @@ def load():
     L.kmc_hip_scatter_totals.argtypes = [vp, C.c_int, C.c_int, u64p, C.POINTER(C.c_double), u64p]
     L.kmc_hip_local_sort_totals.argtypes = [vp, C.c_int, C.c_int, u64p, C.POINTER(C.c_double), u64p, u64p, u64p]
     L.kmc_hip_process_bins_device.argtypes = [vp, C.c_int, C.POINTER(BinParams), C.POINTER(BinDesc), C.c_uint64, C.c_int]
+    L.kmc_hip_order_database_device.argtypes = [vp, C.c_int, C.POINTER(BinParams), C.POINTER(BinDesc), C.c_uint64, C.c_uint32, vp, C.c_uint64, vp, u64p]
     L.kmc_hip_host_alloc.argtypes = [vp, C.c_uint64, C.POINTER(vp)]
     L.kmc_hip_host_free.argtypes = [vp, vp]
     L.kmc_hip_malloc.argtypes = [vp, C.c_int, C.c_uint64, C.POINTER(vp)]
@@ -332,6 +333,12 @@ class Context:
     def process_bins_device(self, p: BinParams, descs, n_streams: int = 0, dev: int = 0):
         """Enqueue many device-resident bins (ctypes array of BinDesc); returns after enqueueing — call synchronize()."""
         self._chk(self.L.kmc_hip_process_bins_device(self.h, dev, C.byref(p), descs, len(descs), n_streams))
+
+    def order_database_device(self, p: BinParams, descs, out_lut_prefix_len: int, d_out: int, out_capacity: int, d_lut_out: int, dev: int = 0) -> int:
+        """All counted k-mers of the bins (device-resident outputs of process_bins_device) as ONE ascending sequence; returns the number of records."""
+        n = C.c_uint64()
+        self._chk(self.L.kmc_hip_order_database_device(self.h, dev, C.byref(p), descs, len(descs), out_lut_prefix_len, d_out, out_capacity, d_lut_out, C.byref(n)))
+        return n.value
 
     def host_alloc(self, nbytes: int) -> np.ndarray:
         """Pinned host memory as a uint8 array (free with host_free(arr))."""

@@ -26,6 +26,7 @@
 #include "../../include/kmc_hip.h"
 #include "kernels.hip.h"
 #include "bucket_sort.hip.h"
+#include "order_db.hip.h"
 #include "stage1_kernels.hip.h"
 
 namespace {
@@ -1130,6 +1131,42 @@ int debug_compact_t(Slot &s, const DevParams &P, u64 n, u64 out_capacity, u64 lu
 	bins[0].d_out_bytes = small_ptr<u64>(s, SM_OUTBYTES);
 	u32 counter_idx = 0;
 	return compact_group<SIZE>(s, bins, (const u64 *)s.recA.p, nullptr, P, lut_entries, counter_idx);
+}
+} // namespace
+
+/* ---- a globally ordered database on the device ---- */
+namespace {
+template <int SIZE>
+int order_database_t(Slot &s, const DevParams &P, const kmc_hip_bin_desc *bins, const std::vector<u64> &n_of, u64 n_total, u32 p_out, uint8_t *d_out, u64 *d_lut_out)
+{
+	constexpr int W = SIZE + 1;
+	const u32 rb_in = P.sbytes + P.cbytes;
+	const u64 n_entries = 1ull << (2 * P.lut_prefix_len);
+	int rc = 0;
+	if ((rc = ensure(s.recA, n_total * W * 8 + 256)) || (rc = ensure(s.recB, n_total * W * 8 + 256)) || (rc = ensure(s.bounds, (n_entries + 2) * 8)))
+		return rc;
+	u64 *recs = (u64 *)s.recA.p, *sums = (u64 *)s.bounds.p;
+	u64 off = 0;
+	for (size_t b = 0; b < n_of.size(); ++b) {
+		if (!n_of[b])
+			continue;
+		k_db_cumsum<<<dim3(1), dim3(256), 0, s.stream>>>((const u64 *)bins[b].d_lut, n_entries, sums);
+		k_db_unpack<SIZE><<<dim3((u32)((n_of[b] + 255) / 256)), dim3(256), 0, s.stream>>>(bins[b].d_out, n_of[b], sums, (u32)n_entries, P.k, P.lut_prefix_len, P.sbytes, P.cbytes,
+		                                                                             recs + off * W);
+		off += n_of[b];
+	}
+	HIPCHK(hipGetLastError());
+	(void)rb_in;
+	u64 *sorted = recs;
+	const u32 key_bytes = (2 * P.k + 7) / 8;
+	if (n_total >= 2)
+		if ((rc = sort_device(s, recs, (u64 *)s.recB.p, n_total, W, key_bytes, &sorted, true /* the count rides above the key: stable LSD passes */)))
+			return rc;
+	HIPCHK(hipMemsetAsync(d_lut_out, 0, (1ull << (2 * p_out)) * 8, s.stream));
+	if (n_total)
+		k_db_pack<SIZE><<<dim3((u32)((n_total + 255) / 256)), dim3(256), 0, s.stream>>>(sorted, n_total, P.k, p_out, P.cbytes, d_out, d_lut_out);
+	HIPCHK(hipGetLastError());
+	return 0;
 }
 } // namespace
 
@@ -2297,6 +2334,61 @@ int kmc_hip_scatter_totals(kmc_hip_ctx *ctx, int dev, int reset, uint64_t *n_lau
 	if (total_records)
 		*total_records = keys;
 	return 0;
+}
+
+int kmc_hip_order_database_device(kmc_hip_ctx *ctx, int dev, const kmc_hip_bin_params *params, const kmc_hip_bin_desc *bins, uint64_t n_bins, uint32_t out_lut_prefix_len,
+                                  uint8_t *d_out, uint64_t out_capacity, uint64_t *d_lut_out, uint64_t *n_kmers)
+{
+	if (int rc = set_dev(ctx, dev))
+		return rc;
+	DevParams P;
+	if (int rc = check_params(params, P))
+		return rc;
+	if ((n_bins && !bins) || !d_out || !d_lut_out || !n_kmers)
+		return fail(KMC_HIP_EINVAL, "kmc_hip_order_database_device: NULL argument");
+	if (P.kff || !P.lut_prefix_len || P.without_output)
+		return fail(KMC_HIP_EINVAL, "kmc_hip_order_database_device: needs KMC-format bins (lut_prefix_len > 0, with output)");
+	if (out_lut_prefix_len < 1 || out_lut_prefix_len > 15 || out_lut_prefix_len >= P.k || (P.k - out_lut_prefix_len) % 4)
+		return fail(KMC_HIP_EINVAL, "kmc_hip_order_database_device: (kmer_len - out_lut_prefix_len) must be a positive multiple of 4, out_lut_prefix_len 1..15");
+	const u32 words = (P.k + 31) / 32;
+	if (words + 1 > 8)
+		return fail(KMC_HIP_EINVAL, "kmc_hip_order_database_device: kmer_len <= 224");
+	Slot &s = ctx->devs[dev]->slot[0];
+	std::lock_guard<std::mutex> lck(s.mtx);
+	const u32 rb_in = P.sbytes + P.cbytes, rb_out = (P.k - out_lut_prefix_len) / 4 + P.cbytes;
+	std::vector<u64> n_of((size_t)n_bins, 0);
+	u64 n_total = 0;
+	for (uint64_t b = 0; b < n_bins; ++b) {
+		u64 ob = 0;
+		HIPCHK(hipMemcpy(&ob, bins[b].d_out_bytes, 8, hipMemcpyDeviceToHost));
+		if (ob % rb_in)
+			return fail(KMC_HIP_ECORRUPT, "kmc_hip_order_database_device: a bin's out_bytes is not a whole number of records");
+		n_of[b] = ob / rb_in;
+		n_total += n_of[b];
+	}
+	*n_kmers = n_total;
+	if (n_total * rb_out > out_capacity)
+		return fail(KMC_HIP_ECAPACITY, "kmc_hip_order_database_device: out_capacity too small");
+	s.timed = false;
+	int rc = KMC_HIP_EINVAL;
+	switch (words) {
+	case 1: rc = order_database_t<1>(s, P, bins, n_of, n_total, out_lut_prefix_len, d_out, (u64 *)d_lut_out); break;
+	case 2: rc = order_database_t<2>(s, P, bins, n_of, n_total, out_lut_prefix_len, d_out, (u64 *)d_lut_out); break;
+	case 3: rc = order_database_t<3>(s, P, bins, n_of, n_total, out_lut_prefix_len, d_out, (u64 *)d_lut_out); break;
+	case 4: rc = order_database_t<4>(s, P, bins, n_of, n_total, out_lut_prefix_len, d_out, (u64 *)d_lut_out); break;
+	case 5: rc = order_database_t<5>(s, P, bins, n_of, n_total, out_lut_prefix_len, d_out, (u64 *)d_lut_out); break;
+	case 6: rc = order_database_t<6>(s, P, bins, n_of, n_total, out_lut_prefix_len, d_out, (u64 *)d_lut_out); break;
+	case 7: rc = order_database_t<7>(s, P, bins, n_of, n_total, out_lut_prefix_len, d_out, (u64 *)d_lut_out); break;
+	}
+	if (rc)
+		return rc;
+	HIPCHK(hipStreamSynchronize(s.stream));
+	if (int rc2 = harvest(s))
+		return rc2;
+	u32 err = 0;
+	if (int rc2 = read_and_clear_sticky(s, err))
+		return rc2;
+	return err_to_code(err);
 }
 
 int kmc_hip_set_hybrid(int mode)

@@ -86,7 +86,7 @@ def build_hostlib(geometry="small", force=False) -> str:
     then run on a box without a GPU (small inputs: one OS thread per GPU thread)."""
     so = os.path.join(EMU_DIR, f"libkmc_hip_emu_{geometry}.so")
     csrc = os.path.join(ROOT, "kmc_amd", "csrc")
-    srcs = [os.path.join(csrc, f) for f in ("kmc_hip.hip", "kernels.hip.h", "bucket_sort.hip.h", "kmer_ops.h", "stage1_kernels.hip.h", "stage1_chain.h")] + [
+    srcs = [os.path.join(csrc, f) for f in ("kmc_hip.hip", "kernels.hip.h", "bucket_sort.hip.h", "order_db.hip.h", "kmer_ops.h", "stage1_kernels.hip.h", "stage1_chain.h")] + [
         os.path.join(ROOT, "include", "kmc_hip.h"), os.path.join(EMU_DIR, "include", "hip", "hip_runtime.h"), os.path.join(EMU_DIR, "include", "hip", "hip_host_api.h"),
         os.path.join(EMU_DIR, "include", "rccl", "rccl.h"), os.path.abspath(__file__)]
     if force or not os.path.exists(so) or any(os.path.getmtime(x) > os.path.getmtime(so) for x in srcs):

@@ -673,3 +673,87 @@ def test_hybrid_sort_only_calls_match_the_oracle(hybrid_everywhere):
         assert np.array_equal(got, O.sort(recs))
     a = np.where(rng.random(200_000) < 0.5, np.uint64(5), np.uint64(0x0011223344556677))
     assert np.array_equal(ctx.sort_records(a.reshape(-1, 1), 7)[:, 0], np.sort(a))
+
+
+# ------------------------------------------------------------------------------------------------ globally ordered database
+def read_kmc2_database(db):
+    """(k, p, counter bytes, per-bin list of (records bytes, LUT counts)) of a KMC database as kmc writes it (kb_completer.cpp:287-320): 'KMCP',
+    per emitted bin uint64[4^p] running record offsets, uint64 total, uint32 signature map, 72-byte header, 'KMCP'."""
+    pre = np.fromfile(db + ".kmc_pre", dtype=np.uint8)
+    suf = np.fromfile(db + ".kmc_suf", dtype=np.uint8)[4:-4]
+    hdr = pre[-76:-4]
+    k, mode, cs, p, sig_len = (int(x) for x in hdr[:20].view(np.uint32))
+    lut_area = pre[4: pre.size - 4 - 72 - ((1 << (2 * sig_len)) + 1) * 4].view(np.uint64)
+    n_entries = 1 << (2 * p)
+    n_bins = (lut_area.size - 1) // n_entries
+    offs = np.concatenate([lut_area[: n_bins * n_entries], lut_area[-1:]])
+    rb = (k - p) // 4 + cs
+    bins = []
+    for b in range(n_bins):
+        o = offs[b * n_entries: (b + 1) * n_entries + 1].astype(np.int64)
+        bins.append((suf[o[0] * rb: o[-1] * rb].copy(), np.diff(o).astype(np.uint64)))
+    return k, p, cs, bins
+
+
+def read_kmc1_database(db):
+    """(lut_prefix_len, LUT uint64[4^p], record bytes) of a database as kmc_tools writes it (kmc1_db_writer.h:309-370)"""
+    pre = np.fromfile(db + ".kmc_pre", dtype=np.uint8)
+    suf = np.fromfile(db + ".kmc_suf", dtype=np.uint8)[4:-4]
+    hdr = pre[-72:-8]
+    p = int(hdr[12:16].view(np.uint32)[0])
+    lut = pre[4: 4 + (8 << (2 * p))].view(np.uint64)
+    return p, lut.copy(), suf.copy()
+
+
+def order_database_on_device(ctx, hparams, bins, p_out):
+    """bins: [(record bytes, LUT counts)] -> (records bytes, LUT) of kmc_hip_order_database_device"""
+    rb = ctx.out_rec_bytes(hparams)
+    n = len(bins)
+    descs = (capi.BinDesc * n)()
+    allocs = []
+    total = 0
+    for i, (recs, lut) in enumerate(bins):
+        d_out, d_lut, d_small = ctx.malloc(recs.size + 256), ctx.malloc(lut.nbytes), ctx.malloc(64)
+        if recs.size:
+            ctx.h2d(d_out, recs)
+        ctx.h2d(d_lut, lut)
+        ctx.h2d(d_small, np.array([0, 0, 0, 0, recs.size, 0, 0, 0], dtype=np.uint64))
+        allocs += [d_out, d_lut, d_small]
+        descs[i] = capi.BinDesc(0, 0, 0, 0, 0, d_out, recs.size, d_small + 32, d_lut, d_small)
+        total += recs.size // rb
+    rb_out = (hparams.kmer_len - p_out) // 4 + (rb - (hparams.kmer_len - hparams.lut_prefix_len) // 4)
+    d_res, d_lut_out = ctx.malloc(total * rb_out + 256), ctx.malloc(8 << (2 * p_out))
+    got_n = ctx.order_database_device(hparams, descs, p_out, d_res, total * rb_out, d_lut_out)
+    out = np.zeros(got_n * rb_out, dtype=np.uint8)
+    lut = np.zeros(1 << (2 * p_out), dtype=np.uint64)
+    if out.size:
+        ctx.d2h(out, d_res)
+    ctx.d2h(lut, d_lut_out)
+    for a in allocs + [d_res, d_lut_out]:
+        ctx.free(a)
+    return out, lut, got_n
+
+
+@pytest.mark.parametrize("flags", [["-k27"], ["-k55", "-ci1", "-cs1000"], ["-k21", "-b"]], ids=lambda f: "".join(f))
+def test_order_database_matches_kmc_tools_transform_sort(ctx, flags, ref_bins, tmp_path):
+    """kmc's database (ordered inside every signature bin) -> one ascending sequence on the device == what the reference's `kmc_tools transform db sort out`
+    writes, records and LUT byte for byte."""
+    if ref_bins is None:
+        pytest.skip("oracle/_ref not shipped")
+    fq = str(tmp_path / "in.fq")
+    from kmc_amd import synth
+
+    small = capi.load().kmc_hip_backend_kind() != 0  # the emulated host library of the CPU suite: one OS thread per GPU thread
+    synth.make_fastq(fq, seed=13, genome_len=60_000 if small else 300_000, n_reads=8_000 if small else 40_000, read_len=150)
+    (tmp_path / "t").mkdir()
+    db, sdb = str(tmp_path / "db"), str(tmp_path / "sorted")
+    subprocess.run([ref_bins["kmc"], *flags, "-sr1", fq, db, str(tmp_path / "t")], check=True, capture_output=True)
+    subprocess.run([ref_bins["kmc_tools"], "transform", db, "sort", sdb], check=True, capture_output=True)
+    k, p, cs, bins = read_kmc2_database(db)
+    p_out, want_lut, want_recs = read_kmc1_database(sdb)
+    hparams = hp(k, lut_prefix_len=p, both_strands=0 if "-b" in flags else 1, cutoff_min=1 if "-ci1" in flags else 2, counter_max=1000 if "-cs1000" in flags else 255)
+    assert ctx.out_rec_bytes(hparams) == (k - p) // 4 + cs
+    out, lut, n = order_database_on_device(ctx, hparams, bins, p_out)
+    assert n == sum(b[0].size for b in bins) // ((k - p) // 4 + cs) and n > 500
+    assert np.array_equal(lut, want_lut), _first_diff(lut, want_lut)
+    assert np.array_equal(out, want_recs), _first_diff(out, want_recs)

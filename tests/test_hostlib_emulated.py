@@ -24,7 +24,7 @@ def _exe(name):
     """oracle/_ref/<name> for the reference and the oracle builds (checkers), kmc_amd/bin/<name> for the product drop-in binaries"""
     return os.path.join(ROOT, "kmc_amd", "bin", name) if name.startswith("kmc_hip") else os.path.join(REF, name)
 
-QUICK = ("process_bin_edges or size_and_n_rec or sort_records_into or allreduce_stats_single or submit_wait or (test_stage1_kernels_match_the_oracle and 27-9) "
+QUICK = ("(order_database and k27) or process_bin_edges or size_and_n_rec or sort_records_into or allreduce_stats_single or submit_wait or (test_stage1_kernels_match_the_oracle and 27-9) "
          "or (compact_stage_matches_oracle and 27-3) or (expand_stage_matches_oracle and 1-27) or (test_process_bin_matches_oracle and k27-cutoff)")
 
 

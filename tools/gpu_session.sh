@@ -28,7 +28,7 @@ t=time.time(); s=capi.synth_bins(seed=2026, genome_len=1000000000, n_reads=20000
     var:*)   v=${step#var:}; KMC_HIP_LIB=kmc_amd/variants/libkmc_hip_$v.so timeout 600 python bench.py $one_bin > $OUT/onebin_$v.json 2> $OUT/onebin_$v.err ;;
     var512:*) v=${step#var512:}; KMC_HIP_LIB=kmc_amd/variants/libkmc_hip_$v.so timeout 600 python bench.py $bins512 > $OUT/bins512_$v.json 2> $OUT/bins512_$v.err ;;
     profk:*) a=${step#profk:}; k=${a%%:*}; e=${a#*:}; cd /tmp; env $e timeout 900 rocprofv3 --kernel-trace --stats -f csv -d $OLDPWD/$OUT/profk_${k}_$e -o kt -- python $OLDPWD/bench.py --k $k --leg quarter --reads 50000000 --genome 250000000 --bins 128 --steps 3 --warmup 1 --no-digest > $OLDPWD/$OUT/profk_${k}_$e.json 2> $OLDPWD/$OUT/profk_${k}_$e.err; cd $OLDPWD; find $OUT/profk_${k}_$e -name "*kernel_trace.csv" -delete; find $OUT/profk_${k}_$e -name "*kernel_stats.csv" | head -1 | xargs -r head -12 | cut -c1-140 ;;
-    pmck:*)  a=${step#pmck:}; k=${a%%:*}; b=${a#*:}; c=${b%%:*}; e=${b#*:}; cd /tmp; env $e timeout 900 rocprofv3 --pmc $c -f csv -d $OLDPWD/$OUT/pmck_${k}_${c}_$e -o pmc -- python $OLDPWD/bench.py --k $k --leg quarter --reads 50000000 --genome 250000000 --bins 128 --steps 1 --warmup 0 --no-digest > $OLDPWD/$OUT/pmck_${k}_${c}_$e.json 2> $OLDPWD/$OUT/pmck_${k}_${c}_$e.err; cd $OLDPWD; python tools/pmc_table.py $OUT/pmck_${k}_${c}_$e/pmc_counter_collection.csv > $OUT/pmck_${k}_${c}_$e.txt 2>&1; rm -rf $OUT/pmck_${k}_${c}_$e; cat $OUT/pmck_${k}_${c}_$e.txt ;;
+    pmck:*)  a=${step#pmck:}; k=${a%%:*}; b=${a#*:}; c=${b%%:*}; e=${b#*:}; cd /tmp; env $e timeout 900 rocprofv3 --pmc ${c//,/ } -f csv -d $OLDPWD/$OUT/pmck_${k}_${c}_$e -o pmc -- python $OLDPWD/bench.py --k $k --leg quarter --reads 50000000 --genome 250000000 --bins 128 --steps 1 --warmup 0 --no-digest > $OLDPWD/$OUT/pmck_${k}_${c}_$e.json 2> $OLDPWD/$OUT/pmck_${k}_${c}_$e.err; cd $OLDPWD; python tools/pmc_table.py $OUT/pmck_${k}_${c}_$e/pmc_counter_collection.csv > $OUT/pmck_${k}_${c}_$e.txt 2>&1; rm -rf $OUT/pmck_${k}_${c}_$e; cat $OUT/pmck_${k}_${c}_$e.txt ;;
     qs:*)    a=${step#qs:}; n=${a%%:*}; e=${a#*:}; env $e timeout 600 python bench.py --cache /dev/shm/kmccache --leg quarter --reads 50000000 --genome 250000000 --bins 128 --steps 3 --warmup 1 --streams $n > $OUT/qs_${n}_$e.json 2> $OUT/qs_${n}_$e.err; python tools/pj.py $OUT/qs_${n}_$e.json 2>&1 | cut -c1-120 ;;
     kq:*)    a=${step#kq:}; k=${a%%:*}; e=${a#*:}; env $e timeout 900 python bench.py --k $k --leg quarter --reads 50000000 --genome 250000000 --bins 128 --steps 3 --warmup 1 --no-digest > $OUT/kq_${k}_$e.json 2> $OUT/kq_${k}_$e.err; python tools/pj.py $OUT/kq_${k}_$e.json 2>&1 | cut -c1-700 ;;
     k:*)     k=${step#k:}; timeout 900 python bench.py --k $k --no-cpu-baseline --no-secondary --no-host-boundary --steps 3 > $OUT/bench_k$k.json 2> $OUT/bench_k$k.err ;;
