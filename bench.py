@@ -60,6 +60,8 @@ CONFIGS = {
                        desc="configs[1]: k=%d, 150 bp synthetic reads, ~2 Gbp, all k-mers as a single bin"),
     "2gbp-512bins": dict(reads=13_300_000, genome=66_000_000, bins=512,
                          desc="2 Gbp sample of the configs[2] read model (13.3 M reads of a 66 Mbp genome, 30x), k=%d, 512 signature bins"),
+    "quarter": dict(reads=50_000_000, genome=250_000_000, bins=128,
+                    desc="a quarter of configs[2]/[4] (50 M reads of a 250 Mbp genome, 30x: 128 signature bins of the same size as the full run's), k=%d"),
 }
 SEED = 2026
 
@@ -563,7 +565,7 @@ def main():
             dg = sum(parts) & ((1 << 64) - 1)
         digest = "%016x" % dg
     oracle_bins = None
-    if rank == 0 and not args.no_oracle_check and not args.leg:
+    if rank == 0 and not args.no_oracle_check and (not args.leg or args.leg == "quarter"):
         try:
             oracle_bins = oracle_check(ctx, w, res)
         except Exception as e:  # noqa: BLE001 — the checker must not take the measurement down with it
@@ -666,6 +668,10 @@ def main():
             s2 = secondary_leg("2gbp-512bins", k, [])
             sec["bins512_2gbp"] = {kk: s2.get(kk) for kk in ("value", "ms_per_step", "config", "roofline", "tallies", "stage2_frac_of_hbm_peak", "error") if kk in s2}
             sec["stage1_groundwork"] = stage1_leg(k)
+            if k == 27:  # configs[4]'s record widths on a quarter of the reads: the hybrid sort; full size: bench.py --k 55 / --k 127
+                for kk in (55, 127):
+                    sk = secondary_leg("quarter", kk, ["--no-digest"])
+                    sec["k%d_quarter" % kk] = {x: sk.get(x) for x in ("value", "ms_per_step", "config", "roofline", "sort_path", "local_sort", "tallies", "self_check", "error") if x in sk}
             out["secondary"] = sec
         if not args.no_cpu_baseline:
             try:
