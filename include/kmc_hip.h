@@ -116,6 +116,17 @@ int kmc_hip_process_bin(kmc_hip_ctx *ctx, int dev, const kmc_hip_bin_params *par
                         uint8_t *out_suffix, uint64_t out_capacity, uint64_t *out_bytes, uint64_t *lut,
                         uint64_t stats[4]);
 
+/* The same bin over ALL devices of the context: the oversized-bin path.
+ * Replaces: strict-memory mode's treatment of a bin that does not fit — the reference cuts it into sub-bins by the k-mers' leading symbols, sorts
+ * them one after the other through the same sort_func and merges (kmc.h:1607-1692, bkb_sorter.h:187, bkb_subbin.h / bkb_merger.h). Here the cut goes
+ * across GPUs: every device expands a share of the expander packs, the records are exchanged by the TOP byte of the key (one all-to-all: RCCL
+ * ncclSend/ncclRecv over xGMI between distinct GPUs, peer copies when the context names one GPU more than once), every device sorts and compacts the
+ * k-mers of its key range, and the ranges are emitted in order. Arguments, outputs and errors as kmc_hip_process_bin; the result is byte-identical to
+ * that call's. Synchronous; takes the first stream slot of every device. */
+int kmc_hip_process_bin_multi(kmc_hip_ctx *ctx, const kmc_hip_bin_params *params, const uint8_t *superkmers, uint64_t size, uint64_t n_rec,
+                              const uint64_t *pack_bytes, uint64_t n_packs, uint8_t *out_suffix, uint64_t out_capacity, uint64_t *out_bytes,
+                              uint64_t *lut, uint64_t stats[4]);
+
 /* Asynchronous pair for double buffering: _submit enqueues H2D + kernels + D2H on the device's stream slot
  * `slot` (0 .. kmc_hip_num_slots()-1) and returns; _wait blocks until that slot's bin is complete and fills out_bytes/stats.
  * Host buffers must stay valid (and out must not alias in) until _wait returns. */

@@ -66,7 +66,7 @@ SYMBOLS = [
     "kmc_hip_device_count",
     "kmc_hip_words", "kmc_hip_counter_size", "kmc_hip_out_rec_bytes", "kmc_hip_lut_entries",
     "kmc_hip_sort_records", "kmc_hip_sort_records_into", "kmc_hip_sort_records_device",
-    "kmc_hip_process_bin", "kmc_hip_process_bin_submit", "kmc_hip_process_bin_wait", "kmc_hip_process_bin_device",
+    "kmc_hip_process_bin", "kmc_hip_process_bin_multi", "kmc_hip_process_bin_submit", "kmc_hip_process_bin_wait", "kmc_hip_process_bin_device",
     "kmc_hip_process_bins_device", "kmc_hip_order_database_device",
     "kmc_hip_allreduce_stats", "kmc_hip_last_timings", "kmc_hip_scatter_totals", "kmc_hip_local_sort_totals", "kmc_hip_set_hybrid",
     "kmc_hip_malloc", "kmc_hip_free", "kmc_hip_memcpy_h2d", "kmc_hip_memcpy_d2h",
@@ -121,6 +121,7 @@ def load():
     L.kmc_hip_sort_records_device.argtypes = [vp, C.c_int, vp, vp, C.c_uint64, C.c_uint32, C.c_uint32, C.POINTER(vp)]
     L.kmc_hip_process_bin.argtypes = [vp, C.c_int, C.POINTER(BinParams), vp, C.c_uint64, C.c_uint64, vp, C.c_uint64, vp, C.c_uint64,
                                       u64p, vp, u64p]
+    L.kmc_hip_process_bin_multi.argtypes = [vp, C.POINTER(BinParams), vp, C.c_uint64, C.c_uint64, vp, C.c_uint64, vp, C.c_uint64, u64p, vp, u64p]
     L.kmc_hip_process_bin_submit.argtypes = [vp, C.c_int, C.c_int, C.POINTER(BinParams), vp, C.c_uint64, C.c_uint64, vp, C.c_uint64,
                                              vp, C.c_uint64, vp]
     L.kmc_hip_process_bin_wait.argtypes = [vp, C.c_int, C.c_int, u64p, u64p]
@@ -196,8 +197,9 @@ class Context:
         return r
 
     # ---- full boundary
-    def process_bin(self, p: BinParams, image: np.ndarray, n_rec: int, pack_bytes=None, out_capacity=None, dev: int = 0):
-        """One bin through kmc_hip_process_bin. Returns (suffix_bytes ndarray, lut ndarray, stats ndarray[4])."""
+    def process_bin(self, p: BinParams, image: np.ndarray, n_rec: int, pack_bytes=None, out_capacity=None, dev: int = 0, multi: bool = False):
+        """One bin through kmc_hip_process_bin — or, multi=True, through kmc_hip_process_bin_multi: the same bin over every device of the context.
+        Returns (suffix_bytes ndarray, lut ndarray, stats ndarray[4])."""
         image = np.ascontiguousarray(image, dtype=np.uint8)
         rec = self.out_rec_bytes(p)
         if out_capacity is None:
@@ -213,8 +215,12 @@ class Context:
             pack_bytes = np.ascontiguousarray(pack_bytes, dtype=np.uint64)
             pb, npk = _vp(pack_bytes), pack_bytes.size
         src = image if image.size else np.zeros(1, dtype=np.uint8)
-        self._chk(self.L.kmc_hip_process_bin(self.h, dev, C.byref(p), _vp(src), image.size, n_rec, pb, npk, _vp(out), out_capacity,
-                                             C.byref(ob), _vp(lut), stats.ctypes.data_as(u64p)))
+        if multi:
+            self._chk(self.L.kmc_hip_process_bin_multi(self.h, C.byref(p), _vp(src), image.size, n_rec, pb, npk, _vp(out), out_capacity, C.byref(ob), _vp(lut),
+                                                       stats.ctypes.data_as(u64p)))
+        else:
+            self._chk(self.L.kmc_hip_process_bin(self.h, dev, C.byref(p), _vp(src), image.size, n_rec, pb, npk, _vp(out), out_capacity,
+                                                 C.byref(ob), _vp(lut), stats.ctypes.data_as(u64p)))
         return out[: ob.value].copy(), lut[:nl].copy(), stats
 
     # ---- stage-isolating test hooks

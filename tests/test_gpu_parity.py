@@ -605,6 +605,89 @@ def test_two_devices_worker_allreduce_and_wide_records(ref_bins, tmp_path):
         assert _md5(str(tmp_path / ("ref" + ext))) == _md5(str(tmp_path / ("hip" + ext))), ext
 
 
+# ------------------------------------------------------------------------------------------------ one bin over several devices
+MULTI_CASES = [
+    (27, dict(lut_prefix_len=3), 2),
+    (27, dict(lut_prefix_len=7, cutoff_min=1), 3),
+    (55, dict(lut_prefix_len=3), 2),
+    (127, dict(lut_prefix_len=3, cutoff_min=1), 4),
+    (27, dict(output_type=1), 2),
+    (21, dict(lut_prefix_len=1, both_strands=0, without_output=1), 2),
+]
+
+
+@pytest.mark.parametrize("k,kw,n_dev", MULTI_CASES, ids=lambda v: str(v).replace(" ", "") if not isinstance(v, dict) else "-".join(f"{a}{b}" for a, b in v.items()))
+def test_process_bin_multi_over_logical_devices_matches_the_oracle(k, kw, n_dev):
+    """kmc_hip_process_bin_multi (the oversized-bin path) on a context that names device 0 n_dev times: every logical device has its
+    own streams and buffers, so each step of the path runs as it would over n_dev GPUs — shares of packs, top-byte histograms, range cuts, one
+    k_onesweep pass, the exchange (copies here; ncclSend / ncclRecv between distinct GPUs: the test below and, emulated, tests/hostlib_two_devices.py),
+    per-range sort + compaction, ordered emission — and the result must be the bin's."""
+    c = capi.Context((0,) * n_dev)
+    try:
+        bins = capi.synth_bins(seed=31, genome_len=60_000, n_reads=9_000, k=k, n_bins=2, read_len=150)
+        p = hp(k, **kw)
+        for i, (img, nrec, packs, _) in enumerate(bins):
+            w = O.process_bin(op(p), img, nrec)
+            for pk in (packs, None):
+                got = c.process_bin(p, img, nrec, pk, multi=True)
+                assert np.array_equal(got[0], w[0]) and np.array_equal(got[1], w[1]) and np.array_equal(got[2], w[2]), (i, pk is None, got[2], w[2])
+    finally:
+        c.close()
+
+
+def test_process_bin_multi_equals_process_bin_on_a_large_bin_and_on_edge_cases(ctx):
+    """a bin of ~10 M k-mers: multi over (0, 0, 0) == kmc_hip_process_bin on one device, byte for byte (size-independent property; the oracle has
+    checked the latter at this size elsewhere); then tiny bins (fewer k-mers than devices), the empty bin, a bin whose records share their top byte,
+    and the error returns"""
+    c = capi.Context((0, 0, 0))
+    try:
+        (img, nrec, packs, _), = capi.synth_bins(seed=77, genome_len=3_000_000, n_reads=100_000, k=27, n_bins=1)
+        p = hp(27, lut_prefix_len=7)
+        want = ctx.process_bin(p, img, nrec, packs)
+        got = c.process_bin(p, img, nrec, packs, multi=True)
+        assert nrec > 5_000_000 and all(np.array_equal(a, b) for a, b in zip(got, want))
+        rng = np.random.default_rng(3)
+        p1 = hp(27, lut_prefix_len=3, cutoff_min=1)
+        for n_sk, mx in ((1, 0), (1, 5), (2, 0), (3, 1), (40, 10)):
+            img, nk, packs = binsynth.random_bin(rng, 27, n_sk, max_extra=mx)
+            w = O.process_bin(op(p1), img, nk)
+            got = c.process_bin(p1, img, nk, packs, multi=True)
+            assert all(np.array_equal(a, b) for a, b in zip(got, w)), (n_sk, mx)
+        out, lut, st = c.process_bin(p1, np.zeros(0, np.uint8), 0, None, multi=True)
+        assert out.size == 0 and not lut.any() and not st.any()
+        (img, nk, packs, _), = capi.synth_bins(seed=5, genome_len=300, n_reads=1500, k=27, n_bins=1, err=0.0)
+        p2 = hp(27)
+        w = O.process_bin(op(p2), img, nk)
+        got = c.process_bin(p2, img, nk, packs, multi=True)
+        assert all(np.array_equal(a, b) for a, b in zip(got, w))
+        with pytest.raises(capi.KmcHipError) as e:
+            c.process_bin(p2, img, nk + 1, packs, multi=True)
+        assert e.value.code == -4  # KMC_HIP_ECORRUPT
+        with pytest.raises(capi.KmcHipError) as e:
+            c.process_bin(hp(27, cutoff_min=1), img, nk, packs, out_capacity=8, multi=True)
+        assert e.value.code == -5  # KMC_HIP_ECAPACITY
+        # the context is still usable
+        got = c.process_bin(p2, img, nk, packs, multi=True)
+        assert all(np.array_equal(a, b) for a, b in zip(got, w))
+    finally:
+        c.close()
+
+
+def test_process_bin_multi_over_two_gpus_exchanges_through_rccl():
+    if _n_devices() < 2:
+        pytest.skip("needs two GPUs")
+    c = capi.Context(tuple(range(min(_n_devices(), 8))))
+    try:
+        for k, kw in ((27, dict(lut_prefix_len=3)), (55, dict(lut_prefix_len=3, cutoff_min=1))):
+            (img, nrec, packs, _), = capi.synth_bins(seed=31, genome_len=200_000, n_reads=30_000, k=k, n_bins=1)
+            p = hp(k, **kw)
+            w = O.process_bin(op(p), img, nrec)
+            got = c.process_bin(p, img, nrec, packs, multi=True)
+            assert all(np.array_equal(a, b) for a, b in zip(got, w)), k
+    finally:
+        c.close()
+
+
 # ------------------------------------------------------------------------------------------------ hybrid sort (bucket_sort.hip.h)
 @pytest.fixture
 def hybrid_everywhere(ctx):
