@@ -18,7 +18,8 @@ rule of kmc.h:1434-1469) -> ~24.8 G k-mers. One "step" = ALL bins through the wh
 
 Extra keys of the N=1 line (each measured after the timed region, none inside it):
   value_two_streams   : the same step with two bins in flight (tails and launch gaps of one bin filled by the other)
-  value_host_boundary : the same bins through kmc_hip_process_bin_submit/_wait from pinned host memory (PCIe inclusive)
+  value_host_boundary : the same bins through kmc_hip_process_bins_submit/_wait (4 bins per call; host_boundary.one_bin_per_call: kmc_hip_process_bin_submit)
+                        from pinned host memory (PCIe inclusive)
   secondary.single_bin: configs[1] — 2 Gbp, all k-mers as ONE bin (the kernel-level datum of round 1)
   secondary.bins512_2gbp: the 2 Gbp sample cut into 512 bins (3.2 M k-mers per bin), tallies checked against the reference
   secondary.stage1_groundwork: NOT stage 2 — the splitter groundwork of DESIGN.md 9 (codes in HBM -> bins in HBM), timed by tools/s1_bench.py
@@ -254,9 +255,12 @@ def oracle_check(ctx, w, res, n_check=3):
 
 
 # ---------------------------------------------------------------------------------------------------------------- host boundary
-def host_boundary_pass(ctx, w, n_threads=8, passes=2):
-    """All own bins through kmc_hip_process_bin_submit/_wait from PINNED host memory: thread t owns stream slots 2t, 2t+1 and
-    keeps two bins in flight (H2D of bin j+1 under the kernels of bin j, D2H at wait time). Returns (best seconds, tallies)."""
+def host_boundary_pass(ctx, w, n_threads=8, passes=2, group=1):
+    """All own bins through the host boundary from PINNED host memory: thread t owns stream slots 2t, 2t+1 and keeps two calls in flight (H2D of call
+    j+1 under the kernels of call j, D2H at wait time). group == 1: kmc_hip_process_bin_submit/_wait, one bin per call; group > 1: `group` consecutive
+    bins per kmc_hip_process_bins_submit/_wait call (sorted together on the device). Returns (best seconds, tallies, seconds to pin, threads)."""
+    from kmc_amd.capi import HostBin
+
     p, L = w.p, ctx.L
     n_slots = L.kmc_hip_num_slots()
     n_threads = max(1, min(n_threads, n_slots // 2))
@@ -269,40 +273,51 @@ def host_boundary_pass(ctx, w, n_threads=8, passes=2):
         offs.append(o)
         o += (img.size + 255) & ~255
     cap_max = max([((x[2] + 1) // max(p.cutoff_min, 1)) * w.rec_bytes for x in w.bins] + [1])
-    outs = [ctx.host_alloc(cap_max + 256) for _ in range(2 * n_threads)]
-    luts = [ctx.host_alloc(max(w.lut_n, 1) * 8) for _ in range(2 * n_threads)]
+    outs = [ctx.host_alloc(cap_max + 256) for _ in range(2 * n_threads * group)]
+    luts = [ctx.host_alloc(max(w.lut_n, 1) * 8) for _ in range(2 * n_threads * group)]
     t_pin = time.time() - t
     errors = []
 
     def worker(tid, acc):
-        mine = list(range(tid, w.n_own, n_threads))
-        inflight = []  # slots (0/1) in submission order, at most two
-        ob, st = C.c_uint64(), (C.c_uint64 * 4)()
+        calls = [list(range(w.n_own))[c:c + group] for c in range(tid * group, w.n_own, n_threads * group)]
+        inflight = []  # (slot 0/1, bins of the call) in submission order, at most two
+        ob, st = (C.c_uint64 * group)(), (C.c_uint64 * (4 * group))()
 
-        def wait(sl):
-            rc = L.kmc_hip_process_bin_wait(ctx.h, 0, 2 * tid + sl, C.byref(ob), st)
+        def wait(sl, n):
+            if group == 1:
+                rc = L.kmc_hip_process_bin_wait(ctx.h, 0, 2 * tid + sl, ob, st)
+            else:
+                rc = L.kmc_hip_process_bins_wait(ctx.h, 0, 2 * tid + sl, ob, st)
             if rc:
                 raise RuntimeError(L.kmc_hip_last_error(ctx.h).decode())
-            for q in range(4):
-                acc[q] += st[q]
-            acc[4] += ob.value
+            for j in range(n):
+                for q in range(4):
+                    acc[q] += st[4 * j + q]
+                acc[4] += ob[j]
 
         try:
-            for j, i in enumerate(mine):
+            for j, mine in enumerate(calls):
                 sl = j & 1
                 if len(inflight) == 2:
-                    wait(inflight.pop(0))  # == sl: the slot this bin is about to reuse
-                b, size, n_rec, n_packs, _ = w.bins[i]
-                pk = w.host_imgs[i][1]
-                cap = ((n_rec + 1) // max(p.cutoff_min, 1)) * w.rec_bytes
-                rc = L.kmc_hip_process_bin_submit(ctx.h, 0, 2 * tid + sl, C.byref(p), C.c_void_p(pin.ctypes.data + offs[i]), size, n_rec,
-                                                  pk.ctypes.data_as(C.c_void_p), pk.size, C.c_void_p(outs[2 * tid + sl].ctypes.data), cap,
-                                                  C.c_void_p(luts[2 * tid + sl].ctypes.data))
+                    wait(*inflight.pop(0))  # == sl: the slot this call is about to reuse
+                arr = (HostBin * group)()
+                for q, i in enumerate(mine):
+                    b, size, n_rec, n_packs, _ = w.bins[i]
+                    pk = w.host_imgs[i][1]
+                    cap = ((n_rec + 1) // max(p.cutoff_min, 1)) * w.rec_bytes
+                    buf = (2 * tid + sl) * group + q
+                    arr[q] = HostBin(pin.ctypes.data + offs[i], size, n_rec, pk.ctypes.data, pk.size, outs[buf].ctypes.data, cap, luts[buf].ctypes.data)
+                if group == 1:
+                    h = arr[0]
+                    rc = L.kmc_hip_process_bin_submit(ctx.h, 0, 2 * tid + sl, C.byref(p), C.c_void_p(h.superkmers), h.size, h.n_rec, C.c_void_p(h.pack_bytes), h.n_packs,
+                                                      C.c_void_p(h.out_suffix), h.out_capacity, C.c_void_p(h.lut))
+                else:
+                    rc = L.kmc_hip_process_bins_submit(ctx.h, 0, 2 * tid + sl, C.byref(p), arr, len(mine))
                 if rc:
                     raise RuntimeError(L.kmc_hip_last_error(ctx.h).decode())
-                inflight.append(sl)
+                inflight.append((sl, len(mine)))
             while inflight:
-                wait(inflight.pop(0))
+                wait(*inflight.pop(0))
         except Exception as e:  # noqa: BLE001
             errors.append(repr(e))
 
@@ -458,6 +473,9 @@ def main():
     ap.add_argument("--leg", default="", help="internal: run as a secondary leg with this workload name")
     ap.add_argument("--no-cpu-baseline", action="store_true", help="skip the reference/e2e legs")
     ap.add_argument("--no-host-boundary", action="store_true")
+    ap.add_argument("--host-group", type=int, default=4, help="bins per call of the host-boundary leg (1: kmc_hip_process_bin_submit, one bin per call)")
+    ap.add_argument("--host-threads", type=int, default=0, help="host threads of the host-boundary leg (0: 4 with several bins per call, 8 with one)")
+    ap.add_argument("--no-host-single", action="store_true", help="skip the one-bin-per-call comparison of the host-boundary leg")
     ap.add_argument("--no-secondary", action="store_true")
     ap.add_argument("--no-two-streams", action="store_true", help="skip the value_two_streams leg (profiling runs: keeps overlapped launches out of the kernel statistics)")
     ap.add_argument("--no-digest", action="store_true")
@@ -649,12 +667,19 @@ def main():
             out["value_two_streams"] = repr(e)
         if want_host:
             try:
-                secs, ht, t_pin, nth = host_boundary_pass(ctx, w)
+                grp = args.host_group
+                secs, ht, t_pin, nth = host_boundary_pass(ctx, w, n_threads=args.host_threads or (4 if grp > 1 else 8), group=grp)
                 out["value_host_boundary"] = w.total_kmers_all / secs / 1e9
-                out["host_boundary"] = {"what": "the same bins through kmc_hip_process_bin_submit/_wait from pinned host memory, %d host threads x 2 stream "
-                                                "slots (H2D + kernels + D2H of every bin; PCIe inclusive), best of 2 passes" % nth,
-                                        "seconds": secs, "bytes_in": w.total_bytes_all, "bytes_out": int(ht[4]), "pin_and_stage_s": t_pin,
+                how = ("kmc_hip_process_bins_submit/_wait, %d consecutive bins per call (sorted together on the device)" % grp) if grp > 1 else \
+                    "kmc_hip_process_bin_submit/_wait, one bin per call"
+                out["host_boundary"] = {"what": "the same bins through %s from pinned host memory, %d host threads x 2 stream slots (H2D + kernels + D2H of every "
+                                                "bin; PCIe inclusive), best of 2 passes" % (how, nth),
+                                        "bins_per_call": grp, "seconds": secs, "bytes_in": w.total_bytes_all, "bytes_out": int(ht[4]), "pin_and_stage_s": t_pin,
                                         "tallies_equal_device_resident": [int(x) for x in ht[:4]] == [int(x) for x in tallies]}
+                if grp > 1 and not args.no_host_single:
+                    secs1, ht1, _, nth1 = host_boundary_pass(ctx, w, n_threads=8, group=1)
+                    out["host_boundary"]["one_bin_per_call"] = {"value": w.total_kmers_all / secs1 / 1e9, "seconds": secs1, "host_threads": nth1,
+                                                                "tallies_equal_device_resident": [int(x) for x in ht1[:4]] == [int(x) for x in tallies]}
             except Exception as e:  # noqa: BLE001
                 out["host_boundary"] = {"error": repr(e)}
         w.free()

@@ -23,6 +23,21 @@ class KmcHipError(RuntimeError):
         self.code = code
 
 
+class HostBin(C.Structure):
+    """struct kmc_hip_host_bin: one bin of a kmc_hip_process_bins_submit call (host pointers)"""
+
+    _fields_ = [
+        ("superkmers", C.c_void_p),
+        ("size", C.c_uint64),
+        ("n_rec", C.c_uint64),
+        ("pack_bytes", C.c_void_p),
+        ("n_packs", C.c_uint64),
+        ("out_suffix", C.c_void_p),
+        ("out_capacity", C.c_uint64),
+        ("lut", C.c_void_p),
+    ]
+
+
 class BinParams(C.Structure):
     """struct kmc_hip_bin_params (mirrors the CKMCParams fields of kb_sorter.h:165-200)."""
 
@@ -66,7 +81,7 @@ SYMBOLS = [
     "kmc_hip_device_count",
     "kmc_hip_words", "kmc_hip_counter_size", "kmc_hip_out_rec_bytes", "kmc_hip_lut_entries",
     "kmc_hip_sort_records", "kmc_hip_sort_records_into", "kmc_hip_sort_records_device",
-    "kmc_hip_process_bin", "kmc_hip_process_bin_multi", "kmc_hip_process_bin_submit", "kmc_hip_process_bin_wait", "kmc_hip_process_bin_device",
+    "kmc_hip_process_bin", "kmc_hip_process_bin_multi", "kmc_hip_process_bins_submit", "kmc_hip_process_bins_wait", "kmc_hip_process_bin_submit", "kmc_hip_process_bin_wait", "kmc_hip_process_bin_device",
     "kmc_hip_process_bins_device", "kmc_hip_order_database_device",
     "kmc_hip_allreduce_stats", "kmc_hip_last_timings", "kmc_hip_scatter_totals", "kmc_hip_local_sort_totals", "kmc_hip_set_hybrid",
     "kmc_hip_malloc", "kmc_hip_free", "kmc_hip_memcpy_h2d", "kmc_hip_memcpy_d2h",
@@ -122,6 +137,8 @@ def load():
     L.kmc_hip_process_bin.argtypes = [vp, C.c_int, C.POINTER(BinParams), vp, C.c_uint64, C.c_uint64, vp, C.c_uint64, vp, C.c_uint64,
                                       u64p, vp, u64p]
     L.kmc_hip_process_bin_multi.argtypes = [vp, C.POINTER(BinParams), vp, C.c_uint64, C.c_uint64, vp, C.c_uint64, vp, C.c_uint64, u64p, vp, u64p]
+    L.kmc_hip_process_bins_submit.argtypes = [vp, C.c_int, C.c_int, C.POINTER(BinParams), C.POINTER(HostBin), C.c_uint32]
+    L.kmc_hip_process_bins_wait.argtypes = [vp, C.c_int, C.c_int, u64p, u64p]
     L.kmc_hip_process_bin_submit.argtypes = [vp, C.c_int, C.c_int, C.POINTER(BinParams), vp, C.c_uint64, C.c_uint64, vp, C.c_uint64,
                                              vp, C.c_uint64, vp]
     L.kmc_hip_process_bin_wait.argtypes = [vp, C.c_int, C.c_int, u64p, u64p]
@@ -222,6 +239,29 @@ class Context:
             self._chk(self.L.kmc_hip_process_bin(self.h, dev, C.byref(p), _vp(src), image.size, n_rec, pb, npk, _vp(out), out_capacity,
                                                  C.byref(ob), _vp(lut), stats.ctypes.data_as(u64p)))
         return out[: ob.value].copy(), lut[:nl].copy(), stats
+
+    def process_bins_host(self, p: BinParams, bins, out_capacity=None, slot: int = 0, dev: int = 0):
+        """Up to 16 bins [(image, n_rec, pack_bytes or None), ...] through ONE kmc_hip_process_bins_submit / _wait pair (the bins are sorted together
+        where the key has spare bits). Returns [(suffix_bytes, lut, stats[4]), ...] in the order of the bins."""
+        n = len(bins)
+        rec, nl = self.out_rec_bytes(p), self.lut_entries(p)
+        arr = (HostBin * max(n, 1))()
+        keep, outs, luts = [], [], []
+        for i, (image, n_rec, pack_bytes) in enumerate(bins):
+            image = np.ascontiguousarray(image, dtype=np.uint8)
+            cap = ((n_rec + 1) // max(p.cutoff_min, 1)) * rec if out_capacity is None else out_capacity
+            out, lut = np.zeros(max(cap, 1), dtype=np.uint8), np.zeros(max(nl, 1), dtype=np.uint64)
+            src = image if image.size else np.zeros(1, dtype=np.uint8)
+            pb = None if pack_bytes is None else np.ascontiguousarray(pack_bytes, dtype=np.uint64)
+            keep += [src, pb]
+            outs.append(out)
+            luts.append(lut)
+            arr[i] = HostBin(src.ctypes.data, image.size, n_rec, None if pb is None else pb.ctypes.data, 0 if pb is None else pb.size, out.ctypes.data, cap,
+                             lut.ctypes.data)
+        self._chk(self.L.kmc_hip_process_bins_submit(self.h, dev, slot, C.byref(p), arr, n))
+        ob, st = np.zeros(max(n, 1), dtype=np.uint64), np.zeros((max(n, 1), 4), dtype=np.uint64)
+        self._chk(self.L.kmc_hip_process_bins_wait(self.h, dev, slot, ob.ctypes.data_as(u64p), st.ctypes.data_as(u64p)))
+        return [(outs[i][: int(ob[i])].copy(), luts[i][:nl].copy(), st[i].copy()) for i in range(n)]
 
     # ---- stage-isolating test hooks
     def debug_expand(self, p: BinParams, image: np.ndarray, n_rec: int, pack_bytes: np.ndarray, dev: int = 0) -> np.ndarray:

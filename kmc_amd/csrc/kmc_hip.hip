@@ -110,6 +110,15 @@ struct ZeroPlan {
 };
 inline size_t up256(size_t x) { return (x + 255) & ~(size_t)255; }
 
+/* results of a host-boundary GROUP (kmc_hip_process_bins_submit): per bin out_bytes + the four tallies, per sort group the hybrid sort's "again"
+ * word, the stream's sticky error word — one block on the device, copied to pinned memory when the group's kernels are done */
+constexpr u32 HB_MAX = 16;
+struct HbRes {
+	u64 w[HB_MAX][8]; /* [0] out_bytes, [1..4] stats */
+	u32 flag[HB_MAX];
+	u32 err, pad[15];
+};
+
 struct Slot {
 	hipStream_t stream = nullptr;
 	std::mutex mtx; /* serialises enqueueing on this slot (asynchronous device-resident calls may come from several threads) */
@@ -146,6 +155,19 @@ struct Slot {
 		std::vector<kmc_hip_bin_desc> descs;
 	};
 	std::vector<PendingGroup> pending_groups;
+	/* host-boundary group in flight */
+	struct HostBin {
+		kmc_hip_bin_desc d; /* device side */
+		uint8_t *h_out;
+		u64 *h_lut;
+	};
+	std::vector<HostBin> hb;
+	std::vector<std::pair<u32, u32>> hb_chunks; /* (first bin, bins) of every sort group */
+	std::vector<char> hb_hybrid;
+	DBuf hb_res;
+	HbRes *h_hb_res = nullptr; /* pinned */
+	DevParams hb_P = {};
+	bool hb_pending = false;
 };
 
 struct Dev {
@@ -227,11 +249,13 @@ int slot_init(Slot &s, u64 portion)
 
 void slot_destroy(Slot &s)
 {
-	for (DBuf *b : {&s.in, &s.pack_start, &s.recA, &s.recB, &s.zero, &s.dbase, &s.out, &s.lut, &s.sticky, &s.bounds, &s.redo_log})
+	for (DBuf *b : {&s.in, &s.pack_start, &s.recA, &s.recB, &s.zero, &s.dbase, &s.out, &s.lut, &s.sticky, &s.bounds, &s.redo_log, &s.hb_res})
 		if (b->p)
 			(void)hipFree(b->p);
 	if (s.h_res)
 		(void)hipHostFree(s.h_res);
+	if (s.h_hb_res)
+		(void)hipHostFree(s.h_hb_res);
 	for (auto &e : s.ev)
 		if (e)
 			(void)hipEventDestroy(e);
@@ -1934,6 +1958,41 @@ int kmc_hip_process_bins_device(kmc_hip_ctx *ctx, int dev, const kmc_hip_bin_par
 	return 0;
 }
 
+/* byte offsets of a bin's expander packs, appended to `ps` (first entry 0, last entry `size`): from the caller's pack sizes, or — none given — by one
+ * walk over the image, a boundary every 4096 super-k-mers */
+static int append_pack_starts(const DevParams &P, const uint8_t *superkmers, u64 size, const uint64_t *pack_bytes, u64 n_packs, std::vector<u64> &ps)
+{
+	if (!size)
+		return 0;
+	ps.push_back(0);
+	if (n_packs) {
+		u64 acc = 0;
+		for (u64 i = 0; i < n_packs; ++i) {
+			if (pack_bytes[i] == 0)
+				continue;
+			acc += pack_bytes[i];
+			ps.push_back(acc);
+		}
+		if (acc != size)
+			return fail(KMC_HIP_ECORRUPT, "sum of pack_bytes != size");
+		return 0;
+	}
+	u64 pos = 0;
+	u32 in_pack = 0;
+	while (pos < size) {
+		const u32 e = superkmers[pos];
+		pos += 1 + (P.k + e + 3) / 4;
+		if (++in_pack == 4096 && pos < size) {
+			ps.push_back(pos);
+			in_pack = 0;
+		}
+	}
+	if (pos != size)
+		return fail(KMC_HIP_ECORRUPT, "super-k-mer stream is ragged");
+	ps.push_back(size);
+	return 0;
+}
+
 /* the kernels of the host-boundary bin whose image is in s.in, and the copy of its results block to pinned memory (caller holds s.mtx) */
 static int enqueue_host_bin(Slot &s, bool classic)
 {
@@ -1963,7 +2022,7 @@ int kmc_hip_process_bin_submit(kmc_hip_ctx *ctx, int dev, int slot, const kmc_hi
 		return rc;
 	Slot &s = ctx->devs[dev]->slot[slot];
 	std::lock_guard<std::mutex> lck(s.mtx);
-	if (s.pending)
+	if (s.pending || s.hb_pending)
 		return fail(KMC_HIP_EINVAL, "slot already has a bin in flight");
 	if (size && !superkmers)
 		return fail(KMC_HIP_EINVAL, "superkmers == NULL");
@@ -2083,6 +2142,181 @@ int kmc_hip_process_bin(kmc_hip_ctx *ctx, int dev, const kmc_hip_bin_params *par
 	if (int rc = kmc_hip_process_bin_submit(ctx, dev, 0, params, superkmers, size, n_rec, pack_bytes, n_packs, out_suffix, out_capacity, lut))
 		return rc;
 	return kmc_hip_process_bin_wait(ctx, dev, 0, out_bytes, stats);
+}
+
+/* ---- host-boundary GROUPS: up to HB_MAX bins per call, sorted together like the bins of kmc_hip_process_bins_device ---- */
+static int hb_enqueue_results(Slot &s)
+{
+	HbRes *res = (HbRes *)s.hb_res.p;
+	HIPCHK(hipMemcpyAsync(&res->err, s.sticky.p, 4, hipMemcpyDeviceToDevice, s.stream));
+	HIPCHK(hipMemcpyAsync(s.h_hb_res, s.hb_res.p, sizeof(HbRes), hipMemcpyDeviceToHost, s.stream));
+	HIPCHK(hipEventRecord(s.done_ev, s.stream));
+	return 0;
+}
+
+int kmc_hip_process_bins_submit(kmc_hip_ctx *ctx, int dev, int slot, const kmc_hip_bin_params *params, const kmc_hip_host_bin *bins, uint32_t n_bins)
+{
+	if (int rc = set_dev(ctx, dev))
+		return rc;
+	if (slot < 0 || slot >= N_SLOTS)
+		return fail(KMC_HIP_EINVAL, "slot out of range (see kmc_hip_num_slots)");
+	DevParams P;
+	if (int rc = check_params(params, P))
+		return rc;
+	if (!bins || n_bins < 1 || n_bins > HB_MAX)
+		return fail(KMC_HIP_EINVAL, "kmc_hip_process_bins_submit: 1..16 bins per call");
+	Slot &s = ctx->devs[dev]->slot[slot];
+	std::lock_guard<std::mutex> lck(s.mtx);
+	if (s.pending || s.hb_pending)
+		return fail(KMC_HIP_EINVAL, "slot already has a bin in flight");
+	const u64 lut_entries = P.kff ? 0 : kmc_hip_lut_entries(params);
+	const u64 lut_pitch = up256(lut_entries * 8);
+	std::vector<u64> &ps = s.h_pack_start;
+	ps.clear();
+	std::vector<u64> in_off(n_bins), out_off(n_bins), ps_off(n_bins), np(n_bins);
+	u64 in_total = 0, out_total = 0, recs = 0;
+	for (u32 i = 0; i < n_bins; ++i) {
+		const kmc_hip_host_bin &b = bins[i];
+		if (b.size && !b.superkmers)
+			return fail(KMC_HIP_EINVAL, "superkmers == NULL");
+		if (!P.without_output && ((b.out_capacity && !b.out_suffix) || (lut_entries && !b.lut)))
+			return fail(KMC_HIP_EINVAL, "output buffers missing");
+		if ((b.n_rec == 0) != (b.size == 0))
+			return fail(KMC_HIP_ECORRUPT, "exactly one of size / n_rec is zero");
+		ps_off[i] = ps.size();
+		if (int rc = append_pack_starts(P, b.superkmers, b.size, b.pack_bytes, b.n_packs, ps))
+			return rc;
+		np[i] = ps.size() > ps_off[i] ? ps.size() - ps_off[i] - 1 : 0;
+		in_off[i] = in_total;
+		in_total += up256(b.size + 256);
+		out_off[i] = out_total;
+		out_total += up256((P.without_output ? 0 : b.out_capacity) + 256);
+		recs += b.n_rec;
+	}
+	int rc = 0;
+	if ((rc = ensure(s.in, in_total + 256)) || (rc = ensure(s.pack_start, (ps.size() + 1) * 8)) || (rc = ensure(s.out, out_total + 256)) ||
+	    (rc = ensure(s.lut, (u64)n_bins * lut_pitch + 256)) || (rc = ensure(s.hb_res, sizeof(HbRes))))
+		return rc;
+	if (!s.h_hb_res)
+		HIPCHK(hipHostMalloc((void **)&s.h_hb_res, sizeof(HbRes), hipHostMallocDefault));
+	HbRes *res = (HbRes *)s.hb_res.p;
+	HIPCHK(hipMemsetAsync(res, 0, sizeof(HbRes), s.stream));
+	if (!ps.empty())
+		HIPCHK(hipMemcpyAsync(s.pack_start.p, ps.data(), ps.size() * 8, hipMemcpyHostToDevice, s.stream));
+	s.hb.resize(n_bins);
+	for (u32 i = 0; i < n_bins; ++i) {
+		const kmc_hip_host_bin &b = bins[i];
+		uint8_t *d_img = (uint8_t *)s.in.p + in_off[i];
+		if (b.size) {
+			HIPCHK(hipMemcpyAsync(d_img, b.superkmers, b.size, hipMemcpyHostToDevice, s.stream));
+			HIPCHK(hipMemsetAsync(d_img + b.size, 0, 256, s.stream));
+		}
+		Slot::HostBin &h = s.hb[i];
+		h.d.d_superkmers = d_img;
+		h.d.size = b.size;
+		h.d.n_rec = b.n_rec;
+		h.d.d_pack_start = (const uint64_t *)s.pack_start.p + ps_off[i];
+		h.d.n_packs = np[i];
+		h.d.d_out = (uint8_t *)s.out.p + out_off[i];
+		h.d.out_capacity = P.without_output ? 0 : b.out_capacity;
+		h.d.d_out_bytes = (uint64_t *)&res->w[i][0];
+		h.d.d_stats = (uint64_t *)&res->w[i][1];
+		h.d.d_lut = (uint64_t *)((char *)s.lut.p + (u64)i * lut_pitch);
+		h.h_out = b.out_suffix;
+		h.h_lut = (u64 *)b.lut;
+	}
+	/* sort groups: as many consecutive bins as the spare bits of the top digit can tag (group_capacity), while the record array stays moderate */
+	const u32 G = group_capacity(P.k, recs / n_bins < GROUP_SMALL_BIN_RECORDS);
+	const u64 rec_bytes_of = (u64)((P.k + 31) / 32) * 8;
+	s.hb_chunks.clear();
+	s.hb_hybrid.clear();
+	s.timed = true;
+	s.hb_P = P;
+	s.lut_entries = lut_entries;
+	s.without_output = P.without_output != 0;
+	for (u32 first = 0; first < n_bins;) {
+		u32 cnt = 0;
+		u64 grp_recs = 0;
+		while (first + cnt < n_bins && cnt < G && (cnt == 0 || (grp_recs + bins[first + cnt].n_rec) * rec_bytes_of <= GROUP_MAX_RECORD_BYTES))
+			grp_recs += bins[first + cnt++].n_rec;
+		const kmc_hip_bin_desc *ptrs[HB_MAX];
+		for (u32 j = 0; j < cnt; ++j)
+			ptrs[j] = &s.hb[first + j].d;
+		bool hyb = false;
+		if ((rc = run_group_device(s, P, ptrs, cnt, lut_entries, false, &res->flag[s.hb_chunks.size()], &hyb)))
+			return rc;
+		s.hb_chunks.emplace_back(first, cnt);
+		s.hb_hybrid.push_back(hyb ? 1 : 0);
+		first += cnt;
+	}
+	if ((rc = hb_enqueue_results(s)))
+		return rc;
+	s.hb_pending = true;
+	return 0;
+}
+
+int kmc_hip_process_bins_wait(kmc_hip_ctx *ctx, int dev, int slot, uint64_t *out_bytes, uint64_t *stats)
+{
+	if (int rc = set_dev(ctx, dev))
+		return rc;
+	if (slot < 0 || slot >= N_SLOTS)
+		return fail(KMC_HIP_EINVAL, "slot out of range (see kmc_hip_num_slots)");
+	Slot &s = ctx->devs[dev]->slot[slot];
+	std::lock_guard<std::mutex> lck(s.mtx);
+	if (!s.hb_pending)
+		return fail(KMC_HIP_EINVAL, "no group of bins in flight on this slot");
+	s.hb_pending = false;
+	HIPCHK(hipEventSynchronize(s.done_ev));
+	if (int rc = harvest(s))
+		return rc;
+	const HbRes &r = *s.h_hb_res;
+	if (!r.err) { /* sort groups whose hybrid sort met a tile it could not handle: again (the images are still in s.in), LSD passes over every byte */
+		bool any = false;
+		for (size_t c = 0; c < s.hb_chunks.size(); ++c) {
+			if (!s.hb_hybrid[c] || !r.flag[c])
+				continue;
+			any = true;
+			note_redo();
+			const kmc_hip_bin_desc *ptrs[HB_MAX];
+			for (u32 j = 0; j < s.hb_chunks[c].second; ++j)
+				ptrs[j] = &s.hb[s.hb_chunks[c].first + j].d;
+			s.timed = false;
+			if (int rc = run_group_device(s, s.hb_P, ptrs, s.hb_chunks[c].second, s.lut_entries, true))
+				return rc;
+		}
+		if (any) {
+			raise_top();
+			if (int rc = hb_enqueue_results(s))
+				return rc;
+			HIPCHK(hipEventSynchronize(s.done_ev));
+		}
+	}
+	if (r.err) {
+		HIPCHK(hipMemset(s.sticky.p, 0, 4));
+		return err_to_code(r.err);
+	}
+	const size_t n = s.hb.size();
+	for (size_t i = 0; i < n; ++i)
+		if (r.w[i][0] > s.hb[i].d.out_capacity && !s.without_output)
+			return fail(KMC_HIP_ECAPACITY, "out_capacity too small for the counted k-mers");
+	if (!s.without_output) { /* exact-size copies */
+		for (size_t i = 0; i < n; ++i) {
+			if (r.w[i][0])
+				HIPCHK(hipMemcpyAsync(s.hb[i].h_out, s.hb[i].d.d_out, r.w[i][0], hipMemcpyDeviceToHost, s.stream));
+			if (s.lut_entries)
+				HIPCHK(hipMemcpyAsync(s.hb[i].h_lut, s.hb[i].d.d_lut, s.lut_entries * 8, hipMemcpyDeviceToHost, s.stream));
+		}
+		HIPCHK(hipEventRecord(s.done_ev, s.stream));
+		HIPCHK(hipEventSynchronize(s.done_ev));
+	}
+	for (size_t i = 0; i < n; ++i) {
+		if (out_bytes)
+			out_bytes[i] = r.w[i][0];
+		if (stats)
+			for (int q = 0; q < 4; ++q)
+				stats[4 * i + q] = r.w[i][1 + q];
+	}
+	return 0;
 }
 
 int kmc_hip_process_bin_multi(kmc_hip_ctx *ctx, const kmc_hip_bin_params *params, const uint8_t *superkmers, uint64_t size, uint64_t n_rec,

@@ -20,6 +20,16 @@ struct KmcBinEngine {
 	virtual int process_bin(const kmc_hip_bin_params &params, const uint8_t *superkmers, uint64_t size, uint64_t n_rec,
 	                        const uint64_t *pack_bytes, uint64_t n_packs, uint8_t *out_suffix, uint64_t out_capacity,
 	                        uint64_t *out_bytes, uint64_t *lut, uint64_t stats[4]) = 0;
+	/* Several bins at once (a worker that found more than one bin waiting): results per bin as process_bin's. The default takes them one after the
+	 * other; the HIP engine hands them to kmc_hip_process_bins_submit/_wait, where they share one sort (include/kmc_hip.h). Returns the first error. */
+	virtual int process_bins(const kmc_hip_bin_params &params, const kmc_hip_host_bin *bins, uint32_t n_bins, uint64_t *out_bytes, uint64_t *stats)
+	{
+		for (uint32_t i = 0; i < n_bins; ++i)
+			if (int rc = process_bin(params, bins[i].superkmers, bins[i].size, bins[i].n_rec, bins[i].pack_bytes, bins[i].n_packs, bins[i].out_suffix,
+			                         bins[i].out_capacity, out_bytes + i, bins[i].lut, stats + 4 * i))
+				return rc;
+		return 0;
+	}
 	virtual std::string last_error() = 0;
 };
 

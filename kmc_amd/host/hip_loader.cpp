@@ -37,6 +37,8 @@ struct Api {
 	int (*submit)(kmc_hip_ctx *, int, int, const kmc_hip_bin_params *, const uint8_t *, uint64_t, uint64_t, const uint64_t *, uint64_t,
 	              uint8_t *, uint64_t, uint64_t *) = nullptr;
 	int (*wait)(kmc_hip_ctx *, int, int, uint64_t *, uint64_t *) = nullptr;
+	int (*submit_bins)(kmc_hip_ctx *, int, int, const kmc_hip_bin_params *, const kmc_hip_host_bin *, uint32_t) = nullptr;
+	int (*wait_bins)(kmc_hip_ctx *, int, int, uint64_t *, uint64_t *) = nullptr;
 	int (*num_slots)(void) = nullptr;
 	int (*sort_into)(kmc_hip_ctx *, int, const void *, void *, uint64_t, uint32_t, uint32_t) = nullptr;
 	int n_slots = 1;
@@ -50,7 +52,7 @@ Api g_api;
 std::once_flag g_once;
 
 /* KMC_HIP_VERBOSE=1: where did the worker spend its time? (printed when the last engine is destroyed) */
-std::atomic<long long> g_ns_init{0}, g_ns_bins{0}, g_n_bins{0}, g_bytes_in{0}, g_bytes_out{0}, g_kmers{0}, g_engines{0};
+std::atomic<long long> g_ns_init{0}, g_ns_bins{0}, g_n_bins{0}, g_n_group_calls{0}, g_bytes_in{0}, g_bytes_out{0}, g_kmers{0}, g_engines{0};
 inline long long now_ns() { return std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 
 std::string exe_dir()
@@ -102,6 +104,7 @@ void load_api_impl()
 	if (!sym(a.so, "kmc_hip_init", a.init, a.err) || !sym(a.so, "kmc_hip_destroy", a.destroy, a.err) ||
 	    !sym(a.so, "kmc_hip_last_error", a.last_error, a.err) || !sym(a.so, "kmc_hip_abi_version", a.abi_version, a.err) ||
 	    !sym(a.so, "kmc_hip_process_bin_submit", a.submit, a.err) || !sym(a.so, "kmc_hip_process_bin_wait", a.wait, a.err) ||
+	    !sym(a.so, "kmc_hip_process_bins_submit", a.submit_bins, a.err) || !sym(a.so, "kmc_hip_process_bins_wait", a.wait_bins, a.err) ||
 	    !sym(a.so, "kmc_hip_num_slots", a.num_slots, a.err) ||
 	    !sym(a.so, "kmc_hip_sort_records_into", a.sort_into, a.err)) {
 		a.so = nullptr;
@@ -158,8 +161,8 @@ struct HipEngine : KmcBinEngine {
 	~HipEngine() override
 	{
 		if (--g_engines == 0 && getenv("KMC_HIP_VERBOSE"))
-			fprintf(stderr, "[kmc_hip] init %.3f s; %lld bins, %.3f s inside the engine (sum over workers), %.1f MB in, %.1f MB out, %lld k-mers\n",
-			        g_ns_init.load() * 1e-9, g_n_bins.load(), g_ns_bins.load() * 1e-9, g_bytes_in.load() / 1e6, g_bytes_out.load() / 1e6,
+			fprintf(stderr, "[kmc_hip] init %.3f s; %lld bins (%lld calls with several bins), %.3f s inside the engine (sum over workers), %.1f MB in, %.1f MB out, %lld k-mers\n",
+			        g_ns_init.load() * 1e-9, g_n_bins.load(), g_n_group_calls.load(), g_ns_bins.load() * 1e-9, g_bytes_in.load() / 1e6, g_bytes_out.load() / 1e6,
 			        g_kmers.load());
 	}
 	int process_bin(const kmc_hip_bin_params &p, const uint8_t *sk, uint64_t size, uint64_t n_rec, const uint64_t *pack_bytes,
@@ -184,6 +187,29 @@ struct HipEngine : KmcBinEngine {
 		g_bytes_in += (long long)size;
 		g_bytes_out += (long long)*out_bytes;
 		g_kmers += (long long)n_rec;
+		return rc;
+	}
+	int process_bins(const kmc_hip_bin_params &p, const kmc_hip_host_bin *bins, uint32_t n_bins, uint64_t *out_bytes, uint64_t *stats) override
+	{
+		if (!g_api.ctx) {
+			err = g_api.err.empty() ? "HIP engine not initialised" : g_api.err;
+			return KMC_HIP_EDEVICE;
+		}
+		std::lock_guard<std::mutex> lck(g_api.slot_mtx[dev & 63][slot]);
+		const long long t0 = now_ns();
+		int rc = g_api.submit_bins(g_api.ctx, dev, slot, &p, bins, n_bins);
+		if (!rc)
+			rc = g_api.wait_bins(g_api.ctx, dev, slot, out_bytes, stats);
+		if (rc)
+			err = g_api.last_error(g_api.ctx);
+		g_ns_bins += now_ns() - t0;
+		g_n_bins += n_bins;
+		++g_n_group_calls;
+		for (uint32_t i = 0; i < n_bins; ++i) {
+			g_bytes_in += (long long)bins[i].size;
+			g_bytes_out += rc ? 0 : (long long)out_bytes[i];
+			g_kmers += (long long)bins[i].n_rec;
+		}
 		return rc;
 	}
 	std::string last_error() override { return err; }

@@ -86,6 +86,7 @@ public:
 template <unsigned SIZE> class CWKmerBinSorter {
 	std::shared_ptr<KmcOrderedEmit> order;
 	CBinDesc *bd;
+	CBinQueue *bq;
 	CExpanderPackDesc *epd;
 	CKmerQueue *kq;
 	CMemoryBins *memory_bins;
@@ -106,6 +107,7 @@ public:
 	CWKmerBinSorter(CKMCParams &Params, CKMCQueues &Queues, SortFunction<CKmer<SIZE>> /*sort_func: CPU sorter, unused*/)
 	{
 		bd = Queues.bd.get();
+		bq = Queues.bq.get();
 		epd = Queues.epd.get();
 		kq = Queues.kq.get();
 		memory_bins = Queues.memory_bins.get();
@@ -139,96 +141,140 @@ public:
 		if (!engine)
 			CCriticalErrorHandler::Inst().HandleCriticalError("Error: cannot create the stage-2 bin engine");
 
-		int32 bin_id;
-		uchar *data;
-		uint64 size, n_rec;
-		int n_sorting_threads;
 		const uint64 lut_recs = bp.lut_prefix_len ? 1ull << (2 * bp.lut_prefix_len) : 0;
 		const uint64 out_rec_bytes = kmc_hip_out_rec_bytes_host(bp);
-		std::vector<uint64> pack_bytes;
+		/* a bin this worker holds between GetNext and kq->push */
+		struct Taken {
+			int32 bin_id = 0;
+			uchar *data = nullptr;
+			uint64 size = 0, n_rec = 0, seq = 0, tmp_size = 0, n_plus_x_recs = 0, out_capacity = 0;
+			int n_sorting_threads = 0; /* 0: taken straight from the bin queue (below), nothing to hand back to the sorters manager */
+			std::vector<uint64> pack_bytes;
+			uchar *out_buffer = nullptr, *raw_lut = nullptr;
+		};
+		/* Bins that are ALREADY waiting when this worker comes for one are taken together (up to KMC_HIP_WORKER_GROUP, default 4, 1 = off) and handed
+		 * to the engine in one call: on the device they share one sort (kmc_hip_process_bins_submit). Only bins the reader has finished are taken —
+		 * CBinQueue::pop_if_any (queues.h:751) never waits — so a worker never holds bins while it waits for more, and the memory they occupy was
+		 * reserved by the reader before it read them: nothing new can block. */
+		static const size_t max_group = [] {
+			const char *e = getenv("KMC_HIP_WORKER_GROUP");
+			const int v = e ? atoi(e) : 4;
+			return (size_t)(v < 1 ? 1 : (v > 16 ? 16 : v));
+		}();
 
 		const long long t_start = KmcOrderedEmit::now_ns();
+		std::vector<Taken> grp;
 		while (true) {
-			uint64 seq = 0;
+			grp.clear();
 			{
 				const long long t0 = KmcOrderedEmit::now_ns();
 				std::lock_guard<std::mutex> lck(order->take_mtx);
-				if (!sorters_manager->GetNext(bin_id, data, size, n_rec, n_sorting_threads))
+				Taken t;
+				if (!sorters_manager->GetNext(t.bin_id, t.data, t.size, t.n_rec, t.n_sorting_threads))
 					break;
-				seq = order->next_take++;
-				if (seq == 0)
+				t.seq = order->next_take++;
+				if (t.seq == 0)
 					KmcTimeline::mark("first bin taken");
+				grp.push_back(std::move(t));
+				while (grp.size() < max_group) {
+					Taken e;
+					if (!bq->pop_if_any(e.bin_id, e.data, e.size, e.n_rec))
+						break;
+					e.seq = order->next_take++;
+					grp.push_back(std::move(e));
+				}
 				order->ns_getnext += KmcOrderedEmit::now_ns() - t0;
 			}
-			CMemDiskFile *file;
-			string desc;
-			uint64 tmp_size, tmp_n_rec, n_plus_x_recs;
-			bd->read(bin_id, file, desc, tmp_size, tmp_n_rec, n_plus_x_recs);
-			sum_n_rec += n_rec;
-			sum_n_plus_x_rec += n_plus_x_recs;
-			if (const char *dd = getenv("KMC_HIP_BINDESC_DUMP")) { /* tests: what stage 1 recorded for this bin (CBinDesc, queues.h:643-680) */
-				static std::mutex dump_mtx;
-				std::lock_guard<std::mutex> lck(dump_mtx);
-				if (FILE *f = fopen(dd, "a")) {
-					fprintf(f, "%d %llu %llu %llu\n", (int)bin_id, (unsigned long long)tmp_size, (unsigned long long)tmp_n_rec, (unsigned long long)n_plus_x_recs);
-					fclose(f);
+			for (Taken &t : grp) {
+				CMemDiskFile *file;
+				string desc;
+				uint64 tmp_n_rec;
+				bd->read(t.bin_id, file, desc, t.tmp_size, tmp_n_rec, t.n_plus_x_recs);
+				sum_n_rec += t.n_rec;
+				sum_n_plus_x_rec += t.n_plus_x_recs;
+				if (const char *dd = getenv("KMC_HIP_BINDESC_DUMP")) { /* tests: what stage 1 recorded for this bin (CBinDesc, queues.h:643-680) */
+					static std::mutex dump_mtx;
+					std::lock_guard<std::mutex> lck(dump_mtx);
+					if (FILE *f = fopen(dd, "a")) {
+						fprintf(f, "%d %llu %llu %llu\n", (int)t.bin_id, (unsigned long long)t.tmp_size, (unsigned long long)tmp_n_rec, (unsigned long long)t.n_plus_x_recs);
+						fclose(f);
+					}
 				}
+				list<pair<uint64, uint64>> packs;
+				epd->pop(t.bin_id, packs);
+				for (auto &e : packs)
+					t.pack_bytes.push_back(e.first);
+				memory_bins->reserve(t.bin_id, t.out_buffer, CMemoryBins::mba_suffix);
+				memory_bins->reserve(t.bin_id, t.raw_lut, CMemoryBins::mba_lut);
+				/* capacity of mba_suffix exactly as the reader sized it (kb_reader.h:141-150) */
+				const uint64 max_out_recs = (t.n_rec + 1) / max((uint32)bp.cutoff_min, 1u);
+				t.out_capacity = max_out_recs * out_rec_bytes;
 			}
 
-			list<pair<uint64, uint64>> packs;
-			epd->pop(bin_id, packs);
-			pack_bytes.clear();
-			for (auto &e : packs)
-				pack_bytes.push_back(e.first);
-
-			uchar *out_buffer = nullptr, *raw_lut = nullptr;
-			memory_bins->reserve(bin_id, out_buffer, CMemoryBins::mba_suffix);
-			memory_bins->reserve(bin_id, raw_lut, CMemoryBins::mba_lut);
-
-			/* capacity of mba_suffix exactly as the reader sized it (kb_reader.h:141-150) */
-			uint64 max_out_recs = (n_rec + 1) / max((uint32)bp.cutoff_min, 1u);
-			uint64 out_capacity = max_out_recs * out_rec_bytes;
-
-			uint64 out_bytes = 0;
-			uint64 stats[4] = {0, 0, 0, 0};
+			uint64 out_bytes[16] = {};
+			uint64 stats[16][4] = {};
 			const long long t1 = KmcOrderedEmit::now_ns();
-			int rc = engine->process_bin(bp, data, tmp_size, n_rec, pack_bytes.data(), pack_bytes.size(), out_buffer,
-			                             out_capacity, &out_bytes, (uint64 *)raw_lut, stats);
+			int rc;
+			if (grp.size() == 1) {
+				Taken &t = grp[0];
+				rc = engine->process_bin(bp, t.data, t.tmp_size, t.n_rec, t.pack_bytes.data(), t.pack_bytes.size(), t.out_buffer, t.out_capacity, &out_bytes[0],
+				                         (uint64 *)t.raw_lut, stats[0]);
+			} else {
+				kmc_hip_host_bin hb[16];
+				for (size_t i = 0; i < grp.size(); ++i) {
+					Taken &t = grp[i];
+					hb[i].superkmers = t.data;
+					hb[i].size = t.tmp_size;
+					hb[i].n_rec = t.n_rec;
+					hb[i].pack_bytes = t.pack_bytes.data();
+					hb[i].n_packs = t.pack_bytes.size();
+					hb[i].out_suffix = t.out_buffer;
+					hb[i].out_capacity = t.out_capacity;
+					hb[i].lut = (uint64_t *)t.raw_lut;
+				}
+				rc = engine->process_bins(bp, hb, (uint32_t)grp.size(), out_bytes, &stats[0][0]);
+				++order->n_group_calls;
+			}
 			order->ns_engine += KmcOrderedEmit::now_ns() - t1;
 			if (rc != 0) {
 				std::ostringstream ostr;
-				ostr << "Error: stage-2 bin engine failed on bin " << bin_id << " (code " << rc << "): " << engine->last_error();
+				ostr << "Error: stage-2 bin engine failed on bin " << grp[0].bin_id;
+				if (grp.size() > 1)
+					ostr << " .. " << grp.back().bin_id << " (one call)";
+				ostr << " (code " << rc << "): " << engine->last_error();
 				CCriticalErrorHandler::Inst().HandleCriticalError(ostr.str());
 			}
 
-			/* the CPU sorter's working slots are never used here, but the region only recycles once every
-			 * slot of the bin is released (queues.h:1556-1583) */
-			memory_bins->free(bin_id, CMemoryBins::mba_input_file);
-			memory_bins->free(bin_id, CMemoryBins::mba_input_array);
-			memory_bins->free(bin_id, CMemoryBins::mba_tmp_array);
-			if (max_x && n_plus_x_recs)
-				memory_bins->free(bin_id, CMemoryBins::mba_kxmer_counters);
+			for (size_t i = 0; i < grp.size(); ++i) {
+				Taken &t = grp[i];
+				/* the CPU sorter's working slots are never used here, but the region only recycles once every
+				 * slot of the bin is released (queues.h:1556-1583) */
+				memory_bins->free(t.bin_id, CMemoryBins::mba_input_file);
+				memory_bins->free(t.bin_id, CMemoryBins::mba_input_array);
+				memory_bins->free(t.bin_id, CMemoryBins::mba_tmp_array);
+				if (max_x && t.n_plus_x_recs)
+					memory_bins->free(t.bin_id, CMemoryBins::mba_kxmer_counters);
 
-			/* data packs exactly as the reference emits them: one pack [0,out_bytes); none when output is off,
-			 * and none for an empty bin on the k+x-mer path (kb_sorter.h:967-968,1105-1106,1269-1271) */
-			list<pair<uint64, uint64>> data_packs;
-			if (!bp.without_output && !(max_x && n_plus_x_recs == 0))
-				data_packs.emplace_back(0, out_bytes);
-			{
-				const long long t2 = KmcOrderedEmit::now_ns();
-				std::unique_lock<std::mutex> lck(order->emit_mtx);
-				order->cv.wait(lck, [&] { return order->next_emit == seq; });
-				const long long t3 = KmcOrderedEmit::now_ns();
-				kq->push(bin_id, out_buffer, data_packs, raw_lut, lut_recs * sizeof(uint64), stats[0], stats[1], stats[2],
-				         stats[3]);
-				++order->next_emit;
-				order->ns_turn += t3 - t2;
-				order->ns_push += KmcOrderedEmit::now_ns() - t3;
+				/* data packs exactly as the reference emits them: one pack [0,out_bytes); none when output is off,
+				 * and none for an empty bin on the k+x-mer path (kb_sorter.h:967-968,1105-1106,1269-1271) */
+				list<pair<uint64, uint64>> data_packs;
+				if (!bp.without_output && !(max_x && t.n_plus_x_recs == 0))
+					data_packs.emplace_back(0, out_bytes[i]);
+				{
+					const long long t2 = KmcOrderedEmit::now_ns();
+					std::unique_lock<std::mutex> lck(order->emit_mtx);
+					order->cv.wait(lck, [&] { return order->next_emit == t.seq; });
+					const long long t3 = KmcOrderedEmit::now_ns();
+					kq->push(t.bin_id, t.out_buffer, data_packs, t.raw_lut, lut_recs * sizeof(uint64), stats[i][0], stats[i][1], stats[i][2], stats[i][3]);
+					++order->next_emit;
+					order->ns_turn += t3 - t2;
+					order->ns_push += KmcOrderedEmit::now_ns() - t3;
+				}
+				order->cv.notify_all();
+				++order->n_bins;
+				if (t.n_sorting_threads)
+					sorters_manager->ReturnThreads(t.n_sorting_threads, t.bin_id);
 			}
-			order->cv.notify_all();
-			++order->n_bins;
-
-			sorters_manager->ReturnThreads(n_sorting_threads, bin_id);
 		}
 		order->ns_worker_wall += KmcOrderedEmit::now_ns() - t_start;
 		if (++order->n_workers_done == n_workers) {

@@ -86,7 +86,7 @@ struct KmcOrderedEmit {
 	/* KMC_HIP_VERBOSE=1: nanoseconds summed over threads */
 	std::atomic<long long> ns_reader_init{0}, ns_reader_read{0}, ns_reader_wall{0}, ns_getnext{0}, ns_engine{0}, ns_turn{0}, ns_push{0},
 	    ns_worker_wall{0};
-	std::atomic<long long> n_bins{0}, n_workers_done{0}, n_readers{0};
+	std::atomic<long long> n_bins{0}, n_workers_done{0}, n_readers{0}, n_group_calls{0};
 	static long long now_ns()
 	{
 		return std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now().time_since_epoch()).count();
@@ -97,9 +97,10 @@ struct KmcOrderedEmit {
 			return;
 		fprintf(stderr,
 		        "[kmc_hip stage 2] %lld bins, %d workers, %lld reader threads | reader: admit %.3f s, read %.3f s (summed), wall %.3f s | workers "
-		        "(summed over threads): wait for a bin %.3f s, engine %.3f s, wait for the turn to push %.3f s, push %.3f s, wall %.3f s\n",
+		        "(summed over threads): wait for a bin %.3f s, engine %.3f s, wait for the turn to push %.3f s, push %.3f s, wall %.3f s | %lld engine calls "
+		        "with several bins\n",
 		        n_bins.load(), n_workers, n_readers.load(), ns_reader_init.load() * 1e-9, ns_reader_read.load() * 1e-9, ns_reader_wall.load() * 1e-9,
-		        ns_getnext.load() * 1e-9, ns_engine.load() * 1e-9, ns_turn.load() * 1e-9, ns_push.load() * 1e-9, ns_worker_wall.load() * 1e-9);
+		        ns_getnext.load() * 1e-9, ns_engine.load() * 1e-9, ns_turn.load() * 1e-9, ns_push.load() * 1e-9, ns_worker_wall.load() * 1e-9, n_group_calls.load());
 	}
 
 	static std::shared_ptr<KmcOrderedEmit> for_queue(CKmerQueue *kq)

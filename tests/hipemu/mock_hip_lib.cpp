@@ -54,6 +54,7 @@ struct kmc_hip_ctx {
 	struct Pending {
 		uint64_t out_bytes = 0, stats[4] = {0, 0, 0, 0};
 		int rc = 0;
+		std::vector<uint64_t> grp_out_bytes, grp_stats; /* kmc_hip_process_bins_submit: per bin */
 	} pending[64][16];
 	std::mutex mtx;
 };
@@ -112,6 +113,33 @@ MOCK_API int kmc_hip_process_bin_wait(kmc_hip_ctx *ctx, int dev, int slot, uint6
 	kmc_hip_ctx::Pending &pd = ctx->pending[dev][slot];
 	*out_bytes = pd.out_bytes;
 	memcpy(stats, pd.stats, sizeof pd.stats);
+	return pd.rc ? fail(KMC_HIP_ECORRUPT, "mock: oracle_process_bin failed") : 0;
+}
+MOCK_API int kmc_hip_process_bins_submit(kmc_hip_ctx *ctx, int dev, int slot, const kmc_hip_bin_params *p, const kmc_hip_host_bin *bins, uint32_t n_bins)
+{
+	if (!ctx || dev < 0 || dev >= ctx->n_dev || slot < 0 || slot >= 4 || !p || !bins || n_bins < 1 || n_bins > 16)
+		return fail(KMC_HIP_EINVAL, "mock submit (bins): bad arguments");
+	kmc_hip_ctx::Pending &pd = ctx->pending[dev][slot];
+	pd.grp_out_bytes.assign(n_bins, 0);
+	pd.grp_stats.assign(4 * (size_t)n_bins, 0);
+	int first_rc = 0;
+	for (uint32_t i = 0; i < n_bins; ++i) { /* every bin on its own through the single-bin mock: the oracle per bin */
+		if (int rc = kmc_hip_process_bin_submit(ctx, dev, slot, p, bins[i].superkmers, bins[i].size, bins[i].n_rec, bins[i].pack_bytes, bins[i].n_packs, bins[i].out_suffix,
+		                                        bins[i].out_capacity, bins[i].lut))
+			return rc;
+		if (pd.rc && !first_rc)
+			first_rc = pd.rc;
+		pd.grp_out_bytes[i] = pd.out_bytes;
+		memcpy(&pd.grp_stats[4 * i], pd.stats, sizeof pd.stats);
+	}
+	pd.rc = first_rc;
+	return 0;
+}
+MOCK_API int kmc_hip_process_bins_wait(kmc_hip_ctx *ctx, int dev, int slot, uint64_t *out_bytes, uint64_t *stats)
+{
+	kmc_hip_ctx::Pending &pd = ctx->pending[dev][slot];
+	memcpy(out_bytes, pd.grp_out_bytes.data(), pd.grp_out_bytes.size() * 8);
+	memcpy(stats, pd.grp_stats.data(), pd.grp_stats.size() * 8);
 	return pd.rc ? fail(KMC_HIP_ECORRUPT, "mock: oracle_process_bin failed") : 0;
 }
 MOCK_API int kmc_hip_split_set_map(kmc_hip_ctx *ctx, int dev, const int32_t *sig_to_bin, uint32_t signature_len)

@@ -605,6 +605,68 @@ def test_two_devices_worker_allreduce_and_wide_records(ref_bins, tmp_path):
         assert _md5(str(tmp_path / ("ref" + ext))) == _md5(str(tmp_path / ("hip" + ext))), ext
 
 
+# ------------------------------------------------------------------------------------------------ several bins per host-boundary call
+HOST_GROUP_CASES = [
+    (27, dict(lut_prefix_len=3), 7),
+    (27, dict(lut_prefix_len=7, cutoff_min=1, cutoff_max=50, counter_max=20), 4),
+    (55, dict(lut_prefix_len=3), 5),
+    (127, dict(lut_prefix_len=3, cutoff_min=1), 6),
+    (32, dict(lut_prefix_len=4), 3),       # no spare bits: every bin sorted on its own, still one call
+    (25, dict(lut_prefix_len=1), 15),      # 6 spare bits: groups of 16
+    (27, dict(output_type=1), 4),          # KFF records
+    (21, dict(lut_prefix_len=1, both_strands=0, without_output=1), 4),
+]
+
+
+@pytest.mark.parametrize("k,kw,n_bins", HOST_GROUP_CASES, ids=lambda v: str(v) if not isinstance(v, dict) else "-".join(f"{a}{b}" for a, b in v.items()))
+@pytest.mark.parametrize("hybrid", [0, 2], ids=["lsd", "hybrid"])
+def test_host_boundary_with_several_bins_per_call_matches_the_oracle_per_bin(ctx, k, kw, n_bins, hybrid):
+    """kmc_hip_process_bins_submit/_wait: the bins of one call are uploaded together and sorted together (tags in the spare bits of the top digit), every
+    bin gets its own records, LUT and tallies — those of kmc_hip_process_bin. With caller-supplied packs and without, an empty bin among them."""
+    before = ctx.set_hybrid(hybrid)
+    try:
+        bins = capi.synth_bins(seed=41, genome_len=40_000, n_reads=8_000, k=k, n_bins=n_bins)
+        p = hp(k, **kw)
+        hb = [(img, nrec, packs if i % 2 else None) for i, (img, nrec, packs, _) in enumerate(bins)]
+        hb.insert(2, (np.zeros(0, np.uint8), 0, None))
+        got = ctx.process_bins_host(p, hb, slot=5)
+        for i, (img, nrec, _) in enumerate(hb):
+            w = O.process_bin(op(p), img, nrec) if nrec else (np.zeros(0, np.uint8), np.zeros(ctx.lut_entries(p), np.uint64), np.zeros(4, np.uint64))
+            assert np.array_equal(got[i][0], w[0]) and np.array_equal(got[i][1], w[1]) and np.array_equal(got[i][2], w[2]), (i, got[i][2], w[2])
+    finally:
+        ctx.set_hybrid(before)
+
+
+def test_host_boundary_group_redo_errors_and_slot_reuse(ctx):
+    before = ctx.set_hybrid(2)
+    try:
+        bins = capi.synth_bins(seed=5, genome_len=300, n_reads=20_000, k=27, n_bins=3, err=0.0)  # one k-mer thousands of times: the hybrid sort hands the group back
+        p = hp(27)
+        r0 = ctx.local_sort_totals()["redo_groups"]
+        got = ctx.process_bins_host(p, [(b[0], b[1], b[2]) for b in bins])
+        for i, b in enumerate(bins):
+            w = O.process_bin(op(p), b[0], b[1])
+            assert all(np.array_equal(x, y) for x, y in zip(got[i], w)), i
+        assert ctx.local_sort_totals()["redo_groups"] > r0
+    finally:
+        ctx.set_hybrid(before)
+    img, nk, packs = binsynth.random_bin(np.random.default_rng(1), 27, 500, max_extra=20)
+    with pytest.raises(capi.KmcHipError) as e:
+        ctx.process_bins_host(p, [(bins[0][0], bins[0][1], bins[0][2]), (img, nk + 1, packs)])
+    assert e.value.code == -4  # KMC_HIP_ECORRUPT
+    with pytest.raises(capi.KmcHipError) as e:
+        ctx.process_bins_host(hp(27, cutoff_min=1), [(img, nk, packs)] * 2, out_capacity=8)
+    assert e.value.code == -5  # KMC_HIP_ECAPACITY
+    with pytest.raises(capi.KmcHipError) as e:
+        ctx.process_bins_host(p, [(img, nk, packs)] * 17)
+    assert e.value.code == -1
+    w = O.process_bin(op(p), img, nk)  # the slot is usable afterwards, by either kind of call
+    got = ctx.process_bins_host(p, [(img, nk, packs)])
+    assert all(np.array_equal(x, y) for x, y in zip(got[0], w))
+    got = ctx.process_bin(p, img, nk, packs)
+    assert all(np.array_equal(x, y) for x, y in zip(got, w))
+
+
 # ------------------------------------------------------------------------------------------------ one bin over several devices
 MULTI_CASES = [
     (27, dict(lut_prefix_len=3), 2),

@@ -70,6 +70,24 @@ def test_product_binary_over_the_emulated_host_library_writes_the_reference_data
     assert "parts through the engine" in got[2] and "[kmc_hip stage 2] 64 bins, 2 workers" in got[2]
 
 
+def test_worker_hands_waiting_bins_to_the_engine_together(tmp_path):
+    """kb_sorter_plugin.h: a worker that finds more bins waiting takes up to KMC_HIP_WORKER_GROUP of them (CBinQueue::pop_if_any, never waiting) and
+    hands them to kmc_hip_process_bins_submit/_wait in one call, where they share one sort; the database stays the reference's, with groups of 4
+    (default), 16, and with grouping off."""
+    if not os.path.exists(_exe("kmc_hip")):
+        pytest.skip("kmc_amd/bin/kmc_hip not built (needs /root/reference)")
+    lib = emu.build_hostlib("small")
+    fq = str(tmp_path / "in.fq")
+    synth.make_fastq(fq, seed=11, genome_len=30_000, n_reads=1_500, read_len=150)
+    common = ["-k27", "-ci1", "-m2", "-sf1", "-n64", "-sp1"]
+    want = _run("kmc", common + ["-sr1"], fq, tmp_path, "ref")
+    for grp, several in (("4", True), ("16", True), ("1", False)):
+        got = _run("kmc_hip", common + ["-sr2"], fq, tmp_path, "g" + grp, env={"KMC_HIP_LIB": lib, "KMC_HIP_VERBOSE": "1", "KMC_HIP_WORKER_GROUP": grp})
+        assert got[:2] == want[:2], grp
+        calls = int(got[2].split(" engine calls with several bins")[0].split()[-1])
+        assert (calls > 0) == several, (grp, calls)
+
+
 def test_two_emulated_devices_context_wide_records_allreduce_and_dropin(tmp_path):
     """the multi-device code of the host library and of the worker loader on TWO emulated devices (HIPEMU_DEVICES=2) — no box this repo has seen
     had two GPUs, so this is where `KMC_HIP_DEVICES=0,1`, the per-device function attributes and kmc_hip_allreduce_stats over two devices run
@@ -118,6 +136,24 @@ for i, (img, nrec, packs, _) in enumerate(bins):
     w = O.process_bin(op, img, nrec)
     assert np.array_equal(got[i][0], w[0]) and np.array_equal(got[i][1], w[1]) and np.array_equal(got[i][2], w[2]), i
 assert ctx.local_sort_totals()["redo_groups"] >= 1
+# the host boundary with several bins per call (kmc_hip_process_bins_submit/_wait): sorted together, results per bin; an empty bin among them
+for k, pl, kw, nb in ((27, 3, {}, 7), (55, 3, {"cutoff_min": 1}, 5), (27, 0, {"output_type": 1}, 4), (32, 4, {}, 3), (25, 1, {}, 15)):
+    bins = capi.synth_bins(seed=7, genome_len=6000, n_reads=1500, k=k, n_bins=nb, n_threads=1)
+    p = capi.make_params(k, lut_prefix_len=pl, **kw)
+    op = O.make_params(p.kmer_len, p.both_strands, p.cutoff_min, p.cutoff_max, p.counter_max, p.lut_prefix_len, p.output_type, p.without_output)
+    hb = [(img, nrec, packs if i & 1 else None) for i, (img, nrec, packs, _) in enumerate(bins)]
+    hb.insert(2, (np.zeros(0, np.uint8), 0, None))
+    got = ctx.process_bins_host(p, hb, slot=3)
+    for i, (img, nrec, _) in enumerate(hb):
+        w = O.process_bin(op, img, nrec) if nrec else (np.zeros(0, np.uint8), np.zeros(ctx.lut_entries(p), np.uint64), np.zeros(4, np.uint64))
+        assert np.array_equal(got[i][0], w[0]) and np.array_equal(got[i][1], w[1]) and np.array_equal(got[i][2], w[2]), (k, i)
+bins = capi.synth_bins(seed=5, genome_len=300, n_reads=1500, k=27, n_bins=3, err=0.0, n_threads=1)  # ... and a group that comes back for LSD passes
+before = ctx.local_sort_totals()["redo_groups"]
+got = ctx.process_bins_host(capi.make_params(27), [(b[0], b[1], b[2]) for b in bins])
+for i, b in enumerate(bins):
+    w = O.process_bin(O.make_params(27), b[0], b[1])
+    assert np.array_equal(got[i][0], w[0]) and np.array_equal(got[i][1], w[1]) and np.array_equal(got[i][2], w[2]), i
+assert ctx.local_sort_totals()["redo_groups"] > before
 rng = np.random.default_rng(3)
 a = rng.integers(0, 2**54, size=(5000, 1), dtype=np.uint64)
 assert np.array_equal(ctx.sort_records(a, 7), O.sort(a))
@@ -127,7 +163,8 @@ print("HYBRID-OK")
 
 def test_hybrid_sort_on_the_emulated_host_library():
     """bucket_sort.hip.h on the CPU: k_bucket_bounds + k_bucket_count (groups of bins, k = 27 / 55, KFF records) and k_bucket_sort (sort-only call)
-    against the oracle, and the redo of a group whose tile does not fit — through the product's host library over the emulated runtime."""
+    against the oracle, and the redo of a group whose tile does not fit — through the product's host library over the emulated runtime; and the host
+    boundary with several bins per call (kmc_hip_process_bins_submit/_wait), hybrid and redo included."""
     lib = emu.build_hostlib("small")
     r = subprocess.run([sys.executable, "-c", _HYBRID_CASE % {"root": ROOT}], env=dict(os.environ, KMC_HIP_LIB=lib), capture_output=True, text=True, timeout=1500, cwd=ROOT)
     assert r.returncode == 0 and "HYBRID-OK" in r.stdout, (r.stdout + r.stderr)[-1500:]
