@@ -354,6 +354,190 @@ __global__ void __launch_bounds__(BsCfg<SIZE>::THREADS) k_bucket_sort(u64 *__res
 	}
 }
 
+/* ------------------------------------------------------------------------------------------------ one-word records: rank inside the bucket
+ * k_bucket_sort finishes a sub-bucket with ONE thread; for one-word k-mers at sequencing depth a bucket is the ~30 copies of one k-mer plus a few
+ * one-off neighbours (read errors below the bucket bits), those land in the same sub-bucket interleaved, and the thread that owns it walks them
+ * serially while 29 of 30 threads have nothing to do. Here every record finds its own place, all at once:
+ *       place(i) = bucket start + #{ j in the bucket : (rem_j, j) < (rem_i, i) }        rem = the key bits below the bucket bits
+ * The pair is one word — rem above, bucket-relative index below: 32 bits whenever the tile's largest bucket leaves room for its indices next to rem (always,
+ * on sequencing data with 24 key bits left), else 64 with the index in the low 16 — so a step of the count is an LDS read (the lanes of a bucket read the
+ * same address: a broadcast), a compare and an add-with-carry; the wave takes as many steps as its largest bucket has records (the bench's bins with the
+ * top 30 key bits ordered: 25 on average). Stable (ties go by index), no atomics, no
+ * data-dependent failure: the only thing it cannot take is a bucket larger than the tile (flag -> the host's LSD passes, as in k_bucket_sort).
+ * Work grows with sum(bucket^2): the host asks for enough HBM passes to keep buckets at a few dozen records (plan_sort). Needs
+ * key_bits - hbits <= 48. The sorted tile goes back in place; run lengths, cutoffs and output are k_compact's, unchanged. */
+__global__ void __launch_bounds__(BsCfg<1>::THREADS) k_bucket_rank(u64 *__restrict__ recs, u32 key_bits, u32 hbits, const u64 *__restrict__ bounds, u32 *flag)
+{
+	constexpr int THREADS = BsCfg<1>::THREADS, ITEMS = BsCfg<1>::ITEMS, CAP = BsCfg<1>::CAP, NW = THREADS / 64;
+	constexpr u64 S = BsCfg<1>::STRIDE;
+	constexpr u32 NONE = 0xFFFFFFFFu;
+	KMC_DYN_LDS(unsigned char, s_raw);
+	u64 *s_key = reinterpret_cast<u64 *>(s_raw);                          /* [CAP] (rem, index) pairs, then the records in order */
+	u32 *s_wfirst = reinterpret_cast<u32 *>(s_key + CAP), *s_wlast = s_wfirst + NW; /* [NW] each: first / last bucket start inside wave w's rows */
+	u32 *s_wmax = s_wlast + NW;                                                      /* [NW] largest bucket a wave has seen */
+
+	const u64 j = blockIdx.x;
+	const u64 b0 = bounds[j], b1 = bounds[j + 1];
+	if (b0 >= (j + 1) * S || b0 >= b1)
+		return; /* no bucket starts in this window */
+	if (b1 - b0 > (u64)CAP) {
+		if (threadIdx.x == 0)
+			atomicOr(flag, 1u);
+		return;
+	}
+	const u32 len = (u32)(b1 - b0);
+	const u32 tid = threadIdx.x, lane = tid & 63;
+	const u32 wave = (u32)__builtin_amdgcn_readfirstlane((int)(tid >> 6));
+	u64 *__restrict__ T = recs + b0;
+	const u32 crel = wave * (ITEMS * 64); /* the wave owns ITEMS rows of 64 consecutive records */
+
+	u64 key[ITEMS];
+#pragma unroll
+	for (int r = 0; r < ITEMS; ++r) {
+		const u32 idx = crel + r * 64 + lane;
+		key[r] = idx < len ? T[idx] : 0ull;
+	}
+	const u32 ksh = 64 - key_bits, bsh = 64 - hbits;
+	auto bucket_of = [&](u64 x) -> u64 { return hbits ? (x << ksh) >> bsh : 0ull; };
+	u64 prev_last = 0;
+	if (crel > 0 && crel - 1 < len)
+		prev_last = bucket_of(T[crel - 1]);
+	u64 heads[ITEMS];
+	u32 wfirst = NONE, wlast = NONE;
+#pragma unroll
+	for (int r = 0; r < ITEMS; ++r) {
+		const u32 rowrel = crel + r * 64, idx = rowrel + lane;
+		const u64 bk = bucket_of(key[r]);
+		u64 pv = __shfl_up(bk, 1);
+		if (lane == 0)
+			pv = prev_last;
+		const u64 m = __ballot(idx < len && (idx == 0 || pv != bk));
+		heads[r] = m;
+		if (m) {
+			if (wfirst == NONE)
+				wfirst = rowrel + (u32)__ffsll((long long)m) - 1;
+			wlast = rowrel + 63 - (u32)__clzll((long long)m);
+		}
+		prev_last = __shfl(bk, 63);
+	}
+	if (lane == 0) {
+		s_wfirst[wave] = wfirst;
+		s_wlast[wave] = wlast;
+	}
+	__syncthreads();
+	u32 carry_f = 0, carry_b = len; /* start of the bucket open at the wave's first record; first bucket start after the wave's last record */
+#pragma unroll
+	for (int w = 0; w < NW; ++w) {
+		const u32 l = s_wlast[w], f = s_wfirst[NW - 1 - w];
+		if (w < (int)wave && l != NONE)
+			carry_f = l;
+		if (NW - 1 - w > (int)wave && f != NONE)
+			carry_b = f;
+	}
+	carry_f = (u32)__builtin_amdgcn_readfirstlane((int)carry_f);
+	carry_b = (u32)__builtin_amdgcn_readfirstlane((int)carry_b);
+	u32 span[ITEMS]; /* [15:0] start of the record's bucket, [31:16] its end (tile-relative; CAP < 65536) */
+#pragma unroll
+	for (int r = ITEMS - 1; r >= 0; --r) {
+		const u32 rowrel = crel + r * 64;
+		const u64 m = heads[r];
+		const u64 above = m & ~(((2ull << lane) - 1));
+		span[r] = (above ? rowrel + (u32)__ffsll((long long)above) - 1 : carry_b) << 16;
+		if (m)
+			carry_b = rowrel + (u32)__ffsll((long long)m) - 1;
+	}
+	const u32 rbits = key_bits - hbits; /* <= 48 (host) */
+	const u64 rmask = rbits >= 64 ? ~0ull : ((1ull << rbits) - 1);
+	u32 rel[ITEMS], widest = 0;
+#pragma unroll
+	for (int r = 0; r < ITEMS; ++r) {
+		const u32 rowrel = crel + r * 64, idx = rowrel + lane;
+		const u64 m = heads[r];
+		const u64 upto = m & ((2ull << lane) - 1);
+		const u32 bstart = upto ? rowrel + 63 - (u32)__clzll((long long)upto) : carry_f;
+		if (m)
+			carry_f = rowrel + 63 - (u32)__clzll((long long)m);
+		span[r] |= bstart;
+		rel[r] = idx - bstart;
+		if (idx < len)
+			widest = widest > (span[r] >> 16) - bstart ? widest : (span[r] >> 16) - bstart;
+		else
+			span[r] = 0; /* nothing to count */
+	}
+	/* the largest bucket of the tile decides the width of the pairs: (rem, index) in 32 bits whenever they fit — half the LDS traffic and one-pass compares */
+#pragma unroll
+	for (int o = 32; o >= 1; o >>= 1) {
+		const u32 other = (u32)__shfl((int)widest, (int)(lane ^ (u32)o));
+		widest = widest > other ? widest : other;
+	}
+	if (lane == 0)
+		s_wmax[wave] = widest;
+	__syncthreads();
+#pragma unroll
+	for (int w = 0; w < NW; ++w)
+		widest = widest > s_wmax[w] ? widest : s_wmax[w];
+	const bool narrow = rbits < 32 && widest <= (1u << (32 - rbits));
+	u32 place[ITEMS];
+	if (narrow) {
+		u32 *s_k32 = reinterpret_cast<u32 *>(s_key);
+		const u32 sh = 32 - rbits;
+		u32 c32[ITEMS];
+#pragma unroll
+		for (int r = 0; r < ITEMS; ++r) {
+			const u32 idx = crel + r * 64 + lane;
+			c32[r] = ((u32)(key[r] & rmask) << sh) | rel[r]; /* rel < widest <= 2^sh */
+			if (idx < len)
+				s_k32[idx] = c32[r];
+		}
+		__syncthreads();
+#pragma unroll
+		for (int r = 0; r < ITEMS; ++r) {
+			const u32 bstart = span[r] & 0xFFFFu, bend = span[r] >> 16;
+			const u32 c = c32[r];
+			u32 rank = 0, q = bstart;
+			for (; q + 4 <= bend; q += 4) {
+				const u32 a0 = s_k32[q], a1 = s_k32[q + 1], a2 = s_k32[q + 2], a3 = s_k32[q + 3];
+				rank += (a0 < c ? 1u : 0u) + (a1 < c ? 1u : 0u) + (a2 < c ? 1u : 0u) + (a3 < c ? 1u : 0u);
+			}
+			for (; q < bend; ++q)
+				rank += s_k32[q] < c ? 1u : 0u;
+			place[r] = bstart + rank;
+		}
+	} else {
+#pragma unroll
+		for (int r = 0; r < ITEMS; ++r) {
+			const u32 idx = crel + r * 64 + lane;
+			if (idx < len)
+				s_key[idx] = ((key[r] & rmask) << 16) | (u64)rel[r];
+		}
+		__syncthreads();
+#pragma unroll
+		for (int r = 0; r < ITEMS; ++r) {
+			const u32 bstart = span[r] & 0xFFFFu, bend = span[r] >> 16;
+			const u64 c = ((key[r] & rmask) << 16) | (u64)rel[r];
+			u32 rank = 0, q = bstart;
+			for (; q + 2 <= bend; q += 2) {
+				const u64 a = s_key[q], b = s_key[q + 1];
+				rank += (a < c ? 1u : 0u) + (b < c ? 1u : 0u);
+			}
+			if (q < bend)
+				rank += s_key[q] < c ? 1u : 0u;
+			place[r] = bstart + rank;
+		}
+	}
+	__syncthreads(); /* every pair has been read */
+#pragma unroll
+	for (int r = 0; r < ITEMS; ++r) {
+		const u32 idx = crel + r * 64 + lane;
+		if (idx < len)
+			s_key[place[r]] = key[r];
+	}
+	__syncthreads();
+	for (u32 idx = tid; idx < len; idx += THREADS)
+		T[idx] = s_key[idx];
+}
+constexpr size_t br_lds_bytes() { return (size_t)BsCfg<1>::CAP * 8 + 3 * (BsCfg<1>::THREADS / 64) * 4 + 16; }
+
 /* ================================================================================================ fused: tile -> (k-mer, count) records
  * What stage 2 wants from the sort is not the sorted records but the RUNS of equal k-mers: ascending distinct k-mers with their counts
  * (kb_sorter.h:1128-1281). All copies of a k-mer share their bucket, hence their tile, hence their sub-bucket — so a tile can be counted

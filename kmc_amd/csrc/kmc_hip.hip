@@ -343,6 +343,7 @@ struct BinPlan {
 struct SortPlan {
 	u32 key_bytes = 0, top = 0;
 	u32 key_bits = 0; /* significant bits of the key (2k + tag bits; 8 key_bytes when the caller cannot tell) */
+	bool rank = false; /* one-word records: the LDS half is k_bucket_rank (sorts the tile in place; k_compact follows) */
 	u32 pass_lo() const { return key_bytes - top; }
 	bool local() const { return top < key_bytes; }
 	u32 hbits() const { return top ? 8 * top - (8 * key_bytes - key_bits) : 0; } /* top bits of the significant key that the HBM passes order (plan_sort: 8 top > spare bits) */
@@ -371,7 +372,17 @@ int hybrid_mode()
 	}();
 	return v;
 }
-template <int SIZE> SortPlan plan_sort(u64 n, u32 key_bytes, u32 key_bits, bool classic, bool fused = false /* k_bucket_count's tiles, not k_bucket_sort's */)
+bool rank_enabled()
+{
+	static const bool v = [] {
+		const char *e = getenv("KMC_HIP_RANK"); /* 0: groups of one-word records keep the LSD passes over every byte */
+		return !e || atoi(e) != 0;
+	}();
+	return v;
+}
+template <int SIZE>
+SortPlan plan_sort(u64 n, u32 key_bytes, u32 key_bits, bool classic, bool fused = false /* k_bucket_count's tiles, not k_bucket_sort's */,
+                   bool rank = false /* one-word records of a group: k_bucket_rank + k_compact */)
 {
 	SortPlan sp;
 	sp.key_bytes = sp.top = key_bytes;
@@ -379,13 +390,17 @@ template <int SIZE> SortPlan plan_sort(u64 n, u32 key_bytes, u32 key_bits, bool 
 	const int mode = hybrid_mode();
 	if (classic || mode == 0 || key_bytes < 3 || n < 2)
 		return sp;
-	if (mode == 1 && (SIZE == 1 || !fused))
+	if (mode == 1 && (SIZE == 1 || !fused) && !rank)
 		return sp;
 	const u32 spare = 8 * key_bytes - key_bits;
 	if (mode < 0) {
 		const u32 h = (u32)(-mode);
 		if (h + 1 <= key_bytes && 8 * h > spare)
 			sp.top = h;
+		if (rank && sp.local() && key_bits - sp.hbits() <= 48)
+			sp.rank = true;
+		else if (rank)
+			sp.top = key_bytes;
 		return sp;
 	}
 	const u64 redo = g_redo_groups.load(std::memory_order_relaxed);
@@ -398,7 +413,9 @@ template <int SIZE> SortPlan plan_sort(u64 n, u32 key_bytes, u32 key_bits, bool 
 			ok = !fused && n <= (u64)BsCfg<SIZE>::CAP; /* groups always take one pass at least: the bins' tags must be ordered */
 		else {
 			const u32 eff = 8 * h > spare ? 8 * h - spare : 0;
-			ok = eff > 0 && (eff >= 63 || (n >> eff) <= (fused ? bc_target_bucket<SIZE>() : bs_target_bucket<SIZE>()));
+			/* rank: k-mers of a signature bin that begin with the bin's minimizers share ~18 bits, so buckets are as fine as the passes allow (the work grows
+			 * with the square of a bucket) */
+			ok = eff > 0 && (eff >= 63 || (n >> eff) <= (rank ? 2 : (fused ? bc_target_bucket<SIZE>() : bs_target_bucket<SIZE>())));
 		}
 		if (ok) {
 			sp.top = h;
@@ -410,6 +427,18 @@ template <int SIZE> SortPlan plan_sort(u64 n, u32 key_bytes, u32 key_bits, bool 
 		sp.top = std::min(std::min(sp.top + extra, 4u), key_bytes);
 		if (sp.top + 2 > key_bytes)
 			sp.top = key_bytes;
+	}
+	if (rank) {
+		static const int forced = [] {
+			const char *e = getenv("KMC_HIP_RANK_TOP"); /* tuning: this many top bytes through HBM */
+			return e ? atoi(e) : 0;
+		}();
+		if (forced >= 1 && (u32)forced + 1 <= key_bytes && 8 * (u32)forced > spare)
+			sp.top = (u32)forced;
+		if (sp.local() && sp.top >= 1 && key_bits - sp.hbits() <= 48)
+			sp.rank = true;
+		else
+			sp.top = key_bytes; /* the pair (key bits below the bucket, index) must fit one word */
 	}
 	return sp;
 }
@@ -543,7 +572,13 @@ int sort_device_t(Slot &s, const ZeroPlan &z, u64 *d_recs, u64 *d_tmp, u64 n, co
 		gbn.n[0] = n;
 		gbn.bounds[0] = bounds;
 		k_bucket_bounds<SIZE><<<dim3((u32)((n_win + 1 + 3) / 4)), dim3(256), 0, s.stream>>>(gbn, (u32)S, sp.key_bits, sp.hbits());
-		k_bucket_sort<SIZE><<<dim3((u32)n_win), dim3(BsCfg<SIZE>::THREADS), bs_lds_bytes<SIZE>(), s.stream>>>(src, sp.key_bits, sp.hbits(), bounds, d_flag);
+		if constexpr (SIZE == 1) {
+			if (sp.rank)
+				k_bucket_rank<<<dim3((u32)n_win), dim3(BsCfg<1>::THREADS), br_lds_bytes(), s.stream>>>(src, sp.key_bits, sp.hbits(), bounds, d_flag);
+			else
+				k_bucket_sort<SIZE><<<dim3((u32)n_win), dim3(BsCfg<SIZE>::THREADS), bs_lds_bytes<SIZE>(), s.stream>>>(src, sp.key_bits, sp.hbits(), bounds, d_flag);
+		} else
+			k_bucket_sort<SIZE><<<dim3((u32)n_win), dim3(BsCfg<SIZE>::THREADS), bs_lds_bytes<SIZE>(), s.stream>>>(src, sp.key_bits, sp.hbits(), bounds, d_flag);
 		if (s.timed)
 			HIPCHK(hipEventRecord(e1, s.stream));
 	}
@@ -900,7 +935,10 @@ int run_group_device_t(Slot &s, const DevParams &P, const kmc_hip_bin_desc *cons
 	const u32 key_bytes = (2 * k + tag_bits + 7) / 8;
 	/* hybrid: only the top bytes of the key go through HBM passes, the rest is sorted inside LDS (bucket_sort.hip.h) */
 	/* ... and then the tiles are counted where they lie (k_bucket_count): possible whenever a tile's records fit its span of the free array */
-	const SortPlan sp = plan_sort<SIZE>(N, key_bytes, 2 * k + tag_bits, classic || !count_applicable<SIZE>(P), true);
+	/* one-word records (k <= 32) of a default run: the top bytes through HBM, every tile put in order inside LDS by k_bucket_rank, then k_compact as ever */
+	const bool by_rank = SIZE == 1 && !classic && hybrid_mode() == 1 && rank_enabled();
+	const SortPlan sp = by_rank ? plan_sort<SIZE>(N, key_bytes, 2 * k + tag_bits, false, false, true)
+	                            : plan_sort<SIZE>(N, key_bytes, 2 * k + tag_bits, classic || !count_applicable<SIZE>(P), true);
 	const u32 n_pass = sp.top;
 	if (used_hybrid)
 		*used_hybrid = sp.local() && N >= 2;
@@ -910,7 +948,7 @@ int run_group_device_t(Slot &s, const DevParams &P, const kmc_hip_bin_desc *cons
 	if (N && ((rc = ensure(s.recA, N * SIZE * 8 + 256)) || (rc = ensure(s.recB, N * SIZE * 8 + 256))))
 		return rc;
 	const ZeroPlan z = plan_group<SIZE>(s, bins, N, n_pass, true, true, true, n_sh > 1 ? (u64)n_sh * lut_entries : 0,
-	                                    sp.local() ? (u64)BcCfg<SIZE>::STRIDE : (u64)CpCfg<SIZE>::TILE);
+	                                    sp.local() && !sp.rank ? (u64)BcCfg<SIZE>::STRIDE : (u64)CpCfg<SIZE>::TILE);
 	if ((rc = apply_plan(s, z))) /* ONE memset per group: small block, bitmaps, look-back words, histograms, LUT and tally shards, scatter status */
 		return rc;
 	for (BinPlan &b : bins) { /* resolved only AFTER apply_plan: growing the zero region moves the small block */
@@ -943,7 +981,7 @@ int run_group_device_t(Slot &s, const DevParams &P, const kmc_hip_bin_desc *cons
 	}
 	u64 *sorted = (u64 *)s.recA.p;
 	u32 *const flag = d_flag ? d_flag : small_ptr<u32>(s, SM_REDO);
-	if (N && (rc = sort_device_t<SIZE>(s, z, (u64 *)s.recA.p, (u64 *)s.recB.p, N, sp, &sorted, counter_idx, hist_done, flag, true)))
+	if (N && (rc = sort_device_t<SIZE>(s, z, (u64 *)s.recA.p, (u64 *)s.recB.p, N, sp, &sorted, counter_idx, hist_done, flag, !sp.rank)))
 		return rc;
 	if (s.timed) {
 		if (!N)
@@ -951,7 +989,7 @@ int run_group_device_t(Slot &s, const DevParams &P, const kmc_hip_bin_desc *cons
 		HIPCHK(hipEventRecord(s.ev[4], s.stream));
 	}
 	u64 *const free_array = N ? (sorted == (u64 *)s.recA.p ? (u64 *)s.recB.p : (u64 *)s.recA.p) : nullptr;
-	if (sp.local() && N >= 2)
+	if (sp.local() && !sp.rank && N >= 2)
 		rc = count_group<SIZE>(s, bins, sorted, free_array, P, lut_entries, sp, N, flag);
 	else
 		rc = compact_group<SIZE>(s, bins, sorted, free_array, P, lut_entries, counter_idx);
