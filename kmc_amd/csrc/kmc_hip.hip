@@ -407,15 +407,19 @@ SortPlan plan_sort(u64 n, u32 key_bytes, u32 key_bits, bool classic, bool fused 
 	if (g_extra_top.load(std::memory_order_relaxed) >= 2 && redo > 128 && redo * 8 > g_hybrid_groups.load(std::memory_order_relaxed))
 		return sp; /* this input defeats the bucket tiles even with two passes more */
 	/* the fewest top bytes that leave buckets of bs_target_bucket() records on average, and only if at least two passes are saved */
-	for (u32 h = 0; h + 2 <= key_bytes && h <= 4; ++h) {
+	for (u32 h = 0; h + 2 <= key_bytes && h <= (rank ? 6u : 4u); ++h) { /* (k_bucket_count keeps bucket numbers in 32 bits, k_bucket_rank in 64) */
 		bool ok;
 		if (h == 0)
 			ok = !fused && n <= (u64)BsCfg<SIZE>::CAP; /* groups always take one pass at least: the bins' tags must be ordered */
 		else {
 			const u32 eff = 8 * h > spare ? 8 * h - spare : 0;
-			/* rank: k-mers of a signature bin that begin with the bin's minimizers share ~18 bits, so buckets are as fine as the passes allow (the work grows
-			 * with the square of a bucket) */
-			ok = eff > 0 && (eff >= 63 || (n >> eff) <= (rank ? 2 : (fused ? bc_target_bucket<SIZE>() : bs_target_bucket<SIZE>())));
+			/* rank: the k-mers of a signature bin that BEGIN with one of the bin's minimizers share ~18 key bits, whatever the size of the bin — 1/19 of the
+			 * records in a few hundred prefixes — and the work grows with the square of a bucket: the passes must reach well below those bits (measured:
+			 * 512 bins of 3.2 M k-mers with 22 key bits ordered 17.7 Gk-mers/s, the 7 LSD passes 24.1; 190 M-record groups with 22 bits 7.2, with 30 bits 31.5) */
+			if (rank)
+				ok = eff >= 28 && (eff >= 63 || (n >> eff) <= 2);
+			else
+				ok = eff > 0 && (eff >= 63 || (n >> eff) <= (fused ? bc_target_bucket<SIZE>() : bs_target_bucket<SIZE>()));
 		}
 		if (ok) {
 			sp.top = h;
@@ -424,7 +428,7 @@ SortPlan plan_sort(u64 n, u32 key_bytes, u32 key_bits, bool classic, bool fused 
 	}
 	if (sp.top < key_bytes && sp.top >= 1) { /* finer buckets after a redo, while that still saves passes and the bucket number fits 32 bits */
 		const u32 extra = g_extra_top.load(std::memory_order_relaxed);
-		sp.top = std::min(std::min(sp.top + extra, 4u), key_bytes);
+		sp.top = std::min(std::max(sp.top, std::min(sp.top + extra, 4u)), key_bytes);
 		if (sp.top + 2 > key_bytes)
 			sp.top = key_bytes;
 	}

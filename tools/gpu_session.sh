@@ -44,6 +44,8 @@ t=time.time(); s=capi.synth_bins(seed=2026, genome_len=1000000000, n_reads=20000
     s1prof)  cd /tmp; timeout 120 rocprofv3 --kernel-trace --stats -f csv -d $OLDPWD/$OUT/s1prof -o kt -- python $OLDPWD/tools/s1_bench.py > $OLDPWD/$OUT/s1_bench.json 2> $OLDPWD/$OUT/s1_bench.err; cd $OLDPWD; cat $OUT/s1_bench.json; tail -2 $OUT/s1_bench.err; find $OUT/s1prof -name "*kernel_trace.csv" -delete ;;
     s1part)  timeout 120 python tools/s1_part_bench.py > $OUT/s1_part_bench.json 2> $OUT/s1_part_bench.err; cat $OUT/s1_part_bench.json; tail -2 $OUT/s1_part_bench.err ;;
     s1parts) KMC_HIP_S1_SORTED_EMIT=1 timeout 120 python tools/s1_part_bench.py > $OUT/s1_part_bench_sorted.json 2> $OUT/s1_part_bench_sorted.err; cat $OUT/s1_part_bench_sorted.json; tail -2 $OUT/s1_part_bench_sorted.err ;;
+    b512e:*) e=${step#b512e:}; env $e timeout 600 python bench.py $bins512 --no-oracle-check > $OUT/bins512_$e.json 2> $OUT/bins512_$e.err; python tools/pj.py $OUT/bins512_$e.json | cut -c1-200 ;;
+    onee:*)  e=${step#onee:}; env $e timeout 600 python bench.py $one_bin --no-oracle-check > $OUT/onebin_$e.json 2> $OUT/onebin_$e.err; python tools/pj.py $OUT/onebin_$e.json | cut -c1-200 ;;
     pcie)    timeout 300 python tools/pcie_probe.py > $OUT/pcie_probe.json 2> $OUT/pcie_probe.err; cat $OUT/pcie_probe.json; tail -2 $OUT/pcie_probe.err ;;
     hb:*)    a=${step#hb:}; g=${a%%:*}; t=${a#*:}; timeout 600 python bench.py --cache /dev/shm/kmccache --leg quarter --reads 50000000 --genome 250000000 --bins 128 --steps 2 --warmup 1 --no-digest --no-oracle-check --no-two-streams --no-host-single --host-group $g --host-threads $t > $OUT/hb_${g}_$t.json 2> $OUT/hb_${g}_$t.err; python - <<PYEOF
 import json
