@@ -35,6 +35,14 @@
 #ifndef BS_WORDS_PER_THREAD
 #define BS_WORDS_PER_THREAD 8 /* 8-byte words a thread holds while a tile is loaded */
 #endif
+#ifndef BR_SLACK_DIV
+#define BR_SLACK_DIV 12 /* k_bucket_rank: windows are 11/12 of a tile's capacity, the rest is room for the bucket that is open at the end of the window (waves
+                         * without records still walk through the kernel: windows of 2/3 32.4, of 5/6 33.4, of 11/12 33.5 Gk-mers/s on the quarter workload).
+                         * A tile that outgrows the capacity is taken in two chunks of whole buckets */
+#endif
+#ifndef BR_MIN_WAVES
+#define BR_MIN_WAVES 6 /* waves per SIMD the register allocator must leave room for: two workgroups of 12 waves per CU (<= 80 VGPRs; it takes 62) */
+#endif
 #ifndef BS_MOVE_LIMIT
 #define BS_MOVE_LIMIT 4096 /* record moves one thread may spend on its sub-buckets before the tile is handed back to the host */
 #endif
@@ -366,10 +374,11 @@ __global__ void __launch_bounds__(BsCfg<SIZE>::THREADS) k_bucket_sort(u64 *__res
  * data-dependent failure: the only thing it cannot take is a bucket larger than the tile (flag -> the host's LSD passes, as in k_bucket_sort).
  * Work grows with sum(bucket^2): the host asks for enough HBM passes to keep buckets at a few dozen records (plan_sort). Needs
  * key_bits - hbits <= 48. The sorted tile goes back in place; run lengths, cutoffs and output are k_compact's, unchanged. */
-__global__ void __launch_bounds__(BsCfg<1>::THREADS) k_bucket_rank(u64 *__restrict__ recs, u32 key_bits, u32 hbits, const u64 *__restrict__ bounds, u32 *flag)
+constexpr int BR_STRIDE = BsCfg<1>::CAP - BsCfg<1>::CAP / BR_SLACK_DIV; /* window length of k_bucket_rank's tiles */
+__global__ void __launch_bounds__(BsCfg<1>::THREADS, BR_MIN_WAVES) k_bucket_rank(u64 *__restrict__ recs, u32 key_bits, u32 hbits, const u64 *__restrict__ bounds, u32 *flag)
 {
 	constexpr int THREADS = BsCfg<1>::THREADS, ITEMS = BsCfg<1>::ITEMS, CAP = BsCfg<1>::CAP, NW = THREADS / 64;
-	constexpr u64 S = BsCfg<1>::STRIDE;
+	constexpr u64 S = BR_STRIDE;
 	constexpr u32 NONE = 0xFFFFFFFFu;
 	KMC_DYN_LDS(unsigned char, s_raw);
 	u64 *s_key = reinterpret_cast<u64 *>(s_raw);                          /* [CAP] (rem, index) pairs, then the records in order */
@@ -380,16 +389,43 @@ __global__ void __launch_bounds__(BsCfg<1>::THREADS) k_bucket_rank(u64 *__restri
 	const u64 b0 = bounds[j], b1 = bounds[j + 1];
 	if (b0 >= (j + 1) * S || b0 >= b1)
 		return; /* no bucket starts in this window */
-	if (b1 - b0 > (u64)CAP) {
-		if (threadIdx.x == 0)
-			atomicOr(flag, 1u);
-		return;
-	}
-	const u32 len = (u32)(b1 - b0);
 	const u32 tid = threadIdx.x, lane = tid & 63;
 	const u32 wave = (u32)__builtin_amdgcn_readfirstlane((int)(tid >> 6));
-	u64 *__restrict__ T = recs + b0;
 	const u32 crel = wave * (ITEMS * 64); /* the wave owns ITEMS rows of 64 consecutive records */
+	const u32 ksh = 64 - key_bits, bsh = 64 - hbits;
+	auto bucket_of = [&](u64 x) -> u64 { return hbits ? (x << ksh) >> bsh : 0ull; };
+	/* A tile longer than the capacity (windows are nearly as long as the capacity: BR_SLACK_DIV) is taken in two chunks of whole buckets, by the two
+	 * workgroups (blockIdx.y = 0, 1) every tile has: the first takes the records up to the last bucket start inside the capacity, the second the rest.
+	 * Nearly every tile fits, and its second workgroup returns at once. */
+	u64 c0 = b0;
+	u32 len;
+	if (b1 - b0 <= (u64)CAP) {
+		if (blockIdx.y)
+			return;
+		len = (u32)(b1 - b0);
+	} else {
+		if (tid == 0)
+			*s_wmax = 0;
+		__syncthreads();
+		for (u32 idx = tid + 1; idx <= (u32)CAP; idx += THREADS) /* b0 + CAP < b1 */
+			if (bucket_of(recs[b0 + idx]) != bucket_of(recs[b0 + idx - 1]))
+				atomicMax(s_wmax, idx);
+		__syncthreads();
+		const u32 cut = *s_wmax;
+		__syncthreads();
+		if (cut == 0 || (b1 - b0) - cut > (u64)CAP) { /* one bucket (or two) beyond the capacity: the host's LSD passes */
+			if (tid == 0 && blockIdx.y == 0)
+				atomicOr(flag, 1u);
+			return;
+		}
+		if (blockIdx.y == 0)
+			len = cut;
+		else {
+			c0 = b0 + cut;
+			len = (u32)(b1 - c0);
+		}
+	}
+	u64 *__restrict__ T = recs + c0;
 
 	u64 key[ITEMS];
 #pragma unroll
@@ -397,8 +433,6 @@ __global__ void __launch_bounds__(BsCfg<1>::THREADS) k_bucket_rank(u64 *__restri
 		const u32 idx = crel + r * 64 + lane;
 		key[r] = idx < len ? T[idx] : 0ull;
 	}
-	const u32 ksh = 64 - key_bits, bsh = 64 - hbits;
-	auto bucket_of = [&](u64 x) -> u64 { return hbits ? (x << ksh) >> bsh : 0ull; };
 	u64 prev_last = 0;
 	if (crel > 0 && crel - 1 < len)
 		prev_last = bucket_of(T[crel - 1]);

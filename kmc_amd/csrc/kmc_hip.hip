@@ -556,7 +556,7 @@ int sort_device_t(Slot &s, const ZeroPlan &z, u64 *d_recs, u64 *d_tmp, u64 n, co
 	} else if (s.timed)
 		HIPCHK(hipEventRecord(s.ev[3], s.stream));
 	if (sp.local() && !local_by_caller) {
-		constexpr u64 S = BsCfg<SIZE>::STRIDE;
+		const u64 S = SIZE == 1 && sp.rank ? (u64)BR_STRIDE : (u64)BsCfg<SIZE>::STRIDE;
 		const u64 n_win = (n + S - 1) / S;
 		if (n_win > 0x7FFFFFF0ull)
 			return fail(KMC_HIP_EINVAL, "bin too large");
@@ -578,7 +578,7 @@ int sort_device_t(Slot &s, const ZeroPlan &z, u64 *d_recs, u64 *d_tmp, u64 n, co
 		k_bucket_bounds<SIZE><<<dim3((u32)((n_win + 1 + 3) / 4)), dim3(256), 0, s.stream>>>(gbn, (u32)S, sp.key_bits, sp.hbits());
 		if constexpr (SIZE == 1) {
 			if (sp.rank)
-				k_bucket_rank<<<dim3((u32)n_win), dim3(BsCfg<1>::THREADS), br_lds_bytes(), s.stream>>>(src, sp.key_bits, sp.hbits(), bounds, d_flag);
+				k_bucket_rank<<<dim3((u32)n_win, 2), dim3(BsCfg<1>::THREADS), br_lds_bytes(), s.stream>>>(src, sp.key_bits, sp.hbits(), bounds, d_flag);
 			else
 				k_bucket_sort<SIZE><<<dim3((u32)n_win), dim3(BsCfg<SIZE>::THREADS), bs_lds_bytes<SIZE>(), s.stream>>>(src, sp.key_bits, sp.hbits(), bounds, d_flag);
 		} else

@@ -106,7 +106,7 @@ template <typename T> inline T from_bits(unsigned long long b)
 /* run `body()` once per GPU thread of every workgroup; `dyn_bytes` of dynamic LDS */
 template <class F> void launch(dim3 grid, dim3 block, size_t dyn_bytes, F body)
 {
-	if (block.x % 64 != 0 || block.y != 1 || block.z != 1 || grid.y != 1 || grid.z != 1)
+	if (block.x % 64 != 0 || block.y != 1 || block.z != 1 || grid.z != 1)
 		abort();
 	Launch L;
 	L.grid = grid;
@@ -127,11 +127,12 @@ template <class F> void launch(dim3 grid, dim3 block, size_t dyn_bytes, F body)
 		th.emplace_back([&, t] {
 			t_threadIdx = dim3(t);
 			t_wave = &L.waves[t / 64];
-			for (unsigned b = 0; b < grid.x; ++b) {
-				t_blockIdx = dim3(b);
-				body();
-				L.block_bar.wait(); /* static "LDS" is reused by the next workgroup */
-			}
+			for (unsigned by = 0; by < grid.y; ++by)
+				for (unsigned b = 0; b < grid.x; ++b) {
+					t_blockIdx = dim3(b, by);
+					body();
+					L.block_bar.wait(); /* static "LDS" is reused by the next workgroup */
+				}
 		});
 	for (auto &x : th)
 		x.join();

@@ -605,6 +605,30 @@ def test_two_devices_worker_allreduce_and_wide_records(ref_bins, tmp_path):
         assert _md5(str(tmp_path / ("ref" + ext))) == _md5(str(tmp_path / ("hip" + ext))), ext
 
 
+# ------------------------------------------------------------------------------------------------ k_bucket_rank (default path of one-word k-mers)
+def test_rank_path_takes_repeats_in_chunks_and_hands_a_giant_bucket_back(ctx):
+    """default mode: groups of one-word k-mers = top bytes through HBM, tiles put in order by k_bucket_rank, k_compact. (The many-bins tests above run this
+    path on ordinary data.) Here: every k-mer ~1600 times — buckets longer than the room at the end of a window, tiles longer than the capacity, taken in
+    chunks of whole buckets, nothing comes back; then one k-mer more often than a tile holds records — the group is run again with LSD passes."""
+    p = hp(27)
+    bins = capi.synth_bins(seed=3, genome_len=6000, n_reads=80_000, k=27, n_bins=4, err=0.0)
+    t0 = ctx.local_sort_totals()
+    got, err = _run_batch(ctx, p, bins, 1)
+    assert err is None, err
+    for i, (img, nrec, packs, _) in enumerate(bins):
+        w = O.process_bin(op(p), img, nrec)
+        assert all(np.array_equal(a, b) for a, b in zip(got[i], w)), i
+    t1 = ctx.local_sort_totals()
+    assert t1["hybrid_groups"] > t0["hybrid_groups"] and t1["redo_groups"] == t0["redo_groups"], (t0, t1)
+    bins = capi.synth_bins(seed=5, genome_len=300, n_reads=20_000, k=27, n_bins=2, err=0.0)
+    got, err = _run_batch(ctx, p, bins, 1)
+    assert err is None, err
+    for i, (img, nrec, packs, _) in enumerate(bins):
+        w = O.process_bin(op(p), img, nrec)
+        assert all(np.array_equal(a, b) for a, b in zip(got[i], w)), i
+    assert ctx.local_sort_totals()["redo_groups"] > t1["redo_groups"]
+
+
 # ------------------------------------------------------------------------------------------------ several bins per host-boundary call
 HOST_GROUP_CASES = [
     (27, dict(lut_prefix_len=3), 7),

@@ -46,6 +46,14 @@ VARIANTS = {
     "bc512mw6": ["-DBC_BLOCK_THREADS=512", "-DBC_MIN_WAVES=6"],  # 8 waves x 4 rows, 80 VGPRs, three workgroups per CU
     "bcmw4": ["-DBC_MIN_WAVES=4"],  # k_bucket_count with 128 VGPRs: one workgroup of 1024 per CU, nothing spilled
     "bc512": ["-DBC_BLOCK_THREADS=512", "-DBC_WORDS_PER_THREAD=8", "-DBC_MIN_WAVES=4"],  # 8 waves x 8 rows, two workgroups per CU at 128 VGPRs
+    "br512x8": ["-DBS_BLOCK_THREADS=512"],  # k_bucket_rank geometry: 8 waves x 8 rows, 4096-record tiles
+    "br1024x4": ["-DBS_BLOCK_THREADS=1024", "-DBS_WORDS_PER_THREAD=4"],  # 16 waves x 4 rows, 4096
+    "br1024x6": ["-DBS_BLOCK_THREADS=1024", "-DBS_WORDS_PER_THREAD=6"],  # 16 waves x 6 rows, 6144
+    "br768x4": ["-DBS_BLOCK_THREADS=768", "-DBS_WORDS_PER_THREAD=4"],  # 12 waves x 4 rows, 3072
+    "brslack6": ["-DBR_SLACK_DIV=6"],  # 768 x 8 with windows of 5120 records (1024 of slack)
+    "brslack12": ["-DBR_SLACK_DIV=12"],  # windows of 5632 (512 of slack)
+    "brslack24": ["-DBR_SLACK_DIV=24"],  # windows of 5888 (256 of slack; longer tiles take a second chunk)
+    "br1024x4s8": ["-DBS_BLOCK_THREADS=1024", "-DBS_WORDS_PER_THREAD=4", "-DBR_SLACK_DIV=8"],
     "bc1": ["-DBC_STOP_AFTER=1"],  # k_bucket_count cut after its phase 1 / 2 / 3 (garbage output): phase costs
     "bc2": ["-DBC_STOP_AFTER=2"],
     "bc3": ["-DBC_STOP_AFTER=3"],
