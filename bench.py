@@ -319,10 +319,12 @@ def host_boundary_pass(ctx, w, n_threads=8, passes=2, group=1):
             while inflight:
                 wait(*inflight.pop(0))
         except Exception as e:  # noqa: BLE001
-            errors.append(repr(e))
+            errors.append("thread %d, call %d of %d (bins %s), %.2f s into the pass: %r" % (tid, j, len(calls), mine, time.perf_counter() - t_pass[0], e))
 
     best, tallies = None, None
+    t_pass = [0.0]
     for _ in range(passes):
+        t_pass[0] = time.perf_counter()
         accs = [[0, 0, 0, 0, 0] for _ in range(n_threads)]
         ths = [threading.Thread(target=worker, args=(t_, accs[t_])) for t_ in range(n_threads)]
         t0 = time.perf_counter()
@@ -475,6 +477,7 @@ def main():
     ap.add_argument("--no-host-boundary", action="store_true")
     ap.add_argument("--host-group", type=int, default=4, help="bins per call of the host-boundary leg (1: kmc_hip_process_bin_submit, one bin per call)")
     ap.add_argument("--host-threads", type=int, default=0, help="host threads of the host-boundary leg (0: 4 with several bins per call, 8 with one)")
+    ap.add_argument("--host-probe", action="store_true", help="diagnostics: the host-boundary leg for every sort selection and call style, errors reported per leg")
     ap.add_argument("--no-host-single", action="store_true", help="skip the one-bin-per-call comparison of the host-boundary leg")
     ap.add_argument("--no-secondary", action="store_true")
     ap.add_argument("--no-two-streams", action="store_true", help="skip the value_two_streams leg (profiling runs: keeps overlapped launches out of the kernel statistics)")
@@ -671,7 +674,25 @@ def main():
             ctx.scatter_totals(reset=True)
         except Exception as e:  # noqa: BLE001
             out["value_two_streams"] = repr(e)
-        if want_host:
+        if want_host and args.host_probe:  # diagnostics: every combination of sort selection and call style, each on its own
+            probe = []
+            for mode in (1, 1, 1, 0):
+                ctx.set_hybrid(mode)
+                for grp in (1, 4):
+                    t0 = time.perf_counter()
+                    try:
+                        secs, ht, t_pin, nth = host_boundary_pass(ctx, w, n_threads=args.host_threads or (4 if grp > 1 else 8), group=grp)
+                        probe.append({"hybrid_mode": mode, "bins_per_call": grp, "value": w.total_kmers_all / secs / 1e9, "wall_s": time.perf_counter() - t0,
+                                      "tallies_equal": [int(x) for x in ht[:4]] == [int(x) for x in tallies]})
+                    except Exception as e:  # noqa: BLE001
+                        probe.append({"hybrid_mode": mode, "bins_per_call": grp, "error": repr(e)[:600], "wall_s": time.perf_counter() - t0})
+                        try:
+                            ctx.synchronize()
+                        except Exception as e2:  # noqa: BLE001
+                            probe[-1]["synchronize"] = repr(e2)[:200]
+            ctx.set_hybrid(1)
+            out["host_probe"] = probe
+        elif want_host:
             try:
                 legs_hb = {}
                 for grp in ([args.host_group] if args.no_host_single else sorted({1, args.host_group})):

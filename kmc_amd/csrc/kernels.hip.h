@@ -43,7 +43,9 @@ typedef kmc_u32 u32;
 #endif
 
 /* device-side error bits (d_err) */
-enum : u32 { KERR_CORRUPT = 1u, KERR_NREC = 2u, KERR_CAPACITY = 4u, KERR_WATCHDOG = 8u };
+enum : u32 { KERR_CORRUPT = 1u, KERR_NREC = 2u, KERR_CAPACITY = 4u, KERR_WATCHDOG = 8u,
+             /* which look-back gave up (diagnostics; reported with KERR_WATCHDOG) */
+             KERR_AT_SCATTER = 0x100u, KERR_AT_EXPAND = 0x200u, KERR_AT_COMPACT = 0x400u, KERR_AT_STAGE1 = 0x800u };
 
 /* tile geometry */
 #ifndef RS_BLOCK_THREADS
@@ -393,7 +395,7 @@ __device__ __forceinline__ u64 lookback64(u64 *status, u32 tile, u64 aggregate, 
 		}
 		tbase -= 64 * used;
 		if (!done && blocked) {
-			if (++spins > SPIN_LIMIT || (spins % 1024 == 0 && (ld_agent(err) & err_watchdog_bit))) {
+			if (++spins > SPIN_LIMIT || (spins % 1024 == 0 && (ld_agent(err) & KERR_WATCHDOG))) {
 				if (lane == 0)
 					atomicOr(err, err_watchdog_bit);
 				break;
@@ -688,7 +690,7 @@ __global__ void __launch_bounds__(EXP_BLOCK) k_expand(const GrpExpand ge, u32 k,
 		}
 		/* slice offset among k-mers: decoupled look-back, one 64-bit word per slice, 64 slices per round trip */
 		if (wave == 0) {
-			const u64 excl = lookback64(status, c, (u64)tot_k, lane, err, KERR_WATCHDOG);
+			const u64 excl = lookback64(status, c, (u64)tot_k, lane, err, KERR_WATCHDOG | KERR_AT_EXPAND);
 			if (lane == 0) {
 				*s_base = excl;
 				if (c == bin_chunks - 1 && excl + tot_k != n_rec)
@@ -1107,7 +1109,7 @@ __global__ void __launch_bounds__(RS_BLOCK, (SIZE <= 4 ? RS_MIN_WAVES : RS_MIN_W
 					t -= used;
 					if (!done && used < RS_LOOKBACK_K) { /* ran into a tile that has not published yet */
 						if (++spins > SPIN_LIMIT || (spins % 1024 == 0 && ld_agent(err) & KERR_WATCHDOG)) {
-							atomicOr(err, KERR_WATCHDOG);
+							atomicOr(err, KERR_WATCHDOG | KERR_AT_SCATTER);
 							break;
 						}
 						__builtin_amdgcn_s_sleep(1);
@@ -1442,7 +1444,7 @@ __global__ void __launch_bounds__(CP_BLOCK, CpCfg<SIZE>::MIN_WAVES) k_compact(co
 				if (lane == 0)
 					status[tile] = tile_counted;
 			} else
-				excl = lookback64(status, tile, (u64)tile_counted, lane, err, KERR_WATCHDOG);
+				excl = lookback64(status, tile, (u64)tile_counted, lane, err, KERR_WATCHDOG | KERR_AT_COMPACT);
 			if (lane == 0) {
 				s_tile_off = excl;
 				if (!two_phase && tile == num_tiles - 1)

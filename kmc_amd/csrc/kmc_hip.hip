@@ -1141,8 +1141,12 @@ int read_redo(Slot &s, bool &redo)
 
 int err_to_code(u32 err)
 {
-	if (err & KERR_WATCHDOG)
-		return fail(KMC_HIP_EINTERNAL, "device look-back watchdog tripped");
+	if (err & KERR_WATCHDOG) {
+		char buf[160];
+		snprintf(buf, sizeof buf, "device look-back watchdog tripped (error word 0x%x:%s%s%s%s)", err, err & KERR_AT_SCATTER ? " scatter pass" : "",
+		         err & KERR_AT_EXPAND ? " expansion" : "", err & KERR_AT_COMPACT ? " compaction" : "", err & KERR_AT_STAGE1 ? " stage 1" : "");
+		return fail(KMC_HIP_EINTERNAL, buf);
+	}
 	if (err & KERR_CORRUPT)
 		return fail(KMC_HIP_ECORRUPT, "super-k-mer stream does not end on a pack boundary");
 	if (err & KERR_NREC)

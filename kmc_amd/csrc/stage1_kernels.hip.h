@@ -191,7 +191,7 @@ __device__ __forceinline__ u64 lookback64_last(u64 *status, u32 tile, u64 own_la
 		if (m_zero & need) {
 			if (++spins > SPIN_LIMIT || (spins % 1024 == 0 && (ld_agent(err) & KERR_WATCHDOG))) {
 				if (lane == 0)
-					atomicOr(err, KERR_WATCHDOG);
+					atomicOr(err, KERR_WATCHDOG | KERR_AT_STAGE1);
 				break;
 			}
 			__builtin_amdgcn_s_sleep(1);
@@ -323,7 +323,7 @@ __global__ void __launch_bounds__(S1_BLOCK) k_s1_cut(const u32 *__restrict__ sig
 		carry_last1 = sub_last1[sub] ? sub_last1[sub] : carry_last1;
 	}
 	if (wave == 0) {
-		const u64 excl = lookback64(status_cnt, tile, (u64)wg_ends, lane, err, KERR_WATCHDOG);
+		const u64 excl = lookback64(status_cnt, tile, (u64)wg_ends, lane, err, KERR_WATCHDOG | KERR_AT_STAGE1);
 		if (lane == 0) {
 			s_carry_cnt = excl;
 			if (tile == num_tiles - 1)
@@ -565,7 +565,7 @@ __global__ void __launch_bounds__(S1_BLOCK) k_s1_text_to_codes(const uint8_t *__
 	u32 tile_nl;
 	const u32 nl_before = block_excl_sum<S1_BLOCK / 64, u32>(my_nl, s_tmp, tile_nl);
 	if (wave == 0) {
-		const u64 excl = lookback64(status_lines, tile, (u64)tile_nl, lane, err, KERR_WATCHDOG);
+		const u64 excl = lookback64(status_lines, tile, (u64)tile_nl, lane, err, KERR_WATCHDOG | KERR_AT_STAGE1);
 		if (lane == 0) {
 			s_carry = excl;
 			if (tile == num_tiles - 1)
@@ -601,7 +601,7 @@ __global__ void __launch_bounds__(S1_BLOCK) k_s1_text_to_codes(const uint8_t *__
 	u32 tile_keep;
 	const u32 keep_before = block_excl_sum<S1_BLOCK / 64, u32>(n_keep, s_tmp, tile_keep);
 	if (wave == 0) {
-		const u64 excl = lookback64(status_out, tile, (u64)tile_keep, lane, err, KERR_WATCHDOG);
+		const u64 excl = lookback64(status_out, tile, (u64)tile_keep, lane, err, KERR_WATCHDOG | KERR_AT_STAGE1);
 		if (lane == 0) {
 			s_carry = excl;
 			if (tile == num_tiles - 1)
@@ -764,7 +764,7 @@ __global__ void __launch_bounds__(S1_BLOCK) k_s1_emit_sorted(const u64 *__restri
 	u32 tile_bytes;
 	const u32 before = block_excl_sum<S1_BLOCK / 64, u32>(mine, s_tmp, tile_bytes);
 	if (wave == 0) {
-		const u64 excl = lookback64(status, tile, (u64)tile_bytes, lane, err, KERR_WATCHDOG);
+		const u64 excl = lookback64(status, tile, (u64)tile_bytes, lane, err, KERR_WATCHDOG | KERR_AT_STAGE1);
 		if (lane == 0)
 			s_carry = excl;
 	}

@@ -162,6 +162,14 @@ public:
 			return (size_t)(v < 1 ? 1 : (v > 16 ? 16 : v));
 		}();
 
+		/* ... and only while the worker holds few k-mers: a call with several LARGE bins uploads all of them before its first kernel starts, and through
+		 * PCIe that costs more overlap than the shared sort saves (bench.py host_boundary.legs: 48 M k-mers per bin, one per call 29.2, four per call 23-27
+		 * Gk-mers/s); small bins are bound by launches, and there the shared sort pays (DESIGN.md 4 "Groups of bins") */
+		static const uint64 group_recs = [] {
+			const char *e = getenv("KMC_HIP_WORKER_GROUP_KMERS");
+			return e ? (uint64)strtoull(e, nullptr, 10) : (uint64)4 << 20;
+		}();
+
 		const long long t_start = KmcOrderedEmit::now_ns();
 		std::vector<Taken> grp;
 		while (true) {
@@ -176,11 +184,13 @@ public:
 				if (t.seq == 0)
 					KmcTimeline::mark("first bin taken");
 				grp.push_back(std::move(t));
-				while (grp.size() < max_group) {
+				uint64 held = grp[0].n_rec;
+				while (grp.size() < max_group && held < group_recs) {
 					Taken e;
 					if (!bq->pop_if_any(e.bin_id, e.data, e.size, e.n_rec))
 						break;
 					e.seq = order->next_take++;
+					held += e.n_rec;
 					grp.push_back(std::move(e));
 				}
 				order->ns_getnext += KmcOrderedEmit::now_ns() - t0;

@@ -46,6 +46,20 @@ t=time.time(); s=capi.synth_bins(seed=2026, genome_len=1000000000, n_reads=20000
     s1parts) KMC_HIP_S1_SORTED_EMIT=1 timeout 120 python tools/s1_part_bench.py > $OUT/s1_part_bench_sorted.json 2> $OUT/s1_part_bench_sorted.err; cat $OUT/s1_part_bench_sorted.json; tail -2 $OUT/s1_part_bench_sorted.err ;;
     b512e:*) e=${step#b512e:}; env $e timeout 600 python bench.py $bins512 --no-oracle-check > $OUT/bins512_$e.json 2> $OUT/bins512_$e.err; python tools/pj.py $OUT/bins512_$e.json | cut -c1-200 ;;
     onee:*)  e=${step#onee:}; env $e timeout 600 python bench.py $one_bin --no-oracle-check > $OUT/onebin_$e.json 2> $OUT/onebin_$e.err; python tools/pj.py $OUT/onebin_$e.json | cut -c1-200 ;;
+    hbq:*)   e=${step#hbq:}; env $e timeout 600 python bench.py --cache /dev/shm/kmccache --reads 50000000 --genome 250000000 --bins 128 --steps 1 --warmup 1 --no-secondary --no-cpu-baseline --no-two-streams --no-oracle-check --no-digest > $OUT/hbq_$e.json 2> $OUT/hbq_$e.err; python - <<PYEOF
+import json
+d=json.loads(open("$OUT/hbq_$e.json").read().strip().splitlines()[-1])
+hb=d.get("host_boundary",{})
+print("$e: value", round(d["value"],2), "host", d.get("value_host_boundary"), hb.get("error"), [(l["bins_per_call"], round(l["value"],2)) for l in hb.get("legs",[])])
+PYEOF
+    ;;
+    hbprobe) timeout 900 python bench.py --cache /dev/shm/kmccache --steps 1 --warmup 1 --no-secondary --no-cpu-baseline --no-oracle-check --no-digest --host-probe > $OUT/hbprobe.json 2> $OUT/hbprobe.err; python - <<PYEOF
+import json
+d=json.loads(open("$OUT/hbprobe.json").read().strip().splitlines()[-1])
+print("value", round(d["value"],2))
+for l in d.get("host_probe",[]): print(l)
+PYEOF
+    ;;
     pcie)    timeout 300 python tools/pcie_probe.py > $OUT/pcie_probe.json 2> $OUT/pcie_probe.err; cat $OUT/pcie_probe.json; tail -2 $OUT/pcie_probe.err ;;
     hb:*)    a=${step#hb:}; g=${a%%:*}; t=${a#*:}; timeout 600 python bench.py --cache /dev/shm/kmccache --leg quarter --reads 50000000 --genome 250000000 --bins 128 --steps 2 --warmup 1 --no-digest --no-oracle-check --no-two-streams --no-host-single --host-group $g --host-threads $t > $OUT/hb_${g}_$t.json 2> $OUT/hb_${g}_$t.err; python - <<PYEOF
 import json
