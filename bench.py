@@ -695,11 +695,22 @@ def main():
         elif want_host:
             try:
                 legs_hb = {}
+                failed = []
                 for grp in ([args.host_group] if args.no_host_single else sorted({1, args.host_group})):
-                    secs, ht, t_pin, nth = host_boundary_pass(ctx, w, n_threads=args.host_threads or (4 if grp > 1 else 8), group=grp)
+                    entry = "kmc_hip_process_bins_submit/_wait" if grp > 1 else "kmc_hip_process_bin_submit/_wait"
+                    try:
+                        secs, ht, t_pin, nth = host_boundary_pass(ctx, w, n_threads=args.host_threads or (4 if grp > 1 else 8), group=grp)
+                    except Exception as e:  # noqa: BLE001 — a leg that fails is reported, the other one still counts
+                        failed.append({"bins_per_call": grp, "entry": entry, "error": repr(e)[:800]})
+                        try:
+                            ctx.synchronize()
+                        except Exception:  # noqa: BLE001
+                            pass
+                        continue
                     legs_hb[grp] = {"value": w.total_kmers_all / secs / 1e9, "seconds": secs, "bins_per_call": grp, "host_threads": nth, "bytes_out": int(ht[4]),
-                                    "pin_and_stage_s": t_pin, "tallies_equal_device_resident": [int(x) for x in ht[:4]] == [int(x) for x in tallies],
-                                    "entry": "kmc_hip_process_bins_submit/_wait" if grp > 1 else "kmc_hip_process_bin_submit/_wait"}
+                                    "pin_and_stage_s": t_pin, "tallies_equal_device_resident": [int(x) for x in ht[:4]] == [int(x) for x in tallies], "entry": entry}
+                if not legs_hb:
+                    raise RuntimeError("; ".join(f["error"] for f in failed))
                 best = max(legs_hb.values(), key=lambda v: v["value"])
                 out["value_host_boundary"] = best["value"]
                 out["host_boundary"] = {"what": "the same bins from pinned host memory through the host boundary, host threads x 2 stream slots (H2D + kernels + D2H of every "
@@ -707,7 +718,7 @@ def main():
                                                 "call (sorted together on the device)" % args.host_group,
                                         "bytes_in": w.total_bytes_all, "best": best["entry"], "seconds": best["seconds"], "bins_per_call": best["bins_per_call"],
                                         "tallies_equal_device_resident": all(v["tallies_equal_device_resident"] for v in legs_hb.values()),
-                                        "legs": [legs_hb[g] for g in sorted(legs_hb)]}
+                                        "legs": [legs_hb[g] for g in sorted(legs_hb)], "failed_legs": failed}
             except Exception as e:  # noqa: BLE001
                 out["host_boundary"] = {"error": repr(e)}
         w.free()
