@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define KMC_HIP_ABI_VERSION 2
+#define KMC_HIP_ABI_VERSION 3 /* 3: + kmc_hip_process_bins_submit/_wait (bound by the worker's loader), kmc_hip_process_bin_multi, kmc_hip_order_database_device */
 
 enum {
 	KMC_HIP_OK = 0,
