@@ -40,6 +40,9 @@
                          * without records still walk through the kernel: windows of 2/3 32.4, of 5/6 33.4, of 11/12 33.5 Gk-mers/s on the quarter workload).
                          * A tile that outgrows the capacity is taken in two chunks of whole buckets */
 #endif
+#ifndef BR_LOOP
+#define BR_LOOP 0 /* shape of the pair loop (tuning): 0 = 4 per iteration + single tail, unrolled as the compiler likes (16 + 4 + 1) */
+#endif
 #ifndef BR_MIN_WAVES
 #define BR_MIN_WAVES 6 /* waves per SIMD the register allocator must leave room for: two workgroups of 12 waves per CU (<= 80 VGPRs; it takes 62) */
 #endif
@@ -529,12 +532,40 @@ __global__ void __launch_bounds__(BsCfg<1>::THREADS, BR_MIN_WAVES) k_bucket_rank
 			const u32 bstart = span[r] & 0xFFFFu, bend = span[r] >> 16;
 			const u32 c = c32[r];
 			u32 rank = 0, q = bstart;
+#if BR_LOOP == 1 /* 4 pairs per iteration, not unrolled further */
+#pragma unroll 1
+			for (; q + 4 <= bend; q += 4) {
+				const u32 a0 = s_k32[q], a1 = s_k32[q + 1], a2 = s_k32[q + 2], a3 = s_k32[q + 3];
+				rank += (a0 < c ? 1u : 0u) + (a1 < c ? 1u : 0u) + (a2 < c ? 1u : 0u) + (a3 < c ? 1u : 0u);
+			}
+#pragma unroll 1
+			for (; q < bend; ++q)
+				rank += s_k32[q] < c ? 1u : 0u;
+#elif BR_LOOP == 2 /* 8 pairs per iteration, not unrolled further */
+#pragma unroll 1
+			for (; q + 8 <= bend; q += 8) {
+#pragma unroll
+				for (int t = 0; t < 8; ++t)
+					rank += s_k32[q + t] < c ? 1u : 0u;
+			}
+#pragma unroll 1
+			for (; q < bend; ++q)
+				rank += s_k32[q] < c ? 1u : 0u;
+#elif BR_LOOP == 3 /* one loop: 4 pairs per iteration, the last iteration masked (the words behind a bucket are other buckets' pairs: readable, not counted) */
+#pragma unroll 1
+			for (; q < bend; q += 4) {
+				const u32 a0 = s_k32[q], a1 = s_k32[q + 1], a2 = s_k32[q + 2], a3 = s_k32[q + 3];
+				const u32 left = bend - q;
+				rank += (a0 < c ? 1u : 0u) + ((a1 < c && left > 1) ? 1u : 0u) + ((a2 < c && left > 2) ? 1u : 0u) + ((a3 < c && left > 3) ? 1u : 0u);
+			}
+#else
 			for (; q + 4 <= bend; q += 4) {
 				const u32 a0 = s_k32[q], a1 = s_k32[q + 1], a2 = s_k32[q + 2], a3 = s_k32[q + 3];
 				rank += (a0 < c ? 1u : 0u) + (a1 < c ? 1u : 0u) + (a2 < c ? 1u : 0u) + (a3 < c ? 1u : 0u);
 			}
 			for (; q < bend; ++q)
 				rank += s_k32[q] < c ? 1u : 0u;
+#endif
 			place[r] = bstart + rank;
 		}
 	} else {

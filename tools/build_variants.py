@@ -54,6 +54,9 @@ VARIANTS = {
     "brslack12": ["-DBR_SLACK_DIV=12"],  # windows of 5632 (512 of slack)
     "brslack24": ["-DBR_SLACK_DIV=24"],  # windows of 5888 (256 of slack; longer tiles take a second chunk)
     "br1024x4s8": ["-DBS_BLOCK_THREADS=1024", "-DBS_WORDS_PER_THREAD=4", "-DBR_SLACK_DIV=8"],
+    "brloop1": ["-DBR_LOOP=1"],  # k_bucket_rank pair loop: 4 per iteration, not unrolled further
+    "brloop2": ["-DBR_LOOP=2"],  # 8 per iteration
+    "brloop3": ["-DBR_LOOP=3"],  # one masked loop, 4 per iteration
     "bc1": ["-DBC_STOP_AFTER=1"],  # k_bucket_count cut after its phase 1 / 2 / 3 (garbage output): phase costs
     "bc2": ["-DBC_STOP_AFTER=2"],
     "bc3": ["-DBC_STOP_AFTER=3"],
