@@ -40,6 +40,9 @@
                          * without records still walk through the kernel: windows of 2/3 32.4, of 5/6 33.4, of 11/12 33.5 Gk-mers/s on the quarter workload).
                          * A tile that outgrows the capacity is taken in two chunks of whole buckets */
 #endif
+#ifndef BR_PROLOGUE
+#define BR_PROLOGUE 0 /* how a record finds its bucket: 0 = 64-bit head masks per row, 1 = ordinal table of bucket starts (as k_bucket_count) */
+#endif
 #ifndef BR_LOOP
 #define BR_LOOP 0 /* shape of the pair loop (tuning): 0 = 4 per iteration + single tail, unrolled as the compiler likes (16 + 4 + 1) */
 #endif
@@ -436,6 +439,62 @@ __global__ void __launch_bounds__(BsCfg<1>::THREADS, BR_MIN_WAVES) k_bucket_rank
 		const u32 idx = crel + r * 64 + lane;
 		key[r] = idx < len ? T[idx] : 0ull;
 	}
+#if BR_PROLOGUE == 1
+	/* Bucket starts ("heads") and, from them, every record's bucket — as in k_bucket_count: a record's bucket is known by its ORDINAL among the tile's
+	 * buckets (heads at or before the record - 1: a popcount below the lane + the heads of the rows and waves before); the start positions go into a table
+	 * indexed by that ordinal, and a record finds the start and the end of its bucket with two LDS reads. A record starts a bucket iff it differs from
+	 * its predecessor above the low `rbits` bits (the predecessor comes through a DPP wave shift, not through the LDS crossbar). */
+	const u32 rbits = key_bits - hbits; /* <= 48 (host) */
+	const u64 rmask = rbits >= 64 ? ~0ull : ((1ull << rbits) - 1);
+	u32 *s_start = s_wmax + NW; /* [CAP + 1] */
+	u64 prev_key = 0;
+	if (crel > 0 && crel - 1 < len)
+		prev_key = T[crel - 1];
+	u32 headbits = 0, below[ITEMS], wheads = 0;
+#pragma unroll
+	for (int r = 0; r < ITEMS; ++r) {
+		const u32 idx = crel + r * 64 + lane;
+		const u32 plo = wave_shift_up1((u32)key[r], (u32)prev_key, lane), phi = wave_shift_up1((u32)(key[r] >> 32), (u32)(prev_key >> 32), lane);
+		const u64 x = (((u64)phi << 32) | plo) ^ key[r];
+		const bool head = idx < len && (idx == 0 || (hbits != 0 && (x >> rbits) != 0));
+		const u64 m = __ballot(head);
+		headbits |= head ? 1u << r : 0u;
+		below[r] = __builtin_amdgcn_mbcnt_hi((u32)(m >> 32), __builtin_amdgcn_mbcnt_lo((u32)m, wheads));
+		wheads += (u32)__popcll(m);
+		prev_key = __shfl(key[r], 63);
+	}
+	if (lane == 0)
+		s_wfirst[wave] = wheads;
+	__syncthreads();
+	u32 wave_heads_before, total_heads;
+	{
+		const u32 v = lane < (u32)NW ? s_wfirst[lane] : 0u;
+		const u32 inc = wave_incl_sum_u32(v, lane);
+		total_heads = __shfl(inc, NW - 1);
+		wave_heads_before = __shfl(inc - v, (int)wave);
+	}
+#pragma unroll
+	for (int r = 0; r < ITEMS; ++r)
+		if ((headbits >> r) & 1u)
+			s_start[wave_heads_before + below[r]] = crel + r * 64 + lane;
+	if (tid == 0)
+		s_start[total_heads] = len;
+	__syncthreads();
+	u32 span[ITEMS], rel[ITEMS], widest = 0;
+#pragma unroll
+	for (int r = 0; r < ITEMS; ++r) {
+		const u32 idx = crel + r * 64 + lane;
+		span[r] = 0;
+		rel[r] = 0;
+		if (idx < len) {
+			const u32 ord = wave_heads_before + below[r] + ((headbits >> r) & 1u) - 1u;
+			const u32 bstart = s_start[ord], bend = s_start[ord + 1];
+			span[r] = bstart | (bend << 16);
+			rel[r] = idx - bstart;
+			widest = widest > bend - bstart ? widest : bend - bstart;
+		}
+	}
+#else
 	u64 prev_last = 0;
 	if (crel > 0 && crel - 1 < len)
 		prev_last = bucket_of(T[crel - 1]);
@@ -501,6 +560,7 @@ __global__ void __launch_bounds__(BsCfg<1>::THREADS, BR_MIN_WAVES) k_bucket_rank
 		else
 			span[r] = 0; /* nothing to count */
 	}
+#endif
 	/* the largest bucket of the tile decides the width of the pairs: (rem, index) in 32 bits whenever they fit — half the LDS traffic and one-pass compares */
 #pragma unroll
 	for (int o = 32; o >= 1; o >>= 1) {
@@ -601,7 +661,7 @@ __global__ void __launch_bounds__(BsCfg<1>::THREADS, BR_MIN_WAVES) k_bucket_rank
 	for (u32 idx = tid; idx < len; idx += THREADS)
 		T[idx] = s_key[idx];
 }
-constexpr size_t br_lds_bytes() { return (size_t)BsCfg<1>::CAP * 8 + 3 * (BsCfg<1>::THREADS / 64) * 4 + 16; }
+constexpr size_t br_lds_bytes() { return (size_t)BsCfg<1>::CAP * 8 + 3 * (BsCfg<1>::THREADS / 64) * 4 + (BR_PROLOGUE == 1 ? ((size_t)BsCfg<1>::CAP + 1) * 4 : 0) + 16; }
 
 /* ================================================================================================ fused: tile -> (k-mer, count) records
  * What stage 2 wants from the sort is not the sorted records but the RUNS of equal k-mers: ascending distinct k-mers with their counts

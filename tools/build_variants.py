@@ -54,6 +54,7 @@ VARIANTS = {
     "brslack12": ["-DBR_SLACK_DIV=12"],  # windows of 5632 (512 of slack)
     "brslack24": ["-DBR_SLACK_DIV=24"],  # windows of 5888 (256 of slack; longer tiles take a second chunk)
     "br1024x4s8": ["-DBS_BLOCK_THREADS=1024", "-DBS_WORDS_PER_THREAD=4", "-DBR_SLACK_DIV=8"],
+    "brpro1": ["-DBR_PROLOGUE=1"],  # k_bucket_rank: ordinal table of bucket starts instead of 64-bit head masks per row
     "brloop1": ["-DBR_LOOP=1"],  # k_bucket_rank pair loop: 4 per iteration, not unrolled further
     "brloop2": ["-DBR_LOOP=2"],  # 8 per iteration
     "brloop3": ["-DBR_LOOP=3"],  # one masked loop, 4 per iteration
