@@ -230,6 +230,11 @@ int kmc_hip_local_sort_totals(kmc_hip_ctx *ctx, int dev, int reset, uint64_t *n_
  * bucket-aligned tiles in LDS —, one-word records the LSD path; 2 = hybrid for every record width, and the LDS sort for sort-only calls; -h = `h` top
  * bytes forced. Also clears the hybrid / redo group counters of kmc_hip_local_sort_totals. Returns the mode that was in force. */
 int kmc_hip_set_hybrid(int mode);
+/* Groups of bins (a bin on its own is a group of one) by the path their sort + compaction took, process-wide since the last kmc_hip_set_hybrid: [0] top bytes
+ * through HBM, tiles ranked AND counted inside LDS (k_bucket_rank fused: the default since round 4, every record width); [1] ranked in place, then k_compact
+ * (one-word records whose output may outgrow a tile's span); [2] k_bucket_count (KMC_HIP_RANK=0, mode 2, or too many key bits below the buckets); [3] 8-bit
+ * LSD passes over every key byte + k_compact (rounds 1-2; redo runs; tiny groups). What replaces raduls_impl.h:216-520 / small_sort.h for a group. */
+int kmc_hip_path_counters(uint64_t counters[4]);
 /* Device memory helpers so non-HIP callers (ctypes tests, the C++ worker) need not link HIP themselves. */
 int kmc_hip_malloc(kmc_hip_ctx *ctx, int dev, uint64_t bytes, void **d_ptr);
 int kmc_hip_free(kmc_hip_ctx *ctx, int dev, void *d_ptr);

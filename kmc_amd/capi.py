@@ -83,7 +83,7 @@ SYMBOLS = [
     "kmc_hip_sort_records", "kmc_hip_sort_records_into", "kmc_hip_sort_records_device",
     "kmc_hip_process_bin", "kmc_hip_process_bin_multi", "kmc_hip_process_bins_submit", "kmc_hip_process_bins_wait", "kmc_hip_process_bin_submit", "kmc_hip_process_bin_wait", "kmc_hip_process_bin_device",
     "kmc_hip_process_bins_device", "kmc_hip_order_database_device",
-    "kmc_hip_allreduce_stats", "kmc_hip_last_timings", "kmc_hip_scatter_totals", "kmc_hip_local_sort_totals", "kmc_hip_set_hybrid",
+    "kmc_hip_allreduce_stats", "kmc_hip_last_timings", "kmc_hip_scatter_totals", "kmc_hip_local_sort_totals", "kmc_hip_set_hybrid", "kmc_hip_path_counters",
     "kmc_hip_malloc", "kmc_hip_free", "kmc_hip_memcpy_h2d", "kmc_hip_memcpy_d2h",
     "kmc_hip_host_register", "kmc_hip_host_unregister", "kmc_hip_host_alloc", "kmc_hip_host_free", "kmc_hip_synchronize",
     "kmc_hip_debug_expand", "kmc_hip_debug_compact", "kmc_hip_debug_split_reads",
@@ -97,6 +97,11 @@ _LIB = None
 def lib_path() -> str:
     """In-tree libkmc_hip.so; $KMC_HIP_LIB overrides (tuning variants built by tools/build_variants.py)."""
     return os.environ.get("KMC_HIP_LIB") or _build.LIB_HIP
+
+
+def backend_kind() -> int:
+    """0 = the GPU library, 1 = the CPU emulation of the host library (tests), 2 = the mock (tests)"""
+    return int(load().kmc_hip_backend_kind())
 
 
 def require_gpu_backend():
@@ -375,6 +380,12 @@ class Context:
         n, t, k, h, r = C.c_uint64(), C.c_double(), C.c_uint64(), C.c_uint64(), C.c_uint64()
         self._chk(self.L.kmc_hip_local_sort_totals(self.h, dev, 1 if reset else 0, C.byref(n), C.byref(t), C.byref(k), C.byref(h), C.byref(r)))
         return dict(launches=n.value, ms=t.value, records=k.value, hybrid_groups=h.value, redo_groups=r.value)
+
+    def path_counters(self):
+        """process-wide group counts by path since the last set_hybrid: dict(rank_count, rank_compact, bucket_count, lsd)"""
+        c = (C.c_uint64 * 4)()
+        self._chk(self.L.kmc_hip_path_counters(c))
+        return dict(rank_count=c[0], rank_compact=c[1], bucket_count=c[2], lsd=c[3])
 
     def process_bins_device(self, p: BinParams, descs, n_streams: int = 0, dev: int = 0):
         """Enqueue many device-resident bins (ctypes array of BinDesc); returns after enqueueing — call synchronize()."""

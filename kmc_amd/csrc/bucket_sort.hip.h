@@ -40,12 +40,6 @@
                          * without records still walk through the kernel: windows of 2/3 32.4, of 5/6 33.4, of 11/12 33.5 Gk-mers/s on the quarter workload).
                          * A tile that outgrows the capacity is taken in two chunks of whole buckets */
 #endif
-#ifndef BR_PROLOGUE
-#define BR_PROLOGUE 0 /* how a record finds its bucket: 0 = 64-bit head masks per row, 1 = ordinal table of bucket starts (as k_bucket_count) */
-#endif
-#ifndef BR_LOOP
-#define BR_LOOP 0 /* shape of the pair loop (tuning): 0 = 4 per iteration + single tail, unrolled as the compiler likes (16 + 4 + 1) */
-#endif
 #ifndef BR_MIN_WAVES
 #define BR_MIN_WAVES 6 /* waves per SIMD the register allocator must leave room for: two workgroups of 12 waves per CU (<= 80 VGPRs; it takes 62) */
 #endif
@@ -368,38 +362,91 @@ __global__ void __launch_bounds__(BsCfg<SIZE>::THREADS) k_bucket_sort(u64 *__res
 	}
 }
 
-/* ------------------------------------------------------------------------------------------------ one-word records: rank inside the bucket
- * k_bucket_sort finishes a sub-bucket with ONE thread; for one-word k-mers at sequencing depth a bucket is the ~30 copies of one k-mer plus a few
- * one-off neighbours (read errors below the bucket bits), those land in the same sub-bucket interleaved, and the thread that owns it walks them
- * serially while 29 of 30 threads have nothing to do. Here every record finds its own place, all at once:
+/* ------------------------------------------------------------------------------------------------ rank inside the bucket, count in place
+ * k_bucket_sort finishes a sub-bucket with ONE thread; at sequencing depth a bucket is the ~30 copies of one k-mer plus a few one-off neighbours
+ * (read errors below the bucket bits), those land in the same sub-bucket interleaved, and the thread that owns it walks them serially while 29 of
+ * 30 threads have nothing to do. Here every record finds its own place, all at once:
  *       place(i) = bucket start + #{ j in the bucket : (rem_j, j) < (rem_i, i) }        rem = the key bits below the bucket bits
- * The pair is one word — rem above, bucket-relative index below: 32 bits whenever the tile's largest bucket leaves room for its indices next to rem (always,
- * on sequencing data with 24 key bits left), else 64 with the index in the low 16 — so a step of the count is an LDS read (the lanes of a bucket read the
- * same address: a broadcast), a compare and an add-with-carry; the wave takes as many steps as its largest bucket has records (the bench's bins with the
- * top 30 key bits ordered: 25 on average). Stable (ties go by index), no atomics, no
- * data-dependent failure: the only thing it cannot take is a bucket larger than the tile (flag -> the host's LSD passes, as in k_bucket_sort).
- * Work grows with sum(bucket^2): the host asks for enough HBM passes to keep buckets at a few dozen records (plan_sort). Needs
- * key_bits - hbits <= 48. The sorted tile goes back in place; run lengths, cutoffs and output are k_compact's, unchanged. */
-constexpr int BR_STRIDE = BsCfg<1>::CAP - BsCfg<1>::CAP / BR_SLACK_DIV; /* window length of k_bucket_rank's tiles */
-__global__ void __launch_bounds__(BsCfg<1>::THREADS, BR_MIN_WAVES) k_bucket_rank(u64 *__restrict__ recs, u32 key_bits, u32 hbits, const u64 *__restrict__ bounds, u32 *flag)
+ * A step of the count is an LDS read (the lanes of a bucket read the same address: a broadcast), a compare and an add-with-carry; the wave takes as
+ * many steps as its largest bucket has records (the bench's bins with the top 30 key bits ordered: 25 on average). Stable (ties go by index), no
+ * atomics, no data-dependent failure: the only thing it cannot take is a bucket larger than the tile (flag -> the host's LSD passes, as in
+ * k_bucket_sort). Work grows with sum(bucket^2): the host asks for enough HBM passes to keep buckets at a few dozen records (plan_sort).
+ * What is compared, by record width:
+ *   one word     (rem, bucket-relative index) in ONE word: 32 bits whenever the tile's largest bucket leaves room for its indices next to rem (always, on
+ *                sequencing data with 24 key bits left), else 64 with the index in the low 16 (host: key_bits - hbits <= 48)
+ *   two words    rem <= 80 bits (host): A = rem >> 16 (64 bits), B = (rem & 0xFFFF) << 16 | index (32 bits); less = A' < A or (A' == A and B' < B)
+ *   wider        the records themselves, arrival order in LDS, lexicographic from the top word (inside a bucket the bucket bits are equal), ties by index
+ * FUSED (round 4): the tile, now in order inside LDS and made of whole buckets — no run of equal k-mers leaves it —, is counted where it lies: run tails,
+ * counts, cutoffs, clamp, ranks of the counted k-mers exactly as k_compact does on rows of 64 records (kb_sorter.h:1128-1281), the (suffix, counter)
+ * records assembled in LDS and written, coalesced, to the tile's span of the free record array (two-phase output: k_compact_fold turns the tiles' counts
+ * into offsets, k_compact_gather moves the records), LUT and tallies sharded as in k_compact. The sorted tile never goes back to HBM: 8 SIZE bytes per
+ * record are read once, ~0.3 bytes per record are written. Not FUSED: the sorted tile is written back in place (k_compact follows; parameter sets
+ * whose records may outgrow a span). */
+#ifndef BR_THREADS
+#define BR_THREADS 768 /* 12 waves; two workgroups per CU (one-word records: 48 KB of pairs / records + 24 KB of bucket starts each) */
+#endif
+template <int SIZE> struct BrCfg {
+	static constexpr int THREADS = BR_THREADS;
+	static constexpr int ITEMS = SIZE == 1 ? 8 : (SIZE == 2 ? 4 : 2); /* rows of 64 records per wave */
+	static constexpr int CAP = THREADS * ITEMS;                        /* records a tile (or a chunk of one) may hold: 6144 / 3072 / 1536 */
+	static constexpr int STRIDE = CAP - CAP / BR_SLACK_DIV;            /* window length */
+	static constexpr int NW = THREADS / 64;
+	static constexpr size_t R0 = (size_t)CAP * SIZE * 8;    /* the pairs; then the records in order; then the staged output */
+	static constexpr size_t R1 = ((size_t)CAP + 2) * 4;     /* the table of bucket starts; then LUT prefixes / counts of the staged records */
+	static constexpr size_t LDS = R0 + R1 + (size_t)(7 * NW + 8) * 4 + 16;
+	static_assert(CAP < 65536, "tile-relative positions are kept in 16 bits");
+};
+template <int SIZE> constexpr size_t br_lds_bytes() { return BrCfg<SIZE>::LDS; }
+/* key bits that may be left below the bucket bits (plan_sort) */
+template <int SIZE> constexpr u32 br_rem_limit() { return SIZE == 1 ? 48u : (SIZE == 2 ? 80u : 64u * SIZE); }
+
+/* The tiles of up to GRP_MAX bins (not FUSED: one array, g = 1). Tile t of bin b = [bounds[b][t], bounds[b][t+1]); one that outgrows the capacity is taken
+ * in two chunks of whole buckets by its two workgroups (blockIdx.y). Chunk y of tile t reports into slot 2 t + y. */
+struct GrpRank {
+	u32 g, win_prefix[GRP_MAX + 1];
+	u64 *S[GRP_MAX];            /* the bin's slice of the record array, ordered by the top `hbits` key bits */
+	const u64 *bounds[GRP_MAX]; /* [windows + 1] (k_bucket_bounds) */
+	uint8_t *scratch[GRP_MAX];  /* FUSED: the bin's slice of the free record array: a chunk's records go to scratch + (its first record) * 8 SIZE */
+	u64 *status[GRP_MAX];       /* FUSED: [2 windows + 1] counted k-mers of every chunk (zeroed by the host) */
+	u64 *chunk_src[GRP_MAX];    /* FUSED: [2 windows] first record of every chunk that counted something (the gather's source) */
+	u64 *lut_base[GRP_MAX];
+	u64 *tally[GRP_MAX];        /* [CP_SHARDS][4] */
+};
+
+template <int SIZE, bool FUSED>
+__global__ void __launch_bounds__(BrCfg<SIZE>::THREADS, BR_MIN_WAVES) k_bucket_rank(const GrpRank gr, DevParams P, u32 key_bits, u32 hbits, u32 lut_shards, u64 lut_stride,
+                                                                                  u32 lut_mask, u32 *flag)
 {
-	constexpr int THREADS = BsCfg<1>::THREADS, ITEMS = BsCfg<1>::ITEMS, CAP = BsCfg<1>::CAP, NW = THREADS / 64;
-	constexpr u64 S = BR_STRIDE;
+	constexpr int THREADS = BrCfg<SIZE>::THREADS, ITEMS = BrCfg<SIZE>::ITEMS, CAP = BrCfg<SIZE>::CAP, NW = BrCfg<SIZE>::NW;
+	constexpr u64 S = BrCfg<SIZE>::STRIDE;
 	constexpr u32 NONE = 0xFFFFFFFFu;
 	KMC_DYN_LDS(unsigned char, s_raw);
-	u64 *s_key = reinterpret_cast<u64 *>(s_raw);                          /* [CAP] (rem, index) pairs, then the records in order */
-	u32 *s_wfirst = reinterpret_cast<u32 *>(s_key + CAP), *s_wlast = s_wfirst + NW; /* [NW] each: first / last bucket start inside wave w's rows */
-	u32 *s_wmax = s_wlast + NW;                                                      /* [NW] largest bucket a wave has seen */
+	u64 *s_key = reinterpret_cast<u64 *>(s_raw);                              /* R0 */
+	u32 *s_start = reinterpret_cast<u32 *>(s_raw + BrCfg<SIZE>::R0);          /* R1 [CAP + 2] */
+	u32 *s_wfirst = s_start + CAP + 2;                                        /* [NW] bucket starts in wave w's rows */
+	u32 *s_wmax = s_wfirst + NW;                                              /* [NW] largest bucket a wave has seen; [0]: the cut of a long tile */
+	u32 *s_wlast = s_wmax + NW;                                               /* [NW] FUSED: the last run tail inside wave w's rows */
+	u32 *s_wcnt = s_wlast + NW;                                               /* [NW] FUSED: counted k-mers of wave w */
+	u32 *s_wtal = s_wcnt + NW;                                                /* [NW][3] FUSED: distinct / below min / above max of wave w */
 
-	const u64 j = blockIdx.x;
-	const u64 b0 = bounds[j], b1 = bounds[j + 1];
-	if (b0 >= (j + 1) * S || b0 >= b1)
+	const u32 gtile = blockIdx.x;
+	const u32 bin = (u32)__builtin_amdgcn_readfirstlane((int)grp_find(gr.win_prefix, gr.g, gtile));
+	const u32 tile = gtile - gr.win_prefix[bin];
+	const u64 *__restrict__ bounds = gr.bounds[bin];
+	u64 *__restrict__ recs = gr.S[bin];
+	const u64 b0 = bounds[tile], b1 = bounds[tile + 1];
+	if (b0 >= ((u64)tile + 1) * S || b0 >= b1)
 		return; /* no bucket starts in this window */
 	const u32 tid = threadIdx.x, lane = tid & 63;
 	const u32 wave = (u32)__builtin_amdgcn_readfirstlane((int)(tid >> 6));
 	const u32 crel = wave * (ITEMS * 64); /* the wave owns ITEMS rows of 64 consecutive records */
-	const u32 ksh = 64 - key_bits, bsh = 64 - hbits;
-	auto bucket_of = [&](u64 x) -> u64 { return hbits ? (x << ksh) >> bsh : 0ull; };
+	const u32 bsh = 64 - hbits;
+	auto bucket_of = [&](const u64(&x)[SIZE]) -> u64 { return hbits ? bs_p64<SIZE>(x, key_bits) >> bsh : 0ull; };
+	auto bucket_at = [&](u64 i) -> u64 {
+		u64 x[SIZE];
+		load_rec<SIZE>(recs + i * SIZE, x);
+		return bucket_of(x);
+	};
 	/* A tile longer than the capacity (windows are nearly as long as the capacity: BR_SLACK_DIV) is taken in two chunks of whole buckets, by the two
 	 * workgroups (blockIdx.y = 0, 1) every tile has: the first takes the records up to the last bucket start inside the capacity, the second the rest.
 	 * Nearly every tile fits, and its second workgroup returns at once. */
@@ -414,7 +461,7 @@ __global__ void __launch_bounds__(BsCfg<1>::THREADS, BR_MIN_WAVES) k_bucket_rank
 			*s_wmax = 0;
 		__syncthreads();
 		for (u32 idx = tid + 1; idx <= (u32)CAP; idx += THREADS) /* b0 + CAP < b1 */
-			if (bucket_of(recs[b0 + idx]) != bucket_of(recs[b0 + idx - 1]))
+			if (bucket_at(b0 + idx) != bucket_at(b0 + idx - 1))
 				atomicMax(s_wmax, idx);
 		__syncthreads();
 		const u32 cut = *s_wmax;
@@ -431,37 +478,39 @@ __global__ void __launch_bounds__(BsCfg<1>::THREADS, BR_MIN_WAVES) k_bucket_rank
 			len = (u32)(b1 - c0);
 		}
 	}
-	u64 *__restrict__ T = recs + c0;
+	u64 *__restrict__ T = recs + c0 * SIZE;
 
-	u64 key[ITEMS];
+	u64 key[ITEMS][SIZE];
 #pragma unroll
 	for (int r = 0; r < ITEMS; ++r) {
 		const u32 idx = crel + r * 64 + lane;
-		key[r] = idx < len ? T[idx] : 0ull;
+		if (idx < len)
+			load_rec<SIZE>(T + (size_t)idx * SIZE, key[r]);
+		else {
+#pragma unroll
+			for (int w = 0; w < SIZE; ++w)
+				key[r][w] = 0;
+		}
 	}
-#if BR_PROLOGUE == 1
 	/* Bucket starts ("heads") and, from them, every record's bucket — as in k_bucket_count: a record's bucket is known by its ORDINAL among the tile's
-	 * buckets (heads at or before the record - 1: a popcount below the lane + the heads of the rows and waves before); the start positions go into a table
-	 * indexed by that ordinal, and a record finds the start and the end of its bucket with two LDS reads. A record starts a bucket iff it differs from
-	 * its predecessor above the low `rbits` bits (the predecessor comes through a DPP wave shift, not through the LDS crossbar). */
-	const u32 rbits = key_bits - hbits; /* <= 48 (host) */
-	const u64 rmask = rbits >= 64 ? ~0ull : ((1ull << rbits) - 1);
-	u32 *s_start = s_wmax + NW; /* [CAP + 1] */
-	u64 prev_key = 0;
+	 * buckets (heads at or before the record - 1: a popcount below the lane + the heads of the rows and waves before); the start positions go into a
+	 * table indexed by that ordinal, and a record finds the start and the end of its bucket with two LDS reads. The predecessor's bucket comes through
+	 * a DPP wave shift, not through the LDS crossbar. */
+	u64 prev_b = 0;
 	if (crel > 0 && crel - 1 < len)
-		prev_key = T[crel - 1];
+		prev_b = bucket_at(c0 + crel - 1);
 	u32 headbits = 0, below[ITEMS], wheads = 0;
 #pragma unroll
 	for (int r = 0; r < ITEMS; ++r) {
 		const u32 idx = crel + r * 64 + lane;
-		const u32 plo = wave_shift_up1((u32)key[r], (u32)prev_key, lane), phi = wave_shift_up1((u32)(key[r] >> 32), (u32)(prev_key >> 32), lane);
-		const u64 x = (((u64)phi << 32) | plo) ^ key[r];
-		const bool head = idx < len && (idx == 0 || (hbits != 0 && (x >> rbits) != 0));
+		const u64 bk = bucket_of(key[r]);
+		const u32 plo = wave_shift_up1((u32)bk, (u32)prev_b, lane), phi = wave_shift_up1((u32)(bk >> 32), (u32)(prev_b >> 32), lane);
+		const bool head = idx < len && (idx == 0 || (((u64)phi << 32) | plo) != bk);
 		const u64 m = __ballot(head);
 		headbits |= head ? 1u << r : 0u;
 		below[r] = __builtin_amdgcn_mbcnt_hi((u32)(m >> 32), __builtin_amdgcn_mbcnt_lo((u32)m, wheads));
 		wheads += (u32)__popcll(m);
-		prev_key = __shfl(key[r], 63);
+		prev_b = __shfl(bk, 63);
 	}
 	if (lane == 0)
 		s_wfirst[wave] = wheads;
@@ -480,11 +529,11 @@ __global__ void __launch_bounds__(BsCfg<1>::THREADS, BR_MIN_WAVES) k_bucket_rank
 	if (tid == 0)
 		s_start[total_heads] = len;
 	__syncthreads();
-	u32 span[ITEMS], rel[ITEMS], widest = 0;
+	u32 span[ITEMS], rel[ITEMS], widest = 0; /* span: [15:0] start of the record's bucket, [31:16] its end (tile-relative; CAP < 65536) */
 #pragma unroll
 	for (int r = 0; r < ITEMS; ++r) {
 		const u32 idx = crel + r * 64 + lane;
-		span[r] = 0;
+		span[r] = 0; /* nothing to count */
 		rel[r] = 0;
 		if (idx < len) {
 			const u32 ord = wave_heads_before + below[r] + ((headbits >> r) & 1u) - 1u;
@@ -494,138 +543,105 @@ __global__ void __launch_bounds__(BsCfg<1>::THREADS, BR_MIN_WAVES) k_bucket_rank
 			widest = widest > bend - bstart ? widest : bend - bstart;
 		}
 	}
-#else
-	u64 prev_last = 0;
-	if (crel > 0 && crel - 1 < len)
-		prev_last = bucket_of(T[crel - 1]);
-	u64 heads[ITEMS];
-	u32 wfirst = NONE, wlast = NONE;
-#pragma unroll
-	for (int r = 0; r < ITEMS; ++r) {
-		const u32 rowrel = crel + r * 64, idx = rowrel + lane;
-		const u64 bk = bucket_of(key[r]);
-		u64 pv = __shfl_up(bk, 1);
-		if (lane == 0)
-			pv = prev_last;
-		const u64 m = __ballot(idx < len && (idx == 0 || pv != bk));
-		heads[r] = m;
-		if (m) {
-			if (wfirst == NONE)
-				wfirst = rowrel + (u32)__ffsll((long long)m) - 1;
-			wlast = rowrel + 63 - (u32)__clzll((long long)m);
-		}
-		prev_last = __shfl(bk, 63);
-	}
-	if (lane == 0) {
-		s_wfirst[wave] = wfirst;
-		s_wlast[wave] = wlast;
-	}
-	__syncthreads();
-	u32 carry_f = 0, carry_b = len; /* start of the bucket open at the wave's first record; first bucket start after the wave's last record */
-#pragma unroll
-	for (int w = 0; w < NW; ++w) {
-		const u32 l = s_wlast[w], f = s_wfirst[NW - 1 - w];
-		if (w < (int)wave && l != NONE)
-			carry_f = l;
-		if (NW - 1 - w > (int)wave && f != NONE)
-			carry_b = f;
-	}
-	carry_f = (u32)__builtin_amdgcn_readfirstlane((int)carry_f);
-	carry_b = (u32)__builtin_amdgcn_readfirstlane((int)carry_b);
-	u32 span[ITEMS]; /* [15:0] start of the record's bucket, [31:16] its end (tile-relative; CAP < 65536) */
-#pragma unroll
-	for (int r = ITEMS - 1; r >= 0; --r) {
-		const u32 rowrel = crel + r * 64;
-		const u64 m = heads[r];
-		const u64 above = m & ~(((2ull << lane) - 1));
-		span[r] = (above ? rowrel + (u32)__ffsll((long long)above) - 1 : carry_b) << 16;
-		if (m)
-			carry_b = rowrel + (u32)__ffsll((long long)m) - 1;
-	}
-	const u32 rbits = key_bits - hbits; /* <= 48 (host) */
-	const u64 rmask = rbits >= 64 ? ~0ull : ((1ull << rbits) - 1);
-	u32 rel[ITEMS], widest = 0;
-#pragma unroll
-	for (int r = 0; r < ITEMS; ++r) {
-		const u32 rowrel = crel + r * 64, idx = rowrel + lane;
-		const u64 m = heads[r];
-		const u64 upto = m & ((2ull << lane) - 1);
-		const u32 bstart = upto ? rowrel + 63 - (u32)__clzll((long long)upto) : carry_f;
-		if (m)
-			carry_f = rowrel + 63 - (u32)__clzll((long long)m);
-		span[r] |= bstart;
-		rel[r] = idx - bstart;
-		if (idx < len)
-			widest = widest > (span[r] >> 16) - bstart ? widest : (span[r] >> 16) - bstart;
-		else
-			span[r] = 0; /* nothing to count */
-	}
-#endif
-	/* the largest bucket of the tile decides the width of the pairs: (rem, index) in 32 bits whenever they fit — half the LDS traffic and one-pass compares */
-#pragma unroll
-	for (int o = 32; o >= 1; o >>= 1) {
-		const u32 other = (u32)__shfl((int)widest, (int)(lane ^ (u32)o));
-		widest = widest > other ? widest : other;
-	}
-	if (lane == 0)
-		s_wmax[wave] = widest;
-	__syncthreads();
-#pragma unroll
-	for (int w = 0; w < NW; ++w)
-		widest = widest > s_wmax[w] ? widest : s_wmax[w];
-	const bool narrow = rbits < 32 && widest <= (1u << (32 - rbits));
+	const u32 rbits = key_bits - hbits; /* <= br_rem_limit (host) */
 	u32 place[ITEMS];
-	if (narrow) {
-		u32 *s_k32 = reinterpret_cast<u32 *>(s_key);
-		const u32 sh = 32 - rbits;
-		u32 c32[ITEMS];
+	if constexpr (SIZE == 1) {
+		const u64 rmask = rbits >= 64 ? ~0ull : ((1ull << rbits) - 1);
+		/* the largest bucket of the tile decides the width of the pairs: (rem, index) in 32 bits whenever they fit — half the LDS traffic and one-pass compares */
+#pragma unroll
+		for (int o = 32; o >= 1; o >>= 1) {
+			const u32 other = (u32)__shfl((int)widest, (int)(lane ^ (u32)o));
+			widest = widest > other ? widest : other;
+		}
+		if (lane == 0)
+			s_wmax[wave] = widest;
+		__syncthreads();
+#pragma unroll
+		for (int w = 0; w < NW; ++w)
+			widest = widest > s_wmax[w] ? widest : s_wmax[w];
+		const bool narrow = rbits < 32 && widest <= (1u << (32 - rbits));
+		if (narrow) {
+			u32 *s_k32 = reinterpret_cast<u32 *>(s_key);
+			const u32 sh = 32 - rbits;
+			u32 c32[ITEMS];
+#pragma unroll
+			for (int r = 0; r < ITEMS; ++r) {
+				const u32 idx = crel + r * 64 + lane;
+				c32[r] = ((u32)(key[r][0] & rmask) << sh) | rel[r]; /* rel < widest <= 2^sh */
+				if (idx < len)
+					s_k32[idx] = c32[r];
+			}
+			__syncthreads();
+#pragma unroll
+			for (int r = 0; r < ITEMS; ++r) {
+				const u32 bstart = span[r] & 0xFFFFu, bend = span[r] >> 16;
+				const u32 c = c32[r];
+				u32 rank = 0, q = bstart;
+				for (; q + 4 <= bend; q += 4) {
+					const u32 a0 = s_k32[q], a1 = s_k32[q + 1], a2 = s_k32[q + 2], a3 = s_k32[q + 3];
+					rank += (a0 < c ? 1u : 0u) + (a1 < c ? 1u : 0u) + (a2 < c ? 1u : 0u) + (a3 < c ? 1u : 0u);
+				}
+				for (; q < bend; ++q)
+					rank += s_k32[q] < c ? 1u : 0u;
+				place[r] = bstart + rank;
+			}
+		} else {
+#pragma unroll
+			for (int r = 0; r < ITEMS; ++r) {
+				const u32 idx = crel + r * 64 + lane;
+				if (idx < len)
+					s_key[idx] = ((key[r][0] & rmask) << 16) | (u64)rel[r];
+			}
+			__syncthreads();
+#pragma unroll
+			for (int r = 0; r < ITEMS; ++r) {
+				const u32 bstart = span[r] & 0xFFFFu, bend = span[r] >> 16;
+				const u64 c = ((key[r][0] & rmask) << 16) | (u64)rel[r];
+				u32 rank = 0, q = bstart;
+				for (; q + 2 <= bend; q += 2) {
+					const u64 a = s_key[q], b = s_key[q + 1];
+					rank += (a < c ? 1u : 0u) + (b < c ? 1u : 0u);
+				}
+				if (q < bend)
+					rank += s_key[q] < c ? 1u : 0u;
+				place[r] = bstart + rank;
+			}
+		}
+	} else if constexpr (SIZE == 2) {
+		u64 *s_A = s_key;                                     /* [CAP] rem >> 16 */
+		u32 *s_B = reinterpret_cast<u32 *>(s_key + CAP);      /* [CAP] (rem & 0xFFFF) << 16 | index */
+		const u64 m1 = rbits > 64 ? ((1ull << (rbits - 64)) - 1) : 0ull; /* rbits - 64 <= 16 */
+		const u64 m0 = rbits >= 64 ? ~0ull : ((1ull << rbits) - 1);
+		u64 cA[ITEMS];
+		u32 cB[ITEMS];
 #pragma unroll
 		for (int r = 0; r < ITEMS; ++r) {
 			const u32 idx = crel + r * 64 + lane;
-			c32[r] = ((u32)(key[r] & rmask) << sh) | rel[r]; /* rel < widest <= 2^sh */
-			if (idx < len)
-				s_k32[idx] = c32[r];
+			const u64 x0 = key[r][0] & m0, x1 = key[r][1] & m1;
+			cA[r] = (x1 << 48) | (x0 >> 16);
+			cB[r] = ((u32)(x0 & 0xFFFFu) << 16) | rel[r];
+			if (idx < len) {
+				s_A[idx] = cA[r];
+				s_B[idx] = cB[r];
+			}
 		}
 		__syncthreads();
 #pragma unroll
 		for (int r = 0; r < ITEMS; ++r) {
 			const u32 bstart = span[r] & 0xFFFFu, bend = span[r] >> 16;
-			const u32 c = c32[r];
+			const u64 A = cA[r];
+			const u32 B = cB[r];
 			u32 rank = 0, q = bstart;
-#if BR_LOOP == 1 /* 4 pairs per iteration, not unrolled further */
-#pragma unroll 1
-			for (; q + 4 <= bend; q += 4) {
-				const u32 a0 = s_k32[q], a1 = s_k32[q + 1], a2 = s_k32[q + 2], a3 = s_k32[q + 3];
-				rank += (a0 < c ? 1u : 0u) + (a1 < c ? 1u : 0u) + (a2 < c ? 1u : 0u) + (a3 < c ? 1u : 0u);
+			for (; q + 2 <= bend; q += 2) {
+				const u64 a0 = s_A[q], a1 = s_A[q + 1];
+				const u32 e0 = s_B[q], e1 = s_B[q + 1];
+				rank += ((a0 < A) || (a0 == A && e0 < B) ? 1u : 0u) + ((a1 < A) || (a1 == A && e1 < B) ? 1u : 0u);
 			}
-#pragma unroll 1
-			for (; q < bend; ++q)
-				rank += s_k32[q] < c ? 1u : 0u;
-#elif BR_LOOP == 2 /* 8 pairs per iteration, not unrolled further */
-#pragma unroll 1
-			for (; q + 8 <= bend; q += 8) {
-#pragma unroll
-				for (int t = 0; t < 8; ++t)
-					rank += s_k32[q + t] < c ? 1u : 0u;
+			if (q < bend) {
+				const u64 a0 = s_A[q];
+				const u32 e0 = s_B[q];
+				rank += (a0 < A) || (a0 == A && e0 < B) ? 1u : 0u;
 			}
-#pragma unroll 1
-			for (; q < bend; ++q)
-				rank += s_k32[q] < c ? 1u : 0u;
-#elif BR_LOOP == 3 /* one loop: 4 pairs per iteration, the last iteration masked (the words behind a bucket are other buckets' pairs: readable, not counted) */
-#pragma unroll 1
-			for (; q < bend; q += 4) {
-				const u32 a0 = s_k32[q], a1 = s_k32[q + 1], a2 = s_k32[q + 2], a3 = s_k32[q + 3];
-				const u32 left = bend - q;
-				rank += (a0 < c ? 1u : 0u) + ((a1 < c && left > 1) ? 1u : 0u) + ((a2 < c && left > 2) ? 1u : 0u) + ((a3 < c && left > 3) ? 1u : 0u);
-			}
-#else
-			for (; q + 4 <= bend; q += 4) {
-				const u32 a0 = s_k32[q], a1 = s_k32[q + 1], a2 = s_k32[q + 2], a3 = s_k32[q + 3];
-				rank += (a0 < c ? 1u : 0u) + (a1 < c ? 1u : 0u) + (a2 < c ? 1u : 0u) + (a3 < c ? 1u : 0u);
-			}
-			for (; q < bend; ++q)
-				rank += s_k32[q] < c ? 1u : 0u;
-#endif
 			place[r] = bstart + rank;
 		}
 	} else {
@@ -633,20 +649,19 @@ __global__ void __launch_bounds__(BsCfg<1>::THREADS, BR_MIN_WAVES) k_bucket_rank
 		for (int r = 0; r < ITEMS; ++r) {
 			const u32 idx = crel + r * 64 + lane;
 			if (idx < len)
-				s_key[idx] = ((key[r] & rmask) << 16) | (u64)rel[r];
+				store_rec<SIZE>(s_key + (size_t)idx * SIZE, key[r]);
 		}
 		__syncthreads();
 #pragma unroll
 		for (int r = 0; r < ITEMS; ++r) {
 			const u32 bstart = span[r] & 0xFFFFu, bend = span[r] >> 16;
-			const u64 c = ((key[r] & rmask) << 16) | (u64)rel[r];
-			u32 rank = 0, q = bstart;
-			for (; q + 2 <= bend; q += 2) {
-				const u64 a = s_key[q], b = s_key[q + 1];
-				rank += (a < c ? 1u : 0u) + (b < c ? 1u : 0u);
+			const u32 me = bstart + rel[r];
+			u32 rank = 0;
+			for (u32 q = bstart; q < bend; ++q) {
+				u64 o[SIZE];
+				load_rec<SIZE>(s_key + (size_t)q * SIZE, o);
+				rank += (kmc_less<SIZE>(o, key[r]) || (q < me && kmc_equal<SIZE>(o, key[r]))) ? 1u : 0u;
 			}
-			if (q < bend)
-				rank += s_key[q] < c ? 1u : 0u;
 			place[r] = bstart + rank;
 		}
 	}
@@ -655,13 +670,225 @@ __global__ void __launch_bounds__(BsCfg<1>::THREADS, BR_MIN_WAVES) k_bucket_rank
 	for (int r = 0; r < ITEMS; ++r) {
 		const u32 idx = crel + r * 64 + lane;
 		if (idx < len)
-			s_key[place[r]] = key[r];
+			store_rec<SIZE>(s_key + (size_t)place[r] * SIZE, key[r]);
 	}
 	__syncthreads();
-	for (u32 idx = tid; idx < len; idx += THREADS)
-		T[idx] = s_key[idx];
+	if constexpr (!FUSED) {
+		for (u32 idx = tid; idx < len; idx += THREADS) {
+			u64 x[SIZE];
+			load_rec<SIZE>(s_key + (size_t)idx * SIZE, x);
+			store_rec<SIZE>(T + (size_t)idx * SIZE, x);
+		}
+	} else {
+		/* ---- the tile is in order in LDS and made of whole buckets: count it where it lies (k_compact's tile body; nothing below the tile matters) */
+		const u32 rec_bytes = P.sbytes + P.cbytes;
+		const bool use_lut = P.lut_prefix_len != 0 && !P.kff && !P.without_output;
+		const u64 lane_lt = (1ull << lane) - 1;
+		u32 tail_bits = 0, wlast = NONE;
+#pragma unroll
+		for (int r = 0; r < ITEMS; ++r) {
+			const u32 idx = crel + r * 64 + lane;
+			bool is_tail = false;
+			if (idx < len) {
+				load_rec<SIZE>(s_key + (size_t)idx * SIZE, key[r]);
+				is_tail = true;
+				if (idx + 1 < len) {
+					u64 nx[SIZE];
+					load_rec<SIZE>(s_key + (size_t)(idx + 1) * SIZE, nx);
+					is_tail = !kmc_equal<SIZE>(nx, key[r]);
+				}
+			}
+			const u64 m = __ballot(is_tail);
+			if (is_tail)
+				tail_bits |= 1u << r;
+			if (m)
+				wlast = crel + r * 64 + 63 - (u32)__clzll((long long)m);
+		}
+		if (lane == 0)
+			s_wlast[wave] = wlast;
+		__syncthreads(); /* the records in order have been read: R0 and R1 are free */
+		u32 carry = NONE; /* -1: no tail before record 0 */
+#pragma unroll
+		for (int w = 0; w < NW; ++w) {
+			const u32 x = s_wlast[w];
+			if (w < (int)wave && x != NONE)
+				carry = x;
+		}
+		carry = (u32)__builtin_amdgcn_readfirstlane((int)carry);
+		u32 cnt[ITEMS];
+		u32 rank2[(ITEMS + 1) / 2]; /* wave-relative rank among counted k-mers, 16 bits each; 0xFFFF = not counted */
+		u32 nu = 0, nb = 0, na = 0, nc = 0;
+#pragma unroll
+		for (int r = 0; r < ITEMS; ++r) {
+			const u32 rowrel = crel + r * 64;
+			const u64 m = __ballot((tail_bits >> r) & 1u);
+			const u64 m_lt = m & lane_lt;
+			const u32 prev = m_lt ? rowrel + 63 - (u32)__clzll((long long)m_lt) : carry;
+			const u32 c = rowrel + lane - prev; /* uint32 like the reference counter */
+			const u64 mb = __ballot(c < P.cutoff_min) & m;
+			const u64 ma = __ballot(c > P.cutoff_max) & m & ~mb;
+			const u64 mc = m & ~mb & ~ma;
+			cnt[r] = c > P.counter_max ? P.counter_max : c;
+			const u32 rk = __builtin_amdgcn_mbcnt_hi((u32)(mc >> 32), __builtin_amdgcn_mbcnt_lo((u32)mc, nc));
+			const u32 rk16 = ((mc >> lane) & 1ull) ? rk : 0xFFFFu;
+			if (r & 1)
+				rank2[r >> 1] |= rk16 << 16;
+			else
+				rank2[r >> 1] = rk16;
+			nu += (u32)__popcll(m);
+			nb += (u32)__popcll(mb);
+			na += (u32)__popcll(ma);
+			nc += (u32)__popcll(mc);
+			if (m)
+				carry = rowrel + 63 - (u32)__clzll((long long)m);
+			__builtin_amdgcn_sched_barrier(0);
+		}
+		if (lane == 0) {
+			s_wcnt[wave] = nc;
+			s_wtal[wave * 3 + 0] = nu;
+			s_wtal[wave * 3 + 1] = nb;
+			s_wtal[wave * 3 + 2] = na;
+		}
+		__syncthreads();
+		u32 wave_off = 0, tile_counted = 0;
+#pragma unroll
+		for (int w = 0; w < NW; ++w) {
+			const u32 x = s_wcnt[w];
+			if (w < (int)wave)
+				wave_off += x;
+			tile_counted += x;
+		}
+		const u32 slot = 2 * tile + blockIdx.y;
+		if (tid == 0) {
+			u32 tu = 0, tb = 0, ta = 0;
+#pragma unroll
+			for (int w = 0; w < NW; ++w) {
+				tu += s_wtal[w * 3 + 0];
+				tb += s_wtal[w * 3 + 1];
+				ta += s_wtal[w * 3 + 2];
+			}
+			u64 *sh = gr.tally[bin] + (size_t)(slot % CP_SHARDS) * 4;
+			if (tu)
+				atomicAdd(&sh[0], (u64)tu);
+			if (tb)
+				atomicAdd(&sh[1], (u64)tb);
+			if (ta)
+				atomicAdd(&sh[2], (u64)ta);
+			if (!P.without_output && tile_counted) {
+				gr.status[bin][slot] = tile_counted;
+				gr.chunk_src[bin][slot] = c0;
+			}
+		}
+		if (!P.without_output && tile_counted) { /* uniform over the workgroup */
+			const u32 tile_bytes = tile_counted * rec_bytes;
+			const u32 pshift = 2 * (P.k - P.lut_prefix_len);
+			uint8_t *const dst = gr.scratch[bin] + c0 * (u64)(SIZE * 8); /* 8-byte aligned; room for 8 SIZE bytes per record of the chunk */
+			u32 *dst32 = reinterpret_cast<u32 *>(dst);
+			const u32 ndw = (tile_bytes + 3) >> 2; /* whole dwords: the bytes behind the last record are the span's own */
+			const u32 inv = rec_bytes > 1 ? (u32)(((1ull << 32) + rec_bytes - 1) / rec_bytes) : 0u; /* x / rec_bytes = umulhi(x, inv), exact for x < 2^29 */
+			u32 *s_aux = s_start; /* R1: LUT prefixes (one word) / counts (wider) of the staged records */
+			if constexpr (SIZE == 1) {
+				/* a record is one 64-bit value in output byte order (rec_bytes <= 8: host) */
+#pragma unroll
+				for (int r = 0; r < ITEMS; ++r) {
+					const u32 rk16 = (rank2[r >> 1] >> ((r & 1) * 16)) & 0xFFFFu;
+					if (rk16 != 0xFFFFu) {
+						const u32 rank = wave_off + rk16;
+						if (use_lut)
+							s_aux[rank] = (u32)kmc_remove_suffix<SIZE>(key[r], pshift) & lut_mask;
+						/* without a LUT prefix (KFF) the suffix bytes reach up to the top of the k-mer: a group tag above bit 2k must not get into them */
+						const u64 k0 = (2 * P.k < 64) ? (key[r][0] & ((1ull << (2 * P.k)) - 1)) : key[r][0];
+						u64 rv = P.sbytes ? __builtin_bswap64(k0 << (8 * (8 - P.sbytes))) : 0ull;
+						if (P.cbytes) {
+							const u32 cv = P.kff ? (__builtin_bswap32(cnt[r]) >> (8 * (4 - P.cbytes))) : cnt[r];
+							rv |= (u64)cv << (8 * P.sbytes);
+						}
+						s_key[rank] = rv;
+					}
+				}
+				__syncthreads();
+				for (u32 w = tid; w < ndw; w += THREADS) {
+					const u32 i0 = w << 2;
+					u32 ri = rec_bytes > 1 ? __umulhi(i0, inv) : i0, q = i0 - ri * rec_bytes;
+					u64 cur = s_key[ri];
+					u32 word = 0;
+#pragma unroll
+					for (int t = 0; t < 4; ++t) {
+						word |= ((u32)(cur >> (8 * q)) & 0xFFu) << (8 * t);
+						if (++q == rec_bytes) {
+							q = 0;
+							++ri;
+							cur = s_key[ri < (u32)CAP ? ri : (u32)CAP - 1];
+						}
+					}
+					dst32[w] = word;
+				}
+				if (use_lut) {
+					u64 *lut = gr.lut_base[bin] + (size_t)(slot % lut_shards) * lut_stride;
+					for (u32 j = tid; j < tile_counted; j += THREADS) {
+						const u32 pf = s_aux[j];
+						if (j + 1 == tile_counted || s_aux[j + 1] != pf)
+							atomicAdd(&lut[pf], (u64)(j + 1));
+						if (j > 0 && s_aux[j - 1] != pf)
+							atomicAdd(&lut[pf], (u64)0 - (u64)j);
+					}
+				}
+			} else {
+				/* staged: the k-mer (tag bits cleared) at its rank where the records were, its count in R1 */
+#pragma unroll
+				for (int r = 0; r < ITEMS; ++r) {
+					const u32 rk16 = (rank2[r >> 1] >> ((r & 1) * 16)) & 0xFFFFu;
+					if (rk16 != 0xFFFFu) {
+						const u32 rank = wave_off + rk16;
+						u64 kx[SIZE];
+#pragma unroll
+						for (int w = 0; w < SIZE; ++w)
+							kx[w] = key[r][w];
+						kmc_mask_low<SIZE>(kx, 2 * P.k);
+						store_rec<SIZE>(s_key + (size_t)rank * SIZE, kx);
+						s_aux[rank] = cnt[r];
+					}
+				}
+				__syncthreads();
+				/* byte i of the chunk's output is byte i % rec_bytes of record i / rec_bytes — suffix bytes high -> low (kb_sorter.h:1198-1199), then the
+				 * counter, little-endian for KMC (:1200-1201), big-endian for KFF (:1210-1211) */
+				auto out_byte = [&](u32 i) -> u32 {
+					const u32 ri = rec_bytes > 1 ? __umulhi(i, inv) : i, q = i - ri * rec_bytes;
+					if (q < P.sbytes) {
+						const u32 pbyte = P.sbytes - 1 - q;
+						return (u32)(s_key[(size_t)ri * SIZE + (pbyte >> 3)] >> ((pbyte & 7) * 8)) & 0xFFu;
+					}
+					const u32 cq = q - P.sbytes;
+					return (s_aux[ri] >> (8 * (P.kff ? (P.cbytes - 1 - cq) : cq))) & 0xFFu;
+				};
+#pragma clang loop unroll(disable) vectorize(disable)
+				for (u32 wd = tid; wd < ndw; wd += THREADS) {
+					const u32 i0 = wd * 4;
+					u32 word = out_byte(i0);
+					word |= (i0 + 1 < tile_bytes ? out_byte(i0 + 1) : 0u) << 8;
+					word |= (i0 + 2 < tile_bytes ? out_byte(i0 + 2) : 0u) << 16;
+					word |= (i0 + 3 < tile_bytes ? out_byte(i0 + 3) : 0u) << 24;
+					dst32[wd] = word;
+				}
+				if (use_lut) {
+					u64 *lut = gr.lut_base[bin] + (size_t)(slot % lut_shards) * lut_stride;
+					auto prefix_of = [&](u32 j) -> u32 {
+						u64 x[SIZE];
+						load_rec<SIZE>(s_key + (size_t)j * SIZE, x);
+						return (u32)kmc_remove_suffix<SIZE>(x, pshift) & lut_mask;
+					};
+					for (u32 j = tid; j < tile_counted; j += THREADS) {
+						const u32 pf = prefix_of(j);
+						if (j + 1 == tile_counted || prefix_of(j + 1) != pf)
+							atomicAdd(&lut[pf], (u64)(j + 1));
+						if (j > 0 && prefix_of(j - 1) != pf)
+							atomicAdd(&lut[pf], (u64)0 - (u64)j);
+					}
+				}
+			}
+		}
+	}
 }
-constexpr size_t br_lds_bytes() { return (size_t)BsCfg<1>::CAP * 8 + 3 * (BsCfg<1>::THREADS / 64) * 4 + (BR_PROLOGUE == 1 ? ((size_t)BsCfg<1>::CAP + 1) * 4 : 0) + 16; }
 
 /* ================================================================================================ fused: tile -> (k-mer, count) records
  * What stage 2 wants from the sort is not the sorted records but the RUNS of equal k-mers: ascending distinct k-mers with their counts

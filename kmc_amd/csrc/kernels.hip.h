@@ -42,10 +42,16 @@ typedef kmc_u32 u32;
 #define KMC_WAVE_LOCKSTEP() ((void)0) /* a point where the code relies on the wave's lanes executing an instruction together */
 #endif
 
-/* device-side error bits (d_err) */
-enum : u32 { KERR_CORRUPT = 1u, KERR_NREC = 2u, KERR_CAPACITY = 4u, KERR_WATCHDOG = 8u,
+/* device-side error bits (word 0 of a stream's 256-byte error block, d_err) */
+enum : u32 { KERR_CORRUPT = 1u, KERR_NREC = 2u, KERR_CAPACITY = 4u,
+             KERR_WATCHDOG = 8u, /* a look-back TIMED OUT: polled more than SPIN_LIMIT times over more than WATCHDOG_TICKS of the 100 MHz clock */
+             KERR_PEER = 0x10u,  /* a look-back gave up early because KERR_WATCHDOG was already set in its stream's word (never set on its own) */
              /* which look-back gave up (diagnostics; reported with KERR_WATCHDOG) */
              KERR_AT_SCATTER = 0x100u, KERR_AT_EXPAND = 0x200u, KERR_AT_COMPACT = 0x400u, KERR_AT_STAGE1 = 0x800u };
+/* Words 1.. of the error block: what the FIRST look-back that timed out saw (the host prints them with the error, kmc_hip.hip err_to_code):
+ * [1] claim (0 -> 1 by the first reporter), [2] KERR_AT_* | lane or digit << 16, [3] the tile that waited, [4] the tile it waited for, [5..6] the status
+ * word it last read there, [7] polls, [8..9] ticks of the 100 MHz clock between its first and its last clock sample, [10] tiles of the launch (0: unknown). */
+constexpr int KERR_DIAG_WORDS = 11;
 
 /* tile geometry */
 #ifndef RS_BLOCK_THREADS
@@ -338,7 +344,50 @@ template <int SIZE> __device__ __forceinline__ void store_rec(u64 *p, const u64 
 
 /* 64-bit look-back words (one per tile/slice): [63:62] flag (0 empty, 1 aggregate, 2 inclusive prefix), [61:0] count */
 constexpr u64 ST64_AGG = 1ull << 62, ST64_PREFIX = 2ull << 62, ST64_MASK = (1ull << 62) - 1;
-constexpr u32 SPIN_LIMIT = 1u << 24; /* look-back watchdog (polls) */
+/* Look-back watchdog. A wait is over when the tile in front publishes — microseconds — or never (a ticket counter that did not start at zero, a
+ * status area somebody else wrote into): the watchdog turns "never" into KMC_HIP_EINTERNAL instead of a hang. It must not fire on a wait that is merely
+ * long (16 streams share the CUs; a workgroup's waves share their SIMDs with spinning neighbours), so it wants BOTH more than SPIN_LIMIT polls AND more
+ * than WATCHDOG_TICKS on the constant 100 MHz clock (4 s; a poll is an s_sleep + a device-coherent load: ~1 us). Polls alone decide only where the
+ * clock does not run (the CPU emulation of tests/hipemu: wall_clock64() == 0) or beyond SPIN_HARD. Round 3 counted polls only (2^24). */
+constexpr u32 SPIN_LIMIT = 1u << 21, SPIN_NOCLOCK = 1u << 24, SPIN_HARD = 1u << 27;
+constexpr u64 WATCHDOG_TICKS = 400000000ull;
+struct LbWatch {
+	u32 spins = 0;
+	u64 t0 = 0;
+};
+/* one blocked poll of a look-back; true = give up (the error word is set). `who`: lane or digit; `waiting_for` / `seen`: the tile and the word last read */
+__device__ __forceinline__ bool lb_blocked(LbWatch &w, u32 *err, u32 at_bits, bool reporter, u32 who, u32 tile, long long waiting_for, u64 seen, u32 num_tiles)
+{
+	if ((++w.spins & 1023u) != 0)
+		return false;
+	if (ld_agent(err) & KERR_WATCHDOG) { /* somebody on this stream has timed out: the results are lost anyway, do not wait 4 s each */
+		if (reporter)
+			atomicOr(err, KERR_PEER);
+		return true;
+	}
+	const u64 now = wall_clock64();
+	if (w.spins == 1024u)
+		w.t0 = now;
+	const bool clock_runs = now != 0 && w.t0 != 0;
+	if (w.spins <= (clock_runs ? SPIN_LIMIT : SPIN_NOCLOCK) || (clock_runs && now - w.t0 <= WATCHDOG_TICKS && w.spins <= SPIN_HARD))
+		return false;
+	if (reporter) {
+		if (atomicCAS(&err[1], 0u, 1u) == 0u) {
+			const u64 dt = now - w.t0;
+			err[2] = (at_bits & ~KERR_WATCHDOG) | (who << 16);
+			err[3] = tile;
+			err[4] = (u32)waiting_for;
+			err[5] = (u32)seen;
+			err[6] = (u32)(seen >> 32);
+			err[7] = w.spins;
+			err[8] = (u32)dt;
+			err[9] = (u32)(dt >> 32);
+			err[10] = num_tiles;
+		}
+		atomicOr(err, KERR_WATCHDOG | at_bits);
+	}
+	return true;
+}
 
 #ifndef LB64_WINDOWS
 #define LB64_WINDOWS 1 /* 64-tile windows fetched per round trip of the 64-bit look-back. One 48 M k-mer bin, compaction: 1 window 0.222 ms,
@@ -363,7 +412,7 @@ __device__ __forceinline__ u64 lookback64(u64 *status, u32 tile, u64 aggregate, 
 		st_agent(&status[tile], ST64_AGG | aggregate);
 	long long tbase = (long long)tile - 1;
 	u64 acc = 0; /* this lane's share of the exclusive prefix */
-	u32 spins = 0;
+	LbWatch watch;
 	bool done = false;
 	while (!done) {
 		u64 v[LB64_WINDOWS];
@@ -395,11 +444,8 @@ __device__ __forceinline__ u64 lookback64(u64 *status, u32 tile, u64 aggregate, 
 		}
 		tbase -= 64 * used;
 		if (!done && blocked) {
-			if (++spins > SPIN_LIMIT || (spins % 1024 == 0 && (ld_agent(err) & KERR_WATCHDOG))) {
-				if (lane == 0)
-					atomicOr(err, err_watchdog_bit);
+			if (lb_blocked(watch, err, err_watchdog_bit, lane == 0, lane, tile, tbase, v[0], 0u)) /* lane 0's word: the nearest tile of the window it is stuck at */
 				break;
-			}
 			__builtin_amdgcn_s_sleep(1);
 		}
 	}
@@ -1081,7 +1127,7 @@ __global__ void __launch_bounds__(RS_BLOCK, (SIZE <= 4 ? RS_MIN_WAVES : RS_MIN_W
 			u32 excl = 0;
 			if (tile > 0) {
 				int t = (int)tile - 1;
-				u32 spins = 0;
+				LbWatch watch;
 				[[maybe_unused]] u32 rounds = 0; /* read by the trace build only */
 				TRACE_STAMP(2, tile, 1);
 				/* decoupled look-back: walk back over earlier tiles, RS_LOOKBACK_K status words per round trip, until an
@@ -1107,18 +1153,16 @@ __global__ void __launch_bounds__(RS_BLOCK, (SIZE <= 4 ? RS_MIN_WAVES : RS_MIN_W
 						}
 					}
 					t -= used;
-					if (!done && used < RS_LOOKBACK_K) { /* ran into a tile that has not published yet */
-						if (++spins > SPIN_LIMIT || (spins % 1024 == 0 && ld_agent(err) & KERR_WATCHDOG)) {
-							atomicOr(err, KERR_WATCHDOG | KERR_AT_SCATTER);
+					if (!done && used < RS_LOOKBACK_K) { /* ran into a tile that has not published yet: tile t, now */
+						if (lb_blocked(watch, err, KERR_WATCHDOG | KERR_AT_SCATTER, true, tid, tile, t, ((u64)used << 32) | v[0], num_tiles))
 							break;
-						}
 						__builtin_amdgcn_s_sleep(1);
 					}
 				}
 				st_agent(&status[(u64)tile * 256 + tid], ST_PREFIX | (excl + cnt));
 				TRACE_STAMP(2, tile, 2);
 				TRACE_VALUE(2, tile, 3, rounds);
-				TRACE_VALUE(2, tile, 4, spins);
+				TRACE_VALUE(2, tile, 4, watch.spins);
 				TRACE_VALUE(2, tile, 5, (u64)((int)tile - 1 - t));
 			}
 			const u64 gbase = digit_base_in[tid] + excl;

@@ -128,6 +128,8 @@ struct Slot {
 	DBuf bounds;   /* hybrid sort: tile boundaries of k_bucket_bounds, u64[windows + 1] */
 	DBuf redo_log; /* hybrid sort: one "sort me again" word per asynchronous group since the last drain (drain_redo) */
 	HostRes *h_res = nullptr; /* pinned */
+	u64 groups_run = 0;     /* groups enqueued on this slot since the context was made */
+	bool zero_grew = false; /* the last group's zero region had to be re-allocated (diagnostics: reported with a watchdog error) */
 	hipEvent_t ev[6] = {};
 	hipEvent_t done_ev = nullptr; /* blocking-sync event: _wait must not spin (stage-2 workers outnumber the cores a container may use) */
 	/* one event pair per scatter launch since the last harvest (roofline input) */
@@ -216,6 +218,11 @@ template <int SIZE> int set_func_attrs()
 		HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_bucket_count<SIZE>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bc_lds_bytes<SIZE>()));
 	if (bs_lds_bytes<SIZE>() > 65536)
 		HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_bucket_sort<SIZE>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bs_lds_bytes<SIZE>()));
+	if (br_lds_bytes<SIZE>() > 65536) {
+		HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_bucket_rank<SIZE, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)br_lds_bytes<SIZE>()));
+		if (SIZE == 1)
+			HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_bucket_rank<1, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)br_lds_bytes<1>()));
+	}
 	if (exp_lds_bytes<true>(EXP_FUSE_MAX_PASS, 1) > 65536) /* worst case: the shortest records (smallest k) and 16 fused passes */
 		HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_expand<SIZE, true>), hipFuncAttributeMaxDynamicSharedMemorySize,
 		                           (int)exp_lds_bytes<true>(EXP_FUSE_MAX_PASS, 1)));
@@ -310,12 +317,26 @@ int harvest(Slot &s)
 }
 
 /* the slot's sticky device error word: kernels OR into it, nothing on the per-bin path clears it, so an error raised by an
- * earlier asynchronous bin on this slot survives until somebody looks (kmc_hip_synchronize, a synchronous call, _wait) */
+ * earlier asynchronous bin on this slot survives until somebody looks (kmc_hip_synchronize, a synchronous call, _wait). Behind it, in the same
+ * 256-byte block, what the first look-back that timed out saw (kernels.hip.h KERR_DIAG_WORDS): kept per host thread for err_to_code's message. */
+thread_local u32 g_diag[KERR_DIAG_WORDS] = {};
+thread_local char g_diag_slot[96] = "";
+int clear_sticky(Slot &s, u32 err)
+{
+	if (err & (KERR_WATCHDOG | KERR_PEER)) {
+		HIPCHK(hipMemcpy(g_diag, s.sticky.p, sizeof g_diag, hipMemcpyDeviceToHost));
+		g_diag[0] = err;
+		snprintf(g_diag_slot, sizeof g_diag_slot, "; group %llu of its stream, zero region %s for it", (unsigned long long)s.groups_run, s.zero_grew ? "re-allocated" : "reused");
+	} else
+		g_diag[0] = 0;
+	HIPCHK(hipMemset(s.sticky.p, 0, 4 * KERR_DIAG_WORDS));
+	return 0;
+}
 int read_and_clear_sticky(Slot &s, u32 &err)
 {
 	HIPCHK(hipMemcpy(&err, s.sticky.p, 4, hipMemcpyDeviceToHost));
 	if (err)
-		HIPCHK(hipMemset(s.sticky.p, 0, 4));
+		return clear_sticky(s, err);
 	return 0;
 }
 
@@ -343,11 +364,13 @@ struct BinPlan {
 struct SortPlan {
 	u32 key_bytes = 0, top = 0;
 	u32 key_bits = 0; /* significant bits of the key (2k + tag bits; 8 key_bytes when the caller cannot tell) */
-	bool rank = false; /* one-word records: the LDS half is k_bucket_rank (sorts the tile in place; k_compact follows) */
+	bool rank = false; /* the LDS half is k_bucket_rank: every tile put in order by pairwise ranking and (fused) counted in place; one-word records whose output
+	                    * may outgrow a span: sorted in place, k_compact follows */
 	u32 pass_lo() const { return key_bytes - top; }
 	bool local() const { return top < key_bytes; }
 	u32 hbits() const { return top ? 8 * top - (8 * key_bytes - key_bits) : 0; } /* top bits of the significant key that the HBM passes order (plan_sort: 8 top > spare bits) */
 };
+std::atomic<u64> g_path[4] = {}; /* groups by the path they took: 0 rank + count in LDS, 1 rank in place + k_compact, 2 k_bucket_count, 3 LSD passes over every byte */
 std::atomic<u64> g_hybrid_groups{0}, g_redo_groups{0}; /* process-wide: input whose buckets keep overflowing the tiles stops being tried */
 std::atomic<u32> g_extra_top{0}; /* HBM passes added to the plan after a group came back (finer buckets for the groups after it) */
 void note_redo() { g_redo_groups.fetch_add(1, std::memory_order_relaxed); }
@@ -382,7 +405,7 @@ bool rank_enabled()
 }
 template <int SIZE>
 SortPlan plan_sort(u64 n, u32 key_bytes, u32 key_bits, bool classic, bool fused = false /* k_bucket_count's tiles, not k_bucket_sort's */,
-                   bool rank = false /* one-word records of a group: k_bucket_rank + k_compact */)
+                   bool rank = false /* the records of a group: k_bucket_rank */)
 {
 	SortPlan sp;
 	sp.key_bytes = sp.top = key_bytes;
@@ -392,12 +415,15 @@ SortPlan plan_sort(u64 n, u32 key_bytes, u32 key_bits, bool classic, bool fused 
 		return sp;
 	if (mode == 1 && (SIZE == 1 || !fused) && !rank)
 		return sp;
+	const u32 rem_limit = br_rem_limit<SIZE>(); /* rank: key bits that may stay below the bucket bits */
 	const u32 spare = 8 * key_bytes - key_bits;
 	if (mode < 0) {
 		const u32 h = (u32)(-mode);
 		if (h + 1 <= key_bytes && 8 * h > spare)
 			sp.top = h;
-		if (rank && sp.local() && key_bits - sp.hbits() <= 48)
+		if (!rank && sp.local() && sp.hbits() > 32)
+			sp.top = key_bytes; /* k_bucket_count keeps bucket numbers in 32 bits */
+		if (rank && sp.local() && key_bits - sp.hbits() <= rem_limit && sp.hbits() <= 48)
 			sp.rank = true;
 		else if (rank)
 			sp.top = key_bytes;
@@ -417,7 +443,7 @@ SortPlan plan_sort(u64 n, u32 key_bytes, u32 key_bits, bool classic, bool fused 
 			 * records in a few hundred prefixes — and the work grows with the square of a bucket: the passes must reach well below those bits (measured:
 			 * 512 bins of 3.2 M k-mers with 22 key bits ordered 17.7 Gk-mers/s, the 7 LSD passes 24.1; 190 M-record groups with 22 bits 7.2, with 30 bits 31.5) */
 			if (rank)
-				ok = eff >= 28 && (eff >= 63 || (n >> eff) <= 2);
+				ok = eff >= 28 && (eff >= 63 || (n >> eff) <= 2) && key_bits - eff <= rem_limit;
 			else
 				ok = eff > 0 && (eff >= 63 || (n >> eff) <= (fused ? bc_target_bucket<SIZE>() : bs_target_bucket<SIZE>()));
 		}
@@ -428,7 +454,7 @@ SortPlan plan_sort(u64 n, u32 key_bytes, u32 key_bits, bool classic, bool fused 
 	}
 	if (sp.top < key_bytes && sp.top >= 1) { /* finer buckets after a redo, while that still saves passes and the bucket number fits 32 bits */
 		const u32 extra = g_extra_top.load(std::memory_order_relaxed);
-		sp.top = std::min(std::max(sp.top, std::min(sp.top + extra, 4u)), key_bytes);
+		sp.top = std::min(std::max(sp.top, std::min(sp.top + extra, rank ? 6u : 4u)), key_bytes);
 		if (sp.top + 2 > key_bytes)
 			sp.top = key_bytes;
 	}
@@ -439,10 +465,10 @@ SortPlan plan_sort(u64 n, u32 key_bytes, u32 key_bits, bool classic, bool fused 
 		}();
 		if (forced >= 1 && (u32)forced + 1 <= key_bytes && 8 * (u32)forced > spare)
 			sp.top = (u32)forced;
-		if (sp.local() && sp.top >= 1 && key_bits - sp.hbits() <= 48)
+		if (sp.local() && sp.top >= 1 && key_bits - sp.hbits() <= rem_limit && sp.hbits() <= 48)
 			sp.rank = true;
 		else
-			sp.top = key_bytes; /* the pair (key bits below the bucket, index) must fit one word */
+			sp.top = key_bytes; /* the pair (key bits below the bucket, index) must fit its words */
 	}
 	return sp;
 }
@@ -451,7 +477,8 @@ SortPlan plan_sort(u64 n, u32 key_bytes, u32 key_bits, bool classic, bool fused 
  * shards | digit histograms | one scatter status area per onesweep launch over the group's `n_total` records */
 template <int SIZE>
 ZeroPlan plan_group(const Slot &s, std::vector<BinPlan> &bins, u64 n_total, u32 n_pass /* passes through HBM */, bool front, bool sort, bool compact, u64 lut_shard_entries,
-                    u64 cp_tile = CpCfg<SIZE>::TILE /* records per compaction tile: k_compact's, or the window of k_bucket_count */)
+                    u64 cp_tile = CpCfg<SIZE>::TILE /* records per compaction tile: k_compact's, or the window of k_bucket_count / k_bucket_rank */,
+                    u32 cp_words = 1 /* status words per tile (k_bucket_rank: one per chunk, two chunks) */)
 {
 	ZeroPlan z;
 	size_t off = up256(SM_BYTES);
@@ -464,7 +491,7 @@ ZeroPlan plan_group(const Slot &s, std::vector<BinPlan> &bins, u64 n_total, u32 
 		}
 		if (compact) {
 			b.off_cp_status = off;
-			off += up256(((b.n_rec + cp_tile - 1) / cp_tile) * 8 + 8);
+			off += up256(((b.n_rec + cp_tile - 1) / cp_tile) * 8 * cp_words + 8);
 			b.off_lutsh = off;
 			off += up256(lut_shard_entries * 8); /* n_shards x entries when the LUT is sharded */
 			b.off_tally = off;
@@ -488,6 +515,8 @@ ZeroPlan plan_group(const Slot &s, std::vector<BinPlan> &bins, u64 n_total, u32 
 
 int apply_plan(Slot &s, const ZeroPlan &z)
 {
+	s.zero_grew = z.total > s.zero.cap;
+	++s.groups_run;
 	if (int rc = ensure(s.zero, z.total))
 		return rc;
 	HIPCHK(hipMemsetAsync(s.zero.p, 0, z.total, s.stream));
@@ -556,7 +585,7 @@ int sort_device_t(Slot &s, const ZeroPlan &z, u64 *d_recs, u64 *d_tmp, u64 n, co
 	} else if (s.timed)
 		HIPCHK(hipEventRecord(s.ev[3], s.stream));
 	if (sp.local() && !local_by_caller) {
-		const u64 S = SIZE == 1 && sp.rank ? (u64)BR_STRIDE : (u64)BsCfg<SIZE>::STRIDE;
+		const u64 S = SIZE == 1 && sp.rank ? (u64)BrCfg<1>::STRIDE : (u64)BsCfg<SIZE>::STRIDE;
 		const u64 n_win = (n + S - 1) / S;
 		if (n_win > 0x7FFFFFF0ull)
 			return fail(KMC_HIP_EINVAL, "bin too large");
@@ -577,9 +606,14 @@ int sort_device_t(Slot &s, const ZeroPlan &z, u64 *d_recs, u64 *d_tmp, u64 n, co
 		gbn.bounds[0] = bounds;
 		k_bucket_bounds<SIZE><<<dim3((u32)((n_win + 1 + 3) / 4)), dim3(256), 0, s.stream>>>(gbn, (u32)S, sp.key_bits, sp.hbits());
 		if constexpr (SIZE == 1) {
-			if (sp.rank)
-				k_bucket_rank<<<dim3((u32)n_win, 2), dim3(BsCfg<1>::THREADS), br_lds_bytes(), s.stream>>>(src, sp.key_bits, sp.hbits(), bounds, d_flag);
-			else
+			if (sp.rank) { /* the whole array as one "bin": tiles sorted in place (the caller's k_compact follows) */
+				GrpRank gr = {};
+				gr.g = 1;
+				gr.win_prefix[1] = (u32)n_win;
+				gr.S[0] = src;
+				gr.bounds[0] = bounds;
+				k_bucket_rank<1, false><<<dim3((u32)n_win, 2), dim3(BrCfg<1>::THREADS), br_lds_bytes<1>(), s.stream>>>(gr, DevParams{}, sp.key_bits, sp.hbits(), 1u, 0ull, 0u, d_flag);
+			} else
 				k_bucket_sort<SIZE><<<dim3((u32)n_win), dim3(BsCfg<SIZE>::THREADS), bs_lds_bytes<SIZE>(), s.stream>>>(src, sp.key_bits, sp.hbits(), bounds, d_flag);
 		} else
 			k_bucket_sort<SIZE><<<dim3((u32)n_win), dim3(BsCfg<SIZE>::THREADS), bs_lds_bytes<SIZE>(), s.stream>>>(src, sp.key_bits, sp.hbits(), bounds, d_flag);
@@ -871,6 +905,93 @@ int count_group(Slot &s, const std::vector<BinPlan> &bins, const u64 *sorted, u6
 	return 0;
 }
 
+/* ---- rank groups (default since round 4): the array is ordered by its top bytes only; k_bucket_rank puts every bucket-aligned tile of every bin in order
+ * inside LDS and counts it there, straight into the tile's span of the free record array; then the fold and the gather of the two-phase output. A tile has
+ * two output slots (one per chunk: a tile that outgrows the capacity is taken by two workgroups). ---- */
+template <int SIZE>
+int rank_group(Slot &s, const std::vector<BinPlan> &bins, u64 *sorted, u64 *scratch, const DevParams &P, u64 lut_entries, const SortPlan &sp, u64 n_total, u32 *d_flag)
+{
+	if (bins.empty())
+		return 0;
+	u32 *err = err_ptr(s);
+	const bool use_lut = lut_entries && !P.without_output && !P.kff;
+	const u32 n_sh = !use_lut ? 1u : lut_shards_for(lut_entries);
+	const u32 rec_bytes = P.sbytes + P.cbytes;
+	constexpr u64 S = BrCfg<SIZE>::STRIDE;
+	GrpBounds gbn = {};
+	GrpRank gr = {};
+	GrpFold gf = {};
+	GrpGather gg = {};
+	gbn.g = gr.g = gg.g = (u32)bins.size();
+	u64 wins = 0, items = 0;
+	for (const BinPlan &b : bins) {
+		items += (b.n_rec + S - 1) / S + 1;
+		wins += (b.n_rec + S - 1) / S;
+	}
+	if (items > 0x3FFFFFF0ull)
+		return fail(KMC_HIP_EINVAL, "bin too large");
+	if (int rc = ensure(s.bounds, (size_t)(items + 2 + 2 * wins) * 8)) /* tile boundaries of every bin, then the chunks' source offsets */
+		return rc;
+	u64 *bounds = (u64 *)s.bounds.p, *chunk_src = bounds + items + 2;
+	items = wins = 0;
+	for (size_t i = 0; i < bins.size(); ++i) {
+		const BinPlan &b = bins[i];
+		const u64 bin_wins = (b.n_rec + S - 1) / S;
+		gbn.item_prefix[i] = (u32)items;
+		gr.win_prefix[i] = (u32)wins;
+		gg.tile_prefix[i] = (u32)(2 * wins);
+		u64 *lut_base = b.d_lut;
+		if (use_lut && n_sh > 1)
+			lut_base = zero_ptr<u64>(s, b.off_lutsh);
+		else if (lut_entries && !P.kff && b.d_lut) /* also without output: the caller's LUT is zero-filled by the callee (include/kmc_hip.h) */
+			HIPCHK(hipMemsetAsync(b.d_lut, 0, lut_entries * 8, s.stream));
+		gbn.S[i] = sorted + b.rec_off * SIZE;
+		gr.S[i] = sorted + b.rec_off * SIZE;
+		gbn.n[i] = gf.n[i] = b.n_rec;
+		gbn.bounds[i] = bounds + items;
+		gr.bounds[i] = bounds + items;
+		gr.scratch[i] = (uint8_t *)(scratch + b.rec_off * SIZE);
+		gr.status[i] = zero_ptr<u64>(s, b.off_cp_status);
+		gr.chunk_src[i] = chunk_src + 2 * wins;
+		gr.lut_base[i] = lut_base;
+		gr.tally[i] = zero_ptr<u64>(s, b.off_tally);
+		gf.tally[i] = gr.tally[i];
+		gf.stats[i] = b.d_stats;
+		gf.lut_base[i] = lut_base;
+		gf.lut_out[i] = b.d_lut;
+		gf.status[i] = gr.status[i];
+		gf.n_tiles[i] = (u32)(2 * bin_wins);
+		gf.out_bytes[i] = b.d_out_bytes;
+		gf.out_capacity[i] = b.out_capacity;
+		gg.scratch[i] = gr.scratch[i];
+		gg.prefix[i] = gr.status[i];
+		gg.out[i] = b.d_out;
+		gg.out_capacity[i] = b.out_capacity;
+		gg.src_rec[i] = gr.chunk_src[i];
+		items += bin_wins + 1;
+		wins += bin_wins;
+	}
+	gbn.item_prefix[bins.size()] = (u32)items;
+	gr.win_prefix[bins.size()] = (u32)wins;
+	gg.tile_prefix[bins.size()] = (u32)(2 * wins);
+	hipEvent_t e0 = nullptr, e1 = nullptr;
+	if (s.timed) {
+		if (int rc = ls_event_pair(s, e0, e1, n_total))
+			return rc;
+		HIPCHK(hipEventRecord(e0, s.stream));
+	}
+	k_bucket_bounds<SIZE><<<dim3((u32)((items + 3) / 4)), dim3(256), 0, s.stream>>>(gbn, (u32)S, sp.key_bits, sp.hbits());
+	k_bucket_rank<SIZE, true><<<dim3((u32)wins, 2), dim3(BrCfg<SIZE>::THREADS), br_lds_bytes<SIZE>(), s.stream>>>(
+	    gr, P, sp.key_bits, sp.hbits(), n_sh, lut_entries, P.lut_prefix_len ? (u32)((1ull << (2 * P.lut_prefix_len)) - 1) : 0u, d_flag);
+	if (s.timed)
+		HIPCHK(hipEventRecord(e1, s.stream));
+	k_compact_fold<<<dim3((u32)bins.size()), dim3(256), 0, s.stream>>>(gf, use_lut ? n_sh : 1u, lut_entries, 1u, rec_bytes, err);
+	if (!P.without_output)
+		k_compact_gather<<<dim3((u32)((2 * wins + 3) / 4)), dim3(256), 0, s.stream>>>(gg, rec_bytes, (u64)SIZE * 8);
+	HIPCHK(hipGetLastError());
+	return 0;
+}
+
 /* ---- a group of bins, everything device resident -------------------------------------------------------------------
  * The top radix digit of a k-mer has 8 ceil(k/4) - 2k spare bits (2 at k = 27, 55, 127). Bins expanded into one record array with the bin's
  * number inside the group in those bits are put into bin-major order by the SAME number of passes one bin needs — as launches 2^spare times
@@ -940,9 +1061,15 @@ int run_group_device_t(Slot &s, const DevParams &P, const kmc_hip_bin_desc *cons
 	/* hybrid: only the top bytes of the key go through HBM passes, the rest is sorted inside LDS (bucket_sort.hip.h) */
 	/* ... and then the tiles are counted where they lie (k_bucket_count): possible whenever a tile's records fit its span of the free array */
 	/* one-word records (k <= 32) of a default run: the top bytes through HBM, every tile put in order inside LDS by k_bucket_rank, then k_compact as ever */
-	const bool by_rank = SIZE == 1 && !classic && hybrid_mode() == 1 && rank_enabled();
-	const SortPlan sp = by_rank ? plan_sort<SIZE>(N, key_bytes, 2 * k + tag_bits, false, false, true)
-	                            : plan_sort<SIZE>(N, key_bytes, 2 * k + tag_bits, classic || !count_applicable<SIZE>(P), true);
+	/* default run (round 4): the top bytes through HBM, every tile put in order inside LDS by k_bucket_rank and counted there (fused: whenever a tile's
+	 * records fit its span of the free array; else, one-word records only, the tile is sorted in place and k_compact follows) */
+	const bool can_fuse = count_applicable<SIZE>(P);
+	const bool by_rank = !classic && hybrid_mode() == 1 && rank_enabled() && (SIZE == 1 || can_fuse);
+	SortPlan sp = by_rank ? plan_sort<SIZE>(N, key_bytes, 2 * k + tag_bits, false, false, true)
+	                      : plan_sort<SIZE>(N, key_bytes, 2 * k + tag_bits, classic || !can_fuse, true);
+	if (by_rank && !sp.rank && SIZE > 1 && can_fuse) /* the rank plan did not apply (too many key bits left below the buckets): k_bucket_count as in round 3 */
+		sp = plan_sort<SIZE>(N, key_bytes, 2 * k + tag_bits, false, true);
+	const bool rank_fused = sp.rank && can_fuse;
 	const u32 n_pass = sp.top;
 	if (used_hybrid)
 		*used_hybrid = sp.local() && N >= 2;
@@ -952,7 +1079,7 @@ int run_group_device_t(Slot &s, const DevParams &P, const kmc_hip_bin_desc *cons
 	if (N && ((rc = ensure(s.recA, N * SIZE * 8 + 256)) || (rc = ensure(s.recB, N * SIZE * 8 + 256))))
 		return rc;
 	const ZeroPlan z = plan_group<SIZE>(s, bins, N, n_pass, true, true, true, n_sh > 1 ? (u64)n_sh * lut_entries : 0,
-	                                    sp.local() && !sp.rank ? (u64)BcCfg<SIZE>::STRIDE : (u64)CpCfg<SIZE>::TILE);
+	                                    rank_fused ? (u64)BrCfg<SIZE>::STRIDE : (sp.local() && !sp.rank ? (u64)BcCfg<SIZE>::STRIDE : (u64)CpCfg<SIZE>::TILE), rank_fused ? 2u : 1u);
 	if ((rc = apply_plan(s, z))) /* ONE memset per group: small block, bitmaps, look-back words, histograms, LUT and tally shards, scatter status */
 		return rc;
 	for (BinPlan &b : bins) { /* resolved only AFTER apply_plan: growing the zero region moves the small block */
@@ -985,7 +1112,7 @@ int run_group_device_t(Slot &s, const DevParams &P, const kmc_hip_bin_desc *cons
 	}
 	u64 *sorted = (u64 *)s.recA.p;
 	u32 *const flag = d_flag ? d_flag : small_ptr<u32>(s, SM_REDO);
-	if (N && (rc = sort_device_t<SIZE>(s, z, (u64 *)s.recA.p, (u64 *)s.recB.p, N, sp, &sorted, counter_idx, hist_done, flag, !sp.rank)))
+	if (N && (rc = sort_device_t<SIZE>(s, z, (u64 *)s.recA.p, (u64 *)s.recB.p, N, sp, &sorted, counter_idx, hist_done, flag, !sp.rank || rank_fused)))
 		return rc;
 	if (s.timed) {
 		if (!N)
@@ -993,7 +1120,11 @@ int run_group_device_t(Slot &s, const DevParams &P, const kmc_hip_bin_desc *cons
 		HIPCHK(hipEventRecord(s.ev[4], s.stream));
 	}
 	u64 *const free_array = N ? (sorted == (u64 *)s.recA.p ? (u64 *)s.recB.p : (u64 *)s.recA.p) : nullptr;
-	if (sp.local() && !sp.rank && N >= 2)
+	if (N >= 2)
+		g_path[rank_fused && sp.local() ? 0 : (sp.rank && sp.local() ? 1 : (sp.local() ? 2 : 3))].fetch_add(1, std::memory_order_relaxed);
+	if (rank_fused && sp.local() && N >= 2)
+		rc = rank_group<SIZE>(s, bins, sorted, free_array, P, lut_entries, sp, N, flag);
+	else if (sp.local() && !sp.rank && N >= 2)
 		rc = count_group<SIZE>(s, bins, sorted, free_array, P, lut_entries, sp, N, flag);
 	else
 		rc = compact_group<SIZE>(s, bins, sorted, free_array, P, lut_entries, counter_idx);
@@ -1141,10 +1272,17 @@ int read_redo(Slot &s, bool &redo)
 
 int err_to_code(u32 err)
 {
-	if (err & KERR_WATCHDOG) {
-		char buf[160];
-		snprintf(buf, sizeof buf, "device look-back watchdog tripped (error word 0x%x:%s%s%s%s)", err, err & KERR_AT_SCATTER ? " scatter pass" : "",
-		         err & KERR_AT_EXPAND ? " expansion" : "", err & KERR_AT_COMPACT ? " compaction" : "", err & KERR_AT_STAGE1 ? " stage 1" : "");
+	if (err & (KERR_WATCHDOG | KERR_PEER)) {
+		char buf[512];
+		int n = snprintf(buf, sizeof buf, "device look-back watchdog tripped (error word 0x%x:%s%s%s%s%s)", err, err & KERR_AT_SCATTER ? " scatter pass" : "",
+		                 err & KERR_AT_EXPAND ? " expansion" : "", err & KERR_AT_COMPACT ? " compaction" : "", err & KERR_AT_STAGE1 ? " stage 1" : "",
+		                 err & KERR_WATCHDOG ? "" : " — only the give-up of a peer, no time-out of its own: a stale bit");
+		if (g_diag[0] == err && g_diag[1]) /* what the first look-back that timed out saw (kernels.hip.h lb_blocked) */
+			snprintf(buf + n, sizeof buf - (size_t)n, "; first time-out: kernel bits 0x%x, lane/digit %u, tile %u of %u waited for tile %d, last word read 0x%08x%08x, %u polls over %.3f s",
+			         g_diag[2] & 0xFFFFu, g_diag[2] >> 16, g_diag[3], g_diag[10], (int)g_diag[4], g_diag[6], g_diag[5], g_diag[7],
+			         (double)(((u64)g_diag[9] << 32) | g_diag[8]) / 1e8);
+		if (g_diag[0] == err)
+			strncat(buf, g_diag_slot, sizeof buf - strlen(buf) - 1);
 		return fail(KMC_HIP_EINTERNAL, buf);
 	}
 	if (err & KERR_CORRUPT)
@@ -2159,7 +2297,8 @@ int kmc_hip_process_bin_wait(kmc_hip_ctx *ctx, int dev, int slot, uint64_t *out_
 		r = *s.h_res;
 	}
 	if (r.err) {
-		HIPCHK(hipMemset(s.sticky.p, 0, 4));
+		if (int rc = clear_sticky(s, r.err))
+			return rc;
 		return err_to_code(r.err);
 	}
 	if (r.out_bytes > s.out_capacity)
@@ -2338,7 +2477,8 @@ int kmc_hip_process_bins_wait(kmc_hip_ctx *ctx, int dev, int slot, uint64_t *out
 		}
 	}
 	if (r.err) {
-		HIPCHK(hipMemset(s.sticky.p, 0, 4));
+		if (int rc = clear_sticky(s, r.err))
+			return rc;
 		return err_to_code(r.err);
 	}
 	const size_t n = s.hb.size();
@@ -3005,7 +3145,18 @@ int kmc_hip_set_hybrid(int mode)
 	g_hybrid_groups.store(0);
 	g_redo_groups.store(0);
 	g_extra_top.store(0);
+	for (auto &c : g_path)
+		c.store(0);
 	return before;
+}
+
+int kmc_hip_path_counters(uint64_t counters[4])
+{
+	if (!counters)
+		return fail(KMC_HIP_EINVAL, "counters == NULL");
+	for (int i = 0; i < 4; ++i)
+		counters[i] = g_path[i].load();
+	return 0;
 }
 
 int kmc_hip_local_sort_totals(kmc_hip_ctx *ctx, int dev, int reset, uint64_t *n_launches, double *total_ms, uint64_t *total_records, uint64_t *n_hybrid_groups,

@@ -179,7 +179,7 @@ __device__ __forceinline__ u64 lookback64_last(u64 *status, u32 tile, u64 own_la
 		st_agent(&status[tile], ST64_AGG | own_last1);
 	long long tbase = (long long)tile - 1;
 	u64 found = 0;
-	u32 spins = 0;
+	LbWatch watch;
 	while (true) {
 		const long long t = tbase - (long long)lane;
 		const u64 v = t >= 0 ? ld_agent(&status[t]) : ST64_PREFIX;
@@ -189,11 +189,8 @@ __device__ __forceinline__ u64 lookback64_last(u64 *status, u32 tile, u64 own_la
 		const int pl = m_pref ? (__ffsll(m_pref) - 1) : 64;
 		const u64 need = pl < 63 ? ((2ull << pl) - 1) : ~0ull;
 		if (m_zero & need) {
-			if (++spins > SPIN_LIMIT || (spins % 1024 == 0 && (ld_agent(err) & KERR_WATCHDOG))) {
-				if (lane == 0)
-					atomicOr(err, KERR_WATCHDOG | KERR_AT_STAGE1);
+			if (lb_blocked(watch, err, KERR_WATCHDOG | KERR_AT_STAGE1, lane == 0, lane, tile, tbase, v, 0u))
 				break;
-			}
 			__builtin_amdgcn_s_sleep(1);
 			continue;
 		}

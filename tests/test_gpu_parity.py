@@ -643,7 +643,7 @@ HOST_GROUP_CASES = [
 
 
 @pytest.mark.parametrize("k,kw,n_bins", HOST_GROUP_CASES, ids=lambda v: str(v) if not isinstance(v, dict) else "-".join(f"{a}{b}" for a, b in v.items()))
-@pytest.mark.parametrize("hybrid", [0, 2], ids=["lsd", "hybrid"])
+@pytest.mark.parametrize("hybrid", [0, 1, 2], ids=["lsd", "default", "hybrid"])
 def test_host_boundary_with_several_bins_per_call_matches_the_oracle_per_bin(ctx, k, kw, n_bins, hybrid):
     """kmc_hip_process_bins_submit/_wait: the bins of one call are uploaded together and sorted together (tags in the spare bits of the top digit), every
     bin gets its own records, LUT and tallies — those of kmc_hip_process_bin. With caller-supplied packs and without, an empty bin among them."""
@@ -659,6 +659,105 @@ def test_host_boundary_with_several_bins_per_call_matches_the_oracle_per_bin(ctx
             assert np.array_equal(got[i][0], w[0]) and np.array_equal(got[i][1], w[1]) and np.array_equal(got[i][2], w[2]), (i, got[i][2], w[2])
     finally:
         ctx.set_hybrid(before)
+
+
+def _host_boundary_storm(c, p, bins, n_threads, group, passes):
+    """bench.py's host-boundary pattern: thread t owns stream slots 2t, 2t+1 and keeps two calls in flight; every bin's out_bytes + four tallies are kept per
+    pass. Returns [pass][bin] -> (out_bytes, unique, below, above, total); raises with the library's message (the watchdog's diagnostics) on any error."""
+    import ctypes as C
+    import threading
+    from kmc_amd.capi import HostBin
+    L = c.L
+    rec, nl = c.out_rec_bytes(p), c.lut_entries(p)
+    caps = [((b[1] + 1) // max(p.cutoff_min, 1)) * rec for b in bins]
+    outs = [c.host_alloc(max(caps) + 256) for _ in range(2 * n_threads * group)]
+    luts = [c.host_alloc(max(nl, 1) * 8) for _ in range(2 * n_threads * group)]
+    pins = []
+    for img, nrec, packs, _ in bins:
+        a = c.host_alloc(img.size + 256)
+        a[:img.size] = img
+        pins.append(a)
+    errors, results = [], []
+
+    def worker(tid, res):
+        calls = [list(range(len(bins)))[q:q + group] for q in range(tid * group, len(bins), n_threads * group)]
+        inflight = []
+        ob, st = (C.c_uint64 * group)(), (C.c_uint64 * (4 * group))()
+
+        def wait(sl, mine):
+            rc = (L.kmc_hip_process_bin_wait if group == 1 else L.kmc_hip_process_bins_wait)(c.h, 0, 2 * tid + sl, ob, st)
+            if rc:
+                raise RuntimeError(L.kmc_hip_last_error(c.h).decode())
+            for j, i in enumerate(mine):
+                res[i] = (ob[j],) + tuple(st[4 * j + q] for q in range(4))
+
+        try:
+            for j, mine in enumerate(calls):
+                sl = j & 1
+                if len(inflight) == 2:
+                    wait(*inflight.pop(0))
+                arr = (HostBin * group)()
+                for q, i in enumerate(mine):
+                    pk = bins[i][2]
+                    buf = (2 * tid + sl) * group + q
+                    arr[q] = HostBin(pins[i].ctypes.data, bins[i][0].size, bins[i][1], pk.ctypes.data, pk.size, outs[buf].ctypes.data, caps[i], luts[buf].ctypes.data)
+                if group == 1:
+                    h = arr[0]
+                    rc = L.kmc_hip_process_bin_submit(c.h, 0, 2 * tid + sl, C.byref(p), C.c_void_p(h.superkmers), h.size, h.n_rec, C.c_void_p(h.pack_bytes), h.n_packs,
+                                                      C.c_void_p(h.out_suffix), h.out_capacity, C.c_void_p(h.lut))
+                else:
+                    rc = L.kmc_hip_process_bins_submit(c.h, 0, 2 * tid + sl, C.byref(p), arr, len(mine))
+                if rc:
+                    raise RuntimeError(L.kmc_hip_last_error(c.h).decode())
+                inflight.append((sl, mine))
+            while inflight:
+                wait(*inflight.pop(0))
+        except Exception as e:  # noqa: BLE001
+            errors.append("thread %d, call %d of %d (bins %s): %r" % (tid, j, len(calls), mine, e))
+
+    try:
+        for ps in range(passes):
+            res = [None] * len(bins)
+            ths = [threading.Thread(target=worker, args=(t, res)) for t in range(n_threads)]
+            for th in ths:
+                th.start()
+            for th in ths:
+                th.join()
+            if errors:
+                raise RuntimeError("pass %d: %s" % (ps, "; ".join(errors)))
+            results.append(res)
+    finally:
+        for a in outs + luts + pins:
+            c.host_free(a)
+    return results
+
+
+@pytest.mark.parametrize("group", [1, 4], ids=["one-bin-per-call", "four-bins-per-call"])
+def test_host_boundary_storm_sixteen_slots_in_flight(group):
+    """The pattern that once (round 3, 1 leg of 11) ended in KMC_HIP_EINTERNAL "look-back watchdog": 8 host threads x 2 stream slots, default mode (one-word
+    k-mers: HBM passes + k_bucket_rank), 64 bins of ~10 M k-mers from pinned memory, 30 passes back to back on a FRESH context (buffers grow in the first pass, while
+    the other slots are busy). Every pass must give every bin the tallies of the first pass, three bins of it are checked against the oracle, and an error carries
+    the watchdog's diagnostics (which look-back, which tile, what it saw, for how long)."""
+    n_bins, passes = 64, 30
+    if capi.backend_kind() != 0:
+        n_bins, passes = 8, 2  # the emulated library: the pattern, not the scale
+    scale = 1 if capi.backend_kind() == 0 else 0
+    bins = capi.synth_bins(seed=2026, genome_len=25_000_000 if scale else 20_000, n_reads=5_300_000 if scale else 1_000, k=27, n_bins=n_bins)
+    p = hp(27, lut_prefix_len=7 if scale else 3)
+    c = capi.Context((0,))
+    try:
+        before = c.path_counters()
+        res = _host_boundary_storm(c, p, bins, n_threads=8 if scale else 2, group=group, passes=passes)
+        assert c.path_counters()["rank_count"] > before["rank_count"]  # the default path ran
+    finally:
+        c.close()
+    for ps in range(1, len(res)):
+        assert res[ps] == res[0], "pass %d differs from pass 0 at bins %s" % (ps, [i for i in range(n_bins) if res[ps][i] != res[0][i]][:8])
+    assert sum(r[4] for r in res[0]) == sum(b[1] for b in bins)
+    order = sorted(range(n_bins), key=lambda i: bins[i][1])
+    for i in (order[0], order[n_bins // 2], order[-1]):
+        w = O.process_bin(op(p), bins[i][0], bins[i][1])
+        assert res[0][i] == (w[0].size,) + tuple(int(x) for x in w[2]), i
 
 
 def test_host_boundary_group_redo_errors_and_slot_reuse(ctx):
