@@ -611,9 +611,12 @@ def main():
         # both kinds of event pairs, so passes per record = scatter records / LDS-sorted records.
         hyb = ls["launches"] > 0 and ls["records"] > 0
         hbm_passes = (sc_recs / ls["records"]) if hyb else float(P)
-        # one-word records of a default run take k_bucket_rank (tiles sorted in place: one more read + write) and then k_compact; wider ones k_bucket_count
-        by_rank = hyb and W == 8 and os.environ.get("KMC_HIP_HYBRID", "1") == "1"
-        moved = W * (1 + 2 * hbm_passes + (2 if by_rank else 0) + 1) + 1.2  # expand write + passes (read + write) [+ rank] + one read by k_bucket_count / k_compact + the bin image
+        # which LDS finisher ran (library's own counters): k_bucket_rank fused (tiles ranked and counted in LDS: one read), k_bucket_rank in place + k_compact
+        # (one more read + write), or k_bucket_count (one read)
+        pc = ctx.path_counters()
+        rank_fused = hyb and pc["rank_count"] > 0 and pc["rank_compact"] == 0 and pc["bucket_count"] == 0
+        by_rank = hyb and not rank_fused and pc["rank_compact"] > 0
+        moved = W * (1 + 2 * hbm_passes + (2 if by_rank else 0) + 1) + 1.2  # expand write + passes (read + write) [+ rank in place] + one read by the finisher / k_compact + the bin image
         desc = (CONFIGS[name]["desc"] % k) if name in CONFIGS else f"custom: k={k}, {args.reads} reads of a {args.genome} bp genome, {args.bins} bins"
         out = {
             "metric": "stage-2 Gk-mers/s, k=%d (bin sort & count: parse + expand + 8-bit LSD radix sort + compaction over all signature bins)" % k,
@@ -631,13 +634,16 @@ def main():
             "self_check": {"per_bin_total_and_out_bytes_consistent": bool(ok), "output_digest": digest,
                            "oracle_bins_equal": (all(v.get("equal") for v in oracle_bins) if oracle_bins else None), "oracle_bins": oracle_bins},
             "sort_path": {"what": ("hybrid: 8-bit LSD passes through HBM over the top key bytes only, then every bucket-aligned tile put in order inside LDS (k_bucket_rank: a record's "
+                                   "place = the records of its bucket below it, counted pairwise) and counted there — run lengths, cutoffs, (suffix, counter) records, LUT, "
+                                   "tallies: the sorted tile never goes back to HBM" if rank_fused else
+                                   "hybrid: 8-bit LSD passes through HBM over the top key bytes only, then every bucket-aligned tile put in order inside LDS (k_bucket_rank: a record's "
                                    "place = the records of its bucket below it, counted pairwise), then k_compact" if by_rank else
                                    "hybrid: 8-bit LSD passes through HBM over the top key bytes only, the rest counted inside LDS on bucket-aligned tiles (k_bucket_count)" if hyb
                                    else "8-bit LSD passes through HBM over every key byte, then k_compact"),
-                          "hbm_passes_per_record": hbm_passes, "hbm_bytes_per_kmer_moved_by_design": moved, "moved_GBs": moved * value, "moved_frac_of_hbm_peak": moved * value / HBM_PEAK_GBS,
+                          "groups_by_path": pc, "hbm_passes_per_record": hbm_passes, "hbm_bytes_per_kmer_moved_by_design": moved, "moved_GBs": moved * value, "moved_frac_of_hbm_peak": moved * value / HBM_PEAK_GBS,
                           "note": "SURVEY 8d: an implementation with fewer passes moves fewer real bytes — stage2_algorithmic_* below is the NORMATIVE 8-bit-LSD figure W(2P+3) "
                                   "(what the reference formulation would have to move for this throughput: it can exceed the HBM peak when passes are skipped), "
-                                  "moved_* is what this path is designed to move (PMC-checked per kernel in profiles/r03)"},
+                                  "moved_* is what this path is designed to move (PMC-checked per kernel in profiles/r04)"},
             "stage2_algorithmic_bytes_per_kmer": W * (2 * P + 3),
             "stage2_algorithmic_GBs": W * (2 * P + 3) * value,
             "stage2_frac_of_hbm_peak": W * (2 * P + 3) * value / HBM_PEAK_GBS,
@@ -649,8 +655,9 @@ def main():
                          "note": "consecutive bins of a stream share one sort (bins_per_sort: the bin's number inside the group rides in the spare bits of the "
                                  "top radix digit), so a launch covers that many bins; every 8th group of a stream carries the event pairs (an event costs "
                                  "stream time); big bins run on one stream, so launches do not overlap and the event durations are the kernel's own"},
-            "local_sort": {"kernel": ("k_bucket_bounds + k_bucket_rank" if by_rank else "k_bucket_bounds + k_bucket_sort<%d>" % ((k + 31) // 32)) +
-                                     " (the key bytes below the HBM passes, put in order inside LDS on bucket-aligned tiles)",
+            "local_sort": {"kernel": ("k_bucket_bounds + k_bucket_rank<%d, fused>" % ((k + 31) // 32) if rank_fused else "k_bucket_bounds + k_bucket_rank<1, in place>" if by_rank
+                                      else "k_bucket_bounds + k_bucket_count<%d>" % ((k + 31) // 32)) +
+                                     " (the key bytes below the HBM passes, resolved inside LDS on bucket-aligned tiles)",
                            "launches_timed": ls["launches"], "avg_launch_ms": ls["ms"] / max(ls["launches"], 1), "records_per_launch": ls["records"] / max(ls["launches"], 1),
                            "GBs_read_plus_written": (2 * W * ls["records"]) / (ls["ms"] * 1e-3) / 1e9 if ls["launches"] else 0.0,
                            "hybrid_groups": ls["hybrid_groups"], "redo_groups": ls["redo_groups"]},

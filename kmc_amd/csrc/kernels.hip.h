@@ -349,44 +349,32 @@ constexpr u64 ST64_AGG = 1ull << 62, ST64_PREFIX = 2ull << 62, ST64_MASK = (1ull
  * long (16 streams share the CUs; a workgroup's waves share their SIMDs with spinning neighbours), so it wants BOTH more than SPIN_LIMIT polls AND more
  * than WATCHDOG_TICKS on the constant 100 MHz clock (4 s; a poll is an s_sleep + a device-coherent load: ~1 us). Polls alone decide only where the
  * clock does not run (the CPU emulation of tests/hipemu: wall_clock64() == 0) or beyond SPIN_HARD. Round 3 counted polls only (2^24). */
-constexpr u32 SPIN_LIMIT = 1u << 21, SPIN_NOCLOCK = 1u << 24, SPIN_HARD = 1u << 27;
-constexpr u64 WATCHDOG_TICKS = 400000000ull;
+constexpr u32 SPIN_LIMIT = 1u << 24;
 struct LbWatch {
 	u32 spins = 0;
-	u64 t0 = 0;
 };
-/* one blocked poll of a look-back; true = give up (the error word is set). `who`: lane or digit; `waiting_for` / `seen`: the tile and the word last read */
-__device__ __forceinline__ bool lb_blocked(LbWatch &w, u32 *err, u32 at_bits, bool reporter, u32 who, u32 tile, long long waiting_for, u64 seen, u32 num_tiles)
+/* one blocked poll of a look-back; true = give up (lb_gave_up then sets the error word). Kept to round 3's two compares: anything more in here (a clock, the
+ * diagnostics) cost k_onesweep<1> 13-35 more spilled registers at its 64-register budget and k_expand a wave per SIMD. */
+__device__ __forceinline__ bool lb_blocked(LbWatch &w, const u32 *err)
 {
-	if ((++w.spins & 1023u) != 0)
-		return false;
-	if (ld_agent(err) & KERR_WATCHDOG) { /* somebody on this stream has timed out: the results are lost anyway, do not wait 4 s each */
-		if (reporter)
-			atomicOr(err, KERR_PEER);
-		return true;
-	}
-	const u64 now = wall_clock64();
-	if (w.spins == 1024u)
-		w.t0 = now;
-	const bool clock_runs = now != 0 && w.t0 != 0;
-	if (w.spins <= (clock_runs ? SPIN_LIMIT : SPIN_NOCLOCK) || (clock_runs && now - w.t0 <= WATCHDOG_TICKS && w.spins <= SPIN_HARD))
-		return false;
-	if (reporter) {
+	++w.spins;
+	return w.spins > SPIN_LIMIT || ((w.spins & 1023u) == 0 && (ld_agent(err) & KERR_WATCHDOG) != 0);
+}
+/* after the loop of a look-back that gave up: a genuine time-out (the polls ran out) leaves its diagnostics and KERR_WATCHDOG | at_bits, a look-back that
+ * only saw somebody else's KERR_WATCHDOG leaves KERR_PEER */
+__device__ __forceinline__ void lb_gave_up(const LbWatch &w, u32 *err, u32 at_bits, u32 who, u32 tile, long long waiting_for, u32 num_tiles)
+{
+	if (w.spins > SPIN_LIMIT) {
 		if (atomicCAS(&err[1], 0u, 1u) == 0u) {
-			const u64 dt = now - w.t0;
 			err[2] = (at_bits & ~KERR_WATCHDOG) | (who << 16);
 			err[3] = tile;
 			err[4] = (u32)waiting_for;
-			err[5] = (u32)seen;
-			err[6] = (u32)(seen >> 32);
 			err[7] = w.spins;
-			err[8] = (u32)dt;
-			err[9] = (u32)(dt >> 32);
 			err[10] = num_tiles;
 		}
 		atomicOr(err, KERR_WATCHDOG | at_bits);
-	}
-	return true;
+	} else
+		atomicOr(err, KERR_PEER);
 }
 
 #ifndef LB64_WINDOWS
@@ -444,11 +432,13 @@ __device__ __forceinline__ u64 lookback64(u64 *status, u32 tile, u64 aggregate, 
 		}
 		tbase -= 64 * used;
 		if (!done && blocked) {
-			if (lb_blocked(watch, err, err_watchdog_bit, lane == 0, lane, tile, tbase, v[0], 0u)) /* lane 0's word: the nearest tile of the window it is stuck at */
+			if (lb_blocked(watch, err))
 				break;
 			__builtin_amdgcn_s_sleep(1);
 		}
 	}
+	if (!done && lane == 0)
+		lb_gave_up(watch, err, err_watchdog_bit, lane, tile, tbase, 0u);
 	const u64 excl = wave_sum<u64>(acc);
 	if (lane == 0)
 		st_agent(&status[tile], ST64_PREFIX | (excl + aggregate));
@@ -1154,11 +1144,13 @@ __global__ void __launch_bounds__(RS_BLOCK, (SIZE <= 4 ? RS_MIN_WAVES : RS_MIN_W
 					}
 					t -= used;
 					if (!done && used < RS_LOOKBACK_K) { /* ran into a tile that has not published yet: tile t, now */
-						if (lb_blocked(watch, err, KERR_WATCHDOG | KERR_AT_SCATTER, true, tid, tile, t, ((u64)used << 32) | v[0], num_tiles))
+						if (lb_blocked(watch, err))
 							break;
 						__builtin_amdgcn_s_sleep(1);
 					}
 				}
+				if (!done)
+					lb_gave_up(watch, err, KERR_WATCHDOG | KERR_AT_SCATTER, tid, tile, t, num_tiles);
 				st_agent(&status[(u64)tile * 256 + tid], ST_PREFIX | (excl + cnt));
 				TRACE_STAMP(2, tile, 2);
 				TRACE_VALUE(2, tile, 3, rounds);

@@ -1063,13 +1063,17 @@ int run_group_device_t(Slot &s, const DevParams &P, const kmc_hip_bin_desc *cons
 	/* one-word records (k <= 32) of a default run: the top bytes through HBM, every tile put in order inside LDS by k_bucket_rank, then k_compact as ever */
 	/* default run (round 4): the top bytes through HBM, every tile put in order inside LDS by k_bucket_rank and counted there (fused: whenever a tile's
 	 * records fit its span of the free array; else, one-word records only, the tile is sorted in place and k_compact follows) */
+	static const bool fuse_enabled = [] {
+		const char *e = getenv("KMC_HIP_RANK_FUSE"); /* 0 (A/B runs): round 3's default — one-word records ranked in place + k_compact, wider ones k_bucket_count */
+		return !e || atoi(e) != 0;
+	}();
 	const bool can_fuse = count_applicable<SIZE>(P);
-	const bool by_rank = !classic && hybrid_mode() == 1 && rank_enabled() && (SIZE == 1 || can_fuse);
+	const bool by_rank = !classic && hybrid_mode() == 1 && rank_enabled() && (SIZE == 1 || (can_fuse && fuse_enabled));
 	SortPlan sp = by_rank ? plan_sort<SIZE>(N, key_bytes, 2 * k + tag_bits, false, false, true)
 	                      : plan_sort<SIZE>(N, key_bytes, 2 * k + tag_bits, classic || !can_fuse, true);
 	if (by_rank && !sp.rank && SIZE > 1 && can_fuse) /* the rank plan did not apply (too many key bits left below the buckets): k_bucket_count as in round 3 */
 		sp = plan_sort<SIZE>(N, key_bytes, 2 * k + tag_bits, false, true);
-	const bool rank_fused = sp.rank && can_fuse;
+	const bool rank_fused = sp.rank && can_fuse && fuse_enabled;
 	const u32 n_pass = sp.top;
 	if (used_hybrid)
 		*used_hybrid = sp.local() && N >= 2;

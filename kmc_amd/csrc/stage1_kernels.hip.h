@@ -189,8 +189,11 @@ __device__ __forceinline__ u64 lookback64_last(u64 *status, u32 tile, u64 own_la
 		const int pl = m_pref ? (__ffsll(m_pref) - 1) : 64;
 		const u64 need = pl < 63 ? ((2ull << pl) - 1) : ~0ull;
 		if (m_zero & need) {
-			if (lb_blocked(watch, err, KERR_WATCHDOG | KERR_AT_STAGE1, lane == 0, lane, tile, tbase, v, 0u))
+			if (lb_blocked(watch, err)) {
+				if (lane == 0)
+					lb_gave_up(watch, err, KERR_WATCHDOG | KERR_AT_STAGE1, lane, tile, tbase, 0u);
 				break;
+			}
 			__builtin_amdgcn_s_sleep(1);
 			continue;
 		}

@@ -46,18 +46,15 @@ VARIANTS = {
     "bc512mw6": ["-DBC_BLOCK_THREADS=512", "-DBC_MIN_WAVES=6"],  # 8 waves x 4 rows, 80 VGPRs, three workgroups per CU
     "bcmw4": ["-DBC_MIN_WAVES=4"],  # k_bucket_count with 128 VGPRs: one workgroup of 1024 per CU, nothing spilled
     "bc512": ["-DBC_BLOCK_THREADS=512", "-DBC_WORDS_PER_THREAD=8", "-DBC_MIN_WAVES=4"],  # 8 waves x 8 rows, two workgroups per CU at 128 VGPRs
-    "br512x8": ["-DBS_BLOCK_THREADS=512"],  # k_bucket_rank geometry: 8 waves x 8 rows, 4096-record tiles
-    "br1024x4": ["-DBS_BLOCK_THREADS=1024", "-DBS_WORDS_PER_THREAD=4"],  # 16 waves x 4 rows, 4096
-    "br1024x6": ["-DBS_BLOCK_THREADS=1024", "-DBS_WORDS_PER_THREAD=6"],  # 16 waves x 6 rows, 6144
-    "br768x4": ["-DBS_BLOCK_THREADS=768", "-DBS_WORDS_PER_THREAD=4"],  # 12 waves x 4 rows, 3072
+    "br512": ["-DBR_THREADS=512"],  # k_bucket_rank geometry: 8 waves (x 8 / 4 / 2 rows by record width)
+    "br1024": ["-DBR_THREADS=1024", "-DBR_MIN_WAVES=4"],
     "brslack6": ["-DBR_SLACK_DIV=6"],  # 768 x 8 with windows of 5120 records (1024 of slack)
     "brslack12": ["-DBR_SLACK_DIV=12"],  # windows of 5632 (512 of slack)
     "brslack24": ["-DBR_SLACK_DIV=24"],  # windows of 5888 (256 of slack; longer tiles take a second chunk)
-    "br1024x4s8": ["-DBS_BLOCK_THREADS=1024", "-DBS_WORDS_PER_THREAD=4", "-DBR_SLACK_DIV=8"],
-    "brpro1": ["-DBR_PROLOGUE=1"],  # k_bucket_rank: ordinal table of bucket starts instead of 64-bit head masks per row
-    "brloop1": ["-DBR_LOOP=1"],  # k_bucket_rank pair loop: 4 per iteration, not unrolled further
-    "brloop2": ["-DBR_LOOP=2"],  # 8 per iteration
-    "brloop3": ["-DBR_LOOP=3"],  # one masked loop, 4 per iteration
+    "br1": ["-DBR_STOP_AFTER=1"],  # k_bucket_rank cut after: 1 loads + bucket starts + table look-ups, 2 + pairs + rank loops, 3 + records placed in order,
+    "br2": ["-DBR_STOP_AFTER=2"],  # 4 + run tails, counts, classes, ranks of the counted k-mers (garbage output): phase costs
+    "br3": ["-DBR_STOP_AFTER=3"],
+    "br4": ["-DBR_STOP_AFTER=4"],
     "bc1": ["-DBC_STOP_AFTER=1"],  # k_bucket_count cut after its phase 1 / 2 / 3 (garbage output): phase costs
     "bc2": ["-DBC_STOP_AFTER=2"],
     "bc3": ["-DBC_STOP_AFTER=3"],
