@@ -406,6 +406,15 @@ def reference_legs(k: int, reads: int, genome: int, runs: int = 2):
                                "sample": f"reference kmc 3.2.4 -k{k} -t{threads_used} -m{mem} ({os.cpu_count()} hardware threads visible, {cores} usable "
                                          f"under the cgroup CPU quota), '2nd stage' wall, best of {len(ref_runs)}; {sample} = {st['total']} k-mers",
                                "stage2_s": s2, "stage1_s": s1, "unique_kmers_per_s": st["unique"] / s2, "stats": st}
+        # the record widths of configs[4] beside their own reference timing on this host (same FASTQ, one run each: kmc_CLI/kmc.cpp:343-344 prints "2nd stage")
+        for kk in ((55, 127) if k == 27 else ()):
+            try:
+                w1, w2, wst, _ = _run_kmc(ref, [f"-k{kk}", f"-t{threads_used}", f"-m{mem}", "-hp"], fq, td, f"ref_k{kk}", timeout=600)
+                out[f"cpu_baseline_k{kk}"] = {"value": wst["total"] / w2 / 1e9, "unit": "Gk-mers/s", "cores": cores, "kind": "reference",
+                                              "sample": f"reference kmc 3.2.4 -k{kk} -t{threads_used} -m{mem}, '2nd stage' wall, one run; {sample} = {wst['total']} k-mers",
+                                              "stage2_s": w2, "stage1_s": w1, "unique_kmers_per_s": wst["unique"] / w2}
+            except Exception as e:  # noqa: BLE001
+                out[f"cpu_baseline_k{kk}"] = {"error": repr(e)[-300:]}
         if os.path.exists(hip):
             env = dict(os.environ, KMC_HIP_LIB=capi.lib_path(), KMC_HIP_VERBOSE="1")
             hip_runs = [_run_kmc(hip, [f"-k{k}", f"-t{threads}", f"-m{mem}", "-sr16", "-hp"], fq, td, f"hip{i}", env) for i in range(runs)]
@@ -521,23 +530,43 @@ def main():
         dist.destroy_process_group()
         return
 
-    if not torch.cuda.is_available():
+    # Rehearsal (tests/test_sharding_cpu.py): $KMC_BENCH_REHEARSAL=1 AND a test build of the library (tests/hipemu: kmc_hip_backend_kind() != 0) run this
+    # very body — sharded generation, run_step, the tally all-reduce, the digest gather — over gloo on the CPU, so that the N-rank path has executed before it
+    # meets N GPUs. The line it prints carries "rehearsal": true and no value; with the GPU library the switch is refused.
+    rehearsal = os.environ.get("KMC_BENCH_REHEARSAL") == "1"
+    if rehearsal and capi.backend_kind() == 0:
+        raise SystemExit("KMC_BENCH_REHEARSAL is for test builds of the library only (kmc_hip_backend_kind() == 0 here: the GPU library)")
+    if not rehearsal and not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (torch.cuda.is_available() is False); there is no CPU path")
-    # one rank per GPU; if the launcher already narrowed the visible devices to one per process, that one is ordinal 0
-    dev_index = local_rank if torch.cuda.device_count() > local_rank else 0
-    torch.cuda.set_device(dev_index)
     dist = None
-    if world > 1:
-        import torch.distributed as dist
+    if rehearsal:
+        dev_index = 0
+        dev = torch.device("cpu")
+        if world > 1:
+            import torch.distributed as dist
 
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", dev_index))
-    dev = torch.device("cuda", dev_index)
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+    else:
+        # one rank per GPU; if the launcher already narrowed the visible devices to one per process, that one is ordinal 0
+        dev_index = local_rank if torch.cuda.device_count() > local_rank else 0
+        torch.cuda.set_device(dev_index)
+        if world > 1:
+            import torch.distributed as dist
+
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", dev_index))
+        dev = torch.device("cuda", dev_index)
+
+    def device_sync():
+        if not rehearsal:
+            torch.cuda.synchronize()
 
     is_main = not args.leg
     name = args.leg or next((n for n, c in CONFIGS.items() if (c["reads"], c["genome"], c["bins"]) == (args.reads, args.genome, args.bins)), "custom")
     k = args.k
-    capi.require_gpu_backend()
+    if not rehearsal:
+        capi.require_gpu_backend()
     ctx = capi.Context((dev_index,))
     pl = args.lut_prefix if args.lut_prefix >= 0 else kmc_lut_prefix_len(k, args.reads, args.bins)
     p = capi.make_params(k, lut_prefix_len=pl)
@@ -550,14 +579,14 @@ def main():
     ctx.local_sort_totals(reset=True)
     if dist:
         dist.barrier()
-    torch.cuda.synchronize()
+    device_sync()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         run_step(ctx, w, args.streams)
     res = read_results(ctx, w)
     own_tallies = res[:, :4].sum(axis=0, dtype=np.uint64) if w.n_own else np.zeros(4, dtype=np.uint64)
     tallies = sharding.allreduce_tallies(own_tallies, device=dev)  # the one RCCL collective of the path (32 bytes)
-    torch.cuda.synchronize()
+    device_sync()
     if dist:
         dist.barrier()
     dt = time.perf_counter() - t0
@@ -757,6 +786,9 @@ def main():
             except Exception as e:  # the baseline is informative; never lose the GPU number over it
                 out["cpu_baseline"] = {"value": None, "unit": "Gk-mers/s", "cores": 0, "kind": "reference", "sample": f"failed: {e}"}
     if rank == 0:
+        if rehearsal:  # control flow only: nothing a reader could take for a measurement
+            out = {"rehearsal": True, "backend_kind": capi.backend_kind(), "n_gpus": out["n_gpus"], "tallies": out["tallies"], "self_check": out["self_check"],
+                   "config": out["config"], "sort_path": {"groups_by_path": out["sort_path"]["groups_by_path"]}, "value": None}
         print(json.dumps(out))
     if dist:
         dist.destroy_process_group()

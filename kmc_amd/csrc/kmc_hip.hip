@@ -387,9 +387,9 @@ int hybrid_mode()
 	if (o != INT32_MIN)
 		return o;
 	static const int v = [] {
-		/* 0 = LSD passes over every byte (rounds 1-2); 1 = default: hybrid where it wins (groups of bins with records of 2+ words, k >= 33: 4 HBM passes
-		 * instead of 14 at k = 55, 3 instead of 32 at k = 127 — at k <= 32 the fused counting kernel costs what the passes it replaces cost);
-		 * 2 = hybrid for every record width and for sort-only calls; -h = force `h` top bytes (tuning) */
+		/* 0 = LSD passes over every byte + k_compact (rounds 1-2); 1 = default: the top key bytes through HBM passes, every bucket-aligned tile ranked and
+		 * counted inside LDS by k_bucket_rank (round 4: every record width; KMC_HIP_RANK=0 / KMC_HIP_RANK_FUSE=0 give round 3's k_bucket_count for k >= 33 and
+		 * rank-in-place + k_compact for k <= 32); 2 = k_bucket_count for every record width and the LDS sort for sort-only calls; -h = force `h` top bytes (tuning) */
 		const char *e = getenv("KMC_HIP_HYBRID");
 		return e ? atoi(e) : 1;
 	}();
@@ -1580,9 +1580,17 @@ int process_bin_multi_t(kmc_hip_ctx *ctx, const DevParams &P, u64 lut_entries, c
 			if ((rc = set_dev(ctx, d)))
 				return rc;
 			for (int g = 0; g < n_dev; ++g)
-				if (cnt[d][g])
-					HIPCHK(hipMemcpyAsync((u64 *)ctx->devs[g]->xchg.p + roff[d][g] * SIZE, parted[d] + soff[d][g] * SIZE, cnt[d][g] * SIZE * 8, hipMemcpyDeviceToDevice,
-					                      S(d).stream));
+				if (cnt[d][g]) {
+					/* a context that names some GPUs twice and others once, e.g. (0, 0, 1), takes this branch too: between two different GPUs the copy is a peer copy with
+					 * both ordinals spelled out (no reliance on the runtime guessing the devices of a plain device-to-device copy) */
+					const int od = ctx->devs[d]->ordinal, og = ctx->devs[g]->ordinal;
+					void *dst = (u64 *)ctx->devs[g]->xchg.p + roff[d][g] * SIZE;
+					const void *src = parted[d] + soff[d][g] * SIZE;
+					if (od == og)
+						HIPCHK(hipMemcpyAsync(dst, src, cnt[d][g] * SIZE * 8, hipMemcpyDeviceToDevice, S(d).stream));
+					else
+						HIPCHK(hipMemcpyPeerAsync(dst, og, src, od, cnt[d][g] * SIZE * 8, S(d).stream));
+				}
 		}
 	}
 	for (int d = 0; d < n_dev; ++d) {
@@ -2292,9 +2300,13 @@ int kmc_hip_process_bin_wait(kmc_hip_ctx *ctx, int dev, int slot, uint64_t *out_
 	if (int rc = harvest(s))
 		return rc;
 	HostRes r = *s.h_res;
-	if (r.redo && !r.err) { /* the hybrid sort met a tile it could not handle: the bin again (its image is still in s.in), LSD passes over every byte */
+	if (r.redo && !(r.err & ~KERR_CAPACITY)) { /* the hybrid sort met a tile it could not handle: the bin again (its image is still in s.in), LSD passes over every byte.
+		                                      * A capacity error of the first attempt does not count: a tile that was handed back may have been compacted unsorted */
 		note_redo();
 		raise_top();
+		if (r.err)
+			if (int rc = clear_sticky(s, r.err))
+				return rc;
 		if (int rc = enqueue_host_bin(s, true))
 			return rc;
 		HIPCHK(hipEventSynchronize(s.done_ev));
@@ -2459,8 +2471,15 @@ int kmc_hip_process_bins_wait(kmc_hip_ctx *ctx, int dev, int slot, uint64_t *out
 	if (int rc = harvest(s))
 		return rc;
 	const HbRes &r = *s.h_hb_res;
-	if (!r.err) { /* sort groups whose hybrid sort met a tile it could not handle: again (the images are still in s.in), LSD passes over every byte */
+	bool any_flag = false;
+	for (size_t c = 0; c < s.hb_chunks.size(); ++c)
+		any_flag = any_flag || (s.hb_hybrid[c] && r.flag[c]);
+	if (!(r.err & ~(any_flag ? KERR_CAPACITY : 0u))) { /* sort groups whose hybrid sort met a tile it could not handle: again (the images are still in s.in), LSD passes over
+		                                                 * every byte; a capacity error next to a flag is the first attempt's (a tile handed back may have been compacted unsorted) */
 		bool any = false;
+		if (r.err)
+			if (int rc = clear_sticky(s, r.err))
+				return rc;
 		for (size_t c = 0; c < s.hb_chunks.size(); ++c) {
 			if (!s.hb_hybrid[c] || !r.flag[c])
 				continue;
@@ -3104,6 +3123,10 @@ int kmc_hip_order_database_device(kmc_hip_ctx *ctx, int dev, const kmc_hip_bin_p
 	const u32 words = (P.k + 31) / 32;
 	if (words + 1 > 8)
 		return fail(KMC_HIP_EINVAL, "kmc_hip_order_database_device: kmer_len <= 224");
+	/* the bins may come from asynchronous kmc_hip_process_bins_device calls on any stream slot: wait for all of them, run the groups whose hybrid sort asked
+	 * for LSD passes again, raise their deferred errors (the body of kmc_hip_synchronize) — before a single out_bytes is read */
+	if (int rc = kmc_hip_synchronize(ctx, dev))
+		return rc;
 	Slot &s = ctx->devs[dev]->slot[0];
 	std::lock_guard<std::mutex> lck(s.mtx);
 	const u32 rb_in = P.sbytes + P.cbytes, rb_out = (P.k - out_lut_prefix_len) / 4 + P.cbytes;

@@ -6,7 +6,8 @@
  * Environment:
  *   KMC_HIP_LIB      path of libkmc_hip.so (default: <dir of the executable>/../../kmc_amd/libkmc_hip.so, then
  *                    plain "libkmc_hip.so" through the loader path)
- *   KMC_HIP_DEVICES  comma-separated HIP ordinals (default "0"); worker i uses device i % n_devices
+ *   KMC_HIP_DEVICES  comma-separated HIP ordinals (default: every visible device, at most $KMC_HIP_MAX_DEVICES of them, minus those that fail to
+ *                    initialise; HIP_VISIBLE_DEVICES narrows the set from outside); worker i uses device i % n_devices
  *   KMC_HIP_EAGER_INIT  "0": load the library at the first stage-2 worker instead of at program start
  *   KMC_HIP_VERBOSE  "1": print where the worker spent its time when the last engine is destroyed
  * There is deliberately NO CPU fallback here: if the library or a GPU is missing the engine reports the error and
@@ -140,7 +141,34 @@ void load_api_impl()
 	}
 	if (devs.empty())
 		devs.push_back(0);
+	const bool chosen_by_user = e && *e;
+	if (!chosen_by_user) { /* the default set may be capped from outside ($KMC_HIP_MAX_DEVICES): a run with few sorter threads leaves the other devices alone */
+		const char *m = getenv("KMC_HIP_MAX_DEVICES");
+		const int cap = m ? atoi(m) : 0;
+		if (cap >= 1 && (size_t)cap < devs.size())
+			devs.resize((size_t)cap);
+	}
 	int rc = a.init(devs.data(), (int)devs.size(), &a.ctx);
+	if (rc && !chosen_by_user && devs.size() > 1) {
+		/* one busy / faulty GPU of a shared node must not fail a run that device 0 alone would have carried (round 2's default): keep the devices that
+		 * initialise on their own. A set named in $KMC_HIP_DEVICES is taken literally and fails loudly. */
+		const std::string first_error = a.last_error(nullptr);
+		std::vector<int> good;
+		for (int d : devs) {
+			kmc_hip_ctx *probe = nullptr;
+			if (a.init(&d, 1, &probe) == 0) {
+				good.push_back(d);
+				a.destroy(probe);
+			} else if (getenv("KMC_HIP_VERBOSE"))
+				fprintf(stderr, "[kmc_hip] device %d left out: %s\n", d, a.last_error(nullptr));
+		}
+		if (!good.empty() && good.size() < devs.size()) {
+			if (getenv("KMC_HIP_VERBOSE"))
+				fprintf(stderr, "[kmc_hip] %zu of %zu visible devices in use (the full set failed: %s)\n", good.size(), devs.size(), first_error.c_str());
+			devs = good;
+			rc = a.init(devs.data(), (int)devs.size(), &a.ctx);
+		}
+	}
 	if (rc) {
 		a.err = std::string("kmc_hip_init failed: ") + a.last_error(nullptr);
 		a.ctx = nullptr;

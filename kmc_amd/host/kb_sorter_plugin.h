@@ -129,6 +129,8 @@ public:
 		worker_idx = worker_counter()++ % (n_workers > 0 ? n_workers : 1);
 	}
 
+	~CWKmerBinSorter() { KmcTimeline::mark_first_last(nullptr, "worker objects destroyed (kmc.h:1735-1742)"); }
+
 	void GetDebugStats(uint64 &_sum_n_recs, uint64 &_sum_n_plus_x_recs)
 	{
 		_sum_n_recs = sum_n_rec;

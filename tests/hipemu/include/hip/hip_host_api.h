@@ -68,6 +68,7 @@ static inline hipError_t hipMemcpy(void *d, const void *s, size_t n, hipMemcpyKi
 	return hipSuccess;
 }
 static inline hipError_t hipMemcpyAsync(void *d, const void *s, size_t n, hipMemcpyKind k, hipStream_t) { return hipMemcpy(d, s, n, k); }
+static inline hipError_t hipMemcpyPeerAsync(void *d, int, const void *s, int, size_t n, hipStream_t) { return hipMemcpy(d, s, n, hipMemcpyDeviceToDevice); }
 static inline hipError_t hipMemset(void *d, int v, size_t n)
 {
 	memset(d, v, n);

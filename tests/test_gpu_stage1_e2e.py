@@ -3,6 +3,7 @@ GPU). The kernels and the launch sequence also run on the CPU under emulation in
 product binary over the product's host library compiled against an emulated HIP runtime (tests/test_hostlib_emulated.py). First met a real GPU in
 the driver's round-2 run (GPUTEST_r02: 4 xpassed); ordinary tests since round 3. Last file of the -m gpu collection."""
 import hashlib
+import re
 import os
 import subprocess
 
@@ -51,4 +52,7 @@ def test_kmc_with_hip_stage1_and_stage2_writes_the_reference_database(flags, tmp
     want = _run("kmc", flags + ["-m4", "-sf1", "-sp1", "-sr1"], fq, tmp_path, "ref")
     got = _run("kmc_hip_s1", flags + ["-m4", "-sf2", "-sp4", "-sr4"], fq, tmp_path, "hip", env={"KMC_HIP_VERBOSE": "1"})
     assert got[:2] == want[:2]
-    assert "parts through the engine" in got[2] and " 0 parts through the engine" not in got[2].split("[kmc_hip stage 1]")[1]
+    # every worker reports; over ALL of them: parts went through the HIP engine, none fell back to the reference splitter (long-read or uncovered parts)
+    rep = re.findall(r"\[kmc_hip stage 1\] worker: (\d+) parts through the engine .*?, (\d+) long-read parts and (\d+) uncovered parts", got[2])
+    assert len(rep) >= 1, got[2][-2000:]
+    assert sum(int(a) for a, _, _ in rep) > 0 and sum(int(b) + int(c) for _, b, c in rep) == 0, rep

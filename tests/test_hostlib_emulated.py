@@ -169,37 +169,48 @@ import oracle_py as O
 from kmc_amd import capi
 from test_gpu_parity import _run_batch
 
-ctx = capi.Context((0,))  # default mode: groups of one-word k-mers take k_bucket_rank + k_compact
+ctx = capi.Context((0,))  # default mode: every group takes k_bucket_rank — tiles ranked and counted inside LDS
 def check(k, bins, **kw):
     p = capi.make_params(k, **kw)
     op = O.make_params(p.kmer_len, p.both_strands, p.cutoff_min, p.cutoff_max, p.counter_max, p.lut_prefix_len, p.output_type, p.without_output)
-    t0 = ctx.local_sort_totals()
+    t0, c0 = ctx.local_sort_totals(), ctx.path_counters()
     got, err = _run_batch(ctx, p, bins, 1)
     assert err is None, err
     for i, (img, nrec, packs, _) in enumerate(bins):
         w = O.process_bin(op, img, nrec)
         assert np.array_equal(got[i][0], w[0]) and np.array_equal(got[i][1], w[1]) and np.array_equal(got[i][2], w[2]), (k, kw, i)
-    t1 = ctx.local_sort_totals()
-    return t1["hybrid_groups"] - t0["hybrid_groups"], t1["redo_groups"] - t0["redo_groups"]
-# 24 key bits left below the passes: (rem, index) pairs of 32 bits; k = 32: 32 bits left, pairs of 64; KFF records; 16 bins per group (k = 25)
+    t1, c1 = ctx.local_sort_totals(), ctx.path_counters()
+    return t1["hybrid_groups"] - t0["hybrid_groups"], t1["redo_groups"] - t0["redo_groups"], {x: c1[x] - c0[x] for x in c1}
+# one-word records. 24 key bits left below the passes: (rem, index) pairs of 32 bits; k = 32: 32 bits left, pairs of 64; KFF records; 16 bins per group (k = 25);
+# forward strand only; without output; counters that clamp and a cutoff_max
 for k, nb, kw in ((27, 5, dict(lut_prefix_len=3)), (32, 3, dict(lut_prefix_len=4)), (27, 4, dict(lut_prefix_len=0, output_type=1)), (25, 9, dict(lut_prefix_len=1, cutoff_min=1)),
-                  (21, 4, dict(lut_prefix_len=1, both_strands=0)), (27, 4, dict(lut_prefix_len=3, without_output=1))):
-    h, r = check(k, capi.synth_bins(seed=7, genome_len=6000, n_reads=1500, k=k, n_bins=nb, n_threads=1), **kw)
-    assert h >= 1 and r == 0, (k, h, r)
+                  (21, 4, dict(lut_prefix_len=1, both_strands=0)), (27, 4, dict(lut_prefix_len=3, without_output=1)), (27, 3, dict(lut_prefix_len=3, cutoff_max=20, counter_max=7))):
+    h, r, c = check(k, capi.synth_bins(seed=7, genome_len=3000, n_reads=500, k=k, n_bins=nb, n_threads=1), **kw)
+    assert h >= 1 and r == 0 and c["rank_count"] >= 1 and c["rank_compact"] == c["bucket_count"] == 0, (k, h, r, c)
+# records that may outgrow a tile's span (k = 32 without a LUT prefix: 8 suffix bytes + a 4-byte counter): ranked in place, then k_compact
+h, r, c = check(32, capi.synth_bins(seed=7, genome_len=3000, n_reads=500, k=32, n_bins=3, n_threads=1), lut_prefix_len=0, cutoff_max=100000, counter_max=70000)
+assert c["rank_compact"] >= 1 and c["rank_count"] == 0, c
+# wider records: two words (A/B pairs, rem <= 80 bits; k = 64: six HBM passes instead of sixteen), KFF, three and more words (whole records compared)
+for k, nb, kw in ((55, 4, dict(lut_prefix_len=3)), (40, 3, dict(lut_prefix_len=4, cutoff_min=1)), (64, 1, dict(lut_prefix_len=4)), (55, 4, dict(lut_prefix_len=0, output_type=1)),
+                  (127, 4, dict(lut_prefix_len=3)), (70, 3, dict(lut_prefix_len=2, both_strands=0)), (200, 2, dict(lut_prefix_len=4))):
+    h, r, c = check(k, capi.synth_bins(seed=7, genome_len=3000, n_reads=400, k=k, n_bins=nb, n_threads=1, read_len=max(150, k + 40)), **kw)
+    assert h >= 1 and r == 0 and c["rank_count"] >= 1 and c["bucket_count"] == 0, (k, h, r, c)
 # every k-mer a few hundred times: buckets longer than the room at the end of a window, tiles longer than the capacity -> taken in chunks, nothing comes back
-for glen, err in ((2000, 0.0), (600, 0.002)):
-    h, r = check(27, capi.synth_bins(seed=3, genome_len=glen, n_reads=1500, k=27, n_bins=4, err=err, n_threads=1), lut_prefix_len=3)
-    assert h >= 1 and r == 0, (glen, h, r)
+for k, glen, err in ((27, 2000, 0.0), (27, 600, 0.002), (55, 1500, 0.0)):
+    h, r, c = check(k, capi.synth_bins(seed=3, genome_len=glen, n_reads=1000, k=k, n_bins=4, err=err, n_threads=1), lut_prefix_len=3)
+    assert h >= 1 and r == 0, (k, glen, h, r)
 # one k-mer more often than a tile holds records: the group comes back for LSD passes
-h, r = check(27, capi.synth_bins(seed=5, genome_len=300, n_reads=1500, k=27, n_bins=2, err=0.0, n_threads=1), lut_prefix_len=3)
-assert r >= 1, (h, r)
+for k in (27, 55):
+    h, r, c = check(k, capi.synth_bins(seed=5, genome_len=300, n_reads=1500, k=k, n_bins=2, err=0.0, n_threads=1), lut_prefix_len=3)
+    assert r >= 1, (k, h, r)
 print("RANK-OK")
 '''
 
 
 def test_rank_path_on_the_emulated_host_library():
-    """k_bucket_rank (bucket_sort.hip.h) on the CPU, as a default run takes it: groups of one-word k-mers through 4+ HBM passes, k_bucket_bounds, the pairwise
-    ranking of every tile (32-bit and 64-bit pairs, chunked tiles), k_compact — per bin against the oracle; and the redo of a group with a bucket beyond a tile."""
+    """k_bucket_rank (bucket_sort.hip.h) on the CPU, as a default run takes it: groups of k-mers of every record width through the HBM passes, k_bucket_bounds,
+    the pairwise ranking of every tile (32- and 64-bit pairs, A/B pairs of two-word records, whole records beyond) and the counting of the ranked tile inside
+    LDS (fused), chunked tiles, the in-place variant + k_compact — per bin against the oracle; and the redo of a group with a bucket beyond a tile."""
     lib = emu.build_hostlib("small")
     r = subprocess.run([sys.executable, "-c", _RANK_CASE % {"root": ROOT}], env=dict(os.environ, KMC_HIP_LIB=lib), capture_output=True, text=True, timeout=1500, cwd=ROOT)
     assert r.returncode == 0 and "RANK-OK" in r.stdout, (r.stdout + r.stderr)[-1500:]

@@ -147,3 +147,37 @@ def test_bench_gpus_n_launches_its_own_ranks(tmp_path):
     assert d["gpus_requested"] == 2 and d["world_size_env"] == 2 and d["ranks_seen_by_all_reduce"] == 2 and d["n_gpus"] == 2
     r = subprocess.run([sys.executable, bench, "--gpus", "2", "--dry-launch"], capture_output=True, text=True, timeout=120, env=dict(env, WORLD_SIZE="3", RANK="0"))
     assert r.returncode != 0 and "must agree" in (r.stderr + r.stdout)
+
+
+def test_bench_multi_rank_body_rehearsed_over_gloo_on_the_emulated_library(tmp_path):
+    """The N-rank body of bench.py — sharded generation, LPT, run_step on every rank's own bins, the tally all-reduce, the gather of the output digests — has
+    only ever met one real GPU. Here it runs as `python bench.py --gpus 2` (its own launcher, two processes, gloo) over the CPU emulation of the host library
+    (KMC_BENCH_REHEARSAL=1 is honoured for test builds only and prints no value): tallies and the order-independent output digest must equal the 1-rank run's,
+    and the 2-rank run must have sorted its own share on each rank. The same switch is refused with the GPU library."""
+    import json
+    import subprocess
+    import sys
+
+    import emu
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    bench = os.path.join(root, "bench.py")
+    lib = emu.build_hostlib("small")
+    base = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env = dict(base, KMC_HIP_LIB=lib, KMC_BENCH_REHEARSAL="1")
+    args = ["--reads", "3000", "--genome", "30000", "--bins", "8", "--steps", "1", "--warmup", "0", "--no-secondary", "--no-cpu-baseline", "--no-host-boundary",
+            "--no-two-streams", "--no-oracle-check"]
+    out = {}
+    for n in (1, 2):
+        r = subprocess.run([sys.executable, bench, "--gpus", str(n), *args], capture_output=True, text=True, timeout=900, env=env, cwd=str(tmp_path))
+        assert r.returncode == 0, (r.stdout + r.stderr)[-1500:]
+        out[n] = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+        assert out[n]["rehearsal"] is True and out[n]["value"] is None and out[n]["n_gpus"] == n
+        assert out[n]["self_check"]["per_bin_total_and_out_bytes_consistent"] is True
+    assert out[2]["tallies"] == out[1]["tallies"] and out[2]["tallies"]["n_total"] == out[1]["config"]["kmers"]
+    assert out[2]["self_check"]["output_digest"] == out[1]["self_check"]["output_digest"]
+    assert 0 < out[2]["config"]["kmers_rank0"] < out[2]["config"]["kmers"] and out[2]["config"]["bins_rank0"] < out[2]["config"]["bins"]
+    if os.path.exists(capi._build.LIB_HIP):  # the GPU library refuses the rehearsal switch (dlopen works without a GPU)
+        r = subprocess.run([sys.executable, bench, "--gpus", "1", *args], capture_output=True, text=True, timeout=300,
+                           env=dict(base, KMC_BENCH_REHEARSAL="1", KMC_HIP_LIB=capi._build.LIB_HIP), cwd=str(tmp_path))
+        assert r.returncode != 0 and "test builds of the library only" in (r.stdout + r.stderr)

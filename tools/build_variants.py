@@ -15,6 +15,14 @@ VARIANTS = {
     "w8": ["-DRS_WORDS_PER_THREAD_1=8"],
     "w16s4": ["-DRS_WORDS_PER_THREAD_1=16", "-DRS_STAGES=4"],  # 16 K-record tiles (512-byte runs), 2 workgroups/CU, ~19 VGPRs spilled
     "w16s4_1cu": ["-DRS_WORDS_PER_THREAD_1=16", "-DRS_STAGES=4", "-DRS_MIN_WAVES=4"],  # same tile, 128 VGPRs, 1 workgroup/CU
+    # one workgroup per CU (128 VGPRs): bigger tiles = longer runs per digit (tools/ubench_scatter.hip: misaligned 320-byte runs 2.8 TB/s, 640: 3.3, 1024: 4.1)
+    "w16s2_1cu": ["-DRS_WORDS_PER_THREAD_1=16", "-DRS_STAGES=2", "-DRS_MIN_WAVES=4"],
+    "w16s1_1cu": ["-DRS_WORDS_PER_THREAD_1=16", "-DRS_STAGES=1", "-DRS_MIN_WAVES=4"],
+    "w20s4_1cu": ["-DRS_WORDS_PER_THREAD_1=20", "-DRS_STAGES=4", "-DRS_MIN_WAVES=4"],
+    "w20s2_1cu": ["-DRS_WORDS_PER_THREAD_1=20", "-DRS_STAGES=2", "-DRS_MIN_WAVES=4"],
+    "w24s4_1cu": ["-DRS_WORDS_PER_THREAD_1=24", "-DRS_STAGES=4", "-DRS_MIN_WAVES=4"],
+    "w24s2_1cu": ["-DRS_WORDS_PER_THREAD_1=24", "-DRS_STAGES=2", "-DRS_MIN_WAVES=4"],
+    "w32s4_1cu": ["-DRS_WORDS_PER_THREAD_1=32", "-DRS_STAGES=4", "-DRS_MIN_WAVES=4"],
     "w12s3": ["-DRS_WORDS_PER_THREAD_1=12", "-DRS_STAGES=3"],  # 12 K-record tiles, 384-byte runs, 2 workgroups/CU
     "w10s2": ["-DRS_WORDS_PER_THREAD_1=10", "-DRS_STAGES=2"],
     "exp16k": ["-DEXP_CHUNK_BYTES=16384"],

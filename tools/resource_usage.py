@@ -18,7 +18,7 @@ def demangle(names):
 
 
 def short(name):
-    m = re.match(r"void (\w+)(<[^>]*>)?", name)
+    m = re.match(r"(?:void )?(\w+)(<[^>]*>)?", name)
     return (m.group(1) + (m.group(2) or "")) if m else name
 
 

@@ -70,7 +70,7 @@ int main()
 		timeit([&] { k_scatter<16><<<(unsigned)(n / (512 * 16)), 512>>>(in, out, n, run, nruns - 1, 0x9E3779B1ull); }, name, 2.0 * n * 8);
 	}
 	// misaligned runs: shift the whole output by 24 bytes so every run straddles cache lines like real bucket boundaries
-	for (u64 run : {32ull, 64ull}) {
+	for (u64 run : {32ull, 40ull, 64ull, 80ull, 96ull, 128ull, 160ull, 256ull, 512ull}) { /* 40 = k_onesweep<1>'s 320-byte runs; 80 / 160: tiles of 20 K / 40 K records */
 		const u64 nruns = n / run - 1;
 		u64 m = 1; while (m * 2 <= nruns) m *= 2;
 		char name[64]; snprintf(name, sizeof name, "scatter %5llu B, +24 B skew", run * 8);
