@@ -411,7 +411,18 @@ struct GrpRank {
 	u64 *chunk_src[GRP_MAX];    /* FUSED: [2 windows] first record of every chunk that counted something (the gather's source) */
 	u64 *lut_base[GRP_MAX];
 	u64 *tally[GRP_MAX];        /* [CP_SHARDS][4] */
+	u32 *giant;                 /* FUSED: [0] number of tiles handed to k_giant_tiles, [1] how many of them have been taken, [2..] their numbers (zeroed by the host) */
 };
+/* A tile whose LARGEST BUCKET does not fit the capacity — one k-mer repeated thousands of times: every genome has those — is not ranked pairwise (the work
+ * grows with the square of a bucket) and, since round 4, no longer sends its whole group back to the host either: k_bucket_rank puts it on a list and
+ * k_giant_tiles sorts it on its own (below). Only a tile beyond GT_MAX_RECORDS still raises the group's flag (-> the host's LSD passes). */
+#ifndef GT_THREADS
+#define GT_THREADS 512
+#endif
+#ifndef GT_MAX_RECORDS_LOG2
+#define GT_MAX_RECORDS_LOG2 20 /* one workgroup sorts up to a million records by itself (~1-2 ms); beyond that the group goes back to the host */
+#endif
+constexpr u64 GT_MAX_RECORDS = 1ull << GT_MAX_RECORDS_LOG2;
 
 template <int SIZE, bool FUSED>
 __global__ void __launch_bounds__(BrCfg<SIZE>::THREADS, BR_MIN_WAVES) k_bucket_rank(const GrpRank gr, DevParams P, u32 key_bits, u32 hbits, u32 lut_shards, u64 lut_stride,
@@ -466,9 +477,13 @@ __global__ void __launch_bounds__(BrCfg<SIZE>::THREADS, BR_MIN_WAVES) k_bucket_r
 		__syncthreads();
 		const u32 cut = *s_wmax;
 		__syncthreads();
-		if (cut == 0 || (b1 - b0) - cut > (u64)CAP) { /* one bucket (or two) beyond the capacity: the host's LSD passes */
-			if (tid == 0 && blockIdx.y == 0)
-				atomicOr(flag, 1u);
+		if (cut == 0 || (b1 - b0) - cut > (u64)CAP) { /* one bucket (or two) beyond the capacity: k_giant_tiles, or (not fused; enormous tiles) the host's LSD passes */
+			if (tid == 0 && blockIdx.y == 0) {
+				if (FUSED && gr.giant && b1 - b0 <= GT_MAX_RECORDS)
+					gr.giant[2 + atomicAdd(&gr.giant[0], 1u)] = gtile;
+				else
+					atomicOr(flag, 1u);
+			}
 			return;
 		}
 		if (blockIdx.y == 0)
@@ -914,6 +929,273 @@ __global__ void __launch_bounds__(BrCfg<SIZE>::THREADS, BR_MIN_WAVES) k_bucket_r
 							atomicAdd(&lut[pf], (u64)0 - (u64)j);
 					}
 				}
+			}
+		}
+	}
+}
+
+/* ------------------------------------------------------------------------------------------------ tiles with a bucket beyond the LDS capacity
+ * What the reference does with a bucket that stays large is recurse (raduls_impl.h:680-737: a big bucket takes a share of the threads and another radix
+ * level); round 3 sent the whole GROUP of bins back through LSD passes over every byte. Here ONE workgroup takes such a tile — CAP < records <=
+ * GT_MAX_RECORDS — and sorts it by itself: stable 8-bit LSD passes between the tile's slice of the record array and its slice of the free array (the span
+ * its output will go to), over the key bits that can differ inside the tile (the bits below the bucket bits + the bits in which its first and last bucket
+ * number differ; an even number of passes, so the records end where they started), each pass = a histogram read + chunks of THREADS x 4 records ranked as
+ * k_onesweep ranks a tile (per-wave digit counts, match-any ballots), with the digit bases running in LDS instead of a look-back. Then it streams through
+ * the sorted records once more — run tails, counts (a run may be as long as the tile), cutoffs, records straight to the span — and reports like a tile of
+ * k_bucket_rank (status, chunk_src, LUT, tallies). Persistent workgroups take the listed tiles one by one; with nothing listed the kernel costs a launch.
+ * It is the rare path (a few tiles per group on repeat-rich input): simple before fast. */
+template <int SIZE>
+__global__ void __launch_bounds__(GT_THREADS) k_giant_tiles(const GrpRank gr, DevParams P, u32 stride, u32 key_bits, u32 hbits, u32 lut_shards, u64 lut_stride, u32 lut_mask)
+{
+	constexpr int THREADS = GT_THREADS, ITEMS = 4, NW = THREADS / 64, CHUNK = THREADS * ITEMS;
+	constexpr u32 NONE = 0xFFFFFFFFu;
+	static_assert(THREADS >= 256, "one digit per thread");
+	__shared__ u32 s_whist[NW * 256];
+	__shared__ u32 s_base[256];
+	__shared__ u32 s_scan[NW + 1];
+	__shared__ u32 s_pick;
+	__shared__ u32 s_wlast[NW], s_wcnt[NW];
+	const u32 tid = threadIdx.x, lane = tid & 63;
+	const u32 wave = (u32)__builtin_amdgcn_readfirstlane((int)(tid >> 6));
+	const u32 rec_bytes = P.sbytes + P.cbytes;
+	const bool use_lut = P.lut_prefix_len != 0 && !P.kff && !P.without_output;
+	const u32 pshift = 2 * (P.k - P.lut_prefix_len);
+	const u32 bsh = 64 - hbits, rbits = key_bits - hbits;
+	const u64 lane_lt = (1ull << lane) - 1;
+	while (true) {
+		__syncthreads();
+		if (tid == 0)
+			s_pick = atomicAdd(&gr.giant[1], 1u);
+		__syncthreads();
+		const u32 pick = s_pick;
+		if (pick >= ld_agent(&gr.giant[0])) /* final: k_bucket_rank ran before this kernel on the stream */
+			break;
+		const u32 gtile = gr.giant[2 + pick];
+		const u32 bin = (u32)__builtin_amdgcn_readfirstlane((int)grp_find(gr.win_prefix, gr.g, gtile));
+		const u32 tile = gtile - gr.win_prefix[bin];
+		const u64 b0 = gr.bounds[bin][tile], b1 = gr.bounds[bin][tile + 1];
+		const u32 L = (u32)(b1 - b0);
+		u64 *T = gr.S[bin] + b0 * SIZE;
+		u64 *U = reinterpret_cast<u64 *>(gr.scratch[bin] + b0 * (u64)(SIZE * 8));
+		(void)stride;
+		/* the key bits to sort by */
+		u32 passes;
+		{
+			u64 x0[SIZE], xl[SIZE];
+			load_rec<SIZE>(T, x0);
+			load_rec<SIZE>(T + (size_t)(L - 1) * SIZE, xl);
+			const u64 k0 = hbits ? bs_p64<SIZE>(x0, key_bits) >> bsh : 0ull, kl = hbits ? bs_p64<SIZE>(xl, key_bits) >> bsh : 0ull;
+			const u64 diff = k0 ^ kl;
+			const u32 dbits = diff ? 64u - (u32)__clzll((long long)diff) : 0u;
+			const u32 nbits = rbits + dbits < key_bits ? rbits + dbits : key_bits;
+			passes = (nbits + 7) / 8;
+			passes += passes & 1u; /* even: the sorted records end in T, the span stays free for the output (<= 8 SIZE: the bytes of a record) */
+			if (passes == 0)
+				passes = 2;
+		}
+		u64 *src = T, *dst = U;
+		for (u32 p = 0; p < passes; ++p) {
+			if (tid < 256)
+				s_base[tid] = 0;
+			__syncthreads();
+			for (u32 i = tid; i < L; i += THREADS) {
+				u64 x[SIZE];
+				load_rec<SIZE>(src + (size_t)i * SIZE, x);
+				(void)__hip_atomic_fetch_add(&s_base[kmc_get_byte<SIZE>(x, p)], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+			}
+			__syncthreads();
+			{
+				const u32 v = tid < 256 ? s_base[tid] : 0u;
+				u32 total;
+				const u32 ex = block_excl_sum<NW, u32>(v, s_scan, total);
+				if (tid < 256)
+					s_base[tid] = ex;
+			}
+			__syncthreads();
+			for (u32 c0 = 0; c0 < L; c0 += CHUNK) {
+				for (u32 i = tid; i < (u32)NW * 256; i += THREADS)
+					s_whist[i] = 0;
+				__syncthreads();
+				u64 key[ITEMS][SIZE];
+				u32 dg[ITEMS];
+#pragma unroll
+				for (int r = 0; r < ITEMS; ++r) {
+					const u32 idx = c0 + wave * (ITEMS * 64) + r * 64 + lane;
+					dg[r] = 0;
+					if (idx < L) {
+						load_rec<SIZE>(src + (size_t)idx * SIZE, key[r]);
+						dg[r] = kmc_get_byte<SIZE>(key[r], p);
+						(void)__hip_atomic_fetch_add(&s_whist[wave * 256 + dg[r]], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+					} else {
+#pragma unroll
+						for (int w = 0; w < SIZE; ++w)
+							key[r][w] = 0;
+					}
+				}
+				__syncthreads();
+				if (tid < 256) { /* counts -> first position of (wave, digit) in dst; the digit's base moves on to the next chunk */
+					u32 run = s_base[tid];
+#pragma unroll
+					for (int w = 0; w < NW; ++w) {
+						const u32 t = s_whist[w * 256 + tid];
+						s_whist[w * 256 + tid] = run;
+						run += t;
+					}
+					s_base[tid] = run;
+				}
+				__syncthreads();
+#pragma unroll
+				for (int r = 0; r < ITEMS; ++r) {
+					const u32 idx = c0 + wave * (ITEMS * 64) + r * 64 + lane;
+					const bool valid = idx < L;
+					const u64 vm = __ballot(valid);
+					u32 lo = (u32)vm, hi = (u32)(vm >> 32);
+#pragma unroll
+					for (int b = 0; b < 8; ++b) { /* the lanes that hold the same digit (k_onesweep's match-any) */
+						const u32 sb = (u32)__builtin_amdgcn_sbfe((int)dg[r], b, 1);
+						const u64 m = __builtin_amdgcn_uicmp(sb, 0u, 33 /* ICMP_NE */);
+						lo = __builtin_amdgcn_bitop3_b32(sb, lo, (u32)m, 0x84);
+						hi = __builtin_amdgcn_bitop3_b32(sb, hi, (u32)(m >> 32), 0x84);
+					}
+					const u32 below = __builtin_amdgcn_mbcnt_hi(hi, __builtin_amdgcn_mbcnt_lo(lo, 0));
+					u32 *ctr = &s_whist[wave * 256 + dg[r]];
+					const u32 slot = __hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+					KMC_WAVE_LOCKSTEP(); /* every lane has read the counter before the lowest peer moves it on */
+					if (valid && below == 0)
+						__hip_atomic_store(ctr, slot + (u32)(__popc(lo) + __popc(hi)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+					KMC_WAVE_LOCKSTEP();
+					if (valid)
+						store_rec<SIZE>(dst + (size_t)(slot + below) * SIZE, key[r]);
+				}
+				__syncthreads();
+			}
+			u64 *t = src;
+			src = dst;
+			dst = t;
+			__syncthreads(); /* a workgroup's global stores are visible to its own loads after the barrier (one CU, one L1) */
+		}
+		/* ---- the tile is in order in T: run lengths, cutoffs, records (kb_sorter.h:1128-1281), chunk by chunk */
+		uint8_t *const span = reinterpret_cast<uint8_t *>(U);
+		const u32 slot_id = 2 * tile;
+		u64 *lut = use_lut ? gr.lut_base[bin] + (size_t)(slot_id % lut_shards) * lut_stride : nullptr;
+		u32 prev_tail = NONE; /* absolute position of the last tail so far, -1 = none */
+		u32 counted_total = 0, nu = 0, nb = 0, na = 0;
+		for (u32 c0 = 0; c0 < L; c0 += CHUNK) {
+			const u32 crel = wave * (ITEMS * 64);
+			u64 key[ITEMS][SIZE];
+			u32 tail_bits = 0, wlast = NONE;
+#pragma unroll
+			for (int r = 0; r < ITEMS; ++r) {
+				const u32 idx = c0 + crel + r * 64 + lane;
+				bool is_tail = false;
+				if (idx < L) {
+					load_rec<SIZE>(T + (size_t)idx * SIZE, key[r]);
+					is_tail = true;
+					if (idx + 1 < L) {
+						u64 nx[SIZE];
+						load_rec<SIZE>(T + (size_t)(idx + 1) * SIZE, nx);
+						is_tail = !kmc_equal<SIZE>(nx, key[r]);
+					}
+				} else {
+#pragma unroll
+					for (int w = 0; w < SIZE; ++w)
+						key[r][w] = 0;
+				}
+				const u64 m = __ballot(is_tail);
+				if (is_tail)
+					tail_bits |= 1u << r;
+				if (m)
+					wlast = crel + r * 64 + 63 - (u32)__clzll((long long)m);
+			}
+			if (lane == 0)
+				s_wlast[wave] = wlast;
+			__syncthreads();
+			u32 carry = prev_tail - c0, chunk_last = NONE; /* chunk-relative, modulo 2^32 */
+#pragma unroll
+			for (int w = 0; w < NW; ++w) {
+				const u32 x = s_wlast[w];
+				if (x != NONE) {
+					chunk_last = x;
+					if (w < (int)wave)
+						carry = x;
+				}
+			}
+			carry = (u32)__builtin_amdgcn_readfirstlane((int)carry);
+			u32 cnt[ITEMS], rk[ITEMS], nc = 0;
+#pragma unroll
+			for (int r = 0; r < ITEMS; ++r) {
+				const u32 rowrel = crel + r * 64;
+				const u64 m = __ballot((tail_bits >> r) & 1u);
+				const u64 m_lt = m & lane_lt;
+				const u32 prev = m_lt ? rowrel + 63 - (u32)__clzll((long long)m_lt) : carry;
+				const u32 c = rowrel + lane - prev; /* uint32 like the reference counter */
+				const u64 mb = __ballot(c < P.cutoff_min) & m;
+				const u64 ma = __ballot(c > P.cutoff_max) & m & ~mb;
+				const u64 mc = m & ~mb & ~ma;
+				cnt[r] = c > P.counter_max ? P.counter_max : c;
+				rk[r] = ((mc >> lane) & 1ull) ? __builtin_amdgcn_mbcnt_hi((u32)(mc >> 32), __builtin_amdgcn_mbcnt_lo((u32)mc, nc)) : NONE;
+				nu += (u32)__popcll(m);
+				nb += (u32)__popcll(mb);
+				na += (u32)__popcll(ma);
+				nc += (u32)__popcll(mc);
+				if (m)
+					carry = rowrel + 63 - (u32)__clzll((long long)m);
+			}
+			if (lane == 0)
+				s_wcnt[wave] = nc;
+			__syncthreads();
+			u32 wave_off = 0, chunk_counted = 0;
+#pragma unroll
+			for (int w = 0; w < NW; ++w) {
+				const u32 x = s_wcnt[w];
+				if (w < (int)wave)
+					wave_off += x;
+				chunk_counted += x;
+			}
+			if (!P.without_output) {
+#pragma unroll
+				for (int r = 0; r < ITEMS; ++r) {
+					if (rk[r] != NONE) {
+						u64 kx[SIZE];
+#pragma unroll
+						for (int w = 0; w < SIZE; ++w)
+							kx[w] = key[r][w];
+						kmc_mask_low<SIZE>(kx, 2 * P.k); /* drops a group tag above the k-mer */
+						kmc_emit_record<SIZE>(span + (size_t)(counted_total + wave_off + rk[r]) * rec_bytes, kx, cnt[r], P.sbytes, P.cbytes, P.kff != 0);
+						if (use_lut)
+							atomicAdd(&lut[(u32)kmc_remove_suffix<SIZE>(kx, pshift) & lut_mask], 1ull);
+					}
+				}
+			}
+			counted_total += chunk_counted;
+			if (chunk_last != NONE)
+				prev_tail = c0 + chunk_last;
+			__syncthreads(); /* s_wlast / s_wcnt are rewritten by the next chunk */
+		}
+		if (lane == 0) { /* nu, nb, na are per wave: summed through LDS */
+			s_whist[wave * 3 + 0] = nu;
+			s_whist[wave * 3 + 1] = nb;
+			s_whist[wave * 3 + 2] = na;
+		}
+		__syncthreads();
+		if (tid == 0) {
+			u32 tu = 0, tb = 0, ta = 0;
+#pragma unroll
+			for (int w = 0; w < NW; ++w) {
+				tu += s_whist[w * 3 + 0];
+				tb += s_whist[w * 3 + 1];
+				ta += s_whist[w * 3 + 2];
+			}
+			u64 *sh = gr.tally[bin] + (size_t)(slot_id % CP_SHARDS) * 4;
+			if (tu)
+				atomicAdd(&sh[0], (u64)tu);
+			if (tb)
+				atomicAdd(&sh[1], (u64)tb);
+			if (ta)
+				atomicAdd(&sh[2], (u64)ta);
+			if (!P.without_output && counted_total) {
+				gr.status[bin][slot_id] = counted_total;
+				gr.chunk_src[bin][slot_id] = b0;
 			}
 		}
 	}

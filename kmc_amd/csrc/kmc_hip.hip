@@ -107,6 +107,7 @@ struct HostRes {
  * look-back words | one scatter status area per onesweep launch. Offsets are 256-byte aligned. */
 struct ZeroPlan {
 	size_t ghist = 0, sc_status = 0, sc_stride = 0, total = 0; /* the per-bin parts are in BinPlan */
+	size_t giant = 0; /* rank groups: the list of tiles handed to k_giant_tiles (count, taken, tile numbers) */
 };
 inline size_t up256(size_t x) { return (x + 255) & ~(size_t)255; }
 
@@ -478,10 +479,14 @@ SortPlan plan_sort(u64 n, u32 key_bytes, u32 key_bits, bool classic, bool fused 
 template <int SIZE>
 ZeroPlan plan_group(const Slot &s, std::vector<BinPlan> &bins, u64 n_total, u32 n_pass /* passes through HBM */, bool front, bool sort, bool compact, u64 lut_shard_entries,
                     u64 cp_tile = CpCfg<SIZE>::TILE /* records per compaction tile: k_compact's, or the window of k_bucket_count / k_bucket_rank */,
-                    u32 cp_words = 1 /* status words per tile (k_bucket_rank: one per chunk, two chunks) */)
+                    u32 cp_words = 1 /* status words per tile (k_bucket_rank: one per chunk, two chunks) */, u64 giant_entries = 0)
 {
 	ZeroPlan z;
 	size_t off = up256(SM_BYTES);
+	if (giant_entries) {
+		z.giant = off;
+		off += up256((size_t)(giant_entries + 2) * 4);
+	}
 	for (BinPlan &b : bins) {
 		if (front) {
 			b.off_bitmap = off;
@@ -909,7 +914,8 @@ int count_group(Slot &s, const std::vector<BinPlan> &bins, const u64 *sorted, u6
  * inside LDS and counts it there, straight into the tile's span of the free record array; then the fold and the gather of the two-phase output. A tile has
  * two output slots (one per chunk: a tile that outgrows the capacity is taken by two workgroups). ---- */
 template <int SIZE>
-int rank_group(Slot &s, const std::vector<BinPlan> &bins, u64 *sorted, u64 *scratch, const DevParams &P, u64 lut_entries, const SortPlan &sp, u64 n_total, u32 *d_flag)
+int rank_group(Slot &s, const std::vector<BinPlan> &bins, u64 *sorted, u64 *scratch, const DevParams &P, u64 lut_entries, const SortPlan &sp, u64 n_total, u32 *d_flag,
+               u32 *d_giant)
 {
 	if (bins.empty())
 		return 0;
@@ -973,6 +979,7 @@ int rank_group(Slot &s, const std::vector<BinPlan> &bins, u64 *sorted, u64 *scra
 	}
 	gbn.item_prefix[bins.size()] = (u32)items;
 	gr.win_prefix[bins.size()] = (u32)wins;
+	gr.giant = d_giant;
 	gg.tile_prefix[bins.size()] = (u32)(2 * wins);
 	hipEvent_t e0 = nullptr, e1 = nullptr;
 	if (s.timed) {
@@ -981,8 +988,10 @@ int rank_group(Slot &s, const std::vector<BinPlan> &bins, u64 *sorted, u64 *scra
 		HIPCHK(hipEventRecord(e0, s.stream));
 	}
 	k_bucket_bounds<SIZE><<<dim3((u32)((items + 3) / 4)), dim3(256), 0, s.stream>>>(gbn, (u32)S, sp.key_bits, sp.hbits());
-	k_bucket_rank<SIZE, true><<<dim3((u32)wins, 2), dim3(BrCfg<SIZE>::THREADS), br_lds_bytes<SIZE>(), s.stream>>>(
-	    gr, P, sp.key_bits, sp.hbits(), n_sh, lut_entries, P.lut_prefix_len ? (u32)((1ull << (2 * P.lut_prefix_len)) - 1) : 0u, d_flag);
+	const u32 lut_mask = P.lut_prefix_len ? (u32)((1ull << (2 * P.lut_prefix_len)) - 1) : 0u;
+	k_bucket_rank<SIZE, true><<<dim3((u32)wins, 2), dim3(BrCfg<SIZE>::THREADS), br_lds_bytes<SIZE>(), s.stream>>>(gr, P, sp.key_bits, sp.hbits(), n_sh, lut_entries, lut_mask, d_flag);
+	/* the tiles with a bucket beyond the LDS capacity (k-mers repeated thousands of times), one workgroup each; nothing listed: a launch that returns */
+	k_giant_tiles<SIZE><<<dim3((u32)std::min<u64>(wins, 256)), dim3(GT_THREADS), 0, s.stream>>>(gr, P, (u32)S, sp.key_bits, sp.hbits(), n_sh, lut_entries, lut_mask);
 	if (s.timed)
 		HIPCHK(hipEventRecord(e1, s.stream));
 	k_compact_fold<<<dim3((u32)bins.size()), dim3(256), 0, s.stream>>>(gf, use_lut ? n_sh : 1u, lut_entries, 1u, rec_bytes, err);
@@ -1082,8 +1091,13 @@ int run_group_device_t(Slot &s, const DevParams &P, const kmc_hip_bin_desc *cons
 	int rc = 0;
 	if (N && ((rc = ensure(s.recA, N * SIZE * 8 + 256)) || (rc = ensure(s.recB, N * SIZE * 8 + 256))))
 		return rc;
+	u64 rank_tiles = 0;
+	if (rank_fused)
+		for (const BinPlan &b : bins)
+			rank_tiles += (b.n_rec + BrCfg<SIZE>::STRIDE - 1) / BrCfg<SIZE>::STRIDE;
 	const ZeroPlan z = plan_group<SIZE>(s, bins, N, n_pass, true, true, true, n_sh > 1 ? (u64)n_sh * lut_entries : 0,
-	                                    rank_fused ? (u64)BrCfg<SIZE>::STRIDE : (sp.local() && !sp.rank ? (u64)BcCfg<SIZE>::STRIDE : (u64)CpCfg<SIZE>::TILE), rank_fused ? 2u : 1u);
+	                                    rank_fused ? (u64)BrCfg<SIZE>::STRIDE : (sp.local() && !sp.rank ? (u64)BcCfg<SIZE>::STRIDE : (u64)CpCfg<SIZE>::TILE), rank_fused ? 2u : 1u,
+	                                    rank_tiles);
 	if ((rc = apply_plan(s, z))) /* ONE memset per group: small block, bitmaps, look-back words, histograms, LUT and tally shards, scatter status */
 		return rc;
 	for (BinPlan &b : bins) { /* resolved only AFTER apply_plan: growing the zero region moves the small block */
@@ -1127,7 +1141,7 @@ int run_group_device_t(Slot &s, const DevParams &P, const kmc_hip_bin_desc *cons
 	if (N >= 2)
 		g_path[rank_fused && sp.local() ? 0 : (sp.rank && sp.local() ? 1 : (sp.local() ? 2 : 3))].fetch_add(1, std::memory_order_relaxed);
 	if (rank_fused && sp.local() && N >= 2)
-		rc = rank_group<SIZE>(s, bins, sorted, free_array, P, lut_entries, sp, N, flag);
+		rc = rank_group<SIZE>(s, bins, sorted, free_array, P, lut_entries, sp, N, flag, zero_ptr<u32>(s, z.giant));
 	else if (sp.local() && !sp.rank && N >= 2)
 		rc = count_group<SIZE>(s, bins, sorted, free_array, P, lut_entries, sp, N, flag);
 	else

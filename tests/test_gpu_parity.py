@@ -606,12 +606,14 @@ def test_two_devices_worker_allreduce_and_wide_records(ref_bins, tmp_path):
 
 
 # ------------------------------------------------------------------------------------------------ k_bucket_rank (default path of one-word k-mers)
-def test_rank_path_takes_repeats_in_chunks_and_hands_a_giant_bucket_back(ctx):
-    """default mode: groups of one-word k-mers = top bytes through HBM, tiles put in order by k_bucket_rank, k_compact. (The many-bins tests above run this
-    path on ordinary data.) Here: every k-mer ~1600 times — buckets longer than the room at the end of a window, tiles longer than the capacity, taken in
-    chunks of whole buckets, nothing comes back; then one k-mer more often than a tile holds records — the group is run again with LSD passes."""
+def test_rank_path_takes_repeats_in_chunks_giant_buckets_on_their_own_and_hands_an_enormous_one_back(ctx):
+    """default mode: the top bytes through HBM, tiles ranked and counted inside LDS by k_bucket_rank. (The many-bins tests above run this path on ordinary
+    data.) Here: every k-mer ~1600 times — buckets longer than the room at the end of a window, tiles longer than the capacity, taken in chunks of whole
+    buckets; then one k-mer more often than a tile holds records (8000 times; k = 27, 55, 127) — the tile is sorted by k_giant_tiles, nothing comes back; then
+    one k-mer more than a million times — the group is run again with LSD passes."""
+    small = capi.backend_kind() != 0  # the emulated host library: the paths, not the scale (GT_MAX_RECORDS is 4096 there)
     p = hp(27)
-    bins = capi.synth_bins(seed=3, genome_len=6000, n_reads=80_000, k=27, n_bins=4, err=0.0)
+    bins = capi.synth_bins(seed=3, genome_len=6000 if not small else 2000, n_reads=80_000 if not small else 1000, k=27, n_bins=4, err=0.0)
     t0 = ctx.local_sort_totals()
     got, err = _run_batch(ctx, p, bins, 1)
     assert err is None, err
@@ -620,13 +622,23 @@ def test_rank_path_takes_repeats_in_chunks_and_hands_a_giant_bucket_back(ctx):
         assert all(np.array_equal(a, b) for a, b in zip(got[i], w)), i
     t1 = ctx.local_sort_totals()
     assert t1["hybrid_groups"] > t0["hybrid_groups"] and t1["redo_groups"] == t0["redo_groups"], (t0, t1)
-    bins = capi.synth_bins(seed=5, genome_len=300, n_reads=20_000, k=27, n_bins=2, err=0.0)
+    for k, kw, err_rate in ((27, {}, 0.0), (27, dict(cutoff_min=1, lut_prefix_len=0, output_type=1), 0.01), (55, dict(lut_prefix_len=3), 0.0), (127, dict(lut_prefix_len=3), 0.002)):
+        pk = hp(k, **kw)
+        bins = capi.synth_bins(seed=5, genome_len=300, n_reads=20_000 if not small else 1500, k=k, n_bins=2, err=err_rate, read_len=max(150, k + 40))
+        got, err = _run_batch(ctx, pk, bins, 1)
+        assert err is None, err
+        for i, (img, nrec, packs, _) in enumerate(bins):
+            w = O.process_bin(op(pk), img, nrec)
+            assert all(np.array_equal(a, b) for a, b in zip(got[i], w)), (k, i)
+    t2 = ctx.local_sort_totals()
+    assert t2["hybrid_groups"] > t1["hybrid_groups"] and t2["redo_groups"] == t1["redo_groups"], (t1, t2)
+    bins = capi.synth_bins(seed=5, genome_len=160, n_reads=1_300_000 if not small else 6000, k=27, n_bins=2, err=0.0)
     got, err = _run_batch(ctx, p, bins, 1)
     assert err is None, err
     for i, (img, nrec, packs, _) in enumerate(bins):
         w = O.process_bin(op(p), img, nrec)
         assert all(np.array_equal(a, b) for a, b in zip(got[i], w)), i
-    assert ctx.local_sort_totals()["redo_groups"] > t1["redo_groups"]
+    assert ctx.local_sort_totals()["redo_groups"] > t2["redo_groups"]
 
 
 # ------------------------------------------------------------------------------------------------ several bins per host-boundary call
