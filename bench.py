@@ -65,6 +65,7 @@ CONFIGS = {
                     desc="a quarter of configs[2]/[4] (50 M reads of a 250 Mbp genome, 30x: 128 signature bins of the same size as the full run's), k=%d"),
 }
 SEED = 2026
+SKEW_REPEATS = "10000:2000:10"
 
 
 def kmc_lut_prefix_len(k: int, n_reads: int, n_bins: int) -> int:
@@ -444,11 +445,11 @@ def reference_legs(k: int, reads: int, genome: int, runs: int = 2):
     return out
 
 
-def secondary_leg(name: str, k: int, extra):
+def secondary_leg(name: str, k: int, extra, env=None):
     cfg = CONFIGS[name]
     cmd = [sys.executable, os.path.abspath(__file__), "--leg", name, "--k", str(k), "--reads", str(cfg["reads"]), "--genome", str(cfg["genome"]),
            "--bins", str(cfg["bins"]), "--steps", "3", "--warmup", "1", *extra]
-    r = subprocess.run(cmd, capture_output=True, text=True)
+    r = subprocess.run(cmd, capture_output=True, text=True, env=dict(os.environ, **env) if env else None)
     for ln in reversed(r.stdout.splitlines()):
         if ln.startswith("{"):
             return json.loads(ln)
@@ -772,6 +773,12 @@ def main():
                 for kk in (55, 127):
                     sk = secondary_leg("quarter", kk, ["--no-digest"])
                     sec["k%d_quarter" % kk] = {x: sk.get(x) for x in ("value", "ms_per_step", "config", "roofline", "sort_path", "local_sort", "tallies", "self_check", "error") if x in sk}
+                # skew: the same quarter with a repeat family planted in the genome (a 10 kbp unit x 2000 copies, 1 % diverged: its k-mers occur tens of thousands
+                # of times — far beyond a tile of the LDS sort): what do k_giant_tiles and, beyond it, the redo through LSD passes cost on repeat-rich input?
+                sk = secondary_leg("quarter", 27, ["--no-digest"], env={"KMC_SYNTH_REPEATS": SKEW_REPEATS})
+                sec["skew_quarter"] = dict({x: sk.get(x) for x in ("value", "ms_per_step", "sort_path", "local_sort", "tallies", "self_check", "error") if x in sk},
+                                           what="quarter workload, k=27, $KMC_SYNTH_REPEATS=%s (unit:copies:per-mille divergence) planted in the genome; sort_path.groups_by_path has "
+                                                "the tiles / records k_giant_tiles took, local_sort.redo_groups the groups that went back through LSD passes" % SKEW_REPEATS)
             out["secondary"] = sec
         if not args.no_cpu_baseline:
             try:

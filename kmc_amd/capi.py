@@ -381,11 +381,12 @@ class Context:
         self._chk(self.L.kmc_hip_local_sort_totals(self.h, dev, 1 if reset else 0, C.byref(n), C.byref(t), C.byref(k), C.byref(h), C.byref(r)))
         return dict(launches=n.value, ms=t.value, records=k.value, hybrid_groups=h.value, redo_groups=r.value)
 
-    def path_counters(self):
-        """process-wide group counts by path since the last set_hybrid: dict(rank_count, rank_compact, bucket_count, lsd)"""
-        c = (C.c_uint64 * 4)()
-        self._chk(self.L.kmc_hip_path_counters(c))
-        return dict(rank_count=c[0], rank_compact=c[1], bucket_count=c[2], lsd=c[3])
+    def path_counters(self, dev: int = 0):
+        """group counts by path since the last set_hybrid (process-wide) + the tiles / records k_giant_tiles took on `dev` since the context was made:
+        dict(rank_count, rank_compact, bucket_count, lsd, giant_tiles, giant_records)"""
+        c = (C.c_uint64 * 8)()
+        self._chk(self.L.kmc_hip_path_counters(self.h, dev, c))
+        return dict(rank_count=c[0], rank_compact=c[1], bucket_count=c[2], lsd=c[3], giant_tiles=c[4], giant_records=c[5])
 
     def process_bins_device(self, p: BinParams, descs, n_streams: int = 0, dev: int = 0):
         """Enqueue many device-resident bins (ctypes array of BinDesc); returns after enqueueing — call synchronize()."""

@@ -945,7 +945,8 @@ __global__ void __launch_bounds__(BrCfg<SIZE>::THREADS, BR_MIN_WAVES) k_bucket_r
  * k_bucket_rank (status, chunk_src, LUT, tallies). Persistent workgroups take the listed tiles one by one; with nothing listed the kernel costs a launch.
  * It is the rare path (a few tiles per group on repeat-rich input): simple before fast. */
 template <int SIZE>
-__global__ void __launch_bounds__(GT_THREADS) k_giant_tiles(const GrpRank gr, DevParams P, u32 stride, u32 key_bits, u32 hbits, u32 lut_shards, u64 lut_stride, u32 lut_mask)
+__global__ void __launch_bounds__(GT_THREADS) k_giant_tiles(const GrpRank gr, DevParams P, u32 stride, u32 key_bits, u32 hbits, u32 lut_shards, u64 lut_stride, u32 lut_mask,
+                                                              u32 *err /* the stream's error block: words 12 and 14-15 count the tiles and records taken here (statistics) */)
 {
 	constexpr int THREADS = GT_THREADS, ITEMS = 4, NW = THREADS / 64, CHUNK = THREADS * ITEMS;
 	constexpr u32 NONE = 0xFFFFFFFFu;
@@ -1197,6 +1198,8 @@ __global__ void __launch_bounds__(GT_THREADS) k_giant_tiles(const GrpRank gr, De
 				gr.status[bin][slot_id] = counted_total;
 				gr.chunk_src[bin][slot_id] = b0;
 			}
+			atomicAdd(&err[12], 1u);
+			atomicAdd(reinterpret_cast<u64 *>(err + 14), (u64)L);
 		}
 	}
 }

@@ -991,7 +991,7 @@ int rank_group(Slot &s, const std::vector<BinPlan> &bins, u64 *sorted, u64 *scra
 	const u32 lut_mask = P.lut_prefix_len ? (u32)((1ull << (2 * P.lut_prefix_len)) - 1) : 0u;
 	k_bucket_rank<SIZE, true><<<dim3((u32)wins, 2), dim3(BrCfg<SIZE>::THREADS), br_lds_bytes<SIZE>(), s.stream>>>(gr, P, sp.key_bits, sp.hbits(), n_sh, lut_entries, lut_mask, d_flag);
 	/* the tiles with a bucket beyond the LDS capacity (k-mers repeated thousands of times), one workgroup each; nothing listed: a launch that returns */
-	k_giant_tiles<SIZE><<<dim3((u32)std::min<u64>(wins, 256)), dim3(GT_THREADS), 0, s.stream>>>(gr, P, (u32)S, sp.key_bits, sp.hbits(), n_sh, lut_entries, lut_mask);
+	k_giant_tiles<SIZE><<<dim3((u32)std::min<u64>(wins, 256)), dim3(GT_THREADS), 0, s.stream>>>(gr, P, (u32)S, sp.key_bits, sp.hbits(), n_sh, lut_entries, lut_mask, err);
 	if (s.timed)
 		HIPCHK(hipEventRecord(e1, s.stream));
 	k_compact_fold<<<dim3((u32)bins.size()), dim3(256), 0, s.stream>>>(gf, use_lut ? n_sh : 1u, lut_entries, 1u, rec_bytes, err);
@@ -3191,12 +3191,24 @@ int kmc_hip_set_hybrid(int mode)
 	return before;
 }
 
-int kmc_hip_path_counters(uint64_t counters[4])
+int kmc_hip_path_counters(kmc_hip_ctx *ctx, int dev, uint64_t counters[8])
 {
 	if (!counters)
 		return fail(KMC_HIP_EINVAL, "counters == NULL");
-	for (int i = 0; i < 4; ++i)
-		counters[i] = g_path[i].load();
+	for (int i = 0; i < 8; ++i)
+		counters[i] = i < 4 ? g_path[i].load() : 0;
+	if (!ctx)
+		return 0;
+	if (int rc = set_dev(ctx, dev))
+		return rc;
+	for (auto &s : ctx->devs[dev]->slot) { /* the tiles k_giant_tiles took: counted on the device, in every stream's error block */
+		std::lock_guard<std::mutex> lck(s.mtx);
+		HIPCHK(hipStreamSynchronize(s.stream));
+		u32 w[4] = {};
+		HIPCHK(hipMemcpy(w, (u32 *)s.sticky.p + 12, sizeof w, hipMemcpyDeviceToHost));
+		counters[4] += w[0];
+		counters[5] += ((u64)w[3] << 32) | w[2];
+	}
 	return 0;
 }
 

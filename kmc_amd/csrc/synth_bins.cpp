@@ -130,6 +130,24 @@ void make_genome(uint64_t seed, uint64_t genome_len, int n_threads, std::vector<
 		});
 	for (auto &x : th)
 		x.join();
+	/* $KMC_SYNTH_REPEATS = "unit:copies[:per_mille]" plants `copies` copies of the genome's first `unit` bases at pseudo-random places, each copy with
+	 * per_mille/1000 of its bases substituted (default 0) — the repeat families a real genome has and a uniform random one lacks: their k-mers occur
+	 * copies x coverage times, far beyond what a tile of the LDS sort holds (bench.py's skew leg, tests). Deterministic in (seed, genome_len). */
+	if (const char *e = getenv("KMC_SYNTH_REPEATS")) {
+		unsigned long long unit = 0, copies = 0, pm = 0;
+		if (sscanf(e, "%llu:%llu:%llu", &unit, &copies, &pm) >= 2 && unit >= 1 && unit * 2 <= genome_len) {
+			const std::vector<uint8_t> u(genome.begin(), genome.begin() + (ptrdiff_t)unit);
+			for (unsigned long long c = 0; c < copies; ++c) {
+				const uint64_t at = unit + mix64(seed ^ (0xC0FFEEull + c * 0x9E3779B97F4A7C15ull)) % (genome_len - 2 * unit + 1);
+				for (uint64_t i = 0; i < unit; ++i) {
+					uint8_t b = u[i];
+					if (pm && mix64(seed + 77 * c + 1315423911ull * i) % 1000 < pm)
+						b = (uint8_t)((b + 1 + mix64(seed + c + i) % 3) & 3);
+					genome[at + i] = b;
+				}
+			}
+		}
+	}
 }
 
 template <typename Sink>

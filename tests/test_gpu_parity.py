@@ -622,6 +622,7 @@ def test_rank_path_takes_repeats_in_chunks_giant_buckets_on_their_own_and_hands_
         assert all(np.array_equal(a, b) for a, b in zip(got[i], w)), i
     t1 = ctx.local_sort_totals()
     assert t1["hybrid_groups"] > t0["hybrid_groups"] and t1["redo_groups"] == t0["redo_groups"], (t0, t1)
+    g0 = ctx.path_counters()
     for k, kw, err_rate in ((27, {}, 0.0), (27, dict(cutoff_min=1, lut_prefix_len=0, output_type=1), 0.01), (55, dict(lut_prefix_len=3), 0.0), (127, dict(lut_prefix_len=3), 0.002)):
         pk = hp(k, **kw)
         bins = capi.synth_bins(seed=5, genome_len=300, n_reads=20_000 if not small else 1500, k=k, n_bins=2, err=err_rate, read_len=max(150, k + 40))
@@ -630,8 +631,9 @@ def test_rank_path_takes_repeats_in_chunks_giant_buckets_on_their_own_and_hands_
         for i, (img, nrec, packs, _) in enumerate(bins):
             w = O.process_bin(op(pk), img, nrec)
             assert all(np.array_equal(a, b) for a, b in zip(got[i], w)), (k, i)
-    t2 = ctx.local_sort_totals()
+    t2, g1 = ctx.local_sort_totals(), ctx.path_counters()
     assert t2["hybrid_groups"] > t1["hybrid_groups"] and t2["redo_groups"] == t1["redo_groups"], (t1, t2)
+    assert g1["giant_tiles"] >= g0["giant_tiles"] + 4 and g1["giant_records"] > g0["giant_records"], (g0, g1)
     bins = capi.synth_bins(seed=5, genome_len=160, n_reads=1_300_000 if not small else 6000, k=27, n_bins=2, err=0.0)
     got, err = _run_batch(ctx, p, bins, 1)
     assert err is None, err

@@ -203,7 +203,7 @@ for k, glen, err in ((27, 2000, 0.0), (27, 600, 0.002), (55, 1500, 0.0)):
 for k, kw, err in ((27, dict(lut_prefix_len=3), 0.0), (27, dict(lut_prefix_len=0, output_type=1), 0.0), (55, dict(lut_prefix_len=3), 0.0), (27, dict(lut_prefix_len=3, cutoff_min=1), 0.01),
                    (70, dict(lut_prefix_len=2), 0.0)):
     h, r, c = check(k, capi.synth_bins(seed=5, genome_len=300, n_reads=1500, k=k, n_bins=2, err=err, n_threads=1), **kw)
-    assert h >= 1 and r == 0, (k, h, r)
+    assert h >= 1 and r == 0 and c["giant_tiles"] >= 1, (k, h, r, c)
 # ... and more often than k_giant_tiles takes (GT_MAX_RECORDS: 4096 in this build): the group comes back for LSD passes
 for k in (27, 55):
     h, r, c = check(k, capi.synth_bins(seed=5, genome_len=160, n_reads=6000, k=k, n_bins=2, err=0.0, n_threads=1), lut_prefix_len=3)
