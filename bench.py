@@ -51,7 +51,7 @@ sys.path.insert(0, ROOT)
 from kmc_amd import capi, sharding  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
-PMC_PROFILE = os.path.join(ROOT, "profiles", "r02", "pmc_hbm_traffic.json")  # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes
+PMC_PROFILE = os.path.join(ROOT, "profiles", "r04", "pmc_hbm_traffic.json")  # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes
 
 # BASELINE.json configs -> generator parameters
 CONFIGS = {
@@ -679,7 +679,7 @@ def main():
             "stage2_frac_of_hbm_peak": W * (2 * P + 3) * value / HBM_PEAK_GBS,
             "roofline": {"bound": "hbm", "kernel": kern, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(kern, rpl),
-                         "traffic_unit": "HBM bytes per launch (PMC FETCH_SIZE x2 + WRITE_SIZE, profiles/r02/pmc_hbm_traffic.json)",
+                         "traffic_unit": "HBM bytes per launch (PMC FETCH_SIZE x2 + WRITE_SIZE, profiles/r04/pmc_hbm_traffic.json)",
                          "algorithmic_bytes_per_launch": 2 * W * rpl, "launches_in_timed_region": n_launch, "avg_launch_ms": avg_ms,
                          "records_per_launch": rpl, "algorithmic_bytes_per_record_per_launch": 2 * W,
                          "note": "consecutive bins of a stream share one sort (bins_per_sort: the bin's number inside the group rides in the spare bits of the "

@@ -799,7 +799,42 @@ __global__ void __launch_bounds__(EXP_BLOCK) k_expand(const GrpExpand ge, u32 k,
 						}
 						v[0] = f;
 					} else {
-						kmc_canonical_at<SIZE>(s_b + s_skpos[si] + 1, off, k, both_strands != 0, v);
+						/* wider records, the same way (round 4; kmc_extract_kmer walks the window byte by byte: ~150 VALU instructions per k-mer at k = 55,
+						 * ~500 at k = 127 — the whole of this kernel's time): the window of 2k bits lies in N = ceil((2k + 30) / 32) aligned LDS dwords; byte-swapped
+						 * they are a big-endian bit stream, and limb i of the k-mer is one funnel shift of two neighbouring dwords. E[] is filled from the END of the
+						 * window so that every register index is static (N is uniform, the shift is per lane). */
+						constexpr int M = 2 * SIZE + 2;
+						const u32 a = 16u + (u32)s_skpos[si] + 1u + (off >> 2);   /* byte offset inside s_raw of the window's first byte */
+						const u32 skip = 8u * (a & 3u) + 2u * (off & 3u);         /* bits in front of the window inside its first dword: <= 30 */
+						const u32 N = (2 * k + 30 + 31) >> 5;                     /* dwords read (uniform) */
+						const u32 *wp = reinterpret_cast<const u32 *>(s_raw + (a & ~3u));
+						u32 E[M]; /* E[M-1] = the window's last dword; the up to three dwords in front of the window (t >= N: still inside s_raw, which starts
+						           * 16 bytes before the slice) land in limbs that kmc_mask_low clears */
+#pragma unroll
+						for (int t = 0; t < M; ++t)
+							E[M - 1 - t] = __builtin_bswap32(wp[(int)N - 1 - t]);
+						const u32 r = 32 * N - skip - 2 * k; /* bits behind the window in the last dword(s): 0..61 */
+						const u32 rs = r & 31u;
+						const bool far = r >= 32u;
+#pragma unroll
+						for (int i = 0; i < 2 * SIZE; ++i) {
+							const u32 lo = far ? E[M - 2 - i] : E[M - 1 - i], hi = far ? E[M - 3 - i] : E[M - 2 - i];
+							const u32 limb = (u32)((((u64)hi << 32) | lo) >> rs);
+							if (i & 1)
+								v[i >> 1] |= (u64)limb << 32;
+							else
+								v[i >> 1] = limb;
+						}
+						kmc_mask_low<SIZE>(v, 2 * k);
+						if (both_strands) {
+							u64 rc[SIZE];
+							kmc_revcomp<SIZE>(v, k, rc);
+							if (kmc_less<SIZE>(rc, v)) {
+#pragma unroll
+								for (int w = 0; w < SIZE; ++w)
+									v[w] = rc[w];
+							}
+						}
 					}
 #pragma unroll
 					for (int w = 0; w < SIZE; ++w)

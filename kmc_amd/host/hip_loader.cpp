@@ -14,11 +14,15 @@
  * the worker raises it through CCriticalErrorHandler.
  */
 #include <dlfcn.h>
+#include <execinfo.h>
+#include <pthread.h>
+#include <signal.h>
 #include <unistd.h>
 
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
+#include <algorithm>
 #include <atomic>
 #include <mutex>
 #include <string>
@@ -264,6 +268,75 @@ struct EagerInit {
 			th.join();
 	}
 } g_eager;
+
+/* KMC_HIP_SAMPLE_MAIN=<ms> (diagnostics): where is the MAIN thread — the one that runs CKMC::Process — while nothing of this repo runs? A sampler thread
+ * signals it every <ms> milliseconds, the handler keeps the return addresses (backtrace), and at exit the samples are printed with the second since the
+ * program started, symbolised. Answers "where do the 0.17 s after the completer has closed its files go" (round-3 verdict) without touching kmc_core. */
+struct MainSampler {
+	static constexpr int MAX_SAMPLES = 4096, DEPTH = 10;
+	static void *frames[MAX_SAMPLES][DEPTH];
+	static int depth[MAX_SAMPLES];
+	static long long when_ns[MAX_SAMPLES];
+	static std::atomic<int> n;
+	static long long t0;
+	pthread_t main_thread;
+	std::thread th;
+	std::atomic<bool> stop{false};
+	static long long now_ns() { return std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+	static void on_signal(int)
+	{
+		const int i = n.fetch_add(1);
+		if (i < MAX_SAMPLES) {
+			when_ns[i] = now_ns();
+			depth[i] = backtrace(frames[i], DEPTH);
+		}
+	}
+	MainSampler()
+	{
+		const char *e = getenv("KMC_HIP_SAMPLE_MAIN");
+		const int ms = e ? atoi(e) : 0;
+		if (ms < 1)
+			return;
+		main_thread = pthread_self(); /* static initialisers run on the main thread */
+		t0 = now_ns();
+		void *warm[4];
+		(void)backtrace(warm, 4); /* loads libgcc outside the handler */
+		signal(SIGUSR2, on_signal);
+		th = std::thread([this, ms] {
+			while (!stop.load()) {
+				std::this_thread::sleep_for(std::chrono::milliseconds(ms));
+				pthread_kill(main_thread, SIGUSR2);
+			}
+		});
+	}
+	~MainSampler()
+	{
+		if (!th.joinable())
+			return;
+		stop.store(true);
+		th.join();
+		const int m = std::min(n.load(), (int)MAX_SAMPLES);
+		fprintf(stderr, "[kmc_hip main-thread samples] %d samples (program start at %.3f s of the steady clock); second of that clock: frames\n", m, t0 * 1e-9);
+		for (int i = 0; i < m; ++i) {
+			fprintf(stderr, "  %.3f:", when_ns[i] * 1e-9);
+			char **sym = backtrace_symbols(frames[i], depth[i]);
+			for (int d = 2; d < depth[i] && d < 8; ++d) { /* 0-1: the handler and the signal trampoline */
+				std::string sname = sym ? sym[d] : "?";
+				const size_t a = sname.find('('), b = sname.find('+', a == std::string::npos ? 0 : a);
+				if (a != std::string::npos && b != std::string::npos && b > a + 1)
+					sname = sname.substr(a + 1, b - a - 1);
+				fprintf(stderr, " %s |", sname.substr(0, 60).c_str());
+			}
+			fprintf(stderr, "\n");
+			free(sym);
+		}
+	}
+} g_main_sampler;
+void *MainSampler::frames[MainSampler::MAX_SAMPLES][MainSampler::DEPTH];
+int MainSampler::depth[MainSampler::MAX_SAMPLES];
+long long MainSampler::when_ns[MainSampler::MAX_SAMPLES];
+std::atomic<int> MainSampler::n{0};
+long long MainSampler::t0 = 0;
 } // namespace
 
 /* the narrow boundary (hip_sort_function.h): one GPU sort on behalf of a reference sorter thread. Threads are spread over the

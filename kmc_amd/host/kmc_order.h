@@ -72,7 +72,7 @@ struct KmcTimeline {
 		if (!on || marks.empty())
 			return;
 		mark("process exit (static destructors)");
-		fprintf(stderr, "[kmc_hip timeline]");
+		fprintf(stderr, "[kmc_hip timeline] (first mark at %.3f s of the steady clock)", marks[0].second * 1e-9);
 		for (auto &e : marks)
 			fprintf(stderr, " %s %.3f |", e.first, (e.second - marks[0].second) * 1e-9);
 		fprintf(stderr, "\n");

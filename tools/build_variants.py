@@ -23,6 +23,9 @@ VARIANTS = {
     "w24s4_1cu": ["-DRS_WORDS_PER_THREAD_1=24", "-DRS_STAGES=4", "-DRS_MIN_WAVES=4"],
     "w24s2_1cu": ["-DRS_WORDS_PER_THREAD_1=24", "-DRS_STAGES=2", "-DRS_MIN_WAVES=4"],
     "w32s4_1cu": ["-DRS_WORDS_PER_THREAD_1=32", "-DRS_STAGES=4", "-DRS_MIN_WAVES=4"],
+    "wm12": ["-DRS_WORDS_PER_THREAD=12"],  # records of 2+ words: 12 words per thread in a scatter tile (k = 55: 6144 records, 384-byte runs)
+    "wm16s4": ["-DRS_WORDS_PER_THREAD=16", "-DRS_STAGES=4"],  # 16 words (k = 55: 8192 records / k = 127: 4096, 512-byte runs), staged in 4 slices
+    "wm12s3": ["-DRS_WORDS_PER_THREAD=12", "-DRS_STAGES=3"],
     "w12s3": ["-DRS_WORDS_PER_THREAD_1=12", "-DRS_STAGES=3"],  # 12 K-record tiles, 384-byte runs, 2 workgroups/CU
     "w10s2": ["-DRS_WORDS_PER_THREAD_1=10", "-DRS_STAGES=2"],
     "exp16k": ["-DEXP_CHUNK_BYTES=16384"],
