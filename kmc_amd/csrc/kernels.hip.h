@@ -66,22 +66,30 @@ constexpr int RS_BLOCK = RS_BLOCK_THREADS, RS_WAVES = RS_BLOCK / 64;            
 constexpr int CP_BLOCK = CP_BLOCK_THREADS;                                                     /* compaction workgroup          */
 
 #ifndef RS_WORDS_PER_THREAD
-#define RS_WORDS_PER_THREAD 8 /* 8-byte words held per thread in a scatter tile, records of 2+ words */
+#define RS_WORDS_PER_THREAD 16 /* 8-byte words held per thread in a scatter tile, records of 4+ words. Round 4 (k = 127, 32-byte records, quarter workload): 8 words
+                                * (2048-record tiles, 256-byte runs) 550 us per launch = 0.51 of the HBM peak, 12: 0.53, 16 in 4 slices (512-byte runs): 506 us = 0.556 */
+#endif
+#ifndef RS_WORDS_PER_THREAD_23
+#define RS_WORDS_PER_THREAD_23 12 /* records of 2-3 words. k = 55 (16-byte records): 8 words (4096-record tiles) 1068 us = 0.536, 12 (6144 records, 384-byte runs) 983 us =
+                                   * 0.582, 16 in 4 slices 1015 us = 0.564 */
 #endif
 #ifndef RS_WORDS_PER_THREAD_1
 #define RS_WORDS_PER_THREAD_1 10 /* one-word records (k <= 32): 10 240-record tiles, 320-byte runs. One launch of 412 M records (round 2):
                                   * 8 words 1.82-1.83 ms, 9: 1.83, 10: 1.69-1.74, 12 (9 VGPRs spilled): 1.71, 16 (19 spilled): 2.16 */
 #endif
 #ifndef RS_STAGES
-#define RS_STAGES 2 /* 10 words: 2 slices 1.69-1.74 ms, 5 slices 1.88 */
+#define RS_STAGES 2 /* LDS staging slices per tile, records of 1-3 words. 10 words: 2 slices 1.69-1.74 ms, 5 slices 1.88 */
 #endif
-#define RS_STAGES_REQ RS_STAGES
+#ifndef RS_STAGES_WIDE
+#define RS_STAGES_WIDE 4 /* records of 4+ words */
+#endif
 template <int SIZE> struct RsCfg { /* records per thread in a scatter tile */
-	static constexpr int WORDS = SIZE == 1 ? RS_WORDS_PER_THREAD_1 : RS_WORDS_PER_THREAD;
+	static constexpr int WORDS = SIZE == 1 ? RS_WORDS_PER_THREAD_1 : (SIZE <= 3 ? RS_WORDS_PER_THREAD_23 : RS_WORDS_PER_THREAD);
 	static constexpr int ITEMS = (WORDS / SIZE) > 2 ? (WORDS / SIZE) : 2;
 	static constexpr int TILE = RS_BLOCK * ITEMS;
 	static_assert(TILE <= 32768, "tile-relative slots are kept as 16-bit values (0xFFFF marks an absent record)");
-	static constexpr int STAGES = (ITEMS % RS_STAGES_REQ == 0) ? RS_STAGES_REQ : 1; /* LDS staging slices per tile */
+	static constexpr int STAGES_REQ = SIZE <= 3 ? RS_STAGES : RS_STAGES_WIDE;
+	static constexpr int STAGES = (ITEMS % STAGES_REQ == 0) ? STAGES_REQ : ITEMS; /* LDS staging slices per tile (else: one record per thread and slice) */
 };
 #ifndef CP_WORDS_PER_THREAD
 #define CP_WORDS_PER_THREAD 16 /* 8-byte words per lane of a compaction tile (records of 2+ words): rows per wave = words / SIZE */
@@ -800,26 +808,24 @@ __global__ void __launch_bounds__(EXP_BLOCK) k_expand(const GrpExpand ge, u32 k,
 						v[0] = f;
 					} else {
 						/* wider records, the same way (round 4; kmc_extract_kmer walks the window byte by byte: ~150 VALU instructions per k-mer at k = 55,
-						 * ~500 at k = 127 — the whole of this kernel's time): the window of 2k bits lies in N = ceil((2k + 30) / 32) aligned LDS dwords; byte-swapped
-						 * they are a big-endian bit stream, and limb i of the k-mer is one funnel shift of two neighbouring dwords. E[] is filled from the END of the
-						 * window so that every register index is static (N is uniform, the shift is per lane). */
-						constexpr int M = 2 * SIZE + 2;
+						 * ~500 at k = 127): the window of 2k bits ends in some aligned LDS dword; that dword and the 2 SIZE before it, byte-swapped, are a big-endian
+						 * bit stream, and limb i of the k-mer is ONE funnel shift of two neighbouring dwords. Every register index is static: the per-lane part is
+						 * the address of the last dword and the shift. (A per-lane choice between two register indices — the first version — is turned into a
+						 * dynamic index by the compiler and expanded into nine-way compare/select chains.) */
+						constexpr int M = 2 * SIZE + 1;
 						const u32 a = 16u + (u32)s_skpos[si] + 1u + (off >> 2);   /* byte offset inside s_raw of the window's first byte */
-						const u32 skip = 8u * (a & 3u) + 2u * (off & 3u);         /* bits in front of the window inside its first dword: <= 30 */
-						const u32 N = (2 * k + 30 + 31) >> 5;                     /* dwords read (uniform) */
-						const u32 *wp = reinterpret_cast<const u32 *>(s_raw + (a & ~3u));
-						u32 E[M]; /* E[M-1] = the window's last dword; the up to three dwords in front of the window (t >= N: still inside s_raw, which starts
-						           * 16 bytes before the slice) land in limbs that kmc_mask_low clears */
+						const u32 endbit = 8u * (a & 3u) + 2u * (off & 3u) + 2 * k; /* first bit behind the window, counted from the dword that holds its first byte */
+						const u32 jl = (endbit - 1) >> 5;                            /* the dword that holds the window's last bit */
+						const u32 *we = reinterpret_cast<const u32 *>(s_raw + (a & ~3u)) + jl;
+						const u32 rs = 32 * (jl + 1) - endbit;                       /* bits behind the window inside that dword: 0..31 */
+						u32 E[M]; /* E[M-1] = the window's last dword; dwords in front of the window (up to three, still inside s_raw, which starts 16 bytes before
+						           * the slice) land in bits that kmc_mask_low clears */
 #pragma unroll
 						for (int t = 0; t < M; ++t)
-							E[M - 1 - t] = __builtin_bswap32(wp[(int)N - 1 - t]);
-						const u32 r = 32 * N - skip - 2 * k; /* bits behind the window in the last dword(s): 0..61 */
-						const u32 rs = r & 31u;
-						const bool far = r >= 32u;
+							E[M - 1 - t] = __builtin_bswap32(we[-t]);
 #pragma unroll
 						for (int i = 0; i < 2 * SIZE; ++i) {
-							const u32 lo = far ? E[M - 2 - i] : E[M - 1 - i], hi = far ? E[M - 3 - i] : E[M - 2 - i];
-							const u32 limb = (u32)((((u64)hi << 32) | lo) >> rs);
+							const u32 limb = (u32)((((u64)E[M - 2 - i] << 32) | E[M - 1 - i]) >> rs);
 							if (i & 1)
 								v[i >> 1] |= (u64)limb << 32;
 							else

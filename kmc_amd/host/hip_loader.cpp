@@ -186,10 +186,16 @@ void load_api_impl()
 		a.n_slots = 1;
 }
 
+void start_main_sampler(); /* below: KMC_HIP_SAMPLE_MAIN diagnostics */
+
 struct HipEngine : KmcBinEngine {
 	int dev, slot;
 	std::string err;
-	HipEngine(int dev, int slot) : dev(dev), slot(slot) { ++g_engines; }
+	HipEngine(int dev, int slot) : dev(dev), slot(slot)
+	{
+		if (++g_engines == 1)
+			start_main_sampler();
+	}
 	~HipEngine() override
 	{
 		if (--g_engines == 0 && getenv("KMC_HIP_VERBOSE"))
@@ -293,12 +299,16 @@ struct MainSampler {
 	}
 	MainSampler()
 	{
-		const char *e = getenv("KMC_HIP_SAMPLE_MAIN");
-		const int ms = e ? atoi(e) : 0;
-		if (ms < 1)
-			return;
 		main_thread = pthread_self(); /* static initialisers run on the main thread */
 		t0 = now_ns();
+	}
+	/* called when the first stage-2 worker is constructed (start-up — the dynamic loader, the HIP runtime coming up on another thread — is over by then) */
+	void start()
+	{
+		const char *e = getenv("KMC_HIP_SAMPLE_MAIN");
+		const int ms = e ? atoi(e) : 0;
+		if (ms < 1 || th.joinable())
+			return;
 		void *warm[4];
 		(void)backtrace(warm, 4); /* loads libgcc outside the handler */
 		signal(SIGUSR2, on_signal);
@@ -337,6 +347,7 @@ int MainSampler::depth[MainSampler::MAX_SAMPLES];
 long long MainSampler::when_ns[MainSampler::MAX_SAMPLES];
 std::atomic<int> MainSampler::n{0};
 long long MainSampler::t0 = 0;
+void start_main_sampler() { g_main_sampler.start(); }
 } // namespace
 
 /* the narrow boundary (hip_sort_function.h): one GPU sort on behalf of a reference sorter thread. Threads are spread over the

@@ -12,7 +12,7 @@ sys.path.insert(0, os.path.join(ROOT, "tools"))
 
 # kernel -> (max scratch bytes per lane, min waves per SIMD)
 BUDGET = {
-    "k_onesweep<1>": (0, 8), "k_onesweep<2>": (0, 8), "k_onesweep<4>": (0, 8),          # the dominant kernel of every record width: 2 workgroups of 1024 per CU
+    "k_onesweep<1>": (0, 8), "k_onesweep<2>": (0, 8), "k_onesweep<4>": (20, 8),          # the dominant kernel of every record width: 2 workgroups of 1024 per CU
     "k_bucket_rank<1, true>": (0, 6), "k_bucket_rank<2, true>": (0, 6), "k_bucket_rank<4, true>": (0, 6),  # two workgroups of 768 per CU
     "k_expand<1, true>": (0, 8), "k_expand<2, true>": (0, 6),
     "k_parse_packs": (0, 8), "k_bucket_bounds<1>": (0, 8), "k_compact_fold": (0, 4), "k_compact_gather": (0, 8),

@@ -32,6 +32,7 @@ t=time.time(); s=capi.synth_bins(seed=2026, genome_len=1000000000, n_reads=20000
     qs:*)    a=${step#qs:}; n=${a%%:*}; e=${a#*:}; env $e timeout 600 python bench.py --cache /dev/shm/kmccache --leg quarter --reads 50000000 --genome 250000000 --bins 128 --steps 3 --warmup 1 --streams $n > $OUT/qs_${n}_$e.json 2> $OUT/qs_${n}_$e.err; python tools/pj.py $OUT/qs_${n}_$e.json 2>&1 | cut -c1-120 ;;
     kq:*)    a=${step#kq:}; k=${a%%:*}; e=${a#*:}; env $e timeout 900 python bench.py --k $k --leg quarter --reads 50000000 --genome 250000000 --bins 128 --steps 3 --warmup 1 --no-digest > $OUT/kq_${k}_$e.json 2> $OUT/kq_${k}_$e.err; python tools/pj.py $OUT/kq_${k}_$e.json 2>&1 | cut -c1-700 ;;
     kqv:*)   a=${step#kqv:}; k=${a%%:*}; v=${a#*:}; lib=kmc_amd/variants/libkmc_hip_$v.so; [ "$v" = base ] && lib=kmc_amd/libkmc_hip.so; KMC_HIP_LIB=$lib timeout 900 python bench.py --k $k --leg quarter --reads 50000000 --genome 250000000 --bins 128 --steps 3 --warmup 1 --no-digest > $OUT/kqv_${k}_$v.json 2> $OUT/kqv_${k}_$v.err; python tools/pj.py $OUT/kqv_${k}_$v.json 2>&1 | cut -c1-330 ;;
+    e2esample) bash tools/e2e_sample_main.sh $OUT/e2e_sample 2>&1 | cut -c1-900 ;;
     k:*)     k=${step#k:}; timeout 900 python bench.py --k $k --no-cpu-baseline --no-secondary --no-host-boundary --steps 3 > $OUT/bench_k$k.json 2> $OUT/bench_k$k.err ;;
     prof)    cd /tmp; timeout 1500 rocprofv3 --kernel-trace --stats -f csv -d $OLDPWD/$OUT/prof -o kt -- python $OLDPWD/bench.py --cache /dev/shm/kmccache --no-cpu-baseline --no-secondary --no-host-boundary --no-two-streams --no-digest --steps 3 > $OLDPWD/$OUT/prof_bench.json 2> $OLDPWD/$OUT/prof.err; cd $OLDPWD; find $OUT/prof -name "*kernel_trace.csv" -delete; find $OUT/prof -name "*kernel_stats.csv" | head -1 | xargs -r head -12 | cut -c1-160 ;;
     pmc:*)   c=${step#pmc:}; cd /tmp; timeout 1500 rocprofv3 --pmc $c -f csv -d $OLDPWD/$OUT/pmc_$c -o pmc -- python $OLDPWD/bench.py --cache /dev/shm/kmccache --no-cpu-baseline --no-secondary --no-host-boundary --no-two-streams --no-digest --steps 1 --warmup 0 > $OLDPWD/$OUT/pmc_$c.json 2> $OLDPWD/$OUT/pmc_$c.err; cd $OLDPWD ;;
