@@ -204,6 +204,8 @@ class CWKmerBinCompleter {
 		KmcTimeline::mark("completer: queue drained");
 		stop_writers();
 		KmcTimeline::mark("completer: writers joined");
+		KmcArena::inst().zap_parallel(); /* every bin is written: the arena's pages go now, in parallel, instead of under the reference's release at the end of the stage */
+		KmcTimeline::mark("completer: arena pages returned");
 	}
 
 	void second_stage()

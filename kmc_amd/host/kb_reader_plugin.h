@@ -117,13 +117,12 @@ template <unsigned SIZE> class CWKmerBinReader {
 	 * timeline: "files closed 0.220 | process exit 0.388"). Where transparent huge pages are in `madvise` mode (the GPU boxes of this pool) the mapping is
 	 * put on 2 MB pages before its first touch: 512x fewer faults and page-table entries to tear down. The first reserved pointer locates the mapping
 	 * (/proc/self/maps). KMC_HIP_ARENA_THP=0 switches it off. */
-	static void advise_arena_once(const void *inside)
+	static void advise_arena_once(const void *inside, uint64 arena_bytes)
 	{
 		static std::once_flag once;
-		std::call_once(once, [inside] {
+		std::call_once(once, [inside, arena_bytes] {
 			const char *e = getenv("KMC_HIP_ARENA_THP");
-			if (e && atoi(e) == 0)
-				return;
+			const bool thp = !(e && atoi(e) == 0);
 			FILE *f = fopen("/proc/self/maps", "r");
 			if (!f)
 				return;
@@ -132,9 +131,15 @@ template <unsigned SIZE> class CWKmerBinReader {
 			while (fgets(line, sizeof line, f)) {
 				unsigned long long a = 0, b = 0;
 				if (sscanf(line, "%llx-%llx", &a, &b) == 2 && p >= a && p < b) {
+					/* only a mapping that IS the arena (a block of this size is an anonymous mapping of its own: the block + the allocator's header, page-rounded);
+					 * a small arena lives in the heap, next to everything else, and is left alone */
+					if (b - a < arena_bytes || b - a > arena_bytes + (1ull << 20) || arena_bytes < (64ull << 20))
+						break;
 					const uintptr_t two_mb = (uintptr_t)2 << 20;
 					const uintptr_t lo = ((uintptr_t)a + two_mb - 1) & ~(two_mb - 1), hi = (uintptr_t)b & ~(two_mb - 1);
-					if (hi > lo) {
+					KmcArena::inst().lo.store((uintptr_t)a);
+					KmcArena::inst().hi.store((uintptr_t)b);
+					if (hi > lo && thp) {
 						const int rc = madvise((void *)lo, hi - lo, MADV_HUGEPAGE);
 						if (getenv("KMC_HIP_VERBOSE"))
 							fprintf(stderr, "[kmc_hip stage 2] arena %.1f GB: madvise(MADV_HUGEPAGE) %s\n", (double)(b - a) / 1e9, rc == 0 ? "ok" : "refused");
@@ -158,7 +163,7 @@ template <unsigned SIZE> class CWKmerBinReader {
 			}
 			b.file->Rewind();
 			memory_bins->reserve(b.bin_id, data, CMemoryBins::mba_input_file);
-			advise_arena_once(data);
+			advise_arena_once(data, (uint64)memory_bins->GetTotalSize());
 			const long long t0 = KmcOrderedEmit::now_ns();
 			uint64 readed = b.file->Read(data, 1, b.size);
 			order->ns_reader_read += KmcOrderedEmit::now_ns() - t0;

@@ -22,6 +22,9 @@
 #include <mutex>
 #include <vector>
 
+#include <sys/mman.h>
+#include <thread>
+#include <algorithm>
 #include "defs.h"
 #include "params.h"
 #include "critical_error_handler.h"
@@ -76,6 +79,38 @@ struct KmcTimeline {
 		for (auto &e : marks)
 			fprintf(stderr, " %s %.3f |", e.first, (e.second - marks[0].second) * 1e-9);
 		fprintf(stderr, "\n");
+	}
+};
+
+/* The arena of CMemoryBins as the reader plug-in found it (one anonymous mapping; kb_reader_plugin.h advise_arena_once). The reference releases it at the end of
+ * stage 2 on a thread it joins before the "2nd stage" timer stops (kmc.h:1602-1605): on the GPU boxes of this pool unmapping the 2.3 GB a 2 Gbp run has touched
+ * takes 0.15-0.19 s — 40 % of the stage once the sort runs on the GPU (main-thread samples, profiles/r04/e2e_teardown.txt) — with 4 KB pages and with huge pages
+ * alike. The pages can go earlier and in parallel: when the completer plug-in has written the last bin, nothing in the arena is needed any more, and 16 threads
+ * of madvise(MADV_DONTNEED) take 0.02 s (tools/ubench_munmap.c); the reference's own release then finds nothing to tear down. */
+struct KmcArena {
+	std::atomic<uintptr_t> lo{0}, hi{0};
+	static KmcArena &inst()
+	{
+		static KmcArena a;
+		return a;
+	}
+	void zap_parallel(int n_threads = 16)
+	{
+		const uintptr_t a = lo.load() + 4096, b = hi.load(); /* the first page holds the allocator's header of the block (free() reads it at the release) */
+		const char *e = getenv("KMC_HIP_ARENA_ZAP");
+		if (a == 4096 || b <= a || (e && atoi(e) == 0))
+			return;
+		const uintptr_t two_mb = (uintptr_t)2 << 20;
+		const uintptr_t per = (((b - a) / (uintptr_t)n_threads) + two_mb - 1) & ~(two_mb - 1);
+		std::vector<std::thread> th;
+		for (int t = 0; t < n_threads; ++t) {
+			const uintptr_t s = a + (uintptr_t)t * per, f = std::min(b, s + per);
+			if (s < f)
+				th.emplace_back([s, f] { (void)madvise((void *)s, f - s, MADV_DONTNEED); });
+		}
+		for (auto &x : th)
+			x.join();
+		lo.store(0);
 	}
 };
 
