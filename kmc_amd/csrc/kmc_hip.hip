@@ -70,6 +70,37 @@ int ensure(DBuf &b, size_t bytes)
 	return 0;
 }
 
+/* is `p` host memory the device can reach by DMA as it is (hipHostMalloc / hipHostRegister)? Ordinary memory is staged through a pinned buffer of the slot. */
+bool host_ptr_is_pinned(const void *p)
+{
+	static const bool always = [] {
+		const char *e = getenv("KMC_HIP_STAGE_PAGEABLE"); /* 0: copy straight from / to pageable memory (rounds 1-3) */
+		return e && atoi(e) == 0;
+	}();
+	if (always || !p)
+		return true;
+	hipPointerAttribute_t at;
+	if (hipPointerGetAttributes(&at, p) != hipSuccess) {
+		(void)hipGetLastError(); /* "invalid value" for memory the runtime has never seen: ordinary memory */
+		return false;
+	}
+	return at.type == hipMemoryTypeHost || at.type == hipMemoryTypeDevice || at.type == hipMemoryTypeManaged;
+}
+int ensure_pinned(void *&p, size_t &cap, size_t bytes)
+{
+	if (bytes <= cap)
+		return 0;
+	if (p) {
+		HIPCHK(hipHostFree(p));
+		p = nullptr;
+		cap = 0;
+	}
+	const size_t want = (bytes + (bytes >> 2) + 4095) & ~(size_t)4095; /* grow-only, with room: bins come in descending size order at first, then vary */
+	HIPCHK(hipHostMalloc(&p, want, hipHostMallocDefault));
+	cap = want;
+	return 0;
+}
+
 /* layout of the per-slot "small" device block (bytes): the first SM_BYTES of the slot's zero region, cleared with it at the start
  * of every bin */
 /* bytes 0..15: unused */
@@ -129,6 +160,12 @@ struct Slot {
 	DBuf bounds;   /* hybrid sort: tile boundaries of k_bucket_bounds, u64[windows + 1] */
 	DBuf redo_log; /* hybrid sort: one "sort me again" word per asynchronous group since the last drain (drain_redo) */
 	HostRes *h_res = nullptr; /* pinned */
+	/* pinned staging for callers whose buffers are ordinary (pageable) memory — the drop-in worker's arena: a copy straight from / to such memory makes the
+	 * runtime pin the caller's pages on the fly, and the unmapping of an arena that has been pinned piecewise costs twice as much at the end of KMC's stage 2
+	 * (tools/ubench_munmap_hip.py: 0.23 s instead of 0.12 s for 2.3 GB; nothing left after a parallel MADV_DONTNEED only when nothing was ever pinned) */
+	void *h_stage_in = nullptr, *h_stage_out = nullptr;
+	size_t h_stage_in_cap = 0, h_stage_out_cap = 0;
+	bool out_staged = false;
 	u64 groups_run = 0;     /* groups enqueued on this slot since the context was made */
 	bool zero_grew = false; /* the last group's zero region had to be re-allocated (diagnostics: reported with a watchdog error) */
 	hipEvent_t ev[6] = {};
@@ -264,6 +301,10 @@ void slot_destroy(Slot &s)
 		(void)hipHostFree(s.h_res);
 	if (s.h_hb_res)
 		(void)hipHostFree(s.h_hb_res);
+	if (s.h_stage_in)
+		(void)hipHostFree(s.h_stage_in);
+	if (s.h_stage_out)
+		(void)hipHostFree(s.h_stage_out);
 	for (auto &e : s.ev)
 		if (e)
 			(void)hipEventDestroy(e);
@@ -2277,10 +2318,18 @@ int kmc_hip_process_bin_submit(kmc_hip_ctx *ctx, int dev, int slot, const kmc_hi
 	    (rc = ensure(s.out, (P.without_output ? 0 : out_capacity) + 256)) || (rc = ensure(s.lut, lut_entries * 8 + 256)))
 		return rc;
 	if (size) {
-		HIPCHK(hipMemcpyAsync(s.in.p, superkmers, size, hipMemcpyHostToDevice, s.stream));
+		const void *src = superkmers;
+		if (!host_ptr_is_pinned(superkmers)) { /* pageable caller (the drop-in's arena): through the slot's pinned staging buffer */
+			if ((rc = ensure_pinned(s.h_stage_in, s.h_stage_in_cap, size)))
+				return rc;
+			memcpy(s.h_stage_in, superkmers, size);
+			src = s.h_stage_in;
+		}
+		HIPCHK(hipMemcpyAsync(s.in.p, src, size, hipMemcpyHostToDevice, s.stream));
 		HIPCHK(hipMemsetAsync((char *)s.in.p + size, 0, 256, s.stream));
 		HIPCHK(hipMemcpyAsync(s.pack_start.p, ps.data(), (np + 1) * 8, hipMemcpyHostToDevice, s.stream));
 	}
+	s.out_staged = !P.without_output && (out_capacity || lut_entries) && !host_ptr_is_pinned(out_capacity ? (const void *)out_suffix : (const void *)lut);
 	s.timed = true;
 	s.sub_P = P;
 	s.sub_size = size;
@@ -2335,12 +2384,27 @@ int kmc_hip_process_bin_wait(kmc_hip_ctx *ctx, int dev, int slot, uint64_t *out_
 		return fail(KMC_HIP_ECAPACITY, "out_capacity too small for the counted k-mers");
 	if (!s.without_output) {
 		/* exact-size copies: out_bytes is only known now (the capacity is ~10x the counted bytes at the default cutoffs) */
+		uint8_t *dst_out = s.h_out;
+		u64 *dst_lut = s.h_lut;
+		const size_t lut_bytes = (size_t)s.lut_entries * 8;
+		if (s.out_staged) { /* pageable caller: records and LUT land in the slot's pinned staging buffer and are copied on from there */
+			if (int rc = ensure_pinned(s.h_stage_out, s.h_stage_out_cap, r.out_bytes + lut_bytes + 16))
+				return rc;
+			dst_lut = (u64 *)s.h_stage_out;
+			dst_out = (uint8_t *)s.h_stage_out + lut_bytes;
+		}
 		if (r.out_bytes)
-			HIPCHK(hipMemcpyAsync(s.h_out, s.out.p, r.out_bytes, hipMemcpyDeviceToHost, s.stream));
+			HIPCHK(hipMemcpyAsync(dst_out, s.out.p, r.out_bytes, hipMemcpyDeviceToHost, s.stream));
 		if (s.lut_entries)
-			HIPCHK(hipMemcpyAsync(s.h_lut, s.lut.p, s.lut_entries * 8, hipMemcpyDeviceToHost, s.stream));
+			HIPCHK(hipMemcpyAsync(dst_lut, s.lut.p, lut_bytes, hipMemcpyDeviceToHost, s.stream));
 		HIPCHK(hipEventRecord(s.done_ev, s.stream));
 		HIPCHK(hipEventSynchronize(s.done_ev));
+		if (s.out_staged) {
+			if (r.out_bytes)
+				memcpy(s.h_out, dst_out, r.out_bytes);
+			if (lut_bytes)
+				memcpy(s.h_lut, dst_lut, lut_bytes);
+		}
 	}
 	if (out_bytes)
 		*out_bytes = r.out_bytes;
@@ -2419,11 +2483,25 @@ int kmc_hip_process_bins_submit(kmc_hip_ctx *ctx, int dev, int slot, const kmc_h
 	if (!ps.empty())
 		HIPCHK(hipMemcpyAsync(s.pack_start.p, ps.data(), ps.size() * 8, hipMemcpyHostToDevice, s.stream));
 	s.hb.resize(n_bins);
+	bool stage_in = false;
+	s.out_staged = false;
+	for (u32 i = 0; i < n_bins; ++i) { /* one pageable buffer among the call's: everything of the call goes through the pinned staging buffers */
+		stage_in = stage_in || (bins[i].size && !host_ptr_is_pinned(bins[i].superkmers));
+		if (!P.without_output)
+			s.out_staged = s.out_staged || (bins[i].out_capacity && !host_ptr_is_pinned(bins[i].out_suffix)) || (lut_entries && !host_ptr_is_pinned(bins[i].lut));
+	}
+	if (stage_in && (rc = ensure_pinned(s.h_stage_in, s.h_stage_in_cap, in_total + 256)))
+		return rc;
 	for (u32 i = 0; i < n_bins; ++i) {
 		const kmc_hip_host_bin &b = bins[i];
 		uint8_t *d_img = (uint8_t *)s.in.p + in_off[i];
 		if (b.size) {
-			HIPCHK(hipMemcpyAsync(d_img, b.superkmers, b.size, hipMemcpyHostToDevice, s.stream));
+			const void *src = b.superkmers;
+			if (stage_in) {
+				memcpy((char *)s.h_stage_in + in_off[i], b.superkmers, b.size);
+				src = (char *)s.h_stage_in + in_off[i];
+			}
+			HIPCHK(hipMemcpyAsync(d_img, src, b.size, hipMemcpyHostToDevice, s.stream));
 			HIPCHK(hipMemsetAsync(d_img + b.size, 0, 256, s.stream));
 		}
 		Slot::HostBin &h = s.hb[i];
@@ -2523,14 +2601,31 @@ int kmc_hip_process_bins_wait(kmc_hip_ctx *ctx, int dev, int slot, uint64_t *out
 		if (r.w[i][0] > s.hb[i].d.out_capacity && !s.without_output)
 			return fail(KMC_HIP_ECAPACITY, "out_capacity too small for the counted k-mers");
 	if (!s.without_output) { /* exact-size copies */
+		const size_t lut_bytes = (size_t)s.lut_entries * 8;
+		std::vector<size_t> off(n + 1, 0);
+		if (s.out_staged) {
+			for (size_t i = 0; i < n; ++i)
+				off[i + 1] = off[i] + (((size_t)r.w[i][0] + lut_bytes + 63) & ~(size_t)63);
+			if (int rc = ensure_pinned(s.h_stage_out, s.h_stage_out_cap, off[n] + 64))
+				return rc;
+		}
 		for (size_t i = 0; i < n; ++i) {
+			uint8_t *dst_out = s.out_staged ? (uint8_t *)s.h_stage_out + off[i] + lut_bytes : s.hb[i].h_out;
+			u64 *dst_lut = s.out_staged ? (u64 *)((uint8_t *)s.h_stage_out + off[i]) : s.hb[i].h_lut;
 			if (r.w[i][0])
-				HIPCHK(hipMemcpyAsync(s.hb[i].h_out, s.hb[i].d.d_out, r.w[i][0], hipMemcpyDeviceToHost, s.stream));
+				HIPCHK(hipMemcpyAsync(dst_out, s.hb[i].d.d_out, r.w[i][0], hipMemcpyDeviceToHost, s.stream));
 			if (s.lut_entries)
-				HIPCHK(hipMemcpyAsync(s.hb[i].h_lut, s.hb[i].d.d_lut, s.lut_entries * 8, hipMemcpyDeviceToHost, s.stream));
+				HIPCHK(hipMemcpyAsync(dst_lut, s.hb[i].d.d_lut, lut_bytes, hipMemcpyDeviceToHost, s.stream));
 		}
 		HIPCHK(hipEventRecord(s.done_ev, s.stream));
 		HIPCHK(hipEventSynchronize(s.done_ev));
+		if (s.out_staged)
+			for (size_t i = 0; i < n; ++i) {
+				if (r.w[i][0])
+					memcpy(s.hb[i].h_out, (uint8_t *)s.h_stage_out + off[i] + lut_bytes, r.w[i][0]);
+				if (lut_bytes)
+					memcpy(s.hb[i].h_lut, (uint8_t *)s.h_stage_out + off[i], lut_bytes);
+			}
 	}
 	for (size_t i = 0; i < n; ++i) {
 		if (out_bytes)

@@ -60,6 +60,10 @@ static inline hipError_t hipFree(void *p)
 }
 static inline hipError_t hipHostMalloc(void **p, size_t bytes, unsigned = 0) { return hipMalloc(p, bytes); }
 static inline hipError_t hipHostFree(void *p) { return hipFree(p); }
+/* every caller buffer counts as ordinary memory: the emulated runs take the library's pinned-staging path */
+enum hipMemoryType { hipMemoryTypeUnregistered = 0, hipMemoryTypeHost = 1, hipMemoryTypeDevice = 2, hipMemoryTypeManaged = 3 };
+struct hipPointerAttribute_t { hipMemoryType type; };
+static inline hipError_t hipPointerGetAttributes(hipPointerAttribute_t *a, const void *) { a->type = hipMemoryTypeUnregistered; return hipSuccess; }
 static inline hipError_t hipHostRegister(void *, size_t, unsigned) { return hipSuccess; }
 static inline hipError_t hipHostUnregister(void *) { return hipSuccess; }
 static inline hipError_t hipMemcpy(void *d, const void *s, size_t n, hipMemcpyKind)
