@@ -30,6 +30,7 @@
 #include <vector>
 
 #include "bin_engine.h"
+#include "host_pool.h"
 
 namespace {
 
@@ -46,6 +47,8 @@ struct Api {
 	int (*wait_bins)(kmc_hip_ctx *, int, int, uint64_t *, uint64_t *) = nullptr;
 	int (*num_slots)(void) = nullptr;
 	int (*sort_into)(kmc_hip_ctx *, int, const void *, void *, uint64_t, uint32_t, uint32_t) = nullptr;
+	int (*host_alloc)(kmc_hip_ctx *, uint64_t, void **) = nullptr; /* optional: pinned buffers for the reader plug-in (KmcHostPool) */
+	int (*host_free)(kmc_hip_ctx *, void *) = nullptr;
 	int n_slots = 1;
 	std::mutex slot_mtx[64][16]; /* the C-ABI wants calls on one (device, slot) serialised; workers may outnumber slots */
 	kmc_hip_ctx *ctx = nullptr;
@@ -179,6 +182,18 @@ void load_api_impl()
 		return;
 	}
 	a.n_dev = (int)devs.size();
+	{ /* the reader plug-in may read bin images straight into pinned memory of this library (kmc_order.h KmcHostPool) */
+		std::string ignore;
+		if (sym(a.so, "kmc_hip_host_alloc", a.host_alloc, ignore) && sym(a.so, "kmc_hip_host_free", a.host_free, ignore)) {
+			KmcHostPool &pool = KmcHostPool::inst();
+			std::lock_guard<std::mutex> lck(pool.m);
+			pool.alloc_fn = [](size_t bytes) -> void * {
+				void *p = nullptr;
+				return g_api.host_alloc(g_api.ctx, bytes, &p) == 0 ? p : nullptr;
+			};
+			pool.free_fn = [](void *p) { (void)g_api.host_free(g_api.ctx, p); };
+		}
+	}
 	a.n_slots = a.num_slots();
 	if (a.n_slots > 16)
 		a.n_slots = 16;

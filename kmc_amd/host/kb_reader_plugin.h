@@ -154,7 +154,7 @@ template <unsigned SIZE> class CWKmerBinReader {
 	/* read (any order) -> wait for this bin's turn -> extend -> push (kb_reader.h:167-205) */
 	void load_and_push(BinPlan &b)
 	{
-		uchar *data = nullptr;
+		uchar *data = nullptr, *pinned = nullptr;
 		if (b.size > 0) {
 			if (b.file == nullptr) {
 				std::ostringstream ostr;
@@ -164,6 +164,11 @@ template <unsigned SIZE> class CWKmerBinReader {
 			b.file->Rewind();
 			memory_bins->reserve(b.bin_id, data, CMemoryBins::mba_input_file);
 			advise_arena_once(data, (uint64)memory_bins->GetTotalSize());
+			/* a pinned buffer of the engine's, if it has any to give: the image never touches the arena (its space there stays reserved, as the protocol
+			 * wants, but no page of it is faulted in); the worker plug-in returns the buffer */
+			pinned = (uchar *)KmcHostPool::inst().get(b.size);
+			if (pinned)
+				data = pinned;
 			const long long t0 = KmcOrderedEmit::now_ns();
 			uint64 readed = b.file->Read(data, 1, b.size);
 			order->ns_reader_read += KmcOrderedEmit::now_ns() - t0;
@@ -178,7 +183,7 @@ template <unsigned SIZE> class CWKmerBinReader {
 		memory_bins->extend(b.bin_id, b.rec_len, b.a_size, b.a_kxmers, b.a_out, b.a_counters, b.a_lut);
 		if (b.size > 0) {
 			memory_bins->reserve(b.bin_id, data, CMemoryBins::mba_input_file);
-			bq->push(b.bin_id, data, b.size, b.n_rec);
+			bq->push(b.bin_id, pinned ? pinned : data, b.size, b.n_rec);
 		} else {
 			bq->push(b.bin_id, nullptr, 0, 0); /* empty bins are pushed too: every bin id must be processed */
 		}

@@ -261,6 +261,7 @@ public:
 				Taken &t = grp[i];
 				/* the CPU sorter's working slots are never used here, but the region only recycles once every
 				 * slot of the bin is released (queues.h:1556-1583) */
+				(void)KmcHostPool::inst().put(t.data); /* the reader plug-in's pinned buffer, if the image came in one */
 				memory_bins->free(t.bin_id, CMemoryBins::mba_input_file);
 				memory_bins->free(t.bin_id, CMemoryBins::mba_input_array);
 				memory_bins->free(t.bin_id, CMemoryBins::mba_tmp_array);

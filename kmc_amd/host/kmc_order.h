@@ -25,6 +25,7 @@
 #include <sys/mman.h>
 #include <thread>
 #include <algorithm>
+#include "host_pool.h"
 #include "defs.h"
 #include "params.h"
 #include "critical_error_handler.h"

@@ -6,6 +6,7 @@
  * their database with the reference's (tests/test_stage1_plugin.py). It is only ever loaded through an explicit KMC_HIP_LIB=<this file>;
  * nothing in the product looks for it, and the GPU library is what every -m gpu test and bench.py load.
  */
+#include <atomic>
 #include <hip/hip_runtime.h>
 
 #include <cstdlib>
@@ -82,6 +83,21 @@ MOCK_API int kmc_hip_init(const int *, int n_dev, kmc_hip_ctx **out)
 MOCK_API void kmc_hip_destroy(kmc_hip_ctx *ctx) { delete ctx; }
 MOCK_API const char *kmc_hip_last_error(kmc_hip_ctx *) { return g_err.c_str(); }
 MOCK_API int kmc_hip_abi_version(void) { return KMC_HIP_ABI_VERSION; }
+/* "pinned" buffers for the reader plug-in's pool (host_pool.h): plain memory here; counted, so that a test can see the pool at work */
+static std::atomic<long long> g_host_allocs{0};
+MOCK_API int kmc_hip_host_alloc(kmc_hip_ctx *, uint64_t bytes, void **p)
+{
+	*p = malloc(bytes ? bytes : 1);
+	++g_host_allocs;
+	if (getenv("KMC_HIP_VERBOSE") && g_host_allocs == 1)
+		fprintf(stderr, "[mock] kmc_hip_host_alloc in use (reader plug-in's pinned pool)\n");
+	return *p ? 0 : -3;
+}
+MOCK_API int kmc_hip_host_free(kmc_hip_ctx *, void *p)
+{
+	free(p);
+	return 0;
+}
 MOCK_API int kmc_hip_backend_kind(void) { return 2; }
 MOCK_API int kmc_hip_num_slots(void) { return 4; }
 MOCK_API int kmc_hip_sort_records_into(kmc_hip_ctx *, int, const void *recs, void *dst, uint64_t n, uint32_t words, uint32_t)

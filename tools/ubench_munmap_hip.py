@@ -18,7 +18,7 @@ TOTAL, PIECE, STRIDE, N = 14 << 30, 4_500_000, 26_000_000, 512
 ctx = capi.Context((0,))
 d = ctx.malloc(PIECE)
 pin = ctx.host_alloc(PIECE)
-for variant in ("no hip copies", "hipMemcpy from the mapping", "memcpy to pinned, hipMemcpy from there"):
+for variant in ("no hip copies", "hipMemcpy from the mapping", "memcpy to pinned, hipMemcpy from there", "d2h: hipMemcpy INTO the mapping (1.1 MB pieces)", "d2h small: hipMemcpy INTO the mapping (128 KB pieces)"):
     for zap in (0, 16):
         m = mmap.mmap(-1, TOTAL, flags=mmap.MAP_PRIVATE | mmap.MAP_ANONYMOUS)
         a = np.frombuffer(m, dtype=np.uint8)
@@ -35,6 +35,11 @@ for variant in ("no hip copies", "hipMemcpy from the mapping", "memcpy to pinned
             elif variant.startswith("memcpy"):
                 pin[:PIECE] = piece
                 ctx.h2d(d, pin[:PIECE])
+            elif variant.startswith("d2h:"):
+                ctx.d2h(piece[:1_100_000], d)
+            elif variant.startswith("d2h small"):
+                for q in range(8):
+                    ctx.d2h(piece[q * 131072:(q + 1) * 131072], d)
         t2 = time.perf_counter()
         tz = 0.0
         if zap:
