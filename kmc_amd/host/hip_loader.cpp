@@ -182,16 +182,16 @@ void load_api_impl()
 		return;
 	}
 	a.n_dev = (int)devs.size();
-	{ /* the reader plug-in may read bin images straight into pinned memory of this library (kmc_order.h KmcHostPool) */
+	{ /* the reader plug-in may read bin images straight into pinned memory of this library (host_pool.h): one slab, allocated here — on the background thread
+	   * that brings the library up during stage 1 — so that stage 2 never waits for the runtime to pin anything */
 		std::string ignore;
-		if (sym(a.so, "kmc_hip_host_alloc", a.host_alloc, ignore) && sym(a.so, "kmc_hip_host_free", a.host_free, ignore)) {
-			KmcHostPool &pool = KmcHostPool::inst();
-			std::lock_guard<std::mutex> lck(pool.m);
-			pool.alloc_fn = [](size_t bytes) -> void * {
-				void *p = nullptr;
-				return g_api.host_alloc(g_api.ctx, bytes, &p) == 0 ? p : nullptr;
-			};
-			pool.free_fn = [](void *p) { (void)g_api.host_free(g_api.ctx, p); };
+		const size_t want = KmcHostPool::wanted_bytes();
+		if (want && sym(a.so, "kmc_hip_host_alloc", a.host_alloc, ignore) && sym(a.so, "kmc_hip_host_free", a.host_free, ignore)) {
+			void *p = nullptr;
+			if (a.host_alloc(a.ctx, want, &p) == 0 && p)
+				KmcHostPool::inst().adopt(p, want, [](void *q) { (void)g_api.host_free(g_api.ctx, q); });
+			else if (getenv("KMC_HIP_VERBOSE"))
+				fprintf(stderr, "[kmc_hip] no pinned pool (%zu MB refused): bin images go through the arena\n", want >> 20);
 		}
 	}
 	a.n_slots = a.num_slots();

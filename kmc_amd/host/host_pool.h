@@ -11,69 +11,91 @@
 #include <mutex>
 #include <utility>
 #include <vector>
+#include <iterator>
 
 /* Pinned host buffers for bin images, shared by the reader plug-in (reads a bin file straight into one) and the worker plug-in (hands it to the engine, gives
  * it back): the image then reaches the GPU by DMA from where the reader put it — no page of the arena is touched for it, and the library has nothing to stage
- * (1.7 of the 2.3 GB a 2 Gbp run moves; summed over the workers the staging copies were 1 s of CPU). The engine's loader supplies the allocator
- * (kmc_hip_host_alloc / _free); without one — the oracle engines of the tests — get() returns NULL and the image goes to the arena as in the reference. Buffers
- * are kept and reused (first fit); the pool stops growing at $KMC_HIP_PINNED_POOL_MB (default 1024) and then says NULL as well. */
+ * (1.7 of the 2.3 GB a 2 Gbp run moves; summed over the workers the staging copies were 1 s of CPU). ONE slab of pinned memory, allocated by the engine's loader
+ * when the library comes up — on its background thread, during KMC's stage 1 ($KMC_HIP_PINNED_POOL_MB, default 1024; allocating pinned buffers one by one while
+ * stage 2 runs serialised the readers behind the runtime: reader wall 0.17 -> 0.42 s) — and cut first-fit. No slab (the oracle engines of the tests), or no room:
+ * get() returns NULL and the image goes to the arena as in the reference. */
 struct KmcHostPool {
 	std::mutex m;
-	void *(*alloc_fn)(size_t) = nullptr;
+	char *slab = nullptr;
+	size_t slab_bytes = 0;
+	std::map<size_t, size_t> free_ranges; /* offset -> length, coalesced */
+	std::map<size_t, size_t> taken;       /* offset -> length */
 	void (*free_fn)(void *) = nullptr;
-	std::vector<std::pair<void *, size_t>> free_list; /* (buffer, capacity) */
-	std::map<void *, size_t> owned;                    /* every buffer of the pool -> capacity */
-	size_t total = 0, limit = 0;
 	static KmcHostPool &inst()
 	{
 		static KmcHostPool p;
 		return p;
 	}
+	static size_t wanted_bytes()
+	{
+		const char *e = getenv("KMC_HIP_PINNED_POOL_MB");
+		return (size_t)(e ? strtoull(e, nullptr, 10) : 1024) << 20;
+	}
+	void adopt(void *p, size_t bytes, void (*release)(void *))
+	{
+		std::lock_guard<std::mutex> lck(m);
+		slab = (char *)p;
+		slab_bytes = bytes;
+		free_fn = release;
+		free_ranges.clear();
+		taken.clear();
+		free_ranges[0] = bytes;
+	}
 	void *get(size_t bytes)
 	{
 		std::lock_guard<std::mutex> lck(m);
-		if (!alloc_fn || !bytes)
+		if (!slab || !bytes)
 			return nullptr;
-		if (!limit) {
-			const char *e = getenv("KMC_HIP_PINNED_POOL_MB");
-			limit = (size_t)(e ? strtoull(e, nullptr, 10) : 1024) << 20;
-			if (!limit)
-				limit = 1; /* "0": the pool is off */
+		const size_t need = (bytes + 4095) & ~(size_t)4095;
+		for (auto it = free_ranges.begin(); it != free_ranges.end(); ++it) {
+			if (it->second < need)
+				continue;
+			const size_t off = it->first, len = it->second;
+			free_ranges.erase(it);
+			if (len > need)
+				free_ranges[off + need] = len - need;
+			taken[off] = need;
+			return slab + off;
 		}
-		size_t best = free_list.size();
-		for (size_t i = 0; i < free_list.size(); ++i)
-			if (free_list[i].second >= bytes && (best == free_list.size() || free_list[i].second < free_list[best].second))
-				best = i;
-		if (best < free_list.size()) {
-			void *p = free_list[best].first;
-			free_list.erase(free_list.begin() + (ptrdiff_t)best);
-			return p;
-		}
-		const size_t cap = (bytes + (bytes >> 2) + 4095) & ~(size_t)4095;
-		if (total + cap > limit)
-			return nullptr;
-		void *p = alloc_fn(cap);
-		if (!p)
-			return nullptr;
-		owned[p] = cap;
-		total += cap;
-		return p;
+		return nullptr;
 	}
 	/* true if `p` was one of the pool's (and is now free again) */
 	bool put(void *p)
 	{
 		std::lock_guard<std::mutex> lck(m);
-		auto it = owned.find(p);
-		if (it == owned.end())
+		if (!slab || (char *)p < slab || (char *)p >= slab + slab_bytes)
 			return false;
-		free_list.emplace_back(p, it->second);
+		size_t off = (size_t)((char *)p - slab);
+		auto it = taken.find(off);
+		if (it == taken.end())
+			return false;
+		size_t len = it->second;
+		taken.erase(it);
+		auto nx = free_ranges.lower_bound(off);
+		if (nx != free_ranges.end() && nx->first == off + len) {
+			len += nx->second;
+			nx = free_ranges.erase(nx);
+		}
+		if (nx != free_ranges.begin()) {
+			auto pv = std::prev(nx);
+			if (pv->first + pv->second == off) {
+				off = pv->first;
+				len += pv->second;
+				free_ranges.erase(pv);
+			}
+		}
+		free_ranges[off] = len;
 		return true;
 	}
 	~KmcHostPool()
 	{
-		if (free_fn)
-			for (auto &e : owned)
-				free_fn(e.first);
+		if (slab && free_fn)
+			free_fn(slab);
 	}
 };
 
