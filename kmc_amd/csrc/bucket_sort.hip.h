@@ -417,7 +417,7 @@ struct GrpRank {
  * grows with the square of a bucket) and, since round 4, no longer sends its whole group back to the host either: k_bucket_rank puts it on a list and
  * k_giant_tiles sorts it on its own (below). Only a tile beyond GT_MAX_RECORDS still raises the group's flag (-> the host's LSD passes). */
 #ifndef GT_THREADS
-#define GT_THREADS 512
+#define GT_THREADS 1024 /* 16 waves; chunks of 8192 one-word records (4096 / 2048 of wider ones): fewer barrier-separated rounds per tile than 512 x 4 (skew leg 24.1 -> see DESIGN) */
 #endif
 #ifndef GT_MAX_RECORDS_LOG2
 #define GT_MAX_RECORDS_LOG2 20 /* one workgroup sorts up to a million records by itself (~1-2 ms); beyond that the group goes back to the host */
@@ -939,7 +939,7 @@ __global__ void __launch_bounds__(BrCfg<SIZE>::THREADS, BR_MIN_WAVES) k_bucket_r
  * level); round 3 sent the whole GROUP of bins back through LSD passes over every byte. Here ONE workgroup takes such a tile — CAP < records <=
  * GT_MAX_RECORDS — and sorts it by itself: stable 8-bit LSD passes between the tile's slice of the record array and its slice of the free array (the span
  * its output will go to), over the key bits that can differ inside the tile (the bits below the bucket bits + the bits in which its first and last bucket
- * number differ; an even number of passes, so the records end where they started), each pass = a histogram read + chunks of THREADS x 4 records ranked as
+ * number differ; an even number of passes, so the records end where they started), each pass = a histogram read + chunks of THREADS x 8 / 4 / 2 records (by record width) ranked as
  * k_onesweep ranks a tile (per-wave digit counts, match-any ballots), with the digit bases running in LDS instead of a look-back. Then it streams through
  * the sorted records once more — run tails, counts (a run may be as long as the tile), cutoffs, records straight to the span — and reports like a tile of
  * k_bucket_rank (status, chunk_src, LUT, tallies). Persistent workgroups take the listed tiles one by one; with nothing listed the kernel costs a launch.
@@ -948,7 +948,7 @@ template <int SIZE>
 __global__ void __launch_bounds__(GT_THREADS) k_giant_tiles(const GrpRank gr, DevParams P, u32 stride, u32 key_bits, u32 hbits, u32 lut_shards, u64 lut_stride, u32 lut_mask,
                                                               u32 *err /* the stream's error block: words 12 and 14-15 count the tiles and records taken here (statistics) */)
 {
-	constexpr int THREADS = GT_THREADS, ITEMS = 4, NW = THREADS / 64, CHUNK = THREADS * ITEMS;
+	constexpr int THREADS = GT_THREADS, ITEMS = SIZE == 1 ? 8 : (SIZE == 2 ? 4 : 2), NW = THREADS / 64, CHUNK = THREADS * ITEMS;
 	constexpr u32 NONE = 0xFFFFFFFFu;
 	static_assert(THREADS >= 256, "one digit per thread");
 	__shared__ u32 s_whist[NW * 256];
