@@ -39,13 +39,13 @@ def multi_equals_oracle(ctx, k, img, nk, packs, **kw):
 
 
 for k, kw in ((27, {"lut_prefix_len": 3}), (55, {"lut_prefix_len": 3, "cutoff_min": 1}), (27, {"output_type": 1}), (200, {"lut_prefix_len": 4}), (27, {"without_output": 1})):
-    (img, nk, packs, _), = capi.synth_bins(seed=7, genome_len=6000, n_reads=600, k=k, n_bins=1, n_threads=1, read_len=300 if k > 150 else 150)
+    (img, nk, packs, _), = capi.synth_bins(seed=7, genome_len=4000, n_reads=250, k=k, n_bins=1, n_threads=1, read_len=300 if k > 150 else 150)
     multi_equals_oracle(c2, k, img, nk, packs, **kw)
     multi_equals_oracle(c2, k, img, nk, None, **kw)  # the library finds the pack boundaries itself
 for n_sk, mx in ((1, 0), (1, 5), (2, 0), (3, 1), (40, 10)):
     img, nk, packs = binsynth.random_bin(rng, 27, n_sk, max_extra=mx)
     multi_equals_oracle(c2, 27, img, nk, packs, lut_prefix_len=3, cutoff_min=1)
-(img, nk, packs, _), = capi.synth_bins(seed=5, genome_len=300, n_reads=1500, k=27, n_bins=1, err=0.0, n_threads=1)
+(img, nk, packs, _), = capi.synth_bins(seed=5, genome_len=300, n_reads=400, k=27, n_bins=1, err=0.0, n_threads=1)
 multi_equals_oracle(c2, 27, img, nk, packs)
 out, lut, st = c2.process_bin(capi.make_params(27), np.zeros(0, np.uint8), 0, None, multi=True)
 assert out.size == 0 and not lut.any() and not st.any()
@@ -59,7 +59,7 @@ for bad, code in (({"n_rec": nk + 1}, -4), ({"n_rec": nk, "out_capacity": 8}, -5
 c2.close()
 # the same over a context that names one device three times: the exchange goes through copies instead of RCCL
 c3 = capi.Context((1, 1, 1))
-(img, nk, packs, _), = capi.synth_bins(seed=9, genome_len=6000, n_reads=600, k=27, n_bins=1, n_threads=1)
+(img, nk, packs, _), = capi.synth_bins(seed=9, genome_len=4000, n_reads=250, k=27, n_bins=1, n_threads=1)
 multi_equals_oracle(c3, 27, img, nk, packs, lut_prefix_len=3)
 c3.close()
 print("two devices ok")

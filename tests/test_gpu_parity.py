@@ -611,7 +611,7 @@ def test_rank_path_takes_repeats_in_chunks_giant_buckets_on_their_own_and_hands_
     data.) Here: every k-mer ~1600 times — buckets longer than the room at the end of a window, tiles longer than the capacity, taken in chunks of whole
     buckets; then one k-mer more often than a tile holds records (8000 times; k = 27, 55, 127) — the tile is sorted by k_giant_tiles, nothing comes back; then
     one k-mer more than a million times — the group is run again with LSD passes."""
-    small = capi.backend_kind() != 0  # the emulated host library: the paths, not the scale (GT_MAX_RECORDS is 4096 there)
+    small = capi.backend_kind() != 0  # the emulated host library: the paths, not the scale (GT_MAX_RECORDS is 2048 there)
     p = hp(27)
     bins = capi.synth_bins(seed=3, genome_len=6000 if not small else 2000, n_reads=80_000 if not small else 1000, k=27, n_bins=4, err=0.0)
     t0 = ctx.local_sort_totals()
@@ -634,7 +634,7 @@ def test_rank_path_takes_repeats_in_chunks_giant_buckets_on_their_own_and_hands_
     t2, g1 = ctx.local_sort_totals(), ctx.path_counters()
     assert t2["hybrid_groups"] > t1["hybrid_groups"] and t2["redo_groups"] == t1["redo_groups"], (t1, t2)
     assert g1["giant_tiles"] >= g0["giant_tiles"] + 4 and g1["giant_records"] > g0["giant_records"], (g0, g1)
-    bins = capi.synth_bins(seed=5, genome_len=160, n_reads=1_300_000 if not small else 6000, k=27, n_bins=2, err=0.0)
+    bins = capi.synth_bins(seed=5, genome_len=160, n_reads=1_300_000 if not small else 2600, k=27, n_bins=2, err=0.0)
     got, err = _run_batch(ctx, p, bins, 1)
     assert err is None, err
     for i, (img, nrec, packs, _) in enumerate(bins):

@@ -185,29 +185,27 @@ def check(k, bins, **kw):
 # forward strand only; without output; counters that clamp and a cutoff_max
 for k, nb, kw in ((27, 5, dict(lut_prefix_len=3)), (32, 3, dict(lut_prefix_len=4)), (27, 4, dict(lut_prefix_len=0, output_type=1)), (25, 9, dict(lut_prefix_len=1, cutoff_min=1)),
                   (21, 4, dict(lut_prefix_len=1, both_strands=0)), (27, 4, dict(lut_prefix_len=3, without_output=1)), (27, 3, dict(lut_prefix_len=3, cutoff_max=20, counter_max=7))):
-    h, r, c = check(k, capi.synth_bins(seed=7, genome_len=3000, n_reads=500, k=k, n_bins=nb, n_threads=1), **kw)
+    h, r, c = check(k, capi.synth_bins(seed=7, genome_len=2500, n_reads=300, k=k, n_bins=nb, n_threads=1), **kw)
     assert h >= 1 and r == 0 and c["rank_count"] >= 1 and c["rank_compact"] == c["bucket_count"] == 0, (k, h, r, c)
 # records that may outgrow a tile's span (k = 32 without a LUT prefix: 8 suffix bytes + a 4-byte counter): ranked in place, then k_compact
-h, r, c = check(32, capi.synth_bins(seed=7, genome_len=3000, n_reads=500, k=32, n_bins=3, n_threads=1), lut_prefix_len=0, cutoff_max=100000, counter_max=70000)
+h, r, c = check(32, capi.synth_bins(seed=7, genome_len=2500, n_reads=300, k=32, n_bins=3, n_threads=1), lut_prefix_len=0, cutoff_max=100000, counter_max=70000)
 assert c["rank_compact"] >= 1 and c["rank_count"] == 0, c
 # wider records: two words (A/B pairs, rem <= 80 bits; k = 64: six HBM passes instead of sixteen), KFF, three and more words (whole records compared)
 for k, nb, kw in ((55, 4, dict(lut_prefix_len=3)), (40, 3, dict(lut_prefix_len=4, cutoff_min=1)), (64, 1, dict(lut_prefix_len=4)), (55, 4, dict(lut_prefix_len=0, output_type=1)),
                   (127, 4, dict(lut_prefix_len=3)), (70, 3, dict(lut_prefix_len=2, both_strands=0)), (200, 2, dict(lut_prefix_len=4))):
-    h, r, c = check(k, capi.synth_bins(seed=7, genome_len=3000, n_reads=400, k=k, n_bins=nb, n_threads=1, read_len=max(150, k + 40)), **kw)
+    h, r, c = check(k, capi.synth_bins(seed=7, genome_len=2500, n_reads=250, k=k, n_bins=nb, n_threads=1, read_len=max(150, k + 40)), **kw)
     assert h >= 1 and r == 0 and c["rank_count"] >= 1 and c["bucket_count"] == 0, (k, h, r, c)
 # every k-mer a few hundred times: buckets longer than the room at the end of a window, tiles longer than the capacity -> taken in chunks, nothing comes back
 for k, glen, err in ((27, 2000, 0.0), (27, 600, 0.002), (55, 1500, 0.0)):
-    h, r, c = check(k, capi.synth_bins(seed=3, genome_len=glen, n_reads=1000, k=k, n_bins=4, err=err, n_threads=1), lut_prefix_len=3)
+    h, r, c = check(k, capi.synth_bins(seed=3, genome_len=glen, n_reads=700, k=k, n_bins=4, err=err, n_threads=1), lut_prefix_len=3)
     assert h >= 1 and r == 0, (k, glen, h, r)
-# one k-mer more often than a tile holds records (also with read errors around it; KFF; three-word records): the tile goes to k_giant_tiles, nothing comes back
-for k, kw, err in ((27, dict(lut_prefix_len=3), 0.0), (27, dict(lut_prefix_len=0, output_type=1), 0.0), (55, dict(lut_prefix_len=3), 0.0), (27, dict(lut_prefix_len=3, cutoff_min=1), 0.01),
-                   (70, dict(lut_prefix_len=2), 0.0)):
+# one k-mer more often than a tile holds records (also with read errors around it; two- and three-word records): the tile goes to k_giant_tiles, nothing comes back
+for k, kw, err in ((27, dict(lut_prefix_len=3, cutoff_min=1), 0.01), (55, dict(lut_prefix_len=3), 0.0), (70, dict(lut_prefix_len=0, output_type=1), 0.0)):
     h, r, c = check(k, capi.synth_bins(seed=5, genome_len=300, n_reads=1500, k=k, n_bins=2, err=err, n_threads=1), **kw)
     assert h >= 1 and r == 0 and c["giant_tiles"] >= 1, (k, h, r, c)
-# ... and more often than k_giant_tiles takes (GT_MAX_RECORDS: 4096 in this build): the group comes back for LSD passes
-for k in (27, 55):
-    h, r, c = check(k, capi.synth_bins(seed=5, genome_len=160, n_reads=6000, k=k, n_bins=2, err=0.0, n_threads=1), lut_prefix_len=3)
-    assert r >= 1, (k, h, r)
+# ... and more often than k_giant_tiles takes (GT_MAX_RECORDS: 2048 in this build): the group comes back for LSD passes
+h, r, c = check(27, capi.synth_bins(seed=5, genome_len=160, n_reads=2600, k=27, n_bins=2, err=0.0, n_threads=1), lut_prefix_len=3)
+assert r >= 1, (h, r)
 print("RANK-OK")
 '''
 
