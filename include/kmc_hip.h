@@ -226,9 +226,10 @@ int kmc_hip_scatter_totals(kmc_hip_ctx *ctx, int dev, int reset, uint64_t *n_lau
 int kmc_hip_local_sort_totals(kmc_hip_ctx *ctx, int dev, int reset, uint64_t *n_launches, double *total_ms, uint64_t *total_records,
                               uint64_t *n_hybrid_groups, uint64_t *n_redo_groups);
 /* Which sort stage 2 runs (process-wide; overrides $KMC_HIP_HYBRID; tests and tuning): 0 = 8-bit LSD passes over every key byte + k_compact (rounds 1-2);
- * 1 = default: groups of bins with records of 2+ words (k >= 33) take the hybrid path — LSD passes over the top key bytes only, then k_bucket_count on
- * bucket-aligned tiles in LDS —, one-word records the LSD path; 2 = hybrid for every record width, and the LDS sort for sort-only calls; -h = `h` top
- * bytes forced. Also clears the hybrid / redo group counters of kmc_hip_local_sort_totals. Returns the mode that was in force. */
+ * 1 = default: LSD passes over the top key bytes only, then every bucket-aligned tile ranked and counted inside LDS by k_bucket_rank (round 4: every record
+ * width; $KMC_HIP_RANK=0 / $KMC_HIP_RANK_FUSE=0 give round 3's k_bucket_count for k >= 33 and rank-in-place + k_compact for k <= 32); 2 = k_bucket_count for every
+ * record width, and the LDS sort for sort-only calls; -h = `h` top bytes forced. Also clears the group counters of kmc_hip_local_sort_totals and
+ * kmc_hip_path_counters. Returns the mode that was in force. */
 int kmc_hip_set_hybrid(int mode);
 /* Groups of bins (a bin on its own is a group of one) by the path their sort + compaction took, process-wide since the last kmc_hip_set_hybrid: [0] top bytes
  * through HBM, tiles ranked AND counted inside LDS (k_bucket_rank fused: the default since round 4, every record width); [1] ranked in place, then k_compact
