@@ -640,18 +640,31 @@ __global__ void __launch_bounds__(256) k_parse_packs(const GrpParse gp, u32 k, u
 #define EXP_CHUNK_BYTES 16384 /* the 1.65 G k-mer bin: 4 KB slices 9.15 ms, 8 KB 7.85, 16 KB 7.15 (fewer scans and look-backs per byte) */
 #endif
 #ifndef EXP_KWIN_KMERS
-#define EXP_KWIN_KMERS 8192
+#define EXP_KWIN_KMERS 4096 /* round 4: with the two super-k-mer lists in one word the workgroup is at 37 KB of LDS at k = 27 — four per CU instead of three at 49.5 KB */
 #endif
 constexpr u32 EXP_FUSE_MAX_PASS = 16; /* the sort's histograms are fused into the expansion up to this many passes (k <= 64) */
 constexpr int EXP_CHUNK = EXP_CHUNK_BYTES, EXP_TAIL = 160, EXP_KWIN = EXP_KWIN_KMERS, EXP_BLOCK = EXP_BLOCK_THREADS;
+/* x >> s for a shift count that is the same in every lane (0..63). The plain expression is a 64-bit shift instruction per lane (the compiler cannot know the
+ * count is uniform, nor that a funnel shift of two dwords by 0..31 bits is v_alignbit_b32); here: one funnel shift, one 32-bit shift, two selects on a scalar
+ * condition, no branch */
+__device__ __forceinline__ u64 shr64_uniform(u64 x, u32 s)
+{
+	const u32 hi = (u32)(x >> 32), lo = (u32)x;
+	const u32 t = hi >> (s & 31), al = __builtin_amdgcn_alignbit(hi, lo, s & 31);
+	const u32 m = 0u - (u32)(s < 32); /* as a mask, not as a condition: the compiler turns a select on a uniform condition into a branch */
+	return ((u64)(t & m) << 32) | ((al & m) | (t & ~m));
+}
 /* most super-k-mers that can START inside one slice: a record is 1 + ceil((k+e)/4) >= 1 + ceil(k/4) bytes long. The two LDS lists are
  * sized by this (k=27: 1025 entries instead of a worst case of 4096 -> 38 KB instead of 57 KB per workgroup: 4 workgroups per CU, not 2) */
 __host__ __device__ constexpr u32 exp_max_sk(u32 k) { return (u32)EXP_CHUNK / (1 + ((k + 3) >> 2)) + 2; }
 
 static_assert(EXP_CHUNK / 32 <= EXP_BLOCK && EXP_CHUNK <= 65536, "one bitmap word per thread; 16-bit positions inside a slice");
 static_assert(EXP_BLOCK >= 256, "the last workgroup scans 256 digits per pass, one per thread");
+#ifndef EXP_FULL_OCCUPANCY_SIZE
+#define EXP_FULL_OCCUPANCY_SIZE 2 /* record widths whose k_expand is compiled for 8 waves per SIMD (<= 64 VGPRs, <= 96 SGPRs): four 512-thread workgroups per CU fit their LDS */
+#endif
 template <int SIZE, bool FUSE_HIST>
-__global__ void __launch_bounds__(EXP_BLOCK) k_expand(const GrpExpand ge, u32 k, u32 both_strands, u32 n_pass, u64 *__restrict__ ghist, u32 *ticket_ctr,
+__global__ void __launch_bounds__(EXP_BLOCK, (SIZE <= EXP_FULL_OCCUPANCY_SIZE ? 8 : 4)) k_expand(const GrpExpand ge, u32 k, u32 both_strands, u32 n_pass, u64 *__restrict__ ghist, u32 *ticket_ctr,
                                                  u32 *err, u64 *__restrict__ digit_base, u32 *done_ctr, u32 pass_lo)
 {
 	/* n_pass histograms are fused: those of key bytes pass_lo .. pass_lo + n_pass - 1 (the hybrid sort of bucket_sort.hip.h only sends the top
@@ -661,15 +674,16 @@ __global__ void __launch_bounds__(EXP_BLOCK) k_expand(const GrpExpand ge, u32 k,
 	 * of passes into bin-major order (kmc_hip.hip run_group_device_t); 0 for a bin on its own. */
 	const u32 n_chunks = ge.chunk_prefix[ge.g];
 	const u32 MAX_SK = exp_max_sk(k);
+	const u64 kmask = 2 * k >= 64 ? ~0ull : (1ull << (2 * k)) - 1; /* one-word records: the k-mer's bits */
 	KMC_DYN_LDS(unsigned char, s_raw);
 	u64 *s_base = reinterpret_cast<u64 *>(s_raw);                             /* [2] (16 bytes keeps s_b 16-B aligned) */
 	uint8_t *s_b = s_raw + 16;                                                /* [EXP_CHUNK + EXP_TAIL] */
-	u32 *s_skoff = reinterpret_cast<u32 *>(s_b + EXP_CHUNK + EXP_TAIL);       /* [MAX_SK + 1] first k-mer of each super-k-mer */
-	u32 *s_tmp = s_skoff + MAX_SK + 1;                                        /* [24] scan scratch */
+	u32 *s_sk = reinterpret_cast<u32 *>(s_b + EXP_CHUNK + EXP_TAIL);          /* [MAX_SK + 1] per super-k-mer: byte position << 16 | first k-mer (both < 2^16: a slice
+	                                                                           * is <= 65536 bytes, and a record of L bytes holds fewer than 4 L k-mers) */
+	u32 *s_tmp = s_sk + MAX_SK + 1;                                           /* [24] scan scratch */
 	u32 *s_ticket = s_tmp + 24;                                                /* [3] */
 	u32 *s_h = s_ticket + 3;                                                  /* [n_pass * 256] when FUSE_HIST */
-	unsigned short *s_skpos = reinterpret_cast<unsigned short *>(s_h + (FUSE_HIST ? n_pass * 256 : 0)); /* [MAX_SK] byte position */
-	unsigned short *s_kidx = s_skpos + ((MAX_SK + 1) & ~1u);                  /* [EXP_KWIN] k-mer (window-relative) -> super-k-mer */
+	unsigned short *s_kidx = reinterpret_cast<unsigned short *>(s_h + (FUSE_HIST ? n_pass * 256 : 0)); /* [EXP_KWIN] k-mer (window-relative) -> super-k-mer */
 
 	if (FUSE_HIST) {
 		for (u32 i = threadIdx.x; i < n_pass * 256; i += EXP_BLOCK)
@@ -725,8 +739,7 @@ __global__ void __launch_bounds__(EXP_BLOCK) k_expand(const GrpExpand ge, u32 k,
 				const u32 bpos = (u32)__ffs((int)bb) - 1;
 				bb &= bb - 1;
 				if (i < MAX_SK) {
-					s_skpos[i] = (unsigned short)(tid * 32 + bpos);
-					s_skoff[i] = ko;
+					s_sk[i] = ((tid * 32 + bpos) << 16) | ko;
 				}
 				ko += (u32)s_b[tid * 32 + bpos] + 1;
 				++i;
@@ -741,20 +754,26 @@ __global__ void __launch_bounds__(EXP_BLOCK) k_expand(const GrpExpand ge, u32 k,
 					atomicOr(err, KERR_NREC); /* CBinDesc n_rec must agree with the byte stream */
 			}
 		}
-		if (tid == 0)
-			s_skoff[tot_sk < MAX_SK ? tot_sk : MAX_SK] = tot_k; /* sentinel */
+		if (tid == 0) {
+			s_sk[tot_sk < MAX_SK ? tot_sk : MAX_SK] = tot_k & 0xFFFFu; /* sentinel */
+			if (tot_k > 0xFFFFu)
+				atomicOr(err, KERR_CORRUPT); /* more k-mers than the bytes of a slice can hold: length bytes that are not a record chain's */
+		}
 		__syncthreads();
 		const u64 base = *s_base;
-		const u32 n_sk = tot_sk < MAX_SK ? tot_sk : MAX_SK;
-		/* k-mers of the slice in windows of EXP_KWIN (one window unless the super-k-mers are unusually long) */
+		const u32 n_sk = tot_k > 0xFFFFu ? 0u : (tot_sk < MAX_SK ? tot_sk : MAX_SK);
+		/* k-mers of the slice in windows of EXP_KWIN (two to four at sequencing depth) */
 		for (u32 w0 = 0; n_sk && w0 < tot_k; w0 += EXP_KWIN) {
 			const u32 wn = (tot_k - w0) < (u32)EXP_KWIN ? (tot_k - w0) : (u32)EXP_KWIN;
+#if defined(EXP_CUT) && EXP_CUT == 2 /* tuning builds only: without the map and the k-mer loop */
+			break;
+#endif
 			/* k-mer -> super-k-mer map: mark each super-k-mer's first k-mer, then a max-scan in k-mer order */
 			for (u32 r = tid; r < wn; r += EXP_BLOCK)
 				s_kidx[r] = 0;
 			__syncthreads();
 			for (u32 i = tid; i < n_sk; i += EXP_BLOCK) {
-				const u32 o = s_skoff[i], o1 = s_skoff[i + 1]; /* [o, o1) = this super-k-mer's k-mers; sentinel at n_sk */
+				const u32 o = s_sk[i] & 0xFFFFu, o1 = s_sk[i + 1] & 0xFFFFu; /* [o, o1) = this super-k-mer's k-mers; sentinel at n_sk */
 				if (o >= w0 && o < w0 + wn)
 					s_kidx[o - w0] = (unsigned short)i;
 				else if (o < w0 && o1 > w0)
@@ -786,23 +805,29 @@ __global__ void __launch_bounds__(EXP_BLOCK) k_expand(const GrpExpand ge, u32 k,
 			}
 			__syncthreads();
 			for (u32 r = tid; r < wn; r += EXP_BLOCK) {
+#if defined(EXP_CUT) && EXP_CUT == 1 /* tuning builds only: everything but the k-mer loop (output garbage) */
+				break;
+#endif
 				const u32 j = w0 + r;
 				const u32 si = s_kidx[r];
 				const u64 gj = base + j;
 				if (gj < n_rec) {
 					u64 v[SIZE];
-					const u32 off = j - s_skoff[si];
+					const u32 sk = s_sk[si];
+					const u32 off = j - (sk & 0xFFFFu);
 					if constexpr (SIZE == 1) {
-						/* k <= 32: the window is <= 70 bits: three aligned LDS dwords, byte-swapped into a bit stream */
-						const u32 a = 16u + (u32)s_skpos[si] + 1u + (off >> 2); /* byte offset inside s_raw (s_b = s_raw + 16) */
-						const u32 *wp = reinterpret_cast<const u32 *>(s_raw + (a & ~3u));
-						const u32 b0 = __builtin_bswap32(wp[0]), b1 = __builtin_bswap32(wp[1]), b2 = __builtin_bswap32(wp[2]);
-						const u32 skip = 8u * (a & 3u) + 2u * (off & 3u); /* <= 30 */
-						const u64 top = ((u64)b0 << 32) | b1;
-						const u64 x = skip ? ((top << skip) | ((u64)b2 >> (32 - skip))) : top;
-						u64 f = x >> (64 - 2 * k);
+						/* k <= 32: the window of 2k bits ends in some aligned LDS dword; that dword and the two before it, byte-swapped, are a big-endian bit
+						 * stream and each half of the k-mer is ONE funnel shift (v_alignbit) of two neighbours — no 64-bit shifts, no branch on "does the window
+						 * start on a dword" (round 4; before: three dwords from the window's FIRST dword, shifted left as a 64-bit pair under a per-lane branch) */
+						/* the window's LAST bit, counted from s_raw (s_b = s_raw + 16; a record's symbols start one byte behind its position; 4 symbols a byte) */
+						const u32 last = 8u * (17u + (sk >> 16)) + 2u * off + 2 * k - 1;
+						const u32 *we = reinterpret_cast<const u32 *>(s_raw + ((last >> 3) & ~3u)); /* the dword that holds it; we[-2] >= s_raw */
+						const u32 rs = ~last & 31u;                                                 /* bits behind the window inside that dword */
+						const u32 e0 = __builtin_bswap32(we[-2]), e1 = __builtin_bswap32(we[-1]), e2 = __builtin_bswap32(we[0]);
+						const u32 lo = __builtin_amdgcn_alignbit(e1, e2, rs), hi = __builtin_amdgcn_alignbit(e0, e1, rs);
+						u64 f = (((u64)hi << 32) | lo) & kmask;
 						if (both_strands) {
-							u64 rc = ~kmc_rev2(f) >> (64 - 2 * k); /* complement + reverse, realigned to the low 2k bits */
+							const u64 rc = shr64_uniform(~kmc_rev2(f), 64 - 2 * k); /* complement + reverse, realigned to the low 2k bits */
 							f = rc < f ? rc : f;
 						}
 						v[0] = f;
@@ -813,11 +838,9 @@ __global__ void __launch_bounds__(EXP_BLOCK) k_expand(const GrpExpand ge, u32 k,
 						 * the address of the last dword and the shift. (A per-lane choice between two register indices — the first version — is turned into a
 						 * dynamic index by the compiler and expanded into nine-way compare/select chains.) */
 						constexpr int M = 2 * SIZE + 1;
-						const u32 a = 16u + (u32)s_skpos[si] + 1u + (off >> 2);   /* byte offset inside s_raw of the window's first byte */
-						const u32 endbit = 8u * (a & 3u) + 2u * (off & 3u) + 2 * k; /* first bit behind the window, counted from the dword that holds its first byte */
-						const u32 jl = (endbit - 1) >> 5;                            /* the dword that holds the window's last bit */
-						const u32 *we = reinterpret_cast<const u32 *>(s_raw + (a & ~3u)) + jl;
-						const u32 rs = 32 * (jl + 1) - endbit;                       /* bits behind the window inside that dword: 0..31 */
+						const u32 last = 8u * (17u + (sk >> 16)) + 2u * off + 2 * k - 1;        /* the window's last bit, counted from s_raw (see SIZE == 1) */
+						const u32 *we = reinterpret_cast<const u32 *>(s_raw + ((last >> 3) & ~3u)); /* the dword that holds it */
+						const u32 rs = ~last & 31u;                                                 /* bits behind the window inside that dword: 0..31 */
 						u32 E[M]; /* E[M-1] = the window's last dword; dwords in front of the window (up to three, still inside s_raw, which starts 16 bytes before
 						           * the slice) land in bits that kmc_mask_low clears */
 #pragma unroll
@@ -849,8 +872,23 @@ __global__ void __launch_bounds__(EXP_BLOCK) k_expand(const GrpExpand ge, u32 k,
 					store_rec<SIZE>(out + gj * SIZE, v);
 #ifndef EXP_NO_HIST /* tuning builds only (-DEXP_NO_HIST): what do the fused histograms cost? (the sort is garbage then) */
 					if (FUSE_HIST) {
-						for (u32 b = 0; b < n_pass; ++b)
-							atomicAdd(&s_h[b * 256 + kmc_get_byte<SIZE>(v, pass_lo + b)], 1u);
+						if constexpr (SIZE == 1) { /* static byte positions below one uniform shift: a bit-field extract + an add per digit */
+							const u64 t = shr64_uniform(v[0], 8 * pass_lo);
+							const u32 tl = (u32)t, th = (u32)(t >> 32);
+							if (n_pass == 4) { /* the hybrid sort's four top bytes (k = 13..32): no branch per digit */
+#pragma unroll
+								for (int b = 0; b < 4; ++b)
+									atomicAdd(&s_h[b * 256 + ((tl >> (8 * b)) & 0xFFu)], 1u);
+							} else {
+#pragma unroll
+								for (int b = 0; b < 8; ++b)
+									if ((u32)b < n_pass)
+										atomicAdd(&s_h[b * 256 + (((b < 4 ? tl : th) >> (8 * (b & 3))) & 0xFFu)], 1u);
+							}
+						} else {
+							for (u32 b = 0; b < n_pass; ++b)
+								atomicAdd(&s_h[b * 256 + kmc_get_byte<SIZE>(v, pass_lo + b)], 1u);
+						}
 					}
 #endif
 				}
@@ -889,8 +927,7 @@ __global__ void __launch_bounds__(EXP_BLOCK) k_expand(const GrpExpand ge, u32 k,
 }
 template <bool FUSE_HIST> constexpr size_t exp_lds_bytes(u32 n_pass, u32 k)
 {
-	return 16 + (size_t)EXP_CHUNK + EXP_TAIL + ((size_t)exp_max_sk(k) + 1 + 24 + 3) * 4 + (FUSE_HIST ? (size_t)n_pass * 1024 : 0) +
-	       (((size_t)exp_max_sk(k) + 1) & ~(size_t)1) * 2 + EXP_KWIN * 2 + 16;
+	return 16 + (size_t)EXP_CHUNK + EXP_TAIL + ((size_t)exp_max_sk(k) + 1 + 24 + 3) * 4 + (FUSE_HIST ? (size_t)n_pass * 1024 : 0) + EXP_KWIN * 2 + 16;
 }
 
 /* ------------------------------------------------------------------------------------------------ histogram

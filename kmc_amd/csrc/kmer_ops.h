@@ -24,8 +24,12 @@ typedef unsigned int kmc_u32;
 KMC_HD kmc_u64 kmc_rev2(kmc_u64 x)
 {
 #if defined(__HIP_DEVICE_COMPILE__)
-	x = __brevll(x); /* v_bfrev_b32 x2: reverses single bits ... */
-	return ((x >> 1) & 0x5555555555555555ull) | ((x & 0x5555555555555555ull) << 1); /* ... swap back inside each pair */
+	/* v_bfrev_b32 on each half reverses single bits, then the two bits of every symbol are swapped back — per 32-bit half: pairs never straddle the halves,
+	 * and written on 64 bits the two one-bit shifts become 64-bit shift instructions */
+	kmc_u32 h = __brev((kmc_u32)x), l = __brev((kmc_u32)(x >> 32));
+	h = ((h >> 1) & 0x55555555u) | ((h & 0x55555555u) << 1);
+	l = ((l >> 1) & 0x55555555u) | ((l & 0x55555555u) << 1);
+	return ((kmc_u64)h << 32) | l;
 #else
 	x = ((x >> 2) & 0x3333333333333333ull) | ((x & 0x3333333333333333ull) << 2);
 	x = ((x >> 4) & 0x0F0F0F0F0F0F0F0Full) | ((x & 0x0F0F0F0F0F0F0F0Full) << 4);

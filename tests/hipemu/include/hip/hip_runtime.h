@@ -191,6 +191,7 @@ template <typename T> static inline T __shfl(T v, int src)
 	hipemu::wave_exchange(hipemu::to_bits(v), all);
 	return hipemu::from_bits<T>(all[src & 63]);
 }
+static inline unsigned __builtin_amdgcn_alignbit(unsigned hi, unsigned lo, unsigned s) { return (unsigned)((((unsigned long long)hi << 32) | lo) >> (s & 31)); } /* v_alignbit_b32 */
 static inline int __builtin_amdgcn_readfirstlane(int v) { return __shfl(v, 0); } /* every lane is active where the kernels use it */
 static inline unsigned long long __builtin_amdgcn_uicmp(unsigned a, unsigned b, int cond)
 {
