@@ -664,7 +664,7 @@ static_assert(EXP_BLOCK >= 256, "the last workgroup scans 256 digits per pass, o
 #define EXP_FULL_OCCUPANCY_SIZE 2 /* record widths whose k_expand is compiled for 8 waves per SIMD (<= 64 VGPRs, <= 96 SGPRs): four 512-thread workgroups per CU fit their LDS */
 #endif
 template <int SIZE, bool FUSE_HIST>
-__global__ void __launch_bounds__(EXP_BLOCK, (SIZE <= EXP_FULL_OCCUPANCY_SIZE ? 8 : 4)) k_expand(const GrpExpand ge, u32 k, u32 both_strands, u32 n_pass, u64 *__restrict__ ghist, u32 *ticket_ctr,
+__global__ void __launch_bounds__(EXP_BLOCK, (SIZE <= EXP_FULL_OCCUPANCY_SIZE ? 8 : (SIZE <= 4 ? 6 : 4))) k_expand(const GrpExpand ge, u32 k, u32 both_strands, u32 n_pass, u64 *__restrict__ ghist, u32 *ticket_ctr,
                                                  u32 *err, u64 *__restrict__ digit_base, u32 *done_ctr, u32 pass_lo)
 {
 	/* n_pass histograms are fused: those of key bytes pass_lo .. pass_lo + n_pass - 1 (the hybrid sort of bucket_sort.hip.h only sends the top
@@ -689,6 +689,8 @@ __global__ void __launch_bounds__(EXP_BLOCK, (SIZE <= EXP_FULL_OCCUPANCY_SIZE ? 
 		for (u32 i = threadIdx.x; i < n_pass * 256; i += EXP_BLOCK)
 			s_h[i] = 0;
 	}
+	/* (Round 4 tried to draw the NEXT slice's ticket while the current slice is worked on, to hide the atomic's round trip: 0.63 -> 0.93 ms. A ticket drawn a slice
+	 * early is a tile of the look-back that publishes a slice late, and every slice behind it polls for that long.) */
 	while (true) {
 		__syncthreads();
 		if (threadIdx.x == 0)
@@ -730,9 +732,10 @@ __global__ void __launch_bounds__(EXP_BLOCK, (SIZE <= EXP_FULL_OCCUPANCY_SIZE ? 
 				my_k += (u32)s_b[tid * 32 + bpos] + 1;
 			}
 		}
-		u32 tot_sk, tot_k;
-		const u32 off_sk = block_excl_sum<EXP_BLOCK / 64, u32>(my_sk, s_tmp, tot_sk);
-		const u32 off_k = block_excl_sum<EXP_BLOCK / 64, u32>(my_k, s_tmp, tot_k);
+		/* one scan for both counts: super-k-mers in the low 14 bits (a slice holds <= 8194 record starts, at k = 1), k-mers above (< 2^16 in a record chain, see s_sk) */
+		u32 tot_packed;
+		const u32 off_packed = block_excl_sum<EXP_BLOCK / 64, u32>(my_sk | (my_k << 14), s_tmp, tot_packed);
+		const u32 tot_sk = tot_packed & 0x3FFFu, tot_k = tot_packed >> 14, off_sk = off_packed & 0x3FFFu, off_k = off_packed >> 14;
 		{
 			u32 bb = bits, i = off_sk, ko = off_k;
 			while (bb) {
@@ -746,6 +749,8 @@ __global__ void __launch_bounds__(EXP_BLOCK, (SIZE <= EXP_FULL_OCCUPANCY_SIZE ? 
 			}
 		}
 		/* slice offset among k-mers: decoupled look-back, one 64-bit word per slice, 64 slices per round trip */
+		/* (Round 4 tried to publish the aggregate here and walk back only after the first window's map was built: 0.63 -> 0.82 ms. An inclusive prefix that comes out
+		 * late makes every slice behind it walk back through hundreds of aggregates — the look-back is short only because prefixes appear at once.) */
 		if (wave == 0) {
 			const u64 excl = lookback64(status, c, (u64)tot_k, lane, err, KERR_WATCHDOG | KERR_AT_EXPAND);
 			if (lane == 0) {
@@ -760,14 +765,14 @@ __global__ void __launch_bounds__(EXP_BLOCK, (SIZE <= EXP_FULL_OCCUPANCY_SIZE ? 
 				atomicOr(err, KERR_CORRUPT); /* more k-mers than the bytes of a slice can hold: length bytes that are not a record chain's */
 		}
 		__syncthreads();
-		const u64 base = *s_base;
 		const u32 n_sk = tot_k > 0xFFFFu ? 0u : (tot_sk < MAX_SK ? tot_sk : MAX_SK);
+		const u64 base = *s_base;
+		/* what the k-mer loop needs of the 64-bit record numbers, as scalars: the first record's address and how many k-mers of this slice are inside the bin */
+		u64 *const out_base = out + base * SIZE;
+		const u32 j_limit = base >= n_rec ? 0u : (n_rec - base > 0xFFFFFFFFull ? 0xFFFFFFFFu : (u32)(n_rec - base));
 		/* k-mers of the slice in windows of EXP_KWIN (two to four at sequencing depth) */
 		for (u32 w0 = 0; n_sk && w0 < tot_k; w0 += EXP_KWIN) {
 			const u32 wn = (tot_k - w0) < (u32)EXP_KWIN ? (tot_k - w0) : (u32)EXP_KWIN;
-#if defined(EXP_CUT) && EXP_CUT == 2 /* tuning builds only: without the map and the k-mer loop */
-			break;
-#endif
 			/* k-mer -> super-k-mer map: mark each super-k-mer's first k-mer, then a max-scan in k-mer order */
 			for (u32 r = tid; r < wn; r += EXP_BLOCK)
 				s_kidx[r] = 0;
@@ -810,8 +815,7 @@ __global__ void __launch_bounds__(EXP_BLOCK, (SIZE <= EXP_FULL_OCCUPANCY_SIZE ? 
 #endif
 				const u32 j = w0 + r;
 				const u32 si = s_kidx[r];
-				const u64 gj = base + j;
-				if (gj < n_rec) {
+				if (j < j_limit) {
 					u64 v[SIZE];
 					const u32 sk = s_sk[si];
 					const u32 off = j - (sk & 0xFFFFu);
@@ -869,7 +873,7 @@ __global__ void __launch_bounds__(EXP_BLOCK, (SIZE <= EXP_FULL_OCCUPANCY_SIZE ? 
 					for (int w = 0; w < SIZE; ++w)
 						if (((2 * k) >> 6) == (u32)w)
 							v[w] |= tag; /* already shifted to its place inside the word that holds bit 2k (k = 32 SIZE: no spare bits, tag 0) */
-					store_rec<SIZE>(out + gj * SIZE, v);
+					store_rec<SIZE>(out_base + (size_t)j * SIZE, v);
 #ifndef EXP_NO_HIST /* tuning builds only (-DEXP_NO_HIST): what do the fused histograms cost? (the sort is garbage then) */
 					if (FUSE_HIST) {
 						if constexpr (SIZE == 1) { /* static byte positions below one uniform shift: a bit-field extract + an add per digit */

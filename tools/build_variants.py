@@ -48,8 +48,7 @@ VARIANTS = {
     "exp8k": ["-DEXP_CHUNK_BYTES=8192"],  # k_expand occupancy: 27 KB of LDS per workgroup (4 per CU) instead of 49.5 (3)
     "exp8kw4": ["-DEXP_CHUNK_BYTES=8192", "-DEXP_KWIN_KMERS=4096"],
     "exp16kw4": ["-DEXP_KWIN_KMERS=4096"],
-    "expcut1": ["-DEXP_CUT=1"],  # k_expand without its k-mer loop, expcut2: without the k-mer -> super-k-mer map too (phase costs; output garbage)
-    "expcut2": ["-DEXP_CUT=2"],
+    "expcut1": ["-DEXP_CUT=1"],  # k_expand without its k-mer loop (phase costs; output garbage)
     "nohist": ["-DEXP_NO_HIST"],  # expand without the fused histograms (sort output is garbage): what do the LDS atomics cost?
     "exp256": ["-DEXP_BLOCK_THREADS=256"],
     "cp_r16": ["-DCP_WORDS_PER_THREAD_1=16"],  # one-word records: 16 rows per wave (8192-record tiles; 64 VGPRs force spills)
