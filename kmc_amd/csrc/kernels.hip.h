@@ -463,22 +463,28 @@ __device__ __forceinline__ u64 lookback64(u64 *status, u32 tile, u64 aggregate, 
  * v2 used pointer doubling over all positions (log2 rounds of two LDS sweeps: 53 k cycles per chunk). */
 constexpr int PARSE_CHUNK = 4096, PARSE_SUB = 128, PARSE_NSUB = PARSE_CHUNK / PARSE_SUB;
 #ifndef PARSE_CAND_POS
-#define PARSE_CAND_POS 16 /* entry positions per sub-block resolved speculatively (multiple of 8); deeper entries take the exact slow path */
+#define PARSE_CAND_POS 16 /* entry positions per sub-block resolved speculatively; deeper entries take the exact slow path */
 #endif
-constexpr int PARSE_CAND = PARSE_CAND_POS;
-static_assert(PARSE_CAND % 8 == 0 && PARSE_CAND >= 8 && PARSE_CAND <= PARSE_SUB, "PARSE_CAND");
+#ifndef PARSE_THREADS
+#define PARSE_THREADS 64 /* ONE wave per pack (round 4; 256 threads before: a pack is a serial chain of ~12 chunks x ~65 dependent LDS hops whatever the width of the
+                          * workgroup, so what counts is how many packs a CU holds at once — 8 workgroups of 4 waves (13 KB of LDS each) meant three rounds of packs
+                          * per group of bins; 28 single waves (5.7 KB each) hold every pack of a group at once: 0.27 -> see DESIGN ms per 190 M-record group) */
+#endif
+constexpr int PARSE_CAND = PARSE_CAND_POS, PARSE_BLOCK = PARSE_THREADS;
+static_assert(PARSE_CAND >= 8 && PARSE_CAND <= PARSE_SUB && (PARSE_CAND & (PARSE_CAND - 1)) == 0, "PARSE_CAND");
+static_assert(PARSE_BLOCK >= PARSE_NSUB && (PARSE_NSUB * PARSE_CAND) % PARSE_BLOCK == 0 && (PARSE_CHUNK / 16) % PARSE_BLOCK == 0, "PARSE_THREADS");
 
-__global__ void __launch_bounds__(256) k_parse_packs(const GrpParse gp, u32 k, u32 *err)
+__global__ void __launch_bounds__(PARSE_BLOCK) k_parse_packs(const GrpParse gp, u32 k, u32 *err)
 {
 	/* Three levels per PARSE_CHUNK bytes staged in LDS (the chain has <= chunk/Lmin hops; walking it serially costs one
 	 * dependent load per hop):
-	 *   L1  every possible entry position p of every 128-byte sub-block, in parallel: X(p) = where the chain started at
-	 *       p leaves the sub-block (<= 128/Lmin hops, up to 16 independent chains per thread interleaved so the LDS
-	 *       latency pipelines)
+	 *   L1  the first PARSE_CAND positions of every 128-byte sub-block as possible entries, in parallel: X(p) = where the chain
+	 *       started at p leaves the sub-block (<= 128/Lmin hops; a thread interleaves its chains so the LDS latency pipelines)
 	 *   L2  one lane hops sub-block to sub-block from the chunk's entry offset: 32 dependent LDS reads instead of ~500
 	 *   L3  one lane per sub-block walks it from its now-known entry and builds the sub-block's 128 start bits */
+	constexpr int NV = PARSE_CHUNK / 16 / PARSE_BLOCK; /* 16-byte pieces of a chunk per thread */
 	__shared__ __attribute__((aligned(16))) uint8_t s_b[PARSE_CHUNK];
-	__shared__ unsigned short s_X[PARSE_CHUNK];
+	__shared__ unsigned short s_X[PARSE_NSUB * PARSE_CAND]; /* [sub-block][candidate] */
 	__shared__ unsigned short s_ent[PARSE_NSUB]; /* entry position + 1 of each sub-block (0 = chain does not start here) */
 	__shared__ u32 s_vis[PARSE_CHUNK / 32];
 	__shared__ u32 s_exit;
@@ -491,18 +497,24 @@ __global__ void __launch_bounds__(256) k_parse_packs(const GrpParse gp, u32 k, u
 	u32 *__restrict__ bitmap = gp.bitmap[bin];
 	const u64 pos0 = gp.pack_start[bin][p], end = gp.pack_start[bin][p + 1];
 	/* Chunks are cut at multiples of PARSE_CHUNK of the IMAGE (not of the pack), and the first one starts at the 16-byte boundary
-	 * below the pack start: every chunk is staged with one aligned 16-byte load per thread (byte loads cost 16 instructions per
+	 * below the pack start: every chunk is staged with aligned 16-byte loads (byte loads cost 16 instructions per
 	 * thread and chunk). The few bytes in front of the pack are never visited: the chain starts at `entry`. */
 	u32 entry = (u32)(pos0 & 15); /* offset inside the current chunk of the first record start */
 	u64 c_next = pos0 & ~15ull;
 	static_assert(PARSE_CHUNK == 4096, "chunk boundaries are computed with shifts");
-	/* the chunk after the one being resolved is already on its way (one 16-byte register per thread): a pack is ~10 chunks that depend
+	/* the chunk after the one being resolved is already on its way (NV 16-byte registers per thread): a pack is ~12 chunks that depend
 	 * on each other through `entry`, and each used to start with an exposed trip to HBM */
-	uint4 staged = make_uint4(0, 0, 0, 0);
+	uint4 staged[NV];
+#pragma unroll
+	for (int v = 0; v < NV; ++v)
+		staged[v] = make_uint4(0, 0, 0, 0);
 	if (c_next < end) {
 		const u64 b0 = ((c_next >> 12) + 1) << 12;
-		if ((u64)tid * 16 < (b0 < end ? b0 : end) - c_next)
-			staged = reinterpret_cast<const uint4 *>(data + c_next)[tid]; /* 16-byte aligned; the image has >= 256 readable bytes of slack */
+		const u64 lim = (b0 < end ? b0 : end) - c_next;
+#pragma unroll
+		for (int v = 0; v < NV; ++v)
+			if ((u64)(tid + v * PARSE_BLOCK) * 16 < lim)
+				staged[v] = reinterpret_cast<const uint4 *>(data + c_next)[tid + v * PARSE_BLOCK]; /* 16-byte aligned; the image has >= 256 readable bytes of slack */
 	}
 	while (c_next < end) {
 		const u64 c0 = c_next;
@@ -510,12 +522,17 @@ __global__ void __launch_bounds__(256) k_parse_packs(const GrpParse gp, u32 k, u
 		const u64 c1 = bound < end ? bound : end;
 		const u32 clen = (u32)(c1 - c0);
 		c_next = c1;
-		if (tid * 16 < clen)
-			reinterpret_cast<uint4 *>(s_b)[tid] = staged; /* every reader of the previous chunk is past the barrier that ends the loop body */
+#pragma unroll
+		for (int v = 0; v < NV; ++v)
+			if ((tid + v * PARSE_BLOCK) * 16 < clen)
+				reinterpret_cast<uint4 *>(s_b)[tid + v * PARSE_BLOCK] = staged[v]; /* every reader of the previous chunk is past the barrier that ends the loop body */
 		if (c1 < end) {
 			const u64 b1 = c1 + PARSE_CHUNK; /* c1 is a multiple of PARSE_CHUNK here */
-			if ((u64)tid * 16 < (b1 < end ? b1 : end) - c1)
-				staged = reinterpret_cast<const uint4 *>(data + c1)[tid];
+			const u64 lim = (b1 < end ? b1 : end) - c1;
+#pragma unroll
+			for (int v = 0; v < NV; ++v)
+				if ((u64)(tid + v * PARSE_BLOCK) * 16 < lim)
+					staged[v] = reinterpret_cast<const uint4 *>(data + c1)[tid + v * PARSE_BLOCK];
 		}
 		if (entry >= clen) { /* only for a ragged image; the final check below reports it */
 			entry -= clen;
@@ -525,26 +542,27 @@ __global__ void __launch_bounds__(256) k_parse_packs(const GrpParse gp, u32 k, u
 		if (tid < PARSE_NSUB)
 			s_ent[tid] = 0;
 		__syncthreads();
-		/* L1. Thread (sub = tid/8, o = tid%8) runs the candidate entry positions sub*128 + o + 8i of its sub-block, i < PARSE_CAND/8; the
+		/* L1. Thread t runs the candidates c = t + PARSE_BLOCK i (sub-block c / PARSE_CAND, position c % PARSE_CAND in it); the
 		 * hop loop stops as soon as the wave has no chain left inside its sub-blocks. */
 		{
-			constexpr int NC = PARSE_CAND / 8;
-			static_assert(PARSE_NSUB * 8 == 256, "one sub-block per 8 threads");
+			constexpr int NC = PARSE_NSUB * PARSE_CAND / PARSE_BLOCK;
 			/* a record is at most maxlen = 1 + ceil((k+255)/4) >= 65 bytes (e <= 255, splitter.cpp:656), so a chain can enter a
 			 * sub-block anywhere in its first maxlen positions — but a record of real data is far shorter than the format allows
 			 * (e rarely exceeds a few dozen), so only the first PARSE_CAND positions are speculated on (2 rounds instead of the 9
-			 * that maxlen asks for at k=27: 0.152 -> 0.089 ms per 57 MB bin, with the prefetch of the next chunk); the rare chain that enters deeper is walked by L2 itself.
+			 * that maxlen asks for at k=27); the rare chain that enters deeper is walked by L2 itself.
 			 * Exactness does not depend on the bound. */
-			const u32 sb0 = (tid >> 3) * PARSE_SUB, sb_end = sb0 + PARSE_SUB;
 			u32 q[NC];
 #pragma unroll
-			for (int i = 0; i < NC; ++i)
-				q[i] = sb0 + (tid & 7) + 8 * i;
+			for (int i = 0; i < NC; ++i) {
+				const u32 c = tid + (u32)PARSE_BLOCK * i;
+				q[i] = (c / PARSE_CAND) * PARSE_SUB + (c % PARSE_CAND);
+			}
 			const u32 max_hops = PARSE_SUB / (1 + ((k + 3) >> 2)) + 1;
 			for (u32 h = 0; h < max_hops; ++h) {
 				bool moved = false;
 #pragma unroll
 				for (int i = 0; i < NC; ++i) {
+					const u32 sb_end = (((tid + (u32)PARSE_BLOCK * i) / PARSE_CAND) + 1) * PARSE_SUB;
 					if (q[i] < sb_end && q[i] < clen) {
 						q[i] += 1 + ((k + s_b[q[i]] + 3) >> 2);
 						moved = true;
@@ -554,11 +572,8 @@ __global__ void __launch_bounds__(256) k_parse_packs(const GrpParse gp, u32 k, u
 					break;
 			}
 #pragma unroll
-			for (int i = 0; i < NC; ++i) {
-				const u32 p0 = sb0 + (tid & 7) + 8 * i;
-				if (p0 < clen)
-					s_X[p0] = (unsigned short)q[i]; /* < clen + 130 */
-			}
+			for (int i = 0; i < NC; ++i)
+				s_X[tid + (u32)PARSE_BLOCK * i] = (unsigned short)q[i]; /* < clen + 130; entries at or behind clen are never looked up */
 		}
 		__syncthreads();
 		/* L2 */
@@ -567,7 +582,7 @@ __global__ void __launch_bounds__(256) k_parse_packs(const GrpParse gp, u32 k, u
 			while (q < clen) {
 				s_ent[q / PARSE_SUB] = (unsigned short)(q + 1);
 				if ((q & (PARSE_SUB - 1)) < (u32)PARSE_CAND)
-					q = s_X[q];
+					q = s_X[(q / PARSE_SUB) * PARSE_CAND + (q & (PARSE_SUB - 1))];
 				else { /* entered deeper than L1 speculated: walk this sub-block here */
 					const u32 sb_end = (q | (PARSE_SUB - 1)) + 1;
 					while (q < sb_end && q < clen)
@@ -604,7 +619,7 @@ __global__ void __launch_bounds__(256) k_parse_packs(const GrpParse gp, u32 k, u
 			const u32 sh = (u32)(c0 & 31);
 			const u64 gw0 = c0 >> 5;
 			const u32 n_gw = (u32)(((c0 + clen + 31) >> 5) - gw0);
-			for (u32 g = tid; g < n_gw; g += 256) {
+			for (u32 g = tid; g < n_gw; g += PARSE_BLOCK) {
 				/* global word g covers local bits [32g - sh, 32g - sh + 32) */
 				const int lw = (int)g - (sh ? 1 : 0);
 				const u32 lo = (lw >= 0 && lw < PARSE_CHUNK / 32) ? s_vis[lw] : 0;

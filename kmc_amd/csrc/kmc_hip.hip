@@ -766,7 +766,7 @@ int front_end_group(Slot &s, const std::vector<BinPlan> &bins, size_t off_ghist,
 	gp.pack_prefix[bins.size()] = (u32)packs;
 	ge.chunk_prefix[bins.size()] = (u32)chunks;
 	u64 *ghist = zero_ptr<u64>(s, off_ghist);
-	k_parse_packs<<<dim3((u32)packs), dim3(256), 0, s.stream>>>(gp, P.k, err);
+	k_parse_packs<<<dim3((u32)packs), dim3(PARSE_BLOCK), 0, s.stream>>>(gp, P.k, err);
 	if (s.timed)
 		HIPCHK(hipEventRecord(s.ev[1], s.stream));
 	const u32 blocks = (u32)std::min<u64>(chunks, 256 * 4 * (512 / EXP_BLOCK)); /* persistent workgroups, up to 4 per CU */

@@ -63,7 +63,7 @@ template <int SIZE> int expand_t(const DevParams &P, const uint8_t *img, u64 siz
 	ge.n_rec[0] = n_rec;
 	ge.out[0] = recs;
 	ge.status[0] = status.data();
-	hipemu::launch(dim3((u32)n_packs), dim3(256), 0, [&] { k_parse_packs(gp, P.k, err); });
+	hipemu::launch(dim3((u32)n_packs), dim3(PARSE_BLOCK), 0, [&] { k_parse_packs(gp, P.k, err); });
 	if (getenv("KMC_EMU_VERBOSE"))
 		fprintf(stderr, "[emu] parse done, err %u\n", *err);
 	const bool fuse = n_pass <= EXP_FUSE_MAX_PASS && n_rec >= 2;
@@ -215,7 +215,7 @@ int group_front_t(const DevParams &P, int g, const uint8_t *const *imgs, const u
 	ge.chunk_prefix[g] = (u32)chunks;
 	std::vector<u64> ghist((size_t)n_pass * 256, 0), dbase((size_t)n_pass * 256, 0);
 	u32 counters[2] = {0, 0};
-	hipemu::launch(dim3((u32)packs), dim3(256), 0, [&] { k_parse_packs(gp, P.k, err); });
+	hipemu::launch(dim3((u32)packs), dim3(PARSE_BLOCK), 0, [&] { k_parse_packs(gp, P.k, err); });
 	const u32 blocks = (u32)std::min<u64>(chunks, 3);
 	hipemu::launch(dim3(blocks), dim3(EXP_BLOCK), exp_lds_bytes<true>(n_pass, P.k),
 	               [&] { k_expand<SIZE, true>(ge, P.k, P.both_strands, n_pass, ghist.data(), &counters[0], err, dbase.data(), &counters[1], 0u); });
