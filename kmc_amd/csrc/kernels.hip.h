@@ -654,11 +654,9 @@ __global__ void __launch_bounds__(PARSE_BLOCK) k_parse_packs(const GrpParse gp, 
 #ifndef EXP_CHUNK_BYTES
 #define EXP_CHUNK_BYTES 16384 /* the 1.65 G k-mer bin: 4 KB slices 9.15 ms, 8 KB 7.85, 16 KB 7.15 (fewer scans and look-backs per byte) */
 #endif
-#ifndef EXP_KWIN_KMERS
-#define EXP_KWIN_KMERS 4096 /* round 4: with the two super-k-mer lists in one word the workgroup is at 37 KB of LDS at k = 27 — four per CU instead of three at 49.5 KB */
-#endif
 constexpr u32 EXP_FUSE_MAX_PASS = 16; /* the sort's histograms are fused into the expansion up to this many passes (k <= 64) */
-constexpr int EXP_CHUNK = EXP_CHUNK_BYTES, EXP_TAIL = 160, EXP_KWIN = EXP_KWIN_KMERS, EXP_BLOCK = EXP_BLOCK_THREADS;
+constexpr int EXP_CHUNK = EXP_CHUNK_BYTES, EXP_TAIL = 160, EXP_BLOCK = EXP_BLOCK_THREADS;
+constexpr u32 EXP_MAX_K = 4 * EXP_CHUNK; /* k-mers of the records that start in one slice: fewer than 4 per byte of them (a record of L bytes holds < 4 L - k) */
 /* x >> s for a shift count that is the same in every lane (0..63). The plain expression is a 64-bit shift instruction per lane (the compiler cannot know the
  * count is uniform, nor that a funnel shift of two dwords by 0..31 bits is v_alignbit_b32); here: one funnel shift, one 32-bit shift, two selects on a scalar
  * condition, no branch */
@@ -676,7 +674,7 @@ __host__ __device__ constexpr u32 exp_max_sk(u32 k) { return (u32)EXP_CHUNK / (1
 static_assert(EXP_CHUNK / 32 <= EXP_BLOCK && EXP_CHUNK <= 65536, "one bitmap word per thread; 16-bit positions inside a slice");
 static_assert(EXP_BLOCK >= 256, "the last workgroup scans 256 digits per pass, one per thread");
 #ifndef EXP_FULL_OCCUPANCY_SIZE
-#define EXP_FULL_OCCUPANCY_SIZE 2 /* record widths whose k_expand is compiled for 8 waves per SIMD (<= 64 VGPRs, <= 96 SGPRs): four 512-thread workgroups per CU fit their LDS */
+#define EXP_FULL_OCCUPANCY_SIZE 4 /* record widths whose k_expand is compiled for 8 waves per SIMD (<= 64 VGPRs, <= 96 SGPRs): four 512-thread workgroups per CU fit their LDS */
 #endif
 template <int SIZE, bool FUSE_HIST>
 __global__ void __launch_bounds__(EXP_BLOCK, (SIZE <= EXP_FULL_OCCUPANCY_SIZE ? 8 : (SIZE <= 4 ? 6 : 4))) k_expand(const GrpExpand ge, u32 k, u32 both_strands, u32 n_pass, u64 *__restrict__ ghist, u32 *ticket_ctr,
@@ -698,7 +696,8 @@ __global__ void __launch_bounds__(EXP_BLOCK, (SIZE <= EXP_FULL_OCCUPANCY_SIZE ? 
 	u32 *s_tmp = s_sk + MAX_SK + 1;                                           /* [24] scan scratch */
 	u32 *s_ticket = s_tmp + 24;                                                /* [3] */
 	u32 *s_h = s_ticket + 3;                                                  /* [n_pass * 256] when FUSE_HIST */
-	unsigned short *s_kidx = reinterpret_cast<unsigned short *>(s_h + (FUSE_HIST ? n_pass * 256 : 0)); /* [EXP_KWIN] k-mer (window-relative) -> super-k-mer */
+	u32 *s_start = s_h + (FUSE_HIST ? n_pass * 256 : 0);                      /* [EXP_MAX_K / 32] one bit per k-mer of the slice; bit p: a super-k-mer starts at k-mer p + 1 */
+	unsigned short *s_rowsk = reinterpret_cast<unsigned short *>(s_start + EXP_MAX_K / 32); /* [EXP_MAX_K / 64] bits in front of each row of 64 */
 
 	if (FUSE_HIST) {
 		for (u32 i = threadIdx.x; i < n_pass * 256; i += EXP_BLOCK)
@@ -735,6 +734,8 @@ __global__ void __launch_bounds__(EXP_BLOCK, (SIZE <= EXP_FULL_OCCUPANCY_SIZE ? 
 			for (u32 i = tid; i < (avail + 15) / 16; i += EXP_BLOCK)
 				l[i] = g[i]; /* the image has >= 256 readable bytes of slack after `size` */
 		}
+		for (u32 i = tid; i < EXP_MAX_K / 32; i += EXP_BLOCK)
+			s_start[i] = 0; /* (nobody reads the previous slice's bits any more: the barrier at the top of the loop) */
 		/* this thread's 32 positions = one bitmap word */
 		const u32 bits = (tid < (u32)EXP_CHUNK / 32 && tid * 32 < clen) ? bitmap[(c0 >> 5) + tid] : 0; /* one bitmap word (32 positions) per thread */
 		__syncthreads();
@@ -756,8 +757,10 @@ __global__ void __launch_bounds__(EXP_BLOCK, (SIZE <= EXP_FULL_OCCUPANCY_SIZE ? 
 			while (bb) {
 				const u32 bpos = (u32)__ffs((int)bb) - 1;
 				bb &= bb - 1;
-				if (i < MAX_SK) {
+				if (i < MAX_SK && ko < EXP_MAX_K) {
 					s_sk[i] = ((tid * 32 + bpos) << 16) | ko;
+					if (ko)
+						atomicOr(&s_start[(ko - 1) >> 5], 1u << ((ko - 1) & 31)); /* bit p: a super-k-mer starts at k-mer p + 1 (an atomic: up to 32 of one k-mer each share a word) */
 				}
 				ko += (u32)s_b[tid * 32 + bpos] + 1;
 				++i;
@@ -785,51 +788,41 @@ __global__ void __launch_bounds__(EXP_BLOCK, (SIZE <= EXP_FULL_OCCUPANCY_SIZE ? 
 		/* what the k-mer loop needs of the 64-bit record numbers, as scalars: the first record's address and how many k-mers of this slice are inside the bin */
 		u64 *const out_base = out + base * SIZE;
 		const u32 j_limit = base >= n_rec ? 0u : (n_rec - base > 0xFFFFFFFFull ? 0xFFFFFFFFu : (u32)(n_rec - base));
-		/* k-mers of the slice in windows of EXP_KWIN (two to four at sequencing depth) */
-		for (u32 w0 = 0; n_sk && w0 < tot_k; w0 += EXP_KWIN) {
-			const u32 wn = (tot_k - w0) < (u32)EXP_KWIN ? (tot_k - w0) : (u32)EXP_KWIN;
-			/* k-mer -> super-k-mer map: mark each super-k-mer's first k-mer, then a max-scan in k-mer order */
-			for (u32 r = tid; r < wn; r += EXP_BLOCK)
-				s_kidx[r] = 0;
-			__syncthreads();
-			for (u32 i = tid; i < n_sk; i += EXP_BLOCK) {
-				const u32 o = s_sk[i] & 0xFFFFu, o1 = s_sk[i + 1] & 0xFFFFu; /* [o, o1) = this super-k-mer's k-mers; sentinel at n_sk */
-				if (o >= w0 && o < w0 + wn)
-					s_kidx[o - w0] = (unsigned short)i;
-				else if (o < w0 && o1 > w0)
-					s_kidx[0] = (unsigned short)i; /* the super-k-mer that straddles the window start */
+		/* k-mer -> super-k-mer: the super-k-mers are numbered in k-mer order and number 0 starts at k-mer 0, so k-mer j belongs to number (super-k-mers that start
+		 * at k-mers 1..j) = (bits in front of position j). A wave's 64 k-mers are one aligned row of the bit array: s_rowsk[row] + the bits of the row's two words
+		 * below the lane (v_mbcnt). Round 4; before, a 16-bit index per k-mer was built per window of 4-8 K k-mers by clear + mark + two sweeps of a max-scan: five
+		 * barriers per window, 0.17 of the kernel's 0.73 ms. */
+		{
+			constexpr int RPT = (int)(EXP_MAX_K / 64 / EXP_BLOCK); /* rows per thread */
+			static_assert(RPT >= 1 && RPT * 64 * EXP_BLOCK == (int)EXP_MAX_K, "rows of the start bits per thread");
+			const u32 n_rows = n_sk ? (tot_k + 63) >> 6 : 0;
+			u32 cnt[RPT], mine = 0;
+#pragma unroll
+			for (int q = 0; q < RPT; ++q) {
+				const u32 row = tid * RPT + q;
+				cnt[q] = row < n_rows ? (u32)__popc(s_start[2 * row]) + (u32)__popc(s_start[2 * row + 1]) : 0u;
+				mine += cnt[q];
 			}
-			__syncthreads();
-			{
-				constexpr int PER = EXP_KWIN / EXP_BLOCK;
-				u32 m = 0;
-#pragma unroll 4
-				for (int q = 0; q < PER; ++q) {
-					const u32 r = tid * PER + q;
-					if (r < wn) {
-						const u32 x = s_kidx[r];
-						m = x > m ? x : m;
-					}
-				}
-				const u32 carry = block_excl_max<EXP_BLOCK / 64, u32>(m, s_tmp);
-				m = carry;
-#pragma unroll 4
-				for (int q = 0; q < PER; ++q) {
-					const u32 r = tid * PER + q;
-					if (r < wn) {
-						const u32 x = s_kidx[r];
-						m = x > m ? x : m;
-						s_kidx[r] = (unsigned short)m;
-					}
-				}
+			u32 total;
+			u32 run = block_excl_sum<EXP_BLOCK / 64, u32>(mine, s_tmp, total);
+#pragma unroll
+			for (int q = 0; q < RPT; ++q) {
+				const u32 row = tid * RPT + q;
+				if (row < n_rows)
+					s_rowsk[row] = (unsigned short)run;
+				run += cnt[q];
 			}
-			__syncthreads();
+		}
+		__syncthreads();
+		{
+			const u32 wn = n_sk ? tot_k : 0u;
 			for (u32 r = tid; r < wn; r += EXP_BLOCK) {
 #if defined(EXP_CUT) && EXP_CUT == 1 /* tuning builds only: everything but the k-mer loop (output garbage) */
 				break;
 #endif
-				const u32 j = w0 + r;
-				const u32 si = s_kidx[r];
+				const u32 j = r;
+				const u32 m_lo = s_start[2 * (r >> 6)], m_hi = s_start[2 * (r >> 6) + 1]; /* the wave's row (r - lane is a multiple of 64) */
+				const u32 si = __builtin_amdgcn_mbcnt_hi(m_hi, __builtin_amdgcn_mbcnt_lo(m_lo, (u32)s_rowsk[r >> 6]));
 				if (j < j_limit) {
 					u64 v[SIZE];
 					const u32 sk = s_sk[si];
@@ -912,7 +905,6 @@ __global__ void __launch_bounds__(EXP_BLOCK, (SIZE <= EXP_FULL_OCCUPANCY_SIZE ? 
 #endif
 				}
 			}
-			__syncthreads();
 		}
 	}
 	if (FUSE_HIST) {
@@ -946,7 +938,7 @@ __global__ void __launch_bounds__(EXP_BLOCK, (SIZE <= EXP_FULL_OCCUPANCY_SIZE ? 
 }
 template <bool FUSE_HIST> constexpr size_t exp_lds_bytes(u32 n_pass, u32 k)
 {
-	return 16 + (size_t)EXP_CHUNK + EXP_TAIL + ((size_t)exp_max_sk(k) + 1 + 24 + 3) * 4 + (FUSE_HIST ? (size_t)n_pass * 1024 : 0) + EXP_KWIN * 2 + 16;
+	return 16 + (size_t)EXP_CHUNK + EXP_TAIL + ((size_t)exp_max_sk(k) + 1 + 24 + 3) * 4 + (FUSE_HIST ? (size_t)n_pass * 1024 : 0) + EXP_MAX_K / 8 + EXP_MAX_K / 32 + 16;
 }
 
 /* ------------------------------------------------------------------------------------------------ histogram
