@@ -398,6 +398,27 @@ template <int SIZE> struct BrCfg {
 };
 template <int SIZE> constexpr size_t br_lds_bytes() { return BrCfg<SIZE>::LDS; }
 /* key bits that may be left below the bucket bits (plan_sort) */
+/* rank += ((x[NW-1] .. x[0], xi) < (y[NW-1] .. y[0], yi)), both read as ONE number of NW + 1 dwords with xi / yi the least significant: a borrow chain — one
+ * subtract-with-borrow per dword and an add-with-carry at the end, the borrow in a scalar register pair. Written as `less || (equal && index before)` over 64-bit
+ * words the compiler emits 64-bit compares under per-lane branches (k = 55: ~11 vector instructions + two branches per pair; a chain written with
+ * __builtin_subc is folded back into the same compares), and the pair loops are where k_bucket_rank<2..> spends its time. */
+template <int NW> __device__ __forceinline__ void br_rank_add_less(u32 &rank, const u32 (&x)[NW], u32 xi, const u32 (&y)[NW], u32 yi)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+	u32 t;
+	u64 c;
+	asm("v_sub_co_u32_e64 %0, %1, %2, %3" : "=v"(t), "=s"(c) : "v"(xi), "v"(yi));
+#pragma unroll
+	for (int i = 0; i < NW; ++i)
+		asm("v_subb_co_u32_e64 %0, %1, %2, %3, %1" : "=v"(t), "+s"(c) : "v"(x[i]), "v"(y[i]));
+	asm("v_addc_co_u32_e64 %0, %1, 0, %0, %1" : "+v"(rank), "+s"(c));
+#else /* tests/hipemu */
+	bool less = xi < yi;
+	for (int i = 0; i < NW; ++i)
+		less = x[i] < y[i] || (x[i] == y[i] && less);
+	rank += less ? 1u : 0u;
+#endif
+}
 template <int SIZE> constexpr u32 br_rem_limit() { return SIZE == 1 ? 48u : (SIZE == 2 ? 80u : 64u * SIZE); }
 
 /* The tiles of up to GRP_MAX bins (not FUSED: one array, g = 1). Tile t of bin b = [bounds[b][t], bounds[b][t+1]); one that outgrows the capacity is taken
@@ -648,18 +669,20 @@ __global__ void __launch_bounds__(BrCfg<SIZE>::THREADS, BR_MIN_WAVES) k_bucket_r
 #pragma unroll
 		for (int r = 0; r < ITEMS; ++r) {
 			const u32 bstart = span[r] & 0xFFFFu, bend = span[r] >> 16;
-			const u64 A = cA[r];
+			const u32 A[2] = {(u32)cA[r], (u32)(cA[r] >> 32)};
 			const u32 B = cB[r];
 			u32 rank = 0, q = bstart;
 			for (; q + 2 <= bend; q += 2) {
 				const u64 a0 = s_A[q], a1 = s_A[q + 1];
 				const u32 e0 = s_B[q], e1 = s_B[q + 1];
-				rank += ((a0 < A) || (a0 == A && e0 < B) ? 1u : 0u) + ((a1 < A) || (a1 == A && e1 < B) ? 1u : 0u);
+				const u32 x0[2] = {(u32)a0, (u32)(a0 >> 32)}, x1[2] = {(u32)a1, (u32)(a1 >> 32)};
+				br_rank_add_less<2>(rank, x0, e0, A, B); /* (A, B) is one 96-bit number: B holds the low rem bits and the index */
+				br_rank_add_less<2>(rank, x1, e1, A, B);
 			}
 			if (q < bend) {
 				const u64 a0 = s_A[q];
-				const u32 e0 = s_B[q];
-				rank += (a0 < A) || (a0 == A && e0 < B) ? 1u : 0u;
+				const u32 x0[2] = {(u32)a0, (u32)(a0 >> 32)};
+				br_rank_add_less<2>(rank, x0, s_B[q], A, B);
 			}
 			place[r] = bstart + rank;
 		}
@@ -676,10 +699,22 @@ __global__ void __launch_bounds__(BrCfg<SIZE>::THREADS, BR_MIN_WAVES) k_bucket_r
 			const u32 bstart = span[r] & 0xFFFFu, bend = span[r] >> 16;
 			const u32 me = bstart + rel[r];
 			u32 rank = 0;
-			for (u32 q = bstart; q < bend; ++q) {
+			u32 y[2 * SIZE];
+#pragma unroll
+			for (int w = 0; w < SIZE; ++w) {
+				y[2 * w] = (u32)key[r][w];
+				y[2 * w + 1] = (u32)(key[r][w] >> 32);
+			}
+			for (u32 q = bstart; q < bend; ++q) { /* records before this one: smaller ones, and equal ones that stand in front of it */
 				u64 o[SIZE];
 				load_rec<SIZE>(s_key + (size_t)q * SIZE, o);
-				rank += (kmc_less<SIZE>(o, key[r]) || (q < me && kmc_equal<SIZE>(o, key[r]))) ? 1u : 0u;
+				u32 x[2 * SIZE];
+#pragma unroll
+				for (int w = 0; w < SIZE; ++w) {
+					x[2 * w] = (u32)o[w];
+					x[2 * w + 1] = (u32)(o[w] >> 32);
+				}
+				br_rank_add_less<2 * SIZE>(rank, x, q, y, me);
 			}
 			place[r] = bstart + rank;
 		}
