@@ -672,17 +672,18 @@ __global__ void __launch_bounds__(BrCfg<SIZE>::THREADS, BR_MIN_WAVES) k_bucket_r
 			const u32 A[2] = {(u32)cA[r], (u32)(cA[r] >> 32)};
 			const u32 B = cB[r];
 			u32 rank = 0, q = bstart;
-			for (; q + 2 <= bend; q += 2) {
-				const u64 a0 = s_A[q], a1 = s_A[q + 1];
-				const u32 e0 = s_B[q], e1 = s_B[q + 1];
-				const u32 x0[2] = {(u32)a0, (u32)(a0 >> 32)}, x1[2] = {(u32)a1, (u32)(a1 >> 32)};
-				br_rank_add_less<2>(rank, x0, e0, A, B); /* (A, B) is one 96-bit number: B holds the low rem bits and the index */
-				br_rank_add_less<2>(rank, x1, e1, A, B);
+			for (; q + 4 <= bend; q += 4) { /* (A, B) is one 96-bit number: B holds the low rem bits and the index */
+#pragma unroll
+				for (int u = 0; u < 4; ++u) {
+					const u64 a = s_A[q + u];
+					const u32 x[2] = {(u32)a, (u32)(a >> 32)};
+					br_rank_add_less<2>(rank, x, s_B[q + u], A, B);
+				}
 			}
-			if (q < bend) {
-				const u64 a0 = s_A[q];
-				const u32 x0[2] = {(u32)a0, (u32)(a0 >> 32)};
-				br_rank_add_less<2>(rank, x0, s_B[q], A, B);
+			for (; q < bend; ++q) {
+				const u64 a = s_A[q];
+				const u32 x[2] = {(u32)a, (u32)(a >> 32)};
+				br_rank_add_less<2>(rank, x, s_B[q], A, B);
 			}
 			place[r] = bstart + rank;
 		}
@@ -705,6 +706,7 @@ __global__ void __launch_bounds__(BrCfg<SIZE>::THREADS, BR_MIN_WAVES) k_bucket_r
 				y[2 * w] = (u32)key[r][w];
 				y[2 * w + 1] = (u32)(key[r][w] >> 32);
 			}
+#pragma unroll 2
 			for (u32 q = bstart; q < bend; ++q) { /* records before this one: smaller ones, and equal ones that stand in front of it */
 				u64 o[SIZE];
 				load_rec<SIZE>(s_key + (size_t)q * SIZE, o);
