@@ -632,10 +632,15 @@ def main():
     if rank == 0:
         W = 8 * ((k + 31) // 32)
         P = (2 * k + 7) // 8
-        kern = "k_onesweep<%d>" % ((k + 31) // 32)
+        # records of three words and more: the HBM passes move one word per record (the key's top four bytes above the record's number), k_bucket_rank gathers the
+        # records by number (library counter [6]); the scatter kernel is then k_onesweep<1> on 8-byte pairs whatever k is
+        pc = ctx.path_counters()
+        indirect = pc.get("indirect", 0) > 0 and pc["indirect"] == pc["rank_count"]
+        SW = 8 if indirect else W   # bytes per record of what the scatter passes move
+        kern = "k_onesweep<%d>" % (1 if indirect else (k + 31) // 32)
         avg_ms = sc_ms / max(n_launch, 1)
         rpl = sc_recs / max(n_launch, 1)
-        achieved = (2 * W * sc_recs) / (sc_ms * 1e-3) / 1e9 if n_launch else 0.0
+        achieved = (2 * SW * sc_recs) / (sc_ms * 1e-3) / 1e9 if n_launch else 0.0
         value = w.total_kmers_all * args.steps / dt / 1e9
         # which sort ran: LSD passes over every key byte (P of them), or — hybrid — over the top bytes only + k_bucket_count in LDS. The sampled groups carry
         # both kinds of event pairs, so passes per record = scatter records / LDS-sorted records.
@@ -643,10 +648,11 @@ def main():
         hbm_passes = (sc_recs / ls["records"]) if hyb else float(P)
         # which LDS finisher ran (library's own counters): k_bucket_rank fused (tiles ranked and counted in LDS: one read), k_bucket_rank in place + k_compact
         # (one more read + write), or k_bucket_count (one read)
-        pc = ctx.path_counters()
         rank_fused = hyb and pc["rank_count"] > 0 and pc["rank_compact"] == 0 and pc["bucket_count"] == 0
         by_rank = hyb and not rank_fused and pc["rank_compact"] > 0
         moved = W * (1 + 2 * hbm_passes + (2 if by_rank else 0) + 1) + 1.2  # expand write + passes (read + write) [+ rank in place] + one read by the finisher / k_compact + the bin image
+        if indirect:
+            moved = W + 8 + 2 * 8 * hbm_passes + 8 + W + 1.2  # expand writes record + pair, the passes move pairs, the finisher reads the pair and gathers the record
         desc = (CONFIGS[name]["desc"] % k) if name in CONFIGS else f"custom: k={k}, {args.reads} reads of a {args.genome} bp genome, {args.bins} bins"
         out = {
             "metric": "stage-2 Gk-mers/s, k=%d (bin sort & count: parse + expand + 8-bit LSD radix sort + compaction over all signature bins)" % k,
@@ -665,7 +671,9 @@ def main():
                            "oracle_bins_equal": (all(v.get("equal") for v in oracle_bins) if oracle_bins else None), "oracle_bins": oracle_bins},
             "sort_path": {"what": ("hybrid: 8-bit LSD passes through HBM over the top key bytes only, then every bucket-aligned tile put in order inside LDS (k_bucket_rank: a record's "
                                    "place = the records of its bucket below it, counted pairwise) and counted there — run lengths, cutoffs, (suffix, counter) records, LUT, "
-                                   "tallies: the sorted tile never goes back to HBM" if rank_fused else
+                                   "tallies: the sorted tile never goes back to HBM" +
+                                   ("; INDIRECT: the passes move (key top, record number) pairs of 8 bytes, the records stay where k_expand wrote them and are gathered by number" if indirect else "")
+                                   if rank_fused else
                                    "hybrid: 8-bit LSD passes through HBM over the top key bytes only, then every bucket-aligned tile put in order inside LDS (k_bucket_rank: a record's "
                                    "place = the records of its bucket below it, counted pairwise), then k_compact" if by_rank else
                                    "hybrid: 8-bit LSD passes through HBM over the top key bytes only, the rest counted inside LDS on bucket-aligned tiles (k_bucket_count)" if hyb
@@ -680,8 +688,8 @@ def main():
             "roofline": {"bound": "hbm", "kernel": kern, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(kern, rpl),
                          "traffic_unit": "HBM bytes per launch (PMC FETCH_SIZE x2 + WRITE_SIZE, profiles/r04/pmc_hbm_traffic.json)",
-                         "algorithmic_bytes_per_launch": 2 * W * rpl, "launches_in_timed_region": n_launch, "avg_launch_ms": avg_ms,
-                         "records_per_launch": rpl, "algorithmic_bytes_per_record_per_launch": 2 * W,
+                         "algorithmic_bytes_per_launch": 2 * SW * rpl, "launches_in_timed_region": n_launch, "avg_launch_ms": avg_ms,
+                         "records_per_launch": rpl, "algorithmic_bytes_per_record_per_launch": 2 * SW,
                          "note": "consecutive bins of a stream share one sort (bins_per_sort: the bin's number inside the group rides in the spare bits of the "
                                  "top radix digit), so a launch covers that many bins; every 8th group of a stream carries the event pairs (an event costs "
                                  "stream time); big bins run on one stream, so launches do not overlap and the event durations are the kernel's own"},

@@ -236,7 +236,9 @@ int kmc_hip_set_hybrid(int mode);
  * (one-word records whose output may outgrow a tile's span); [2] k_bucket_count (KMC_HIP_RANK=0, mode 2, or too many key bits below the buckets); [3] 8-bit
  * LSD passes over every key byte + k_compact (rounds 1-2; redo runs; tiny groups). With a context (ctx != NULL; waits for the device's streams): [4] tiles whose
  * largest bucket did not fit LDS and that k_giant_tiles sorted on their own (k-mers repeated thousands of times) and [5] the records in them, since the context
- * was made. [6..7] reserved (0). What replaces raduls_impl.h:216-520, :680-737 / small_sort.h for a group. */
+ * was made. [6] the groups of [0] (records of three words and more) whose HBM passes moved one word per record — the key's top four bytes above the record's
+ * number — with the records gathered by number inside k_bucket_rank (process-wide, like [0..3]). [7] reserved (0). What replaces raduls_impl.h:216-520,
+ * :680-737 / small_sort.h for a group. */
 int kmc_hip_path_counters(kmc_hip_ctx *ctx, int dev, uint64_t counters[8]);
 /* Device memory helpers so non-HIP callers (ctypes tests, the C++ worker) need not link HIP themselves. */
 int kmc_hip_malloc(kmc_hip_ctx *ctx, int dev, uint64_t bytes, void **d_ptr);

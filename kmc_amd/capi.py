@@ -383,10 +383,11 @@ class Context:
 
     def path_counters(self, dev: int = 0):
         """group counts by path since the last set_hybrid (process-wide) + the tiles / records k_giant_tiles took on `dev` since the context was made:
-        dict(rank_count, rank_compact, bucket_count, lsd, giant_tiles, giant_records)"""
+        dict(rank_count, rank_compact, bucket_count, lsd, giant_tiles, giant_records, indirect); `indirect`: the groups of rank_count whose HBM passes moved
+        (key top, record number) pairs instead of records (three words and more)"""
         c = (C.c_uint64 * 8)()
         self._chk(self.L.kmc_hip_path_counters(self.h, dev, c))
-        return dict(rank_count=c[0], rank_compact=c[1], bucket_count=c[2], lsd=c[3], giant_tiles=c[4], giant_records=c[5])
+        return dict(rank_count=c[0], rank_compact=c[1], bucket_count=c[2], lsd=c[3], giant_tiles=c[4], giant_records=c[5], indirect=c[6])
 
     def process_bins_device(self, p: BinParams, descs, n_streams: int = 0, dev: int = 0):
         """Enqueue many device-resident bins (ctypes array of BinDesc); returns after enqueueing — call synchronize()."""

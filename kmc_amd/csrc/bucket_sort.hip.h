@@ -433,6 +433,9 @@ struct GrpRank {
 	u64 *lut_base[GRP_MAX];
 	u64 *tally[GRP_MAX];        /* [CP_SHARDS][4] */
 	u32 *giant;                 /* FUSED: [0] number of tiles handed to k_giant_tiles, [1] how many of them have been taken, [2..] their numbers (zeroed by the host) */
+	const u64 *rec_base;        /* indirect sort (records of three words and more): S is the ordered array of (top four key bytes << 32 | record number) PAIRS, one word
+	                             * each, and the records stay where k_expand wrote them: record number i of the group is rec_base + i SIZE. NULL: S holds the records. */
+	u64 *giant_T[GRP_MAX];      /* indirect sort: the bin's slice of a third record array — k_giant_tiles gathers a tile's records there before it sorts them in place */
 };
 /* A tile whose LARGEST BUCKET does not fit the capacity — one k-mer repeated thousands of times: every genome has those — is not ranked pairwise (the work
  * grows with the square of a bucket) and, since round 4, no longer sends its whole group back to the host either: k_bucket_rank puts it on a list and
@@ -474,7 +477,10 @@ __global__ void __launch_bounds__(BrCfg<SIZE>::THREADS, BR_MIN_WAVES) k_bucket_r
 	const u32 crel = wave * (ITEMS * 64); /* the wave owns ITEMS rows of 64 consecutive records */
 	const u32 bsh = 64 - hbits;
 	auto bucket_of = [&](const u64(&x)[SIZE]) -> u64 { return hbits ? bs_p64<SIZE>(x, key_bits) >> bsh : 0ull; };
+	const u64 *__restrict__ rec_base = gr.rec_base; /* indirect: `recs` are pairs */
 	auto bucket_at = [&](u64 i) -> u64 {
+		if (rec_base)
+			return recs[i] >> 32; /* the top four key bytes ARE the bucket number: the bits above the key in the top byte are zero (kmc_hip.hip: hbits = 32 - those bits) */
 		u64 x[SIZE];
 		load_rec<SIZE>(recs + i * SIZE, x);
 		return bucket_of(x);
@@ -514,15 +520,18 @@ __global__ void __launch_bounds__(BrCfg<SIZE>::THREADS, BR_MIN_WAVES) k_bucket_r
 			len = (u32)(b1 - c0);
 		}
 	}
-	u64 *__restrict__ T = recs + c0 * SIZE;
+	u64 *__restrict__ T = recs + c0 * (rec_base ? 1 : SIZE);
 
 	u64 key[ITEMS][SIZE];
 #pragma unroll
 	for (int r = 0; r < ITEMS; ++r) {
 		const u32 idx = crel + r * 64 + lane;
-		if (idx < len)
-			load_rec<SIZE>(T + (size_t)idx * SIZE, key[r]);
-		else {
+		if (idx < len) {
+			if (rec_base) /* a gather of whole records by number: 24+ bytes each, one or two HBM sectors */
+				load_rec<SIZE>(rec_base + (size_t)(u32)T[idx] * SIZE, key[r]);
+			else
+				load_rec<SIZE>(T + (size_t)idx * SIZE, key[r]);
+		} else {
 #pragma unroll
 			for (int w = 0; w < SIZE; ++w)
 				key[r][w] = 0;
@@ -1014,6 +1023,16 @@ __global__ void __launch_bounds__(GT_THREADS) k_giant_tiles(const GrpRank gr, De
 		const u64 b0 = gr.bounds[bin][tile], b1 = gr.bounds[bin][tile + 1];
 		const u32 L = (u32)(b1 - b0);
 		u64 *T = gr.S[bin] + b0 * SIZE;
+		if (gr.rec_base) { /* indirect sort: the tile is a run of (key top, record number) pairs; its records are brought together first */
+			T = gr.giant_T[bin] + b0 * SIZE;
+			const u64 *pairs = gr.S[bin] + b0;
+			for (u32 i = tid; i < L; i += THREADS) {
+				u64 x[SIZE];
+				load_rec<SIZE>(gr.rec_base + (size_t)(u32)pairs[i] * SIZE, x);
+				store_rec<SIZE>(T + (size_t)i * SIZE, x);
+			}
+			__syncthreads();
+		}
 		u64 *U = reinterpret_cast<u64 *>(gr.scratch[bin] + b0 * (u64)(SIZE * 8));
 		(void)stride;
 		/* the key bits to sort by */

@@ -131,6 +131,8 @@ struct GrpExpand {
 	u64 *out[GRP_MAX];    /* the bin's slice of the shared record array */
 	u64 *status[GRP_MAX]; /* look-back words, one per slice of the bin */
 	u64 tag[GRP_MAX];     /* the bin's number inside the group, shifted to bit 2k of the record word that holds it */
+	u64 *pair_out[GRP_MAX]; /* indirect sort (kmc_hip.hip run_group_device_t): the bin's slice of the group's (top four key bytes << 32 | record number) array, or all NULL */
+	u64 *pair_base;         /* ... and the array's first word: a record's number is its distance from there */
 };
 struct GrpCompact {
 	u32 g, tile_prefix[GRP_MAX + 1];
@@ -720,6 +722,7 @@ __global__ void __launch_bounds__(EXP_BLOCK, (SIZE <= EXP_FULL_OCCUPANCY_SIZE ? 
 		const u32 *__restrict__ bitmap = ge.bitmap[bin];
 		const u64 size = ge.size[bin], n_rec = ge.n_rec[bin], tag = ge.tag[bin];
 		u64 *__restrict__ out = ge.out[bin];
+		u64 *__restrict__ pair_out = ge.pair_out[bin];
 		u64 *status = ge.status[bin];
 		u32 tid = threadIdx.x;
 		KMC_LAUNDER(tid);
@@ -787,6 +790,8 @@ __global__ void __launch_bounds__(EXP_BLOCK, (SIZE <= EXP_FULL_OCCUPANCY_SIZE ? 
 		const u64 base = *s_base;
 		/* what the k-mer loop needs of the 64-bit record numbers, as scalars: the first record's address and how many k-mers of this slice are inside the bin */
 		u64 *const out_base = out + base * SIZE;
+		u64 *const pair_row = pair_out ? pair_out + base : nullptr;
+		const u32 pair_first = pair_out ? (u32)(pair_row - ge.pair_base) : 0u; /* the group holds fewer than 2^32 records (the host checks) */
 		const u32 j_limit = base >= n_rec ? 0u : (n_rec - base > 0xFFFFFFFFull ? 0xFFFFFFFFu : (u32)(n_rec - base));
 		/* k-mer -> super-k-mer: the super-k-mers are numbered in k-mer order and number 0 starts at k-mer 0, so k-mer j belongs to number (super-k-mers that start
 		 * at k-mers 1..j) = (bits in front of position j). A wave's 64 k-mers are one aligned row of the bit array: s_rowsk[row] + the bits of the row's two words
@@ -898,8 +903,14 @@ __global__ void __launch_bounds__(EXP_BLOCK, (SIZE <= EXP_FULL_OCCUPANCY_SIZE ? 
 										atomicAdd(&s_h[b * 256 + (((b < 4 ? tl : th) >> (8 * (b & 3))) & 0xFFu)], 1u);
 							}
 						} else {
-							for (u32 b = 0; b < n_pass; ++b)
-								atomicAdd(&s_h[b * 256 + kmc_get_byte<SIZE>(v, pass_lo + b)], 1u);
+							u32 top = 0; /* the digits of the HBM passes, lowest first: with four passes, the key's top four bytes */
+							for (u32 b = 0; b < n_pass; ++b) {
+								const u32 dg = kmc_get_byte<SIZE>(v, pass_lo + b);
+								atomicAdd(&s_h[b * 256 + dg], 1u);
+								top |= dg << ((8 * b) & 31);
+							}
+							if (pair_row)
+								pair_row[j] = ((u64)top << 32) | (pair_first + j);
 						}
 					}
 #endif

@@ -156,7 +156,7 @@ struct Slot {
 	std::mutex mtx; /* serialises enqueueing on this slot (asynchronous device-resident calls may come from several threads) */
 	u64 portion = PORTION_MAX;
 	DBuf in, pack_start;
-	DBuf recA, recB, zero, dbase, out, lut, sticky;
+	DBuf recA, recB, recC, pairA, pairB, zero, dbase, out, lut, sticky;
 	DBuf bounds;   /* hybrid sort: tile boundaries of k_bucket_bounds, u64[windows + 1] */
 	DBuf redo_log; /* hybrid sort: one "sort me again" word per asynchronous group since the last drain (drain_redo) */
 	HostRes *h_res = nullptr; /* pinned */
@@ -294,7 +294,7 @@ int slot_init(Slot &s, u64 portion)
 
 void slot_destroy(Slot &s)
 {
-	for (DBuf *b : {&s.in, &s.pack_start, &s.recA, &s.recB, &s.zero, &s.dbase, &s.out, &s.lut, &s.sticky, &s.bounds, &s.redo_log, &s.hb_res})
+	for (DBuf *b : {&s.in, &s.pack_start, &s.recA, &s.recB, &s.recC, &s.pairA, &s.pairB, &s.zero, &s.dbase, &s.out, &s.lut, &s.sticky, &s.bounds, &s.redo_log, &s.hb_res})
 		if (b->p)
 			(void)hipFree(b->p);
 	if (s.h_res)
@@ -413,6 +413,7 @@ struct SortPlan {
 	u32 hbits() const { return top ? 8 * top - (8 * key_bytes - key_bits) : 0; } /* top bits of the significant key that the HBM passes order (plan_sort: 8 top > spare bits) */
 };
 std::atomic<u64> g_path[4] = {}; /* groups by the path they took: 0 rank + count in LDS, 1 rank in place + k_compact, 2 k_bucket_count, 3 LSD passes over every byte */
+std::atomic<u64> g_indirect_groups{0}; /* ... of path 0: sorted through (key top, record number) pairs */
 std::atomic<u64> g_hybrid_groups{0}, g_redo_groups{0}; /* process-wide: input whose buckets keep overflowing the tiles stops being tried */
 std::atomic<u32> g_extra_top{0}; /* HBM passes added to the plan after a group came back (finer buckets for the groups after it) */
 void note_redo() { g_redo_groups.fetch_add(1, std::memory_order_relaxed); }
@@ -730,7 +731,7 @@ int check_params(const kmc_hip_bin_params *p, DevParams &P)
  * the slices of all bins) with the sort's histograms fused in; the last workgroup turns the histograms into digit bases ---- */
 template <int SIZE>
 int front_end_group(Slot &s, const std::vector<BinPlan> &bins, size_t off_ghist, const DevParams &P, u32 n_pass /* digits through HBM */, u32 pass_lo, u32 &counter_idx,
-                    bool &hist_done, u64 *d_recs, bool fuse)
+                    bool &hist_done, u64 *d_recs, bool fuse, u64 *d_pairs = nullptr /* indirect sort: (top key bytes, record number) per record */)
 {
 	if (bins.empty())
 		return 0;
@@ -760,11 +761,13 @@ int front_end_group(Slot &s, const std::vector<BinPlan> &bins, size_t off_ghist,
 		ge.size[i] = b.size;
 		ge.n_rec[i] = b.n_rec;
 		ge.out[i] = d_recs + b.rec_off * SIZE;
+		ge.pair_out[i] = d_pairs ? d_pairs + b.rec_off : nullptr;
 		ge.status[i] = zero_ptr<u64>(s, b.off_exp_status);
 		ge.tag[i] = (u64)i << tag_shift; /* 0 for a group of one */
 	}
 	gp.pack_prefix[bins.size()] = (u32)packs;
 	ge.chunk_prefix[bins.size()] = (u32)chunks;
+	ge.pair_base = d_pairs;
 	u64 *ghist = zero_ptr<u64>(s, off_ghist);
 	k_parse_packs<<<dim3((u32)packs), dim3(PARSE_BLOCK), 0, s.stream>>>(gp, P.k, err);
 	if (s.timed)
@@ -956,7 +959,7 @@ int count_group(Slot &s, const std::vector<BinPlan> &bins, const u64 *sorted, u6
  * two output slots (one per chunk: a tile that outgrows the capacity is taken by two workgroups). ---- */
 template <int SIZE>
 int rank_group(Slot &s, const std::vector<BinPlan> &bins, u64 *sorted, u64 *scratch, const DevParams &P, u64 lut_entries, const SortPlan &sp, u64 n_total, u32 *d_flag,
-               u32 *d_giant)
+               u32 *d_giant, const u64 *d_recs_indirect = nullptr /* indirect sort: `sorted` is the ordered PAIR array (one word per record), the records are here */)
 {
 	if (bins.empty())
 		return 0;
@@ -992,12 +995,13 @@ int rank_group(Slot &s, const std::vector<BinPlan> &bins, u64 *sorted, u64 *scra
 			lut_base = zero_ptr<u64>(s, b.off_lutsh);
 		else if (lut_entries && !P.kff && b.d_lut) /* also without output: the caller's LUT is zero-filled by the callee (include/kmc_hip.h) */
 			HIPCHK(hipMemsetAsync(b.d_lut, 0, lut_entries * 8, s.stream));
-		gbn.S[i] = sorted + b.rec_off * SIZE;
-		gr.S[i] = sorted + b.rec_off * SIZE;
+		gbn.S[i] = sorted + b.rec_off * (d_recs_indirect ? 1 : SIZE);
+		gr.S[i] = sorted + b.rec_off * (d_recs_indirect ? 1 : SIZE);
 		gbn.n[i] = gf.n[i] = b.n_rec;
 		gbn.bounds[i] = bounds + items;
 		gr.bounds[i] = bounds + items;
 		gr.scratch[i] = (uint8_t *)(scratch + b.rec_off * SIZE);
+		gr.giant_T[i] = d_recs_indirect ? (u64 *)s.recC.p + b.rec_off * SIZE : nullptr; /* k_giant_tiles sorts records in place: it gathers a listed tile's records here first */
 		gr.status[i] = zero_ptr<u64>(s, b.off_cp_status);
 		gr.chunk_src[i] = chunk_src + 2 * wins;
 		gr.lut_base[i] = lut_base;
@@ -1021,6 +1025,7 @@ int rank_group(Slot &s, const std::vector<BinPlan> &bins, u64 *sorted, u64 *scra
 	gbn.item_prefix[bins.size()] = (u32)items;
 	gr.win_prefix[bins.size()] = (u32)wins;
 	gr.giant = d_giant;
+	gr.rec_base = d_recs_indirect;
 	gg.tile_prefix[bins.size()] = (u32)(2 * wins);
 	hipEvent_t e0 = nullptr, e1 = nullptr;
 	if (s.timed) {
@@ -1028,7 +1033,10 @@ int rank_group(Slot &s, const std::vector<BinPlan> &bins, u64 *sorted, u64 *scra
 			return rc;
 		HIPCHK(hipEventRecord(e0, s.stream));
 	}
-	k_bucket_bounds<SIZE><<<dim3((u32)((items + 3) / 4)), dim3(256), 0, s.stream>>>(gbn, (u32)S, sp.key_bits, sp.hbits());
+	if (d_recs_indirect) /* a pair's top half is the bucket number */
+		k_bucket_bounds<1><<<dim3((u32)((items + 3) / 4)), dim3(256), 0, s.stream>>>(gbn, (u32)S, 64u, 32u);
+	else
+		k_bucket_bounds<SIZE><<<dim3((u32)((items + 3) / 4)), dim3(256), 0, s.stream>>>(gbn, (u32)S, sp.key_bits, sp.hbits());
 	const u32 lut_mask = P.lut_prefix_len ? (u32)((1ull << (2 * P.lut_prefix_len)) - 1) : 0u;
 	k_bucket_rank<SIZE, true><<<dim3((u32)wins, 2), dim3(BrCfg<SIZE>::THREADS), br_lds_bytes<SIZE>(), s.stream>>>(gr, P, sp.key_bits, sp.hbits(), n_sh, lut_entries, lut_mask, d_flag);
 	/* the tiles with a bucket beyond the LDS capacity (k-mers repeated thousands of times), one workgroup each; nothing listed: a launch that returns */
@@ -1067,6 +1075,11 @@ u32 group_capacity(u32 k, bool small_bins)
 constexpr u64 GROUP_SMALL_BIN_RECORDS = 2ull << 20; /* average records per bin below which bins count as small. Measured: 512 bins of 0.48 M k-mers
                                                       * 15.7 (groups of 4) vs 18.3 Gk-mers/s (groups of 16 + one pass); 512 bins of 3.2 M k-mers 22.1 vs 21.0 */
 constexpr u64 GROUP_MAX_RECORD_BYTES = 6ull << 30; /* per record array of a group */
+#ifndef INDIRECT_MIN_WORDS
+#define INDIRECT_MIN_WORDS 2 /* record widths (64-bit words) from which a group is sorted through (key top, record number) pairs: run_group_device_t. Measured (quarter
+                              * workloads): k = 127 10.6 -> 18.1 Gk-mers/s (gathering 32-byte records costs the finisher 0.14 ms, the passes shrink from 2.03 to 0.61);
+                              * k = 55 21.3 -> 22.7 (16-byte gathers waste half of every HBM sector: finisher 1.81 -> 2.91 ms, passes 3.92 -> 2.20) */
+#endif
 
 /* d_stats / d_out_bytes == NULL in a descriptor (groups of one only): the slot's own small block (host-boundary path) */
 template <int SIZE>
@@ -1129,8 +1142,19 @@ int run_group_device_t(Slot &s, const DevParams &P, const kmc_hip_bin_desc *cons
 		*used_hybrid = sp.local() && N >= 2;
 	/* the histograms of the HBM passes are fused into the expansion up to 16 of them (plain LSD: k <= 64); a bin on its own with a single record has nothing to sort */
 	const bool fuse = n_pass >= 1 && n_pass <= EXP_FUSE_MAX_PASS && N >= 2;
+	/* Indirect sort (end of round 4), records of INDIRECT_MIN_WORDS (two) words and more: what goes through the four HBM passes is one word per record — the key's top four
+	 * bytes (exactly the digits of those passes) above the record's number in the group —, sorted by k_onesweep<1>; the records stay where k_expand wrote them and
+	 * k_bucket_rank gathers each tile's records by number. Per record 4 x 16 bytes of passes + 8 written + 8 SIZE gathered instead of 4 x 16 SIZE (k = 127: ~130
+	 * instead of ~290 bytes per k-mer). k_giant_tiles (which sorts a tile's records in place) first gathers a listed tile's records into its slice of a third array. */
+	static const bool indirect_enabled = [] {
+		const char *e = getenv("KMC_HIP_INDIRECT"); /* 0 (A/B runs): records of every width go through the passes themselves */
+		return !e || atoi(e) != 0;
+	}();
+	const bool indirect = SIZE >= INDIRECT_MIN_WORDS && indirect_enabled && rank_fused && sp.local() && n_pass == 4 && fuse && N < (1ull << 32);
 	int rc = 0;
 	if (N && ((rc = ensure(s.recA, N * SIZE * 8 + 256)) || (rc = ensure(s.recB, N * SIZE * 8 + 256))))
+		return rc;
+	if (indirect && ((rc = ensure(s.pairA, N * 8 + 256)) || (rc = ensure(s.pairB, N * 8 + 256)) || (rc = ensure(s.recC, N * SIZE * 8 + 256))))
 		return rc;
 	u64 rank_tiles = 0;
 	if (rank_fused)
@@ -1161,7 +1185,7 @@ int run_group_device_t(Slot &s, const DevParams &P, const kmc_hip_bin_desc *cons
 		HIPCHK(hipEventRecord(s.ev[0], s.stream));
 	u32 counter_idx = 0;
 	bool hist_done = false;
-	if ((rc = front_end_group<SIZE>(s, bins, z.ghist, P, n_pass, sp.pass_lo(), counter_idx, hist_done, (u64 *)s.recA.p, fuse)))
+	if ((rc = front_end_group<SIZE>(s, bins, z.ghist, P, n_pass, sp.pass_lo(), counter_idx, hist_done, (u64 *)s.recA.p, fuse, indirect ? (u64 *)s.pairA.p : nullptr)))
 		return rc;
 	if (n_pass == 0)
 		hist_done = true; /* no HBM pass, no histogram */
@@ -1171,18 +1195,27 @@ int run_group_device_t(Slot &s, const DevParams &P, const kmc_hip_bin_desc *cons
 	}
 	u64 *sorted = (u64 *)s.recA.p;
 	u32 *const flag = d_flag ? d_flag : small_ptr<u32>(s, SM_REDO);
-	if (N && (rc = sort_device_t<SIZE>(s, z, (u64 *)s.recA.p, (u64 *)s.recB.p, N, sp, &sorted, counter_idx, hist_done, flag, !sp.rank || rank_fused)))
+	if (indirect) { /* the pairs' bytes 4..7 are the key's bytes pass_lo .. pass_lo + 3: the same four digit histograms, the same digit bases */
+		SortPlan pp;
+		pp.key_bytes = 8;
+		pp.top = 4;
+		pp.key_bits = 64;
+		if ((rc = sort_device_t<1>(s, z, (u64 *)s.pairA.p, (u64 *)s.pairB.p, N, pp, &sorted, counter_idx, hist_done, flag, true)))
+			return rc;
+	} else if (N && (rc = sort_device_t<SIZE>(s, z, (u64 *)s.recA.p, (u64 *)s.recB.p, N, sp, &sorted, counter_idx, hist_done, flag, !sp.rank || rank_fused)))
 		return rc;
 	if (s.timed) {
 		if (!N)
 			HIPCHK(hipEventRecord(s.ev[3], s.stream));
 		HIPCHK(hipEventRecord(s.ev[4], s.stream));
 	}
-	u64 *const free_array = N ? (sorted == (u64 *)s.recA.p ? (u64 *)s.recB.p : (u64 *)s.recA.p) : nullptr;
+	u64 *const free_array = indirect ? (u64 *)s.recB.p : (N ? (sorted == (u64 *)s.recA.p ? (u64 *)s.recB.p : (u64 *)s.recA.p) : nullptr);
 	if (N >= 2)
 		g_path[rank_fused && sp.local() ? 0 : (sp.rank && sp.local() ? 1 : (sp.local() ? 2 : 3))].fetch_add(1, std::memory_order_relaxed);
+	if (indirect && N >= 2)
+		g_indirect_groups.fetch_add(1, std::memory_order_relaxed);
 	if (rank_fused && sp.local() && N >= 2)
-		rc = rank_group<SIZE>(s, bins, sorted, free_array, P, lut_entries, sp, N, flag, zero_ptr<u32>(s, z.giant));
+		rc = rank_group<SIZE>(s, bins, sorted, free_array, P, lut_entries, sp, N, flag, zero_ptr<u32>(s, z.giant), indirect ? (const u64 *)s.recA.p : nullptr);
 	else if (sp.local() && !sp.rank && N >= 2)
 		rc = count_group<SIZE>(s, bins, sorted, free_array, P, lut_entries, sp, N, flag);
 	else
@@ -3283,6 +3316,7 @@ int kmc_hip_set_hybrid(int mode)
 	g_extra_top.store(0);
 	for (auto &c : g_path)
 		c.store(0);
+	g_indirect_groups.store(0);
 	return before;
 }
 
@@ -3291,7 +3325,7 @@ int kmc_hip_path_counters(kmc_hip_ctx *ctx, int dev, uint64_t counters[8])
 	if (!counters)
 		return fail(KMC_HIP_EINVAL, "counters == NULL");
 	for (int i = 0; i < 8; ++i)
-		counters[i] = i < 4 ? g_path[i].load() : 0;
+		counters[i] = i < 4 ? g_path[i].load() : (i == 6 ? g_indirect_groups.load() : 0);
 	if (!ctx)
 		return 0;
 	if (int rc = set_dev(ctx, dev))

@@ -195,6 +195,9 @@ for k, nb, kw in ((55, 4, dict(lut_prefix_len=3)), (40, 3, dict(lut_prefix_len=4
                   (127, 4, dict(lut_prefix_len=3)), (70, 3, dict(lut_prefix_len=2, both_strands=0)), (200, 2, dict(lut_prefix_len=4))):
     h, r, c = check(k, capi.synth_bins(seed=7, genome_len=2500, n_reads=250, k=k, n_bins=nb, n_threads=1, read_len=max(150, k + 40)), **kw)
     assert h >= 1 and r == 0 and c["rank_count"] >= 1 and c["bucket_count"] == 0, (k, h, r, c)
+    # two words and more with FOUR HBM passes (k = 40, 200: five — bits above the key in the top byte; k = 64: six): the passes move (key top, record number) pairs of
+    # 8 bytes, the records stay where k_expand wrote them and k_bucket_rank gathers them by number
+    assert (c["indirect"] >= 1) == (k in (55, 127, 70)), (k, c)
 # every k-mer a few hundred times: buckets longer than the room at the end of a window, tiles longer than the capacity -> taken in chunks, nothing comes back
 for k, glen, err in ((27, 2000, 0.0), (27, 600, 0.002), (55, 1500, 0.0)):
     h, r, c = check(k, capi.synth_bins(seed=3, genome_len=glen, n_reads=700, k=k, n_bins=4, err=err, n_threads=1), lut_prefix_len=3)
