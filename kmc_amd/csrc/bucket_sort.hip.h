@@ -715,8 +715,7 @@ __global__ void __launch_bounds__(BrCfg<SIZE>::THREADS, BR_MIN_WAVES) k_bucket_r
 				y[2 * w] = (u32)key[r][w];
 				y[2 * w + 1] = (u32)(key[r][w] >> 32);
 			}
-#pragma unroll 2
-			for (u32 q = bstart; q < bend; ++q) { /* records before this one: smaller ones, and equal ones that stand in front of it */
+			auto count_one = [&](u32 q) { /* records before this one: smaller ones, and equal ones that stand in front of it */
 				u64 o[SIZE];
 				load_rec<SIZE>(s_key + (size_t)q * SIZE, o);
 				u32 x[2 * SIZE];
@@ -726,7 +725,14 @@ __global__ void __launch_bounds__(BrCfg<SIZE>::THREADS, BR_MIN_WAVES) k_bucket_r
 					x[2 * w + 1] = (u32)(o[w] >> 32);
 				}
 				br_rank_add_less<2 * SIZE>(rank, x, q, y, me);
+			};
+			u32 q = bstart;
+			for (; q + 2 <= bend; q += 2) { /* two chains per iteration (a `#pragma unroll 2` is refused around the inline assembly) */
+				count_one(q);
+				count_one(q + 1);
 			}
+			if (q < bend)
+				count_one(q);
 			place[r] = bstart + rank;
 		}
 	}
