@@ -645,11 +645,13 @@ __global__ void __launch_bounds__(PARSE_BLOCK) k_parse_packs(const GrpParse gp, 
 /* ------------------------------------------------------------------------------------------------ expand
  * Fully parallel over EXP_CHUNK-byte slices of the image (packs no longer matter): a workgroup reads its slice and
  * the slice's start bits, lists the super-k-mers that START in it (position, first k-mer index) in LDS, gets the
- * slice's k-mer offset by a 64-bit decoupled look-back over slices, and then runs one THREAD per k-mer: binary search
- * of the super-k-mer in the LDS list, window extraction from the LDS copy of the bytes, reverse complement by bit
- * tricks (kmer_ops.h), canonical = min; consecutive threads write consecutive records. The per-pass byte histograms
- * of the radix sort are accumulated in LDS on the way (one global flush per persistent workgroup), which removes the
- * separate 8 B/record histogram read of the first version. */
+ * slice's k-mer offset by a 64-bit decoupled look-back over slices, and then runs one THREAD per k-mer: its super-k-mer
+ * from one start bit per k-mer + per-row counts (round 4; a binary search of the list in round 1, a per-k-mer index
+ * built by windowed max-scans in rounds 2-3), window extraction from the LDS copy of the bytes by funnel shifts, reverse
+ * complement by bit tricks (kmer_ops.h), canonical = min; consecutive threads write consecutive records. The byte
+ * histograms of the sort's HBM passes are accumulated in LDS on the way (one global flush per persistent workgroup),
+ * which removes the separate 8 B/record histogram read of the first version; for records of two words and more the
+ * (key top, record number) pair of the indirect sort is written next to the record (kmc_hip.hip run_group_device_t). */
 #ifndef EXP_BLOCK_THREADS
 #define EXP_BLOCK_THREADS 512 /* measured on the 1.65 G k-mer bin: 256 thr 13.7 ms, 512 thr 9.2 ms, 1024 thr 12.1 ms */
 #endif
