@@ -496,7 +496,9 @@ SortPlan plan_sort(u64 n, u32 key_bytes, u32 key_bits, bool classic, bool fused 
 		}
 	}
 	if (sp.top < key_bytes && sp.top >= 1) { /* finer buckets after a redo, while that still saves passes and the bucket number fits 32 bits */
-		const u32 extra = g_extra_top.load(std::memory_order_relaxed);
+		/* (not for the rank path since round 4: a tile with a bucket beyond LDS goes to k_giant_tiles, and what still comes back is ONE k-mer repeated a million
+		 * times — no number of passes splits that; a fifth pass would only cost every later group its time, and records of two words and more their indirect sort) */
+		const u32 extra = rank ? 0u : g_extra_top.load(std::memory_order_relaxed);
 		sp.top = std::min(std::max(sp.top, std::min(sp.top + extra, rank ? 6u : 4u)), key_bytes);
 		if (sp.top + 2 > key_bytes)
 			sp.top = key_bytes;
