@@ -40,6 +40,9 @@
                          * without records still walk through the kernel: windows of 2/3 32.4, of 5/6 33.4, of 11/12 33.5 Gk-mers/s on the quarter workload).
                          * A tile that outgrows the capacity is taken in two chunks of whole buckets */
 #endif
+#ifndef BR_INDIRECT_MIN_SIZE
+#define BR_INDIRECT_MIN_SIZE 2 /* = INDIRECT_MIN_WORDS of kmc_hip.hip at most */
+#endif
 #ifndef BR_MIN_WAVES
 #define BR_MIN_WAVES 6 /* waves per SIMD the register allocator must leave room for: two workgroups of 12 waves per CU (<= 80 VGPRs; it takes 62) */
 #endif
@@ -477,7 +480,7 @@ __global__ void __launch_bounds__(BrCfg<SIZE>::THREADS, BR_MIN_WAVES) k_bucket_r
 	const u32 crel = wave * (ITEMS * 64); /* the wave owns ITEMS rows of 64 consecutive records */
 	const u32 bsh = 64 - hbits;
 	auto bucket_of = [&](const u64(&x)[SIZE]) -> u64 { return hbits ? bs_p64<SIZE>(x, key_bits) >> bsh : 0ull; };
-	const u64 *__restrict__ rec_base = gr.rec_base; /* indirect: `recs` are pairs */
+	const u64 *__restrict__ rec_base = SIZE >= BR_INDIRECT_MIN_SIZE ? gr.rec_base : nullptr; /* indirect: `recs` are pairs (never for one-word records: folded away at compile time) */
 	auto bucket_at = [&](u64 i) -> u64 {
 		if (rec_base)
 			return recs[i] >> 32; /* the top four key bytes ARE the bucket number: the bits above the key in the top byte are zero (kmc_hip.hip: hbits = 32 - those bits) */

@@ -47,6 +47,7 @@ VARIANTS = {
     "combo1": ["-DRS_WORDS_PER_THREAD_1=10", "-DRS_STAGES=2", "-DEXP_CHUNK_BYTES=16384", "-DCP_BLOCK_THREADS=512"],
     "exp8k": ["-DEXP_CHUNK_BYTES=8192"],  # k_expand occupancy: 27 KB of LDS per workgroup (4 per CU) instead of 49.5 (3)
     "ind3": ["-DINDIRECT_MIN_WORDS=3"],  # two-word records through the HBM passes themselves (the default sorts them through pairs too: 16-byte gathers, half of every HBM sector wasted, still +7 %)
+    "brind1": ["-DBR_INDIRECT_MIN_SIZE=1"],  # k_bucket_rank<1> with the indirect-sort branches decided at run time (as before the compile-time guard)
     "expcut1": ["-DEXP_CUT=1"],  # k_expand without its k-mer loop (phase costs; output garbage)
     "nohist": ["-DEXP_NO_HIST"],  # expand without the fused histograms (sort output is garbage): what do the LDS atomics cost?
     "exp256": ["-DEXP_BLOCK_THREADS=256"],
