@@ -526,18 +526,35 @@ __global__ void __launch_bounds__(BrCfg<SIZE>::THREADS, BR_MIN_WAVES) k_bucket_r
 	u64 *__restrict__ T = recs + c0 * (rec_base ? 1 : SIZE);
 
 	u64 key[ITEMS][SIZE];
+	if (rec_base) { /* a gather of whole records by number (16+ bytes each: one or two HBM sectors). Every row's pair first, then every row's record: two round trips
+	                 * to HBM — written row by row, each row's pair load waited for the row before (eight round trips per tile of two-word records) */
+		u32 number[ITEMS];
 #pragma unroll
-	for (int r = 0; r < ITEMS; ++r) {
-		const u32 idx = crel + r * 64 + lane;
-		if (idx < len) {
-			if (rec_base) /* a gather of whole records by number: 24+ bytes each, one or two HBM sectors */
-				load_rec<SIZE>(rec_base + (size_t)(u32)T[idx] * SIZE, key[r]);
-			else
+		for (int r = 0; r < ITEMS; ++r) {
+			const u32 idx = crel + r * 64 + lane;
+			number[r] = (u32)T[idx < len ? idx : 0u]; /* (no branch around the load: the compiler waits for a load at the end of its branch) */
+		}
+#pragma unroll
+		for (int r = 0; r < ITEMS; ++r) {
+			const u32 idx = crel + r * 64 + lane;
+			load_rec<SIZE>(rec_base + (size_t)number[r] * SIZE, key[r]); /* rows behind the tile's end read record 0 and are cleared below */
+			if (idx >= len) {
+#pragma unroll
+				for (int w = 0; w < SIZE; ++w)
+					key[r][w] = 0;
+			}
+		}
+	} else {
+#pragma unroll
+		for (int r = 0; r < ITEMS; ++r) {
+			const u32 idx = crel + r * 64 + lane;
+			if (idx < len)
 				load_rec<SIZE>(T + (size_t)idx * SIZE, key[r]);
-		} else {
+			else {
 #pragma unroll
-			for (int w = 0; w < SIZE; ++w)
-				key[r][w] = 0;
+				for (int w = 0; w < SIZE; ++w)
+					key[r][w] = 0;
+			}
 		}
 	}
 	/* Bucket starts ("heads") and, from them, every record's bucket — as in k_bucket_count: a record's bucket is known by its ORDINAL among the tile's
