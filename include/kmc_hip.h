@@ -25,7 +25,8 @@
 extern "C" {
 #endif
 
-#define KMC_HIP_ABI_VERSION 3 /* 3: + kmc_hip_process_bins_submit/_wait (bound by the worker's loader), kmc_hip_process_bin_multi, kmc_hip_order_database_device */
+#define KMC_HIP_ABI_VERSION 4 /* 3: + kmc_hip_process_bins_submit/_wait (bound by the worker's loader), kmc_hip_process_bin_multi, kmc_hip_order_database_device;
+                               * 4: kmc_hip_split_params.part_kind (long-read parts) */
 
 enum {
 	KMC_HIP_OK = 0,
@@ -296,15 +297,22 @@ void kmc_hip_split_reads_free(kmc_hip_ctx *ctx, kmc_hip_s1_plan *plan);
  * larger buffer) and per bin the three sums a
  * collector keeps: bin_kmers (n_recs), bin_superkmers (n_super_kmers), bin_plus_x (n_plus_x_recs, kb_collector.h:72-118); *n_reads = titles
  * in the part. kmc_hip_split_set_map uploads CSignatureMapper's map (s_mapper.h:232; 4^signature_len + 1 entries) once per device.
- * Returns 0, a negative KMC_HIP_E* code, or KMC_HIP_UNCOVERED: the text is not what the kernels reproduce CSplitter::GetSeq on (blank lines,
- * quality of another length than its sequence, a lone '\r', a line of mem_part_pmm_reads symbols or more, ...) — nothing was produced and the
- * caller gives the part to the reference splitter. Calls on one (dev, slot) are serialised. */
+ * part_kind 1 = a part the reader labelled ReadType::long_read (queues.h:40: a record longer than the reader's buffer, handed out in parts that
+ * overlap by k - 1 symbols): an optional title, then symbols only (CSplitter::GetSeqLongRead, splitter.cpp:70-86). Lines of mem_part_pmm_reads
+ * symbols or more inside an ordinary part, and long-read parts, reach the reference's super-k-mer loop in pieces that overlap by k - 1 symbols
+ * (splitter.cpp:141-145, :226-231, :80-84); the kernels cut super-k-mers at the same piece starts, so the three sums agree with the reference's.
+ * Returns 0, a negative KMC_HIP_E* code, or KMC_HIP_UNCOVERED: the text is MALFORMED in a way CSplitter::GetSeq tolerates and the kernels do not
+ * reproduce (blank lines, quality of another length than its sequence, a lone '\r', control characters) — nothing was produced; the stage-1 worker
+ * stops the run with an error (it has no path into the reference splitter unless built with -DKMC_HIP_S1_REFERENCE_FALLBACK). Calls on one
+ * (dev, slot) are serialised. */
 #define KMC_HIP_UNCOVERED 1
 typedef struct kmc_hip_split_params {
 	uint32_t kmer_len, signature_len, n_bins, max_x; /* max_x: CKMCParams::max_x (0..3) */
 	uint32_t both_strands;
 	uint32_t file_type;                              /* 0 = FASTA (one line per sequence), 1 = FASTQ */
 	uint64_t line_cap;                               /* CKMCParams::mem_part_pmm_reads */
+	uint32_t part_kind;                              /* 0 = whole records (ReadType::normal_read), 1 = ReadType::long_read */
+	uint32_t reserved;                               /* 0 */
 } kmc_hip_split_params;
 int kmc_hip_split_set_map(kmc_hip_ctx *ctx, int dev, const int32_t *sig_to_bin, uint32_t signature_len);
 int kmc_hip_split_part(kmc_hip_ctx *ctx, int dev, int slot, const kmc_hip_split_params *p, const uint8_t *text, uint64_t size, uint8_t *recs,

@@ -2877,7 +2877,7 @@ int kmc_hip_debug_split_reads(kmc_hip_ctx *ctx, int dev, const int8_t *codes, ui
 	k_s1_signatures<<<dim3((u32)tiles), dim3(S1_BLOCK), 0, s.stream>>>((const int8_t *)d_codes, n, kmer_len, signature_len, (u32 *)d_sig);
 	k_s1_cut<false><<<dim3((u32)ctiles), dim3(S1_BLOCK), 0, s.stream>>>((const u32 *)d_sig, (const int8_t *)nullptr, 0u, n, kmer_len,
 	                                                                      (u64 *)d_status, (u64 *)d_status + ctiles, (u32 *)d_small + 2, (u64 *)d_pos, (u32 *)d_len,
-	                                                                     (u32 *)d_ssig, sk_cap, (u64 *)d_small, err_ptr(s));
+	                                                                     (u32 *)d_ssig, sk_cap, (u64 *)d_small, (const u64 *)nullptr, err_ptr(s));
 	S1CHK(hipGetLastError());
 	u64 cnt = 0;
 	S1CHK(hipMemcpyAsync(&cnt, d_small, 8, hipMemcpyDeviceToHost, s.stream));
@@ -2967,7 +2967,7 @@ int kmc_hip_split_reads_plan(kmc_hip_ctx *ctx, int dev, const int8_t *d_codes, u
 		S1CHK(hipMemsetAsync(d_small, 0, 64, s.stream));
 		k_s1_cut<true><<<dim3((u32)tiles), dim3(S1_BLOCK), 0, s.stream>>>((const u32 *)nullptr, d_codes, signature_len, n, kmer_len, (u64 *)d_status,
 		                                                                    (u64 *)d_status + tiles, (u32 *)d_small + 2, (u64 *)p->d_pos, (u32 *)p->d_len,
-		                                                                    (u32 *)p->d_ssig, cap, (u64 *)d_small, (u32 *)d_small + 4);
+		                                                                    (u32 *)p->d_ssig, cap, (u64 *)d_small, (const u64 *)nullptr, (u32 *)d_small + 4);
 		S1CHK(hipGetLastError());
 		u64 small[3] = {0, 0, 0}; /* count | ticket | the cut's own error word: a short guess must not poison the stream's sticky word */
 		S1CHK(hipMemcpyAsync(small, d_small, sizeof small, hipMemcpyDeviceToHost, s.stream));
@@ -3088,7 +3088,7 @@ int kmc_hip_split_part(kmc_hip_ctx *ctx, int dev, int slot, const kmc_hip_split_
 	if (!p || (size && !text) || !recs || !recs_bytes || !bin_off || !bin_bytes || !bin_kmers || !bin_superkmers || !bin_plus_x || !n_reads || slot < 0 || slot >= N_SLOTS)
 		return fail(KMC_HIP_EINVAL, "kmc_hip_split_part: bad argument");
 	if (p->kmer_len < 1 || p->kmer_len > (uint32_t)S1_MAX_K || p->signature_len < 5 || p->signature_len > 11 || p->signature_len > p->kmer_len || p->n_bins < 1 ||
-	    p->n_bins > (uint32_t)S1_MAX_BINS || p->max_x > 3 || p->file_type > 1 || (p->max_x && p->kmer_len < 4))
+	    p->n_bins > (uint32_t)S1_MAX_BINS || p->max_x > 3 || p->file_type > 1 || p->part_kind > 1 || (p->max_x && p->kmer_len < 4))
 		return fail(KMC_HIP_EINVAL, "kmc_hip_split_part: unsupported parameters");
 	Dev &d = *ctx->devs[dev];
 	if (!d.d_sig_map || d.sig_map_entries != (1u << (2 * p->signature_len)) + 1)
@@ -3115,6 +3115,13 @@ int kmc_hip_split_part(kmc_hip_ctx *ctx, int dev, int slot, const kmc_hip_split_
 	sp.d_sig_to_bin = d.d_sig_map;
 	sp.sorted_emit = getenv("KMC_HIP_S1_SORTED_EMIT") != nullptr; /* the alternative emit (stage1_kernels.hip.h): to be measured before it becomes the default */
 	S1PartResult R;
+	u64 long_reads = 0;
+	if (p->part_kind == 1) { /* a long-read part: the title (if the part has it) is taken off here, the symbols go up from an aligned buffer */
+		const u64 skip = s1_long_read_title(text, size, p->file_type, long_reads);
+		text += skip;
+		size -= skip;
+		sp.lines_per_record = 0;
+	}
 	try {
 		uint8_t *d_text = (uint8_t *)be.alloc(size + 16);
 		if (size) {
@@ -3123,6 +3130,8 @@ int kmc_hip_split_part(kmc_hip_ctx *ctx, int dev, int slot, const kmc_hip_split_
 				return fail_hip("hipMemcpyAsync(text)", e);
 		}
 		const int rc = s1_split_part(be, d_text, size, size && text[size - 1] == '\n', sp, R);
+		if (p->part_kind == 1)
+			R.n_reads = long_reads;
 		if (rc == S1_CHAIN_UNCOVERED)
 			return KMC_HIP_UNCOVERED;
 		if (rc != S1_CHAIN_OK)

@@ -25,7 +25,8 @@
 #include "stage1_kernels.hip.h"
 
 struct S1PartParams {
-	u32 k, m, n_bins, max_x, both_strands, lines_per_record; /* lines_per_record: 2 = FASTA, 4 = FASTQ */
+	u32 k, m, n_bins, max_x, both_strands, lines_per_record; /* lines_per_record: 2 = FASTA, 4 = FASTQ, 0 = the symbols of a long-read part (the caller
+	                                                           * has taken the title off: d_text starts at its end of line, GetSeqLongRead splitter.cpp:70-86) */
 	u64 line_cap;                                             /* mem_part_pmm_reads */
 	const int *d_sig_to_bin;                                  /* device: 4^m + 1 entries */
 	u64 sk_guess_div = 8;                                     /* first guess of the number of super-k-mers: symbols / this + 4096 */
@@ -40,6 +41,21 @@ struct S1PartResult {
 };
 enum { S1_CHAIN_OK = 0, S1_CHAIN_UNCOVERED = 1, S1_CHAIN_DEVICE_ERROR = -1, S1_CHAIN_BACKEND_FAILURE = -2 };
 
+/* A long-read part (ReadType::long_read, queues.h:40; CSplitter::GetSeqLongRead, splitter.cpp:70-86): if it starts with the format's marker it carries the
+ * read's title — one read counted, and the symbols start AT the title's end of line (that byte is a symbol like every other: an invalid one). Returns the
+ * number of bytes to take off the front; the rest goes through s1_split_part with lines_per_record = 0. */
+static inline u64 s1_long_read_title(const uint8_t *text, u64 size, u32 file_type /* 0 FASTA, 1 FASTQ */, u64 &n_reads)
+{
+	n_reads = 0;
+	if (!size || text[0] != (file_type == 1 ? '@' : '>'))
+		return 0;
+	n_reads = 1;
+	u64 p = 0;
+	while (p < size && text[p] != '\n' && text[p] != '\r')
+		++p;
+	return p;
+}
+
 template <class B> int s1_split_part(B &be, const uint8_t *d_text, u64 size, bool text_ends_with_newline, const S1PartParams &P, S1PartResult &R)
 {
 	const u32 nb = P.n_bins, lpr = P.lines_per_record;
@@ -51,17 +67,24 @@ template <class B> int s1_split_part(B &be, const uint8_t *d_text, u64 size, boo
 	R.bin_plus_x.assign(nb, 0);
 	if (!size)
 		return S1_CHAIN_OK;
-	/* small block: [0] '\\n' count | [1] code bytes | [2] super-k-mers | [3] lo: ticket, hi: error word */
+	/* small block: [0] '\\n' count | [1] code bytes | [2] super-k-mers | [3] lo: ticket, hi: error word | [4] != 0: some code carries S1_PIECE_MARK */
 	u64 *d_small = (u64 *)be.alloc(64);
 	u32 *d_ticket = (u32 *)(d_small + 3), *d_err = d_ticket + 1;
+	u64 *d_has_marks = d_small + 4;
 	u64 small[4];
-	/* ---- text -> codes. A line of real reads is tens of bytes; text with more line ends than size / 4 goes to the reference splitter. */
-	const u64 nl_cap = size / 4 + 1024;
+	/* pieces of an over-long line start every `stride` symbols (S1_PIECE_MARK); k_s1_cut takes at most one mark per workgroup window */
+	if (P.line_cap < (u64)P.k + S1_WG_TILE + 2)
+		return S1_CHAIN_UNCOVERED;
+	const u64 stride = P.line_cap - P.k + 1;
+	/* ---- text -> codes. A line of real reads is tens of bytes; text with more line ends than size / 4 is not taken. */
+	const u64 nl_cap = lpr ? size / 4 + 1024 : 1;
 	const u32 tiles = (u32)((size + S1_TXT_TILE - 1) / S1_TXT_TILE);
 	int8_t *d_codes = (int8_t *)be.alloc(size + 16);
 	u64 *d_nl = (u64 *)be.alloc(nl_cap * 8);
+	u64 *d_seq_start = (u64 *)be.alloc_uninit((nl_cap / (lpr ? lpr : 1) + 2) * 8);
 	u64 *d_status = (u64 *)be.alloc((size_t)tiles * 16);
-	S1_LAUNCH(B, be, k_s1_text_to_codes, dim3(tiles), dim3(S1_BLOCK), d_text, size, lpr, d_status, d_status + tiles, d_ticket, d_codes, d_nl, nl_cap, d_small, d_err);
+	S1_LAUNCH(B, be, k_s1_text_to_codes, dim3(tiles), dim3(S1_BLOCK), d_text, size, lpr, d_status, d_status + tiles, d_ticket, d_codes, d_nl, nl_cap, d_seq_start, d_small,
+	          d_err);
 	if (!be.d2h(small, d_small, sizeof small))
 		return S1_CHAIN_BACKEND_FAILURE;
 	u32 err = (u32)(small[3] >> 32);
@@ -73,9 +96,13 @@ template <class B> int s1_split_part(B &be, const uint8_t *d_text, u64 size, boo
 	}
 	const u64 n_lines = small[0], n = small[1];
 	R.n_symbols = n;
-	const u64 lines = n_lines + (text_ends_with_newline ? 0 : 1); /* titles in the part: every lpr-th line, an unterminated last line included */
-	R.n_reads = (lines + lpr - 1) / lpr;
-	S1_LAUNCH(B, be, k_s1_check_records, dim3((u32)((n_lines / lpr + 1 + 255) / 256)), dim3(256), d_text, size, (const u64 *)d_nl, n_lines, lpr, P.line_cap, d_err);
+	if (lpr) {
+		const u64 lines = n_lines + (text_ends_with_newline ? 0 : 1); /* titles in the part: every lpr-th line, an unterminated last line included */
+		R.n_reads = (lines + lpr - 1) / lpr;
+		S1_LAUNCH(B, be, k_s1_check_records, dim3((u32)((n_lines / lpr + 1 + 255) / 256)), dim3(256), d_text, size, (const u64 *)d_nl, n_lines, lpr, P.line_cap, stride,
+		          (const u64 *)d_seq_start, d_codes, d_has_marks, d_err);
+	} else if (n > stride) /* n_reads of a long-read part: the caller knows whether it took a title off */
+		S1_LAUNCH(B, be, k_s1_mark_raw, dim3(1), dim3(256), d_codes, n, stride, d_has_marks);
 	/* ---- codes -> super-k-mers. Their number is only known afterwards: a guess, and a second cut with the exact number when it was short. */
 	u64 n_sk = 0, cap = n / P.sk_guess_div + 4096;
 	u64 *d_pos = nullptr;
@@ -93,7 +120,7 @@ template <class B> int s1_split_part(B &be, const uint8_t *d_text, u64 size, boo
 			}
 			be.zero(d_ticket, 4);
 			S1_LAUNCH(B, be, (k_s1_cut<true>), dim3(ct), dim3(S1_BLOCK), (const u32 *)nullptr, (const int8_t *)d_codes, P.m, n, P.k, d_cstat, d_cstat + ct, d_ticket, d_pos,
-			          d_len, d_sig, cap, d_small + 2, d_err);
+			          d_len, d_sig, cap, d_small + 2, (const u64 *)d_has_marks, d_err);
 			if (!be.d2h(small, d_small, sizeof small))
 				return S1_CHAIN_BACKEND_FAILURE;
 			err = (u32)(small[3] >> 32);

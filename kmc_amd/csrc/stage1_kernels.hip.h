@@ -30,6 +30,12 @@
 constexpr int S1_BLOCK = 256, S1_PER = 4, S1_TILE = S1_BLOCK * S1_PER; /* positions per workgroup */
 constexpr int S1_MAX_K = 256;
 constexpr u32 S1_NOSIG = 0xFFFFFFFFu;
+/* A line of mem_part_pmm_reads symbols or more reaches CSplitter::ProcessReads in pieces that overlap by k - 1 symbols (splitter.cpp:141-145,
+ * :226-231; a long-read part likewise, GetSeqLongRead :80-84), and every piece starts its super-k-mers afresh: the k-mer that starts at a
+ * multiple of stride = mem_part_pmm_reads - k + 1 (counted from the line's first symbol) never shares a super-k-mer with the k-mer before it.
+ * k_s1_check_records / k_s1_mark_raw put this bit into the code of those positions (codes are 0..3 or negative: every consumer masks with 3
+ * or tests the sign), k_s1_cut starts a run there. The k-mers — and so the database — do not depend on it; "Total no. of super-k-mers" does. */
+constexpr int8_t S1_PIECE_MARK = 0x40;
 
 /* norm of an m-mer (kmc_api/mmer.h:39-95: the smaller of the m-mer and its reverse complement among the ALLOWED ones, 4^m if neither is)
  * computed, not looked up: the reference's table is 1 MB at m = 9, and one gather per position from it made the L2 -> L1 path the limit of
@@ -229,9 +235,10 @@ __host__ __device__ inline u64 s1_cut_tiles(u64 n) { return (n + S1_WG_TILE - 1)
 template <bool FUSED>
 __global__ void __launch_bounds__(S1_BLOCK) k_s1_cut(const u32 *__restrict__ sig, const int8_t *__restrict__ codes, u32 m, u64 n, u32 k,
                                                       u64 *status_last, u64 *status_cnt, u32 *ticket_ctr, u64 *__restrict__ sk_pos, u32 *__restrict__ sk_len,
-                                                      u32 *__restrict__ sk_sig, u64 sk_cap, u64 *n_sk, u32 *err)
+                                                      u32 *__restrict__ sk_sig, u64 sk_cap, u64 *n_sk, const u64 *has_marks, u32 *err)
 {
 	__shared__ u32 s_sig[S1_WG_TILE + 2]; /* signatures of positions w0 - 1 .. w0 + S1_WG_TILE */
+	__shared__ u32 s_mark;
 	__shared__ u64 s_tmp64[S1_BLOCK / 64 + 1];
 	__shared__ u32 s_tmp32[S1_BLOCK / 64 + 1];
 	__shared__ u64 s_carry_last1, s_carry_cnt;
@@ -255,6 +262,26 @@ __global__ void __launch_bounds__(S1_BLOCK) k_s1_cut(const u32 *__restrict__ sig
 			const long long q = (long long)w0 - 1 + (long long)i;
 			s_sig[i] = (q >= 0 && (u64)q < n) ? sig[q] : S1_NOSIG;
 		}
+		__syncthreads();
+	}
+	if (FUSED && has_marks && *has_marks) {
+		/* S1_PIECE_MARK somewhere in the part (uniform, rare: a line of mem_part_pmm_reads symbols or more): a marked position starts a run whatever
+		 * the signatures say. Marks are >= stride positions apart and the host refuses a stride within a workgroup's window, so the window holds at
+		 * most one: the signatures from it on get bit 31 — they then differ from the one before the mark and from nothing else they are compared with. */
+		if (tid == 0)
+			s_mark = 0xFFFFFFFFu;
+		__syncthreads();
+		for (u32 i = tid; i < (u32)S1_WG_TILE + 2; i += S1_BLOCK) {
+			const long long q = (long long)w0 - 1 + (long long)i;
+			if (q >= 0 && (u64)q < n && (codes[q] & 0xC0) == S1_PIECE_MARK)
+				atomicMin(&s_mark, i);
+		}
+		__syncthreads();
+		const u32 mk = s_mark;
+		if (mk != 0xFFFFFFFFu)
+			for (u32 i = tid; i < (u32)S1_WG_TILE + 2; i += S1_BLOCK)
+				if (i >= mk && s_sig[i] != S1_NOSIG)
+					s_sig[i] |= 0x80000000u;
 		__syncthreads();
 	}
 	/* Pass A, per sub-tile: run starts inside this thread's S1_PER positions (valid, and the k-mer before is invalid or has another
@@ -344,7 +371,7 @@ __global__ void __launch_bounds__(S1_BLOCK) k_s1_cut(const u32 *__restrict__ sig
 				if (idx < sk_cap) {
 					sk_pos[idx] = t0 + j - piece;
 					sk_len[idx] = k + piece;
-					sk_sig[idx] = s_sig[l0 + j + 1];
+					sk_sig[idx] = s_sig[l0 + j + 1] & 0x7FFFFFFFu;
 				} else
 					atomicOr(err, KERR_CAPACITY);
 				++idx;
@@ -521,7 +548,7 @@ __global__ void __launch_bounds__(256) k_s1_emit(const int8_t *__restrict__ code
  * '\r', a quality line of another length than its sequence: it skips quality by LENGTH, :281) is not reproduced — k_s1_check_records
  * recognises every such part, and the engine must hand those to the reference splitter. */
 constexpr int S1_TXT_PER = 16, S1_TXT_TILE = S1_BLOCK * S1_TXT_PER;
-constexpr u32 S1_TEXT_BAD = 16u; /* error bit: the part is outside what k_s1_text_to_codes reproduces */
+constexpr u32 S1_TEXT_BAD = 0x1000u; /* error bit: the part is outside what k_s1_text_to_codes reproduces (its own bit: 0x10 is KERR_PEER) */
 
 __device__ __forceinline__ int8_t s1_symbol_code(uint8_t c)
 {
@@ -530,7 +557,8 @@ __device__ __forceinline__ int8_t s1_symbol_code(uint8_t c)
 }
 
 __global__ void __launch_bounds__(S1_BLOCK) k_s1_text_to_codes(const uint8_t *__restrict__ text, u64 n, u32 lines_per_record, u64 *status_lines, u64 *status_out,
-                                                                u32 *ticket_ctr, int8_t *__restrict__ codes, u64 *__restrict__ nl_pos, u64 nl_cap, u64 *totals, u32 *err)
+                                                                u32 *ticket_ctr, int8_t *__restrict__ codes, u64 *__restrict__ nl_pos, u64 nl_cap, u64 *__restrict__ seq_start,
+                                                                u64 *totals, u32 *err)
 {
 	__shared__ u32 s_tmp[S1_BLOCK / 64 + 1];
 	__shared__ u64 s_carry;
@@ -558,6 +586,17 @@ __global__ void __launch_bounds__(S1_BLOCK) k_s1_text_to_codes(const uint8_t *__
 			c[j] = p0 + j < n ? text[p0 + j] : (uint8_t)0;
 	}
 	c[S1_TXT_PER] = p0 + S1_TXT_PER < n ? text[p0 + S1_TXT_PER] : (uint8_t)0;
+	if (lines_per_record == 0) {
+		/* a LONG-READ part behind its title (queues.h:40; CSplitter::GetSeqLongRead, splitter.cpp:70-86): no lines, no records — every byte is a
+		 * symbol, the ends of line among them (their code is negative like any other byte that is not ACGT) */
+		if (tile == num_tiles - 1 && tid == 0)
+			totals[1] = n;
+#pragma unroll
+		for (int j = 0; j < S1_TXT_PER; ++j)
+			if (p0 + j < n)
+				codes[p0 + j] = s1_symbol_code(c[j]);
+		return;
+	}
 	u32 my_nl = 0;
 #pragma unroll
 	for (int j = 0; j < S1_TXT_PER; ++j)
@@ -573,7 +612,8 @@ __global__ void __launch_bounds__(S1_BLOCK) k_s1_text_to_codes(const uint8_t *__
 		}
 	}
 	__syncthreads();
-	u64 line = s_carry + nl_before;
+	const u64 line0 = s_carry + nl_before;
+	u64 line = line0;
 	__syncthreads();
 	/* which bytes are kept: every byte of a sequence line except a '\r' (which must be followed by '\n'), the '\n' included (it becomes the separator) */
 	u32 keep = 0, n_keep = 0;
@@ -610,17 +650,35 @@ __global__ void __launch_bounds__(S1_BLOCK) k_s1_text_to_codes(const uint8_t *__
 	}
 	__syncthreads();
 	u64 at = s_carry + keep_before;
+	line = line0;
 #pragma unroll
-	for (int j = 0; j < S1_TXT_PER; ++j)
+	for (int j = 0; j < S1_TXT_PER; ++j) {
 		if (keep & (1u << j))
 			codes[at++] = c[j] == '\n' ? (int8_t)-1 : s1_symbol_code(c[j]);
+		if (p0 + j < n && c[j] == '\n') {
+			/* the end of a title line: the record's sequence starts at the next code (k_s1_check_records marks the pieces of an over-long line from there) */
+			if ((line & (u64)(lines_per_record - 1)) == 0 && line < nl_cap)
+				seq_start[line / lines_per_record] = at;
+			++line;
+		}
+	}
+}
+
+/* The piece starts of a long-read part (see S1_PIECE_MARK): every stride-th position of the raw code stream. One workgroup. */
+__global__ void __launch_bounds__(256) k_s1_mark_raw(int8_t *__restrict__ codes, u64 n, u64 stride, u64 *has_marks)
+{
+	for (u64 p = ((u64)threadIdx.x + 1) * stride; p < n; p += 256 * stride) {
+		if (codes[p] >= 0)
+			codes[p] |= S1_PIECE_MARK;
+		*has_marks = 1;
+	}
 }
 
 /* One thread per record (n_lines / lines_per_record of them; a FASTA part may end inside its last sequence line): the title starts with the
  * marker, the third line of a FASTQ record with '+', sequence and quality have one length, the sequence is shorter than line_cap
  * (mem_part_pmm_reads: GetSeq cuts longer lines into overlapping pieces). Raises S1_TEXT_BAD. */
 __global__ void __launch_bounds__(256) k_s1_check_records(const uint8_t *__restrict__ text, u64 n, const u64 *__restrict__ nl_pos, u64 n_lines, u32 lines_per_record,
-                                                            u64 line_cap, u32 *err)
+                                                            u64 line_cap, u64 stride, const u64 *__restrict__ seq_start, int8_t *__restrict__ codes, u64 *has_marks, u32 *err)
 {
 	const u64 r = (u64)blockIdx.x * 256 + threadIdx.x;
 	const u64 first = r * lines_per_record; /* number of the record's title line */
@@ -633,22 +691,32 @@ __global__ void __launch_bounds__(256) k_s1_check_records(const uint8_t *__restr
 		const u64 b = ln ? nl_pos[ln - 1] + 1 : 0, e = nl_pos[ln];
 		return e - b - ((e > b && text[e - 1] == '\r') ? 1 : 0);
 	};
+	u64 seq_len = 0;
 	if (lines_per_record == 4) {
 		if (first + 4 > n_lines)
 			bad = true; /* a FASTQ record must be whole, every line terminated (GetSeq drops it otherwise, splitter.cpp:222-223, :283-284) */
 		else {
 			bad = bad || text[nl_pos[first + 1] + 1] != '+';
-			bad = bad || line_len(first + 1) != line_len(first + 3);
-			bad = bad || line_len(first + 1) >= line_cap; /* GetSeq hands such a line out in overlapping pieces (splitter.cpp:226-231) */
+			seq_len = line_len(first + 1);
+			bad = bad || seq_len != line_len(first + 3);
 		}
 	} else if (first + 1 > n_lines)
 		bad = true; /* a FASTA title without its end of line */
 	else {
 		const u64 b = nl_pos[first] + 1, e = first + 1 < n_lines ? nl_pos[first + 1] : n;
-		bad = bad || e - b >= line_cap;
+		seq_len = e - b - ((e > b && text[e - 1] == '\r') ? 1 : 0);
 	}
-	if (bad)
+	if (bad) {
 		atomicOr(err, S1_TEXT_BAD);
+		return;
+	}
+	if (seq_len >= line_cap) { /* GetSeq hands such a line out in overlapping pieces (splitter.cpp:141-145, :226-231): S1_PIECE_MARK */
+		const u64 s0 = seq_start[r];
+		for (u64 p = stride; p < seq_len; p += stride)
+			if (codes[s0 + p] >= 0)
+				codes[s0 + p] |= S1_PIECE_MARK;
+		*has_marks = 1;
+	}
 }
 
 /* n_plus_x_recs per bin: how many (k+x)-mer records the reference's stage 2 expands each super-k-mer into (kb_collector.cpp:83-100,
@@ -676,13 +744,14 @@ __global__ void __launch_bounds__(256) k_s1_bin_plus_x(const int8_t *__restrict_
 			total = 1 + (n - k) / (max_x + 1);
 		else {
 			const int8_t *q = codes + sk_pos[i];
-			u32 fwd = ((u32)q[0] << 6) | ((u32)q[1] << 4) | ((u32)q[2] << 2) | (u32)q[3];
-			u32 rc = ((3u - q[k - 1]) << 6) | ((3u - q[k - 2]) << 4) | ((3u - q[k - 3]) << 2) | (3u - q[k - 4]);
+			/* & 3: a code may carry S1_PIECE_MARK */
+			u32 fwd = ((u32)(q[0] & 3) << 6) | ((u32)(q[1] & 3) << 4) | ((u32)(q[2] & 3) << 2) | (u32)(q[3] & 3);
+			u32 rc = ((3u - (q[k - 1] & 3)) << 6) | ((3u - (q[k - 2] & 3)) << 4) | ((3u - (q[k - 3] & 3)) << 2) | (3u - (q[k - 4] & 3));
 			u32 state = fwd < rc ? 0u : (rc < fwd ? 1u : 2u), run = 0;
 			total = 0;
 			for (u32 t = 0; t + k < n; ++t) {
-				rc = (rc >> 2) | ((3u - q[k + t]) << 6);
-				fwd = ((fwd << 2) & 0xFFu) | (u32)q[4 + t];
+				rc = (rc >> 2) | ((3u - (q[k + t] & 3)) << 6);
+				fwd = ((fwd << 2) & 0xFFu) | (u32)(q[4 + t] & 3);
 				const u32 st = fwd < rc ? 0u : (rc < fwd ? 1u : 2u);
 				if (st == state) {
 					if (st == 2)

@@ -63,7 +63,7 @@ struct HipSplitEngine : KmcSplitEngine {
 		map_hash = h ? h : 1;
 	}
 	std::string last_error() override { return err; }
-	int split_part(const uint8_t *text, uint64_t size, KmcSplitResult &out) override
+	int split_part(const uint8_t *text, uint64_t size, bool long_read, KmcSplitResult &out) override
 	{
 		if (!g_split.ctx) {
 			err = g_split.err.empty() ? "HIP split engine not initialised" : g_split.err;
@@ -87,6 +87,8 @@ struct HipSplitEngine : KmcSplitEngine {
 		hp.both_strands = P.both_strands ? 1u : 0u;
 		hp.file_type = (uint32_t)P.file_type;
 		hp.line_cap = P.line_cap;
+		hp.part_kind = long_read ? 1u : 0u;
+		hp.reserved = 0;
 		/* records of real reads take ~0.3 bytes per symbol; text whose k-mers are nearly all their own super-k-mer needs more: second call */
 		if (recs.size() < size + 256ull * (P.n_bins + 1))
 			recs.resize(size + 256ull * (P.n_bins + 1));

@@ -5,8 +5,8 @@
  * Drop-in for the reference's CWSplitter (splitter.h:100-113, splitter.cpp:814-867): the same class name, constructor, operator()(),
  * GetTotal() and destructor, so CKMC<SIZE>::ProcessStage1_impl (kmc.h:1274-1362) builds against it unchanged. Compiled in with
  * `-include kb_splitter_plugin.h` ahead of kmc_runner.cpp; the reference's own splitter.cpp is compiled with -DCWSplitter=CWSplitter_ref
- * (oracle/Makefile), which is what this header declares first: CSplitter stays the reference's (statistics, small k, histogram estimation
- * use it directly) and CWSplitter_ref runs whenever the fast path below does not cover the job.
+ * (oracle/Makefile), which is what this header declares first: CSplitter stays the reference's for what is NOT this worker (stage 0's signature
+ * statistics, the small-k path and histogram estimation use it directly, kmc.h:1100-1200); this worker itself never calls it (see FAILS CLOSED below).
  *
  * Protocol kept from CWSplitter::operator() + CSplitter::ProcessReads + CKmerBinCollector:
  *   pq->pop(part, size, read_type) -> [engine: text -> sequences -> super-k-mers -> bin records] -> pmm_fastq->free(part)
@@ -19,10 +19,16 @@
  * The reference pushes a buffer when the next RECORD does not fit; here the unit is the part's piece for that bin (its three sums come
  * from the engine in one go), walked record by record only when a piece is larger than what an empty buffer holds.
  *
- * Falls back to the reference, per job: input other than FASTA / FASTQ, homopolymer compression, histogram estimation while counting;
- * per part: ReadType::long_read (the reader could not delimit whole records, queues.h:40), and any part the engine reports as
- * KMC_SPLIT_UNCOVERED (text on which it does not reproduce CSplitter::GetSeq) — our buffers are pushed first, then a reference CSplitter of
- * this thread takes the part.
+ * FAILS CLOSED (round 5): this worker has no path into the reference's CSplitter. What the engine does not cover stops the run through
+ * CCriticalErrorHandler with a message that names it —
+ *   per job : input other than FASTA / FASTQ (multi-line FASTA, BAM, KMC), homopolymer compression (-hc), histogram estimation while counting (--opt-out-size; -e alone runs the reference's estimate-only worker, not this one):
+ *             "use kmc_hip" (the reference's stage 1 + this library's stage 2) is the answer the message gives;
+ *   per part: KMC_SPLIT_UNCOVERED — MALFORMED text that CSplitter::GetSeq happens to tolerate (blank lines, a quality string of another length than its
+ *             sequence, control characters, a lone '\r').
+ * Parts the reader labelled ReadType::long_read (queues.h:40) and lines of mem_part_pmm_reads symbols or more go through the engine like any other.
+ * Only a build with -DKMC_HIP_S1_REFERENCE_FALLBACK (no shipped binary has it; oracle/_ref/kmc_emu_s1_fb is the test build) AND $KMC_HIP_S1_FALLBACK=1
+ * in the environment hands such jobs / parts to the reference (CWSplitter_ref / a CSplitter of this thread, our buffers pushed first) and says so on stderr;
+ * nothing run that way is covered by this repo's parity claims.
  */
 #ifndef KMC_AMD_KB_SPLITTER_PLUGIN_H
 #define KMC_AMD_KB_SPLITTER_PLUGIN_H
@@ -89,8 +95,11 @@ class CWSplitter {
 	CMemoryPool *pmm_fastq, *pmm_bins;
 	CKMCParams *params;
 	CKMCQueues *queues;
+#ifdef KMC_HIP_S1_REFERENCE_FALLBACK
 	std::unique_ptr<CWSplitter_ref> ref;    /* non-null: the reference worker runs the whole job */
-	std::unique_ptr<CSplitter> ref_splitter; /* long-read parts of this thread */
+	std::unique_ptr<CSplitter> ref_splitter; /* uncovered parts of this thread */
+	bool fallback_on = false;               /* $KMC_HIP_S1_FALLBACK=1 */
+#endif
 	std::unique_ptr<KmcSplitEngine> engine;
 	std::vector<BinBuf> bins;
 	uint32 kmer_len, max_x, buffer_size;
@@ -100,10 +109,15 @@ class CWSplitter {
 	uint64 st_parts = 0, st_long_parts = 0, st_uncovered_parts = 0, st_pieces = 0, st_cut_pieces = 0, st_pushes = 0, st_bytes = 0;
 	long long st_engine_ns = 0;
 
-	static bool covered(const CKMCParams &P)
+	static const char *uncovered_job(const CKMCParams &P)
 	{
-		return (P.file_type == InputType::FASTA || P.file_type == InputType::FASTQ) && !P.homopolymer_compressed &&
-		       P.estimateHistogramCfg != KMC::EstimateHistogramCfg::ESTIMATE_AND_COUNT_KMERS;
+		if (P.file_type != InputType::FASTA && P.file_type != InputType::FASTQ)
+			return "an input format other than FASTA / FASTQ (multi-line FASTA, BAM, KMC)";
+		if (P.homopolymer_compressed)
+			return "homopolymer compression (-hc)";
+		if (P.estimateHistogramCfg == KMC::EstimateHistogramCfg::ESTIMATE_AND_COUNT_KMERS)
+			return "histogram estimation while counting (--opt-out-size)";
+		return nullptr;
 	}
 
 	void push(uint32 bin_no) /* CKmerBinCollector::Flush, kb_collector.cpp:88-106 */
@@ -153,6 +167,7 @@ class CWSplitter {
 			at += len;
 		}
 	}
+#ifdef KMC_HIP_S1_REFERENCE_FALLBACK
 	/* the reference's own splitter for this part. Its collectors reserve n_bins pmm_bins buffers (one each, CKmerBinCollector's constructor), and the
 	 * pool is sized for n_splitters x n_bins buffers beyond the storer's share (kmc.h:491-501): a worker must never hold two sets. So ours go to the
 	 * storer first, and the reference splitter is completed (its collectors flushed and their buffers handed over) and dropped as soon as the part is
@@ -171,6 +186,7 @@ class CWSplitter {
 		n_reads += n;
 		ref_splitter.reset();
 	}
+#endif
 	void push_all()
 	{
 		for (uint32 i = 0; i < (uint32)bins.size(); ++i)
@@ -191,10 +207,27 @@ public:
 		max_x = Params.max_x;
 		both_strands = Params.both_strands;
 		buffer_size = Params.bin_part_size;
-		if (!covered(Params) || getenv("KMC_HIP_SPLITTER_REF")) {
-			ref = std::make_unique<CWSplitter_ref>(Params, Queues);
-			return;
+		if (const char *what = uncovered_job(Params)) {
+#ifdef KMC_HIP_S1_REFERENCE_FALLBACK
+			const char *fb = getenv("KMC_HIP_S1_FALLBACK");
+			if (fb && fb[0] == '1') {
+				static std::atomic<int> said{0};
+				if (!said++)
+					fprintf(stderr, "[kmc_hip stage 1] %s: the REFERENCE splitter runs stage 1 of this job (KMC_HIP_S1_FALLBACK=1); nothing of stage 1 is on the device\n", what);
+				ref = std::make_unique<CWSplitter_ref>(Params, Queues);
+				return;
+			}
+#endif
+			std::ostringstream ostr;
+			ostr << "Error: stage 1 on the device does not cover " << what << ". Run this job with kmc_hip (the reference's stage 1, stage 2 on the device).";
+			CCriticalErrorHandler::Inst().HandleCriticalError(ostr.str());
 		}
+#ifdef KMC_HIP_S1_REFERENCE_FALLBACK
+		{
+			const char *fb = getenv("KMC_HIP_S1_FALLBACK");
+			fallback_on = fb && fb[0] == '1';
+		}
+#endif
 		bins.resize(Params.n_bins);
 		KmcSplitParams sp;
 		sp.kmer_len = Params.kmer_len;
@@ -214,30 +247,39 @@ public:
 	void operator()()
 	{
 		KmcTimeline::mark_first_last("splitter: first worker started", nullptr);
+#ifdef KMC_HIP_S1_REFERENCE_FALLBACK
 		if (ref) {
 			(*ref)();
 			KmcTimeline::mark_first_last(nullptr, "splitter: last worker done");
 			return;
 		}
+#endif
 		while (!pq->completed()) {
 			uchar *part;
 			uint64 size;
 			ReadType read_type;
 			if (!pq->pop(part, size, read_type))
 				continue;
-			if (read_type != ReadType::normal_read) {
-				++st_long_parts;
-				to_reference(part, size, read_type);
-				continue;
-			}
+			if (read_type == ReadType::na) /* only the multi-line FASTA reader makes these (fastq_reader.cpp:253-341), and that format is refused above */
+				CCriticalErrorHandler::Inst().HandleCriticalError("Error: stage 1 on the device got a part of ReadType::na");
+			const bool long_read = read_type == ReadType::long_read;
+			st_long_parts += long_read ? 1 : 0;
 			KmcSplitResult r;
 			const auto t0 = std::chrono::steady_clock::now();
-			const int rc = engine->split_part(part, size, r);
+			const int rc = engine->split_part(part, size, long_read, r);
 			st_engine_ns += std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count();
 			if (rc == KMC_SPLIT_UNCOVERED) {
 				++st_uncovered_parts;
-				to_reference(part, size, read_type);
-				continue;
+#ifdef KMC_HIP_S1_REFERENCE_FALLBACK
+				if (fallback_on) {
+					to_reference(part, size, read_type);
+					continue;
+				}
+#endif
+				CCriticalErrorHandler::Inst().HandleCriticalError(
+				    "Error: stage 1 on the device: a part of the input is malformed FASTA / FASTQ text (a blank line, a quality string of another length than its "
+				    "sequence, a control character or a lone carriage return). The device splitter does not guess what such text means; "
+				    "run this input with kmc_hip (the reference's stage 1, stage 2 on the device).");
 			}
 			if (rc != 0) {
 				std::ostringstream ostr;
@@ -252,18 +294,11 @@ public:
 					append(b, r.recs + r.bin_off[b], r.bin_bytes[b], r.bin_kmers[b], r.bin_superkmers[b], r.bin_plus_x[b]);
 		}
 		push_all();
-		if (ref_splitter) {
-			ref_splitter->Complete();
-			uint64 n = 0;
-			ref_splitter->GetTotal(n);
-			n_reads += n;
-			ref_splitter.reset();
-		}
 		bpq->mark_completed();
 		engine.reset();
 		KmcTimeline::mark_first_last(nullptr, "splitter: last worker done");
 		if (getenv("KMC_HIP_VERBOSE"))
-			fprintf(stderr, "[kmc_hip stage 1] worker: %llu parts through the engine (%.3f s inside), %llu long-read parts and %llu uncovered parts to the reference splitter, "
+			fprintf(stderr, "[kmc_hip stage 1] worker: %llu parts through the engine (%.3f s inside; %llu of them long-read parts), %llu uncovered parts, "
 			                "%llu bin pieces (%llu cut record by record), %llu buffers / %.1f MB pushed\n",
 			        (unsigned long long)st_parts, st_engine_ns * 1e-9, (unsigned long long)st_long_parts, (unsigned long long)st_uncovered_parts,
 			        (unsigned long long)st_pieces,
@@ -272,10 +307,13 @@ public:
 
 	void GetTotal(uint64 &_n_reads)
 	{
-		if (ref)
+#ifdef KMC_HIP_S1_REFERENCE_FALLBACK
+		if (ref) {
 			ref->GetTotal(_n_reads);
-		else
-			_n_reads = n_reads;
+			return;
+		}
+#endif
+		_n_reads = n_reads;
 	}
 	~CWSplitter() {}
 };

@@ -33,13 +33,15 @@ struct KmcSplitResult {
 	uint64_t n_reads;          /* records whose title line the part holds (CSplitter::n_reads) */
 };
 
-/* split_part() returns 0, a negative error code, or KMC_SPLIT_UNCOVERED: the part is text the engine does not reproduce CSplitter::GetSeq on
- * (blank lines, quality of another length than its sequence, ...): nothing was produced, the worker gives the part to the reference splitter */
+/* split_part() returns 0, a negative error code, or KMC_SPLIT_UNCOVERED: the part is MALFORMED text the engine does not reproduce CSplitter::GetSeq
+ * on (blank lines, quality of another length than its sequence, control characters ...): nothing was produced, and the worker stops the run (a build
+ * with -DKMC_HIP_S1_REFERENCE_FALLBACK and $KMC_HIP_S1_FALLBACK=1 gives the part to the reference splitter instead).
+ * long_read: the reader labelled the part ReadType::long_read (queues.h:40) — an optional title, then symbols only (GetSeqLongRead, splitter.cpp:70-86). */
 enum { KMC_SPLIT_UNCOVERED = 1 };
 
 struct KmcSplitEngine {
 	virtual ~KmcSplitEngine() {}
-	virtual int split_part(const uint8_t *text, uint64_t size, KmcSplitResult &out) = 0;
+	virtual int split_part(const uint8_t *text, uint64_t size, bool long_read, KmcSplitResult &out) = 0;
 	virtual std::string last_error() = 0;
 };
 

@@ -27,6 +27,8 @@ uint32_t oracle_s1_pack(const int8_t *seq, uint32_t n, uint32_t kmer_len, uint8_
 uint32_t oracle_s1_kxmer_recs(const int8_t *seq, uint32_t n, uint32_t kmer_len, uint32_t max_x, int both_strands);
 int64_t oracle_s1_parse_part(const uint8_t *part, uint64_t part_size, int file_type, uint32_t kmer_len, uint64_t line_cap, int8_t *codes_out, uint64_t *seq_off,
                              uint64_t seq_cap, uint64_t *n_reads);
+int64_t oracle_s1_parse_long_read_part(const uint8_t *part, uint64_t part_size, int file_type, uint32_t kmer_len, uint64_t line_cap, int8_t *codes_out,
+                                       uint64_t *seq_off, uint64_t seq_cap, uint64_t *n_reads);
 }
 
 struct KmcOracleSplitEngine : KmcSplitEngine {
@@ -45,13 +47,14 @@ struct KmcOracleSplitEngine : KmcSplitEngine {
 		oracle_s1_norm(P.signature_len, norm.data());
 	}
 	std::string last_error() override { return err; }
-	int split_part(const uint8_t *text, uint64_t size, KmcSplitResult &out) override
+	int split_part(const uint8_t *text, uint64_t size, bool long_read, KmcSplitResult &out) override
 	{
 		const uint32_t nb = P.n_bins;
-		codes.resize(size + 16);
+		codes.resize(size + (size / (P.line_cap - P.kmer_len + 1) + 2) * P.kmer_len + 16); /* the pieces of an over-long line overlap by k - 1 */
 		seq_off.resize(size / 2 + 16);
 		uint64_t n_reads = 0;
-		const int64_t n_seq = oracle_s1_parse_part(text, size, P.file_type, P.kmer_len, P.line_cap, codes.data(), seq_off.data(), seq_off.size() - 1, &n_reads);
+		const int64_t n_seq = long_read ? oracle_s1_parse_long_read_part(text, size, P.file_type, P.kmer_len, P.line_cap, codes.data(), seq_off.data(), seq_off.size() - 1, &n_reads)
+		                                : oracle_s1_parse_part(text, size, P.file_type, P.kmer_len, P.line_cap, codes.data(), seq_off.data(), seq_off.size() - 1, &n_reads);
 		if (n_seq < 0) {
 			err = "oracle_s1_parse_part: too many sequences";
 			return -1;

@@ -378,7 +378,41 @@ static int s1_get_seq(oracle_s1_part *st, int file_type, uint32_t kmer_len, uint
 	return 1;
 }
 
-/* All sequences of one part: codes back to back into `codes_out` (capacity >= part_size), seq_off[0 .. n_seq]; *n_reads = records whose
+/* A part the reader labelled ReadType::long_read (queues.h:40): CSplitter::GetSeqLongRead, splitter.cpp:70-86 — a title only if the part starts
+ * with the marker (one read counted; the scan stops AT its end of line, which is then handed out as a symbol: an invalid one), after that every
+ * byte is a symbol, in pieces of line_cap that overlap by kmer_len - 1. Same outputs as oracle_s1_parse_part; codes_out must hold
+ * part_size + (part_size / (line_cap - kmer_len + 1) + 2) * kmer_len bytes. */
+int64_t oracle_s1_parse_long_read_part(const uint8_t *part, uint64_t part_size, int file_type, uint32_t kmer_len, uint64_t line_cap, int8_t *codes_out,
+                                       uint64_t *seq_off, uint64_t seq_cap, uint64_t *n_reads)
+{
+	const uint8_t marker = file_type == 0 ? '>' : '@';
+	uint64_t part_pos = 0, n = 0, at = 0;
+	*n_reads = 0;
+	seq_off[0] = 0;
+	while (part_pos < part_size) { /* GetSeq :94 */
+		uint64_t pos = 0;
+		if (part_pos == 0 && part[0] == marker) { /* :74-79 */
+			++*n_reads;
+			while (part_pos < part_size && part[part_pos] != '\n' && part[part_pos] != '\r')
+				++part_pos;
+		}
+		while (pos < line_cap && part_pos < part_size) /* :80-81 */
+			codes_out[at + pos++] = s1_code(part[part_pos++]);
+		if (n >= seq_cap)
+			return -1;
+		at += pos;
+		seq_off[++n] = at;
+		if (part_pos < part_size) { /* :83-84 */
+			if (line_cap < kmer_len)
+				return -1; /* would never advance */
+			part_pos -= kmer_len - 1;
+		}
+	}
+	return (int64_t)n;
+}
+
+/* All sequences of one part: codes back to back into `codes_out` (capacity >= part_size + (part_size / (line_cap - kmer_len + 1) + 2) * kmer_len: the
+ * pieces of an over-long line overlap), seq_off[0 .. n_seq]; *n_reads = records whose
  * title was seen. Returns the number of sequences handed out, or -1 when seq_cap is too small. */
 int64_t oracle_s1_parse_part(const uint8_t *part, uint64_t part_size, int file_type, uint32_t kmer_len, uint64_t line_cap, int8_t *codes_out, uint64_t *seq_off,
                              uint64_t seq_cap, uint64_t *n_reads)

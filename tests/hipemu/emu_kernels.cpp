@@ -410,11 +410,11 @@ EMU_API int emu_s1_split(const int8_t *codes, u64 n, unsigned k, unsigned m, u32
 	hipemu::launch(dim3(tiles), dim3(S1_BLOCK), 0, [&] { k_s1_signatures(codes, n, k, m, sig); });
 	if (fused)
 		hipemu::launch(dim3(ctiles), dim3(S1_BLOCK), 0, [&] {
-			k_s1_cut<true>((const u32 *)nullptr, codes, m, n, k, st_last.data(), st_cnt.data(), &ticket, sk_pos, sk_len, sk_sig, sk_cap, n_sk, &err);
+			k_s1_cut<true>((const u32 *)nullptr, codes, m, n, k, st_last.data(), st_cnt.data(), &ticket, sk_pos, sk_len, sk_sig, sk_cap, n_sk, (const u64 *)nullptr, &err);
 		});
 	else
 		hipemu::launch(dim3(ctiles), dim3(S1_BLOCK), 0, [&] {
-			k_s1_cut<false>(sig, (const int8_t *)nullptr, 0u, n, k, st_last.data(), st_cnt.data(), &ticket, sk_pos, sk_len, sk_sig, sk_cap, n_sk, &err);
+			k_s1_cut<false>(sig, (const int8_t *)nullptr, 0u, n, k, st_last.data(), st_cnt.data(), &ticket, sk_pos, sk_len, sk_sig, sk_cap, n_sk, (const u64 *)nullptr, &err);
 		});
 	return (int)err;
 }
@@ -461,22 +461,37 @@ EMU_API int emu_s1_scatter(const int8_t *codes, const u64 *sk_pos, const u32 *sk
 	return 0;
 }
 
-/* text of one part -> code stream (+ positions of the line ends) and the record check; totals[0] = '\n' count, totals[1] = bytes of codes */
-EMU_API int emu_s1_text_to_codes(const uint8_t *text, u64 n, unsigned lines_per_record, int8_t *codes, u64 *nl_pos, u64 nl_cap, u64 *totals)
+/* text of one part -> code stream (+ positions of the line ends) and the record check; totals[0] = '\n' count, totals[1] = bytes of codes.
+ * lines_per_record 0: the symbols of a long-read part. line_cap: pieces of longer lines are marked in the codes (S1_PIECE_MARK; *has_marks tells). */
+EMU_API int emu_s1_text_to_codes_cap(const uint8_t *text, u64 n, unsigned lines_per_record, int8_t *codes, u64 *nl_pos, u64 nl_cap, u64 *totals, u64 line_cap, unsigned k,
+                                     u64 *has_marks)
 {
 	u32 err = 0, ticket = 0;
 	totals[0] = totals[1] = 0;
+	*has_marks = 0;
 	if (!n)
 		return 0;
 	const u32 tiles = (u32)((n + S1_TXT_TILE - 1) / S1_TXT_TILE);
-	std::vector<u64> st_a(tiles, 0), st_b(tiles, 0);
+	std::vector<u64> st_a(tiles, 0), st_b(tiles, 0), seq_start(nl_cap + 2, 0);
 	hipemu::launch(dim3(tiles), dim3(S1_BLOCK), 0,
-	               [&] { k_s1_text_to_codes(text, n, lines_per_record, st_a.data(), st_b.data(), &ticket, codes, nl_pos, nl_cap, totals, &err); });
+	               [&] { k_s1_text_to_codes(text, n, lines_per_record, st_a.data(), st_b.data(), &ticket, codes, nl_pos, nl_cap, seq_start.data(), totals, &err); });
 	if (err & KERR_CAPACITY)
 		return (int)err;
+	const u64 stride = line_cap - k + 1;
+	if (!lines_per_record) {
+		if (totals[1] > stride)
+			hipemu::launch(dim3(1), dim3(256), 0, [&] { k_s1_mark_raw(codes, totals[1], stride, has_marks); });
+		return (int)err;
+	}
 	const u64 recs = totals[0] / lines_per_record + 1;
-	hipemu::launch(dim3((u32)((recs + 255) / 256)), dim3(256), 0, [&] { k_s1_check_records(text, n, nl_pos, totals[0], lines_per_record, (u64)131080, &err); });
+	hipemu::launch(dim3((u32)((recs + 255) / 256)), dim3(256), 0,
+	               [&] { k_s1_check_records(text, n, nl_pos, totals[0], lines_per_record, line_cap, stride, seq_start.data(), codes, has_marks, &err); });
 	return (int)err;
+}
+EMU_API int emu_s1_text_to_codes(const uint8_t *text, u64 n, unsigned lines_per_record, int8_t *codes, u64 *nl_pos, u64 nl_cap, u64 *totals)
+{
+	u64 has_marks = 0;
+	return emu_s1_text_to_codes_cap(text, n, lines_per_record, codes, nl_pos, nl_cap, totals, (u64)131080, 27u, &has_marks);
 }
 
 EMU_API void emu_s1_plus_x(const int8_t *codes, const u64 *sk_pos, const u32 *sk_len, const u32 *sk_sig, u64 n_sk, unsigned k, unsigned max_x, unsigned both_strands,

@@ -56,7 +56,7 @@ struct EmuSplitEngine : KmcSplitEngine {
 	explicit EmuSplitEngine(const KmcSplitParams &p) : P(p) {}
 	std::string last_error() override { return err_msg; }
 
-	int split_part(const uint8_t *text, uint64_t size, KmcSplitResult &out) override
+	int split_part(const uint8_t *text, uint64_t size, bool long_read, KmcSplitResult &out) override
 	{
 		std::lock_guard<std::mutex> lck(g_launch_mtx);
 		be.release();
@@ -72,7 +72,19 @@ struct EmuSplitEngine : KmcSplitEngine {
 		sp.sorted_emit = getenv("KMC_HIP_S1_SORTED_EMIT") != nullptr;
 		if (const char *g = getenv("KMC_EMU_SK_GUESS_DIV"))
 			sp.sk_guess_div = strtoull(g, nullptr, 10);
+		u64 long_reads = 0;
+		std::vector<uint8_t> aligned; /* the kernels load 16 aligned bytes at a time */
+		if (long_read) {
+			const u64 skip = s1_long_read_title(text, size, (u32)P.file_type, long_reads);
+			aligned.assign(text + skip, text + size);
+			aligned.resize(aligned.size() + 16);
+			text = aligned.data();
+			size -= skip;
+			sp.lines_per_record = 0;
+		}
 		const int rc = s1_split_part(be, text, size, size && text[size - 1] == '\n', sp, R);
+		if (long_read)
+			R.n_reads = long_reads;
 		if (rc == S1_CHAIN_UNCOVERED)
 			return KMC_SPLIT_UNCOVERED;
 		if (rc != S1_CHAIN_OK) {

@@ -269,6 +269,13 @@ template <typename T> static inline T atomicMax(T *p, T v)
 	}
 	return old;
 }
+template <typename T> static inline T atomicMin(T *p, T v)
+{
+	T old = __atomic_load_n(p, __ATOMIC_SEQ_CST);
+	while (old > v && !__atomic_compare_exchange_n(p, &old, v, false, __ATOMIC_SEQ_CST, __ATOMIC_SEQ_CST)) {
+	}
+	return old;
+}
 
 #ifdef HIPEMU_HOST_API
 #include "hip_host_api.h" /* the runtime API of the product's host library, over plain memory (tests/emu.py build_hostlib) */

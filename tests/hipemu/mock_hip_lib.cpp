@@ -188,7 +188,19 @@ MOCK_API int kmc_hip_split_part(kmc_hip_ctx *ctx, int dev, int slot, const kmc_h
 	sp.d_sig_to_bin = ctx->sig_map.data();
 	sp.sorted_emit = getenv("KMC_HIP_S1_SORTED_EMIT") != nullptr;
 	S1PartResult R;
+	u64 long_reads = 0;
+	std::vector<uint8_t> aligned; /* the kernels load 16 aligned bytes at a time */
+	if (p->part_kind == 1) {
+		const u64 skip = s1_long_read_title(text, size, p->file_type, long_reads);
+		aligned.assign(text + skip, text + size);
+		aligned.resize(aligned.size() + 16);
+		text = aligned.data();
+		size -= skip;
+		sp.lines_per_record = 0;
+	}
 	const int rc = s1_split_part(be, text, size, size && text[size - 1] == '\n', sp, R);
+	if (p->part_kind == 1)
+		R.n_reads = long_reads;
 	if (rc == S1_CHAIN_UNCOVERED)
 		return KMC_HIP_UNCOVERED;
 	if (rc != S1_CHAIN_OK)

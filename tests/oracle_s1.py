@@ -34,6 +34,8 @@ def lib():
         L.oracle_s1_kxmer_recs.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int]
         L.oracle_s1_parse_part.restype = C.c_int64
         L.oracle_s1_parse_part.argtypes = [C.c_void_p, C.c_uint64, C.c_int, C.c_uint32, C.c_uint64, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p]
+        L.oracle_s1_parse_long_read_part.restype = C.c_int64
+        L.oracle_s1_parse_long_read_part.argtypes = L.oracle_s1_parse_part.argtypes
         _LIB = L
     return _LIB
 
@@ -83,13 +85,14 @@ def split_stream(codes: np.ndarray, k: int, sig_len: int = 9):
     return out[:n, 0].copy(), out[:n, 1].copy(), out[:n, 2].copy()
 
 
-def parse_part(text: bytes, file_type: int, k: int, line_cap: int = 131080):
-    """CSplitter::GetSeq over one part (0 = FASTA, 1 = FASTQ) -> (list of code arrays, n_reads)"""
+def parse_part(text: bytes, file_type: int, k: int, line_cap: int = 131080, long_read: bool = False):
+    """CSplitter::GetSeq over one part (0 = FASTA, 1 = FASTQ; long_read: a part the reader labelled ReadType::long_read, GetSeqLongRead) -> (list of code arrays, n_reads)"""
     t = np.frombuffer(text, dtype=np.uint8)
-    codes = np.zeros(t.size + 16, dtype=np.int8)
+    codes = np.zeros(t.size + (t.size // max(line_cap - k + 1, 1) + 2) * k + 16, dtype=np.int8)  # the pieces of an over-long line overlap by k - 1
     off = np.zeros(t.size // 2 + 16, dtype=np.uint64)
     nr = C.c_uint64(0)
-    n = lib().oracle_s1_parse_part(t.ctypes.data, t.size, file_type, k, line_cap, codes.ctypes.data, off.ctypes.data, off.size - 1, C.addressof(nr))
+    fn = lib().oracle_s1_parse_long_read_part if long_read else lib().oracle_s1_parse_part
+    n = fn(t.ctypes.data, t.size, file_type, k, line_cap, codes.ctypes.data, off.ctypes.data, off.size - 1, C.addressof(nr))
     assert n >= 0
     return [codes[int(off[i]):int(off[i + 1])].copy() for i in range(n)], nr.value
 

@@ -168,15 +168,29 @@ def test_bench_multi_rank_body_rehearsed_over_gloo_on_the_emulated_library(tmp_p
     args = ["--reads", "3000", "--genome", "30000", "--bins", "8", "--steps", "1", "--warmup", "0", "--no-secondary", "--no-cpu-baseline", "--no-host-boundary",
             "--no-two-streams", "--no-oracle-check"]
     out = {}
-    for n in (1, 2):
+    for n in (1, 2, 4, 8):
         r = subprocess.run([sys.executable, bench, "--gpus", str(n), *args], capture_output=True, text=True, timeout=900, env=env, cwd=str(tmp_path))
         assert r.returncode == 0, (r.stdout + r.stderr)[-1500:]
-        out[n] = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
-        assert out[n]["rehearsal"] is True and out[n]["value"] is None and out[n]["n_gpus"] == n
+        last = r.stdout.rstrip("\n").splitlines()[-1]
+        # the line the driver parses: the LAST line of stdout, one JSON object, short enough for the tail the driver keeps (round 4's 22 KB line was cut)
+        assert len(last) < 6000, len(last)
+        out[n] = json.loads(last)
+        assert out[n]["rehearsal"] is True and out[n]["value"] is None and out[n]["ms_per_step"] is None and out[n]["n_gpus"] == n
+        for key in ("metric", "unit", "steps", "warmup", "dtype", "config", "roofline", "cpu_baseline", "self_check", "moved_bytes_per_kmer", "scaling"):
+            assert key in out[n], key
+        assert out[n]["roofline"]["kernel"].startswith("k_onesweep") and out[n]["roofline"]["peak"] == 8000.0
         assert out[n]["self_check"]["per_bin_total_and_out_bytes_consistent"] is True
-    assert out[2]["tallies"] == out[1]["tallies"] and out[2]["tallies"]["n_total"] == out[1]["config"]["kmers"]
-    assert out[2]["self_check"]["output_digest"] == out[1]["self_check"]["output_digest"]
-    assert 0 < out[2]["config"]["kmers_rank0"] < out[2]["config"]["kmers"] and out[2]["config"]["bins_rank0"] < out[2]["config"]["bins"]
+        if n == 1:
+            assert "no scaling curve" in out[n]["multi_gpu"]
+        else:  # what every rank did is in the line: its k-mers, its bins, the LPT imbalance
+            pr = out[n]["per_rank"]
+            assert [x["rank"] for x in pr] == list(range(n)) and sum(x["kmers"] for x in pr) == out[n]["config"]["kmers"]
+            assert sum(x["bins"] for x in pr) == out[n]["config"]["bins"] and out[n]["lpt_imbalance"] >= 1.0
+            assert out[n]["tallies"] == out[1]["tallies"] and out[n]["tallies"]["n_total"] == out[1]["config"]["kmers"]
+            assert out[n]["self_check"]["output_digest"] == out[1]["self_check"]["output_digest"]
+            assert 0 < out[n]["config"]["kmers_rank0"] < out[n]["config"]["kmers"] and out[n]["config"]["bins_rank0"] < out[n]["config"]["bins"]
+    detail = json.load(open(os.path.join(root, "bench_detail.json")))  # the whole record went to the side file
+    assert detail["rehearsal"] is True and "sort_path" in detail and len(json.dumps(detail)) > len(last)
     if os.path.exists(capi._build.LIB_HIP):  # the GPU library refuses the rehearsal switch (dlopen works without a GPU)
         r = subprocess.run([sys.executable, bench, "--gpus", "1", *args], capture_output=True, text=True, timeout=300,
                            env=dict(base, KMC_BENCH_REHEARSAL="1", KMC_HIP_LIB=capi._build.LIB_HIP), cwd=str(tmp_path))

@@ -1,6 +1,8 @@
 """First stage-1 kernels (kmc_amd/csrc/stage1_kernels.hip.h: minimizer signature per k-mer, super-k-mer cutting) executed on the CPU under
 tests/hipemu and compared with the stage-1 oracle, which tests/test_stage1_oracle.py pins to the reference. Groundwork for SURVEY.md §8f
 rank 2; the kernels are not part of the drop-in yet."""
+import ctypes as C
+
 import numpy as np
 import pytest
 
@@ -245,8 +247,8 @@ def test_emulated_text_check_flags_parts_outside_its_domain(what):
            "lone cr": good.replace(b"ACGT\n+", b"AC\rGT\n+"), "missing last eol": good[:-1], "no title marker": b"x" + good[1:],
            "control char": good.replace(b"@b\nACGT", b"@b\n\tACGT")}[what]
     assert emu.s1_text_to_codes(good, 4)[0] == 0
-    assert emu.s1_text_to_codes(bad, 4)[0] & 16
-    assert emu.s1_text_to_codes(b">a\nACGT\n>b\nAC", 2)[0] == 0 and emu.s1_text_to_codes(b">a\nACGT\n>b", 2)[0] & 16
+    assert emu.s1_text_to_codes(bad, 4)[0] & 0x1000  # S1_TEXT_BAD (its own bit: 0x10 is KERR_PEER)
+    assert emu.s1_text_to_codes(b">a\nACGT\n>b\nAC", 2)[0] == 0 and emu.s1_text_to_codes(b">a\nACGT\n>b", 2)[0] & 0x1000
 
 
 @pytest.mark.parametrize("k,max_x,both", [(27, 3, True), (27, 3, False), (21, 3, True), (55, 2, True), (40, 1, True), (27, 0, True), (14, 3, True)])
@@ -298,3 +300,119 @@ def test_emulated_emit_through_a_sort_writes_bins_in_read_order(k, m, n_bins):
         assert np.all(np.diff(ps) > 0) if size else ps.tolist() == [0]
         starts = np.concatenate([[0], np.cumsum([int(w_off[i + 1] - w_off[i]) for i in idx])]) if idx.size else np.zeros(1, dtype=np.int64)
         assert np.all(np.isin(ps, starts))
+
+
+# ---- lines of mem_part_pmm_reads symbols or more, and the parts the reader labels ReadType::long_read (round 5: the stage-1 worker has no path into the
+# reference splitter any more, so the engine takes them): the whole chain of kmc_hip_split_part (stage1_chain.h under the emulation, through the C-ABI of
+# tests/hipemu/libkmc_hip_mock.so) against the oracle's restatement of CSplitter::GetSeq / GetSeqLongRead + ProcessReads, with a small line_cap
+class _SplitParams(C.Structure):
+    _fields_ = [("kmer_len", C.c_uint32), ("signature_len", C.c_uint32), ("n_bins", C.c_uint32), ("max_x", C.c_uint32), ("both_strands", C.c_uint32),
+                ("file_type", C.c_uint32), ("line_cap", C.c_uint64), ("part_kind", C.c_uint32), ("reserved", C.c_uint32)]
+
+
+def _mock_split_part(text, file_type, k, m, n_bins, smap, line_cap, long_read, max_x=3, both=True):
+    L = C.CDLL(emu.build_mock())
+    assert L.kmc_hip_abi_version() == 4
+    h = C.c_void_p()
+    assert L.kmc_hip_init(None, 1, C.byref(h)) == 0
+    L.kmc_hip_last_error.restype = C.c_char_p
+    try:
+        assert L.kmc_hip_split_set_map(h, 0, smap.ctypes.data_as(C.c_void_p), m) == 0
+        p = _SplitParams(k, m, n_bins, max_x, 1 if both else 0, file_type, line_cap, 1 if long_read else 0, 0)
+        t = np.frombuffer(text, dtype=np.uint8)
+        recs = np.zeros(2 * t.size + 256 * (n_bins + 1) + 4096, dtype=np.uint8)
+        arr = [np.zeros(n_bins, dtype=np.uint64) for _ in range(5)]
+        need, n_reads = C.c_uint64(0), C.c_uint64(0)
+        rc = L.kmc_hip_split_part(h, 0, 0, C.byref(p), t.ctypes.data_as(C.c_void_p), C.c_uint64(t.size), recs.ctypes.data_as(C.c_void_p), C.c_uint64(recs.size), C.byref(need),
+                                  *[a.ctypes.data_as(C.c_void_p) for a in arr], C.byref(n_reads))
+        if rc:
+            return rc, L.kmc_hip_last_error(h)
+        off, nbytes, kmers, supers, plus_x = arr
+        return 0, dict(bins=[recs[int(off[b]):int(off[b] + nbytes[b])].copy() for b in range(n_bins)], kmers=kmers, supers=supers, plus_x=plus_x, n_reads=n_reads.value)
+    finally:
+        L.kmc_hip_destroy(h)
+
+
+def _oracle_split_part(text, file_type, k, m, n_bins, smap, line_cap, long_read, max_x=3, both=True):
+    """what CSplitter::ProcessReads + the collectors make of the part (oracle/oracle_engine_s1.h, in Python): records per bin, the three sums, n_reads"""
+    seqs, n_reads = S1.parse_part(text, file_type, k, line_cap, long_read=long_read)
+    want = dict(bins=[[] for _ in range(n_bins)], kmers=np.zeros(n_bins, dtype=np.uint64), supers=np.zeros(n_bins, dtype=np.uint64),
+                plus_x=np.zeros(n_bins, dtype=np.uint64), n_reads=n_reads, pieces=len(seqs))
+    letters = np.frombuffer(b"ACGTN", dtype=np.uint8)
+    for q in seqs:
+        if q.size < k:
+            continue
+        ascii_ = letters[np.where(q < 0, 4, q)].tobytes()
+        sig, off, recs = S1.split([ascii_], k, m)
+        pos, ln, sg = S1.split_stream(q, k, m)
+        assert np.array_equal(sig, sg)
+        for i in range(sig.size):
+            b = int(smap[sig[i]])
+            want["bins"][b].append(bytes(recs[int(off[i]):int(off[i + 1])]))
+            want["kmers"][b] += int(ln[i]) - k + 1
+            want["supers"][b] += 1
+            want["plus_x"][b] += S1.kxmer_recs(q[int(pos[i]):int(pos[i] + ln[i])], k, max_x, both)
+    return want
+
+
+def _check_part(text, file_type, k, m, long_read, line_cap, max_x=3, both=True, n_bins=37):
+    smap = _sig_map(m, n_bins, 5)
+    rc, got = _mock_split_part(text, file_type, k, m, n_bins, smap, line_cap, long_read, max_x, both)
+    assert rc == 0, got
+    want = _oracle_split_part(text, file_type, k, m, n_bins, smap, line_cap, long_read, max_x, both)
+    assert got["n_reads"] == want["n_reads"]
+    for b in range(n_bins):
+        assert _parse_bin(got["bins"][b], k) == sorted(want["bins"][b]), b
+    for key in ("kmers", "supers", "plus_x"):
+        assert np.array_equal(got[key], want[key]), key
+    return want
+
+
+@pytest.mark.parametrize("fmt,eol,k,both", [("fq", b"\n", 27, True), ("fq", b"\r\n", 27, False), ("fa", b"\n", 55, True), ("fa", b"\r\n", 21, True)])
+def test_lines_beyond_the_line_cap_are_cut_where_the_reference_cuts_them(fmt, eol, k, both):
+    """CSplitter::GetSeq hands a line of mem_part_pmm_reads symbols or more to ProcessReads in pieces that overlap by k - 1 symbols (splitter.cpp:141-145,
+    :226-231), and every piece starts its super-k-mers afresh. The kernels mark the piece starts in the code stream (S1_PIECE_MARK) and k_s1_cut starts a run
+    there: records, k-mer / super-k-mer / k+x-mer sums of every bin must equal the reference restatement's — with a line cap small enough (k + 4105: a stride
+    just beyond one workgroup window of k_s1_cut) for text of test size to have lines of 1, 2 and 5 pieces, one of exactly the cap, one a symbol short of it."""
+    rng = np.random.default_rng(k)
+    acgt = np.frombuffer(b"ACGT", dtype=np.uint8)
+    rnd = lambda n: acgt[rng.integers(0, 4, size=n)].tobytes()
+    line_cap = k + 4105
+    stride = line_cap - k + 1
+    long5 = bytearray(rnd(4 * stride + 900))
+    long5[stride] = ord("N")  # an invalid symbol exactly where a piece starts: no mark is needed there, none may be invented
+    long5[2 * stride - 3] = ord("n")
+    recs = [rnd(int(rng.integers(k, 300))) for _ in range(40)] + [rnd(line_cap), rnd(60), rnd(line_cap - 1), bytes(long5), rnd(100), rnd(line_cap + 1), rnd(2 * stride + 5),
+                                                                    b"A" * (line_cap + 300), rnd(80)]
+    text = _records_text(fmt, eol, recs)
+    want = _check_part(text, 1 if fmt == "fq" else 0, k, 9, False, line_cap, both=both)
+    assert want["pieces"] >= len(recs) + 8  # the oracle did hand out pieces (1 extra for the lines of the cap and one beyond, 4 for the five-piece line, 2 + 1)
+    if fmt == "fa":  # a FASTA part may end inside a long last line
+        text2 = _records_text(fmt, eol, recs[:5] + [rnd(3 * stride + 77)])
+        _check_part(text2[: len(text2) - len(eol)], 0, k, 9, False, line_cap, both=both)
+
+
+@pytest.mark.parametrize("fmt,k", [("fa", 27), ("fq", 27), ("fa", 55), ("fq", 14)])
+def test_long_read_parts_go_through_the_kernels(fmt, k):
+    """ReadType::long_read parts (queues.h:40; reader: fastq_reader.cpp:619-661, :704-721, :746-790, :843-897): the first part of a read carries its title, the
+    others start inside the sequence and overlap the previous one by k - 1 symbols; a FASTQ read's last part ends with the sequence line's end of line. After the
+    title every byte is a symbol (CSplitter::GetSeqLongRead, splitter.cpp:70-86), handed out in pieces of mem_part_pmm_reads."""
+    rng = np.random.default_rng(100 + k)
+    acgt = np.frombuffer(b"ACGTACGTACGTACGTN", dtype=np.uint8)
+    rnd = lambda n: acgt[rng.integers(0, acgt.size, size=n)].tobytes()
+    line_cap = k + 4105
+    ft = 1 if fmt == "fq" else 0
+    marker = b"@" if fmt == "fq" else b">"
+    body = rnd(3 * (line_cap - k + 1) + 1234)
+    first = marker + b"read 1 of a long-read file\n" + body
+    w = _check_part(first, ft, k, 7 if k == 14 else 9, True, line_cap)
+    assert w["n_reads"] == 1 and w["pieces"] == 4
+    w = _check_part(marker + b"t\r\n" + body[:3000], ft, k, 7 if k == 14 else 9, True, line_cap)  # CRLF behind the title: two invalid symbols in front
+    assert w["n_reads"] == 1
+    cont = body[-(k - 1):] + rnd(2 * (line_cap - k + 1) + 17)  # a continuation: no title, no read counted — even if it starts with a letter only
+    w = _check_part(cont, ft, k, 7 if k == 14 else 9, True, line_cap)
+    assert w["n_reads"] == 0 and w["pieces"] == 3
+    w = _check_part(cont[:500] + b"\n", ft, k, 7 if k == 14 else 9, True, line_cap)  # the last part of a FASTQ read: the end of line comes along as an invalid symbol
+    assert w["n_reads"] == 0
+    w = _check_part(b"ACGT", ft, k, 7 if k == 14 else 9, True, line_cap)  # shorter than a k-mer
+    assert sum(int(x) for x in w["kmers"]) == 0

@@ -203,19 +203,66 @@ def test_emulated_stage1_kernels_inside_the_reference_pipeline(fmt, eol, flags, 
     assert _report_sum("parts through the engine") > 0 and _report_sum("uncovered parts") == 0 and _report_sum("bin pieces") > 0
 
 
+def _run_raw(exe, flags, inp, tmp_path, tag, env=None):
+    t = tmp_path / ("tmp_" + tag)
+    t.mkdir(exist_ok=True)
+    return subprocess.run([_exe(exe), *flags, inp, str(tmp_path / ("db_" + tag)), str(t)], capture_output=True, text=True, env=dict(os.environ, **(env or {})), timeout=600)
+
+
 @needs_emu
-def test_text_the_kernels_do_not_cover_goes_to_the_reference_splitter(tmp_path):
-    """a blank line between records is fine with CSplitter::GetSeq (splitter.cpp:293-298) but not with the kernels' line model: the record check
-    must flag the part, the worker must hand it to the reference splitter, and the database must not change"""
+def test_text_the_kernels_do_not_cover_stops_the_run(tmp_path):
+    """FAIL CLOSED (round 5). A blank line between records is fine with CSplitter::GetSeq (splitter.cpp:293-298) but not with the kernels' line model: the
+    record check flags the part and the worker must stop the run with a message that names the cause — it has no path into the reference splitter. Only the
+    test build with -DKMC_HIP_S1_REFERENCE_FALLBACK, and only under KMC_HIP_S1_FALLBACK=1, hands the part over (and the database then does not change)."""
     path = str(tmp_path / "in.fq")
     text = _small_text("fq", b"\n", 27, n_reads=600)
     cut = text.index(b"@r300 ")
     with open(path, "wb") as f:
         f.write(text[:cut] + b"\n" + text[cut:])
     common = ["-k27", "-ci1", "-m2", "-sf1", "-sr1"]
+    r = _run_raw("kmc_emu_s1", common + ["-sp1"], path, tmp_path, "emu", env={"KMC_HIP_VERBOSE": "1", "KMC_HIP_S1_FALLBACK": "1"})  # the switch means nothing to the default build
+    assert r.returncode != 0 and "malformed FASTA / FASTQ" in r.stdout + r.stderr, (r.stdout + r.stderr)[-800:]
+    if not os.path.exists(_exe("kmc_emu_s1_fb")):
+        pytest.skip("oracle/_ref/kmc_emu_s1_fb not built")
+    r = _run_raw("kmc_emu_s1_fb", common + ["-sp1"], path, tmp_path, "fb0")  # compiled in, not switched on: still an error
+    assert r.returncode != 0 and "malformed FASTA / FASTQ" in r.stdout + r.stderr
     want = _run("kmc", common + ["-sp1"], path, tmp_path, "ref")
-    got = _run("kmc_emu_s1", common + ["-sp1"], path, tmp_path, "emu", env={"KMC_HIP_VERBOSE": "1"})
+    got = _run("kmc_emu_s1_fb", common + ["-sp1"], path, tmp_path, "fb1", env={"KMC_HIP_VERBOSE": "1", "KMC_HIP_S1_FALLBACK": "1"})
     assert got == want and _report_sum("uncovered parts") > 0
+
+
+@needs_emu
+@pytest.mark.parametrize("flags,what", [(["-k27", "-hc"], "homopolymer compression"), (["-k27", "-fm"], "other than FASTA / FASTQ"), (["-k27", "--opt-out-size"], "histogram estimation")],
+                         ids=lambda v: "".join(v) if isinstance(v, list) else None)
+def test_jobs_the_device_splitter_does_not_cover_are_refused(flags, what, tmp_path):
+    """-hc, multi-line FASTA / BAM / KMC input and --opt-out-size: the stage-1 worker refuses the job by name and points at kmc_hip (reference stage 1 + device stage 2);
+    it does not run the reference's CWSplitter behind the user's back"""
+    path = str(tmp_path / ("in.fa" if "-fm" in flags else "in.fq"))
+    with open(path, "wb") as f:
+        f.write(_small_text("fa" if "-fm" in flags else "fq", b"\n", 27, n_reads=200))
+    r = _run_raw("kmc_emu_s1", flags + ["-ci1", "-m2", "-sf1", "-sr1", "-sp1"], path, tmp_path, "emu")
+    assert r.returncode != 0 and "does not cover" in r.stdout + r.stderr and what in r.stdout + r.stderr and "kmc_hip" in r.stdout + r.stderr, (r.stdout + r.stderr)[-800:]
+
+
+@needs_emu
+@pytest.mark.parametrize("fmt", ["fa", "fq"])
+def test_long_lines_and_long_read_parts_inside_the_reference_pipeline(fmt, tmp_path):
+    """the reader's own long-read parts (a record longer than its buffer: fastq_reader.cpp:704-721, :843-860) and lines of mem_part_pmm_reads = 524 296 symbols or
+    more inside ordinary parts, through the emulated kernels inside the reference pipeline: database AND statistics (reads, super-k-mers) equal the reference's,
+    no part refused. -m2 makes the reader's buffer small (kmc.h:390-399) so that a few Mbp are enough."""
+    rng = np.random.default_rng(3)
+    k = 27
+    recs = [_rnd(rng, 200), _rnd(rng, 600_000), _rnd(rng, 150), _rnd(rng, int(os.environ.get("KMC_TEST_LONG_READ_BP", "3400000"))), _rnd(rng, 90), _rnd(rng, 530_000)]
+    path = str(tmp_path / ("in." + fmt))
+    with open(path, "wb") as f:
+        for i, r in enumerate(recs):
+            f.write((b"@r%d\n" % i + r + b"\n+\n" + b"I" * len(r) + b"\n") if fmt == "fq" else (b">r%d\n" % i + r + b"\n"))
+    common = ["-k%d" % k, "-ci1", "-m2", "-sf1", "-sr1"] + (["-fa"] if fmt == "fa" else [])
+    want = _run("kmc", common + ["-sp1"], path, tmp_path, "ref")
+    got = _run("kmc_emu_s1", common + ["-sp2"], path, tmp_path, "emu", env={"KMC_HIP_VERBOSE": "1"})
+    assert got == want
+    assert _report_sum("parts through the engine") > 0 and _report_sum("uncovered parts") == 0
+    assert _report_sum("of them long-read parts") >= 2  # the 3.4 Mbp record does not fit the reader's 3 MB buffer ("Input buffer size" under -m2)
 
 
 @needs_emu
@@ -250,12 +297,12 @@ def test_hip_stage1_binary_fails_loudly_without_a_gpu(tmp_path):
         r = subprocess.run([exe, "-k27", "-t2", fq, str(tmp_path / ("out" + eager)), str(tmp)], env=env, capture_output=True, text=True, timeout=120)
         assert r.returncode != 0, r.stdout + r.stderr
         assert "split engine" in r.stdout + r.stderr and ("no ROCm-capable device" in r.stdout + r.stderr or "HIP" in r.stdout + r.stderr), r.stdout + r.stderr
-    # with the reference splitter forced, stage 1 passes and the stage-2 worker is the one that stops the run
-    env = dict(os.environ, KMC_HIP_LIB=os.path.join(ROOT, "kmc_amd", "libkmc_hip.so"), KMC_HIP_SPLITTER_REF="1")
-    tmp = tmp_path / "tmpref"
+    # a job the device splitter does not cover is refused by name before any device is needed (no silent hand-over to the reference's CWSplitter)
+    tmp = tmp_path / "tmphc"
     tmp.mkdir()
-    r = subprocess.run([exe, "-k27", "-t2", fq, str(tmp_path / "outref"), str(tmp)], env=env, capture_output=True, text=True, timeout=120)
-    assert r.returncode != 0 and "split engine" not in r.stdout + r.stderr
+    r = subprocess.run([exe, "-k27", "-t2", "-hc", fq, str(tmp_path / "outhc"), str(tmp)], env=dict(os.environ, KMC_HIP_LIB=os.path.join(ROOT, "kmc_amd", "libkmc_hip.so")),
+                       capture_output=True, text=True, timeout=120)
+    assert r.returncode != 0 and "does not cover homopolymer compression" in r.stdout + r.stderr, r.stdout + r.stderr
 
 
 def _random_text(seed):
