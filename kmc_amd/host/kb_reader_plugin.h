@@ -119,35 +119,29 @@ template <unsigned SIZE> class CWKmerBinReader {
 	 * (/proc/self/maps). KMC_HIP_ARENA_THP=0 switches it off. */
 	static void advise_arena_once(const void *inside, uint64 arena_bytes)
 	{
+		KmcArena::inst().note(inside, arena_bytes); /* every call: the completer's zap looks the block up again from the LATEST pointer */
 		static std::once_flag once;
 		std::call_once(once, [inside, arena_bytes] {
 			const char *e = getenv("KMC_HIP_ARENA_THP");
 			const bool thp = !(e && atoi(e) == 0);
-			FILE *f = fopen("/proc/self/maps", "r");
-			if (!f)
+			uintptr_t blo = 0, bhi = 0;
+			/* a small arena lives in the heap, next to everything else, and is left alone; a large one is the allocator's own mapping — identified by the
+			 * allocator's chunk header, never by the bounds of the VMA (KmcArena::find_block: adjacent mappings are merged into one VMA) */
+			const bool found = arena_bytes >= (64ull << 20) && KmcArena::find_block(inside, arena_bytes, blo, bhi);
+			if (!found) {
+				if (getenv("KMC_HIP_VERBOSE"))
+					fprintf(stderr, "[kmc_hip stage 2] arena %.1f GB: its block was not identified (no huge-page advice, no parallel zap)\n", (double)arena_bytes / 1e9);
 				return;
-			char line[512];
-			const uintptr_t p = (uintptr_t)inside;
-			while (fgets(line, sizeof line, f)) {
-				unsigned long long a = 0, b = 0;
-				if (sscanf(line, "%llx-%llx", &a, &b) == 2 && p >= a && p < b) {
-					/* only a mapping that IS the arena (a block of this size is an anonymous mapping of its own: the block + the allocator's header, page-rounded);
-					 * a small arena lives in the heap, next to everything else, and is left alone */
-					if (b - a < arena_bytes || b - a > arena_bytes + (1ull << 20) || arena_bytes < (64ull << 20))
-						break;
-					const uintptr_t two_mb = (uintptr_t)2 << 20;
-					const uintptr_t lo = ((uintptr_t)a + two_mb - 1) & ~(two_mb - 1), hi = (uintptr_t)b & ~(two_mb - 1);
-					KmcArena::inst().lo.store((uintptr_t)a);
-					KmcArena::inst().hi.store((uintptr_t)b);
-					if (hi > lo && thp) {
-						const int rc = madvise((void *)lo, hi - lo, MADV_HUGEPAGE);
-						if (getenv("KMC_HIP_VERBOSE"))
-							fprintf(stderr, "[kmc_hip stage 2] arena %.1f GB: madvise(MADV_HUGEPAGE) %s\n", (double)(b - a) / 1e9, rc == 0 ? "ok" : "refused");
-					}
-					break;
-				}
 			}
-			fclose(f);
+			KmcArena::inst().lo.store(blo);
+			KmcArena::inst().hi.store(bhi);
+			const uintptr_t two_mb = (uintptr_t)2 << 20;
+			const uintptr_t lo = (blo + two_mb - 1) & ~(two_mb - 1), hi = bhi & ~(two_mb - 1);
+			if (hi > lo && thp) {
+				const int rc = madvise((void *)lo, hi - lo, MADV_HUGEPAGE);
+				if (getenv("KMC_HIP_VERBOSE"))
+					fprintf(stderr, "[kmc_hip stage 2] arena %.1f GB: madvise(MADV_HUGEPAGE) %s\n", (double)(bhi - blo) / 1e9, rc == 0 ? "ok" : "refused");
+			}
 		});
 	}
 

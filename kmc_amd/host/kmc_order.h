@@ -89,18 +89,91 @@ struct KmcTimeline {
  * alike. The pages can go earlier and in parallel: when the completer plug-in has written the last bin, nothing in the arena is needed any more, and 16 threads
  * of madvise(MADV_DONTNEED) take 0.02 s (tools/ubench_munmap.c); the reference's own release then finds nothing to tear down. */
 struct KmcArena {
-	std::atomic<uintptr_t> lo{0}, hi{0};
+	std::atomic<uintptr_t> lo{0}, hi{0};     /* the arena's allocator block [lo, hi), page-granular; 0 = not found: nothing is advised or zapped */
+	std::atomic<uintptr_t> last_inside{0};   /* a pointer CMemoryBins handed out most recently: the buffer may have been re-allocated since the first one (queues.h:1196-1207) */
+	std::atomic<uint64_t> arena_bytes{0};
 	static KmcArena &inst()
 	{
 		static KmcArena a;
 		return a;
 	}
+	/* The block malloc() gave CMemoryBins::prepare (queues.h:1130: total_size + ALIGNMENT bytes — far beyond the mmap threshold, so glibc serves it with a
+	 * mapping of its own and a 16-byte chunk header at the mapping's first bytes: [prev_size = 0][size | IS_MMAPPED]). The kernel MERGES adjacent anonymous
+	 * mappings into one VMA, so the VMA around `inside` is usually NOT the arena alone (a neighbour's pages zapped = silent corruption); the range is
+	 * therefore taken from the allocator's own header: the VMA is walked chunk by chunk from its start, every step checked (mmapped flag, whole pages, inside the
+	 * VMA), and the chunk that holds `inside` must have exactly the size CMemoryBins asked for, page-rounded. Anything else: not found, feature off. */
+	static bool find_block(const void *inside, uint64_t bytes, uintptr_t &blo, uintptr_t &bhi)
+	{
+		FILE *f = fopen("/proc/self/maps", "r");
+		if (!f)
+			return false;
+		/* private read-write mappings, adjacent ones joined: madvise(MADV_HUGEPAGE) on a part of the block SPLITS its VMA in three, and neighbours of the same
+		 * kind are merged into it — either way the allocator's headers decide, not the VMA bounds. Every start of a VMA at or below `inside` inside the joined
+		 * region is tried as the start of a chain of chunks. */
+		std::vector<std::pair<uintptr_t, uintptr_t>> region;
+		char line[512], perms[8];
+		const uintptr_t p = (uintptr_t)inside;
+		bool past = false;
+		while (fgets(line, sizeof line, f) && !past) {
+			unsigned long long a = 0, b = 0;
+			if (sscanf(line, "%llx-%llx %7s", &a, &b, perms) != 3)
+				continue;
+			const bool rw = perms[0] == 'r' && perms[1] == 'w' && perms[3] == 'p';
+			if (!rw || (!region.empty() && region.back().second != (uintptr_t)a)) {
+				if (!region.empty() && p >= region.front().first && p < region.back().second)
+					past = true; /* the region that holds `inside` is complete */
+				else
+					region.clear();
+				if (!rw || past)
+					continue;
+			}
+			region.emplace_back((uintptr_t)a, (uintptr_t)b);
+		}
+		fclose(f);
+		if (region.empty() || p < region.front().first || p >= region.back().second)
+			return false;
+		const uintptr_t end = region.back().second;
+		const uint64_t page = 4096, want_lo = bytes + 256 + 8, want_hi = want_lo + 2 * page; /* request = total_size + ALIGNMENT, + the header, page-rounded */
+		for (size_t i = region.size(); i-- > 0;) {
+			if (region[i].first > p)
+				continue;
+			for (uintptr_t c = region[i].first; c + 16 <= end;) {
+				const size_t prev = ((const size_t *)c)[0], sz = ((const size_t *)c)[1];
+				const size_t len = sz & ~(size_t)7;
+				if (prev != 0 || (sz & 7) != 2 || len < page || (len & (page - 1)) || len > end - c)
+					break; /* not a chain of glibc's mmapped chunks from here: try the VMA start before it */
+				if (p >= c + 16 && p < c + len) {
+					if (len >= want_lo && len <= want_hi) {
+						blo = c;
+						bhi = c + len;
+						return true;
+					}
+					break;
+				}
+				c += len;
+			}
+		}
+		return false;
+	}
+	void note(const void *inside, uint64_t bytes)
+	{
+		last_inside.store((uintptr_t)inside);
+		arena_bytes.store(bytes);
+	}
 	void zap_parallel(int n_threads = 16)
 	{
-		const uintptr_t a = lo.load() + 4096, b = hi.load(); /* the first page holds the allocator's header of the block (free() reads it at the release) */
 		const char *e = getenv("KMC_HIP_ARENA_ZAP");
-		if (a == 4096 || b <= a || (e && atoi(e) == 0))
+		const uintptr_t in = last_inside.load();
+		if (!in || (e && atoi(e) == 0))
 			return;
+		uintptr_t blo = 0, bhi = 0; /* looked up NOW, from the latest pointer: CMemoryBins may have re-allocated its buffer since the reader advised the first one */
+		const bool found = arena_bytes.load() >= (64ull << 20) && find_block((const void *)in, arena_bytes.load(), blo, bhi);
+		if (getenv("KMC_HIP_VERBOSE"))
+			fprintf(stderr, "[kmc_hip stage 2] arena zap: %s\n", found ? "block found, pages returned in parallel" : "the arena's block was not identified: nothing zapped");
+		last_inside.store(0);
+		if (!found)
+			return;
+		const uintptr_t a = blo + 4096, b = bhi; /* the first page holds the allocator's header of the block (free() reads it at the release) */
 		const uintptr_t two_mb = (uintptr_t)2 << 20;
 		const uintptr_t per = (((b - a) / (uintptr_t)n_threads) + two_mb - 1) & ~(two_mb - 1);
 		std::vector<std::thread> th;
@@ -111,7 +184,6 @@ struct KmcArena {
 		}
 		for (auto &x : th)
 			x.join();
-		lo.store(0);
 	}
 };
 
