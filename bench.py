@@ -121,11 +121,48 @@ class Workload:
         self.allocs = []
 
 
-def build_workload(ctx, args, k, p, rank, world, keep_host=False):
-    """Generate + shard the bin set (kmc_amd/sharding.py), upload this rank's bins. Returns Workload."""
+class DumpedBins:
+    """The bins of a real run as kmc_hip's stage-2 worker received them from the reference's stage 1 ($KMC_HIP_BIN_DUMP_DIR, kb_sorter_plugin.h): the interface
+    build_workload wants from a bin set. Real bin-size spread (s_mapper.h:143-233 balances by statistics and still leaves a tail), real pack lists."""
+
+    def __init__(self, directory):
+        self.timings = {}
+        t = time.time()
+        self.meta = {}
+        for fn in sorted(os.listdir(directory)):
+            if fn.endswith(".meta"):
+                with open(os.path.join(directory, fn)) as f:
+                    b, size, n_rec, n_packs = (int(x) for x in f.readline().split())
+                    packs = np.array([int(x) for x in f.read().split()], dtype=np.uint64)
+                assert packs.size == n_packs and int(packs.sum()) == size, fn
+                self.meta[b] = (size, n_rec, packs, os.path.join(directory, fn[:-5] + ".img"))
+        self.own = [b for b in sorted(self.meta) if self.meta[b][1] > 0]  # empty bins carry nothing to sort
+        nb = max(self.meta) + 1 if self.meta else 0
+        self.size = np.zeros(nb, dtype=np.int64)
+        self.n_rec = np.zeros(nb, dtype=np.int64)
+        self.n_packs = np.zeros(nb, dtype=np.int64)
+        self.n_super = np.zeros(nb, dtype=np.int64)  # not recorded by the dump
+        for b, (size, n_rec, packs, _) in self.meta.items():
+            self.size[b], self.n_rec[b], self.n_packs[b] = size, n_rec, packs.size
+        self.pieces = {b: [(self.image(b), None)] for b in self.own}
+        self.timings["load_dump"] = time.time() - t
+
+    def image(self, b):
+        return np.fromfile(self.meta[b][3], dtype=np.uint8)
+
+    def packs(self, b):
+        return self.meta[b][2]
+
+    def close(self):
+        self.pieces = {}
+
+
+def build_workload(ctx, args, k, p, rank, world, keep_host=False, sb=None):
+    """Generate + shard the bin set (kmc_amd/sharding.py), upload this rank's bins. Returns Workload. sb: a prepared bin set instead (DumpedBins)."""
     w = Workload(ctx, p, k)
     n_threads = max(2, 2 * sharding.effective_cpus() // max(world, 1))  # the box may grant fewer CPUs (cgroup quota) than it shows
-    sb = sharding.generate_sharded_bins(SEED, args.genome, args.reads, k, args.bins, rank, world, n_threads, cache_dir=args.cache or None)
+    if sb is None:
+        sb = sharding.generate_sharded_bins(SEED, args.genome, args.reads, k, args.bins, rank, world, n_threads, cache_dir=args.cache or None)
     w.setup_s.update(sb.timings)
     own = sb.own
 
@@ -175,7 +212,7 @@ def build_workload(ctx, args, k, p, rank, world, keep_host=False):
     w.total_kmers_all = int(np.sum(sb.n_rec))
     w.total_super_all = int(np.sum(sb.n_super))
     w.total_bytes_all = int(np.sum(sb.size))
-    w.n_bins_all = args.bins
+    w.n_bins_all = args.bins if args is not None else len(own)
     w.own_kmers = int(sum(x[2] for x in w.bins))
     w.host_imgs = host_imgs
     w.sb = sb
@@ -419,8 +456,12 @@ def short_line(out):
     if isinstance(out.get("e2e"), dict):
         s["e2e"] = _pick(out["e2e"], ("ref_stage2_s", "hip_stage2_s", "speedup", "hip_Gkmers_per_s", "stats_equal"))
     if isinstance(out.get("e2e_large"), dict):
-        s["e2e_large"] = _pick(out["e2e_large"], ("input", "kmers", "ref_stage2_s", "hip_stage2_s", "speedup", "hip_Gkmers_per_s", "ref_Gkmers_per_s", "stats_equal",
-                                                   "device_resident_on_reference_bins", "error"))
+        s["e2e_large"] = _pick(out["e2e_large"], ("kmers", "ref_stage2_s", "hip_stage2_s", "speedup", "hip_Gkmers_per_s", "ref_Gkmers_per_s", "stats_equal", "error"))
+        if "input" in out["e2e_large"]:
+            s["e2e_large"]["input"] = out["e2e_large"]["input"].split(",")[0]
+        dr = out["e2e_large"].get("device_resident_on_reference_bins")
+        if isinstance(dr, dict):
+            s["e2e_large"]["device_resident_on_reference_bins"] = _pick(dr, ("value", "ms_per_step", "bins", "tallies_equal_reference_statistics", "bin_kmers_min_median_max"))
     s["detail"] = "bench_detail.json (next to bench.py; also gpurun_out/ when that directory exists)"
 
     def rnd(o):
@@ -561,6 +602,76 @@ def reference_legs(k: int, reads: int, genome: int, runs: int = 3):
     return out
 
 
+def e2e_large_leg(ctx, k: int, gbp: float, budget_s: float = 1500.0):
+    """The drop-in inside the reference's pipeline at a size where the pipeline, not the start-up, is what is timed (round 4's e2e ran 2 Gbp: 0.25 s). One FASTQ of
+    `gbp` Gbp (30x of a random genome, the read model of configs[2]); ONE run each of the unmodified reference (oracle/_ref/kmc) and of the drop-in (kmc_amd/bin/kmc_hip:
+    the reference's stage 1, reader / worker / completer plug-ins over this library), RAM-only mode (-r) for both; then the bins exactly as the reference's stage 1
+    produced them (a third run of the drop-in dumps what its worker received: $KMC_HIP_BIN_DUMP_DIR) go through kmc_hip_process_bins_device device-resident —
+    real bin-size spread instead of synth_bins' near-equal bins — and their tallies must equal the reference's five statistics."""
+    ref = os.path.join(ROOT, "oracle", "_ref", "kmc")
+    hip = os.path.join(ROOT, "kmc_amd", "bin", "kmc_hip")
+    if not (os.path.exists(ref) and os.path.exists(hip)):
+        return {"error": "oracle/_ref/kmc or kmc_amd/bin/kmc_hip not built"}
+    t_leg = time.time()
+    reads = int(gbp * 1e9 / 150)
+    cores = sharding.effective_cpus()
+    threads = max(2, min(os.cpu_count() or 1, 128, cores))
+    ram_gb = os.sysconf("SC_PAGE_SIZE") * os.sysconf("SC_PHYS_PAGES") >> 30
+    mem = max(4, min(512, ram_gb // 3))
+    need = int(reads * 316 * 1.1) + int(reads * 150 * 1.4) + (1 << 30)  # FASTQ + the dumped bins
+    d, free = scratch_dir(need)
+    if free < need:
+        reads = max(int(reads * free / need * 0.9), 1_000_000)
+    genome = reads * 150 // 30
+    out = {"input": f"{reads} reads x150bp = {reads * 150 / 1e9:.1f} Gbp, 30x of a {genome} bp random genome (seed {SEED + 1}), FASTQ in {d}", "kmc_flags": f"-k{k} -t{threads} -m{mem} -r"}
+    with tempfile.TemporaryDirectory(dir=d) as td:
+        fq = os.path.join(td, "large.fq")
+        t = time.time()
+        capi.synth_fastq(fq, seed=SEED + 1, genome_len=genome, n_reads=reads)
+        out["fastq_s"] = time.time() - t
+        flags = [f"-k{k}", f"-t{threads}", f"-m{mem}", "-r", "-hp"]
+        r1, r2, rst, _ = _run_kmc(ref, flags, fq, td, "lref", timeout=budget_s)
+        env = dict(os.environ, KMC_HIP_LIB=capi.lib_path(), KMC_HIP_VERBOSE="1")
+        h1, h2, hst, verbose = _run_kmc(hip, flags + ["-sr16"], fq, td, "lhip", env, timeout=budget_s)
+        out.update(kmers=rst["total"], ref_stage1_s=r1, ref_stage2_s=r2, hip_stage1_s=h1, hip_stage2_s=h2, speedup=r2 / h2, ref_Gkmers_per_s=rst["total"] / r2 / 1e9,
+                   hip_Gkmers_per_s=hst["total"] / h2 / 1e9, stats_equal=hst == rst, ref_stats=rst)
+        rep = " ".join(verbose)
+        m = re.search(r"reader: admit ([0-9.]+) s, read ([0-9.]+) s \(summed\), wall ([0-9.]+) s \| workers \(summed over threads\): wait for a bin ([0-9.]+) s, engine ([0-9.]+) s, "
+                      r"wait for the turn to push ([0-9.]+) s, push ([0-9.]+) s, wall ([0-9.]+) s", rep)
+        if m:
+            out["worker_report"] = dict(zip(("reader_admit_s", "reader_read_s_summed", "reader_wall_s", "workers_wait_for_a_bin_s_summed", "engine_s_summed",
+                                             "wait_to_push_s_summed", "push_s_summed", "workers_wall_s_summed"), (float(x) for x in m.groups())))
+        tl = [ln for ln in verbose if ln.startswith("[kmc_hip timeline]")]
+        if tl:
+            out["timeline"] = tl[0][:900]
+        # the same bins, device resident: what is left when reader, host link and completer are taken away
+        if time.time() - t_leg < budget_s * 0.6:
+            dump = os.path.join(td, "dump")
+            os.makedirs(dump)
+            _run_kmc(hip, flags + ["-sr16"], fq, td, "ldump", dict(env, KMC_HIP_BIN_DUMP_DIR=dump), timeout=budget_s)
+            os.remove(fq)
+            sb = DumpedBins(dump)
+            pl = kmc_lut_prefix_len(k, reads, 512)
+            p = capi.make_params(k, lut_prefix_len=pl)
+            w = build_workload(ctx, None, k, p, 0, 1, sb=sb)
+            run_step(ctx, w, 0)
+            t0 = time.perf_counter()
+            for _ in range(2):
+                run_step(ctx, w, 0)
+            dt = (time.perf_counter() - t0) / 2
+            res = read_results(ctx, w)
+            tl_ = res[:, :4].sum(axis=0, dtype=np.uint64)
+            got = {"unique": int(tl_[0]), "below_min": int(tl_[1]), "above_max": int(tl_[2]), "total": int(tl_[3]), "unique_counted": int(tl_[0]) - int(tl_[1]) - int(tl_[2])}
+            nr = np.sort(np.array([x[2] for x in w.bins], dtype=np.int64))
+            out["device_resident_on_reference_bins"] = {
+                "value": w.total_kmers_all / dt / 1e9, "ms_per_step": dt * 1e3, "bins": len(w.bins), "tallies_equal_reference_statistics": got == rst,
+                "bin_kmers_min_median_max": [int(nr[0]), int(nr[nr.size // 2]), int(nr[-1])], "bin_kmers_p90_over_median": float(nr[int(nr.size * 0.9)] / max(nr[nr.size // 2], 1)),
+                "groups_by_path": ctx.path_counters()}
+            w.free()
+    out["leg_s"] = time.time() - t_leg
+    return out
+
+
 def secondary_leg(name: str, k: int, extra, env=None):
     cfg = CONFIGS[name]
     cmd = [sys.executable, os.path.abspath(__file__), "--leg", name, "--k", str(k), "--reads", str(cfg["reads"]), "--genome", str(cfg["genome"]),
@@ -610,6 +721,7 @@ def main():
     ap.add_argument("--no-digest", action="store_true")
     ap.add_argument("--no-oracle-check", action="store_true", help="skip the byte-for-byte comparison of three of the timed run's bins with the oracle")
     ap.add_argument("--cache", default="", help="directory for the generated bin set (tuning sessions: generate once, reuse)")
+    ap.add_argument("--e2e-gbp", type=float, default=8.0, help="size of the e2e_large leg's FASTQ in Gbp (0 = skip; 30 = the full configs[2] shape, ~4 minutes more)")
     ap.add_argument("--dry-launch", action="store_true", help="launcher check (runs without a GPU): start the ranks --gpus asks for, rendezvous over gloo, print what they see")
     args = ap.parse_args()
 
@@ -933,6 +1045,11 @@ def main():
                         and s2t["n_total"] == st["total"])
             except Exception as e:  # the baseline is informative; never lose the GPU number over it
                 out["cpu_baseline"] = {"value": None, "unit": "Gk-mers/s", "cores": 0, "kind": "reference", "sample": f"failed: {e}"}
+            if args.e2e_gbp > 0:
+                try:
+                    out["e2e_large"] = e2e_large_leg(ctx, k, args.e2e_gbp)
+                except Exception as e:  # noqa: BLE001
+                    out["e2e_large"] = {"error": repr(e)[-600:]}
     if rank == 0:
         if rehearsal:  # control flow only: the same record with every timing taken out, so that nothing in it can be taken for a measurement
             out.update(rehearsal=True, backend_kind=capi.backend_kind(), value=None, ms_per_step=None, unique_kmers_per_s=None, stage2_algorithmic_GBs=None,

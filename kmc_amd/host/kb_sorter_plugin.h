@@ -216,6 +216,20 @@ public:
 				epd->pop(t.bin_id, packs);
 				for (auto &e : packs)
 					t.pack_bytes.push_back(e.first);
+				if (const char *dir = getenv("KMC_HIP_BIN_DUMP_DIR")) { /* measurement aid (bench.py e2e_large): the bins exactly as the reference's stage 1 handed them over */
+					const std::string base = std::string(dir) + "/bin_" + std::to_string(t.bin_id);
+					if (FILE *f = fopen((base + ".img").c_str(), "wb")) {
+						if (t.tmp_size)
+							fwrite(t.data, 1, t.tmp_size, f);
+						fclose(f);
+					}
+					if (FILE *f = fopen((base + ".meta").c_str(), "w")) {
+						fprintf(f, "%d %llu %llu %llu\n", (int)t.bin_id, (unsigned long long)t.tmp_size, (unsigned long long)t.n_rec, (unsigned long long)t.pack_bytes.size());
+						for (uint64 pb : t.pack_bytes)
+							fprintf(f, "%llu\n", (unsigned long long)pb);
+						fclose(f);
+					}
+				}
 				memory_bins->reserve(t.bin_id, t.out_buffer, CMemoryBins::mba_suffix);
 				memory_bins->reserve(t.bin_id, t.raw_lut, CMemoryBins::mba_lut);
 				/* capacity of mba_suffix exactly as the reader sized it (kb_reader.h:141-150) */

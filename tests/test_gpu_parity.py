@@ -321,15 +321,21 @@ def test_kmc_with_hip_sorter_writes_the_reference_database(flags, ref_bins, tmp_
     # hip4: four workers sharing two stream slots of device 0 twice over (KMC_HIP_DEVICES=0,0 exercises the
     # multi-device mapping on a 1-GPU box); ordered emission keeps the bytes equal to the reference's -sr1 run
     runs = (("kmc", "ref", ["-sr1"], {}), ("kmc_hip", "hip", ["-sr1"], {}), ("kmc_hip", "hip4", ["-t8", "-sr4"], {"KMC_HIP_DEVICES": "0,0"}))
+    if flags == ["-k27"]:  # the 4-GPU worker layout on one GPU: eight workers over four logical devices (what `kmc_hip -sr8` does on a 4-GPU node, queues.h:2045-2146)
+        runs += (("kmc_hip", "hip8", ["-t16", "-sr8"], {"KMC_HIP_DEVICES": "0,0,0,0", "KMC_HIP_VERBOSE": "1"}),)
     for exe, out, mode, extra in runs:
         env = dict(os.environ, KMC_HIP_LIB=capi.lib_path(), **extra)
         tmp = tmp_path / ("tmp_" + out)
         tmp.mkdir()
         r = subprocess.run([ref_bins[exe], *flags, *mode, fq, str(tmp_path / out), str(tmp)], env=env, capture_output=True, text=True)
         assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+        if out == "hip8":
+            assert "8 workers" in r.stderr, r.stderr[-1500:]
     for ext in (".kmc_pre", ".kmc_suf"):
         assert _md5(str(tmp_path / ("ref" + ext))) == _md5(str(tmp_path / ("hip" + ext))), ext
         assert _md5(str(tmp_path / ("ref" + ext))) == _md5(str(tmp_path / ("hip4" + ext))), ext + " (4 workers, 2 devices)"
+        if flags == ["-k27"]:
+            assert _md5(str(tmp_path / ("ref" + ext))) == _md5(str(tmp_path / ("hip8" + ext))), ext + " (8 workers, 4 devices)"
 
 
 def test_sort_and_bin_cross_portion_boundaries(monkeypatch):

@@ -385,3 +385,34 @@ def test_emit_through_a_sort_gives_the_same_database_and_bins_in_read_order(fmt,
     want = _run("kmc", common + ["-sp1"], path, tmp_path, "ref")
     got = _run("kmc_emu_s1", common + ["-sp2"], path, tmp_path, "emu", env={"KMC_HIP_S1_SORTED_EMIT": "1", "KMC_HIP_VERBOSE": "1"})
     assert got == want and _report_sum("parts through the engine") > 0
+
+
+def test_bin_dump_of_the_stage2_worker_is_what_bench_reads(tmp_path):
+    """bench.py's e2e_large leg runs the bins of a REAL run device-resident: kmc_hip's worker writes what it received from the reference's stage 1
+    ($KMC_HIP_BIN_DUMP_DIR: image + pack list per bin) and bench.DumpedBins reads it back. Here on the mock library: the dumped bins, counted by the oracle,
+    must add up to the statistics the run printed, and the pack lists must tile the images."""
+    if not os.path.exists(_exe("kmc_hip")):
+        pytest.skip("kmc_amd/bin/kmc_hip not built")
+    import sys
+
+    import emu
+    import oracle_py as O
+
+    sys.path.insert(0, ROOT)
+    import bench
+
+    fq = str(tmp_path / "in.fq")
+    synth.make_fastq(fq, seed=5, genome_len=40_000, n_reads=3_000, read_len=150)
+    dump = tmp_path / "dump"
+    dump.mkdir()
+    md5, stats = _run("kmc_hip", ["-k27", "-m2", "-sf1", "-sp2", "-sr2"], fq, tmp_path, "hip", env={"KMC_HIP_LIB": emu.build_mock(), "KMC_HIP_BIN_DUMP_DIR": str(dump)})
+    sb = bench.DumpedBins(str(dump))
+    assert len(sb.meta) == 512 and 0 < len(sb.own) <= 512
+    tot = np.zeros(4, dtype=np.uint64)
+    for b in sb.own:
+        img = sb.image(b)
+        assert img.size == sb.size[b] == int(sb.packs(b).sum())
+        _, _, st = O.process_bin(O.make_params(27), img, int(sb.n_rec[b]))
+        tot += np.asarray(st, dtype=np.uint64)
+    below, above, unique, counted, total = (int(x) for x in stats[:5])
+    assert [int(x) for x in tot] == [unique, below, above, total] and counted == unique - below - above
