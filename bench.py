@@ -66,6 +66,9 @@ CONFIGS = {
 }
 SEED = 2026
 SKEW_REPEATS = "10000:2000:10"
+# a spectrum of repeat families (round 5; kmc_amd/csrc/synth_bins.cpp): an Alu-like 300 bp unit x 100 000 copies at 12 % divergence, an L1-like 6 kbp unit x 5 000 at 2 %, a
+# 171 bp satellite x 100 000 at 2 %, one poly-A run of 20 kbp: ~77 Mbp of the quarter workload's 250 Mbp genome
+SKEW_SPECTRUM = "300:100000:120,6000:5000:20,171:100000:20,H20000"
 
 
 def kmc_lut_prefix_len(k: int, n_reads: int, n_bins: int) -> int:
@@ -1032,6 +1035,10 @@ def main():
                 sec["skew_quarter"] = dict({x: sk.get(x) for x in ("value", "ms_per_step", "sort_path", "local_sort", "tallies", "self_check", "error") if x in sk},
                                            what="quarter workload, k=27, $KMC_SYNTH_REPEATS=%s (unit:copies:per-mille divergence) planted in the genome; sort_path.groups_by_path has "
                                                 "the tiles / records k_giant_tiles took, local_sort.redo_groups the groups that went back through LSD passes" % SKEW_REPEATS)
+                sk = secondary_leg("quarter", 27, ["--no-digest"], env={"KMC_SYNTH_REPEATS": SKEW_SPECTRUM})
+                sec["skew_spectrum_quarter"] = dict({x: sk.get(x) for x in ("value", "ms_per_step", "sort_path", "local_sort", "tallies", "self_check", "error") if x in sk},
+                                                    what="quarter workload, k=27, $KMC_SYNTH_REPEATS=%s: a spectrum of repeat families (unit:copies:per-mille divergence, H = a "
+                                                         "homopolymer run) planted in the genome" % SKEW_SPECTRUM)
             out["secondary"] = sec
         if not args.no_cpu_baseline:
             try:

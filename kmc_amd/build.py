@@ -21,7 +21,7 @@ def _newer(target: str, sources) -> bool:
 
 
 def build_hip(force: bool = False) -> str:
-    srcs = [os.path.join(CSRC, f) for f in ("kmc_hip.hip", "kernels.hip.h", "bucket_sort.hip.h", "order_db.hip.h", "stage1_kernels.hip.h", "stage1_chain.h", "kmer_ops.h")] + [os.path.join(ROOT, "include", "kmc_hip.h")]
+    srcs = [os.path.join(CSRC, f) for f in sorted(os.listdir(CSRC)) if f.endswith((".hip", ".h"))] + [os.path.join(ROOT, "include", "kmc_hip.h")]  # kmc_hip.hip + everything it includes
     if force or _newer(LIB_HIP, srcs):
         hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
         cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wall", "-Wno-unused-function",

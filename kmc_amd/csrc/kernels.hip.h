@@ -355,10 +355,10 @@ template <int SIZE> __device__ __forceinline__ void store_rec(u64 *p, const u64 
 /* 64-bit look-back words (one per tile/slice): [63:62] flag (0 empty, 1 aggregate, 2 inclusive prefix), [61:0] count */
 constexpr u64 ST64_AGG = 1ull << 62, ST64_PREFIX = 2ull << 62, ST64_MASK = (1ull << 62) - 1;
 /* Look-back watchdog. A wait is over when the tile in front publishes — microseconds — or never (a ticket counter that did not start at zero, a
- * status area somebody else wrote into): the watchdog turns "never" into KMC_HIP_EINTERNAL instead of a hang. It must not fire on a wait that is merely
- * long (16 streams share the CUs; a workgroup's waves share their SIMDs with spinning neighbours), so it wants BOTH more than SPIN_LIMIT polls AND more
- * than WATCHDOG_TICKS on the constant 100 MHz clock (4 s; a poll is an s_sleep + a device-coherent load: ~1 us). Polls alone decide only where the
- * clock does not run (the CPU emulation of tests/hipemu: wall_clock64() == 0) or beyond SPIN_HARD. Round 3 counted polls only (2^24). */
+ * status area somebody else wrote into): the watchdog turns "never" into KMC_HIP_EINTERNAL instead of a hang. It counts POLLS, nothing else: a poll is an
+ * s_sleep + a device-coherent load (~1 us), so SPIN_LIMIT = 2^24 polls is on the order of 10+ seconds of one wave waiting — three to four orders of magnitude
+ * beyond the longest wait the storm test produces (16 streams sharing the CUs). A clock-based second condition (wall_clock64) was tried in round 4 and taken out
+ * again: inside lb_blocked it cost k_onesweep<1> 13-35 spilled registers (the comment had kept describing it). */
 constexpr u32 SPIN_LIMIT = 1u << 24;
 struct LbWatch {
 	u32 spins = 0;

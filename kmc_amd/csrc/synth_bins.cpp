@@ -132,20 +132,40 @@ void make_genome(uint64_t seed, uint64_t genome_len, int n_threads, std::vector<
 		x.join();
 	/* $KMC_SYNTH_REPEATS = "unit:copies[:per_mille]" plants `copies` copies of the genome's first `unit` bases at pseudo-random places, each copy with
 	 * per_mille/1000 of its bases substituted (default 0) — the repeat families a real genome has and a uniform random one lacks: their k-mers occur
-	 * copies x coverage times, far beyond what a tile of the LDS sort holds (bench.py's skew leg, tests). Deterministic in (seed, genome_len). */
+	 * copies x coverage times, far beyond what a tile of the LDS sort holds (bench.py's skew leg, tests). Deterministic in (seed, genome_len).
+	 * Round 5: a comma-separated SPECTRUM of families — family j's unit is the `unit` bases behind the units of the families before it (family 0: as ever, so
+	 * the one-family leg of round 4 is unchanged) — and "H<len>": one homopolymer run of `len` A's. E.g. "300:100000:120,6000:5000:20,171:100000:20,H20000":
+	 * an Alu-like family, an L1-like one, a satellite and a poly-A run. */
 	if (const char *e = getenv("KMC_SYNTH_REPEATS")) {
-		unsigned long long unit = 0, copies = 0, pm = 0;
-		if (sscanf(e, "%llu:%llu:%llu", &unit, &copies, &pm) >= 2 && unit >= 1 && unit * 2 <= genome_len) {
-			const std::vector<uint8_t> u(genome.begin(), genome.begin() + (ptrdiff_t)unit);
-			for (unsigned long long c = 0; c < copies; ++c) {
-				const uint64_t at = unit + mix64(seed ^ (0xC0FFEEull + c * 0x9E3779B97F4A7C15ull)) % (genome_len - 2 * unit + 1);
-				for (uint64_t i = 0; i < unit; ++i) {
-					uint8_t b = u[i];
-					if (pm && mix64(seed + 77 * c + 1315423911ull * i) % 1000 < pm)
-						b = (uint8_t)((b + 1 + mix64(seed + c + i) % 3) & 3);
-					genome[at + i] = b;
+		uint64_t unit_off = 0;
+		unsigned fam = 0;
+		for (const char *q = e; *q; ++fam) {
+			unsigned long long unit = 0, copies = 0, pm = 0;
+			if (*q == 'H') {
+				const unsigned long long len = strtoull(q + 1, nullptr, 10);
+				if (len >= 1 && len * 2 <= genome_len) {
+					const uint64_t at = mix64(seed ^ 0xA11A11ull ^ fam) % (genome_len - len + 1);
+					for (uint64_t i = 0; i < len; ++i)
+						genome[at + i] = 0;
 				}
+			} else if (sscanf(q, "%llu:%llu:%llu", &unit, &copies, &pm) >= 2 && unit >= 1 && unit_off + unit * 2 <= genome_len) {
+				const std::vector<uint8_t> u(genome.begin() + (ptrdiff_t)unit_off, genome.begin() + (ptrdiff_t)(unit_off + unit));
+				const uint64_t fs = seed ^ ((uint64_t)fam * 0xD1B54A32D192ED03ull); /* family 0: the seed itself */
+				for (unsigned long long c = 0; c < copies; ++c) {
+					const uint64_t at = unit_off + unit + mix64(fs ^ (0xC0FFEEull + c * 0x9E3779B97F4A7C15ull)) % (genome_len - unit_off - 2 * unit + 1);
+					for (uint64_t i = 0; i < unit; ++i) {
+						uint8_t b = u[i];
+						if (pm && mix64(fs + 77 * c + 1315423911ull * i) % 1000 < pm)
+							b = (uint8_t)((b + 1 + mix64(fs + c + i) % 3) & 3);
+						genome[at + i] = b;
+					}
+				}
+				unit_off += unit;
 			}
+			while (*q && *q != ',')
+				++q;
+			if (*q == ',')
+				++q;
 		}
 	}
 }

@@ -92,11 +92,10 @@ struct KmcHostPool {
 		free_ranges[off] = len;
 		return true;
 	}
-	~KmcHostPool()
-	{
-		if (slab && free_fn)
-			free_fn(slab);
-	}
+	/* No destructor work: this object dies during static destruction, and hipHostFree through a dlopen'd library at that point runs after (or during) the HIP
+	 * runtime's own atexit teardown unless the pool happened to be constructed after the library was loaded. The slab lives as long as the process;
+	 * the kernel returns pinned memory at exit. */
+	~KmcHostPool() {}
 };
 
 #endif

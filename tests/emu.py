@@ -86,7 +86,8 @@ def build_hostlib(geometry="small", force=False) -> str:
     then run on a box without a GPU (small inputs: one OS thread per GPU thread)."""
     so = os.path.join(EMU_DIR, f"libkmc_hip_emu_{geometry}.so")
     csrc = os.path.join(ROOT, "kmc_amd", "csrc")
-    srcs = [os.path.join(csrc, f) for f in ("kmc_hip.hip", "kernels.hip.h", "bucket_sort.hip.h", "order_db.hip.h", "kmer_ops.h", "stage1_kernels.hip.h", "stage1_chain.h")] + [
+    host_parts = sorted(f for f in os.listdir(csrc) if f.startswith("host_") and f.endswith(".hip.h"))  # kmc_hip.hip's own parts (they hold kernel launches)
+    srcs = [os.path.join(csrc, f) for f in ["kmc_hip.hip", "kernels.hip.h", "bucket_sort.hip.h", "order_db.hip.h", "kmer_ops.h", "stage1_kernels.hip.h", "stage1_chain.h"] + host_parts] + [
         os.path.join(ROOT, "include", "kmc_hip.h"), os.path.join(EMU_DIR, "include", "hip", "hip_runtime.h"), os.path.join(EMU_DIR, "include", "hip", "hip_host_api.h"),
         os.path.join(EMU_DIR, "include", "rccl", "rccl.h"), os.path.abspath(__file__)]
     if force or not os.path.exists(so) or any(os.path.getmtime(x) > os.path.getmtime(so) for x in srcs):
@@ -94,7 +95,14 @@ def build_hostlib(geometry="small", force=False) -> str:
         os.makedirs(gen_dir, exist_ok=True)
         gen = os.path.join(gen_dir, f"kmc_hip_emu_{geometry}.cpp")
         with open(srcs[0]) as f:
-            text = rewrite_launches(f.read())
+            text = f.read()
+        for part in host_parts:  # inline the parts again: the launch rewriter works on one text
+            inc = '#include "%s"' % part
+            assert text.count(inc) == 1, part
+            line = text[text.index(inc):].split("\n", 1)[0]
+            with open(os.path.join(csrc, part)) as f:
+                text = text.replace(line, f.read())
+        text = rewrite_launches(text)
         with open(gen, "w") as f:
             f.write("/* GENERATED by tests/emu.py build_hostlib from kmc_amd/csrc/kmc_hip.hip: only the kernel launches were rewritten */\n" + text)
         subprocess.check_call(["g++", "-std=c++17", "-O1", "-g", "-fPIC", "-shared", "-pthread", "-w", "-fno-gnu-unique", "-Wl,-Bsymbolic", "-DHIPEMU_HOST_API",

@@ -1045,3 +1045,23 @@ def test_order_database_matches_kmc_tools_transform_sort(ctx, flags, ref_bins, t
     assert n == sum(b[0].size for b in bins) // ((k - p) // 4 + cs) and n > 500
     assert np.array_equal(lut, want_lut), _first_diff(lut, want_lut)
     assert np.array_equal(out, want_recs), _first_diff(out, want_recs)
+
+
+def test_collapsing_finisher_stays_correct_behind_its_switch():
+    """KMC_HIP_RANK_COLLAPSE=1 (read once per process) selects k_bucket_rank_c — a row's copies folded into weighted entries before anything is ranked (round 5; not the
+    default: on 30x data it costs more than it saves) — instead of k_bucket_rank<SIZE, true>: the switch must keep selecting a correct kernel — the smoke
+    check (reference golden bins + synthetic k = 27 / 55 bins against the oracle) and a repeat-rich bin set in a process of its own."""
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import os, sys, numpy as np; sys.path.insert(0, 'tests'); import __graft_entry__ as g; g.smoke();"
+            "import oracle_py as O; from kmc_amd import capi; from test_gpu_parity import _run_batch;"
+            "ctx = capi.Context((0,));"
+            "os.environ['KMC_SYNTH_REPEATS'] = '300:400:100,2000:60:10,H3000';"
+            "bins = capi.synth_bins(seed=9, genome_len=400_000, n_reads=120_000, k=27, n_bins=8);"
+            "p = capi.make_params(27, lut_prefix_len=3); got, err = _run_batch(ctx, p, bins, 1); assert err is None, err;"
+            "ok = all(all(np.array_equal(a, b) for a, b in zip(got[i], O.process_bin(O.make_params(27, lut_prefix_len=3), img, nrec))) for i, (img, nrec, pk, _) in enumerate(bins));"
+            "print('repeats', ok, ctx.path_counters())")
+    r = subprocess.run([sys.executable, "-c", code], cwd=root, env=dict(os.environ, KMC_HIP_RANK_COLLAPSE="1"), capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "smoke OK" in r.stdout and "repeats True" in r.stdout, (r.stdout + r.stderr)[-1500:]

@@ -213,12 +213,15 @@ print("RANK-OK")
 '''
 
 
-def test_rank_path_on_the_emulated_host_library():
-    """k_bucket_rank (bucket_sort.hip.h) on the CPU, as a default run takes it: groups of k-mers of every record width through the HBM passes, k_bucket_bounds,
+@pytest.mark.parametrize("collapse", ["1", "0"], ids=["k_bucket_rank_c", "k_bucket_rank"])
+def test_rank_path_on_the_emulated_host_library(collapse):
+    """k_bucket_rank_c (round 5's default: a row's copies folded into weighted entries before anything is ranked) and k_bucket_rank (round 4's, KMC_HIP_RANK_COLLAPSE=0)
+    (bucket_sort.hip.h) on the CPU, as a default run takes them: groups of k-mers of every record width through the HBM passes, k_bucket_bounds,
     the pairwise ranking of every tile (32- and 64-bit pairs, A/B pairs of two-word records, whole records beyond) and the counting of the ranked tile inside
     LDS (fused), chunked tiles, the in-place variant + k_compact — per bin against the oracle; and the redo of a group with a bucket beyond a tile."""
     lib = emu.build_hostlib("small")
-    r = subprocess.run([sys.executable, "-c", _RANK_CASE % {"root": ROOT}], env=dict(os.environ, KMC_HIP_LIB=lib), capture_output=True, text=True, timeout=1500, cwd=ROOT)
+    r = subprocess.run([sys.executable, "-c", _RANK_CASE % {"root": ROOT}], env=dict(os.environ, KMC_HIP_LIB=lib, KMC_HIP_RANK_COLLAPSE=collapse), capture_output=True, text=True,
+                       timeout=1500, cwd=ROOT)
     assert r.returncode == 0 and "RANK-OK" in r.stdout, (r.stdout + r.stderr)[-1500:]
 
 

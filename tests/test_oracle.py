@@ -129,7 +129,7 @@ def test_cabi_library_exports_every_declared_symbol():
     L = capi.load()
     for name in declared:
         assert hasattr(L, name), name
-    assert L.kmc_hip_abi_version() == 3
+    assert L.kmc_hip_abi_version() == 4  # 4: kmc_hip_split_params.part_kind
     # pure host-side helpers agree with the oracle
     for cx, cs in ((10**9, 255), (10**9, 1), (200, 70000), (10**9, 70000), (10**9, 2**24)):
         assert L.kmc_hip_counter_size(cx, cs) == O.lib().oracle_counter_size(cx, cs)

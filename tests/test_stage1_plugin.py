@@ -106,9 +106,10 @@ def test_splitter_plugin_when_one_bin_takes_whole_parts(tmp_path):
 
 
 @needs_ref
-def test_splitter_plugin_hands_long_read_parts_to_the_reference_splitter(tmp_path):
-    """a record larger than a part of the reader arrives as ReadType::long_read pieces: the worker pushes its own buffers and lets a reference
-    CSplitter of the same thread take those parts; short reads before and after go through the engine"""
+def test_splitter_plugin_takes_long_read_parts_through_its_engine(tmp_path):
+    """a record larger than a part of the reader arrives as ReadType::long_read pieces (queues.h:40): since round 5 they go through the engine like every other
+    part (here the oracle's restatement of CSplitter::GetSeqLongRead): database and statistics — the super-k-mer count among them: the pieces of
+    mem_part_pmm_reads symbols are cut where the reference cuts them — equal the unmodified reference's; short reads before and after likewise"""
     rng = np.random.default_rng(9)
     path = str(tmp_path / "in.fq")
     with open(path, "wb") as f:
@@ -123,18 +124,23 @@ def test_splitter_plugin_hands_long_read_parts_to_the_reference_splitter(tmp_pat
     common = ["-k27", "-ci1", "-m2", "-sf1", "-sr1"]
     want = _run("kmc", common + ["-sp1"], path, tmp_path, "ref")
     assert _run("kmc_oracle_s1", common + ["-sp2"], path, tmp_path, "plug", env={"KMC_HIP_VERBOSE": "1"}) == want
-    assert _report_sum("long-read parts") > 0 and _report_sum("parts through the engine") > 0
+    assert _report_sum("of them long-read parts") > 0 and _report_sum("parts through the engine") > 0 and _report_sum("uncovered parts") == 0
 
 
 @needs_ref
-def test_splitter_plugin_falls_back_for_jobs_it_does_not_cover(tmp_path):
+def test_splitter_plugin_refuses_jobs_it_does_not_cover(tmp_path):
+    """-hc (homopolymer compression) is not what the engine computes: the worker stops the run and names the reason (it used to run the reference's worker
+    instead: a silent path into the reference). -e alone is the reference's estimate-only worker, not this class: unchanged."""
     fq = str(tmp_path / "in.fq")
     synth.make_fastq(fq, seed=4, genome_len=50_000, n_reads=5_000, read_len=150)
-    for flags in (["-k27", "-hc"], ["-k27", "-e"]):  # homopolymer compression; histogram estimation while counting
-        common = flags + ["-ci1", "-m2", "-sf1", "-sr1"]
-        want = _run("kmc", common + ["-sp1"], fq, tmp_path, "ref")
-        assert _run("kmc_oracle_s1", common + ["-sp2"], fq, tmp_path, "plug", env={"KMC_HIP_VERBOSE": "1"}) == want, flags
-        assert not _run.report  # the reference worker ran the whole job
+    t = tmp_path / "tmp_hc"
+    t.mkdir()
+    r = subprocess.run([_exe("kmc_oracle_s1"), "-k27", "-hc", "-ci1", "-m2", "-sf1", "-sr1", "-sp2", fq, str(tmp_path / "db_hc"), str(t)], capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and "does not cover homopolymer compression" in r.stdout + r.stderr, (r.stdout + r.stderr)[-800:]
+    t2 = tmp_path / "tmp_e"
+    t2.mkdir()
+    r = subprocess.run([_exe("kmc_oracle_s1"), "-k27", "-e", "-m2", "-sf1", "-sp2", fq, str(tmp_path / "db_e"), str(t2)], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, (r.stdout + r.stderr)[-800:]  # estimation only: CWEstimateOnlySplitter, the reference's own class
 
 
 @needs_ref
