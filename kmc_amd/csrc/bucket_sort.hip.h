@@ -390,12 +390,11 @@ __global__ void __launch_bounds__(BsCfg<SIZE>::THREADS) k_bucket_sort(u64 *__res
 #endif
 /* Buckets beyond BR_BIG records are not ranked by their own records' walks: a record's walk is as long as its bucket, a bucket sits in one or two waves, and the
  * workgroup waits for its slowest wave — on repeat-rich input a bucket of a few hundred records in 40 % of the tiles made the rank loops 2.7 x as long as on
- * uniform reads although the pair work per record was the same 20-25 (profiles/r05: bucket_hist_*.txt, experiments). Such buckets go on a list and ALL waves
- * rank them together (k_bucket_rank: "big buckets"). 30x reads of a random genome have no bucket beyond 128. */
+ * uniform reads although the pair work per record was the same 20-25 (profiles/r05: bucket_hist_*.txt, experiments). Their records are dealt out again
+ * over ALL waves (k_bucket_rank: "big buckets"). 30x reads of a random genome have no bucket beyond 128. */
 #ifndef BR_BIG
 #define BR_BIG 128
 #endif
-constexpr int BR_BIG_MAX = 64; /* listed buckets per tile: a tile holds at most CAP / (BR_BIG + 1) = 47 of them */
 template <int SIZE> struct BrCfg {
 	static constexpr int THREADS = BR_THREADS;
 	static constexpr int ITEMS = SIZE == 1 ? 8 : (SIZE == 2 ? 4 : 2); /* rows of 64 records per wave */
@@ -474,8 +473,7 @@ __global__ void __launch_bounds__(BrCfg<SIZE>::THREADS, BR_MIN_WAVES) k_bucket_r
 	u32 *s_wlast = s_wmax + NW;                                               /* [NW] FUSED: the last run tail inside wave w's rows */
 	u32 *s_wcnt = s_wlast + NW;                                               /* [NW] FUSED: counted k-mers of wave w */
 	u32 *s_wtal = s_wcnt + NW;                                                /* [NW][3] FUSED: distinct / below min / above max of wave w */
-	u32 *s_nbig = s_wtal + 5 * NW + 8;                                        /* [1] buckets beyond BR_BIG records in this tile, [BR_BIG_MAX] their spans (behind k_bucket_rank_c's two rows) */
-	u32 *s_big = s_nbig + 1;
+	u32 *s_nbig = s_wtal + 5 * NW + 8;                                        /* [1] != 0: the tile has a bucket beyond BR_BIG records (behind k_bucket_rank_c's two rows) */
 
 	const u32 gtile = blockIdx.x;
 	const u32 bin = (u32)__builtin_amdgcn_readfirstlane((int)grp_find(gr.win_prefix, gr.g, gtile));
@@ -607,6 +605,7 @@ __global__ void __launch_bounds__(BrCfg<SIZE>::THREADS, BR_MIN_WAVES) k_bucket_r
 		s_start[total_heads] = len;
 	__syncthreads();
 	u32 span[ITEMS], rel[ITEMS], widest = 0; /* span: [15:0] start of the record's bucket, [31:16] its end (tile-relative; CAP < 65536) */
+	bool any_big = false;
 #pragma unroll
 	for (int r = 0; r < ITEMS; ++r) {
 		const u32 idx = crel + r * 64 + lane;
@@ -618,40 +617,38 @@ __global__ void __launch_bounds__(BrCfg<SIZE>::THREADS, BR_MIN_WAVES) k_bucket_r
 			span[r] = bstart | (bend << 16);
 			rel[r] = idx - bstart;
 			widest = widest > bend - bstart ? widest : bend - bstart;
-			if (((headbits >> r) & 1u) && bend - bstart > (u32)BR_BIG) { /* the bucket's first record puts it on the list */
-				const u32 j = atomicAdd(s_nbig, 1u);
-				if (j < (u32)BR_BIG_MAX)
-					s_big[j] = span[r];
-			}
+			if (bend - bstart > (u32)BR_BIG)
+				any_big = true;
 		}
 	}
-	/* Big buckets: every thread of the workgroup takes (record, part of the bucket) items — the record's pair against the pairs of that part, partial counts added
-	 * up in LDS (R1: the bucket table is dead once the spans are in registers) — instead of the bucket's own two or three waves walking all of it.
-	 * `less(q, i)`: is the pair at tile position q in front of the pair at i. Called by all threads, after the barrier behind the pair stores. */
+	if (any_big)
+		atomicOr(s_nbig, 1u); /* (no value returned: one LDS OR; the barrier behind the pair stores publishes it) */
+	/* Big buckets (beyond BR_BIG records): their records change hands. A record's walk is as long as its bucket and a bucket lies in one or two waves, so the
+	 * owners' walks made the whole workgroup wait for those waves. Instead the big records are dealt out again by their POSITION — record idx to thread idx mod
+	 * THREADS: a bucket's consecutive records to consecutive threads of several waves — each thread walks the bucket of the records it was dealt, and the owners
+	 * read the ranks back. R1 carries both ways (the bucket table is dead once the spans are in registers): the owner leaves its span there with bit 31 set
+	 * (table entries are positions: bit 31 clear), the dealer puts the rank in its place. No list, no atomics: the first version registered the buckets through a
+	 * returning LDS atomic and lost entries on the device (never under the emulation; profiles/r05/experiments). `less(q, i)`: is the pair at tile position q in
+	 * front of the pair at i — given as `count(bs, be, i)`: how many pairs of [bs, be) are in front of the pair at i (the one-word forms read eight pairs per step: a walk
+	 * of one load, one compare and one add at a time is bound by the LDS latency, and only the few waves the bucket was dealt to are running). Called by all threads,
+	 * after the barrier behind the pair stores. */
 	u32 place[ITEMS];
 	u32 *s_rank = s_start;
 	auto is_big = [&](int r) -> bool { return (span[r] >> 16) - (span[r] & 0xFFFFu) > (u32)BR_BIG; };
-	auto rank_big_buckets = [&](auto less) {
-		const u32 nbig = *s_nbig < (u32)BR_BIG_MAX ? *s_nbig : (u32)BR_BIG_MAX; /* uniform */
-		if (!nbig)
+	auto rank_big_buckets = [&](auto count) {
+		if (!*s_nbig) /* uniform */
 			return;
 #pragma unroll
 		for (int r = 0; r < ITEMS; ++r)
-			if (is_big(r))
-				s_rank[crel + r * 64 + lane] = 0;
+			if (crel + r * 64 + lane < len) /* every slot below len is written: what the table or an earlier workgroup left there must not be taken for a span */
+				s_rank[crel + r * 64 + lane] = is_big(r) ? span[r] | 0x80000000u : 0u;
 		__syncthreads();
-		for (u32 b = 0; b < nbig; ++b) {
-			const u32 bs = s_big[b] & 0xFFFFu, be = s_big[b] >> 16, n = be - bs;
-			const u32 parts = n >= (u32)THREADS ? 1u : ((u32)THREADS + n - 1) / n; /* about one item per thread for buckets below the workgroup's size */
-			const u32 plen = (n + parts - 1) / parts;
-			for (u32 w = tid; w < n * parts; w += THREADS) {
-				const u32 part = w / n, i = bs + (w - part * n); /* consecutive threads: consecutive records, the same part (its pairs are read as broadcasts) */
-				const u32 q0 = bs + part * plen, q1 = q0 + plen < be ? q0 + plen : be;
-				u32 cnt = 0;
-				for (u32 q = q0; q < q1; ++q)
-					cnt += less(q, i) ? 1u : 0u;
-				if (cnt)
-					atomicAdd(&s_rank[i], cnt);
+#pragma unroll 1
+		for (int m = 0; m < ITEMS; ++m) {
+			const u32 i = (u32)m * THREADS + tid;
+			const u32 v = i < len ? s_rank[i] : 0u;
+			if (v >> 31) {
+				s_rank[i] = count(v & 0xFFFFu, (v >> 16) & 0x7FFFu, i); /* read and written by this thread only */
 			}
 		}
 		__syncthreads();
@@ -707,7 +704,22 @@ __global__ void __launch_bounds__(BrCfg<SIZE>::THREADS, BR_MIN_WAVES) k_bucket_r
 					rank += s_k32[q] < c ? 1u : 0u;
 				place[r] = bstart + rank;
 			}
-			rank_big_buckets([&](u32 q, u32 i) { return s_k32[q] < s_k32[i]; });
+			rank_big_buckets([&](u32 bs, u32 be, u32 i) {
+				const u32 c = s_k32[i];
+				u32 n = 0, q = bs;
+				for (; q + 8 <= be; q += 8) {
+					u32 x[8];
+#pragma unroll
+					for (int u = 0; u < 8; ++u)
+						x[u] = s_k32[q + u];
+#pragma unroll
+					for (int u = 0; u < 8; ++u)
+						n += x[u] < c ? 1u : 0u;
+				}
+				for (; q < be; ++q)
+					n += s_k32[q] < c ? 1u : 0u;
+				return n;
+			});
 		} else {
 #pragma unroll
 			for (int r = 0; r < ITEMS; ++r) {
@@ -731,7 +743,22 @@ __global__ void __launch_bounds__(BrCfg<SIZE>::THREADS, BR_MIN_WAVES) k_bucket_r
 					rank += s_key[q] < c ? 1u : 0u;
 				place[r] = bstart + rank;
 			}
-			rank_big_buckets([&](u32 q, u32 i) { return s_key[q] < s_key[i]; });
+			rank_big_buckets([&](u32 bs, u32 be, u32 i) {
+				const u64 c = s_key[i];
+				u32 n = 0, q = bs;
+				for (; q + 8 <= be; q += 8) {
+					u64 x[8];
+#pragma unroll
+					for (int u = 0; u < 8; ++u)
+						x[u] = s_key[q + u];
+#pragma unroll
+					for (int u = 0; u < 8; ++u)
+						n += x[u] < c ? 1u : 0u;
+				}
+				for (; q < be; ++q)
+					n += s_key[q] < c ? 1u : 0u;
+				return n;
+			});
 		}
 	} else if constexpr (SIZE == 2) {
 		u64 *s_A = s_key;                                     /* [CAP] rem >> 16 */
@@ -775,7 +802,26 @@ __global__ void __launch_bounds__(BrCfg<SIZE>::THREADS, BR_MIN_WAVES) k_bucket_r
 			}
 			place[r] = bstart + rank;
 		}
-		rank_big_buckets([&](u32 q, u32 i) { return s_A[q] < s_A[i] || (s_A[q] == s_A[i] && s_B[q] < s_B[i]); });
+		rank_big_buckets([&](u32 bs, u32 be, u32 i) {
+			const u64 a = s_A[i];
+			const u32 A[2] = {(u32)a, (u32)(a >> 32)};
+			const u32 B = s_B[i];
+			u32 n = 0, q = bs;
+			for (; q + 4 <= be; q += 4) {
+#pragma unroll
+				for (int u = 0; u < 4; ++u) {
+					const u64 o = s_A[q + u];
+					const u32 x[2] = {(u32)o, (u32)(o >> 32)};
+					br_rank_add_less<2>(n, x, s_B[q + u], A, B);
+				}
+			}
+			for (; q < be; ++q) {
+				const u64 o = s_A[q];
+				const u32 x[2] = {(u32)o, (u32)(o >> 32)};
+				br_rank_add_less<2>(n, x, s_B[q], A, B);
+			}
+			return n;
+		});
 	} else {
 #pragma unroll
 		for (int r = 0; r < ITEMS; ++r) {
@@ -817,13 +863,27 @@ __global__ void __launch_bounds__(BrCfg<SIZE>::THREADS, BR_MIN_WAVES) k_bucket_r
 				count_one(q);
 			place[r] = bstart + rank;
 		}
-		rank_big_buckets([&](u32 q, u32 i) { /* whole records, most significant word first; equal records: the one in front */
-			for (int w = SIZE - 1; w >= 0; --w) {
-				const u64 a = s_key[(size_t)q * SIZE + w], b = s_key[(size_t)i * SIZE + w];
-				if (a != b)
-					return a < b;
+		rank_big_buckets([&](u32 bs, u32 be, u32 i) { /* whole records, the position as the last word: as in the owners' walks */
+			u64 m[SIZE];
+			load_rec<SIZE>(s_key + (size_t)i * SIZE, m);
+			u32 y[2 * SIZE], n = 0;
+#pragma unroll
+			for (int w = 0; w < SIZE; ++w) {
+				y[2 * w] = (u32)m[w];
+				y[2 * w + 1] = (u32)(m[w] >> 32);
 			}
-			return q < i;
+			for (u32 q = bs; q < be; ++q) {
+				u64 o[SIZE];
+				load_rec<SIZE>(s_key + (size_t)q * SIZE, o);
+				u32 x[2 * SIZE];
+#pragma unroll
+				for (int w = 0; w < SIZE; ++w) {
+					x[2 * w] = (u32)o[w];
+					x[2 * w + 1] = (u32)(o[w] >> 32);
+				}
+				br_rank_add_less<2 * SIZE>(n, x, q, y, i);
+			}
+			return n;
 		});
 	}
 #if defined(BR_STOP_AFTER) && BR_STOP_AFTER <= 2

@@ -673,7 +673,7 @@ int rank_group(Slot &s, const std::vector<BinPlan> &bins, u64 *sorted, u64 *scra
 	else
 		k_bucket_rank<SIZE, true><<<dim3((u32)wins, 2), dim3(BrCfg<SIZE>::THREADS), br_lds_bytes<SIZE>() + lds_pad, s.stream>>>(gr, P, sp.key_bits, sp.hbits(), n_sh, lut_entries, lut_mask, d_flag);
 	/* the tiles with a bucket beyond the LDS capacity (k-mers repeated thousands of times), one workgroup each; nothing listed: a launch that returns */
-	k_giant_tiles<SIZE><<<dim3((u32)std::min<u64>(wins, 256)), dim3(GT_THREADS), 0, s.stream>>>(gr, P, (u32)S, sp.key_bits, sp.hbits(), n_sh, lut_entries, lut_mask, err);
+	k_giant_tiles<SIZE><<<dim3((u32)std::min<u64>(wins, 256 * (1024 / GT_THREADS))), dim3(GT_THREADS), 0, s.stream>>>(gr, P, (u32)S, sp.key_bits, sp.hbits(), n_sh, lut_entries, lut_mask, err);
 	if (s.timed)
 		HIPCHK(hipEventRecord(e1, s.stream));
 	k_compact_fold<<<dim3((u32)bins.size()), dim3(256), 0, s.stream>>>(gf, use_lut ? n_sh : 1u, lut_entries, 1u, rec_bytes, err);
