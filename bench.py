@@ -51,7 +51,7 @@ sys.path.insert(0, ROOT)
 from kmc_amd import capi, sharding  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
-PMC_PROFILE = os.path.join(ROOT, "profiles", "r04", "pmc_hbm_traffic.json")  # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes
+PMC_PROFILE = os.path.join(ROOT, "profiles", "r05", "pmc_hbm_traffic.json")  # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes
 
 # BASELINE.json configs -> generator parameters
 CONFIGS = {
@@ -922,13 +922,13 @@ def main():
                           "groups_by_path": pc, "hbm_passes_per_record": hbm_passes, "hbm_bytes_per_kmer_moved_by_design": moved, "moved_GBs": moved * value, "moved_frac_of_hbm_peak": moved * value / HBM_PEAK_GBS,
                           "note": "SURVEY 8d: an implementation with fewer passes moves fewer real bytes — stage2_algorithmic_* below is the NORMATIVE 8-bit-LSD figure W(2P+3) "
                                   "(what the reference formulation would have to move for this throughput: it can exceed the HBM peak when passes are skipped), "
-                                  "moved_* is what this path is designed to move (PMC-checked per kernel in profiles/r04)"},
+                                  "moved_* is what this path is designed to move (PMC-checked per kernel in profiles/r05)"},
             "stage2_algorithmic_bytes_per_kmer": W * (2 * P + 3),
             "stage2_algorithmic_GBs": W * (2 * P + 3) * value,
             "stage2_frac_of_hbm_peak": W * (2 * P + 3) * value / HBM_PEAK_GBS,
             "roofline": {"bound": "hbm", "kernel": kern, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(kern, rpl),
-                         "traffic_unit": "HBM bytes per launch (PMC FETCH_SIZE x2 + WRITE_SIZE, profiles/r04/pmc_hbm_traffic.json)",
+                         "traffic_unit": "HBM bytes per launch (PMC FETCH_SIZE x2 + WRITE_SIZE, profiles/r05/pmc_hbm_traffic.json)",
                          "algorithmic_bytes_per_launch": 2 * SW * rpl, "launches_in_timed_region": n_launch, "avg_launch_ms": avg_ms,
                          "records_per_launch": rpl, "algorithmic_bytes_per_record_per_launch": 2 * SW,
                          "note": "consecutive bins of a stream share one sort (bins_per_sort: the bin's number inside the group rides in the spare bits of the "

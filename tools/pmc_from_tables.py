@@ -26,7 +26,8 @@ def main():
         rd, wr = 2.0 * f[k][0] * 1024.0, w.get(k, (0, 0))[0] * 1024.0
         kernels[k] = {"launches": f[k][1], "hbm_read_bytes_per_launch": rd, "hbm_write_bytes_per_launch": wr, "hbm_bytes_per_launch": rd + wr}
     rpl = line["roofline"]["records_per_launch"]
-    per_group = sum(v["hbm_bytes_per_launch"] * v["launches"] for k, v in kernels.items()) / max(kernels.get("k_expand<1, true>", kernels[next(iter(kernels))])["launches"], 1)
+    groups = kernels.get("k_parse_packs", kernels[next(iter(kernels))])["launches"]  # one parse launch per group, whatever the record width
+    per_group = sum(v["hbm_bytes_per_launch"] * v["launches"] for k, v in kernels.items()) / max(groups, 1)
     json.dump({"note": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes over `python bench.py --k K --leg quarter --steps 1 --warmup 0 --no-digest` "
                        "(tools/gpu_session.sh pmck). Counters are KiB, averaged per launch; FETCH_SIZE x2 (gfx950 reports half, calibrated on tools/ubench_scatter.hip in "
                        "round 1), WRITE_SIZE exact.",
