@@ -443,6 +443,8 @@ def short_line(out):
         v = sec[name_]
         if isinstance(v, dict):
             e = {"value": v.get("value"), "ms_per_step": v.get("ms_per_step")}
+            if isinstance(v.get("value_two_streams"), float):
+                e["value_two_streams"] = v["value_two_streams"]
             if v.get("error"):
                 e = {"error": str(v["error"])[-120:]}
             eq = (v.get("self_check") or {}).get("oracle_bins_equal")
@@ -725,6 +727,7 @@ def main():
     ap.add_argument("--no-oracle-check", action="store_true", help="skip the byte-for-byte comparison of three of the timed run's bins with the oracle")
     ap.add_argument("--cache", default="", help="directory for the generated bin set (tuning sessions: generate once, reuse)")
     ap.add_argument("--e2e-gbp", type=float, default=8.0, help="size of the e2e_large leg's FASTQ in Gbp (0 = skip; 30 = the full configs[2] shape, ~4 minutes more)")
+    ap.add_argument("--also-two-streams", action="store_true", help="secondary legs: time the step with two groups in flight as well (value_two_streams)")
     ap.add_argument("--dry-launch", action="store_true", help="launcher check (runs without a GPU): start the ranks --gpus asks for, rendezvous over gloo, print what they see")
     args = ap.parse_args()
 
@@ -952,6 +955,17 @@ def main():
             if rehearsal:
                 for pr in per_rank:
                     pr["busy_ms_per_step"] = None
+    if rank == 0 and world == 1 and args.leg and args.also_two_streams:
+        # a secondary leg on repeat-rich input: what the latency-bound k_giant_tiles costs when another group's kernels can run beside it (the drop-in's normal
+        # mode: several slots in flight). The leg's `value` stays the one-stream schedule, comparable with the rounds before.
+        try:
+            run_step(ctx, w, 2)
+            t1 = time.perf_counter()
+            for _ in range(2):
+                run_step(ctx, w, 2)
+            out["value_two_streams"] = w.total_kmers_all * 2 / (time.perf_counter() - t1) / 1e9
+        except Exception as e:  # noqa: BLE001
+            out["value_two_streams"] = repr(e)
     # ---- after the timed region: overlapped streams, host boundary, secondary workloads, the reference (rank 0 of a 1-GPU run only)
     if rank == 0 and world == 1 and is_main:
         # The timed region runs big bins back to back on ONE stream, so that a k_onesweep launch has the GPU to itself and its
@@ -1031,12 +1045,12 @@ def main():
                     sec["k%d_quarter" % kk] = {x: sk.get(x) for x in ("value", "ms_per_step", "config", "roofline", "sort_path", "local_sort", "tallies", "self_check", "error") if x in sk}
                 # skew: the same quarter with a repeat family planted in the genome (a 10 kbp unit x 2000 copies, 1 % diverged: its k-mers occur tens of thousands
                 # of times — far beyond a tile of the LDS sort): what do k_giant_tiles and, beyond it, the redo through LSD passes cost on repeat-rich input?
-                sk = secondary_leg("quarter", 27, ["--no-digest"], env={"KMC_SYNTH_REPEATS": SKEW_REPEATS})
-                sec["skew_quarter"] = dict({x: sk.get(x) for x in ("value", "ms_per_step", "sort_path", "local_sort", "tallies", "self_check", "error") if x in sk},
+                sk = secondary_leg("quarter", 27, ["--no-digest", "--also-two-streams"], env={"KMC_SYNTH_REPEATS": SKEW_REPEATS})
+                sec["skew_quarter"] = dict({x: sk.get(x) for x in ("value", "value_two_streams", "ms_per_step", "sort_path", "local_sort", "tallies", "self_check", "error") if x in sk},
                                            what="quarter workload, k=27, $KMC_SYNTH_REPEATS=%s (unit:copies:per-mille divergence) planted in the genome; sort_path.groups_by_path has "
                                                 "the tiles / records k_giant_tiles took, local_sort.redo_groups the groups that went back through LSD passes" % SKEW_REPEATS)
-                sk = secondary_leg("quarter", 27, ["--no-digest"], env={"KMC_SYNTH_REPEATS": SKEW_SPECTRUM})
-                sec["skew_spectrum_quarter"] = dict({x: sk.get(x) for x in ("value", "ms_per_step", "sort_path", "local_sort", "tallies", "self_check", "error") if x in sk},
+                sk = secondary_leg("quarter", 27, ["--no-digest", "--also-two-streams"], env={"KMC_SYNTH_REPEATS": SKEW_SPECTRUM})
+                sec["skew_spectrum_quarter"] = dict({x: sk.get(x) for x in ("value", "value_two_streams", "ms_per_step", "sort_path", "local_sort", "tallies", "self_check", "error") if x in sk},
                                                     what="quarter workload, k=27, $KMC_SYNTH_REPEATS=%s: a spectrum of repeat families (unit:copies:per-mille divergence, H = a "
                                                          "homopolymer run) planted in the genome" % SKEW_SPECTRUM)
             out["secondary"] = sec
