@@ -457,6 +457,7 @@ struct GrpRank {
 #define GT_MAX_RECORDS_LOG2 20 /* one workgroup sorts up to a million records by itself (~1-2 ms); beyond that the group goes back to the host */
 #endif
 constexpr u64 GT_MAX_RECORDS = 1ull << GT_MAX_RECORDS_LOG2;
+constexpr u32 GT_CUT_SHIFT = 19; /* a list entry of k_giant_tiles: [18:0] the tile's number in the group, [31:19] the records in front of the giant part (< 8192) */
 
 template <int SIZE, bool FUSED>
 __global__ void __launch_bounds__(BrCfg<SIZE>::THREADS, BR_MIN_WAVES) k_bucket_rank(const GrpRank gr, DevParams P, u32 key_bits, u32 hbits, u32 lut_shards, u64 lut_stride,
@@ -517,16 +518,22 @@ __global__ void __launch_bounds__(BrCfg<SIZE>::THREADS, BR_MIN_WAVES) k_bucket_r
 		__syncthreads();
 		const u32 cut = *s_wmax;
 		__syncthreads();
-		if (cut == 0 || (b1 - b0) - cut > (u64)CAP) { /* one bucket (or two) beyond the capacity: k_giant_tiles, or (not fused; enormous tiles) the host's LSD passes */
+		if (cut == 0 || (b1 - b0) - cut > (u64)CAP) {
+			/* one bucket (or two) beyond the capacity. Round 5: only what lies BEHIND the cut — the giant bucket itself: nothing else starts in the window once a
+			 * bucket longer than the capacity has — goes to k_giant_tiles (list entry: tile | cut << GT_CUT_SHIFT; it reports into the tile's second slot); the
+			 * buckets in front of it are an ordinary first chunk and stay here. k_giant_tiles then sorts ONE bucket: only the bits below the bucket bits (three
+			 * passes at k = 27 instead of six over the whole tile's key range). Not fused, or beyond GT_MAX_RECORDS: the host's LSD passes, as ever. */
+			const bool listed = FUSED && gr.giant && (b1 - b0) - cut <= GT_MAX_RECORDS;
 			if (tid == 0 && blockIdx.y == 0) {
-				if (FUSED && gr.giant && b1 - b0 <= GT_MAX_RECORDS)
-					gr.giant[2 + atomicAdd(&gr.giant[0], 1u)] = gtile;
+				if (listed)
+					gr.giant[2 + atomicAdd(&gr.giant[0], 1u)] = gtile | (cut << GT_CUT_SHIFT);
 				else
 					atomicOr(flag, FUSED ? 0x10000u << bin : 1u); /* fused: only this BIN comes back (bits 16 + its number in the group); in place: the group */
 			}
-			return;
-		}
-		if (blockIdx.y == 0)
+			if (!listed || cut == 0 || blockIdx.y != 0)
+				return;
+			len = cut; /* blockIdx.y == 0: the buckets in front of the giant one */
+		} else if (blockIdx.y == 0)
 			len = cut;
 		else {
 			c0 = b0 + cut;
@@ -1783,10 +1790,11 @@ __global__ void __launch_bounds__(GT_THREADS) k_giant_tiles(const GrpRank gr, De
 		const u32 pick = s_pick;
 		if (pick >= ld_agent(&gr.giant[0])) /* final: k_bucket_rank ran before this kernel on the stream */
 			break;
-		const u32 gtile = gr.giant[2 + pick];
+		const u32 entry = gr.giant[2 + pick];
+		const u32 gtile = entry & ((1u << GT_CUT_SHIFT) - 1u), cut = entry >> GT_CUT_SHIFT; /* cut != 0: k_bucket_rank kept the tile's first `cut` records (its first chunk) */
 		const u32 bin = (u32)__builtin_amdgcn_readfirstlane((int)grp_find(gr.win_prefix, gr.g, gtile));
 		const u32 tile = gtile - gr.win_prefix[bin];
-		const u64 b0 = gr.bounds[bin][tile], b1 = gr.bounds[bin][tile + 1];
+		const u64 b0 = gr.bounds[bin][tile] + cut, b1 = gr.bounds[bin][tile + 1];
 		const u32 L = (u32)(b1 - b0);
 		u64 *T = gr.S[bin] + b0 * SIZE;
 		if (gr.rec_base) { /* indirect sort: the tile is a run of (key top, record number) pairs; its records are brought together first */
@@ -1811,10 +1819,8 @@ __global__ void __launch_bounds__(GT_THREADS) k_giant_tiles(const GrpRank gr, De
 			const u64 diff = k0 ^ kl;
 			const u32 dbits = diff ? 64u - (u32)__clzll((long long)diff) : 0u;
 			const u32 nbits = rbits + dbits < key_bits ? rbits + dbits : key_bits;
-			passes = (nbits + 7) / 8;
-			passes += passes & 1u; /* even: the sorted records end in T, the span stays free for the output (<= 8 SIZE: the bytes of a record) */
-			if (passes == 0)
-				passes = 2;
+			passes = (nbits + 7) / 8; /* an odd number leaves the sorted records in U, the span the output goes to: the counting below then works in place (it
+			                           * writes behind what it has read: a counted k-mer's record is no longer than the record it was counted from) */
 		}
 		u64 *src = T, *dst = U;
 		for (u32 p = 0; p < passes; ++p) {
@@ -1897,9 +1903,10 @@ __global__ void __launch_bounds__(GT_THREADS) k_giant_tiles(const GrpRank gr, De
 			dst = t;
 			__syncthreads(); /* a workgroup's global stores are visible to its own loads after the barrier (one CU, one L1) */
 		}
-		/* ---- the tile is in order in T: run lengths, cutoffs, records (kb_sorter.h:1128-1281), chunk by chunk */
+		/* ---- the tile is in order in `src` (T, or U after an odd number of passes): run lengths, cutoffs, records (kb_sorter.h:1128-1281), chunk by chunk */
+		const u64 *const Sd = src;
 		uint8_t *const span = reinterpret_cast<uint8_t *>(U);
-		const u32 slot_id = 2 * tile;
+		const u32 slot_id = 2 * tile + (cut ? 1u : 0u);
 		u64 *lut = use_lut ? gr.lut_base[bin] + (size_t)(slot_id % lut_shards) * lut_stride : nullptr;
 		u32 prev_tail = NONE; /* absolute position of the last tail so far, -1 = none */
 		u32 counted_total = 0, nu = 0, nb = 0, na = 0;
@@ -1912,11 +1919,11 @@ __global__ void __launch_bounds__(GT_THREADS) k_giant_tiles(const GrpRank gr, De
 				const u32 idx = c0 + crel + r * 64 + lane;
 				bool is_tail = false;
 				if (idx < L) {
-					load_rec<SIZE>(T + (size_t)idx * SIZE, key[r]);
+					load_rec<SIZE>(Sd + (size_t)idx * SIZE, key[r]);
 					is_tail = true;
 					if (idx + 1 < L) {
 						u64 nx[SIZE];
-						load_rec<SIZE>(T + (size_t)(idx + 1) * SIZE, nx);
+						load_rec<SIZE>(Sd + (size_t)(idx + 1) * SIZE, nx);
 						is_tail = !kmc_equal<SIZE>(nx, key[r]);
 					}
 				} else {

@@ -1065,3 +1065,44 @@ def test_collapsing_finisher_stays_correct_behind_its_switch():
             "print('repeats', ok, ctx.path_counters())")
     r = subprocess.run([sys.executable, "-c", code], cwd=root, env=dict(os.environ, KMC_HIP_RANK_COLLAPSE="1"), capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "smoke OK" in r.stdout and "repeats True" in r.stdout, (r.stdout + r.stderr)[-1500:]
+
+
+@pytest.mark.parametrize("repeats", ["5000:6:0", "5000:9:0", "1000:100:10", "2000:40:5,300:230:0,H2000"])
+def test_rank_path_buckets_of_a_few_hundred_to_a_few_thousand_records(repeats, monkeypatch):
+    """Repeat families make buckets of copies x coverage records: 180 (one-word pairs of 32 bits), 270 (64-bit pairs), 3000 (several records per thread), and a mixture with a
+    giant bucket and a poly-A run — the buckets beyond BR_BIG whose records k_bucket_rank deals out again over the whole workgroup. Dense: a dozen of them per tile. The first
+    version of that path passed every other test of this file and the emulations and was wrong exactly here (profiles/r05/experiments/README.md 5)."""
+    monkeypatch.setenv("KMC_SYNTH_REPEATS", repeats)
+    bins = capi.synth_bins(seed=3, genome_len=200_000, n_reads=40_000, k=27, n_bins=4, n_threads=4)
+    monkeypatch.delenv("KMC_SYNTH_REPEATS")
+    ctx = capi.Context((0,))
+    try:
+        for k_, kw in ((27, dict(lut_prefix_len=3)),):
+            p = capi.make_params(k_, **kw)
+            op = O.make_params(p.kmer_len, p.both_strands, p.cutoff_min, p.cutoff_max, p.counter_max, p.lut_prefix_len, p.output_type, p.without_output)
+            got, err = _run_batch(ctx, p, bins, 1)
+            assert err is None, err
+            for i, (img, nrec, packs, _) in enumerate(bins):
+                w = O.process_bin(op, img, nrec)
+                assert np.array_equal(got[i][2], w[2]), (repeats, i, got[i][2], w[2])
+                assert np.array_equal(got[i][0], w[0]) and np.array_equal(got[i][1], w[1]), (repeats, i)
+    finally:
+        ctx.close()
+
+
+def test_rank_path_big_buckets_of_two_word_records(monkeypatch):
+    """the same at k = 55 (A/B pairs, the indirect sort's gathered records): buckets of ~200 and ~3000 two-word records"""
+    monkeypatch.setenv("KMC_SYNTH_REPEATS", "4000:7:0,1000:100:5")
+    bins = capi.synth_bins(seed=4, genome_len=200_000, n_reads=40_000, k=55, n_bins=4, n_threads=4)
+    monkeypatch.delenv("KMC_SYNTH_REPEATS")
+    ctx = capi.Context((0,))
+    try:
+        p = capi.make_params(55, lut_prefix_len=3)
+        op = O.make_params(55, lut_prefix_len=3)
+        got, err = _run_batch(ctx, p, bins, 1)
+        assert err is None, err
+        for i, (img, nrec, packs, _) in enumerate(bins):
+            w = O.process_bin(op, img, nrec)
+            assert all(np.array_equal(a, b) for a, b in zip(got[i], w)), i
+    finally:
+        ctx.close()
