@@ -617,7 +617,8 @@ int kmc_hip_process_bin_submit(kmc_hip_ctx *ctx, int dev, int slot, const kmc_hi
 		HIPCHK(hipMemsetAsync((char *)s.in.p + size, 0, 256, s.stream));
 		HIPCHK(hipMemcpyAsync(s.pack_start.p, ps.data(), (np + 1) * 8, hipMemcpyHostToDevice, s.stream));
 	}
-	s.out_staged = !P.without_output && (out_capacity || lut_entries) && !host_ptr_is_pinned(out_capacity ? (const void *)out_suffix : (const void *)lut);
+	/* staged when EITHER destination is ordinary memory (the records and the LUT may come from different allocations), as the several-bins path decides it */
+	s.out_staged = !P.without_output && ((out_capacity && !host_ptr_is_pinned((const void *)out_suffix)) || (lut_entries && !host_ptr_is_pinned((const void *)lut)));
 	s.timed = true;
 	s.sub_P = P;
 	s.sub_size = size;
