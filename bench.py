@@ -16,7 +16,11 @@ rule of kmc.h:1434-1469) -> ~24.8 G k-mers. One "step" = ALL bins through the wh
              (RCCL) inside the timed region. value = all k-mers of the bin set / max-over-ranks time => STRONG scaling (configs[3]).
              Each rank generates 1/N of the reads; bin pieces are exchanged through a scratch directory before the timed region.
 
-Extra keys of the N=1 line (each measured after the timed region, none inside it):
+What is printed (round 5): the LAST line of stdout is a SHORT record (short_line(): < 6000 bytes — the driver keeps the tail of stdout) with the contract's keys, `roofline`,
+`cpu_baseline` and the headline numbers of the legs below; the whole record (prose, per-leg records, worker reports) goes to bench_detail.json next to this file (and under
+gpurun_out/ when that exists), a few human lines to stderr.
+
+Keys of the N=1 record (each measured after the timed region, none inside it):
   value_two_streams   : the same step with two bins in flight (tails and launch gaps of one bin filled by the other)
   value_host_boundary : the same bins from pinned host memory (PCIe inclusive) through kmc_hip_process_bin_submit/_wait (one bin per call) and through
                         kmc_hip_process_bins_submit/_wait (4 bins per call): the better of the two, both in host_boundary.legs
@@ -24,6 +28,10 @@ Extra keys of the N=1 line (each measured after the timed region, none inside it
   secondary.bins512_2gbp: the 2 Gbp sample cut into 512 bins (3.2 M k-mers per bin), tallies checked against the reference
   secondary.stage1_groundwork: NOT stage 2 — the splitter groundwork of DESIGN.md 9 (codes in HBM -> bins in HBM), timed by tools/s1_bench.py
   e2e_stage1          : NOT stage 2 — "1st stage" seconds of the reference pipeline with the splitter worker swapped too (kmc_hip_s1)
+  secondary.skew_quarter / skew_spectrum_quarter: the quarter workload with one repeat family / a spectrum of families planted in the genome ($KMC_SYNTH_REPEATS), value on one
+                        stream and value_two_streams
+  e2e_large           : ONE FASTQ of --e2e-gbp Gbp (default 8): reference vs drop-in "2nd stage" in RAM-only mode, and the reference's own stage-1 bins (dumped by the drop-in's
+                        worker) device-resident, tallies against the reference's statistics
   cpu_baseline / e2e  : the REAL reference (oracle/_ref/kmc, built from /root/reference by oracle/Makefile) and the drop-in
                         (kmc_amd/bin/kmc_hip = reference pipeline + this library) on a FASTQ of the SAME reads as the 2 Gbp sample:
                         "2nd stage" seconds of each, the five statistics compared.
