@@ -35,6 +35,9 @@
 #ifndef BS_WORDS_PER_THREAD
 #define BS_WORDS_PER_THREAD 8 /* 8-byte words a thread holds while a tile is loaded */
 #endif
+#ifndef BR_NARROW_LOOP
+#define BR_NARROW_LOOP 0 /* the owners' walk over 32-bit pairs: 0 as shipped; 1, 2: tuning variants (k_bucket_rank, narrow mode) */
+#endif
 #ifndef BR_SLACK_DIV
 #define BR_SLACK_DIV 12 /* k_bucket_rank: windows are 11/12 of a tile's capacity, the rest is room for the bucket that is open at the end of the window (waves
                          * without records still walk through the kernel: windows of 2/3 32.4, of 5/6 33.4, of 11/12 33.5 Gk-mers/s on the quarter workload).
@@ -703,12 +706,99 @@ __global__ void __launch_bounds__(BrCfg<SIZE>::THREADS, BR_MIN_WAVES) k_bucket_r
 				u32 rank = 0, q = bstart;
 				if (is_big(r))
 					q = bend; /* ranked by the whole workgroup below */
+#if BR_NARROW_LOOP == 0
 				for (; q + 4 <= bend; q += 4) {
 					const u32 a0 = s_k32[q], a1 = s_k32[q + 1], a2 = s_k32[q + 2], a3 = s_k32[q + 3];
 					rank += (a0 < c ? 1u : 0u) + (a1 < c ? 1u : 0u) + (a2 < c ? 1u : 0u) + (a3 < c ? 1u : 0u);
 				}
 				for (; q < bend; ++q)
 					rank += s_k32[q] < c ? 1u : 0u;
+#else
+				/* tuning (tools/build_variants.py brnl*): the walk as the source says it — steps of BR_NARROW_STEP pairs, not interleaved four times over by the
+				 * compiler (a 16-pair body with an 8-pair, a 4-pair and a pairwise epilogue, each entered by every wave that has one lane in need of it) — and ONE
+				 * masked step for the last 1..3 pairs instead of up to three dependent LDS round trips (slots behind the bucket's end are read and not counted) */
+#if BR_NARROW_LOOP == 2
+#pragma clang loop vectorize(disable) interleave(disable) unroll(disable)
+				for (; q + 8 <= bend; q += 8) {
+					u32 a[8];
+#pragma unroll
+					for (int u = 0; u < 8; ++u)
+						a[u] = s_k32[q + u];
+#pragma unroll
+					for (int u = 0; u < 8; ++u)
+						rank += a[u] < c ? 1u : 0u;
+				}
+				if (q + 4 <= bend) {
+					const u32 a0 = s_k32[q], a1 = s_k32[q + 1], a2 = s_k32[q + 2], a3 = s_k32[q + 3];
+					rank += (a0 < c ? 1u : 0u) + (a1 < c ? 1u : 0u) + (a2 < c ? 1u : 0u) + (a3 < c ? 1u : 0u);
+					q += 4;
+				}
+#elif BR_NARROW_LOOP == 4 /* steps of 8, then ONE masked step for the last 1..7 pairs */
+#pragma clang loop vectorize(disable) interleave(disable) unroll(disable)
+				for (; q + 8 <= bend; q += 8) {
+					u32 a[8];
+#pragma unroll
+					for (int u = 0; u < 8; ++u)
+						a[u] = s_k32[q + u];
+#pragma unroll
+					for (int u = 0; u < 8; ++u)
+						rank += a[u] < c ? 1u : 0u;
+				}
+				if (q < bend) {
+					const u32 left = bend - q;
+					u32 a[7];
+#pragma unroll
+					for (int u = 0; u < 7; ++u)
+						a[u] = s_k32[q + u];
+					rank += a[0] < c ? 1u : 0u;
+#pragma unroll
+					for (int u = 1; u < 7; ++u)
+						rank += ((u32)u < left) & (a[u] < c) ? 1u : 0u;
+					q = bend;
+				}
+#elif BR_NARROW_LOOP == 5 /* steps of 16, one of 8, one of 4, one masked step */
+#pragma clang loop vectorize(disable) interleave(disable) unroll(disable)
+				for (; q + 16 <= bend; q += 16) {
+					u32 a[16];
+#pragma unroll
+					for (int u = 0; u < 16; ++u)
+						a[u] = s_k32[q + u];
+#pragma unroll
+					for (int u = 0; u < 16; ++u)
+						rank += a[u] < c ? 1u : 0u;
+				}
+				if (q + 8 <= bend) {
+					u32 a[8];
+#pragma unroll
+					for (int u = 0; u < 8; ++u)
+						a[u] = s_k32[q + u];
+#pragma unroll
+					for (int u = 0; u < 8; ++u)
+						rank += a[u] < c ? 1u : 0u;
+					q += 8;
+				}
+				if (q + 4 <= bend) {
+					const u32 a0 = s_k32[q], a1 = s_k32[q + 1], a2 = s_k32[q + 2], a3 = s_k32[q + 3];
+					rank += (a0 < c ? 1u : 0u) + (a1 < c ? 1u : 0u) + (a2 < c ? 1u : 0u) + (a3 < c ? 1u : 0u);
+					q += 4;
+				}
+#elif BR_NARROW_LOOP == 3 /* the shipped loop (interleaved by the compiler) and the masked last step */
+				for (; q + 4 <= bend; q += 4) {
+					const u32 a0 = s_k32[q], a1 = s_k32[q + 1], a2 = s_k32[q + 2], a3 = s_k32[q + 3];
+					rank += (a0 < c ? 1u : 0u) + (a1 < c ? 1u : 0u) + (a2 < c ? 1u : 0u) + (a3 < c ? 1u : 0u);
+				}
+#else
+#pragma clang loop vectorize(disable) interleave(disable) unroll(disable)
+				for (; q + 4 <= bend; q += 4) {
+					const u32 a0 = s_k32[q], a1 = s_k32[q + 1], a2 = s_k32[q + 2], a3 = s_k32[q + 3];
+					rank += (a0 < c ? 1u : 0u) + (a1 < c ? 1u : 0u) + (a2 < c ? 1u : 0u) + (a3 < c ? 1u : 0u);
+				}
+#endif
+				if (q < bend) { /* one to three pairs are left */
+					const u32 a0 = s_k32[q], a1 = s_k32[q + 1], a2 = s_k32[q + 2];
+					rank += (a0 < c ? 1u : 0u) + ((q + 1 < bend) & (a1 < c) ? 1u : 0u) + ((q + 2 < bend) & (a2 < c) ? 1u : 0u);
+				}
+#endif
 				place[r] = bstart + rank;
 			}
 			rank_big_buckets([&](u32 bs, u32 be, u32 i) {
