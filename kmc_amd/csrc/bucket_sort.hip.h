@@ -36,7 +36,7 @@
 #define BS_WORDS_PER_THREAD 8 /* 8-byte words a thread holds while a tile is loaded */
 #endif
 #ifndef BR_NARROW_LOOP
-#define BR_NARROW_LOOP 0 /* the owners' walk over 32-bit pairs: 0 as shipped; 1, 2: tuning variants (k_bucket_rank, narrow mode) */
+#define BR_NARROW_LOOP 2 /* k_bucket_rank's walk over 32-bit pairs: 2 = steps of 8 / 4 / one masked step (shipped); 0 = the walk of rounds 3-5 (tools/build_variants.py brnl0) */
 #endif
 #ifndef BR_SLACK_DIV
 #define BR_SLACK_DIV 12 /* k_bucket_rank: windows are 11/12 of a tile's capacity, the rest is room for the bucket that is open at the end of the window (waves
@@ -699,13 +699,13 @@ __global__ void __launch_bounds__(BrCfg<SIZE>::THREADS, BR_MIN_WAVES) k_bucket_r
 					s_k32[idx] = c32[r];
 			}
 			__syncthreads();
-#pragma unroll
-			for (int r = 0; r < ITEMS; ++r) {
-				const u32 bstart = span[r] & 0xFFFFu, bend = span[r] >> 16;
-				const u32 c = c32[r];
-				u32 rank = 0, q = bstart;
-				if (is_big(r))
-					q = bend; /* ranked by the whole workgroup below */
+			/* How many pairs of [q, bend) are in front of the pair c. Steps of 8, one step of 4, and ONE masked step for the last 1..3 pairs (the slots behind the
+			 * bucket's end are read and not counted) — spelled out and kept from the loop optimiser: what it made of `for (; q + 4 <= bend; q += 4)` + a pairwise
+			 * tail was a 16-pair body with an 8-pair, a 4-pair and a pairwise epilogue, each entered by every wave with one lane in need of it, and a tail of up to
+			 * three DEPENDENT LDS round trips per row. Round 5, sessions x / y: 1.53-1.57 -> 1.39-1.41 ms per group of 190 M records, 35.7-36.0 -> 36.3-36.9 Gk-mers/s
+			 * on the quarter workload (profiles/r05/experiments/README.md 10; -DBR_NARROW_LOOP=0 builds the old walk). */
+			auto walk32 = [&](u32 q, const u32 bend, const u32 c) -> u32 {
+				u32 rank = 0;
 #if BR_NARROW_LOOP == 0
 				for (; q + 4 <= bend; q += 4) {
 					const u32 a0 = s_k32[q], a1 = s_k32[q + 1], a2 = s_k32[q + 2], a3 = s_k32[q + 3];
@@ -714,10 +714,6 @@ __global__ void __launch_bounds__(BrCfg<SIZE>::THREADS, BR_MIN_WAVES) k_bucket_r
 				for (; q < bend; ++q)
 					rank += s_k32[q] < c ? 1u : 0u;
 #else
-				/* tuning (tools/build_variants.py brnl*): the walk as the source says it — steps of BR_NARROW_STEP pairs, not interleaved four times over by the
-				 * compiler (a 16-pair body with an 8-pair, a 4-pair and a pairwise epilogue, each entered by every wave that has one lane in need of it) — and ONE
-				 * masked step for the last 1..3 pairs instead of up to three dependent LDS round trips (slots behind the bucket's end are read and not counted) */
-#if BR_NARROW_LOOP == 2
 #pragma clang loop vectorize(disable) interleave(disable) unroll(disable)
 				for (; q + 8 <= bend; q += 8) {
 					u32 a[8];
@@ -733,90 +729,19 @@ __global__ void __launch_bounds__(BrCfg<SIZE>::THREADS, BR_MIN_WAVES) k_bucket_r
 					rank += (a0 < c ? 1u : 0u) + (a1 < c ? 1u : 0u) + (a2 < c ? 1u : 0u) + (a3 < c ? 1u : 0u);
 					q += 4;
 				}
-#elif BR_NARROW_LOOP == 4 /* steps of 8, then ONE masked step for the last 1..7 pairs */
-#pragma clang loop vectorize(disable) interleave(disable) unroll(disable)
-				for (; q + 8 <= bend; q += 8) {
-					u32 a[8];
-#pragma unroll
-					for (int u = 0; u < 8; ++u)
-						a[u] = s_k32[q + u];
-#pragma unroll
-					for (int u = 0; u < 8; ++u)
-						rank += a[u] < c ? 1u : 0u;
-				}
-				if (q < bend) {
-					const u32 left = bend - q;
-					u32 a[7];
-#pragma unroll
-					for (int u = 0; u < 7; ++u)
-						a[u] = s_k32[q + u];
-					rank += a[0] < c ? 1u : 0u;
-#pragma unroll
-					for (int u = 1; u < 7; ++u)
-						rank += ((u32)u < left) & (a[u] < c) ? 1u : 0u;
-					q = bend;
-				}
-#elif BR_NARROW_LOOP == 5 /* steps of 16, one of 8, one of 4, one masked step */
-#pragma clang loop vectorize(disable) interleave(disable) unroll(disable)
-				for (; q + 16 <= bend; q += 16) {
-					u32 a[16];
-#pragma unroll
-					for (int u = 0; u < 16; ++u)
-						a[u] = s_k32[q + u];
-#pragma unroll
-					for (int u = 0; u < 16; ++u)
-						rank += a[u] < c ? 1u : 0u;
-				}
-				if (q + 8 <= bend) {
-					u32 a[8];
-#pragma unroll
-					for (int u = 0; u < 8; ++u)
-						a[u] = s_k32[q + u];
-#pragma unroll
-					for (int u = 0; u < 8; ++u)
-						rank += a[u] < c ? 1u : 0u;
-					q += 8;
-				}
-				if (q + 4 <= bend) {
-					const u32 a0 = s_k32[q], a1 = s_k32[q + 1], a2 = s_k32[q + 2], a3 = s_k32[q + 3];
-					rank += (a0 < c ? 1u : 0u) + (a1 < c ? 1u : 0u) + (a2 < c ? 1u : 0u) + (a3 < c ? 1u : 0u);
-					q += 4;
-				}
-#elif BR_NARROW_LOOP == 3 /* the shipped loop (interleaved by the compiler) and the masked last step */
-				for (; q + 4 <= bend; q += 4) {
-					const u32 a0 = s_k32[q], a1 = s_k32[q + 1], a2 = s_k32[q + 2], a3 = s_k32[q + 3];
-					rank += (a0 < c ? 1u : 0u) + (a1 < c ? 1u : 0u) + (a2 < c ? 1u : 0u) + (a3 < c ? 1u : 0u);
-				}
-#else
-#pragma clang loop vectorize(disable) interleave(disable) unroll(disable)
-				for (; q + 4 <= bend; q += 4) {
-					const u32 a0 = s_k32[q], a1 = s_k32[q + 1], a2 = s_k32[q + 2], a3 = s_k32[q + 3];
-					rank += (a0 < c ? 1u : 0u) + (a1 < c ? 1u : 0u) + (a2 < c ? 1u : 0u) + (a3 < c ? 1u : 0u);
-				}
-#endif
 				if (q < bend) { /* one to three pairs are left */
 					const u32 a0 = s_k32[q], a1 = s_k32[q + 1], a2 = s_k32[q + 2];
 					rank += (a0 < c ? 1u : 0u) + ((q + 1 < bend) & (a1 < c) ? 1u : 0u) + ((q + 2 < bend) & (a2 < c) ? 1u : 0u);
 				}
 #endif
-				place[r] = bstart + rank;
+				return rank;
+			};
+#pragma unroll
+			for (int r = 0; r < ITEMS; ++r) {
+				const u32 bstart = span[r] & 0xFFFFu, bend = span[r] >> 16;
+				place[r] = bstart + walk32(is_big(r) ? bend /* ranked by the whole workgroup below */ : bstart, bend, c32[r]);
 			}
-			rank_big_buckets([&](u32 bs, u32 be, u32 i) {
-				const u32 c = s_k32[i];
-				u32 n = 0, q = bs;
-				for (; q + 8 <= be; q += 8) {
-					u32 x[8];
-#pragma unroll
-					for (int u = 0; u < 8; ++u)
-						x[u] = s_k32[q + u];
-#pragma unroll
-					for (int u = 0; u < 8; ++u)
-						n += x[u] < c ? 1u : 0u;
-				}
-				for (; q < be; ++q)
-					n += s_k32[q] < c ? 1u : 0u;
-				return n;
-			});
+			rank_big_buckets([&](u32 bs, u32 be, u32 i) { return walk32(bs, be, s_k32[i]); });
 		} else {
 #pragma unroll
 			for (int r = 0; r < ITEMS; ++r) {

@@ -66,11 +66,7 @@ VARIANTS = {
     "brslack6": ["-DBR_SLACK_DIV=6"],  # 768 x 8 with windows of 5120 records (1024 of slack)
     "brslack12": ["-DBR_SLACK_DIV=12"],  # windows of 5632 (512 of slack)
     "brslack24": ["-DBR_SLACK_DIV=24"],  # windows of 5888 (256 of slack; longer tiles take a second chunk)
-    "brnl1": ["-DBR_NARROW_LOOP=1"],  # k_bucket_rank, 32-bit pairs: steps of 4 as written (no interleaving by the compiler) + one masked step for the last 1..3 pairs
-    "brnl2": ["-DBR_NARROW_LOOP=2"],  # steps of 8, one step of 4, one masked step
-    "brnl3": ["-DBR_NARROW_LOOP=3"],  # the shipped (compiler-interleaved) loop + the masked last step
-    "brnl4": ["-DBR_NARROW_LOOP=4"],  # steps of 8, one masked step for the last 1..7
-    "brnl5": ["-DBR_NARROW_LOOP=5"],  # steps of 16, one of 8, one of 4, one masked step
+    "brnl0": ["-DBR_NARROW_LOOP=0"],  # k_bucket_rank, 32-bit pairs: the walk of rounds 3-5 (steps of 4 + a pairwise tail, interleaved by the compiler); the shipped one is 8 / 4 / one masked step
     "br1": ["-DBR_STOP_AFTER=1"],  # k_bucket_rank cut after: 1 loads + bucket starts + table look-ups, 2 + pairs + rank loops, 3 + records placed in order,
     "br2": ["-DBR_STOP_AFTER=2"],  # 4 + run tails, counts, classes, ranks of the counted k-mers (garbage output): phase costs
     "br3": ["-DBR_STOP_AFTER=3"],
