@@ -38,6 +38,12 @@
 #ifndef BR_NARROW_LOOP
 #define BR_NARROW_LOOP 2 /* k_bucket_rank's walk over 32-bit pairs: 2 = steps of 8 / 4 / one masked step (shipped); 0 = the walk of rounds 3-5 (tools/build_variants.py brnl0) */
 #endif
+#ifndef BR_WIDE_LOOP
+#define BR_WIDE_LOOP 1 /* k_bucket_rank<1>'s walk over 64-bit pairs: 1 = steps of BR_WIDE_STEP, 4, 2, 1 (shipped); 0 = steps of 2 + one (tools/build_variants.py brwl0) */
+#endif
+#ifndef BR_WIDE_STEP
+#define BR_WIDE_STEP 8
+#endif
 #ifndef BR_SLACK_DIV
 #define BR_SLACK_DIV 12 /* k_bucket_rank: windows are 11/12 of a tile's capacity, the rest is room for the bucket that is open at the end of the window (waves
                          * without records still walk through the kernel: windows of 2/3 32.4, of 5/6 33.4, of 11/12 33.5 Gk-mers/s on the quarter workload).
@@ -750,37 +756,49 @@ __global__ void __launch_bounds__(BrCfg<SIZE>::THREADS, BR_MIN_WAVES) k_bucket_r
 					s_key[idx] = ((key[r][0] & rmask) << 16) | (u64)rel[r];
 			}
 			__syncthreads();
-#pragma unroll
-			for (int r = 0; r < ITEMS; ++r) {
-				const u32 bstart = span[r] & 0xFFFFu, bend = span[r] >> 16;
-				const u64 c = ((key[r][0] & rmask) << 16) | (u64)rel[r];
-				u32 rank = 0, q = bstart;
-				if (is_big(r))
-					q = bend;
+			/* walk32's shape for 64-bit pairs (k = 28..32, and any tile of narrower records with a bucket beyond what a 32-bit pair numbers: the repeat-rich legs): steps of
+			 * BR_WIDE_STEP, halved down to one — no dependent round trip per two pairs, no interleaving by the compiler. -DBR_WIDE_LOOP=0: steps of 2 + one (rounds 3-5). */
+			auto walk64 = [&](u32 q, const u32 bend, const u64 c) -> u32 {
+				u32 rank = 0;
+#if BR_WIDE_LOOP == 0
 				for (; q + 2 <= bend; q += 2) {
 					const u64 a = s_key[q], b = s_key[q + 1];
 					rank += (a < c ? 1u : 0u) + (b < c ? 1u : 0u);
 				}
+#else
+#pragma clang loop vectorize(disable) interleave(disable) unroll(disable)
+				for (; q + BR_WIDE_STEP <= bend; q += BR_WIDE_STEP) {
+					u64 a[BR_WIDE_STEP];
+#pragma unroll
+					for (int u = 0; u < BR_WIDE_STEP; ++u)
+						a[u] = s_key[q + u];
+#pragma unroll
+					for (int u = 0; u < BR_WIDE_STEP; ++u)
+						rank += a[u] < c ? 1u : 0u;
+				}
+#if BR_WIDE_STEP > 4
+				if (q + 4 <= bend) {
+					const u64 a0 = s_key[q], a1 = s_key[q + 1], a2 = s_key[q + 2], a3 = s_key[q + 3];
+					rank += (a0 < c ? 1u : 0u) + (a1 < c ? 1u : 0u) + (a2 < c ? 1u : 0u) + (a3 < c ? 1u : 0u);
+					q += 4;
+				}
+#endif
+				if (q + 2 <= bend) {
+					const u64 a = s_key[q], b = s_key[q + 1];
+					rank += (a < c ? 1u : 0u) + (b < c ? 1u : 0u);
+					q += 2;
+				}
+#endif
 				if (q < bend)
 					rank += s_key[q] < c ? 1u : 0u;
-				place[r] = bstart + rank;
+				return rank;
+			};
+#pragma unroll
+			for (int r = 0; r < ITEMS; ++r) {
+				const u32 bstart = span[r] & 0xFFFFu, bend = span[r] >> 16;
+				place[r] = bstart + walk64(is_big(r) ? bend : bstart, bend, ((key[r][0] & rmask) << 16) | (u64)rel[r]);
 			}
-			rank_big_buckets([&](u32 bs, u32 be, u32 i) {
-				const u64 c = s_key[i];
-				u32 n = 0, q = bs;
-				for (; q + 8 <= be; q += 8) {
-					u64 x[8];
-#pragma unroll
-					for (int u = 0; u < 8; ++u)
-						x[u] = s_key[q + u];
-#pragma unroll
-					for (int u = 0; u < 8; ++u)
-						n += x[u] < c ? 1u : 0u;
-				}
-				for (; q < be; ++q)
-					n += s_key[q] < c ? 1u : 0u;
-				return n;
-			});
+			rank_big_buckets([&](u32 bs, u32 be, u32 i) { return walk64(bs, be, s_key[i]); });
 		}
 	} else if constexpr (SIZE == 2) {
 		u64 *s_A = s_key;                                     /* [CAP] rem >> 16 */

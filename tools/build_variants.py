@@ -67,6 +67,8 @@ VARIANTS = {
     "brslack12": ["-DBR_SLACK_DIV=12"],  # windows of 5632 (512 of slack)
     "brslack24": ["-DBR_SLACK_DIV=24"],  # windows of 5888 (256 of slack; longer tiles take a second chunk)
     "brnl0": ["-DBR_NARROW_LOOP=0"],  # k_bucket_rank, 32-bit pairs: the walk of rounds 3-5 (steps of 4 + a pairwise tail, interleaved by the compiler); the shipped one is 8 / 4 / one masked step
+    "brwl0": ["-DBR_WIDE_LOOP=0", "-DBR_NARROW_LOOP=2"],  # k_bucket_rank<1>, 64-bit pairs: steps of 2 + one, and the dealers' count 8 + one by one (rounds 3-5)
+    "brwl4": ["-DBR_WIDE_STEP=4"],  # steps of 4, 2, 1
     "br1": ["-DBR_STOP_AFTER=1"],  # k_bucket_rank cut after: 1 loads + bucket starts + table look-ups, 2 + pairs + rank loops, 3 + records placed in order,
     "br2": ["-DBR_STOP_AFTER=2"],  # 4 + run tails, counts, classes, ranks of the counted k-mers (garbage output): phase costs
     "br3": ["-DBR_STOP_AFTER=3"],
