@@ -412,7 +412,9 @@ template <int SIZE> struct BrCfg {
 	static constexpr int NW = THREADS / 64;
 	static constexpr size_t R0 = (size_t)CAP * SIZE * 8;    /* the pairs; then the records in order; then the staged output */
 	static constexpr size_t R1 = ((size_t)CAP + 2) * 4;     /* the table of bucket starts; then LUT prefixes / counts of the staged records */
-	static constexpr size_t LDS = R0 + R1 + (size_t)(7 * NW + 8) * 4 + 16;
+	static constexpr size_t TRAILER_WORDS = 10 * NW + 16;   /* s_wfirst, s_wmax, s_wlast, s_wcnt [NW each], s_wtal [5 NW + 8], s_nbig (the
+	                                                         * trailer had outgrown the 7 NW + 8 words reserved for it and lived on the allocation granule) */
+	static constexpr size_t LDS = R0 + R1 + TRAILER_WORDS * 4 + 16;
 	static_assert(CAP < 65536, "tile-relative positions are kept in 16 bits");
 };
 template <int SIZE> constexpr size_t br_lds_bytes() { return BrCfg<SIZE>::LDS; }
@@ -455,7 +457,27 @@ struct GrpRank {
 	const u64 *rec_base;        /* indirect sort (records of three words and more): S is the ordered array of (top four key bytes << 32 | record number) PAIRS, one word
 	                             * each, and the records stay where k_expand wrote them: record number i of the group is rec_base + i SIZE. NULL: S holds the records. */
 	u64 *giant_T[GRP_MAX];      /* indirect sort: the bin's slice of a third record array — k_giant_tiles gathers a tile's records there before it sorts them in place */
+	/* one-word records, FUSED (round 6, arena_sort.hip.h): the group's repeat-rich buckets are sorted together by HBM passes of their own. NULL: as in round 5. */
+	u32 *arena_dyn;             /* AR_* words (zeroed by the host) */
+	struct ArenaEntry *arena_ent; /* [arena_cap] the listed buckets */
+	u32 arena_cap;
+	u32 *heavy;                 /* [heavy_cap] chunks (gtile << 1 | chunk) whose buckets beyond BR_MID records went to the arena: ranked and counted by k_bucket_rank_heavy once those are back in order */
+	u32 heavy_cap;
 };
+/* A bucket the arena sorts. kind 0: a GIANT bucket (beyond a tile's capacity, any length): sorted and counted from the arena, segment by segment, into the output slots of the
+ * windows it covers. kind 1: a bucket of BR_MID < records <= capacity inside a tile: sorted in the arena, written back in place; its tile is ranked afterwards. */
+struct ArenaEntry {
+	u64 w0;    /* [39:0] first record (its index in the group's ordered array: gr.S[0] + ...), [43:40] the bin's number in the group, [44] kind */
+	u32 len;   /* records */
+	u32 gtile; /* kind 0: the tile (group-wide number) the bucket starts in */
+};
+constexpr u32 AR_N_ENT = 0, AR_M = 1, AR_N_PASS = 2, AR_N_ITEMS = 3, AR_ITEM_TICKET = 4, AR_OVERFLOW = 5, AR_N_HEAVY = 6, AR_HEAVY_TICKET = 7, AR_PASS_TICKET = 8 /* .. 15 */,
+              AR_STAT_MID_N = 20, AR_STAT_MID_REC = 22 /* u64: words 22-23 */, AR_DYN_WORDS = 32;
+#ifndef BR_MID
+#define BR_MID 384 /* one-word records: a bucket beyond this many records is not ranked pairwise at all (the work grows with its square: 0.07 ps x n^2 against ~30 ps x n of
+                    * arena passes) — it goes through the arena and comes back in order */
+#endif
+static_assert(BR_MID >= BR_BIG, "buckets the arena takes are a subset of the big ones");
 /* A tile whose LARGEST BUCKET does not fit the capacity — one k-mer repeated thousands of times: every genome has those — is not ranked pairwise (the work
  * grows with the square of a bucket) and, since round 4, no longer sends its whole group back to the host either: k_bucket_rank puts it on a list and
  * k_giant_tiles sorts it on its own (below). Only a tile beyond GT_MAX_RECORDS still raises the group's flag (-> the host's LSD passes). */
@@ -468,14 +490,17 @@ struct GrpRank {
 constexpr u64 GT_MAX_RECORDS = 1ull << GT_MAX_RECORDS_LOG2;
 constexpr u32 GT_CUT_SHIFT = 19; /* a list entry of k_giant_tiles: [18:0] the tile's number in the group, [31:19] the records in front of the giant part (< 8192) */
 
-template <int SIZE, bool FUSED>
-__global__ void __launch_bounds__(BrCfg<SIZE>::THREADS, BR_MIN_WAVES) k_bucket_rank(const GrpRank gr, DevParams P, u32 key_bits, u32 hbits, u32 lut_shards, u64 lut_stride,
-                                                                                  u32 lut_mask, u32 *flag)
+/* chunk `by` (0, 1) of tile `gtile`. HEAVY (one-word records): the second visit of a chunk whose buckets beyond BR_MID records have been through the arena — they are in
+ * order where they lie and keep their places; everything else as on the first visit, which listed them and returned. */
+template <int SIZE, bool FUSED, bool HEAVY>
+__device__ __forceinline__ void br_tile(const GrpRank &gr, const DevParams &P, const u32 key_bits, const u32 hbits, const u32 lut_shards, const u64 lut_stride, const u32 lut_mask,
+                                        u32 *flag, const u32 gtile, const u32 by, unsigned char *s_raw)
 {
 	constexpr int THREADS = BrCfg<SIZE>::THREADS, ITEMS = BrCfg<SIZE>::ITEMS, CAP = BrCfg<SIZE>::CAP, NW = BrCfg<SIZE>::NW;
 	constexpr u64 S = BrCfg<SIZE>::STRIDE;
 	constexpr u32 NONE = 0xFFFFFFFFu;
-	KMC_DYN_LDS(unsigned char, s_raw);
+	static_assert(!HEAVY || (SIZE == 1 && FUSED), "the arena takes one-word records of fused groups");
+	const bool arena = SIZE == 1 && FUSED && gr.arena_dyn != nullptr;
 	u64 *s_key = reinterpret_cast<u64 *>(s_raw);                              /* R0 */
 	u32 *s_start = reinterpret_cast<u32 *>(s_raw + BrCfg<SIZE>::R0);          /* R1 [CAP + 2] */
 	u32 *s_wfirst = s_start + CAP + 2;                                        /* [NW] bucket starts in wave w's rows */
@@ -483,9 +508,9 @@ __global__ void __launch_bounds__(BrCfg<SIZE>::THREADS, BR_MIN_WAVES) k_bucket_r
 	u32 *s_wlast = s_wmax + NW;                                               /* [NW] FUSED: the last run tail inside wave w's rows */
 	u32 *s_wcnt = s_wlast + NW;                                               /* [NW] FUSED: counted k-mers of wave w */
 	u32 *s_wtal = s_wcnt + NW;                                                /* [NW][3] FUSED: distinct / below min / above max of wave w */
-	u32 *s_nbig = s_wtal + 5 * NW + 8;                                        /* [1] != 0: the tile has a bucket beyond BR_BIG records (behind k_bucket_rank_c's two rows) */
+	u32 *s_nbig = s_wtal + 5 * NW + 8;                                        /* [1] != 0: the tile has a bucket beyond BR_BIG records */
+	static_assert(9 * NW + 8 + 1 <= (int)BrCfg<SIZE>::TRAILER_WORDS, "the trailer arrays lie inside the dynamic LDS the launch asks for");
 
-	const u32 gtile = blockIdx.x;
 	const u32 bin = (u32)__builtin_amdgcn_readfirstlane((int)grp_find(gr.win_prefix, gr.g, gtile));
 	const u32 tile = gtile - gr.win_prefix[bin];
 	const u64 *__restrict__ bounds = gr.bounds[bin];
@@ -509,12 +534,12 @@ __global__ void __launch_bounds__(BrCfg<SIZE>::THREADS, BR_MIN_WAVES) k_bucket_r
 		return bucket_of(x);
 	};
 	/* A tile longer than the capacity (windows are nearly as long as the capacity: BR_SLACK_DIV) is taken in two chunks of whole buckets, by the two
-	 * workgroups (blockIdx.y = 0, 1) every tile has: the first takes the records up to the last bucket start inside the capacity, the second the rest.
+	 * workgroups (by = 0, 1) every tile has: the first takes the records up to the last bucket start inside the capacity, the second the rest.
 	 * Nearly every tile fits, and its second workgroup returns at once. */
 	u64 c0 = b0;
 	u32 len;
 	if (b1 - b0 <= (u64)CAP) {
-		if (blockIdx.y)
+		if (by)
 			return;
 		len = (u32)(b1 - b0);
 	} else {
@@ -532,17 +557,26 @@ __global__ void __launch_bounds__(BrCfg<SIZE>::THREADS, BR_MIN_WAVES) k_bucket_r
 			 * bucket longer than the capacity has — goes to k_giant_tiles (list entry: tile | cut << GT_CUT_SHIFT; it reports into the tile's second slot); the
 			 * buckets in front of it are an ordinary first chunk and stay here. k_giant_tiles then sorts ONE bucket: only the bits below the bucket bits (three
 			 * passes at k = 27 instead of six over the whole tile's key range). Not fused, or beyond GT_MAX_RECORDS: the host's LSD passes, as ever. */
-			const bool listed = FUSED && gr.giant && (b1 - b0) - cut <= GT_MAX_RECORDS;
-			if (tid == 0 && blockIdx.y == 0) {
-				if (listed)
+			/* Round 6, one-word records: the giant bucket — of ANY length — becomes an entry of the group's arena (arena_sort.hip.h: sorted by HBM passes over all the
+			 * listed buckets at once, counted segment by segment by the whole GPU); no bin comes back for a satellite any more. */
+			const u64 glen = (b1 - b0) - cut;
+			const bool listed = FUSED && (arena ? glen < (1ull << 32) : (gr.giant && glen <= GT_MAX_RECORDS));
+			if (tid == 0 && by == 0 && !HEAVY) { /* (the second visit of the chunk in front of it must not list it again) */
+				if (listed && arena) {
+					const u32 e = atomicAdd(&gr.arena_dyn[AR_N_ENT], 1u);
+					if (e < gr.arena_cap)
+						gr.arena_ent[e] = ArenaEntry{((u64)(recs - gr.S[0]) + b0 + cut) | ((u64)bin << 40), (u32)glen, gtile};
+					else
+						atomicOr(&gr.arena_dyn[AR_OVERFLOW], 1u);
+				} else if (listed)
 					gr.giant[2 + atomicAdd(&gr.giant[0], 1u)] = gtile | (cut << GT_CUT_SHIFT);
 				else
 					atomicOr(flag, FUSED ? 0x10000u << bin : 1u); /* fused: only this BIN comes back (bits 16 + its number in the group); in place: the group */
 			}
-			if (!listed || cut == 0 || blockIdx.y != 0)
+			if (!listed || cut == 0 || by != 0)
 				return;
-			len = cut; /* blockIdx.y == 0: the buckets in front of the giant one */
-		} else if (blockIdx.y == 0)
+			len = cut; /* by == 0: the buckets in front of the giant one */
+		} else if (by == 0)
 			len = cut;
 		else {
 			c0 = b0 + cut;
@@ -632,9 +666,11 @@ __global__ void __launch_bounds__(BrCfg<SIZE>::THREADS, BR_MIN_WAVES) k_bucket_r
 			const u32 bstart = s_start[ord], bend = s_start[ord + 1];
 			span[r] = bstart | (bend << 16);
 			rel[r] = idx - bstart;
-			widest = widest > bend - bstart ? widest : bend - bstart;
-			if (bend - bstart > (u32)BR_BIG)
-				any_big = true;
+			if (!(HEAVY && bend - bstart > (u32)BR_MID)) { /* HEAVY: a bucket the arena has put in order is not walked (and does not count for the width of the pairs) */
+				widest = widest > bend - bstart ? widest : bend - bstart;
+				if (bend - bstart > (u32)BR_BIG)
+					any_big = true;
+			}
 		}
 	}
 	if (any_big)
@@ -650,7 +686,8 @@ __global__ void __launch_bounds__(BrCfg<SIZE>::THREADS, BR_MIN_WAVES) k_bucket_r
 	 * after the barrier behind the pair stores. */
 	u32 place[ITEMS];
 	u32 *s_rank = s_start;
-	auto is_big = [&](int r) -> bool { return (span[r] >> 16) - (span[r] & 0xFFFFu) > (u32)BR_BIG; };
+	auto in_order = [&](int r) -> bool { return HEAVY && (span[r] >> 16) - (span[r] & 0xFFFFu) > (u32)BR_MID; }; /* back from the arena: the record's place is where it lies */
+	auto is_big = [&](int r) -> bool { return (span[r] >> 16) - (span[r] & 0xFFFFu) > (u32)BR_BIG && !in_order(r); };
 	auto rank_big_buckets = [&](auto count) {
 		if (!*s_nbig) /* uniform */
 			return;
@@ -692,6 +729,32 @@ __global__ void __launch_bounds__(BrCfg<SIZE>::THREADS, BR_MIN_WAVES) k_bucket_r
 #pragma unroll
 		for (int w = 0; w < NW; ++w)
 			widest = widest > s_wmax[w] ? widest : s_wmax[w];
+		if constexpr (FUSED && !HEAVY) {
+			/* Round 6: a chunk with a bucket beyond BR_MID records is not finished here. Every such bucket is listed for the arena (its first record's thread speaks for
+			 * it; at most CAP / BR_MID per chunk), the chunk is listed for k_bucket_rank_heavy, and this workgroup is done: what pairwise ranking costs grows with the
+			 * square of a bucket, what the arena's passes cost does not depend on the shape of the input at all. */
+			if (arena && widest > (u32)BR_MID) { /* uniform */
+#pragma unroll
+				for (int r = 0; r < ITEMS; ++r) {
+					const u32 bstart = span[r] & 0xFFFFu, bend = span[r] >> 16;
+					if (((headbits >> r) & 1u) && bend - bstart > (u32)BR_MID) {
+						const u32 e = atomicAdd(&gr.arena_dyn[AR_N_ENT], 1u);
+						if (e < gr.arena_cap)
+							gr.arena_ent[e] = ArenaEntry{((u64)(recs - gr.S[0]) + c0 + bstart) | ((u64)bin << 40) | (1ull << 44), bend - bstart, gtile};
+						else
+							atomicOr(&gr.arena_dyn[AR_OVERFLOW], 1u);
+					}
+				}
+				if (tid == 0) {
+					const u32 h = atomicAdd(&gr.arena_dyn[AR_N_HEAVY], 1u);
+					if (h < gr.heavy_cap)
+						gr.heavy[h] = (gtile << 1) | by;
+					else
+						atomicOr(&gr.arena_dyn[AR_OVERFLOW], 1u);
+				}
+				return;
+			}
+		}
 		const bool narrow = rbits < 32 && widest <= (1u << (32 - rbits));
 		if (narrow) {
 			u32 *s_k32 = reinterpret_cast<u32 *>(s_key);
@@ -745,7 +808,9 @@ __global__ void __launch_bounds__(BrCfg<SIZE>::THREADS, BR_MIN_WAVES) k_bucket_r
 #pragma unroll
 			for (int r = 0; r < ITEMS; ++r) {
 				const u32 bstart = span[r] & 0xFFFFu, bend = span[r] >> 16;
-				place[r] = bstart + walk32(is_big(r) ? bend /* ranked by the whole workgroup below */ : bstart, bend, c32[r]);
+				place[r] = bstart + walk32(is_big(r) || in_order(r) ? bend /* ranked by the whole workgroup below / in order already */ : bstart, bend, c32[r]);
+				if (in_order(r))
+					place[r] = bstart + rel[r];
 			}
 			rank_big_buckets([&](u32 bs, u32 be, u32 i) { return walk32(bs, be, s_k32[i]); });
 		} else {
@@ -796,7 +861,9 @@ __global__ void __launch_bounds__(BrCfg<SIZE>::THREADS, BR_MIN_WAVES) k_bucket_r
 #pragma unroll
 			for (int r = 0; r < ITEMS; ++r) {
 				const u32 bstart = span[r] & 0xFFFFu, bend = span[r] >> 16;
-				place[r] = bstart + walk64(is_big(r) ? bend : bstart, bend, ((key[r][0] & rmask) << 16) | (u64)rel[r]);
+				place[r] = bstart + walk64(is_big(r) || in_order(r) ? bend : bstart, bend, ((key[r][0] & rmask) << 16) | (u64)rel[r]);
+				if (in_order(r))
+					place[r] = bstart + rel[r];
 			}
 			rank_big_buckets([&](u32 bs, u32 be, u32 i) { return walk64(bs, be, s_key[i]); });
 		}
@@ -1037,7 +1104,7 @@ __global__ void __launch_bounds__(BrCfg<SIZE>::THREADS, BR_MIN_WAVES) k_bucket_r
 		if (tile_counted != 0x7FFFFFFFu)
 			return;
 #endif
-		const u32 slot = 2 * tile + blockIdx.y;
+		const u32 slot = 2 * tile + by;
 		if (tid == 0) {
 			u32 tu = 0, tb = 0, ta = 0;
 #pragma unroll
@@ -1176,615 +1243,36 @@ __global__ void __launch_bounds__(BrCfg<SIZE>::THREADS, BR_MIN_WAVES) k_bucket_r
 	}
 }
 
-/* ------------------------------------------------------------------------------------------------ k_bucket_rank_c: tiles COLLAPSED, ranked and counted (round 5)
- * The default finisher since round 5 (KMC_HIP_RANK_COLLAPSE=0: k_bucket_rank<SIZE, true> above, round 4's). Same tiles, same inputs and outputs, same chunks and
- * hand-over of giant tiles as k_bucket_rank<SIZE, true>; what differs is WHAT is ranked: not the tile's records but its ENTRIES (below) — the pairwise ranks
- * cost the sum of the squares of the buckets, and a bucket is mostly copies. What this replaces in the reference stays what it was: the recursion of RadulsSort
- * into small buckets, CSmallSort (raduls_impl.h:497-510, :680-737; small_sort.h:29-179) and CompactKmers (kb_sorter.h:1128-1281). */
-template <int SIZE>
-__global__ void __launch_bounds__(BrCfg<SIZE>::THREADS, BR_MIN_WAVES) k_bucket_rank_c(const GrpRank gr, DevParams P, u32 key_bits, u32 hbits, u32 lut_shards, u64 lut_stride,
+template <int SIZE, bool FUSED>
+__global__ void __launch_bounds__(BrCfg<SIZE>::THREADS, BR_MIN_WAVES) k_bucket_rank(const GrpRank gr, DevParams P, u32 key_bits, u32 hbits, u32 lut_shards, u64 lut_stride,
                                                                                   u32 lut_mask, u32 *flag)
 {
-	constexpr int THREADS = BrCfg<SIZE>::THREADS, ITEMS = BrCfg<SIZE>::ITEMS, CAP = BrCfg<SIZE>::CAP, NW = BrCfg<SIZE>::NW;
-	constexpr u64 S = BrCfg<SIZE>::STRIDE;
-	constexpr u32 NONE = 0xFFFFFFFFu;
 	KMC_DYN_LDS(unsigned char, s_raw);
-	u64 *s_key = reinterpret_cast<u64 *>(s_raw);                              /* R0 */
-	u32 *s_start = reinterpret_cast<u32 *>(s_raw + BrCfg<SIZE>::R0);          /* R1 [CAP + 2] */
-	u32 *s_wfirst = s_start + CAP + 2;                                        /* [NW] bucket starts in wave w's rows */
-	u32 *s_wmax = s_wfirst + NW;                                              /* [NW] largest bucket a wave has seen; [0]: the cut of a long tile */
-	u32 *s_wlast = s_wmax + NW;                                               /* [NW] FUSED: the last run tail inside wave w's rows */
-	u32 *s_wcnt = s_wlast + NW;                                               /* [NW] FUSED: counted k-mers of wave w */
-	u32 *s_wtal = s_wcnt + NW;                                                /* [NW][3] distinct / below min / above max of wave w */
-	u32 *s_wents = s_wtal + 3 * NW;                                           /* [NW] entries (see below) of wave w's rows */
-	u32 *s_wsum = s_wents + NW;                                               /* [NW] sum of the weights of the entries wave w counts */
-
-	const u32 gtile = blockIdx.x;
-	const u32 bin = (u32)__builtin_amdgcn_readfirstlane((int)grp_find(gr.win_prefix, gr.g, gtile));
-	const u32 tile = gtile - gr.win_prefix[bin];
-	const u64 *__restrict__ bounds = gr.bounds[bin];
-	u64 *__restrict__ recs = gr.S[bin];
-	const u64 b0 = bounds[tile], b1 = bounds[tile + 1];
-	if (b0 >= ((u64)tile + 1) * S || b0 >= b1)
-		return; /* no bucket starts in this window */
-	const u32 tid = threadIdx.x, lane = tid & 63;
-	const u32 wave = (u32)__builtin_amdgcn_readfirstlane((int)(tid >> 6));
-	const u32 crel = wave * (ITEMS * 64); /* the wave owns ITEMS rows of 64 consecutive records */
-	const u32 bsh = 64 - hbits;
-	auto bucket_of = [&](const u64(&x)[SIZE]) -> u64 { return hbits ? bs_p64<SIZE>(x, key_bits) >> bsh : 0ull; };
-	const u64 *__restrict__ rec_base = SIZE >= BR_INDIRECT_MIN_SIZE ? gr.rec_base : nullptr; /* indirect: `recs` are pairs (never for one-word records: folded away at compile time) */
-	auto bucket_at = [&](u64 i) -> u64 {
-		if (rec_base)
-			return recs[i] >> 32; /* the top four key bytes ARE the bucket number: the bits above the key in the top byte are zero (kmc_hip.hip: hbits = 32 - those bits) */
-		u64 x[SIZE];
-		load_rec<SIZE>(recs + i * SIZE, x);
-		return bucket_of(x);
-	};
-	/* A tile longer than the capacity (windows are nearly as long as the capacity: BR_SLACK_DIV) is taken in two chunks of whole buckets, by the two
-	 * workgroups (blockIdx.y = 0, 1) every tile has: the first takes the records up to the last bucket start inside the capacity, the second the rest.
-	 * Nearly every tile fits, and its second workgroup returns at once. */
-	u64 c0 = b0;
-	u32 len;
-	if (b1 - b0 <= (u64)CAP) {
-		if (blockIdx.y)
-			return;
-		len = (u32)(b1 - b0);
-	} else {
-		if (tid == 0)
-			*s_wmax = 0;
-		__syncthreads();
-		for (u32 idx = tid + 1; idx <= (u32)CAP; idx += THREADS) /* b0 + CAP < b1 */
-			if (bucket_at(b0 + idx) != bucket_at(b0 + idx - 1))
-				atomicMax(s_wmax, idx);
-		__syncthreads();
-		const u32 cut = *s_wmax;
-		__syncthreads();
-		if (cut == 0 || (b1 - b0) - cut > (u64)CAP) { /* one bucket (or two) beyond the capacity: k_giant_tiles, or (not fused; enormous tiles) the host's LSD passes */
-			if (tid == 0 && blockIdx.y == 0) {
-				if (gr.giant && b1 - b0 <= GT_MAX_RECORDS)
-					gr.giant[2 + atomicAdd(&gr.giant[0], 1u)] = gtile;
-				else
-					atomicOr(flag, 0x10000u << bin); /* only this BIN comes back */
-			}
-			return;
-		}
-		if (blockIdx.y == 0)
-			len = cut;
-		else {
-			c0 = b0 + cut;
-			len = (u32)(b1 - c0);
-		}
-	}
-	u64 *__restrict__ T = recs + c0 * (rec_base ? 1 : SIZE);
-
-	u64 key[ITEMS][SIZE];
-	if (rec_base) { /* a gather of whole records by number (16+ bytes each: one or two HBM sectors). Every row's pair first, then every row's record: two round trips
-	                 * to HBM — written row by row, each row's pair load waited for the row before (eight round trips per tile of two-word records) */
-		u32 number[ITEMS];
-#pragma unroll
-		for (int r = 0; r < ITEMS; ++r) {
-			const u32 idx = crel + r * 64 + lane;
-			number[r] = (u32)T[idx < len ? idx : 0u]; /* (no branch around the load: the compiler waits for a load at the end of its branch) */
-		}
-#pragma unroll
-		for (int r = 0; r < ITEMS; ++r) {
-			const u32 idx = crel + r * 64 + lane;
-			load_rec<SIZE>(rec_base + (size_t)number[r] * SIZE, key[r]); /* rows behind the tile's end read record 0 and are cleared below */
-			if (idx >= len) {
-#pragma unroll
-				for (int w = 0; w < SIZE; ++w)
-					key[r][w] = 0;
-			}
-		}
-	} else {
-#pragma unroll
-		for (int r = 0; r < ITEMS; ++r) {
-			const u32 idx = crel + r * 64 + lane;
-			if (idx < len)
-				load_rec<SIZE>(T + (size_t)idx * SIZE, key[r]);
-			else {
-#pragma unroll
-				for (int w = 0; w < SIZE; ++w)
-					key[r][w] = 0;
-			}
-		}
-	}
-	/* ---- Bucket starts ("heads") as in k_bucket_rank, and the COLLAPSE of a row's copies (round 5).
-	 * The work of the pairwise ranks is the sum of the SQUARES of the buckets, and a bucket is mostly the copies of one k-mer (30x coverage: ~25 of them) —
-	 * on a genome with repeat families hundreds to thousands. Copies need no ranking. So before anything is ranked, every row of 64 records (in registers)
-	 * folds the copies of its segments' first records: a SEGMENT is the part of a bucket inside the row (buckets are contiguous; lane 0 starts one even when
-	 * its bucket began in the row before), its PIVOT the record of its first lane (one cross-lane read per 32 key bits that can differ), and
-	 *   - the segment's first lane becomes an ENTRY (k-mer, weight = records of the segment equal to the pivot),
-	 *   - every record that differs from its pivot becomes an entry of weight 1,
-	 *   - the pivot's copies are done.
-	 * Entries keep the tile's order (bucket by bucket), take consecutive numbers (mbcnt + the entries of the rows and waves before), and everything after —
-	 * bucket table, pairs, ranks, places, run tails — works on ENTRIES: a bucket of 25 copies and 3 one-offs is 4-5 entries, a bucket of 3000 copies of two
-	 * repeat k-mers about 100. Equal k-mers still meet (another segment's pivot, a one-off that is a copy after all): they end up adjacent in the ranked
-	 * order, and a run's count is the sum of its entries' weights (a prefix sum over the tile) instead of its length. */
-	u64 prev_b = 0;
-	if (crel > 0 && crel - 1 < len)
-		prev_b = bucket_at(c0 + crel - 1);
-	const u32 rbits = key_bits - hbits; /* <= br_rem_limit (host) */
-	const u64 lane_le = (2ull << lane) - 1; /* lanes 0 .. lane */
-	u32 headbits = 0, entbits = 0, be[ITEMS], wheads = 0, wents = 0; /* be: [15:0] bucket starts, [31:16] entries of this wave before the lane (<= 512 each) */
-	u32 wgt4[(ITEMS + 3) / 4]; /* weights, one byte each: weight - 1 (1 .. 64) */
-#pragma unroll
-	for (int r = 0; r < (ITEMS + 3) / 4; ++r)
-		wgt4[r] = 0;
-#pragma unroll
-	for (int r = 0; r < ITEMS; ++r) {
-		const u32 idx = crel + r * 64 + lane;
-		const bool valid = idx < len;
-		const u64 bk = bucket_of(key[r]);
-		const u32 plo = wave_shift_up1((u32)bk, (u32)prev_b, lane), phi = wave_shift_up1((u32)(bk >> 32), (u32)(prev_b >> 32), lane);
-		const bool head = valid && (idx == 0 || (((u64)phi << 32) | plo) != bk);
-		const u64 m = __ballot(head);
-		headbits |= head ? 1u << r : 0u;
-		const u32 below = __builtin_amdgcn_mbcnt_hi((u32)(m >> 32), __builtin_amdgcn_mbcnt_lo((u32)m, wheads));
-		wheads += (u32)__popcll(m);
-		prev_b = __shfl(bk, 63);
-		/* the segment of this lane: from the last segment start at or below it to the next one above it */
-		const u64 seg = m | 1ull;
-		const u32 sl = 63u - (u32)__clzll((long long)(seg & lane_le));
-		const u64 above = seg & ~lane_le;
-		const u32 nx = above ? (u32)__ffsll((long long)above) - 1u : 64u;
-		bool eq = valid;
-#pragma unroll
-		for (int w = 0; w < 2 * SIZE; ++w) /* the bits above the bucket bits are equal inside a segment: only the dwords that hold `rem` bits are fetched */
-			if ((u32)(32 * w) < rbits) {
-				const u32 mine = (u32)(key[r][w >> 1] >> (32 * (w & 1)));
-				const u32 pivot = (u32)__shfl((int)mine, (int)sl); /* every lane takes part in the cross-lane read: no `&&` in front of it */
-				eq = eq & (pivot == mine);
-			}
-		const u64 E = __ballot(eq);
-		const u32 cum = __builtin_amdgcn_mbcnt_hi((u32)(E >> 32), __builtin_amdgcn_mbcnt_lo((u32)E, 0u)); /* copies of pivots below this lane */
-		const u32 cum_at = (u32)__shfl((int)cum, (int)(nx & 63u)); /* unconditional, see above */
-		const u32 cum_nx = nx < 64u ? cum_at : (u32)__popcll(E);
-		const bool first = valid && sl == lane;
-		const bool ent = valid && (first || !eq);
-		const u32 weight = first ? cum_nx - cum : 1u; /* the lanes sl .. nx - 1 that equal the pivot (the pivot among them) */
-		const u64 em = __ballot(ent);
-		entbits |= ent ? 1u << r : 0u;
-		be[r] = below | (__builtin_amdgcn_mbcnt_hi((u32)(em >> 32), __builtin_amdgcn_mbcnt_lo((u32)em, wents)) << 16);
-		wents += (u32)__popcll(em);
-		wgt4[r >> 2] |= (ent ? weight - 1u : 0u) << (8 * (r & 3));
-		__builtin_amdgcn_sched_barrier(0); /* one row at a time: interleaved, the eight rows' masks and cross-lane reads do not fit the register budget of two workgroups per CU */
-	}
-	if (lane == 0) {
-		s_wfirst[wave] = wheads;
-		s_wents[wave] = wents;
-	}
-	__syncthreads();
-	u32 wave_heads_before, total_heads, wave_ents_before, n2;
-	{
-		const u32 v = lane < (u32)NW ? s_wfirst[lane] : 0u;
-		const u32 inc = wave_incl_sum_u32(v, lane);
-		total_heads = __shfl(inc, NW - 1);
-		wave_heads_before = __shfl(inc - v, (int)wave);
-		const u32 e = lane < (u32)NW ? s_wents[lane] : 0u;
-		const u32 einc = wave_incl_sum_u32(e, lane);
-		n2 = __shfl(einc, NW - 1);
-		wave_ents_before = __shfl(einc - e, (int)wave);
-	}
-	/* the table of bucket starts, in ENTRY numbers (a bucket's head is its first entry) */
-#pragma unroll
-	for (int r = 0; r < ITEMS; ++r)
-		if ((headbits >> r) & 1u)
-			s_start[wave_heads_before + (be[r] & 0xFFFFu)] = wave_ents_before + (be[r] >> 16);
-	if (tid == 0)
-		s_start[total_heads] = n2;
-	__syncthreads();
-	u32 span[ITEMS], widest = 0; /* span: [15:0] first entry of the entry's bucket, [31:16] its end (CAP < 65536); 0: not an entry */
-#pragma unroll
-	for (int r = 0; r < ITEMS; ++r) {
-		span[r] = 0;
-		if ((entbits >> r) & 1u) {
-			const u32 ord = wave_heads_before + (be[r] & 0xFFFFu) + ((headbits >> r) & 1u) - 1u;
-			const u32 bstart = s_start[ord], bend = s_start[ord + 1];
-			span[r] = bstart | (bend << 16);
-			widest = widest > bend - bstart ? widest : bend - bstart;
-		}
-		be[r] = wave_ents_before + (be[r] >> 16); /* from here on: the entry's number in the tile */
-	}
-	auto rel_of = [&](int r) -> u32 { return be[r] - (span[r] & 0xFFFFu); }; /* the entry's number inside its bucket (entries only) */
-	u32 place[ITEMS];
-	if constexpr (SIZE == 1) {
-		const u64 rmask = rbits >= 64 ? ~0ull : ((1ull << rbits) - 1);
-		/* the largest bucket of the tile (in entries) decides the width of the pairs: (rem, index) in 32 bits whenever they fit */
-#pragma unroll
-		for (int o = 32; o >= 1; o >>= 1) {
-			const u32 other = (u32)__shfl((int)widest, (int)(lane ^ (u32)o));
-			widest = widest > other ? widest : other;
-		}
-		if (lane == 0)
-			s_wmax[wave] = widest;
-		__syncthreads();
-#pragma unroll
-		for (int w = 0; w < NW; ++w)
-			widest = widest > s_wmax[w] ? widest : s_wmax[w];
-		const bool narrow = rbits < 32 && widest <= (1u << (32 - rbits));
-		if (narrow) {
-			u32 *s_k32 = reinterpret_cast<u32 *>(s_key);
-			const u32 sh = 32 - rbits;
-			u32 klo[ITEMS]; /* the pairs take half of R0: the entries' upper key halves wait in the other half instead of in eight registers */
-#pragma unroll
-			for (int r = 0; r < ITEMS; ++r) {
-				klo[r] = (u32)key[r][0];
-				if ((entbits >> r) & 1u) {
-					s_k32[be[r]] = ((u32)(key[r][0] & rmask) << sh) | rel_of(r); /* rel < widest <= 2^sh */
-					s_k32[CAP + be[r]] = (u32)(key[r][0] >> 32);
-				}
-			}
-			__syncthreads();
-#pragma unroll
-			for (int r = 0; r < ITEMS; ++r) {
-				const u32 bstart = span[r] & 0xFFFFu, bend = span[r] >> 16;
-				const u32 c = ((klo[r] & (u32)rmask) << sh) | rel_of(r); /* made again rather than kept: eight registers less across the barrier */
-				u32 rank = 0, q = bstart;
-				for (; q + 4 <= bend; q += 4) {
-					const u32 a0 = s_k32[q], a1 = s_k32[q + 1], a2 = s_k32[q + 2], a3 = s_k32[q + 3];
-					rank += (a0 < c ? 1u : 0u) + (a1 < c ? 1u : 0u) + (a2 < c ? 1u : 0u) + (a3 < c ? 1u : 0u);
-				}
-				for (; q < bend; ++q)
-					rank += s_k32[q] < c ? 1u : 0u;
-				place[r] = bstart + rank;
-			}
-#pragma unroll
-			for (int r = 0; r < ITEMS; ++r)
-				key[r][0] = (u64)klo[r] | ((u64)(((entbits >> r) & 1u) ? s_k32[CAP + be[r]] : 0u) << 32);
-		} else {
-#pragma unroll
-			for (int r = 0; r < ITEMS; ++r)
-				if ((entbits >> r) & 1u)
-					s_key[be[r]] = ((key[r][0] & rmask) << 16) | (u64)rel_of(r);
-			__syncthreads();
-#pragma unroll
-			for (int r = 0; r < ITEMS; ++r) {
-				const u32 bstart = span[r] & 0xFFFFu, bend = span[r] >> 16;
-				const u64 c = ((key[r][0] & rmask) << 16) | (u64)rel_of(r);
-				u32 rank = 0, q = bstart;
-				for (; q + 2 <= bend; q += 2) {
-					const u64 a = s_key[q], b = s_key[q + 1];
-					rank += (a < c ? 1u : 0u) + (b < c ? 1u : 0u);
-				}
-				if (q < bend)
-					rank += s_key[q] < c ? 1u : 0u;
-				place[r] = bstart + rank;
-			}
-		}
-	} else if constexpr (SIZE == 2) {
-		u64 *s_A = s_key;                                     /* [CAP] rem >> 16 */
-		u32 *s_B = reinterpret_cast<u32 *>(s_key + CAP);      /* [CAP] (rem & 0xFFFF) << 16 | index */
-		const u64 m1 = rbits > 64 ? ((1ull << (rbits - 64)) - 1) : 0ull; /* rbits - 64 <= 16 */
-		const u64 m0 = rbits >= 64 ? ~0ull : ((1ull << rbits) - 1);
-		u64 cA[ITEMS];
-		u32 cB[ITEMS];
-#pragma unroll
-		for (int r = 0; r < ITEMS; ++r) {
-			const u64 x0 = key[r][0] & m0, x1 = key[r][1] & m1;
-			cA[r] = (x1 << 48) | (x0 >> 16);
-			cB[r] = ((u32)(x0 & 0xFFFFu) << 16) | rel_of(r);
-			if ((entbits >> r) & 1u) {
-				s_A[be[r]] = cA[r];
-				s_B[be[r]] = cB[r];
-			}
-		}
-		__syncthreads();
-#pragma unroll
-		for (int r = 0; r < ITEMS; ++r) {
-			const u32 bstart = span[r] & 0xFFFFu, bend = span[r] >> 16;
-			const u32 A[2] = {(u32)cA[r], (u32)(cA[r] >> 32)};
-			const u32 B = cB[r];
-			u32 rank = 0, q = bstart;
-			for (; q + 4 <= bend; q += 4) { /* (A, B) is one 96-bit number: B holds the low rem bits and the index */
-#pragma unroll
-				for (int u = 0; u < 4; ++u) {
-					const u64 a = s_A[q + u];
-					const u32 x[2] = {(u32)a, (u32)(a >> 32)};
-					br_rank_add_less<2>(rank, x, s_B[q + u], A, B);
-				}
-			}
-			for (; q < bend; ++q) {
-				const u64 a = s_A[q];
-				const u32 x[2] = {(u32)a, (u32)(a >> 32)};
-				br_rank_add_less<2>(rank, x, s_B[q], A, B);
-			}
-			place[r] = bstart + rank;
-		}
-	} else {
-#pragma unroll
-		for (int r = 0; r < ITEMS; ++r)
-			if ((entbits >> r) & 1u)
-				store_rec<SIZE>(s_key + (size_t)be[r] * SIZE, key[r]);
-		__syncthreads();
-#pragma unroll
-		for (int r = 0; r < ITEMS; ++r) {
-			const u32 bstart = span[r] & 0xFFFFu, bend = span[r] >> 16;
-			const u32 me = be[r];
-			u32 rank = 0;
-			u32 y[2 * SIZE];
-#pragma unroll
-			for (int w = 0; w < SIZE; ++w) {
-				y[2 * w] = (u32)key[r][w];
-				y[2 * w + 1] = (u32)(key[r][w] >> 32);
-			}
-			auto count_one = [&](u32 q) { /* entries before this one: smaller ones, and equal ones that stand in front of it */
-				u64 o[SIZE];
-				load_rec<SIZE>(s_key + (size_t)q * SIZE, o);
-				u32 x[2 * SIZE];
-#pragma unroll
-				for (int w = 0; w < SIZE; ++w) {
-					x[2 * w] = (u32)o[w];
-					x[2 * w + 1] = (u32)(o[w] >> 32);
-				}
-				br_rank_add_less<2 * SIZE>(rank, x, q, y, me);
-			};
-			u32 q = bstart;
-			for (; q + 2 <= bend; q += 2) {
-				count_one(q);
-				count_one(q + 1);
-			}
-			if (q < bend)
-				count_one(q);
-			place[r] = bstart + rank;
-		}
-	}
-	__syncthreads(); /* every pair has been read; the bucket table (R1) is dead: the weights go there */
-	u32 *s_w = s_start;
-#pragma unroll
-	for (int r = 0; r < ITEMS; ++r)
-		if ((entbits >> r) & 1u) {
-			store_rec<SIZE>(s_key + (size_t)place[r] * SIZE, key[r]);
-			s_w[place[r]] = ((wgt4[r >> 2] >> (8 * (r & 3))) & 0xFFu) + 1u;
-		}
-	__syncthreads();
-	{
-		/* ---- the tile's ENTRIES are in order in LDS (n2 of them, dense) and made of whole buckets: count them where they lie — k_compact's tile body with a run's
-		 * count = the sum of its entries' weights. The n2 entries are dealt out again: rows2 rows of 64 to every wave. */
-		const u32 rows2 = (n2 + 64u * NW - 1u) / (64u * NW); /* <= ITEMS */
-		const u32 crel2 = wave * rows2 * 64u;
-		const u32 rec_bytes = P.sbytes + P.cbytes;
-		const bool use_lut = P.lut_prefix_len != 0 && !P.kff && !P.without_output;
-		const u64 lane_lt = (1ull << lane) - 1;
-		u32 tail_bits = 0, wlast = NONE, wrun = 0, psum[ITEMS];
-#pragma unroll
-		for (int r = 0; r < ITEMS; ++r) {
-			const u32 idx = crel2 + r * 64 + lane;
-			bool is_tail = false;
-			u32 wv = 0;
-			if ((u32)r < rows2 && idx < n2) {
-				load_rec<SIZE>(s_key + (size_t)idx * SIZE, key[r]);
-				wv = s_w[idx];
-				is_tail = true;
-				if (idx + 1 < n2) {
-					u64 nx[SIZE];
-					load_rec<SIZE>(s_key + (size_t)(idx + 1) * SIZE, nx);
-					is_tail = !kmc_equal<SIZE>(nx, key[r]);
-				}
-			}
-			const u64 m = __ballot(is_tail);
-			if (is_tail)
-				tail_bits |= 1u << r;
-			if (m)
-				wlast = crel2 + r * 64 + 63 - (u32)__clzll((long long)m);
-			const u32 winc = wave_incl_sum_u32(wv, lane); /* the weights up to this entry: inside the row, + the rows of this wave before it (wrun) */
-			psum[r] = wrun + winc;
-			wrun += (u32)__shfl((int)winc, 63);
-			__builtin_amdgcn_sched_barrier(0);
-		}
-		if (lane == 0) {
-			s_wlast[wave] = wlast;
-			s_wsum[wave] = wrun;
-		}
-		__syncthreads(); /* the entries in order have been read: R0 is free, R1 takes the prefix sums of the weights */
-		{
-			u32 woff = 0;
-#pragma unroll
-			for (int w = 0; w < NW; ++w)
-				woff += w < (int)wave ? s_wsum[w] : 0u;
-#pragma unroll
-			for (int r = 0; r < ITEMS; ++r) {
-				const u32 idx = crel2 + r * 64 + lane;
-				psum[r] += woff;
-				if ((u32)r < rows2 && idx < n2)
-					s_w[idx] = psum[r]; /* every lane overwrites the weight it has read itself */
-			}
-		}
-		__syncthreads();
-		u32 carry = NONE; /* -1: no tail before record 0 */
-#pragma unroll
-		for (int w = 0; w < NW; ++w) {
-			const u32 x = s_wlast[w];
-			if (w < (int)wave && x != NONE)
-				carry = x;
-		}
-		carry = (u32)__builtin_amdgcn_readfirstlane((int)carry);
-		u32 cnt[ITEMS];
-		u32 rank2[(ITEMS + 1) / 2]; /* wave-relative rank among counted k-mers, 16 bits each; 0xFFFF = not counted */
-		u32 nu = 0, nb = 0, na = 0, nc = 0;
-#pragma unroll
-		for (int r = 0; r < ITEMS; ++r) {
-			const u32 rowrel = crel2 + r * 64;
-			const u64 m = __ballot((tail_bits >> r) & 1u);
-			const u64 m_lt = m & lane_lt;
-			const u32 prev = m_lt ? rowrel + 63 - (u32)__clzll((long long)m_lt) : carry;
-			const u32 c = psum[r] - (prev != NONE ? s_w[prev < (u32)CAP ? prev : 0u] : 0u); /* the weights of the run that ends here (uint32 like the reference counter) */
-			const u64 mb = __ballot(c < P.cutoff_min) & m;
-			const u64 ma = __ballot(c > P.cutoff_max) & m & ~mb;
-			const u64 mc = m & ~mb & ~ma;
-			cnt[r] = c > P.counter_max ? P.counter_max : c;
-			const u32 rk = __builtin_amdgcn_mbcnt_hi((u32)(mc >> 32), __builtin_amdgcn_mbcnt_lo((u32)mc, nc));
-			const u32 rk16 = ((mc >> lane) & 1ull) ? rk : 0xFFFFu;
-			if (r & 1)
-				rank2[r >> 1] |= rk16 << 16;
-			else
-				rank2[r >> 1] = rk16;
-			nu += (u32)__popcll(m);
-			nb += (u32)__popcll(mb);
-			na += (u32)__popcll(ma);
-			nc += (u32)__popcll(mc);
-			if (m)
-				carry = rowrel + 63 - (u32)__clzll((long long)m);
-			__builtin_amdgcn_sched_barrier(0);
-		}
-		if (lane == 0) {
-			s_wcnt[wave] = nc;
-			s_wtal[wave * 3 + 0] = nu;
-			s_wtal[wave * 3 + 1] = nb;
-			s_wtal[wave * 3 + 2] = na;
-		}
-		__syncthreads();
-		u32 wave_off = 0, tile_counted = 0;
-#pragma unroll
-		for (int w = 0; w < NW; ++w) {
-			const u32 x = s_wcnt[w];
-			if (w < (int)wave)
-				wave_off += x;
-			tile_counted += x;
-		}
-#if defined(BR_STOP_AFTER) && BR_STOP_AFTER <= 4
-		if (tile_counted != 0x7FFFFFFFu)
-			return;
-#endif
-		const u32 slot = 2 * tile + blockIdx.y;
-		if (tid == 0) {
-			u32 tu = 0, tb = 0, ta = 0;
-#pragma unroll
-			for (int w = 0; w < NW; ++w) {
-				tu += s_wtal[w * 3 + 0];
-				tb += s_wtal[w * 3 + 1];
-				ta += s_wtal[w * 3 + 2];
-			}
-			u64 *sh = gr.tally[bin] + (size_t)(slot % CP_SHARDS) * 4;
-			if (tu)
-				atomicAdd(&sh[0], (u64)tu);
-			if (tb)
-				atomicAdd(&sh[1], (u64)tb);
-			if (ta)
-				atomicAdd(&sh[2], (u64)ta);
-			if (!P.without_output && tile_counted) {
-				gr.status[bin][slot] = tile_counted;
-				gr.chunk_src[bin][slot] = c0;
-			}
-		}
-		if (!P.without_output && tile_counted) { /* uniform over the workgroup */
-			const u32 tile_bytes = tile_counted * rec_bytes;
-			const u32 pshift = 2 * (P.k - P.lut_prefix_len);
-			uint8_t *const dst = gr.scratch[bin] + c0 * (u64)(SIZE * 8); /* 8-byte aligned; room for 8 SIZE bytes per record of the chunk */
-			u32 *dst32 = reinterpret_cast<u32 *>(dst);
-			const u32 ndw = (tile_bytes + 3) >> 2; /* whole dwords: the bytes behind the last record are the span's own */
-			const u32 inv = rec_bytes > 1 ? (u32)(((1ull << 32) + rec_bytes - 1) / rec_bytes) : 0u; /* x / rec_bytes = umulhi(x, inv), exact for x < 2^29 */
-			u32 *s_aux = s_start; /* R1: LUT prefixes (one word) / counts (wider) of the staged records */
-			if constexpr (SIZE == 1) {
-				/* counted k-mers and their counts go to their ranks as they are (two LDS stores per row); the records — one 64-bit value in output byte order
-				 * (rec_bytes <= 8: host) — and the LUT prefixes are then made by ONE pass of tile_counted threads (~5 % of the records at cutoff 2) instead of by
-				 * every row of every wave */
-#pragma unroll
-				for (int r = 0; r < ITEMS; ++r) {
-					const u32 rk16 = (rank2[r >> 1] >> ((r & 1) * 16)) & 0xFFFFu;
-					if (rk16 != 0xFFFFu) {
-						s_key[wave_off + rk16] = key[r][0];
-						s_aux[wave_off + rk16] = cnt[r];
-					}
-				}
-				__syncthreads();
-				for (u32 j = tid; j < tile_counted; j += THREADS) {
-					/* without a LUT prefix (KFF) the suffix bytes reach up to the top of the k-mer: a group tag above bit 2k must not get into them */
-					u64 kx[1] = {(2 * P.k < 64) ? (s_key[j] & ((1ull << (2 * P.k)) - 1)) : s_key[j]};
-					const u32 c = s_aux[j];
-					u64 rv = P.sbytes ? __builtin_bswap64(kx[0] << (8 * (8 - P.sbytes))) : 0ull;
-					if (P.cbytes) {
-						const u32 cv = P.kff ? (__builtin_bswap32(c) >> (8 * (4 - P.cbytes))) : c;
-						rv |= (u64)cv << (8 * P.sbytes);
-					}
-					s_key[j] = rv;
-					if (use_lut)
-						s_aux[j] = (u32)kmc_remove_suffix<1>(kx, pshift) & lut_mask;
-				}
-				__syncthreads();
-				for (u32 w = tid; w < ndw; w += THREADS) {
-					const u32 i0 = w << 2;
-					u32 ri = rec_bytes > 1 ? __umulhi(i0, inv) : i0, q = i0 - ri * rec_bytes;
-					u64 cur = s_key[ri];
-					u32 word = 0;
-#pragma unroll
-					for (int t = 0; t < 4; ++t) {
-						word |= ((u32)(cur >> (8 * q)) & 0xFFu) << (8 * t);
-						if (++q == rec_bytes) {
-							q = 0;
-							++ri;
-							cur = s_key[ri < (u32)CAP ? ri : (u32)CAP - 1];
-						}
-					}
-					dst32[w] = word;
-				}
-				if (use_lut) {
-					u64 *lut = gr.lut_base[bin] + (size_t)(slot % lut_shards) * lut_stride;
-					for (u32 j = tid; j < tile_counted; j += THREADS) {
-						const u32 pf = s_aux[j];
-						if (j + 1 == tile_counted || s_aux[j + 1] != pf)
-							atomicAdd(&lut[pf], (u64)(j + 1));
-						if (j > 0 && s_aux[j - 1] != pf)
-							atomicAdd(&lut[pf], (u64)0 - (u64)j);
-					}
-				}
-			} else {
-				/* staged: the k-mer (tag bits cleared) at its rank where the records were, its count in R1 */
-#pragma unroll
-				for (int r = 0; r < ITEMS; ++r) {
-					const u32 rk16 = (rank2[r >> 1] >> ((r & 1) * 16)) & 0xFFFFu;
-					if (rk16 != 0xFFFFu) {
-						const u32 rank = wave_off + rk16;
-						u64 kx[SIZE];
-#pragma unroll
-						for (int w = 0; w < SIZE; ++w)
-							kx[w] = key[r][w];
-						kmc_mask_low<SIZE>(kx, 2 * P.k);
-						store_rec<SIZE>(s_key + (size_t)rank * SIZE, kx);
-						s_aux[rank] = cnt[r];
-					}
-				}
-				__syncthreads();
-				/* byte i of the chunk's output is byte i % rec_bytes of record i / rec_bytes — suffix bytes high -> low (kb_sorter.h:1198-1199), then the
-				 * counter, little-endian for KMC (:1200-1201), big-endian for KFF (:1210-1211) */
-				auto out_byte = [&](u32 i) -> u32 {
-					const u32 ri = rec_bytes > 1 ? __umulhi(i, inv) : i, q = i - ri * rec_bytes;
-					if (q < P.sbytes) {
-						const u32 pbyte = P.sbytes - 1 - q;
-						return (u32)(s_key[(size_t)ri * SIZE + (pbyte >> 3)] >> ((pbyte & 7) * 8)) & 0xFFu;
-					}
-					const u32 cq = q - P.sbytes;
-					return (s_aux[ri] >> (8 * (P.kff ? (P.cbytes - 1 - cq) : cq))) & 0xFFu;
-				};
-#pragma clang loop unroll(disable) vectorize(disable)
-				for (u32 wd = tid; wd < ndw; wd += THREADS) {
-					const u32 i0 = wd * 4;
-					u32 word = out_byte(i0);
-					word |= (i0 + 1 < tile_bytes ? out_byte(i0 + 1) : 0u) << 8;
-					word |= (i0 + 2 < tile_bytes ? out_byte(i0 + 2) : 0u) << 16;
-					word |= (i0 + 3 < tile_bytes ? out_byte(i0 + 3) : 0u) << 24;
-					dst32[wd] = word;
-				}
-				if (use_lut) {
-					u64 *lut = gr.lut_base[bin] + (size_t)(slot % lut_shards) * lut_stride;
-					auto prefix_of = [&](u32 j) -> u32 {
-						u64 x[SIZE];
-						load_rec<SIZE>(s_key + (size_t)j * SIZE, x);
-						return (u32)kmc_remove_suffix<SIZE>(x, pshift) & lut_mask;
-					};
-					for (u32 j = tid; j < tile_counted; j += THREADS) {
-						const u32 pf = prefix_of(j);
-						if (j + 1 == tile_counted || prefix_of(j + 1) != pf)
-							atomicAdd(&lut[pf], (u64)(j + 1));
-						if (j > 0 && prefix_of(j - 1) != pf)
-							atomicAdd(&lut[pf], (u64)0 - (u64)j);
-					}
-				}
-			}
-		}
-	}
+	br_tile<SIZE, FUSED, false>(gr, P, key_bits, hbits, lut_shards, lut_stride, lut_mask, flag, blockIdx.x, blockIdx.y, s_raw);
 }
 
+/* The chunks k_bucket_rank listed (gr.heavy: a bucket beyond BR_MID records in them), once the arena has put those buckets in order where they lie: persistent workgroups
+ * take them one by one. Nothing listed: a launch that returns. */
+template <int SIZE>
+__global__ void __launch_bounds__(BrCfg<SIZE>::THREADS, BR_MIN_WAVES / 2) k_bucket_rank_heavy(const GrpRank gr, DevParams P, u32 key_bits, u32 hbits, u32 lut_shards, u64 lut_stride,
+                                                                                        u32 lut_mask, u32 *flag)
+{
+	KMC_DYN_LDS(unsigned char, s_raw);
+	__shared__ u32 s_pick;
+	const u32 n = ld_agent(&gr.arena_dyn[AR_N_HEAVY]); /* final: k_bucket_rank and k_arena_plan ran before this kernel on the stream */
+#pragma unroll 1
+	while (true) {
+		if (threadIdx.x == 0)
+			s_pick = atomicAdd(&gr.arena_dyn[AR_HEAVY_TICKET], 1u);
+		__syncthreads();
+		const u32 pick = s_pick;
+		if (pick >= n)
+			break;
+		const u32 entry = gr.heavy[pick];
+		br_tile<SIZE, true, true>(gr, P, key_bits, hbits, lut_shards, lut_stride, lut_mask, flag, entry >> 1, entry & 1u, s_raw);
+		__syncthreads(); /* LDS and the ticket word are reused */
+	}
+}
 
 /* ------------------------------------------------------------------------------------------------ tiles with a bucket beyond the LDS capacity
  * What the reference does with a bucket that stays large is recurse (raduls_impl.h:680-737: a big bucket takes a share of the threads and another radix

@@ -55,6 +55,14 @@ int hybrid_mode()
 	}();
 	return v;
 }
+bool arena_enabled()
+{
+	static const bool v = [] {
+		const char *e = getenv("KMC_HIP_ARENA"); /* 0 (A/B runs): round 5's finisher — big buckets walked by the whole workgroup, k_giant_tiles, bins with a satellite redone */
+		return !e || atoi(e) != 0;
+	}();
+	return v;
+}
 bool rank_enabled()
 {
 	static const bool v = [] {
@@ -140,13 +148,17 @@ SortPlan plan_sort(u64 n, u32 key_bytes, u32 key_bits, bool classic, bool fused 
 template <int SIZE>
 ZeroPlan plan_group(const Slot &s, std::vector<BinPlan> &bins, u64 n_total, u32 n_pass /* passes through HBM */, bool front, bool sort, bool compact, u64 lut_shard_entries,
                     u64 cp_tile = CpCfg<SIZE>::TILE /* records per compaction tile: k_compact's, or the window of k_bucket_count / k_bucket_rank */,
-                    u32 cp_words = 1 /* status words per tile (k_bucket_rank: one per chunk, two chunks) */, u64 giant_entries = 0)
+                    u32 cp_words = 1 /* status words per tile (k_bucket_rank: one per chunk, two chunks) */, u64 giant_entries = 0, bool arena = false)
 {
 	ZeroPlan z;
 	size_t off = up256(SM_BYTES);
 	if (giant_entries) {
 		z.giant = off;
 		off += up256((size_t)(giant_entries + 2) * 4);
+	}
+	if (arena) {
+		z.arena = off;
+		off += up256((size_t)AR_DYN_WORDS * 4) + up256((size_t)AR_MAX_PASS * 256 * 8);
 	}
 	for (BinPlan &b : bins) {
 		if (front) {
@@ -578,7 +590,8 @@ int count_group(Slot &s, const std::vector<BinPlan> &bins, const u64 *sorted, u6
  * two output slots (one per chunk: a tile that outgrows the capacity is taken by two workgroups). ---- */
 template <int SIZE>
 int rank_group(Slot &s, const std::vector<BinPlan> &bins, u64 *sorted, u64 *scratch, const DevParams &P, u64 lut_entries, const SortPlan &sp, u64 n_total, u32 *d_flag,
-               u32 *d_giant, const u64 *d_recs_indirect = nullptr /* indirect sort: `sorted` is the ordered PAIR array (one word per record), the records are here */)
+               u32 *d_giant, const u64 *d_recs_indirect = nullptr /* indirect sort: `sorted` is the ordered PAIR array (one word per record), the records are here */,
+               u32 *d_arena = nullptr /* one-word records: the arena's words in the zero region (plan_group), the buckets beyond BR_MID records go through arena_sort.hip.h */)
 {
 	if (bins.empty())
 		return 0;
@@ -646,6 +659,59 @@ int rank_group(Slot &s, const std::vector<BinPlan> &bins, u64 *sorted, u64 *scra
 	gr.giant = d_giant;
 	gr.rec_base = d_recs_indirect;
 	gg.tile_prefix[bins.size()] = (u32)(2 * wins);
+	/* The arena (one-word records): every bucket beyond BR_MID records is disjoint from every other, a giant one owns a tile — n_total / BR_MID + wins entries can never be
+	 * exceeded. Work area: entries | arena_off | item_off | bucket numbers | heavy chunks | digit bases | look-back rows of up to AR_MAX_PASS passes over up to n_total records. */
+	ArenaWork aw = {};
+	u32 ar_pass_max = 0;
+	const u32 rbits = sp.key_bits - sp.hbits();
+	if constexpr (SIZE == 1) {
+		if (d_arena && wins < (1ull << 30) && n_total < (1ull << 40)) {
+			const u64 cap = n_total / BR_MID + wins + 16, heavy_cap = 2 * wins + 16;
+			const u64 max_tiles = (std::min<u64>(n_total, AR_MAX_RECORDS) + RsCfg<1>::TILE - 1) / RsCfg<1>::TILE;
+			u32 obits = 0;
+			while (obits < 32 && (1ull << obits) < cap)
+				++obits;
+			ar_pass_max = std::min<u32>(AR_MAX_PASS, (rbits + obits + 7) / 8);
+			size_t off = 0;
+			const size_t o_ent = off;
+			off += up256(cap * sizeof(ArenaEntry));
+			const size_t o_aoff = off;
+			off += up256((cap + 1) * 4);
+			const size_t o_ioff = off;
+			off += up256((cap + 1) * 4);
+			const size_t o_hi = off;
+			off += up256(cap * 8);
+			const size_t o_heavy = off;
+			off += up256(heavy_cap * 4);
+			const size_t o_dbase = off;
+			off += up256((size_t)(AR_MAX_PASS + 1) * 256 * 8);
+			const size_t o_status = off;
+			const size_t stride = up256(max_tiles * 256 * 4);
+			off += stride * ar_pass_max;
+			if (int rc = ensure(s.arena_work, off))
+				return rc;
+			if (int rc = ensure(s.pairA, n_total * 8 + 256))
+				return rc;
+			if (int rc = ensure(s.pairB, n_total * 8 + 256))
+				return rc;
+			char *base = (char *)s.arena_work.p;
+			gr.arena_dyn = d_arena;
+			gr.arena_ent = (ArenaEntry *)(base + o_ent);
+			gr.arena_cap = (u32)std::min<u64>(cap, 0xFFFFFFF0ull);
+			gr.heavy = (u32 *)(base + o_heavy);
+			gr.heavy_cap = (u32)heavy_cap;
+			aw.arena_off = (u32 *)(base + o_aoff);
+			aw.item_off = (u32 *)(base + o_ioff);
+			aw.bucket_hi = (u64 *)(base + o_hi);
+			aw.A = (u64 *)s.pairA.p;
+			aw.B = (u64 *)s.pairB.p;
+			aw.ghist = (u64 *)((char *)d_arena + up256((size_t)AR_DYN_WORDS * 4));
+			aw.dbase = (u64 *)(base + o_dbase);
+			aw.status = (u32 *)(base + o_status);
+			aw.status_stride = (u32)(stride / 4);
+			aw.S0 = gr.S[0];
+		}
+	}
 	hipEvent_t e0 = nullptr, e1 = nullptr;
 	if (s.timed) {
 		if (int rc = ls_event_pair(s, e0, e1, n_total))
@@ -657,23 +723,182 @@ int rank_group(Slot &s, const std::vector<BinPlan> &bins, u64 *sorted, u64 *scra
 	else
 		k_bucket_bounds<SIZE><<<dim3((u32)((items + 3) / 4)), dim3(256), 0, s.stream>>>(gbn, (u32)S, sp.key_bits, sp.hbits());
 	const u32 lut_mask = P.lut_prefix_len ? (u32)((1ull << (2 * P.lut_prefix_len)) - 1) : 0u;
-	/* round 5: the finisher ranks a tile's ENTRIES (the copies of a row's pivots folded first: bucket_sort.hip.h k_bucket_rank_c); KMC_HIP_RANK_COLLAPSE=0 (A/B runs)
-	 * gives round 4's kernel, which ranks every record */
-	static const bool collapse = [] {
-		const char *e = getenv("KMC_HIP_RANK_COLLAPSE");
-		return e && atoi(e) != 0;
-	}();
 	static const size_t lds_pad = [] { /* experiments: more dynamic LDS than the kernel uses = fewer workgroups per CU (room for another stream's kernels beside it) */
 		const char *e = getenv("KMC_HIP_RANK_LDS_PAD");
 		const size_t v = e ? (size_t)strtoull(e, nullptr, 10) : (size_t)0;
 		return v > 32 * 1024 ? (size_t)32 * 1024 : v;
 	}();
-	if (collapse)
-		k_bucket_rank_c<SIZE><<<dim3((u32)wins, 2), dim3(BrCfg<SIZE>::THREADS), br_lds_bytes<SIZE>() + lds_pad, s.stream>>>(gr, P, sp.key_bits, sp.hbits(), n_sh, lut_entries, lut_mask, d_flag);
-	else
-		k_bucket_rank<SIZE, true><<<dim3((u32)wins, 2), dim3(BrCfg<SIZE>::THREADS), br_lds_bytes<SIZE>() + lds_pad, s.stream>>>(gr, P, sp.key_bits, sp.hbits(), n_sh, lut_entries, lut_mask, d_flag);
+	k_bucket_rank<SIZE, true><<<dim3((u32)wins, 2), dim3(BrCfg<SIZE>::THREADS), br_lds_bytes<SIZE>() + lds_pad, s.stream>>>(gr, P, sp.key_bits, sp.hbits(), n_sh, lut_entries, lut_mask, d_flag);
+	bool arena_ran = false;
+	if constexpr (SIZE == 1) {
+		if (gr.arena_dyn) { /* the buckets beyond BR_MID records, sorted together (arena_sort.hip.h); nothing listed: launches that return */
+			arena_ran = true;
+			u32 *dyn = gr.arena_dyn;
+			auto grid_of = [](const char *name) -> u32 { /* tuning / debugging: persistent workgroups per kernel */
+				const char *e = getenv(name);
+				const int v = e ? atoi(e) : 0;
+				return v > 0 ? (u32)v : 256u * 2u;
+			};
+			static const u32 g_gather = grid_of("KMC_HIP_ARENA_GRID_GATHER"), g_sweep = grid_of("KMC_HIP_ARENA_GRID_SWEEP"), g_finish = grid_of("KMC_HIP_ARENA_GRID_FINISH"),
+			                 g_heavy = grid_of("KMC_HIP_ARENA_GRID_HEAVY");
+			k_arena_plan<<<dim3(1), dim3(AR_THREADS), 0, s.stream>>>(gr, aw, rbits, d_flag);
+			k_arena_gather<<<dim3(g_gather), dim3(AR_THREADS), (size_t)ar_pass_max * 1024, s.stream>>>(gr, aw, rbits, ar_pass_max);
+			k_hist_scan<<<dim3(ar_pass_max), dim3(256), 0, s.stream>>>(aw.ghist, aw.dbase);
+			static const bool debug_steps = getenv("KMC_HIP_ARENA_DEBUG") && atoi(getenv("KMC_HIP_ARENA_DEBUG")) >= 2;
+			std::vector<u64> dbg_prev;
+			auto debug_step = [&](int pass) -> int { /* diagnostics: the arena after the gather (pass -1) / after pass `pass`, against what the host makes of the step's input */
+				HIPCHK(hipStreamSynchronize(s.stream));
+				u32 h_dyn[AR_DYN_WORDS];
+				HIPCHK(hipMemcpy(h_dyn, dyn, sizeof h_dyn, hipMemcpyDeviceToHost));
+				const u32 M = h_dyn[AR_M], ne = h_dyn[AR_N_ENT], np = h_dyn[AR_N_PASS];
+				if (!M || pass >= (int)np)
+					return 0;
+				std::vector<u64> cur(M);
+				HIPCHK(hipMemcpy(cur.data(), (pass & 1) ? aw.B : aw.A, (size_t)M * 8, hipMemcpyDeviceToHost)); /* pass -1 -> A (odd as a bit pattern: & 1 == 1)... handled below */
+				if (pass < 0) {
+					HIPCHK(hipMemcpy(cur.data(), aw.A, (size_t)M * 8, hipMemcpyDeviceToHost));
+					std::vector<u32> off(ne + 1);
+					std::vector<ArenaEntry> ent(ne);
+					HIPCHK(hipMemcpy(off.data(), aw.arena_off, (size_t)(ne + 1) * 4, hipMemcpyDeviceToHost));
+					HIPCHK(hipMemcpy(ent.data(), gr.arena_ent, (size_t)ne * sizeof(ArenaEntry), hipMemcpyDeviceToHost));
+					const u64 rmask = rbits >= 64 ? ~0ull : ((1ull << rbits) - 1);
+					u64 bad = 0, first = ~0ull, badoff = 0;
+					std::vector<u64> slice;
+					u64 run = 0;
+					for (u32 e = 0; e < ne; ++e) {
+						if (off[e] != run)
+							++badoff;
+						run += ent[e].len;
+						slice.resize(ent[e].len);
+						HIPCHK(hipMemcpy(slice.data(), aw.S0 + (ent[e].w0 & ((1ull << 40) - 1)), (size_t)ent[e].len * 8, hipMemcpyDeviceToHost));
+						for (u32 i = 0; i < ent[e].len; ++i)
+							if (off[e] + i < M && cur[off[e] + i] != (((u64)e << rbits) | (slice[i] & rmask))) {
+								if (!bad)
+									first = off[e] + i;
+								++bad;
+							}
+					}
+					std::vector<u64> gh((size_t)AR_MAX_PASS * 256), want((size_t)AR_MAX_PASS * 256, 0);
+					HIPCHK(hipMemcpy(gh.data(), aw.ghist, gh.size() * 8, hipMemcpyDeviceToHost));
+					for (u32 i = 0; i < M; ++i)
+						for (u32 b = 0; b < np; ++b)
+							++want[b * 256 + ((cur[i] >> (8 * b)) & 255)];
+					u64 badh = 0;
+					for (size_t i = 0; i < (size_t)np * 256; ++i)
+						badh += gh[i] != want[i];
+					fprintf(stderr, "[arena debug] gather: %llu of %u records differ from the host's (first %llu), %llu offsets off (sum %llu), %llu histogram cells differ\n", (unsigned long long)bad, M,
+					        (unsigned long long)first, (unsigned long long)badoff, (unsigned long long)run, (unsigned long long)badh);
+				} else {
+					HIPCHK(hipMemcpy(cur.data(), (pass & 1) ? aw.A : aw.B, (size_t)M * 8, hipMemcpyDeviceToHost)); /* pass p writes B when p is even */
+					std::vector<u64> want(dbg_prev);
+					std::stable_sort(want.begin(), want.end(), [&](u64 a, u64 b) { return ((a >> (8 * pass)) & 255) < ((b >> (8 * pass)) & 255); });
+					u64 bad = 0, first = ~0ull;
+					for (u32 i = 0; i < M; ++i)
+						if (cur[i] != want[i]) {
+							if (!bad)
+								first = i;
+							++bad;
+						}
+					fprintf(stderr, "[arena debug] pass %d: %llu of %u records differ from a stable sort of the pass's input by its digit (first %llu)\n", pass, (unsigned long long)bad, M,
+					        (unsigned long long)first);
+					u32 shown = 0;
+					for (u32 i = 0; i < M && shown < 12; ++i)
+						if (cur[i] != want[i]) {
+							u64 where = ~0ull; /* where the host expected the record the device put here */
+							for (u32 j = 0; j < M; ++j)
+								if (want[j] == cur[i]) {
+									where = j;
+									break;
+								}
+							fprintf(stderr, "[arena debug]   at %u: device %016llx host %016llx (the device's record belongs at %lld)\n", i, (unsigned long long)cur[i], (unsigned long long)want[i], (long long)where);
+							++shown;
+						}
+				}
+				dbg_prev.swap(cur);
+				return 0;
+			};
+			if (debug_steps)
+				if (int rc = debug_step(-1))
+					return rc;
+			for (u32 pass = 0; pass < ar_pass_max; ++pass) {
+				if (debug_steps && pass)
+					if (int rc = debug_step((int)pass - 1))
+						return rc;
+				static const bool debug_static = getenv("KMC_HIP_ARENA_DEBUG") && atoi(getenv("KMC_HIP_ARENA_DEBUG")) >= 3;
+				if (debug_static) { /* diagnostics: the pass by the ordinary kernel, its length read back by the host */
+					HIPCHK(hipStreamSynchronize(s.stream));
+					u32 h_dyn[AR_DYN_WORDS];
+					HIPCHK(hipMemcpy(h_dyn, dyn, sizeof h_dyn, hipMemcpyDeviceToHost));
+					if (h_dyn[AR_M] && pass < h_dyn[AR_N_PASS]) {
+						const u32 tiles = (h_dyn[AR_M] + RsCfg<1>::TILE - 1) / RsCfg<1>::TILE;
+						k_onesweep<1><<<dim3(tiles), dim3(RS_BLOCK), rs_lds_bytes<1>(), s.stream>>>((pass & 1u) ? aw.B : aw.A, (pass & 1u) ? aw.A : aw.B, h_dyn[AR_M], pass,
+						                                                                         aw.dbase + (size_t)pass * 256, aw.dbase + (size_t)AR_MAX_PASS * 256,
+						                                                                         aw.status + (size_t)pass * aw.status_stride, dyn + AR_PASS_TICKET + pass, tiles, err);
+					}
+					continue;
+				}
+				k_onesweep_dyn<1><<<dim3(g_sweep), dim3(RS_BLOCK), rs_lds_bytes<1>(), s.stream>>>((pass & 1u) ? aw.B : aw.A, (pass & 1u) ? aw.A : aw.B, dyn + AR_M, pass,
+				                                                                                  aw.dbase + (size_t)pass * 256, aw.dbase + (size_t)AR_MAX_PASS * 256,
+				                                                                                  aw.status + (size_t)pass * aw.status_stride, dyn + AR_PASS_TICKET + pass, err);
+			}
+			if (debug_steps)
+				if (int rc = debug_step((int)ar_pass_max - 1))
+					return rc;
+			static const bool debug = getenv("KMC_HIP_ARENA_DEBUG") != nullptr;
+			if (debug) { /* is the arena in order, and is every entry's slice the multiset of its bucket? (the stream is drained: diagnostics only) */
+				HIPCHK(hipStreamSynchronize(s.stream));
+				u32 h_dyn[AR_DYN_WORDS];
+				HIPCHK(hipMemcpy(h_dyn, dyn, sizeof h_dyn, hipMemcpyDeviceToHost));
+				const u32 M = h_dyn[AR_M], ne = h_dyn[AR_N_ENT], np = h_dyn[AR_N_PASS];
+				fprintf(stderr, "[arena debug] entries %u records %u passes %u (max %u) items %u heavy %u overflow %u rbits %u\n", ne, M, np, ar_pass_max, h_dyn[AR_N_ITEMS], h_dyn[AR_N_HEAVY],
+				        h_dyn[AR_OVERFLOW], rbits);
+				if (M) {
+					std::vector<u64> ar(M);
+					std::vector<u32> off(ne + 1);
+					std::vector<ArenaEntry> ent(ne);
+					HIPCHK(hipMemcpy(ar.data(), (np & 1u) ? aw.B : aw.A, (size_t)M * 8, hipMemcpyDeviceToHost));
+					HIPCHK(hipMemcpy(off.data(), aw.arena_off, (size_t)(ne + 1) * 4, hipMemcpyDeviceToHost));
+					HIPCHK(hipMemcpy(ent.data(), gr.arena_ent, (size_t)ne * sizeof(ArenaEntry), hipMemcpyDeviceToHost));
+					u64 inversions = 0, first_inv = ~0ull;
+					for (u32 i = 1; i < M; ++i)
+						if (ar[i - 1] > ar[i]) {
+							if (!inversions)
+								first_inv = i;
+							++inversions;
+						}
+					u64 bad_entries = 0, first_bad = ~0ull, bad_ord = 0;
+					const u64 rmask = rbits >= 64 ? ~0ull : ((1ull << rbits) - 1);
+					std::vector<u64> slice;
+					for (u32 e = 0; e < ne; ++e) {
+						const u64 gpos = ent[e].w0 & ((1ull << 40) - 1);
+						slice.resize(ent[e].len);
+						HIPCHK(hipMemcpy(slice.data(), aw.S0 + gpos, (size_t)ent[e].len * 8, hipMemcpyDeviceToHost));
+						for (auto &x : slice)
+							x = ((u64)e << rbits) | (x & rmask);
+						std::sort(slice.begin(), slice.end());
+						bool ok = off[e + 1] - off[e] == ent[e].len;
+						for (u32 i = 0; ok && i < ent[e].len; ++i)
+							ok = ar[off[e] + i] == slice[i];
+						for (u32 i = off[e]; i < off[e + 1] && i < M; ++i)
+							if ((ar[i] >> rbits) != e)
+								++bad_ord;
+						if (!ok) {
+							if (!bad_entries)
+								first_bad = e;
+							++bad_entries;
+						}
+					}
+					fprintf(stderr, "[arena debug] inversions %llu (first at %llu), entries whose slice is not their bucket in order: %llu (first %llu), records under a foreign ordinal %llu\n",
+					        (unsigned long long)inversions, (unsigned long long)first_inv, (unsigned long long)bad_entries, (unsigned long long)first_bad, (unsigned long long)bad_ord);
+				}
+			}
+			k_arena_finish<<<dim3(g_finish), dim3(AR_THREADS), 0, s.stream>>>(gr, aw, P, rbits, n_sh, lut_entries, lut_mask, err);
+			k_bucket_rank_heavy<1><<<dim3(g_heavy), dim3(BrCfg<1>::THREADS), br_lds_bytes<1>(), s.stream>>>(gr, P, sp.key_bits, sp.hbits(), n_sh, lut_entries, lut_mask, d_flag);
+		}
+	}
 	/* the tiles with a bucket beyond the LDS capacity (k-mers repeated thousands of times), one workgroup each; nothing listed: a launch that returns */
-	k_giant_tiles<SIZE><<<dim3((u32)std::min<u64>(wins, 256 * (1024 / GT_THREADS))), dim3(GT_THREADS), 0, s.stream>>>(gr, P, (u32)S, sp.key_bits, sp.hbits(), n_sh, lut_entries, lut_mask, err);
+	if (!arena_ran)
+		k_giant_tiles<SIZE><<<dim3((u32)std::min<u64>(wins, 256 * (1024 / GT_THREADS))), dim3(GT_THREADS), 0, s.stream>>>(gr, P, (u32)S, sp.key_bits, sp.hbits(), n_sh, lut_entries, lut_mask, err);
 	if (s.timed)
 		HIPCHK(hipEventRecord(e1, s.stream));
 	k_compact_fold<<<dim3((u32)bins.size()), dim3(256), 0, s.stream>>>(gf, use_lut ? n_sh : 1u, lut_entries, 1u, rec_bytes, err);
@@ -799,7 +1024,7 @@ int run_group_device_t(Slot &s, const DevParams &P, const kmc_hip_bin_desc *cons
 			rank_tiles += (b.n_rec + BrCfg<SIZE>::STRIDE - 1) / BrCfg<SIZE>::STRIDE;
 	const ZeroPlan z = plan_group<SIZE>(s, bins, N, n_pass, true, true, true, n_sh > 1 ? (u64)n_sh * lut_entries : 0,
 	                                    rank_fused ? (u64)BrCfg<SIZE>::STRIDE : (sp.local() && !sp.rank ? (u64)BcCfg<SIZE>::STRIDE : (u64)CpCfg<SIZE>::TILE), rank_fused ? 2u : 1u,
-	                                    rank_tiles);
+	                                    rank_tiles, rank_fused && SIZE == 1 && arena_enabled());
 	if ((rc = apply_plan(s, z))) /* ONE memset per group: small block, bitmaps, look-back words, histograms, LUT and tally shards, scatter status */
 		return rc;
 	for (BinPlan &b : bins) { /* resolved only AFTER apply_plan: growing the zero region moves the small block */
@@ -852,7 +1077,8 @@ int run_group_device_t(Slot &s, const DevParams &P, const kmc_hip_bin_desc *cons
 	if (indirect && N >= 2)
 		g_indirect_groups.fetch_add(1, std::memory_order_relaxed);
 	if (rank_fused && sp.local() && N >= 2)
-		rc = rank_group<SIZE>(s, bins, sorted, free_array, P, lut_entries, sp, N, flag, zero_ptr<u32>(s, z.giant), indirect ? (const u64 *)s.recA.p : nullptr);
+		rc = rank_group<SIZE>(s, bins, sorted, free_array, P, lut_entries, sp, N, flag, zero_ptr<u32>(s, z.giant), indirect ? (const u64 *)s.recA.p : nullptr,
+		                      z.arena ? zero_ptr<u32>(s, z.arena) : nullptr);
 	else if (sp.local() && !sp.rank && N >= 2)
 		rc = count_group<SIZE>(s, bins, sorted, free_array, P, lut_entries, sp, N, flag);
 	else

@@ -1063,36 +1063,15 @@ template <int SIZE> __device__ __forceinline__ u32 rs_digit(const u64 (&x)[SIZE]
 	return __builtin_amdgcn_ubfe(half, (byte_idx & 3) * 8, 8);
 }
 
+/* one tile of a pass (steps 2-6 above); the caller has the tile's number and runs a barrier behind it before the LDS is used again */
 template <int SIZE>
-__global__ void __launch_bounds__(RS_BLOCK, (SIZE <= 4 ? RS_MIN_WAVES : RS_MIN_WAVES / 2)) k_onesweep(const u64 *__restrict__ in, u64 *__restrict__ out, u32 n, u32 byte_idx,
-                                                        const u64 *__restrict__ digit_base_in, u64 *__restrict__ digit_base_next,
-                                                        u32 *status, u32 *tile_counter, u32 num_tiles, u32 *err)
+__device__ __forceinline__ void onesweep_tile(const u64 *__restrict__ in, u64 *__restrict__ out, const u32 n, const u32 byte_idx, const u64 *__restrict__ digit_base_in,
+                                              u64 *__restrict__ digit_base_next, u32 *status, const u32 tile, const u32 num_tiles, u32 *err, u64 *s_goff, u64 *s_keys, u32 *s_whist,
+                                              u32 *s_wsum)
 {
 	constexpr int ITEMS = RsCfg<SIZE>::ITEMS;
 	constexpr int TILE = RsCfg<SIZE>::TILE;
-	KMC_DYN_LDS(unsigned char, s_raw);
-	u64 *s_goff = reinterpret_cast<u64 *>(s_raw);              /* [256]  global index of LDS slot 0 as seen by digit d */
-	u64 *s_keys = s_goff + 256;                                /* [SIZE*TILE/STAGES] word-major staging area            */
-	u32 *s_whist = reinterpret_cast<u32 *>(s_keys + SIZE * TILE / RsCfg<SIZE>::STAGES); /* [RS_WAVES*256] per-wave digit counters -> slots */
-	u32 *s_wsum = s_whist + RS_WAVES * 256;                    /* [4]                                                    */
-	u32 *s_tile = s_wsum + 4;                                  /* [1]                                                    */
-
-#if RS_TILE_FROM_BLOCKIDX
-	const u32 ticket = blockIdx.x;
-	(void)tile_counter;
-	(void)s_tile;
-#else
-	if (threadIdx.x == 0)
-		*s_tile = atomicAdd(tile_counter, 1u);
-	__syncthreads();
-	const u32 ticket = (u32)__builtin_amdgcn_readfirstlane((int)*s_tile); /* scalar: tile-level addresses live in SGPRs */
-#endif
-
-#pragma unroll 1
-	for (int it = 0; it < RS_TPB; ++it) {
-		const u32 tile = ticket * RS_TPB + it;
-		if (tile >= num_tiles)
-			break;
+	{
 		/* lane-constant addresses must be recomputed per tile: hoisted out of this loop they cost ~60 VGPRs and spill */
 		u32 tid = threadIdx.x;
 		KMC_LAUNDER(tid);
@@ -1102,7 +1081,11 @@ __global__ void __launch_bounds__(RS_BLOCK, (SIZE <= 4 ? RS_MIN_WAVES : RS_MIN_W
 			s_whist[wave * 256 + i * 64 + lane] = 0;
 		KMC_WAVE_LOCKSTEP(); /* the wave's own counters are zero before any of its lanes counts into them */
 		const u64 tile_base = (u64)tile * TILE;
-		const u32 tile_n = (n - tile_base) < (u64)TILE ? (u32)(n - tile_base) : (u32)TILE;
+		/* (32-bit arithmetic: tile < num_tiles, so tile * TILE < n. The 64-bit form `(n - tile_base) < TILE ? ... : TILE` compiled to a v_cmp_lt_u64 into vcc and an
+		 * s_cselect_b32 on whatever SCC held — the "is this the last tile" compare of a few lines further down in k_onesweep, by luck the same condition there; in
+		 * k_onesweep_dyn the borrow of the subtraction: a partial tile taken for a full one, records dropped. Round 6, found on the device, not under the emulation.) */
+		const u32 tile_rest = n - tile * (u32)TILE;
+		const u32 tile_n = tile_rest < (u32)TILE ? tile_rest : (u32)TILE;
 		TRACE_STAMP(0, tile, 0);
 
 		/* the body is instantiated twice: all tiles but the last of a portion are full, and for them every bounds
@@ -1310,7 +1293,71 @@ __global__ void __launch_bounds__(RS_BLOCK, (SIZE <= 4 ? RS_MIN_WAVES : RS_MIN_W
 			tile_body(std::true_type{});
 		else
 			tile_body(std::false_type{});
+	}
+}
+
+template <int SIZE>
+__global__ void __launch_bounds__(RS_BLOCK, (SIZE <= 4 ? RS_MIN_WAVES : RS_MIN_WAVES / 2)) k_onesweep(const u64 *__restrict__ in, u64 *__restrict__ out, u32 n, u32 byte_idx,
+                                                        const u64 *__restrict__ digit_base_in, u64 *__restrict__ digit_base_next,
+                                                        u32 *status, u32 *tile_counter, u32 num_tiles, u32 *err)
+{
+	constexpr int TILE = RsCfg<SIZE>::TILE;
+	KMC_DYN_LDS(unsigned char, s_raw);
+	u64 *s_goff = reinterpret_cast<u64 *>(s_raw);              /* [256]  global index of LDS slot 0 as seen by digit d */
+	u64 *s_keys = s_goff + 256;                                /* [SIZE*TILE/STAGES] word-major staging area            */
+	u32 *s_whist = reinterpret_cast<u32 *>(s_keys + SIZE * TILE / RsCfg<SIZE>::STAGES); /* [RS_WAVES*256] per-wave digit counters -> slots */
+	u32 *s_wsum = s_whist + RS_WAVES * 256;                    /* [4]                                                    */
+	u32 *s_tile = s_wsum + 4;                                  /* [1]                                                    */
+
+#if RS_TILE_FROM_BLOCKIDX
+	const u32 ticket = blockIdx.x;
+	(void)tile_counter;
+	(void)s_tile;
+#else
+	if (threadIdx.x == 0)
+		*s_tile = atomicAdd(tile_counter, 1u);
+	__syncthreads();
+	const u32 ticket = (u32)__builtin_amdgcn_readfirstlane((int)*s_tile); /* scalar: tile-level addresses live in SGPRs */
+#endif
+
+#pragma unroll 1
+	for (int it = 0; it < RS_TPB; ++it) {
+		const u32 tile = ticket * RS_TPB + it;
+		if (tile >= num_tiles)
+			break;
+		onesweep_tile<SIZE>(in, out, n, byte_idx, digit_base_in, digit_base_next, status, tile, num_tiles, err, s_goff, s_keys, s_whist, s_wsum);
 		__syncthreads(); /* LDS is reused by the next tile of this ticket */
+	}
+}
+
+/* The same pass over an array whose LENGTH is only known on the device (arena_sort.hip.h: the records of a group's repeat-rich buckets): dyn[0] = records, dyn[1] =
+ * passes to run (launch `pass` >= dyn[1]: nothing to do). A fixed grid of persistent workgroups takes tiles by ticket until none is left — a workgroup that
+ * draws ticket t is running, so is (or was) every workgroup that drew a lower one: the look-back cannot wait for a tile nobody has. */
+template <int SIZE>
+__global__ void __launch_bounds__(RS_BLOCK, (SIZE <= 4 ? RS_MIN_WAVES : RS_MIN_WAVES / 2)) k_onesweep_dyn(const u64 *__restrict__ in, u64 *__restrict__ out, const u32 *__restrict__ dyn, u32 pass,
+                                                        const u64 *__restrict__ digit_base_in, u64 *__restrict__ digit_base_next, u32 *status, u32 *tile_counter, u32 *err)
+{
+	constexpr int TILE = RsCfg<SIZE>::TILE;
+	KMC_DYN_LDS(unsigned char, s_raw);
+	u64 *s_goff = reinterpret_cast<u64 *>(s_raw);
+	u64 *s_keys = s_goff + 256;
+	u32 *s_whist = reinterpret_cast<u32 *>(s_keys + SIZE * TILE / RsCfg<SIZE>::STAGES);
+	u32 *s_wsum = s_whist + RS_WAVES * 256;
+	u32 *s_tile = s_wsum + 4;
+	const u32 n = dyn[0];
+	if (n == 0 || pass >= dyn[1])
+		return;
+	const u32 num_tiles = (n + (u32)TILE - 1) / (u32)TILE;
+#pragma unroll 1
+	while (true) {
+		if (threadIdx.x == 0)
+			*s_tile = atomicAdd(tile_counter, 1u);
+		__syncthreads();
+		const u32 tile = (u32)__builtin_amdgcn_readfirstlane((int)*s_tile);
+		if (tile >= num_tiles)
+			break;
+		onesweep_tile<SIZE>(in, out, n, pass, digit_base_in, digit_base_next, status, tile, num_tiles, err, s_goff, s_keys, s_whist, s_wsum);
+		__syncthreads(); /* LDS (and the ticket word) are reused by the next tile */
 	}
 }
 

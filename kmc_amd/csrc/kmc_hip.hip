@@ -26,6 +26,7 @@
 #include "../../include/kmc_hip.h"
 #include "kernels.hip.h"
 #include "bucket_sort.hip.h"
+#include "arena_sort.hip.h"
 #include "order_db.hip.h"
 #include "stage1_kernels.hip.h"
 
@@ -139,6 +140,7 @@ struct HostRes {
 struct ZeroPlan {
 	size_t ghist = 0, sc_status = 0, sc_stride = 0, total = 0; /* the per-bin parts are in BinPlan */
 	size_t giant = 0; /* rank groups: the list of tiles handed to k_giant_tiles (count, taken, tile numbers) */
+	size_t arena = 0; /* rank groups of one-word records: the arena's AR_DYN_WORDS words, then its AR_MAX_PASS x 256 digit counters (arena_sort.hip.h); 0: no arena */
 };
 inline size_t up256(size_t x) { return (x + 255) & ~(size_t)255; }
 
@@ -158,6 +160,7 @@ struct Slot {
 	DBuf in, pack_start;
 	DBuf recA, recB, recC, pairA, pairB, zero, dbase, out, lut, sticky;
 	DBuf bounds;   /* hybrid sort: tile boundaries of k_bucket_bounds, u64[windows + 1] */
+	DBuf arena_work; /* rank groups of one-word records: entries, offsets, bucket numbers, heavy chunks, digit bases and look-back rows of the arena's passes (the arenas: pairA / pairB) */
 	DBuf redo_log; /* hybrid sort: one "sort me again" word per asynchronous group since the last drain (drain_redo) */
 	HostRes *h_res = nullptr; /* pinned */
 	/* pinned staging for callers whose buffers are ordinary (pageable) memory — the drop-in worker's arena: a copy straight from / to such memory makes the
@@ -258,9 +261,10 @@ template <int SIZE> int set_func_attrs()
 		HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_bucket_sort<SIZE>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bs_lds_bytes<SIZE>()));
 	if (br_lds_bytes<SIZE>() > 65536) {
 		HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_bucket_rank<SIZE, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)br_lds_bytes<SIZE>() + 32 * 1024)); /* + room for $KMC_HIP_RANK_LDS_PAD */
-		HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_bucket_rank_c<SIZE>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)br_lds_bytes<SIZE>() + 32 * 1024)); /* + room for $KMC_HIP_RANK_LDS_PAD */
-		if (SIZE == 1)
+		if (SIZE == 1) {
 			HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_bucket_rank<1, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)br_lds_bytes<1>()));
+			HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_bucket_rank_heavy<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)br_lds_bytes<1>()));
+		}
 	}
 	if (exp_lds_bytes<true>(EXP_FUSE_MAX_PASS, 1) > 65536) /* worst case: the shortest records (smallest k) and 16 fused passes */
 		HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_expand<SIZE, true>), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -295,7 +299,7 @@ int slot_init(Slot &s, u64 portion)
 
 void slot_destroy(Slot &s)
 {
-	for (DBuf *b : {&s.in, &s.pack_start, &s.recA, &s.recB, &s.recC, &s.pairA, &s.pairB, &s.zero, &s.dbase, &s.out, &s.lut, &s.sticky, &s.bounds, &s.redo_log, &s.hb_res})
+	for (DBuf *b : {&s.in, &s.pack_start, &s.recA, &s.recB, &s.recC, &s.pairA, &s.pairB, &s.zero, &s.dbase, &s.out, &s.lut, &s.sticky, &s.bounds, &s.arena_work, &s.redo_log, &s.hb_res})
 		if (b->p)
 			(void)hipFree(b->p);
 	if (s.h_res)

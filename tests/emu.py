@@ -15,7 +15,7 @@ EMU_DIR = os.path.join(ROOT, "tests", "hipemu")
 # Two builds of the same kernel source: the product's tile geometry (512-thread workgroups: hundreds of OS threads per emulated workgroup,
 # slow) and a small one (128/256-thread workgroups, 4 KB expand slices) that runs the same code paths ~10x faster. Tests use the small one
 # unless they ask for "product".
-GEOMETRY_FLAGS = {"small": ["-DCP_BLOCK_THREADS=128", "-DEXP_BLOCK_THREADS=256", "-DEXP_CHUNK_BYTES=4096", "-DRS_BLOCK_THREADS=256", "-DCP_FOLD_CHUNK=256", "-DS1_SK_TILE_N=64", "-DS1_PACK_BYTES_N=16384", "-DS1_SUB_N=2", "-DBS_BLOCK_THREADS=128", "-DBC_BLOCK_THREADS=128", "-DBR_THREADS=128", "-DGT_THREADS=256", "-DGT_MAX_RECORDS_LOG2=11"], "product": []}
+GEOMETRY_FLAGS = {"small": ["-DCP_BLOCK_THREADS=128", "-DEXP_BLOCK_THREADS=256", "-DEXP_CHUNK_BYTES=4096", "-DRS_BLOCK_THREADS=256", "-DCP_FOLD_CHUNK=256", "-DS1_SK_TILE_N=64", "-DS1_PACK_BYTES_N=16384", "-DS1_SUB_N=2", "-DBS_BLOCK_THREADS=128", "-DBC_BLOCK_THREADS=128", "-DBR_THREADS=128", "-DGT_THREADS=256", "-DGT_MAX_RECORDS_LOG2=11", "-DAR_THREADS=256", "-DBR_MID=192"], "product": []}
 _LIBS = {}
 
 
@@ -87,7 +87,7 @@ def build_hostlib(geometry="small", force=False) -> str:
     so = os.path.join(EMU_DIR, f"libkmc_hip_emu_{geometry}.so")
     csrc = os.path.join(ROOT, "kmc_amd", "csrc")
     host_parts = sorted(f for f in os.listdir(csrc) if f.startswith("host_") and f.endswith(".hip.h"))  # kmc_hip.hip's own parts (they hold kernel launches)
-    srcs = [os.path.join(csrc, f) for f in ["kmc_hip.hip", "kernels.hip.h", "bucket_sort.hip.h", "order_db.hip.h", "kmer_ops.h", "stage1_kernels.hip.h", "stage1_chain.h"] + host_parts] + [
+    srcs = [os.path.join(csrc, f) for f in ["kmc_hip.hip", "kernels.hip.h", "bucket_sort.hip.h", "arena_sort.hip.h", "order_db.hip.h", "kmer_ops.h", "stage1_kernels.hip.h", "stage1_chain.h"] + host_parts] + [
         os.path.join(ROOT, "include", "kmc_hip.h"), os.path.join(EMU_DIR, "include", "hip", "hip_runtime.h"), os.path.join(EMU_DIR, "include", "hip", "hip_host_api.h"),
         os.path.join(EMU_DIR, "include", "rccl", "rccl.h"), os.path.abspath(__file__)]
     if force or not os.path.exists(so) or any(os.path.getmtime(x) > os.path.getmtime(so) for x in srcs):
