@@ -50,17 +50,21 @@ struct ArenaWork {
 	const u64 *S0;     /* the group's ordered array (gr.S[0]) */
 };
 
-__device__ __forceinline__ u32 ar_upper_bound(const u32 *__restrict__ a, u32 n, u32 x) /* number of a[0..n) that are <= x (a ascending) */
+/* the entry that holds arena record x (off[e] <= x < off[e + 1]; off[0] = 0 <= x < off[n]): a 64-ary search, executed by ONE full wave — three round trips for 2^18
+ * entries where a binary search by one thread takes eighteen */
+__device__ __forceinline__ u32 ar_find_entry(const u32 *__restrict__ off, u32 n, u32 x, u32 lane)
 {
-	u32 lo = 0, hi = n;
-	while (lo < hi) {
-		const u32 mid = (lo + hi) >> 1;
-		if (a[mid] <= x)
-			lo = mid + 1;
-		else
-			hi = mid;
+	u32 a = 0, b = n; /* the answer is in [a, b) */
+	while (b - a > 1) {
+		const u32 step = (b - a + 63) / 64;
+		const u32 q = a + lane * step;
+		const bool le = q < b && off[q] <= x; /* true for a prefix of the lanes (lane 0: q = a) */
+		const u64 m = __ballot(le);
+		const u32 last = 63u - (u32)__clzll((long long)m);
+		a = a + last * step;
+		b = a + step < b ? a + step : b;
 	}
-	return lo;
+	return a;
 }
 
 __global__ void __launch_bounds__(AR_THREADS) k_arena_plan(const GrpRank gr, const ArenaWork aw, u32 rbits, u32 *flag)
@@ -129,6 +133,7 @@ __global__ void __launch_bounds__(AR_THREADS) k_arena_gather(const GrpRank gr, c
 {
 	KMC_DYN_LDS(u32, s_h); /* [n_pass_max][256] */
 	__shared__ u32 s_off[AR_CHUNK_ENT + 1];
+	__shared__ u64 s_gpos[AR_CHUNK_ENT + 1];
 	__shared__ u32 s_e0;
 	const u32 *dyn = gr.arena_dyn;
 	const u32 M = dyn[AR_M];
@@ -147,32 +152,40 @@ __global__ void __launch_bounds__(AR_THREADS) k_arena_gather(const GrpRank gr, c
 	const u64 rmask = rbits >= 64 ? ~0ull : ((1ull << rbits) - 1);
 	for (u32 base = blockIdx.x * (u32)AR_CHUNK; base < M; base += gridDim.x * (u32)AR_CHUNK) {
 		__syncthreads(); /* s_off / s_e0 of the chunk before; the counters' zeroes */
-		if (tid == 0)
-			s_e0 = ar_upper_bound(aw.arena_off, n_ent, base) - 1u; /* arena_off[0] = 0 <= base */
+		if (wave == 0) {
+			const u32 e = ar_find_entry(aw.arena_off, n_ent, base, lane);
+			if (lane == 0)
+				s_e0 = e;
+		}
 		__syncthreads();
 		const u32 e0 = s_e0;
-		if (tid <= (u32)AR_CHUNK_ENT)
+		if (tid <= (u32)AR_CHUNK_ENT) {
 			s_off[tid] = e0 + tid <= n_ent ? aw.arena_off[e0 + tid] : 0xFFFFFFFFu; /* arena_off[n_ent] = M */
+			s_gpos[tid] = e0 + tid < n_ent ? gr.arena_ent[e0 + tid].w0 & ((1ull << 40) - 1) : 0ull;
+		}
 		__syncthreads();
-#pragma unroll 1
-		for (int r = 0; r < AR_ITEMS; ++r) {
+		u64 v[AR_ITEMS];
+#pragma unroll
+		for (int r = 0; r < AR_ITEMS; ++r) { /* every row's load is under way before the first one is waited for */
 			const u32 i = base + wave * (AR_ITEMS * 64) + r * 64 + lane;
-			const bool valid = i < M;
-			u64 v = 0;
-			if (valid) {
+			v[r] = 0;
+			if (i < M) {
 				u32 j = 0; /* the chunk's entry that holds record i: a row of 64 lies inside one entry nearly always */
 				while (s_off[j + 1] <= i)
 					++j;
-				const u32 e = e0 + j;
-				const u64 gpos = gr.arena_ent[e].w0 & ((1ull << 40) - 1);
-				v = ((u64)e << rbits) | (aw.S0[gpos + (i - s_off[j])] & rmask);
-				if (rbits >= 64)
-					v = aw.S0[gpos + (i - s_off[j])];
-				aw.A[i] = v;
+				const u64 x = aw.S0[s_gpos[j] + (i - s_off[j])];
+				v[r] = rbits >= 64 ? x : (((u64)(e0 + j) << rbits) | (x & rmask));
 			}
+		}
+#pragma unroll
+		for (int r = 0; r < AR_ITEMS; ++r) {
+			const u32 i = base + wave * (AR_ITEMS * 64) + r * 64 + lane;
+			const bool valid = i < M;
+			if (valid)
+				aw.A[i] = v[r];
 			const u64 act = __ballot(valid);
 			for (u32 b = 0; b < n_pass; ++b) { /* as k_hist: a wave whose lanes hold one digit value — the copies of one k-mer — adds once */
-				const u32 d = (u32)(v >> (8 * b)) & 0xFFu;
+				const u32 d = (u32)(v[r] >> (8 * b)) & 0xFFu;
 				const u32 d0 = (u32)__builtin_amdgcn_readfirstlane((int)d);
 				if (act && __ballot(valid && d == d0) == act) {
 					if (lane == (u32)__ffsll((long long)act) - 1u)
@@ -190,16 +203,17 @@ __global__ void __launch_bounds__(AR_THREADS) k_arena_gather(const GrpRank gr, c
 	}
 }
 
-/* grid: persistent workgroups over the work items (dyn[AR_ITEM_TICKET]) */
+/* grid: workgroup b of G takes the work items that START in its share [M b / G, M (b + 1) / G) of the arena (items are 385 .. ~11 000 records: shares of equal length
+ * are shares of equal work, and nothing is drawn from a counter: a ticket + a binary search by one thread per item were 12 us of latency in front of ~3 us of work). */
 __global__ void __launch_bounds__(AR_THREADS) k_arena_finish(const GrpRank gr, const ArenaWork aw, DevParams P, u32 rbits, u32 lut_shards, u64 lut_stride, u32 lut_mask, u32 *err)
 {
 	constexpr int THREADS = AR_THREADS, ITEMS = AR_ITEMS, NW = AR_NW, CHUNK = AR_CHUNK;
 	constexpr u32 NONE = 0xFFFFFFFFu;
-	__shared__ u32 s_item, s_ent, s_prev;
+	__shared__ u32 s_ent, s_prev;
 	__shared__ u32 s_wlast[NW], s_wcnt[NW], s_tal[NW * 3];
 	u32 *dyn = gr.arena_dyn;
-	const u32 n_items = dyn[AR_N_ITEMS];
-	if (n_items == 0)
+	const u32 M = dyn[AR_M];
+	if (M == 0)
 		return;
 	const u32 n_ent = dyn[AR_N_ENT];
 	const u64 *__restrict__ src = (dyn[AR_N_PASS] & 1u) ? aw.B : aw.A;
@@ -211,27 +225,45 @@ __global__ void __launch_bounds__(AR_THREADS) k_arena_finish(const GrpRank gr, c
 	const u32 pshift = 2 * (P.k - P.lut_prefix_len);
 	const u64 kmask = 2 * P.k < 64 ? ((1ull << (2 * P.k)) - 1) : ~0ull; /* drops a group tag above the k-mer */
 	const u64 lane_lt = (1ull << lane) - 1;
-	while (true) {
-		__syncthreads();
-		if (tid == 0) {
-			const u32 it = atomicAdd(&dyn[AR_ITEM_TICKET], 1u);
-			s_item = it;
-			s_ent = it < n_items ? ar_upper_bound(aw.item_off, n_ent, it) - 1u : 0u;
-		}
-		__syncthreads();
-		const u32 item = s_item;
-		if (item >= n_items)
+	/* the LUT prefix of a k-mer lies in the key bits above rbits whenever 2 (k - p) >= rbits: every k-mer of a bucket has the same one, and a segment adds its counted k-mers
+	 * to it ONCE (one add per counted k-mer on one address — same-address device atomics take ~11 ns each — was most of this kernel's time on repeat-rich input) */
+	const bool lut_once = pshift >= rbits;
+	const u32 lo = (u32)((u64)M * blockIdx.x / gridDim.x), hi = (u32)((u64)M * (blockIdx.x + 1) / gridDim.x);
+	if (lo >= hi)
+		return;
+	if (wave == 0) { /* the entry that holds arena record `lo` */
+		const u32 a = ar_find_entry(aw.arena_off, n_ent, lo, lane);
+		if (lane == 0)
+			s_ent = a;
+	}
+	__syncthreads();
+	for (u32 e = s_ent; e < n_ent; ++e) {
+		const u32 off = aw.arena_off[e];
+		if (off >= hi)
 			break;
-		const u32 e = s_ent;
+		const u32 e_items = aw.item_off[e + 1] - aw.item_off[e], e_len = gr.arena_ent[e].len;
+		/* the entry's segments: segment s starts at off + e_len s / e_items */
+		u32 seg = 0;
+		if (off < lo) { /* the first segment that starts at or behind lo */
+			seg = (u32)((((u64)(lo - off)) * e_items + e_len - 1) / e_len);
+			while (seg > 0 && off + (u32)((u64)e_len * (seg - 1) / e_items) >= lo)
+				--seg;
+			while (seg < e_items && off + (u32)((u64)e_len * seg / e_items) < lo)
+				++seg;
+		}
+		for (; seg < e_items; ++seg) {
+			if (off + (u32)((u64)e_len * seg / e_items) >= hi)
+				break;
+			__syncthreads(); /* the LDS words of the item before */
 		const ArenaEntry en = gr.arena_ent[e];
 		const u64 gpos = en.w0 & ((1ull << 40) - 1);
 		const u32 len = en.len;
-		const u64 *__restrict__ B = src + aw.arena_off[e]; /* the bucket, in order */
-		const u64 hi = rbits < 64 ? aw.bucket_hi[e] << rbits : 0ull;
+		const u64 *__restrict__ B = src + off; /* the bucket, in order */
+		const u64 khi = rbits < 64 ? aw.bucket_hi[e] << rbits : 0ull; /* the key bits above rbits */
 		if ((en.w0 >> 44) & 1ull) { /* back to where it came from, in order; k_bucket_rank_heavy takes the tile from there */
 			u64 *dst = const_cast<u64 *>(aw.S0) + gpos;
 			for (u32 i = tid; i < len; i += THREADS)
-				dst[i] = hi | (B[i] & rmask);
+				dst[i] = khi | (B[i] & rmask);
 			if (tid == 0) {
 				atomicAdd(&dyn[AR_STAT_MID_N], 1u);
 				atomicAdd(reinterpret_cast<u64 *>(dyn + AR_STAT_MID_REC), (u64)len);
@@ -241,7 +273,7 @@ __global__ void __launch_bounds__(AR_THREADS) k_arena_finish(const GrpRank gr, c
 		/* ---- a segment of a giant bucket: run lengths, cutoffs, records (kb_sorter.h:1128-1281), chunk by chunk, into the segment's own output slot */
 		const u32 bin = (u32)(en.w0 >> 40) & 15u;
 		const u32 w = en.gtile - gr.win_prefix[bin];
-		const u32 seg = item - aw.item_off[e], nseg = aw.item_off[e + 1] - aw.item_off[e];
+		const u32 nseg = e_items;
 		const u32 s0 = (u32)((u64)len * seg / nseg), s1 = (u32)((u64)len * (seg + 1) / nseg);
 		const u32 slot_id = seg == 0 ? 2 * w + 1 : 2 * (w + 1) + (seg - 1);
 		const u64 pos = gpos - (u64)(gr.S[bin] - gr.S[0]); /* bin-relative */
@@ -327,9 +359,9 @@ __global__ void __launch_bounds__(AR_THREADS) k_arena_finish(const GrpRank gr, c
 #pragma unroll
 				for (int r = 0; r < ITEMS; ++r) {
 					if (rk[r] != NONE) {
-						const u64 kx[1] = {(hi | (key[r] & rmask)) & kmask};
+						const u64 kx[1] = {(khi | (key[r] & rmask)) & kmask};
 						kmc_emit_record<1>(span + (size_t)(counted_total + wave_off + rk[r]) * rec_bytes, kx, cnt[r], P.sbytes, P.cbytes, P.kff != 0);
-						if (use_lut)
+						if (use_lut && !lut_once)
 							atomicAdd(&lut[(u32)kmc_remove_suffix<1>(kx, pshift) & lut_mask], 1ull);
 					}
 				}
@@ -363,13 +395,18 @@ __global__ void __launch_bounds__(AR_THREADS) k_arena_finish(const GrpRank gr, c
 			if (!P.without_output && counted_total) {
 				gr.status[bin][slot_id] = counted_total;
 				gr.chunk_src[bin][slot_id] = pos + s0;
+				if (use_lut && lut_once) {
+					const u64 kx[1] = {khi & kmask};
+					atomicAdd(&lut[(u32)kmc_remove_suffix<1>(kx, pshift) & lut_mask], (u64)counted_total);
+				}
 			}
 			if (seg == 0) { /* statistics: the buckets and records that took this road (the stream's error block, as k_giant_tiles) */
 				atomicAdd(&err[12], 1u);
 				atomicAdd(reinterpret_cast<u64 *>(err + 14), (u64)len);
 			}
 		}
-	}
+		} /* segments */
+	} /* entries */
 }
 
 #endif

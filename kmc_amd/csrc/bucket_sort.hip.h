@@ -474,7 +474,7 @@ struct ArenaEntry {
 constexpr u32 AR_N_ENT = 0, AR_M = 1, AR_N_PASS = 2, AR_N_ITEMS = 3, AR_ITEM_TICKET = 4, AR_OVERFLOW = 5, AR_N_HEAVY = 6, AR_HEAVY_TICKET = 7, AR_PASS_TICKET = 8 /* .. 15 */,
               AR_STAT_MID_N = 20, AR_STAT_MID_REC = 22 /* u64: words 22-23 */, AR_DYN_WORDS = 32;
 #ifndef BR_MID
-#define BR_MID 384 /* one-word records: a bucket beyond this many records is not ranked pairwise at all (the work grows with its square: 0.07 ps x n^2 against ~30 ps x n of
+#define BR_MID 768 /* one-word records: a bucket beyond this many records is not ranked pairwise at all (the work grows with its square: 0.07 ps x n^2 against ~30 ps x n of
                     * arena passes) — it goes through the arena and comes back in order */
 #endif
 static_assert(BR_MID >= BR_BIG, "buckets the arena takes are a subset of the big ones");
@@ -518,7 +518,10 @@ __device__ __forceinline__ void br_tile(const GrpRank &gr, const DevParams &P, c
 	const u64 b0 = bounds[tile], b1 = bounds[tile + 1];
 	if (b0 >= ((u64)tile + 1) * S || b0 >= b1)
 		return; /* no bucket starts in this window */
-	const u32 tid = threadIdx.x, lane = tid & 63;
+	u32 tid_ = threadIdx.x;
+	if constexpr (HEAVY)
+		KMC_LAUNDER(tid_); /* the persistent loop around this tile: what derives from the thread's number must not be hoisted out of it (119 VGPRs, one workgroup per CU) */
+	const u32 tid = tid_, lane = tid & 63;
 	const u32 wave = (u32)__builtin_amdgcn_readfirstlane((int)(tid >> 6));
 	const u32 crel = wave * (ITEMS * 64); /* the wave owns ITEMS rows of 64 consecutive records */
 	if (tid == 0)
@@ -1255,8 +1258,10 @@ __global__ void __launch_bounds__(BrCfg<SIZE>::THREADS, BR_MIN_WAVES) k_bucket_r
  * take them one by one. Nothing listed: a launch that returns. */
 template <int SIZE>
 __global__ void __launch_bounds__(BrCfg<SIZE>::THREADS, BR_MIN_WAVES / 2) k_bucket_rank_heavy(const GrpRank gr, DevParams P, u32 key_bits, u32 hbits, u32 lut_shards, u64 lut_stride,
-                                                                                        u32 lut_mask, u32 *flag)
+                                                                                            u32 lut_mask, u32 *flag)
 {
+	/* (107 VGPRs with the loop around the tile: one workgroup per CU. A real call of the tile body — 80 VGPRs, two workgroups — was slower: 1.25 against 0.83 ms per group of
+	 * the spectrum leg, the descriptor read from device memory and 5 registers spilled; profiles/r06/experiments.md) */
 	KMC_DYN_LDS(unsigned char, s_raw);
 	__shared__ u32 s_pick;
 	const u32 n = ld_agent(&gr.arena_dyn[AR_N_HEAVY]); /* final: k_bucket_rank and k_arena_plan ran before this kernel on the stream */
