@@ -33,6 +33,9 @@
 #define AR_THREADS 1024
 #endif
 constexpr int AR_ITEMS = 8, AR_CHUNK = AR_THREADS * AR_ITEMS, AR_NW = AR_THREADS / 64;
+#ifndef AF_THREADS
+#define AF_THREADS 256 /* k_arena_finish: its items are a few hundred to ~11 000 records — small workgroups, many of them in flight (1024 threads: 0.70 ms per group of the spectrum leg) */
+#endif
 constexpr u32 AR_MAX_PASS = 8;
 constexpr u64 AR_MAX_RECORDS = 1ull << 29;             /* one portion of k_onesweep (30-bit look-back counts) */
 constexpr int AR_CHUNK_ENT = AR_CHUNK / BR_MID + 3;    /* entries a chunk of the arena can touch: every entry has more than BR_MID records */
@@ -67,6 +70,111 @@ __device__ __forceinline__ u32 ar_find_entry(const u32 *__restrict__ off, u32 n,
 	return a;
 }
 
+/* first i in (lo, hi] with pred(i), for a predicate that is false up to some index and true from there on, given pred(hi) (hi may be a virtual end): 64-ary, executed by ONE
+ * full wave. Indices are modulo 2^64: lo = -1 stands for "nothing in front of index 0". */
+template <typename Pred> __device__ __forceinline__ u64 bd_first(u64 lo, u64 hi, u32 lane, Pred pred)
+{
+	while (hi - lo > 1) {
+		const u64 span = hi - lo - 1; /* candidates lo + 1 .. hi - 1 */
+		const u64 stp = (span + 63) / 64;
+		const u64 t = lo + 1 + (u64)lane * stp;
+		const bool in = t - lo - 1 < span; /* (modular: t < hi) */
+		const bool pr = in && pred(t);
+		const u64 m = __ballot(pr), inm = __ballot(in);
+		if (m) {
+			const u32 f = (u32)__ffsll((long long)m) - 1u;
+			hi = lo + 1 + (u64)f * stp;
+			if (f)
+				lo = hi - stp;
+			else
+				break; /* lo + 1 itself */
+		} else
+			lo = lo + 1 + (u64)((u32)__popcll(inm) - 1u) * stp;
+	}
+	return hi;
+}
+
+struct GrpDetect {
+	u32 g, blk_prefix[GRP_MAX + 1]; /* blocks of 64 BD_STRIDE records of bin b */
+	u64 n[GRP_MAX];
+};
+/* The buckets beyond BR_MID records of a group, found without reading it: one wave per block of 64 x BD_STRIDE records looks at every BD_STRIDE-th record (a 64-byte
+ * sector each: 1/88 of the array's sectors). Two neighbouring samples with the same bucket number are a bucket of BD_STRIDE + 1 records at least, and a bucket of
+ * 2 BD_STRIDE records cannot lie between the samples: every bucket beyond BR_MID >= 2 BD_STRIDE - 1 records shows. The wave that holds the FIRST sample of such a run finds the
+ * bucket's first record (behind the sample in front of it: one or two rounds) and its end (the probes' distance grows by 64 x per round, then narrows by 64 x per round: a satellite of
+ * millions of records costs a dozen round trips) and lists it when it is longer than BR_MID: kind 1 up to a tile's capacity, kind 0 (giant) beyond. Replaces the listing by
+ * k_bucket_rank's workgroups and their second visit (round 6, first version: the tiles with such a bucket were read and their bucket starts found twice). */
+__global__ void __launch_bounds__(256) k_bucket_detect(const GrpRank gr, const GrpDetect gd, u32 rbits)
+{
+	constexpr u64 DS = BD_STRIDE, S = BrCfg<1>::STRIDE;
+	const u32 lane = threadIdx.x & 63;
+	const u32 item = blockIdx.x * 4 + (threadIdx.x >> 6);
+	if (item >= gd.blk_prefix[gd.g])
+		return;
+	const u32 bin = (u32)__builtin_amdgcn_readfirstlane((int)grp_find(gd.blk_prefix, gd.g, item));
+	const u64 *__restrict__ recs = gr.S[bin];
+	const u64 n = gd.n[bin];
+	const u64 p0 = (u64)(item - gd.blk_prefix[bin]) * (64 * DS);
+	auto bucket_at = [&](u64 i) -> u64 { return recs[i] >> rbits; };
+	const u64 pos = p0 + (u64)lane * DS;
+	const bool valid = pos < n;
+	/* the block's 64 samples, the one in front of them (lane 0) and the one behind them (lane 63): three loads under way together */
+	const bool edge_p = lane == 0 && valid && pos >= DS, edge_n = lane == 63 && pos + DS < n;
+	const u64 x = recs[valid ? pos : 0], xe = recs[edge_p ? pos - DS : (edge_n ? pos + DS : 0)];
+	const u64 bk = valid ? x >> rbits : 0ull;
+	u64 pb = __shfl_up(bk, 1), nb = __shfl_down(bk, 1);
+	bool pvalid = true, nvalid = (bool)__shfl_down((int)valid, 1);
+	if (lane == 0) {
+		pvalid = edge_p;
+		pb = xe >> rbits;
+	}
+	if (lane == 63) {
+		nvalid = edge_n;
+		nb = xe >> rbits;
+	}
+	const bool same_prev = valid && pvalid && pb == bk, same_next = valid && nvalid && nb == bk;
+	u64 starts = __ballot(same_next && !same_prev);
+	while (starts) { /* wave-uniform */
+		const u32 l = (u32)__ffsll((long long)starts) - 1u;
+		starts &= starts - 1;
+		const u64 b = __shfl(bk, (int)l);
+		const u64 q = p0 + (u64)l * DS;
+		/* the sample at q - DS (if there is one) lies in another bucket, the one at q + DS in this one */
+		const u64 first = bd_first(q - DS, q, lane, [&](u64 i) { return (long long)i >= 0 && bucket_at(i) == b; });
+		u64 lo = q + DS, hi, step = DS;
+		while (true) { /* outwards */
+			const u64 t = lo + (u64)(lane + 1) * step;
+			const bool diff = t >= n || t < lo || bucket_at(t) != b;
+			const u64 m = __ballot(diff);
+			if (m) {
+				const u32 f = (u32)__ffsll((long long)m) - 1u;
+				hi = lo + (u64)(f + 1) * step;
+				if (hi > n || hi < lo)
+					hi = n;
+				lo = lo + (u64)f * step;
+				break;
+			}
+			lo += 64 * step;
+			if (step < (1ull << 40))
+				step *= 64;
+		}
+		const u64 end = bd_first(lo, hi, lane, [&](u64 i) { return i >= n || bucket_at(i) != b; });
+		const u64 len = end - first;
+		if (lane == 0 && len > (u64)BR_MID) {
+			if (len >= (1ull << 32))
+				atomicOr(&gr.arena_dyn[AR_OVERFLOW], 1u);
+			else {
+				const u32 e = atomicAdd(&gr.arena_dyn[AR_N_ENT], 1u);
+				if (e < gr.arena_cap)
+					gr.arena_ent[e] = ArenaEntry{((u64)(recs - gr.S[0]) + first) | ((u64)bin << 40) | (len > (u64)BrCfg<1>::CAP ? 0ull : 1ull << 44), (u32)len,
+					                             gr.win_prefix[bin] + (u32)(first / S)};
+				else
+					atomicOr(&gr.arena_dyn[AR_OVERFLOW], 1u);
+			}
+		}
+	}
+}
+
 __global__ void __launch_bounds__(AR_THREADS) k_arena_plan(const GrpRank gr, const ArenaWork aw, u32 rbits, u32 *flag)
 {
 	constexpr u64 S = BrCfg<1>::STRIDE;
@@ -75,7 +183,7 @@ __global__ void __launch_bounds__(AR_THREADS) k_arena_plan(const GrpRank gr, con
 	u32 *dyn = gr.arena_dyn;
 	const u32 tid = threadIdx.x;
 	const u32 listed = dyn[AR_N_ENT];
-	const bool overflow = dyn[AR_OVERFLOW] != 0 || listed > gr.arena_cap || dyn[AR_N_HEAVY] > gr.heavy_cap;
+	const bool overflow = dyn[AR_OVERFLOW] != 0 || listed > gr.arena_cap;
 	if (listed == 0 && !overflow)
 		return; /* the usual case: every dyn word stays zero, every later launch returns */
 	const u32 obits = listed > 1 ? 32u - (u32)__clz((int)(listed - 1)) : 0u;
@@ -115,8 +223,9 @@ __global__ void __launch_bounds__(AR_THREADS) k_arena_plan(const GrpRank gr, con
 			bail = true;
 	}
 	if (tid == 0) {
-		if (bail) { /* nothing of the listed work may run: the chunks k_bucket_rank left for later stay unreported, the group comes back (LSD passes over every byte) */
-			dyn[AR_M] = dyn[AR_N_PASS] = dyn[AR_N_ITEMS] = dyn[AR_N_HEAVY] = 0;
+		if (bail) { /* nothing of the listed work may run and k_bucket_rank reports nothing either: the group comes back (LSD passes over every byte) */
+			dyn[AR_M] = dyn[AR_N_PASS] = dyn[AR_N_ITEMS] = 0;
+			dyn[AR_OVERFLOW] = 2; /* k_bucket_rank: no bucket of this group has been put in order — leave every tile alone */
 			atomicOr(flag, 1u);
 		} else {
 			aw.arena_off[listed] = (u32)m_run;
@@ -205,9 +314,9 @@ __global__ void __launch_bounds__(AR_THREADS) k_arena_gather(const GrpRank gr, c
 
 /* grid: workgroup b of G takes the work items that START in its share [M b / G, M (b + 1) / G) of the arena (items are 385 .. ~11 000 records: shares of equal length
  * are shares of equal work, and nothing is drawn from a counter: a ticket + a binary search by one thread per item were 12 us of latency in front of ~3 us of work). */
-__global__ void __launch_bounds__(AR_THREADS) k_arena_finish(const GrpRank gr, const ArenaWork aw, DevParams P, u32 rbits, u32 lut_shards, u64 lut_stride, u32 lut_mask, u32 *err)
+__global__ void __launch_bounds__(AF_THREADS) k_arena_finish(const GrpRank gr, const ArenaWork aw, DevParams P, u32 rbits, u32 lut_shards, u64 lut_stride, u32 lut_mask, u32 *err)
 {
-	constexpr int THREADS = AR_THREADS, ITEMS = AR_ITEMS, NW = AR_NW, CHUNK = AR_CHUNK;
+	constexpr int THREADS = AF_THREADS, ITEMS = AR_ITEMS, NW = AF_THREADS / 64, CHUNK = AF_THREADS * AR_ITEMS;
 	constexpr u32 NONE = 0xFFFFFFFFu;
 	__shared__ u32 s_ent, s_prev;
 	__shared__ u32 s_wlast[NW], s_wcnt[NW], s_tal[NW * 3];

@@ -461,23 +461,28 @@ struct GrpRank {
 	u32 *arena_dyn;             /* AR_* words (zeroed by the host) */
 	struct ArenaEntry *arena_ent; /* [arena_cap] the listed buckets */
 	u32 arena_cap;
-	u32 *heavy;                 /* [heavy_cap] chunks (gtile << 1 | chunk) whose buckets beyond BR_MID records went to the arena: ranked and counted by k_bucket_rank_heavy once those are back in order */
-	u32 heavy_cap;
 };
 /* A bucket the arena sorts. kind 0: a GIANT bucket (beyond a tile's capacity, any length): sorted and counted from the arena, segment by segment, into the output slots of the
- * windows it covers. kind 1: a bucket of BR_MID < records <= capacity inside a tile: sorted in the arena, written back in place; its tile is ranked afterwards. */
+ * windows it covers. kind 1: a bucket of BR_MID < records <= capacity inside a tile: sorted in the arena, written back in place BEFORE its tile is ranked. */
 struct ArenaEntry {
 	u64 w0;    /* [39:0] first record (its index in the group's ordered array: gr.S[0] + ...), [43:40] the bin's number in the group, [44] kind */
 	u32 len;   /* records */
 	u32 gtile; /* kind 0: the tile (group-wide number) the bucket starts in */
 };
-constexpr u32 AR_N_ENT = 0, AR_M = 1, AR_N_PASS = 2, AR_N_ITEMS = 3, AR_ITEM_TICKET = 4, AR_OVERFLOW = 5, AR_N_HEAVY = 6, AR_HEAVY_TICKET = 7, AR_PASS_TICKET = 8 /* .. 15 */,
+constexpr u32 AR_N_ENT = 0, AR_M = 1, AR_N_PASS = 2, AR_N_ITEMS = 3, AR_OVERFLOW = 5, AR_PASS_TICKET = 8 /* .. 15 */,
               AR_STAT_MID_N = 20, AR_STAT_MID_REC = 22 /* u64: words 22-23 */, AR_DYN_WORDS = 32;
 #ifndef BR_MID
-#define BR_MID 768 /* one-word records: a bucket beyond this many records is not ranked pairwise at all (the work grows with its square: 0.07 ps x n^2 against ~30 ps x n of
+#define BR_MID 351 /* one-word records: a bucket beyond this many records is not ranked pairwise at all (the work grows with its square: 0.07 ps x n^2 against ~40 ps x n of
                     * arena passes) — it goes through the arena and comes back in order */
 #endif
+#ifndef BD_STRIDE_N
+#define BD_STRIDE_N 176
+#endif
+constexpr u32 BD_STRIDE = BD_STRIDE_N; /* k_bucket_detect looks at every 176th record: two neighbouring samples with one bucket number = a bucket of 177+ records; a bucket of 2 x 176
+                               * records and more cannot hide between the samples. Every sample is a 64-byte sector of its own: stride 88 (BR_MID 255) cost 83 us per group of 190 M
+                               * records with nothing to find, and the spectrum leg ran no faster for it (23.8 against 24.0 Gk-mers/s with BR_MID 383) */
 static_assert(BR_MID >= BR_BIG, "buckets the arena takes are a subset of the big ones");
+static_assert(BR_MID + 1 >= 2 * BD_STRIDE, "every bucket beyond BR_MID records must show in two neighbouring samples");
 /* A tile whose LARGEST BUCKET does not fit the capacity — one k-mer repeated thousands of times: every genome has those — is not ranked pairwise (the work
  * grows with the square of a bucket) and, since round 4, no longer sends its whole group back to the host either: k_bucket_rank puts it on a list and
  * k_giant_tiles sorts it on its own (below). Only a tile beyond GT_MAX_RECORDS still raises the group's flag (-> the host's LSD passes). */
@@ -490,16 +495,15 @@ static_assert(BR_MID >= BR_BIG, "buckets the arena takes are a subset of the big
 constexpr u64 GT_MAX_RECORDS = 1ull << GT_MAX_RECORDS_LOG2;
 constexpr u32 GT_CUT_SHIFT = 19; /* a list entry of k_giant_tiles: [18:0] the tile's number in the group, [31:19] the records in front of the giant part (< 8192) */
 
-/* chunk `by` (0, 1) of tile `gtile`. HEAVY (one-word records): the second visit of a chunk whose buckets beyond BR_MID records have been through the arena — they are in
- * order where they lie and keep their places; everything else as on the first visit, which listed them and returned. */
-template <int SIZE, bool FUSED, bool HEAVY>
+/* chunk `by` (0, 1) of tile `gtile`. With the arena (one-word records, fused): the buckets beyond BR_MID records have been found (k_bucket_detect), sorted by the arena's passes
+ * and written back BEFORE this kernel runs — they are in order where they lie and keep their places; giant buckets are counted from the arena and only cut off here. */
+template <int SIZE, bool FUSED>
 __device__ __forceinline__ void br_tile(const GrpRank &gr, const DevParams &P, const u32 key_bits, const u32 hbits, const u32 lut_shards, const u64 lut_stride, const u32 lut_mask,
                                         u32 *flag, const u32 gtile, const u32 by, unsigned char *s_raw)
 {
 	constexpr int THREADS = BrCfg<SIZE>::THREADS, ITEMS = BrCfg<SIZE>::ITEMS, CAP = BrCfg<SIZE>::CAP, NW = BrCfg<SIZE>::NW;
 	constexpr u64 S = BrCfg<SIZE>::STRIDE;
 	constexpr u32 NONE = 0xFFFFFFFFu;
-	static_assert(!HEAVY || (SIZE == 1 && FUSED), "the arena takes one-word records of fused groups");
 	const bool arena = SIZE == 1 && FUSED && gr.arena_dyn != nullptr;
 	u64 *s_key = reinterpret_cast<u64 *>(s_raw);                              /* R0 */
 	u32 *s_start = reinterpret_cast<u32 *>(s_raw + BrCfg<SIZE>::R0);          /* R1 [CAP + 2] */
@@ -518,10 +522,9 @@ __device__ __forceinline__ void br_tile(const GrpRank &gr, const DevParams &P, c
 	const u64 b0 = bounds[tile], b1 = bounds[tile + 1];
 	if (b0 >= ((u64)tile + 1) * S || b0 >= b1)
 		return; /* no bucket starts in this window */
-	u32 tid_ = threadIdx.x;
-	if constexpr (HEAVY)
-		KMC_LAUNDER(tid_); /* the persistent loop around this tile: what derives from the thread's number must not be hoisted out of it (119 VGPRs, one workgroup per CU) */
-	const u32 tid = tid_, lane = tid & 63;
+	if (arena && gr.arena_dyn[AR_OVERFLOW])
+		return; /* the arena's plan was dropped (k_arena_plan: the group's flag is up): the buckets beyond BR_MID records are NOT in order — nothing may be reported */
+	const u32 tid = threadIdx.x, lane = tid & 63;
 	const u32 wave = (u32)__builtin_amdgcn_readfirstlane((int)(tid >> 6));
 	const u32 crel = wave * (ITEMS * 64); /* the wave owns ITEMS rows of 64 consecutive records */
 	if (tid == 0)
@@ -560,18 +563,12 @@ __device__ __forceinline__ void br_tile(const GrpRank &gr, const DevParams &P, c
 			 * bucket longer than the capacity has — goes to k_giant_tiles (list entry: tile | cut << GT_CUT_SHIFT; it reports into the tile's second slot); the
 			 * buckets in front of it are an ordinary first chunk and stay here. k_giant_tiles then sorts ONE bucket: only the bits below the bucket bits (three
 			 * passes at k = 27 instead of six over the whole tile's key range). Not fused, or beyond GT_MAX_RECORDS: the host's LSD passes, as ever. */
-			/* Round 6, one-word records: the giant bucket — of ANY length — becomes an entry of the group's arena (arena_sort.hip.h: sorted by HBM passes over all the
-			 * listed buckets at once, counted segment by segment by the whole GPU); no bin comes back for a satellite any more. */
+			/* Round 6, one-word records with the arena: the giant bucket — of ANY length — is an entry of the group's arena already (k_bucket_detect listed it; sorted by HBM
+			 * passes over all the listed buckets at once, counted segment by segment by the whole GPU: arena_sort.hip.h); no bin comes back for a satellite any more. */
 			const u64 glen = (b1 - b0) - cut;
-			const bool listed = FUSED && (arena ? glen < (1ull << 32) : (gr.giant && glen <= GT_MAX_RECORDS));
-			if (tid == 0 && by == 0 && !HEAVY) { /* (the second visit of the chunk in front of it must not list it again) */
-				if (listed && arena) {
-					const u32 e = atomicAdd(&gr.arena_dyn[AR_N_ENT], 1u);
-					if (e < gr.arena_cap)
-						gr.arena_ent[e] = ArenaEntry{((u64)(recs - gr.S[0]) + b0 + cut) | ((u64)bin << 40), (u32)glen, gtile};
-					else
-						atomicOr(&gr.arena_dyn[AR_OVERFLOW], 1u);
-				} else if (listed)
+			const bool listed = FUSED && (arena || (gr.giant && glen <= GT_MAX_RECORDS));
+			if (tid == 0 && by == 0 && !arena) {
+				if (listed)
 					gr.giant[2 + atomicAdd(&gr.giant[0], 1u)] = gtile | (cut << GT_CUT_SHIFT);
 				else
 					atomicOr(flag, FUSED ? 0x10000u << bin : 1u); /* fused: only this BIN comes back (bits 16 + its number in the group); in place: the group */
@@ -667,9 +664,13 @@ __device__ __forceinline__ void br_tile(const GrpRank &gr, const DevParams &P, c
 		if (idx < len) {
 			const u32 ord = wave_heads_before + below[r] + ((headbits >> r) & 1u) - 1u;
 			const u32 bstart = s_start[ord], bend = s_start[ord + 1];
-			span[r] = bstart | (bend << 16);
-			rel[r] = idx - bstart;
-			if (!(HEAVY && bend - bstart > (u32)BR_MID)) { /* HEAVY: a bucket the arena has put in order is not walked (and does not count for the width of the pairs) */
+			if (arena && bend - bstart > (u32)BR_MID) {
+				/* a bucket the arena has put in order (k_bucket_detect, arena_sort.hip.h): the record lies where it belongs. An empty span at its own position: nothing is
+				 * walked, place = position; the bucket does not count for the width of the pairs either */
+				span[r] = idx | (idx << 16);
+			} else {
+				span[r] = bstart | (bend << 16);
+				rel[r] = idx - bstart;
 				widest = widest > bend - bstart ? widest : bend - bstart;
 				if (bend - bstart > (u32)BR_BIG)
 					any_big = true;
@@ -689,8 +690,7 @@ __device__ __forceinline__ void br_tile(const GrpRank &gr, const DevParams &P, c
 	 * after the barrier behind the pair stores. */
 	u32 place[ITEMS];
 	u32 *s_rank = s_start;
-	auto in_order = [&](int r) -> bool { return HEAVY && (span[r] >> 16) - (span[r] & 0xFFFFu) > (u32)BR_MID; }; /* back from the arena: the record's place is where it lies */
-	auto is_big = [&](int r) -> bool { return (span[r] >> 16) - (span[r] & 0xFFFFu) > (u32)BR_BIG && !in_order(r); };
+	auto is_big = [&](int r) -> bool { return (span[r] >> 16) - (span[r] & 0xFFFFu) > (u32)BR_BIG; };
 	auto rank_big_buckets = [&](auto count) {
 		if (!*s_nbig) /* uniform */
 			return;
@@ -732,32 +732,6 @@ __device__ __forceinline__ void br_tile(const GrpRank &gr, const DevParams &P, c
 #pragma unroll
 		for (int w = 0; w < NW; ++w)
 			widest = widest > s_wmax[w] ? widest : s_wmax[w];
-		if constexpr (FUSED && !HEAVY) {
-			/* Round 6: a chunk with a bucket beyond BR_MID records is not finished here. Every such bucket is listed for the arena (its first record's thread speaks for
-			 * it; at most CAP / BR_MID per chunk), the chunk is listed for k_bucket_rank_heavy, and this workgroup is done: what pairwise ranking costs grows with the
-			 * square of a bucket, what the arena's passes cost does not depend on the shape of the input at all. */
-			if (arena && widest > (u32)BR_MID) { /* uniform */
-#pragma unroll
-				for (int r = 0; r < ITEMS; ++r) {
-					const u32 bstart = span[r] & 0xFFFFu, bend = span[r] >> 16;
-					if (((headbits >> r) & 1u) && bend - bstart > (u32)BR_MID) {
-						const u32 e = atomicAdd(&gr.arena_dyn[AR_N_ENT], 1u);
-						if (e < gr.arena_cap)
-							gr.arena_ent[e] = ArenaEntry{((u64)(recs - gr.S[0]) + c0 + bstart) | ((u64)bin << 40) | (1ull << 44), bend - bstart, gtile};
-						else
-							atomicOr(&gr.arena_dyn[AR_OVERFLOW], 1u);
-					}
-				}
-				if (tid == 0) {
-					const u32 h = atomicAdd(&gr.arena_dyn[AR_N_HEAVY], 1u);
-					if (h < gr.heavy_cap)
-						gr.heavy[h] = (gtile << 1) | by;
-					else
-						atomicOr(&gr.arena_dyn[AR_OVERFLOW], 1u);
-				}
-				return;
-			}
-		}
 		const bool narrow = rbits < 32 && widest <= (1u << (32 - rbits));
 		if (narrow) {
 			u32 *s_k32 = reinterpret_cast<u32 *>(s_key);
@@ -811,9 +785,7 @@ __device__ __forceinline__ void br_tile(const GrpRank &gr, const DevParams &P, c
 #pragma unroll
 			for (int r = 0; r < ITEMS; ++r) {
 				const u32 bstart = span[r] & 0xFFFFu, bend = span[r] >> 16;
-				place[r] = bstart + walk32(is_big(r) || in_order(r) ? bend /* ranked by the whole workgroup below / in order already */ : bstart, bend, c32[r]);
-				if (in_order(r))
-					place[r] = bstart + rel[r];
+				place[r] = bstart + walk32(is_big(r) ? bend /* ranked by the whole workgroup below */ : bstart, bend, c32[r]);
 			}
 			rank_big_buckets([&](u32 bs, u32 be, u32 i) { return walk32(bs, be, s_k32[i]); });
 		} else {
@@ -864,9 +836,7 @@ __device__ __forceinline__ void br_tile(const GrpRank &gr, const DevParams &P, c
 #pragma unroll
 			for (int r = 0; r < ITEMS; ++r) {
 				const u32 bstart = span[r] & 0xFFFFu, bend = span[r] >> 16;
-				place[r] = bstart + walk64(is_big(r) || in_order(r) ? bend : bstart, bend, ((key[r][0] & rmask) << 16) | (u64)rel[r]);
-				if (in_order(r))
-					place[r] = bstart + rel[r];
+				place[r] = bstart + walk64(is_big(r) ? bend : bstart, bend, ((key[r][0] & rmask) << 16) | (u64)rel[r]);
 			}
 			rank_big_buckets([&](u32 bs, u32 be, u32 i) { return walk64(bs, be, s_key[i]); });
 		}
@@ -1251,32 +1221,7 @@ __global__ void __launch_bounds__(BrCfg<SIZE>::THREADS, BR_MIN_WAVES) k_bucket_r
                                                                                   u32 lut_mask, u32 *flag)
 {
 	KMC_DYN_LDS(unsigned char, s_raw);
-	br_tile<SIZE, FUSED, false>(gr, P, key_bits, hbits, lut_shards, lut_stride, lut_mask, flag, blockIdx.x, blockIdx.y, s_raw);
-}
-
-/* The chunks k_bucket_rank listed (gr.heavy: a bucket beyond BR_MID records in them), once the arena has put those buckets in order where they lie: persistent workgroups
- * take them one by one. Nothing listed: a launch that returns. */
-template <int SIZE>
-__global__ void __launch_bounds__(BrCfg<SIZE>::THREADS, BR_MIN_WAVES / 2) k_bucket_rank_heavy(const GrpRank gr, DevParams P, u32 key_bits, u32 hbits, u32 lut_shards, u64 lut_stride,
-                                                                                            u32 lut_mask, u32 *flag)
-{
-	/* (107 VGPRs with the loop around the tile: one workgroup per CU. A real call of the tile body — 80 VGPRs, two workgroups — was slower: 1.25 against 0.83 ms per group of
-	 * the spectrum leg, the descriptor read from device memory and 5 registers spilled; profiles/r06/experiments.md) */
-	KMC_DYN_LDS(unsigned char, s_raw);
-	__shared__ u32 s_pick;
-	const u32 n = ld_agent(&gr.arena_dyn[AR_N_HEAVY]); /* final: k_bucket_rank and k_arena_plan ran before this kernel on the stream */
-#pragma unroll 1
-	while (true) {
-		if (threadIdx.x == 0)
-			s_pick = atomicAdd(&gr.arena_dyn[AR_HEAVY_TICKET], 1u);
-		__syncthreads();
-		const u32 pick = s_pick;
-		if (pick >= n)
-			break;
-		const u32 entry = gr.heavy[pick];
-		br_tile<SIZE, true, true>(gr, P, key_bits, hbits, lut_shards, lut_stride, lut_mask, flag, entry >> 1, entry & 1u, s_raw);
-		__syncthreads(); /* LDS and the ticket word are reused */
-	}
+	br_tile<SIZE, FUSED>(gr, P, key_bits, hbits, lut_shards, lut_stride, lut_mask, flag, blockIdx.x, blockIdx.y, s_raw);
 }
 
 /* ------------------------------------------------------------------------------------------------ tiles with a bucket beyond the LDS capacity

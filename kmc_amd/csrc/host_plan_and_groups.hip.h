@@ -660,13 +660,13 @@ int rank_group(Slot &s, const std::vector<BinPlan> &bins, u64 *sorted, u64 *scra
 	gr.rec_base = d_recs_indirect;
 	gg.tile_prefix[bins.size()] = (u32)(2 * wins);
 	/* The arena (one-word records): every bucket beyond BR_MID records is disjoint from every other, a giant one owns a tile — n_total / BR_MID + wins entries can never be
-	 * exceeded. Work area: entries | arena_off | item_off | bucket numbers | heavy chunks | digit bases | look-back rows of up to AR_MAX_PASS passes over up to n_total records. */
+	 * exceeded. Work area: entries | arena_off | item_off | bucket numbers | digit bases | look-back rows of up to AR_MAX_PASS passes over up to n_total records. */
 	ArenaWork aw = {};
 	u32 ar_pass_max = 0;
 	const u32 rbits = sp.key_bits - sp.hbits();
 	if constexpr (SIZE == 1) {
 		if (d_arena && wins < (1ull << 30) && n_total < (1ull << 40)) {
-			const u64 cap = n_total / BR_MID + wins + 16, heavy_cap = 2 * wins + 16;
+			const u64 cap = n_total / BR_MID + wins + 16;
 			const u64 max_tiles = (std::min<u64>(n_total, AR_MAX_RECORDS) + RsCfg<1>::TILE - 1) / RsCfg<1>::TILE;
 			u32 obits = 0;
 			while (obits < 32 && (1ull << obits) < cap)
@@ -681,8 +681,6 @@ int rank_group(Slot &s, const std::vector<BinPlan> &bins, u64 *sorted, u64 *scra
 			off += up256((cap + 1) * 4);
 			const size_t o_hi = off;
 			off += up256(cap * 8);
-			const size_t o_heavy = off;
-			off += up256(heavy_cap * 4);
 			const size_t o_dbase = off;
 			off += up256((size_t)(AR_MAX_PASS + 1) * 256 * 8);
 			const size_t o_status = off;
@@ -698,8 +696,6 @@ int rank_group(Slot &s, const std::vector<BinPlan> &bins, u64 *sorted, u64 *scra
 			gr.arena_dyn = d_arena;
 			gr.arena_ent = (ArenaEntry *)(base + o_ent);
 			gr.arena_cap = (u32)std::min<u64>(cap, 0xFFFFFFF0ull);
-			gr.heavy = (u32 *)(base + o_heavy);
-			gr.heavy_cap = (u32)heavy_cap;
 			aw.arena_off = (u32 *)(base + o_aoff);
 			aw.item_off = (u32 *)(base + o_ioff);
 			aw.bucket_hi = (u64 *)(base + o_hi);
@@ -728,7 +724,6 @@ int rank_group(Slot &s, const std::vector<BinPlan> &bins, u64 *sorted, u64 *scra
 		const size_t v = e ? (size_t)strtoull(e, nullptr, 10) : (size_t)0;
 		return v > 32 * 1024 ? (size_t)32 * 1024 : v;
 	}();
-	k_bucket_rank<SIZE, true><<<dim3((u32)wins, 2), dim3(BrCfg<SIZE>::THREADS), br_lds_bytes<SIZE>() + lds_pad, s.stream>>>(gr, P, sp.key_bits, sp.hbits(), n_sh, lut_entries, lut_mask, d_flag);
 	bool arena_ran = false;
 	if constexpr (SIZE == 1) {
 		if (gr.arena_dyn) { /* the buckets beyond BR_MID records, sorted together (arena_sort.hip.h); nothing listed: launches that return */
@@ -739,8 +734,17 @@ int rank_group(Slot &s, const std::vector<BinPlan> &bins, u64 *sorted, u64 *scra
 				const int v = e ? atoi(e) : 0;
 				return v > 0 ? (u32)v : 256u * 2u;
 			};
-			static const u32 g_gather = grid_of("KMC_HIP_ARENA_GRID_GATHER"), g_sweep = grid_of("KMC_HIP_ARENA_GRID_SWEEP"), g_finish = grid_of("KMC_HIP_ARENA_GRID_FINISH"),
-			                 g_heavy = grid_of("KMC_HIP_ARENA_GRID_HEAVY");
+			static const u32 g_gather = grid_of("KMC_HIP_ARENA_GRID_GATHER"), g_sweep = grid_of("KMC_HIP_ARENA_GRID_SWEEP"), g_finish = grid_of("KMC_HIP_ARENA_GRID_FINISH");
+			GrpDetect gd = {};
+			gd.g = gr.g;
+			u64 blocks = 0;
+			for (size_t i = 0; i < bins.size(); ++i) {
+				gd.blk_prefix[i] = (u32)blocks;
+				gd.n[i] = bins[i].n_rec;
+				blocks += (bins[i].n_rec + 64 * BD_STRIDE - 1) / (64 * BD_STRIDE);
+			}
+			gd.blk_prefix[bins.size()] = (u32)blocks;
+			k_bucket_detect<<<dim3((u32)((blocks + 3) / 4)), dim3(256), 0, s.stream>>>(gr, gd, rbits);
 			k_arena_plan<<<dim3(1), dim3(AR_THREADS), 0, s.stream>>>(gr, aw, rbits, d_flag);
 			k_arena_gather<<<dim3(g_gather), dim3(AR_THREADS), (size_t)ar_pass_max * 1024, s.stream>>>(gr, aw, rbits, ar_pass_max);
 			k_hist_scan<<<dim3(ar_pass_max), dim3(256), 0, s.stream>>>(aw.ghist, aw.dbase);
@@ -850,7 +854,7 @@ int rank_group(Slot &s, const std::vector<BinPlan> &bins, u64 *sorted, u64 *scra
 				u32 h_dyn[AR_DYN_WORDS];
 				HIPCHK(hipMemcpy(h_dyn, dyn, sizeof h_dyn, hipMemcpyDeviceToHost));
 				const u32 M = h_dyn[AR_M], ne = h_dyn[AR_N_ENT], np = h_dyn[AR_N_PASS];
-				fprintf(stderr, "[arena debug] entries %u records %u passes %u (max %u) items %u heavy %u overflow %u rbits %u\n", ne, M, np, ar_pass_max, h_dyn[AR_N_ITEMS], h_dyn[AR_N_HEAVY],
+				fprintf(stderr, "[arena debug] entries %u records %u passes %u (max %u) items %u heavy %u overflow %u rbits %u\n", ne, M, np, ar_pass_max, h_dyn[AR_N_ITEMS], 0u,
 				        h_dyn[AR_OVERFLOW], rbits);
 				if (M) {
 					std::vector<u64> ar(M);
@@ -892,10 +896,11 @@ int rank_group(Slot &s, const std::vector<BinPlan> &bins, u64 *sorted, u64 *scra
 					        (unsigned long long)inversions, (unsigned long long)first_inv, (unsigned long long)bad_entries, (unsigned long long)first_bad, (unsigned long long)bad_ord);
 				}
 			}
-			k_arena_finish<<<dim3(g_finish), dim3(AR_THREADS), 0, s.stream>>>(gr, aw, P, rbits, n_sh, lut_entries, lut_mask, err);
-			k_bucket_rank_heavy<1><<<dim3(g_heavy), dim3(BrCfg<1>::THREADS), br_lds_bytes<1>(), s.stream>>>(gr, P, sp.key_bits, sp.hbits(), n_sh, lut_entries, lut_mask, d_flag);
+			k_arena_finish<<<dim3(g_finish * (AR_THREADS / AF_THREADS)), dim3(AF_THREADS), 0, s.stream>>>(gr, aw, P, rbits, n_sh, lut_entries, lut_mask, err);
 		}
 	}
+	/* every tile ranked and counted inside LDS (with the arena: its buckets beyond BR_MID records are in order by now and keep their places) */
+	k_bucket_rank<SIZE, true><<<dim3((u32)wins, 2), dim3(BrCfg<SIZE>::THREADS), br_lds_bytes<SIZE>() + lds_pad, s.stream>>>(gr, P, sp.key_bits, sp.hbits(), n_sh, lut_entries, lut_mask, d_flag);
 	/* the tiles with a bucket beyond the LDS capacity (k-mers repeated thousands of times), one workgroup each; nothing listed: a launch that returns */
 	if (!arena_ran)
 		k_giant_tiles<SIZE><<<dim3((u32)std::min<u64>(wins, 256 * (1024 / GT_THREADS))), dim3(GT_THREADS), 0, s.stream>>>(gr, P, (u32)S, sp.key_bits, sp.hbits(), n_sh, lut_entries, lut_mask, err);

@@ -263,7 +263,6 @@ template <int SIZE> int set_func_attrs()
 		HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_bucket_rank<SIZE, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)br_lds_bytes<SIZE>() + 32 * 1024)); /* + room for $KMC_HIP_RANK_LDS_PAD */
 		if (SIZE == 1) {
 			HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_bucket_rank<1, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)br_lds_bytes<1>()));
-			HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_bucket_rank_heavy<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)br_lds_bytes<1>()));
 		}
 	}
 	if (exp_lds_bytes<true>(EXP_FUSE_MAX_PASS, 1) > 65536) /* worst case: the shortest records (smallest k) and 16 fused passes */

@@ -15,7 +15,7 @@ EMU_DIR = os.path.join(ROOT, "tests", "hipemu")
 # Two builds of the same kernel source: the product's tile geometry (512-thread workgroups: hundreds of OS threads per emulated workgroup,
 # slow) and a small one (128/256-thread workgroups, 4 KB expand slices) that runs the same code paths ~10x faster. Tests use the small one
 # unless they ask for "product".
-GEOMETRY_FLAGS = {"small": ["-DCP_BLOCK_THREADS=128", "-DEXP_BLOCK_THREADS=256", "-DEXP_CHUNK_BYTES=4096", "-DRS_BLOCK_THREADS=256", "-DCP_FOLD_CHUNK=256", "-DS1_SK_TILE_N=64", "-DS1_PACK_BYTES_N=16384", "-DS1_SUB_N=2", "-DBS_BLOCK_THREADS=128", "-DBC_BLOCK_THREADS=128", "-DBR_THREADS=128", "-DGT_THREADS=256", "-DGT_MAX_RECORDS_LOG2=11", "-DAR_THREADS=256", "-DBR_MID=192"], "product": []}
+GEOMETRY_FLAGS = {"small": ["-DCP_BLOCK_THREADS=128", "-DEXP_BLOCK_THREADS=256", "-DEXP_CHUNK_BYTES=4096", "-DRS_BLOCK_THREADS=256", "-DCP_FOLD_CHUNK=256", "-DS1_SK_TILE_N=64", "-DS1_PACK_BYTES_N=16384", "-DS1_SUB_N=2", "-DBS_BLOCK_THREADS=128", "-DBC_BLOCK_THREADS=128", "-DBR_THREADS=128", "-DGT_THREADS=256", "-DGT_MAX_RECORDS_LOG2=11", "-DAR_THREADS=256", "-DBR_MID=192", "-DBD_STRIDE_N=88"], "product": []}
 _LIBS = {}
 
 

@@ -67,7 +67,7 @@ VARIANTS = {
     "brslack12": ["-DBR_SLACK_DIV=12"],  # windows of 5632 (512 of slack)
     "brslack24": ["-DBR_SLACK_DIV=24"],  # windows of 5888 (256 of slack; longer tiles take a second chunk)
     # round 6: buckets beyond BR_MID records go through the arena (arena_sort.hip.h) instead of the whole workgroup's pairwise walk
-    "brmid128": ["-DBR_MID=128"], "brmid192": ["-DBR_MID=192"], "brmid256": ["-DBR_MID=256"], "brmid768": ["-DBR_MID=768"], "brmid1536": ["-DBR_MID=1536"],
+    "brmid175": ["-DBR_MID=175"], "brmid383": ["-DBR_MID=383"], "brmid767": ["-DBR_MID=767"], "brmid1535": ["-DBR_MID=1535"],
     "brnl0": ["-DBR_NARROW_LOOP=0"],  # k_bucket_rank, 32-bit pairs: the walk of rounds 3-5 (steps of 4 + a pairwise tail, interleaved by the compiler); the shipped one is 8 / 4 / one masked step
     "brwl0": ["-DBR_WIDE_LOOP=0", "-DBR_NARROW_LOOP=2"],  # k_bucket_rank<1>, 64-bit pairs: steps of 2 + one, and the dealers' count 8 + one by one (rounds 3-5)
     "brwl4": ["-DBR_WIDE_STEP=4"],  # steps of 4, 2, 1
