@@ -30,6 +30,13 @@ Keys of the N=1 record (each measured after the timed region, none inside it):
   e2e_stage1          : NOT stage 2 — "1st stage" seconds of the reference pipeline with the splitter worker swapped too (kmc_hip_s1)
   secondary.skew_quarter / skew_spectrum_quarter: the quarter workload with one repeat family / a spectrum of families planted in the genome ($KMC_SYNTH_REPEATS), value on one
                         stream and value_two_streams
+  secondary.k55_full / k127_full: configs[4]'s record widths at FULL size on one GPU (200 M reads, 512 bins); their `roofline` is the kernel that dominates them — the finisher
+                        k_bucket_rank<2|4> (pair read + record gathered by number) —, the scatter passes' own in roofline_scatter; 16 bins each against the oracle
+  cpu_baseline_skew / cpu_baseline_spectrum: the reference's "2nd stage" on a FASTQ of the skew legs' reads (one run each), the GPU's value on the same reads beside it;
+                        gpu_over_cpu: the three ratios (uniform, skew, spectrum) side by side
+  moved_bytes_per_kmer: {"pmc": from the committed rocprofv3 --pmc run of this workload (profiles/r06/pmc_hbm_traffic.json: every kernel of one step), "design": what the path
+                        is designed to move}; moved_frac_of_hbm_peak likewise. Neither is a counter of THIS run (counters cannot be read from inside it); roofline.traffic idem.
+  self_check.oracle_bins: 16 bins of the timed run, stratified by size, byte for byte against the oracle (one host thread per bin)
   e2e_large           : ONE FASTQ of --e2e-gbp Gbp (default 8): reference vs drop-in "2nd stage" in RAM-only mode, and the reference's own stage-1 bins (dumped by the drop-in's
                         worker) device-resident, tallies against the reference's statistics
   cpu_baseline / e2e  : the REAL reference (oracle/_ref/kmc, built from /root/reference by oracle/Makefile) and the drop-in
@@ -59,7 +66,7 @@ sys.path.insert(0, ROOT)
 from kmc_amd import capi, sharding  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
-PMC_PROFILE = os.path.join(ROOT, "profiles", "r05", "pmc_hbm_traffic.json")  # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes
+PMC_PROFILE = os.path.join(ROOT, "profiles", "r06", "pmc_hbm_traffic.json")  # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes
 
 # BASELINE.json configs -> generator parameters
 CONFIGS = {
@@ -100,6 +107,18 @@ def pmc_traffic(kernel: str, records_per_launch: float):
         if abs(d["records_per_launch_avg"] - records_per_launch) > 0.02 * records_per_launch:
             return None
         return d["kernels"][kernel]["hbm_bytes_per_launch"]
+    except Exception:
+        return None
+
+
+def pmc_moved_bytes_per_kmer(kernel: str, records_per_launch: float, kmers: int):
+    """HBM bytes per k-mer that ALL kernels of one step moved, from the same committed PMC profile (one step of this workload under rocprofv3 --pmc: every launch counted):
+    sum over kernels of bytes per launch x launches / the k-mers of the step. None for any other workload."""
+    try:
+        d = json.load(open(PMC_PROFILE))
+        if abs(d["records_per_launch_avg"] - records_per_launch) > 0.02 * records_per_launch or kernel not in d["kernels"]:
+            return None
+        return sum(v["hbm_bytes_per_launch"] * v["launches"] for v in d["kernels"].values()) / kmers
     except Exception:
         return None
 
@@ -266,15 +285,16 @@ def output_digest(ctx, w, res):
     return dig
 
 
-def oracle_check(ctx, w, res, n_check=3):
-    """The timed run's own output against the oracle, at the scale that was timed: the largest, the median and the smallest bin of this rank are copied
-    back (image, suffix records, LUT, tallies) and compared byte for byte with oracle/stage2_oracle.c's process_bin on the same image. The oracle is
-    the CHECKER here (tests/oracle_py.py, ctypes over oracle/liboracle_stage2.so); nothing of it is timed or shipped."""
+def oracle_check(ctx, w, res, n_check=16):
+    """The timed run's own output against the oracle, at the scale that was timed: `n_check` bins of this rank, stratified by size (the smallest, the largest and the
+    quantiles between them), are copied back (image, suffix records, LUT, tallies) and compared byte for byte with oracle/stage2_oracle.c's process_bin on the same
+    image, one host thread per bin. The oracle is the CHECKER here (tests/oracle_py.py, ctypes over oracle/liboracle_stage2.so); nothing of it is timed or shipped."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import oracle_py as O
 
     order = sorted(range(w.n_own), key=lambda i: w.bins[i][2])
-    picks = sorted({order[-1], order[len(order) // 2], order[0]}, key=lambda i: -w.bins[i][2])[:n_check] if order else []
+    n_check = max(1, min(n_check, len(order), 2 * sharding.effective_cpus()))
+    picks = sorted({order[round(q * (len(order) - 1) / max(n_check - 1, 1))] for q in range(n_check)}, key=lambda i: -w.bins[i][2]) if order else []
     p = w.p
     op = O.make_params(p.kmer_len, p.both_strands, p.cutoff_min, p.cutoff_max, p.counter_max, p.lut_prefix_len, p.output_type, p.without_output)
     verdicts = [None] * len(picks)
@@ -433,8 +453,8 @@ def short_line(out):
     sc = out.get("self_check", {})
     s["self_check"] = _pick(sc, ("per_bin_total_and_out_bytes_consistent", "oracle_bins_equal", "output_digest", "gpu_tallies_equal_reference_on_2gbp_sample"))
     sp = out.get("sort_path", {})
-    s["moved_bytes_per_kmer"] = sp.get("hbm_bytes_per_kmer_moved_by_design")
-    s["moved_frac_of_hbm_peak"] = sp.get("moved_frac_of_hbm_peak")
+    s["moved_bytes_per_kmer"] = {"pmc": sp.get("hbm_bytes_per_kmer_moved_pmc"), "design": sp.get("hbm_bytes_per_kmer_moved_by_design")}
+    s["moved_frac_of_hbm_peak"] = {"pmc": sp.get("moved_frac_of_hbm_peak_pmc"), "design": sp.get("moved_frac_of_hbm_peak")}
     s["stage2_algorithmic_bytes_per_kmer"] = out.get("stage2_algorithmic_bytes_per_kmer")
     s["stage2_frac_of_hbm_peak"] = out.get("stage2_frac_of_hbm_peak")
     s["groups_by_path"] = sp.get("groups_by_path")
@@ -460,12 +480,19 @@ def short_line(out):
                 e["oracle_bins_equal"] = eq
             if isinstance(v.get("roofline"), dict):
                 e["roofline_frac"] = v["roofline"].get("frac")
+                if v["roofline"].get("kernel") != "k_onesweep<1>":
+                    e["roofline_kernel"] = v["roofline"].get("kernel")
             opt[name_] = e
     if opt:
         s["secondary"] = opt
     for kk in ("cpu_baseline_k55", "cpu_baseline_k127"):
         if isinstance(out.get(kk), dict):
             s[kk] = _pick(out[kk], ("value", "cores", "stage2_s", "error"))
+    for kk in ("cpu_baseline_skew", "cpu_baseline_spectrum"):
+        if isinstance(out.get(kk), dict):
+            s[kk] = _pick(out[kk], ("value", "cores", "stage2_s", "input_kmers", "gpu_value_same_reads", "gpu_over_cpu", "error"))
+    if isinstance(out.get("gpu_over_cpu"), dict):
+        s["gpu_over_cpu"] = _pick(out["gpu_over_cpu"], ("uniform", "skew", "spectrum"))
     if isinstance(out.get("e2e"), dict):
         s["e2e"] = _pick(out["e2e"], ("ref_stage2_s", "hip_stage2_s", "speedup", "hip_Gkmers_per_s", "stats_equal"))
     if isinstance(out.get("e2e_large"), dict):
@@ -487,7 +514,7 @@ def short_line(out):
         return o
 
     s = rnd(s)
-    for drop in ("secondary", "e2e_large", "e2e", "cpu_baseline_k127", "cpu_baseline_k55", "groups_by_path", "local_sort", "tallies", "per_rank"):
+    for drop in ("e2e", "cpu_baseline_k127", "cpu_baseline_k55", "e2e_large", "secondary", "cpu_baseline_spectrum", "cpu_baseline_skew", "groups_by_path", "local_sort", "tallies", "per_rank"):
         if len(json.dumps(s)) < SHORT_LINE_LIMIT:
             break
         s.pop(drop, None)
@@ -615,6 +642,40 @@ def reference_legs(k: int, reads: int, genome: int, runs: int = 3):
     return out
 
 
+def reference_repeat_legs(k: int, threads: int, gpu_legs: dict):
+    """cpu_baseline_skew / cpu_baseline_spectrum: the REAL reference's "2nd stage" (kmc_CLI/kmc.cpp:390-391) on a FASTQ of the reads the skew legs' bins were
+    cut from — the quarter workload (50 M reads x 150 bp of a 250 Mbp genome, seed 2026) with the same $KMC_SYNTH_REPEATS planted —, one run each, RAM-only mode off (the
+    default KMC run, as cpu_baseline). The GPU's device-resident value on the same reads is put beside it (speed-up on the inputs where the GPU is weakest)."""
+    ref = os.path.join(ROOT, "oracle", "_ref", "kmc")
+    cfg = CONFIGS["quarter"]
+    ram_gb = os.sysconf("SC_PAGE_SIZE") * os.sysconf("SC_PHYS_PAGES") >> 30
+    mem = max(2, min(128, ram_gb // 2))
+    cores = sharding.effective_cpus()
+    out = {}
+    for key, spec, gpu_key in (("cpu_baseline_skew", SKEW_REPEATS, "skew_quarter"), ("cpu_baseline_spectrum", SKEW_SPECTRUM, "skew_spectrum_quarter")):
+        try:
+            need = int(cfg["reads"] * 316 * 1.3) + (1 << 30)
+            d, free = scratch_dir(need)
+            if free < need:
+                raise RuntimeError(f"no scratch directory with {need >> 30} GiB free for the FASTQ")
+            with tempfile.TemporaryDirectory(dir=d) as td:
+                fq = os.path.join(td, "r.fq")
+                os.environ["KMC_SYNTH_REPEATS"] = spec
+                try:
+                    capi.synth_fastq(fq, seed=SEED, genome_len=cfg["genome"], n_reads=cfg["reads"])
+                finally:
+                    del os.environ["KMC_SYNTH_REPEATS"]
+                s1, s2, st, _ = _run_kmc(ref, [f"-k{k}", f"-t{threads}", f"-m{mem}", "-hp"], fq, td, key, timeout=900)
+            gv = (gpu_legs.get(gpu_key) or {}).get("value")
+            out[key] = {"value": st["total"] / s2 / 1e9, "unit": "Gk-mers/s", "cores": cores, "kind": "reference", "stage2_s": s2, "stage1_s": s1, "input_kmers": st["total"],
+                        "sample": f"reference kmc 3.2.4 -k{k} -t{threads} -m{mem}, '2nd stage' wall, one run; {cfg['reads']} reads x150bp of a {cfg['genome']} bp genome with "
+                                  f"$KMC_SYNTH_REPEATS={spec} (the reads of secondary.{gpu_key})",
+                        "gpu_value_same_reads": gv, "gpu_over_cpu": (gv / (st["total"] / s2 / 1e9)) if isinstance(gv, float) else None, "stats": st}
+        except Exception as e:  # noqa: BLE001
+            out[key] = {"error": repr(e)[-300:]}
+    return out
+
+
 def e2e_large_leg(ctx, k: int, gbp: float, budget_s: float = 1500.0):
     """The drop-in inside the reference's pipeline at a size where the pipeline, not the start-up, is what is timed (round 4's e2e ran 2 Gbp: 0.25 s). One FASTQ of
     `gbp` Gbp (30x of a random genome, the read model of configs[2]); ONE run each of the unmodified reference (oracle/_ref/kmc) and of the drop-in (kmc_amd/bin/kmc_hip:
@@ -730,9 +791,12 @@ def main():
     ap.add_argument("--host-probe", action="store_true", help="diagnostics: the host-boundary leg for every sort selection and call style, errors reported per leg")
     ap.add_argument("--no-host-single", action="store_true", help="skip the one-bin-per-call comparison of the host-boundary leg")
     ap.add_argument("--no-secondary", action="store_true")
+    ap.add_argument("--no-full-wide", action="store_true", help="skip the full-size k = 55 / k = 127 legs (configs[4] on one GPU, ~80 s each)")
+    ap.add_argument("--no-repeat-baselines", action="store_true", help="skip cpu_baseline_skew / cpu_baseline_spectrum (the reference on the skew legs' reads, ~40 s each)")
     ap.add_argument("--no-two-streams", action="store_true", help="skip the value_two_streams leg (profiling runs: keeps overlapped launches out of the kernel statistics)")
     ap.add_argument("--no-digest", action="store_true")
     ap.add_argument("--no-oracle-check", action="store_true", help="skip the byte-for-byte comparison of three of the timed run's bins with the oracle")
+    ap.add_argument("--oracle-bins", type=int, default=0, help="bins of the timed run compared byte for byte with the oracle (0: 16 on the full workload, 3 on a quarter leg)")
     ap.add_argument("--cache", default="", help="directory for the generated bin set (tuning sessions: generate once, reuse)")
     ap.add_argument("--e2e-gbp", type=float, default=8.0, help="size of the e2e_large leg's FASTQ in Gbp (0 = skip; 30 = the full configs[2] shape, ~4 minutes more)")
     ap.add_argument("--also-two-streams", action="store_true", help="secondary legs: time the step with two groups in flight as well (value_two_streams)")
@@ -869,9 +933,9 @@ def main():
             dg = sum(parts) & ((1 << 64) - 1)
         digest = "%016x" % dg
     oracle_bins = None
-    if rank == 0 and not args.no_oracle_check and (not args.leg or args.leg == "quarter"):
+    if rank == 0 and not args.no_oracle_check and args.leg in ("", "quarter", "configs[2]"):
         try:
-            oracle_bins = oracle_check(ctx, w, res)
+            oracle_bins = oracle_check(ctx, w, res, args.oracle_bins or (16 if args.leg in ("", "configs[2]") else 3))
         except Exception as e:  # noqa: BLE001 — the checker must not take the measurement down with it
             oracle_bins = [{"error": repr(e)}]
     if dist:
@@ -905,6 +969,7 @@ def main():
         moved = W * (1 + 2 * hbm_passes + (2 if by_rank else 0) + 1) + 1.2  # expand write + passes (read + write) [+ rank in place] + one read by the finisher / k_compact + the bin image
         if indirect:
             moved = W + 8 + 2 * 8 * hbm_passes + 8 + W + 1.2  # expand writes record + pair, the passes move pairs, the finisher reads the pair and gathers the record
+        moved_pmc = pmc_moved_bytes_per_kmer(kern, rpl, w.total_kmers_all) if world == 1 else None
         desc = (CONFIGS[name]["desc"] % k) if name in CONFIGS else f"custom: k={k}, {args.reads} reads of a {args.genome} bp genome, {args.bins} bins"
         out = {
             "metric": "stage-2 Gk-mers/s, k=%d (bin sort & count: parse + expand + 8-bit LSD radix sort + compaction over all signature bins)" % k,
@@ -931,6 +996,8 @@ def main():
                                    "hybrid: 8-bit LSD passes through HBM over the top key bytes only, the rest counted inside LDS on bucket-aligned tiles (k_bucket_count)" if hyb
                                    else "8-bit LSD passes through HBM over every key byte, then k_compact"),
                           "groups_by_path": pc, "hbm_passes_per_record": hbm_passes, "hbm_bytes_per_kmer_moved_by_design": moved, "moved_GBs": moved * value, "moved_frac_of_hbm_peak": moved * value / HBM_PEAK_GBS,
+                          "hbm_bytes_per_kmer_moved_pmc": moved_pmc, "moved_frac_of_hbm_peak_pmc": (moved_pmc * value / HBM_PEAK_GBS) if moved_pmc else None,
+                          "pmc_source": os.path.relpath(PMC_PROFILE, ROOT) + " (a rocprofv3 --pmc run of this workload on the committed tree, not a counter of THIS run: counters cannot be read from inside it)",
                           "note": "SURVEY 8d: an implementation with fewer passes moves fewer real bytes — stage2_algorithmic_* below is the NORMATIVE 8-bit-LSD figure W(2P+3) "
                                   "(what the reference formulation would have to move for this throughput: it can exceed the HBM peak when passes are skipped), "
                                   "moved_* is what this path is designed to move (PMC-checked per kernel in profiles/r05)"},
@@ -939,7 +1006,7 @@ def main():
             "stage2_frac_of_hbm_peak": W * (2 * P + 3) * value / HBM_PEAK_GBS,
             "roofline": {"bound": "hbm", "kernel": kern, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(kern, rpl),
-                         "traffic_unit": "HBM bytes per launch (PMC FETCH_SIZE x2 + WRITE_SIZE, profiles/r05/pmc_hbm_traffic.json)",
+                         "traffic_unit": "HBM bytes per launch (PMC FETCH_SIZE x2 + WRITE_SIZE of a rocprofv3 run of this workload, profiles/r06/pmc_hbm_traffic.json: a committed constant, not a counter of this run)",
                          "algorithmic_bytes_per_launch": 2 * SW * rpl, "launches_in_timed_region": n_launch, "avg_launch_ms": avg_ms,
                          "records_per_launch": rpl, "algorithmic_bytes_per_record_per_launch": 2 * SW,
                          "note": "consecutive bins of a stream share one sort (bins_per_sort: the bin's number inside the group rides in the spare bits of the "
@@ -956,6 +1023,21 @@ def main():
                            "the scatter passes, compaction + fold + gather)",
             "setup_s": w.setup_s,
         }
+        if indirect and ls["launches"]:
+            # records of two words and more: the scatter passes move 8-byte pairs and are the smaller part of the step; the kernel that dominates is the finisher
+            # (profiles/r05/quarter_k55_kernel_stats.csv: k_bucket_rank<2> 46 %, k_onesweep<1> 35 %). Its algorithmic bytes per record: the pair it reads (8) + the
+            # record it gathers by number (W); the (suffix, counter) records it writes are counted from the run's own out_bytes.
+            fin_bytes = (8 + W) * ls["records"] + float(res[:, 4].sum()) * ls["records"] / max(w.own_kmers, 1)
+            fin_ach = fin_bytes / (ls["ms"] * 1e-3) / 1e9
+            out["roofline_scatter"] = out["roofline"]
+            out["roofline"] = {"bound": "hbm", "kernel": "k_bucket_rank<%d, true>" % (W // 8), "achieved": fin_ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                               "frac": fin_ach / HBM_PEAK_GBS, "traffic": None, "algorithmic_bytes_per_launch": fin_bytes / ls["launches"],
+                               "launches_in_timed_region": ls["launches"], "avg_launch_ms": ls["ms"] / ls["launches"], "records_per_launch": ls["records"] / ls["launches"],
+                               "algorithmic_bytes_per_record_per_launch": 8 + W,
+                               "note": "the dominant kernel of this record width (k >= 33: indirect sort): HIP events around k_bucket_bounds + k_bucket_rank of every 8th "
+                                       "group; algorithmic bytes = (8-byte pair + W-byte record gathered by number) per record + the output records written. The gather "
+                                       "pulls a 64-byte request per record (profiles/r05/pmc_hbm_traffic_k55.json): traffic is ~3x this at k = 55; the scatter passes' own "
+                                       "roofline is in roofline_scatter"}
         if per_rank:
             out["per_rank"] = per_rank
             km = [pr["kmers"] for pr in per_rank]
@@ -1061,6 +1143,12 @@ def main():
                 sec["skew_spectrum_quarter"] = dict({x: sk.get(x) for x in ("value", "value_two_streams", "ms_per_step", "sort_path", "local_sort", "tallies", "self_check", "error") if x in sk},
                                                     what="quarter workload, k=27, $KMC_SYNTH_REPEATS=%s: a spectrum of repeat families (unit:copies:per-mille divergence, H = a "
                                                          "homopolymer run) planted in the genome" % SKEW_SPECTRUM)
+                # configs[4]'s record widths at FULL size (200 M reads, 512 bins, one GPU): the legs the quarter numbers above stand in for; roofline = the kernel that
+                # dominates THEM (the finisher), 16 bins each against the oracle
+                if not args.no_full_wide:
+                    for kk in (55, 127):
+                        sk = secondary_leg("configs[2]", kk, ["--no-digest"])
+                        sec["k%d_full" % kk] = {x: sk.get(x) for x in ("value", "ms_per_step", "config", "roofline", "roofline_scatter", "sort_path", "local_sort", "tallies", "self_check", "error") if x in sk}
             out["secondary"] = sec
         if not args.no_cpu_baseline:
             try:
@@ -1074,6 +1162,15 @@ def main():
                         and s2t["n_total"] == st["total"])
             except Exception as e:  # the baseline is informative; never lose the GPU number over it
                 out["cpu_baseline"] = {"value": None, "unit": "Gk-mers/s", "cores": 0, "kind": "reference", "sample": f"failed: {e}"}
+            if k == 27 and not args.no_secondary and not args.no_repeat_baselines:
+                m = re.search(r"-t(\d+)", (out.get("cpu_baseline") or {}).get("sample") or "")
+                out.update(reference_repeat_legs(k, int(m.group(1)) if m else max(2, sharding.effective_cpus()), out.get("secondary") or {}))
+                cb = out.get("cpu_baseline") or {}
+                if isinstance(cb.get("value"), float):
+                    out["gpu_over_cpu"] = {"uniform": out["value"] / cb["value"], "skew": (out.get("cpu_baseline_skew") or {}).get("gpu_over_cpu"),
+                                           "spectrum": (out.get("cpu_baseline_spectrum") or {}).get("gpu_over_cpu"),
+                                           "note": "device-resident GPU value / the reference's '2nd stage' rate on this host's cores: uniform = configs[2] over the 2 Gbp sample's "
+                                                   "baseline; skew / spectrum = the quarter legs over the reference on a FASTQ of the same reads"}
             if args.e2e_gbp > 0:
                 try:
                     out["e2e_large"] = e2e_large_leg(ctx, k, args.e2e_gbp)

@@ -241,6 +241,12 @@ int kmc_hip_set_hybrid(int mode);
  * number — with the records gathered by number inside k_bucket_rank (process-wide, like [0..3]). [7] reserved (0). What replaces raduls_impl.h:216-520,
  * :680-737 / small_sort.h for a group. */
 int kmc_hip_path_counters(kmc_hip_ctx *ctx, int dev, uint64_t counters[8]);
+/* Diagnostics (process-wide, since the library was loaded): where the host-boundary calls (kmc_hip_process_bin_submit/_wait, kmc_hip_process_bins_submit/_wait) spent
+ * their wall time, in seconds summed over all slots: [0] pack starts + device buffers, [1] staging copy in (callers whose images are in ordinary memory), [2] enqueueing
+ * copies and launches, [3] waiting for the kernels (includes the H2D copy in front of them and whatever other slots queued before), [4] D2H of the exact-size results,
+ * [5] staging copy out (callers whose output buffers are ordinary memory); [6] calls, [7] redo rounds (counts). What the drop-in's worker report prints under
+ * $KMC_HIP_VERBOSE; no reference counterpart (the CPU worker has no host link). */
+int kmc_hip_host_boundary_times(double seconds[8]);
 /* Device memory helpers so non-HIP callers (ctypes tests, the C++ worker) need not link HIP themselves. */
 int kmc_hip_malloc(kmc_hip_ctx *ctx, int dev, uint64_t bytes, void **d_ptr);
 int kmc_hip_free(kmc_hip_ctx *ctx, int dev, void *d_ptr);

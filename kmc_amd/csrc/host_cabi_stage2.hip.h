@@ -158,10 +158,12 @@ int kmc_hip_init(const int *device_ids, int n_dev, kmc_hip_ctx **out)
 	return 0;
 }
 
+static void hb_report();
 void kmc_hip_destroy(kmc_hip_ctx *ctx)
 {
 	if (!ctx)
 		return;
+	hb_report();
 	for (auto &d : ctx->devs) {
 		(void)hipSetDevice(d->ordinal);
 		(void)hipDeviceSynchronize();
@@ -499,6 +501,45 @@ int kmc_hip_process_bins_device(kmc_hip_ctx *ctx, int dev, const kmc_hip_bin_par
 
 /* byte offsets of a bin's expander packs, appended to `ps` (first entry 0, last entry `size`): from the caller's pack sizes, or — none given — by one
  * walk over the image, a boundary every 4096 super-k-mers */
+/* Where the host-boundary calls spend their wall time, summed over all slots (KMC_HIP_VERBOSE prints them when the context is destroyed; the drop-in's workers sit in these
+ * calls for most of stage 2 — profiles/r05/e2e_large_30gbp.json: 40 s summed over 16 workers for 0.73 s of kernels): [0] pack starts + buffers, [1] staging copy in (pageable
+ * callers), [2] enqueue (copies + launches), [3] wait for the kernels (includes the H2D in front of them and every other slot's work queued before), [4] D2H of the exact-size
+ * results, [5] staging copy out (pageable callers), [6] calls, [7] redo rounds */
+static std::atomic<long long> g_hb_ns[8];
+static inline long long hb_now()
+{
+	return std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+struct HbLap {
+	long long t = hb_now();
+	void lap(int i)
+	{
+		const long long n = hb_now();
+		g_hb_ns[i] += n - t;
+		t = n;
+	}
+};
+static void hb_report()
+{
+	if (!getenv("KMC_HIP_VERBOSE") || g_hb_ns[6].load() == 0)
+		return;
+	fprintf(stderr, "[kmc_hip host boundary] %lld calls (%lld redo rounds), seconds summed over slots: pack starts + buffers %.3f, staging copy in %.3f, enqueue %.3f, wait for "
+	                "the kernels %.3f, D2H of the results %.3f, staging copy out %.3f\n",
+	        g_hb_ns[6].load(), g_hb_ns[7].load(), g_hb_ns[0].load() * 1e-9, g_hb_ns[1].load() * 1e-9, g_hb_ns[2].load() * 1e-9, g_hb_ns[3].load() * 1e-9, g_hb_ns[4].load() * 1e-9,
+	        g_hb_ns[5].load() * 1e-9);
+}
+
+int kmc_hip_host_boundary_times(double seconds[8])
+{
+	if (!seconds)
+		return fail(KMC_HIP_EINVAL, "seconds == NULL");
+	for (int i = 0; i < 6; ++i)
+		seconds[i] = g_hb_ns[i].load() * 1e-9;
+	seconds[6] = (double)g_hb_ns[6].load();
+	seconds[7] = (double)g_hb_ns[7].load();
+	return 0;
+}
+
 static int append_pack_starts(const DevParams &P, const uint8_t *superkmers, u64 size, const uint64_t *pack_bytes, u64 n_packs, std::vector<u64> &ps)
 {
 	if (!size)
@@ -570,6 +611,8 @@ int kmc_hip_process_bin_submit(kmc_hip_ctx *ctx, int dev, int slot, const kmc_hi
 		return fail(KMC_HIP_EINVAL, "output buffers missing");
 
 	/* pack starts (byte offsets). Without packs from the caller, walk the image once on the host. */
+	HbLap lap;
+	++g_hb_ns[6];
 	std::vector<u64> &ps = s.h_pack_start;
 	ps.clear();
 	if (size) {
@@ -605,6 +648,7 @@ int kmc_hip_process_bin_submit(kmc_hip_ctx *ctx, int dev, int slot, const kmc_hi
 	if ((rc = ensure(s.in, size + 256)) || (rc = ensure(s.pack_start, (np + 1) * 8)) ||
 	    (rc = ensure(s.out, (P.without_output ? 0 : out_capacity) + 256)) || (rc = ensure(s.lut, lut_entries * 8 + 256)))
 		return rc;
+	lap.lap(0);
 	if (size) {
 		const void *src = superkmers;
 		if (!host_ptr_is_pinned(superkmers)) { /* pageable caller (the drop-in's arena): through the slot's pinned staging buffer */
@@ -612,6 +656,7 @@ int kmc_hip_process_bin_submit(kmc_hip_ctx *ctx, int dev, int slot, const kmc_hi
 				return rc;
 			memcpy(s.h_stage_in, superkmers, size);
 			src = s.h_stage_in;
+			lap.lap(1);
 		}
 		HIPCHK(hipMemcpyAsync(s.in.p, src, size, hipMemcpyHostToDevice, s.stream));
 		HIPCHK(hipMemsetAsync((char *)s.in.p + size, 0, 256, s.stream));
@@ -628,6 +673,7 @@ int kmc_hip_process_bin_submit(kmc_hip_ctx *ctx, int dev, int slot, const kmc_hi
 	s.lut_entries = lut_entries;
 	if ((rc = enqueue_host_bin(s, false)))
 		return rc;
+	lap.lap(2);
 	s.pending = true;
 	s.h_out = out_suffix;
 	s.h_lut = (u64 *)lut;
@@ -648,9 +694,11 @@ int kmc_hip_process_bin_wait(kmc_hip_ctx *ctx, int dev, int slot, uint64_t *out_
 	if (!s.pending)
 		return fail(KMC_HIP_EINVAL, "no bin in flight on this slot");
 	s.pending = false;
+	HbLap lap;
 	HIPCHK(hipEventSynchronize(s.done_ev)); /* blocks in the kernel driver instead of spinning */
 	if (int rc = harvest(s))
 		return rc;
+	lap.lap(3);
 	HostRes r = *s.h_res;
 	if (r.redo && !(r.err & ~KERR_CAPACITY)) { /* the hybrid sort met a tile it could not handle: the bin again (its image is still in s.in), LSD passes over every byte.
 		                                      * A capacity error of the first attempt does not count: a tile that was handed back may have been compacted unsorted */
@@ -663,6 +711,8 @@ int kmc_hip_process_bin_wait(kmc_hip_ctx *ctx, int dev, int slot, uint64_t *out_
 			return rc;
 		HIPCHK(hipEventSynchronize(s.done_ev));
 		r = *s.h_res;
+		++g_hb_ns[7];
+		lap.lap(3);
 	}
 	if (r.err) {
 		if (int rc = clear_sticky(s, r.err))
@@ -688,11 +738,13 @@ int kmc_hip_process_bin_wait(kmc_hip_ctx *ctx, int dev, int slot, uint64_t *out_
 			HIPCHK(hipMemcpyAsync(dst_lut, s.lut.p, lut_bytes, hipMemcpyDeviceToHost, s.stream));
 		HIPCHK(hipEventRecord(s.done_ev, s.stream));
 		HIPCHK(hipEventSynchronize(s.done_ev));
+		lap.lap(4);
 		if (s.out_staged) {
 			if (r.out_bytes)
 				memcpy(s.h_out, dst_out, r.out_bytes);
 			if (lut_bytes)
 				memcpy(s.h_lut, dst_lut, lut_bytes);
+			lap.lap(5);
 		}
 	}
 	if (out_bytes)
@@ -739,6 +791,8 @@ int kmc_hip_process_bins_submit(kmc_hip_ctx *ctx, int dev, int slot, const kmc_h
 		return fail(KMC_HIP_EINVAL, "slot already has a bin in flight");
 	const u64 lut_entries = P.kff ? 0 : kmc_hip_lut_entries(params);
 	const u64 lut_pitch = up256(lut_entries * 8);
+	HbLap lap;
+	++g_hb_ns[6];
 	std::vector<u64> &ps = s.h_pack_start;
 	ps.clear();
 	std::vector<u64> in_off(n_bins), out_off(n_bins), ps_off(n_bins), np(n_bins);
@@ -781,6 +835,7 @@ int kmc_hip_process_bins_submit(kmc_hip_ctx *ctx, int dev, int slot, const kmc_h
 	}
 	if (stage_in && (rc = ensure_pinned(s.h_stage_in, s.h_stage_in_cap, in_total + 256)))
 		return rc;
+	lap.lap(0);
 	for (u32 i = 0; i < n_bins; ++i) {
 		const kmc_hip_host_bin &b = bins[i];
 		uint8_t *d_img = (uint8_t *)s.in.p + in_off[i];
@@ -789,6 +844,7 @@ int kmc_hip_process_bins_submit(kmc_hip_ctx *ctx, int dev, int slot, const kmc_h
 			if (stage_in) {
 				memcpy((char *)s.h_stage_in + in_off[i], b.superkmers, b.size);
 				src = (char *)s.h_stage_in + in_off[i];
+				lap.lap(1);
 			}
 			HIPCHK(hipMemcpyAsync(d_img, src, b.size, hipMemcpyHostToDevice, s.stream));
 			HIPCHK(hipMemsetAsync(d_img + b.size, 0, 256, s.stream));
@@ -833,6 +889,7 @@ int kmc_hip_process_bins_submit(kmc_hip_ctx *ctx, int dev, int slot, const kmc_h
 	}
 	if ((rc = hb_enqueue_results(s)))
 		return rc;
+	lap.lap(2);
 	s.hb_pending = true;
 	return 0;
 }
@@ -848,9 +905,11 @@ int kmc_hip_process_bins_wait(kmc_hip_ctx *ctx, int dev, int slot, uint64_t *out
 	if (!s.hb_pending)
 		return fail(KMC_HIP_EINVAL, "no group of bins in flight on this slot");
 	s.hb_pending = false;
+	HbLap lap;
 	HIPCHK(hipEventSynchronize(s.done_ev));
 	if (int rc = harvest(s))
 		return rc;
+	lap.lap(3);
 	const HbRes &r = *s.h_hb_res;
 	bool any_flag = false;
 	for (size_t c = 0; c < s.hb_chunks.size(); ++c)
@@ -878,6 +937,8 @@ int kmc_hip_process_bins_wait(kmc_hip_ctx *ctx, int dev, int slot, uint64_t *out
 			if (int rc = hb_enqueue_results(s))
 				return rc;
 			HIPCHK(hipEventSynchronize(s.done_ev));
+			++g_hb_ns[7];
+			lap.lap(3);
 		}
 	}
 	if (r.err) {
@@ -908,13 +969,16 @@ int kmc_hip_process_bins_wait(kmc_hip_ctx *ctx, int dev, int slot, uint64_t *out
 		}
 		HIPCHK(hipEventRecord(s.done_ev, s.stream));
 		HIPCHK(hipEventSynchronize(s.done_ev));
-		if (s.out_staged)
+		lap.lap(4);
+		if (s.out_staged) {
 			for (size_t i = 0; i < n; ++i) {
 				if (r.w[i][0])
 					memcpy(s.hb[i].h_out, (uint8_t *)s.h_stage_out + off[i] + lut_bytes, r.w[i][0]);
 				if (lut_bytes)
 					memcpy(s.hb[i].h_lut, (uint8_t *)s.h_stage_out + off[i], lut_bytes);
 			}
+			lap.lap(5);
+		}
 	}
 	for (size_t i = 0; i < n; ++i) {
 		if (out_bytes)

@@ -666,7 +666,11 @@ int rank_group(Slot &s, const std::vector<BinPlan> &bins, u64 *sorted, u64 *scra
 	const u32 rbits = sp.key_bits - sp.hbits();
 	if constexpr (SIZE == 1) {
 		if (d_arena && wins < (1ull << 30) && n_total < (1ull << 40)) {
-			const u64 cap = n_total / BR_MID + wins + 16;
+			static const u64 cap_limit = [] { /* tests: a list too short for the group's buckets — the plan is dropped, the group comes back through LSD passes */
+				const char *e = getenv("KMC_HIP_ARENA_CAP");
+				return e ? (u64)strtoull(e, nullptr, 10) : ~0ull;
+			}();
+			const u64 cap = std::min<u64>(n_total / BR_MID + wins + 16, cap_limit);
 			const u64 max_tiles = (std::min<u64>(n_total, AR_MAX_RECORDS) + RsCfg<1>::TILE - 1) / RsCfg<1>::TILE;
 			u32 obits = 0;
 			while (obits < 32 && (1ull << obits) < cap)

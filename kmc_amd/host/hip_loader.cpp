@@ -217,6 +217,12 @@ struct HipEngine : KmcBinEngine {
 			fprintf(stderr, "[kmc_hip] init %.3f s; %lld bins (%lld calls with several bins), %.3f s inside the engine (sum over workers), %.1f MB in, %.1f MB out, %lld k-mers\n",
 			        g_ns_init.load() * 1e-9, g_n_bins.load(), g_n_group_calls.load(), g_ns_bins.load() * 1e-9, g_bytes_in.load() / 1e6, g_bytes_out.load() / 1e6,
 			        g_kmers.load());
+		int (*hb_times)(double *) = nullptr;
+		std::string ignore;
+		double t[8];
+		if (getenv("KMC_HIP_VERBOSE") && g_engines == 0 && g_api.so && sym(g_api.so, "kmc_hip_host_boundary_times", hb_times, ignore) && hb_times(t) == 0)
+			fprintf(stderr, "[kmc_hip host boundary] %.0f calls (%.0f redo rounds); seconds summed over workers: pack starts + buffers %.3f, staging copy in %.3f, enqueue %.3f, "
+			                "wait for the kernels %.3f, D2H of the results %.3f, staging copy out %.3f\n", t[6], t[7], t[0], t[1], t[2], t[3], t[4], t[5]);
 	}
 	int process_bin(const kmc_hip_bin_params &p, const uint8_t *sk, uint64_t size, uint64_t n_rec, const uint64_t *pack_bytes,
 	                uint64_t n_packs, uint8_t *out, uint64_t cap, uint64_t *out_bytes, uint64_t *lut, uint64_t stats[4]) override

@@ -368,7 +368,7 @@ def test_sort_and_bin_cross_portion_boundaries(monkeypatch):
 
 
 # ------------------------------------------------------------------------------------------------ many bins in one call
-def _run_batch(ctx, p, bins, n_streams=0, shrink_cap_of=None):
+def _run_batch(ctx, p, bins, n_streams=0, shrink_cap_of=None, dev=0):
     """bins: list of (image, n_rec, pack_bytes, ...). Uploads everything, ONE kmc_hip_process_bins_device call, returns per bin
     (out bytes array, lut array, stats[4])."""
     rec = ctx.out_rec_bytes(p)
@@ -382,37 +382,37 @@ def _run_batch(ctx, p, bins, n_streams=0, shrink_cap_of=None):
         cap = ((nrec + 1) // max(p.cutoff_min, 1)) * rec
         if shrink_cap_of is not None and i == shrink_cap_of:
             cap = rec  # room for one record only
-        d_in = ctx.malloc(img.size + 256)
-        d_ps = ctx.malloc(ps.nbytes)
-        d_out = ctx.malloc(cap + 256)
-        d_lut = ctx.malloc(max(nl, 1) * 8)
-        d_small = ctx.malloc(64)
-        ctx.h2d(d_in, np.concatenate([img, np.zeros(256, dtype=np.uint8)]))
-        ctx.h2d(d_ps, ps)
+        d_in = ctx.malloc(img.size + 256, dev)
+        d_ps = ctx.malloc(ps.nbytes, dev)
+        d_out = ctx.malloc(cap + 256, dev)
+        d_lut = ctx.malloc(max(nl, 1) * 8, dev)
+        d_small = ctx.malloc(64, dev)
+        ctx.h2d(d_in, np.concatenate([img, np.zeros(256, dtype=np.uint8)]), dev)
+        ctx.h2d(d_ps, ps, dev)
         allocs.append((d_in, d_ps, d_out, d_lut, d_small))
         caps.append(cap)
         descs[i] = capi.BinDesc(d_in, img.size, nrec, d_ps, packs.size, d_out, cap, d_small + 32, d_lut, d_small)
     err = None
     try:
-        ctx.process_bins_device(p, descs, n_streams)
-        ctx.synchronize()
+        ctx.process_bins_device(p, descs, n_streams, dev)
+        ctx.synchronize(dev)
     except capi.KmcHipError as e:
         err = e
     out = []
     for i in range(n):
         small = np.zeros(8, dtype=np.uint64)
-        ctx.d2h(small, allocs[i][4])
+        ctx.d2h(small, allocs[i][4], dev)
         ob = int(small[4])
         o = np.zeros(min(ob, caps[i]), dtype=np.uint8)
         if o.size:
-            ctx.d2h(o, allocs[i][2])
+            ctx.d2h(o, allocs[i][2], dev)
         lut = np.zeros(max(nl, 1), dtype=np.uint64)
         if nl:
-            ctx.d2h(lut, allocs[i][3])
+            ctx.d2h(lut, allocs[i][3], dev)
         out.append((o, lut[:nl], small[:4].copy()))
     for a in allocs:
         for d in a:
-            ctx.free(d)
+            ctx.free(d, dev)
     return out, err
 
 
@@ -611,12 +611,75 @@ def test_two_devices_worker_allreduce_and_wide_records(ref_bins, tmp_path):
         assert _md5(str(tmp_path / ("ref" + ext))) == _md5(str(tmp_path / ("hip" + ext))), ext
 
 
+def test_eight_logical_devices_run_their_lpt_shards_concurrently_and_reduce_the_tallies():
+    """configs[3]'s control flow without the hardware: a context that names device 0 EIGHT times — every logical device has its own streams, slots and
+    buffers, exactly as eight physical devices would —, 64 signature bins sharded over them by LPT on their k-mer counts (kmc_amd/sharding.py, the order KMC hands bins to
+    sorters: queues.h:499-558, :2045-2146), one host thread per logical device running its shard through kmc_hip_process_bins_device at the same time as the seven others,
+    then kmc_hip_allreduce_stats over the eight members. Every bin byte-equal to the SAME bin from a one-device context, per-device tallies summing to the one-device
+    totals. RCCL may refuse a communicator that names one physical device more than once: then the reduce leg says so (the tallies are summed on the host for the check) —
+    the collective itself runs on two real devices in test_two_devices_worker_allreduce_and_wide_records."""
+    import threading
+
+    from kmc_amd import sharding
+
+    bins = capi.synth_bins(seed=11, genome_len=3_000_000, n_reads=600_000, k=27, n_bins=64, n_threads=4)
+    p = hp(27, lut_prefix_len=5)
+    c1 = capi.Context((0,))
+    try:
+        want, err = _run_batch(c1, p, bins, 0)
+        assert err is None, err
+    finally:
+        c1.close()
+    shards = sharding.lpt_assign([b[1] for b in bins], 8)
+    assert sorted(i for sh in shards for i in sh) == list(range(64)) and all(shards)
+    loads = [sum(bins[i][1] for i in sh) for sh in shards]
+    assert max(loads) <= 1.15 * (sum(loads) / 8), loads  # LPT on 64 near-equal bins: a few per cent of imbalance
+    c8 = capi.Context((0,) * 8)
+    try:
+        got, errs = [None] * 64, [None] * 8
+        gate = threading.Barrier(8)
+
+        def rank(r):
+            try:
+                gate.wait(timeout=60)  # all eight enter the library together
+                outs, e = _run_batch(c8, p, [bins[i] for i in shards[r]], 0, dev=r)
+                if e is not None:
+                    raise e
+                for i, o in zip(shards[r], outs):
+                    got[i] = o
+            except Exception as e:  # noqa: BLE001
+                errs[r] = repr(e)
+
+        ths = [threading.Thread(target=rank, args=(r,)) for r in range(8)]
+        for t in ths:
+            t.start()
+        for t in ths:
+            t.join()
+        assert errs == [None] * 8, errs
+        for i in range(64):
+            assert all(np.array_equal(a, b) for a, b in zip(got[i], want[i])), i
+        per_dev = np.array([np.sum([got[i][2] for i in shards[r]], axis=0, dtype=np.uint64) for r in range(8)], dtype=np.uint64)
+        total = np.sum([w[2] for w in want], axis=0, dtype=np.uint64)
+        assert np.array_equal(per_dev.sum(axis=0, dtype=np.uint64), total)
+        try:
+            red = c8.allreduce_stats(per_dev)
+            assert all(np.array_equal(red[r], total) for r in range(8)), (red, total)
+            print("kmc_hip_allreduce_stats over 8 logical devices of one GPU: ok")
+        except capi.KmcHipError as e:
+            # an 8-member communicator over ONE physical device: RCCL's own rule, not this library's (ncclCommInitAll rejects duplicate devices)
+            assert "nccl" in str(e).lower(), e
+            print("kmc_hip_allreduce_stats over 8 logical devices of one GPU refused by RCCL:", e)
+    finally:
+        c8.close()
+
+
 # ------------------------------------------------------------------------------------------------ k_bucket_rank (default path of one-word k-mers)
 def test_rank_path_takes_repeats_in_chunks_giant_buckets_on_their_own_and_hands_an_enormous_one_back(ctx):
     """default mode: the top bytes through HBM, tiles ranked and counted inside LDS by k_bucket_rank. (The many-bins tests above run this path on ordinary
     data.) Here: every k-mer ~1600 times — buckets longer than the room at the end of a window, tiles longer than the capacity, taken in chunks of whole
-    buckets; then one k-mer more often than a tile holds records (8000 times; k = 27, 55, 127) — the tile is sorted by k_giant_tiles, nothing comes back; then
-    one k-mer more than a million times — the group is run again with LSD passes."""
+    buckets (one-word records since round 6: buckets beyond BR_MID records go through the arena); then one k-mer more often than a tile holds records (8000 times;
+    k = 27: the arena; k = 55, 127: k_giant_tiles) — nothing comes back; then one k-mer more than a million times — one-word records: the arena takes a bucket of any
+    length, nothing comes back; two-word records: the bin is run again with LSD passes."""
     small = capi.backend_kind() != 0  # the emulated host library: the paths, not the scale (GT_MAX_RECORDS is 2048 there)
     p = hp(27)
     bins = capi.synth_bins(seed=3, genome_len=6000 if not small else 2000, n_reads=80_000 if not small else 1000, k=27, n_bins=4, err=0.0)
@@ -640,13 +703,20 @@ def test_rank_path_takes_repeats_in_chunks_giant_buckets_on_their_own_and_hands_
     t2, g1 = ctx.local_sort_totals(), ctx.path_counters()
     assert t2["hybrid_groups"] > t1["hybrid_groups"] and t2["redo_groups"] == t1["redo_groups"], (t1, t2)
     assert g1["giant_tiles"] >= g0["giant_tiles"] + 4 and g1["giant_records"] > g0["giant_records"], (g0, g1)
-    bins = capi.synth_bins(seed=5, genome_len=160, n_reads=1_300_000 if not small else 2600, k=27, n_bins=2, err=0.0)
-    got, err = _run_batch(ctx, p, bins, 1)
-    assert err is None, err
-    for i, (img, nrec, packs, _) in enumerate(bins):
-        w = O.process_bin(op(p), img, nrec)
-        assert all(np.array_equal(a, b) for a, b in zip(got[i], w)), i
-    assert ctx.local_sort_totals()["redo_groups"] > t2["redo_groups"]
+    arena = os.environ.get("KMC_HIP_ARENA", "1") != "0"
+    for k, comes_back in ((27, not arena), (55, True)):
+        pk = hp(k)
+        before, g2 = ctx.local_sort_totals()["redo_groups"], ctx.path_counters()
+        bins = capi.synth_bins(seed=5, genome_len=160 if k == 27 else 190, n_reads=1_300_000 if not small else 2600, k=k, n_bins=2, err=0.0)
+        got, err = _run_batch(ctx, pk, bins, 1)
+        assert err is None, err
+        for i, (img, nrec, packs, _) in enumerate(bins):
+            w = O.process_bin(op(pk), img, nrec)
+            assert all(np.array_equal(a, b) for a, b in zip(got[i], w)), (k, i)
+        assert (ctx.local_sort_totals()["redo_groups"] > before) == comes_back, (k, comes_back)
+        if not comes_back:
+            g3 = ctx.path_counters()
+            assert g3["giant_records"] - g2["giant_records"] > (2_000_000 if not small else 2000), (g2, g3)
 
 
 # ------------------------------------------------------------------------------------------------ several bins per host-boundary call
@@ -1047,24 +1117,69 @@ def test_order_database_matches_kmc_tools_transform_sort(ctx, flags, ref_bins, t
     assert np.array_equal(out, want_recs), _first_diff(out, want_recs)
 
 
-def test_collapsing_finisher_stays_correct_behind_its_switch():
-    """KMC_HIP_RANK_COLLAPSE=1 (read once per process) selects k_bucket_rank_c — a row's copies folded into weighted entries before anything is ranked (round 5; not the
-    default: on 30x data it costs more than it saves) — instead of k_bucket_rank<SIZE, true>: the switch must keep selecting a correct kernel — the smoke
-    check (reference golden bins + synthetic k = 27 / 55 bins against the oracle) and a repeat-rich bin set in a process of its own."""
+ARENA_CASES = [
+    # (KMC_SYNTH_REPEATS, k, params, giant buckets expected): buckets of copies x 30 records
+    ("3000:20:5", 27, dict(lut_prefix_len=3), False),                              # ~600: dense buckets that fit a tile (kind 1: sorted in the arena, written back, ranked in place)
+    ("2000:60:0,3000:13:0", 27, dict(lut_prefix_len=3), False),                    # ~1800 and ~390 (just beyond BR_MID)
+    ("1000:150:10", 27, dict(lut_prefix_len=7, cutoff_min=1), False),              # ~4500: most of a tile
+    ("2000:300:10", 27, dict(lut_prefix_len=3), False),                            # up to ~9000 (the copies diverge: most buckets still fit a tile)
+    ("300:1500:5,5000:6:0", 27, dict(lut_prefix_len=3, cutoff_max=3000, counter_max=255), True),  # ~45 000: giant buckets (kind 0: counted from the arena, segment by segment), clamped counters, a cutoff_max inside the giant runs
+    ("171:40000:20,H20000", 27, dict(lut_prefix_len=3), True),                     # a satellite (> 2^20 copies of its k-mers: no bin comes back) and a poly-A run
+    ("300:1500:5,3000:20:5", 27, dict(lut_prefix_len=0, output_type=1), True),    # KFF records (no LUT: the suffix reaches up to the k-mer's top)
+    ("300:1500:5,3000:20:5", 27, dict(lut_prefix_len=3, without_output=1), True), # tallies only
+    ("300:1500:5,3000:20:5", 27, dict(lut_prefix_len=3, both_strands=0), True),   # forward strand only
+    ("300:1500:5,3000:20:5", 32, dict(lut_prefix_len=4), True),                   # 32 key bits below the passes: a 5-byte arena key, 64-bit pairs in the tiles
+    ("300:1500:5,3000:20:5", 25, dict(lut_prefix_len=1), True),                   # 6 spare bits: 16 bins per group, the tag rides in the bucket number
+    ("300:1500:5,3000:20:5", 21, dict(lut_prefix_len=1), True),                   # 42-bit keys: 10 bits below the four passes
+]
+
+
+@pytest.mark.parametrize("repeats,k,kw,giant", ARENA_CASES, ids=lambda v: str(v).replace(" ", "") if not isinstance(v, dict) else "-".join(f"{a}{b}" for a, b in v.items()))
+def test_arena_sorts_the_repeat_rich_buckets_of_one_word_records(repeats, k, kw, giant, monkeypatch):
+    """Round 6 (arena_sort.hip.h): every bucket beyond BR_MID records of a group of one-word records — found by k_bucket_detect's samples — is sorted by HBM passes of its own over
+    (entry ordinal, key bits below the bucket bits); buckets that fit a tile come back in place before k_bucket_rank runs, giant ones are counted from the arena. Per bin
+    against the oracle; no group and no bin may come back for LSD passes, whatever the length of a bucket."""
+    monkeypatch.setenv("KMC_SYNTH_REPEATS", repeats)
+    bins = capi.synth_bins(seed=3, genome_len=200_000, n_reads=40_000, k=k, n_bins=16 if k == 25 else 4, n_threads=4)
+    monkeypatch.delenv("KMC_SYNTH_REPEATS")
+    ctx = capi.Context((0,))
+    try:
+        p = capi.make_params(k, **kw)
+        op_ = O.make_params(p.kmer_len, p.both_strands, p.cutoff_min, p.cutoff_max, p.counter_max, p.lut_prefix_len, p.output_type, p.without_output)
+        t0, c0 = ctx.local_sort_totals(), ctx.path_counters()
+        got, err = _run_batch(ctx, p, bins, 1)
+        assert err is None, err
+        for i, (img, nrec, packs, _) in enumerate(bins):
+            w = O.process_bin(op_, img, nrec)
+            assert np.array_equal(got[i][2], w[2]), (repeats, i, got[i][2], w[2])
+            assert np.array_equal(got[i][0], w[0]) and np.array_equal(got[i][1], w[1]), (repeats, i)
+        t1, c1 = ctx.local_sort_totals(), ctx.path_counters()
+        assert t1["redo_groups"] == t0["redo_groups"] and c1["rank_count"] > c0["rank_count"] and c1["lsd"] == c0["lsd"], (t0, t1, c0, c1)
+        if giant:
+            assert c1["giant_tiles"] > c0["giant_tiles"], (c0, c1)
+    finally:
+        ctx.close()
+
+
+def test_arena_that_cannot_take_its_buckets_sends_the_group_back_and_the_old_finisher_stays_selectable():
+    """KMC_HIP_ARENA_CAP=3 (read once per process): the list of buckets overflows, k_arena_plan drops the plan, k_bucket_rank reports nothing for the group and the host runs it
+    again with LSD passes over every byte — results equal to the oracle's. KMC_HIP_ARENA=0: round 5's finisher (big buckets walked by the whole workgroup, k_giant_tiles)."""
     import subprocess
     import sys
 
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    code = ("import os, sys, numpy as np; sys.path.insert(0, 'tests'); import __graft_entry__ as g; g.smoke();"
+    code = ("import os, sys, numpy as np; sys.path.insert(0, 'tests');"
             "import oracle_py as O; from kmc_amd import capi; from test_gpu_parity import _run_batch;"
             "ctx = capi.Context((0,));"
-            "os.environ['KMC_SYNTH_REPEATS'] = '300:400:100,2000:60:10,H3000';"
+            "os.environ['KMC_SYNTH_REPEATS'] = '300:400:100,2000:60:10,2000:300:10,H3000';"
             "bins = capi.synth_bins(seed=9, genome_len=400_000, n_reads=120_000, k=27, n_bins=8);"
             "p = capi.make_params(27, lut_prefix_len=3); got, err = _run_batch(ctx, p, bins, 1); assert err is None, err;"
             "ok = all(all(np.array_equal(a, b) for a, b in zip(got[i], O.process_bin(O.make_params(27, lut_prefix_len=3), img, nrec))) for i, (img, nrec, pk, _) in enumerate(bins));"
-            "print('repeats', ok, ctx.path_counters())")
-    r = subprocess.run([sys.executable, "-c", code], cwd=root, env=dict(os.environ, KMC_HIP_RANK_COLLAPSE="1"), capture_output=True, text=True, timeout=600)
-    assert r.returncode == 0 and "smoke OK" in r.stdout and "repeats True" in r.stdout, (r.stdout + r.stderr)[-1500:]
+            "print('repeats', ok, 'redo', ctx.local_sort_totals()['redo_groups'], ctx.path_counters())")
+    for env, redo in (({"KMC_HIP_ARENA_CAP": "3"}, True), ({"KMC_HIP_ARENA": "0"}, False)):
+        r = subprocess.run([sys.executable, "-c", code], cwd=root, env=dict(os.environ, **env), capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0 and "repeats True" in r.stdout, (env, (r.stdout + r.stderr)[-1500:])
+        assert (int(r.stdout.split("redo ")[1].split()[0]) > 0) == redo, (env, r.stdout[-400:])
 
 
 @pytest.mark.parametrize("repeats", ["5000:6:0", "5000:9:0", "1000:100:10", "2000:40:5,300:230:0,H2000"])

@@ -188,12 +188,12 @@ for k, nb, kw in ((27, 5, dict(lut_prefix_len=3)), (32, 3, dict(lut_prefix_len=4
     h, r, c = check(k, capi.synth_bins(seed=7, genome_len=2500, n_reads=300, k=k, n_bins=nb, n_threads=1), **kw)
     assert h >= 1 and r == 0 and c["rank_count"] >= 1 and c["rank_compact"] == c["bucket_count"] == 0, (k, h, r, c)
 import os
-SUBSET = os.environ.get("KMC_TEST_RANK_SUBSET") == "1"  # the kernel behind the switch: the one-word cases above + the repeats and giant tiles of one-word records
+ARENA = os.environ.get("KMC_HIP_ARENA", "1") != "0"  # round 6 (one-word records): buckets beyond BR_MID records through arena_sort.hip.h; 0: round 5's finisher
 # records that may outgrow a tile's span (k = 32 without a LUT prefix: 8 suffix bytes + a 4-byte counter): ranked in place, then k_compact
 h, r, c = check(32, capi.synth_bins(seed=7, genome_len=2500, n_reads=300, k=32, n_bins=3, n_threads=1), lut_prefix_len=0, cutoff_max=100000, counter_max=70000)
 assert c["rank_compact"] >= 1 and c["rank_count"] == 0, c
 # wider records: two words (A/B pairs, rem <= 80 bits; k = 64: six HBM passes instead of sixteen), KFF, three and more words (whole records compared)
-for k, nb, kw in (((55, 4, dict(lut_prefix_len=3)), (127, 4, dict(lut_prefix_len=3))) if SUBSET else
+for k, nb, kw in (((55, 4, dict(lut_prefix_len=3)), (127, 4, dict(lut_prefix_len=3))) if not ARENA else
                   ((55, 4, dict(lut_prefix_len=3)), (40, 3, dict(lut_prefix_len=4, cutoff_min=1)), (64, 1, dict(lut_prefix_len=4)), (55, 4, dict(lut_prefix_len=0, output_type=1)),
                    (127, 4, dict(lut_prefix_len=3)), (70, 3, dict(lut_prefix_len=2, both_strands=0)), (200, 2, dict(lut_prefix_len=4)))):
     h, r, c = check(k, capi.synth_bins(seed=7, genome_len=2500, n_reads=250, k=k, n_bins=nb, n_threads=1, read_len=max(150, k + 40)), **kw)
@@ -201,30 +201,41 @@ for k, nb, kw in (((55, 4, dict(lut_prefix_len=3)), (127, 4, dict(lut_prefix_len
     # two words and more with FOUR HBM passes (k = 40, 200: five — bits above the key in the top byte; k = 64: six): the passes move (key top, record number) pairs of
     # 8 bytes, the records stay where k_expand wrote them and k_bucket_rank gathers them by number
     assert (c["indirect"] >= 1) == (k in (55, 127, 70)), (k, c)
-# every k-mer a few hundred times: buckets longer than the room at the end of a window, tiles longer than the capacity -> taken in chunks, nothing comes back
+# every k-mer a few hundred times: buckets longer than the room at the end of a window, tiles longer than the capacity -> taken in chunks (one-word records with the arena:
+# buckets beyond BR_MID — 192 in this build — sorted there and written back), nothing comes back
 for k, glen, err in ((27, 2000, 0.0), (27, 600, 0.002), (55, 1500, 0.0)):
     h, r, c = check(k, capi.synth_bins(seed=3, genome_len=glen, n_reads=700, k=k, n_bins=4, err=err, n_threads=1), lut_prefix_len=3)
     assert h >= 1 and r == 0, (k, glen, h, r)
-# one k-mer more often than a tile holds records (also with read errors around it; two- and three-word records): the tile goes to k_giant_tiles, nothing comes back
-for k, kw, err in (((27, dict(lut_prefix_len=3, cutoff_min=1), 0.01),) if SUBSET else
+# one k-mer more often than a tile holds records (also with read errors around it; two- and three-word records): k_giant_tiles / the arena's giant segments, nothing comes back
+for k, kw, err in (((27, dict(lut_prefix_len=3, cutoff_min=1), 0.01),) if not ARENA else
                    ((27, dict(lut_prefix_len=3, cutoff_min=1), 0.01), (55, dict(lut_prefix_len=3), 0.0), (70, dict(lut_prefix_len=0, output_type=1), 0.0))):
     h, r, c = check(k, capi.synth_bins(seed=5, genome_len=300, n_reads=1500, k=k, n_bins=2, err=err, n_threads=1), **kw)
     assert h >= 1 and r == 0 and c["giant_tiles"] >= 1, (k, h, r, c)
-# ... and more often than k_giant_tiles takes (GT_MAX_RECORDS: 2048 in this build): the group comes back for LSD passes
+# ... and more often than k_giant_tiles takes (GT_MAX_RECORDS: 2048 in this build): round 5's finisher sends the bins back for LSD passes; the arena takes a bucket of any length
 h, r, c = check(27, capi.synth_bins(seed=5, genome_len=160, n_reads=2600, k=27, n_bins=2, err=0.0, n_threads=1), lut_prefix_len=3)
-assert r >= 1, (h, r)
+assert (r >= 1) == (not ARENA) and (not ARENA or c["giant_records"] > 100000), (h, r, c)
+if ARENA:
+    # repeat families, a satellite and a poly-A run in one group: buckets of every size class at once; KFF; clamped counters and a cutoff_max inside the giant runs; k = 32
+    os.environ["KMC_SYNTH_REPEATS"] = "300:40:10,60:400:0,H500"
+    b = capi.synth_bins(seed=9, genome_len=20000, n_reads=3000, k=27, n_bins=3, n_threads=1)
+    del os.environ["KMC_SYNTH_REPEATS"]
+    for kw in (dict(lut_prefix_len=3), dict(lut_prefix_len=0, output_type=1), dict(lut_prefix_len=3, cutoff_max=50, counter_max=7)):
+        h, r, c = check(27, b, **kw)
+        assert r == 0 and c["giant_tiles"] >= 1, (kw, h, r, c)
+    h, r, c = check(32, capi.synth_bins(seed=5, genome_len=300, n_reads=1500, k=32, n_bins=2, err=0.01, n_threads=1), lut_prefix_len=4)
+    assert r == 0 and c["giant_tiles"] >= 1, (h, r, c)
 print("RANK-OK")
 '''
 
 
-@pytest.mark.parametrize("collapse", ["1", "0"], ids=["k_bucket_rank_c", "k_bucket_rank"])
-def test_rank_path_on_the_emulated_host_library(collapse):
-    """k_bucket_rank_c (round 5's default: a row's copies folded into weighted entries before anything is ranked) and k_bucket_rank (round 4's, KMC_HIP_RANK_COLLAPSE=0)
-    (bucket_sort.hip.h) on the CPU, as a default run takes them: groups of k-mers of every record width through the HBM passes, k_bucket_bounds,
-    the pairwise ranking of every tile (32- and 64-bit pairs, A/B pairs of two-word records, whole records beyond) and the counting of the ranked tile inside
-    LDS (fused), chunked tiles, the in-place variant + k_compact — per bin against the oracle; and the redo of a group with a bucket beyond a tile."""
+@pytest.mark.parametrize("arena", ["1", "0"], ids=["arena", "round-5-finisher"])
+def test_rank_path_on_the_emulated_host_library(arena):
+    """k_bucket_rank (bucket_sort.hip.h) and, for one-word records, the arena of the repeat-rich buckets (arena_sort.hip.h: k_bucket_detect, k_arena_plan / _gather, k_onesweep_dyn,
+    k_arena_finish; KMC_HIP_ARENA=0: round 5's finisher — big buckets walked by the whole workgroup, k_giant_tiles, bins with an enormous bucket sent back) on the CPU, as a default
+    run takes them: groups of k-mers of every record width through the HBM passes, k_bucket_bounds, the pairwise ranking of every tile (32- and 64-bit pairs, A/B pairs of two-word
+    records, whole records beyond) and the counting of the ranked tile inside LDS (fused), chunked tiles, the in-place variant + k_compact — per bin against the oracle."""
     lib = emu.build_hostlib("small")
-    r = subprocess.run([sys.executable, "-c", _RANK_CASE % {"root": ROOT}], env=dict(os.environ, KMC_HIP_LIB=lib, KMC_HIP_RANK_COLLAPSE=collapse, KMC_TEST_RANK_SUBSET=collapse),
+    r = subprocess.run([sys.executable, "-c", _RANK_CASE % {"root": ROOT}], env=dict(os.environ, KMC_HIP_LIB=lib, KMC_HIP_ARENA=arena),
                        capture_output=True, text=True, timeout=1500, cwd=ROOT)
     assert r.returncode == 0 and "RANK-OK" in r.stdout, (r.stdout + r.stderr)[-1500:]
 

@@ -17,8 +17,8 @@ BUDGET = {
     "k_expand<1, true>": (0, 8), "k_expand<2, true>": (0, 8), "k_expand<4, true>": (0, 8),  # four workgroups of 512 per CU (LDS: 39 KB at k = 27)
     "k_parse_packs": (0, 7),  # one wave per pack, 5.7 KB of LDS each: 28 per CU either way
     "k_bucket_bounds<1>": (0, 8), "k_compact_fold": (0, 4), "k_compact_gather": (0, 8),
-    # behind KMC_HIP_RANK_COLLAPSE=1 (round 5: measured slower than k_bucket_rank on 30x data): known spills, must not grow
-    "k_bucket_rank_c<1>": (32, 6), "k_bucket_rank_c<2>": (0, 6), "k_bucket_rank_c<4>": (0, 6),
+    # round 6: the arena of the repeat-rich buckets (arena_sort.hip.h). With nothing listed its launches return at once; the pass kernel is k_onesweep<1>'s tile body in a loop
+    "k_bucket_detect": (0, 8), "k_arena_plan": (0, 8), "k_arena_gather": (0, 8), "k_arena_finish": (0, 4), "k_onesweep_dyn<1>": (24, 8),
     # off the default path since round 4 (redo / LSD runs; KMC_HIP_RANK=0): known spills, must not grow
     "k_compact<1>": (124, 8), "k_compact<2>": (60, 4), "k_bucket_count<1>": (56, 8), "k_bucket_count<2>": (16, 8),
 }
