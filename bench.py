@@ -37,6 +37,8 @@ Keys of the N=1 record (each measured after the timed region, none inside it):
   moved_bytes_per_kmer: {"pmc": from the committed rocprofv3 --pmc run of this workload (profiles/r06/pmc_hbm_traffic.json: every kernel of one step), "design": what the path
                         is designed to move}; moved_frac_of_hbm_peak likewise. Neither is a counter of THIS run (counters cannot be read from inside it); roofline.traffic idem.
   self_check.oracle_bins: 16 bins of the timed run, stratified by size, byte for byte against the oracle (one host thread per bin)
+  logical_devices     : the resident bins LPT-sharded over 8 LOGICAL devices of the one GPU (a context naming it 8 times), one enqueueing host thread each: the control flow of
+                        --gpus 8 inside one process; value ~ `value` means the scheduling around the kernels costs nothing; enqueue_ms_per_bin = host time per bin. Not a scaling number.
   e2e_large           : ONE FASTQ of --e2e-gbp Gbp (default 8): reference vs drop-in "2nd stage" in RAM-only mode, and the reference's own stage-1 bins (dumped by the drop-in's
                         worker) device-resident, tallies against the reference's statistics
   cpu_baseline / e2e  : the REAL reference (oracle/_ref/kmc, built from /root/reference by oracle/Makefile) and the drop-in
@@ -323,6 +325,64 @@ def oracle_check(ctx, w, res, n_check=16):
     return verdicts
 
 
+# ---------------------------------------------------------------------------------------------------------------- logical devices
+def logical_devices_leg(dev_index, w, n_logical, tallies, steps=2):
+    """configs[3]'s host side on ONE GPU: a context that names this GPU `n_logical` times — each logical device with streams, slots and buffers of its own,
+    as physical devices would have —, the resident bins sharded over them by LPT (kmc_amd/sharding.py), one host thread per logical device enqueueing its shard through
+    kmc_hip_process_bins_device at the same time as the others. The kernels of all shards share the one GPU, so `value` says what the scheduling around them costs (nothing, if it
+    equals the one-device value), enqueue_ms_per_bin what a bin costs its host thread; tallies must equal the timed run's. Not a scaling number."""
+    c = capi.Context((dev_index,) * n_logical)
+    try:
+        shards = sharding.lpt_assign([b[2] for b in w.bins], n_logical)
+        descs = []
+        for sh in shards:
+            arr = (capi.BinDesc * max(len(sh), 1))()
+            for j, i in enumerate(sh):
+                arr[j] = w.descs[i]
+            descs.append(arr)
+        enq = [0.0] * n_logical
+        errs = []
+
+        def rank(r):
+            try:
+                t = time.perf_counter()
+                if shards[r]:
+                    rc = c.L.kmc_hip_process_bins_device(c.h, r, C.byref(w.p), descs[r], len(shards[r]), 0)
+                    if rc:
+                        raise RuntimeError(c.L.kmc_hip_last_error(c.h).decode())
+                enq[r] += time.perf_counter() - t
+            except Exception as e:  # noqa: BLE001
+                errs.append("logical device %d: %r" % (r, e))
+
+        def step():
+            ths = [threading.Thread(target=rank, args=(r,)) for r in range(n_logical)]
+            for t in ths:
+                t.start()
+            for t in ths:
+                t.join()
+            for r in range(n_logical):
+                c.synchronize(r)
+
+        step()
+        enq = [0.0] * n_logical
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            step()
+        dt = (time.perf_counter() - t0) / steps
+        if errs:
+            return {"error": "; ".join(errs)[-400:]}
+        res = read_results(c, w)
+        got = res[:, :4].sum(axis=0, dtype=np.uint64)
+        loads = [sum(w.bins[i][2] for i in sh) for sh in shards]
+        return {"n_logical": n_logical, "value": w.total_kmers_all / dt / 1e9, "ms_per_step": dt * 1e3, "tallies_equal_timed_run": [int(x) for x in got] == [int(x) for x in tallies],
+                "enqueue_ms_per_bin": 1e3 * sum(enq) / steps / max(w.n_own, 1), "enqueue_ms_per_step_max_over_threads": 1e3 * max(enq) / steps,
+                "lpt_imbalance": max(loads) / (sum(loads) / n_logical) if sum(loads) else None,
+                "what": "the resident bins LPT-sharded over %d logical devices of this one GPU, one enqueueing host thread each (the control flow of --gpus %d inside one process); "
+                        "the kernels share the GPU: value ~ the one-device value means the scheduling costs nothing" % (n_logical, n_logical)}
+    finally:
+        c.close()
+
+
 # ---------------------------------------------------------------------------------------------------------------- host boundary
 def host_boundary_pass(ctx, w, n_threads=8, passes=2, group=1):
     """All own bins through the host boundary from PINNED host memory: thread t owns stream slots 2t, 2t+1 and keeps two calls in flight (H2D of call
@@ -491,6 +551,8 @@ def short_line(out):
     for kk in ("cpu_baseline_skew", "cpu_baseline_spectrum"):
         if isinstance(out.get(kk), dict):
             s[kk] = _pick(out[kk], ("value", "cores", "stage2_s", "input_kmers", "gpu_value_same_reads", "gpu_over_cpu", "error"))
+    if isinstance(out.get("logical_devices"), dict):
+        s["logical_devices"] = _pick(out["logical_devices"], ("n_logical", "value", "ms_per_step", "enqueue_ms_per_bin", "tallies_equal_timed_run", "lpt_imbalance", "error"))
     if isinstance(out.get("gpu_over_cpu"), dict):
         s["gpu_over_cpu"] = _pick(out["gpu_over_cpu"], ("uniform", "skew", "spectrum"))
     if isinstance(out.get("e2e"), dict):
@@ -514,7 +576,7 @@ def short_line(out):
         return o
 
     s = rnd(s)
-    for drop in ("e2e", "cpu_baseline_k127", "cpu_baseline_k55", "e2e_large", "secondary", "cpu_baseline_spectrum", "cpu_baseline_skew", "groups_by_path", "local_sort", "tallies", "per_rank"):
+    for drop in ("logical_devices", "e2e", "cpu_baseline_k127", "cpu_baseline_k55", "e2e_large", "secondary", "cpu_baseline_spectrum", "cpu_baseline_skew", "groups_by_path", "local_sort", "tallies", "per_rank"):
         if len(json.dumps(s)) < SHORT_LINE_LIMIT:
             break
         s.pop(drop, None)
@@ -791,6 +853,7 @@ def main():
     ap.add_argument("--host-probe", action="store_true", help="diagnostics: the host-boundary leg for every sort selection and call style, errors reported per leg")
     ap.add_argument("--no-host-single", action="store_true", help="skip the one-bin-per-call comparison of the host-boundary leg")
     ap.add_argument("--no-secondary", action="store_true")
+    ap.add_argument("--logical", type=int, default=8, help="after the timed region: the same bins over this many LOGICAL devices of the one GPU, one host thread each (0/1 = skip)")
     ap.add_argument("--no-full-wide", action="store_true", help="skip the full-size k = 55 / k = 127 legs (configs[4] on one GPU, ~80 s each)")
     ap.add_argument("--no-repeat-baselines", action="store_true", help="skip cpu_baseline_skew / cpu_baseline_spectrum (the reference on the skew legs' reads, ~40 s each)")
     ap.add_argument("--no-two-streams", action="store_true", help="skip the value_two_streams leg (profiling runs: keeps overlapped launches out of the kernel statistics)")
@@ -1071,6 +1134,11 @@ def main():
             ctx.scatter_totals(reset=True)
         except Exception as e:  # noqa: BLE001
             out["value_two_streams"] = repr(e)
+        if args.logical > 1 and not rehearsal:
+            try:
+                out["logical_devices"] = logical_devices_leg(dev_index, w, args.logical, tallies)
+            except Exception as e:  # noqa: BLE001
+                out["logical_devices"] = {"error": repr(e)[-400:]}
         if want_host and args.host_probe:  # diagnostics: every combination of sort selection and call style, each on its own
             probe = []
             for mode in (1, 1, 1, 0):

@@ -220,7 +220,7 @@ int kmc_hip_last_timings(kmc_hip_ctx *ctx, int dev, float ms[6]);
  * duration (HIP events around each launch, on the launch's own stream) and the records they moved — the roofline
  * input of bench.py. Waits for the device's streams. */
 int kmc_hip_scatter_totals(kmc_hip_ctx *ctx, int dev, int reset, uint64_t *n_launches, double *total_ms, uint64_t *total_records);
-/* The LDS half of the hybrid sort (k_bucket_bounds + k_bucket_sort, kmc_amd/csrc/bucket_sort.hip.h; replaces the small-bucket recursion and
+/* The LDS half of the hybrid sort (k_bucket_bounds + k_bucket_rank, kmc_amd/csrc/bucket_sort.hip.h; replaces the small-bucket recursion and
  * CSmallSort of raduls_impl.h:133-141,497-510 / small_sort.h:29-179): launches, summed duration (HIP events on the launch's stream) and records
  * since the last reset; plus, process-wide, how many groups of bins took the hybrid sort and how many of them had to be sorted again with LSD
  * passes over every byte because a bucket did not fit a tile. Any pointer may be NULL. Waits for the device's streams. */
@@ -228,13 +228,13 @@ int kmc_hip_local_sort_totals(kmc_hip_ctx *ctx, int dev, int reset, uint64_t *n_
                               uint64_t *n_hybrid_groups, uint64_t *n_redo_groups);
 /* Which sort stage 2 runs (process-wide; overrides $KMC_HIP_HYBRID; tests and tuning): 0 = 8-bit LSD passes over every key byte + k_compact (rounds 1-2);
  * 1 = default: LSD passes over the top key bytes only, then every bucket-aligned tile ranked and counted inside LDS by k_bucket_rank (round 4: every record
- * width; $KMC_HIP_RANK=0 / $KMC_HIP_RANK_FUSE=0 give round 3's k_bucket_count for k >= 33 and rank-in-place + k_compact for k <= 32); 2 = k_bucket_count for every
- * record width, and the LDS sort for sort-only calls; -h = `h` top bytes forced. Also clears the group counters of kmc_hip_local_sort_totals and
+ * width; $KMC_HIP_RANK_FUSE=0: rank-in-place + k_compact for k <= 32, LSD passes for wider records); -h = `h` top bytes forced. (2 — round 3's k_bucket_count /
+ * k_bucket_sort, which left the library in round 6 — is taken as 1.) Also clears the group counters of kmc_hip_local_sort_totals and
  * kmc_hip_path_counters. Returns the mode that was in force. */
 int kmc_hip_set_hybrid(int mode);
 /* Groups of bins (a bin on its own is a group of one) by the path their sort + compaction took, process-wide since the last kmc_hip_set_hybrid: [0] top bytes
  * through HBM, tiles ranked AND counted inside LDS (k_bucket_rank fused: the default since round 4, every record width); [1] ranked in place, then k_compact
- * (one-word records whose output may outgrow a tile's span); [2] k_bucket_count (KMC_HIP_RANK=0, mode 2, or too many key bits below the buckets); [3] 8-bit
+ * (one-word records whose output may outgrow a tile's span); [2] unused since round 6 (0; was k_bucket_count); [3] 8-bit
  * LSD passes over every key byte + k_compact (rounds 1-2; redo runs; tiny groups). With a context (ctx != NULL; waits for the device's streams): [4] tiles whose
  * largest bucket did not fit LDS and that k_giant_tiles sorted on their own (k-mers repeated thousands of times) and [5] the records in them, since the context
  * was made. [6] the groups of [0] (records of three words and more) whose HBM passes moved one word per record — the key's top four bytes above the record's

@@ -8,18 +8,19 @@
  *
  *   k_bucket_bounds   cuts the array into tiles that start and end on bucket boundaries: tile j = the buckets that START in
  *                     window [j S, (j+1) S). One wave per window finds "first bucket boundary at or after j S".
- *   k_bucket_sort     one workgroup per tile: records -> registers -> LDS, grouped by an order-preserving sub-bucket number
- *                     (every bucket of the tile cut into as many equal slices as it has records: counting with returning LDS
- *                     atomics, one scan, one placement), then every sub-bucket (a few records, or the copies of one k-mer) is finished by one thread
- *                     with an insertion sort whose fast path is "not smaller than the last one" (duplicates cost one compare);
- *                     the sorted tile is written back in place, coalesced. 8 B read + 8 B written per record, once, whatever k.
+ *   k_bucket_rank     one workgroup per tile: every record finds its place inside its bucket by counting the records of the bucket below it (pairwise, in LDS),
+ *                     and the ordered tile is counted where it lies — run lengths, cutoffs, (suffix, counter) records, LUT, tallies (below: "rank inside the
+ *                     bucket, count in place"). 8 SIZE bytes read per record, once, whatever k; the sorted tile never goes back to HBM.
+ *   k_giant_tiles     a tile whose largest bucket does not fit LDS (records of two words and more; one-word records: arena_sort.hip.h).
+ *
+ * (Rounds 3-5 also shipped k_bucket_sort — sub-buckets finished by one thread each, sort-only — and k_bucket_count — tiles counted through an LDS hash table without
+ * sorting; neither was on a default path after round 4 and both left the library in round 6: profiles/r06/experiments/removed_finishers.patch.)
  *
  * This replaces what the reference does below its first radix levels — RadulsSort's recursion into small buckets and the
  * insertion / shell sorts of CSmallSort (raduls_impl.h:133-141,497-510; small_sort.h:29-179) — with an LDS-resident equivalent.
  *
- * A tile longer than the LDS capacity (a bucket far larger than n / 2^(8H): one k-mer repeated thousands of times, or
- * adversarial input) and a tile whose sub-bucket sort exceeds its move budget set `*flag`: the host then sorts that group
- * again with LSD passes over all bytes (kmc_hip.hip: "redo"). Nothing is ever left partially sorted silently.
+ * What the kernels cannot take (a bucket beyond GT_MAX_RECORDS of records of two words and more, an arena that overflows) sets `*flag`: the host then sorts that
+ * bin or group again with LSD passes over all bytes (host_plan_and_groups.hip.h: "redo"). Nothing is ever left partially sorted silently.
  *
  * Contract (SortFunction, kb_sorter.h:761-775): the bytes of a record above the key are zero, so comparing whole records
  * orders them by the key.
@@ -29,12 +30,6 @@
 
 #include "kernels.hip.h"
 
-#ifndef BS_BLOCK_THREADS
-#define BS_BLOCK_THREADS 768 /* 12 waves; two workgroups per CU at 72 KB of LDS each (records 48 KB + one counter per record slot) */
-#endif
-#ifndef BS_WORDS_PER_THREAD
-#define BS_WORDS_PER_THREAD 8 /* 8-byte words a thread holds while a tile is loaded */
-#endif
 #ifndef BR_NARROW_LOOP
 #define BR_NARROW_LOOP 2 /* k_bucket_rank's walk over 32-bit pairs: 2 = steps of 8 / 4 / one masked step (shipped); 0 = the walk of rounds 3-5 (tools/build_variants.py brnl0) */
 #endif
@@ -55,25 +50,6 @@
 #ifndef BR_MIN_WAVES
 #define BR_MIN_WAVES 6 /* waves per SIMD the register allocator must leave room for: two workgroups of 12 waves per CU (<= 80 VGPRs; it takes 62) */
 #endif
-#ifndef BS_MOVE_LIMIT
-#define BS_MOVE_LIMIT 4096 /* record moves one thread may spend on its sub-buckets before the tile is handed back to the host */
-#endif
-
-template <int SIZE> struct BsCfg {
-	static constexpr int THREADS = BS_BLOCK_THREADS;
-	static constexpr int ITEMS = (BS_WORDS_PER_THREAD / SIZE) > 2 ? (BS_WORDS_PER_THREAD / SIZE) : 2;
-	static constexpr int CAP = THREADS * ITEMS;   /* records a tile may hold */
-	static constexpr int STRIDE = CAP / 3 * 2;    /* window length S: a tile is S records on average, CAP - S of slack for its last bucket */
-	static_assert(CAP < 65536, "tile-relative positions are kept in 16 bits");
-};
-template <int SIZE> constexpr size_t bs_lds_bytes()
-{
-	return (size_t)BsCfg<SIZE>::CAP * SIZE * 8 + ((size_t)BsCfg<SIZE>::CAP + 1) * 4 + (3 * (BsCfg<SIZE>::THREADS / 64) + 2) * 4 + 16;
-}
-/* average bucket size the host aims for when it picks H: two orders of magnitude below the slack, because k-mers that share a
- * minimizer are clustered (measured on the bench's bins: the largest of 2^22 buckets holds 100x the average) */
-template <int SIZE> constexpr u64 bs_target_bucket() { return (BsCfg<SIZE>::CAP - BsCfg<SIZE>::STRIDE) / 64 > 4 ? (BsCfg<SIZE>::CAP - BsCfg<SIZE>::STRIDE) / 64 : 4; }
-
 /* the top 64 bits of the key (key_bits = 8 * key bytes, bits [key_bits-1 : 0] of the record), left-aligned */
 template <int SIZE> __device__ __forceinline__ u64 bs_p64(const u64 (&x)[SIZE], u32 key_bits)
 {
@@ -168,221 +144,13 @@ __global__ void __launch_bounds__(256) k_bucket_bounds(const GrpBounds gb, u32 s
 		gb.bounds[bin][j] = b;
 }
 
-/* One workgroup per window j: sorts tile [bounds[j], bounds[j+1]) in place (empty when no bucket starts in the window).
- *
- * Sub-buckets. K-mers of a signature bin are clustered (those that START with the bin's minimizers share 18+ bits: measured on the bench's
- * bins, half of all records sit in buckets of more than 3x the average size), so cutting the tile's key range into equal slices leaves
- * hundreds of distinct keys in one slice and none in most. Instead every bucket of the tile — a run of n_b records at tile positions
- * [s, s + n_b), known from the bucket boundaries inside the tile — gets n_b counters of its own, [s, s + n_b), and a record goes to
- *       id = s + floor(rem32 * n_b / 2^32)           rem32 = the 32 key bits below the bucket bits
- * which is order-preserving, needs no table, and adapts to the density: one distinct key per counter on average wherever the bits below the
- * bucket bits are uniform (they are: the clustering comes from the minimizer, and that sits in the bits above). */
-template <int SIZE>
-__global__ void __launch_bounds__(BsCfg<SIZE>::THREADS) k_bucket_sort(u64 *__restrict__ recs, u32 key_bits, u32 hbits, const u64 *__restrict__ bounds, u32 *flag)
-{
-	constexpr int THREADS = BsCfg<SIZE>::THREADS, ITEMS = BsCfg<SIZE>::ITEMS, CAP = BsCfg<SIZE>::CAP, NW = THREADS / 64;
-	constexpr u64 S = BsCfg<SIZE>::STRIDE;
-	constexpr u32 NONE = 0xFFFFFFFFu;
-	KMC_DYN_LDS(unsigned char, s_raw);
-	u64 *s_rec = reinterpret_cast<u64 *>(s_raw);                      /* [CAP * SIZE] record-major */
-	u32 *s_cnt = reinterpret_cast<u32 *>(s_rec + (size_t)CAP * SIZE); /* [CAP + 1] counts -> first slot of each sub-bucket */
-	u32 *s_tmp = s_cnt + CAP + 1;                                     /* [NW + 1] scan scratch */
-	u32 *s_wfirst = s_tmp + NW + 1, *s_wlast = s_wfirst + NW;         /* [NW] each: first / last bucket start inside wave w's rows */
-	u32 *s_fail = s_wlast + NW;
-
-	const u64 j = blockIdx.x;
-	const u64 b0 = bounds[j], b1 = bounds[j + 1];
-	if (b0 >= (j + 1) * S || b0 >= b1)
-		return; /* no bucket starts in this window */
-	if (b1 - b0 > (u64)CAP) {
-		if (threadIdx.x == 0)
-			atomicOr(flag, 1u); /* a bucket (or two) far beyond the expected size: the host sorts this group again with LSD passes */
-		return;
-	}
-	const u32 len = (u32)(b1 - b0);
-	const u32 tid = threadIdx.x, lane = tid & 63;
-	const u32 wave = (u32)__builtin_amdgcn_readfirstlane((int)(tid >> 6));
-	u64 *__restrict__ T = recs + b0 * SIZE;
-	const u32 crel = wave * (ITEMS * 64); /* the wave owns ITEMS rows of 64 consecutive records */
-
-	for (u32 i = tid; i <= (u32)CAP; i += THREADS)
-		s_cnt[i] = 0;
-	if (tid == 0)
-		*s_fail = 0;
-	u64 key[ITEMS][SIZE];
-#pragma unroll
-	for (int r = 0; r < ITEMS; ++r) {
-		const u32 idx = crel + r * 64 + lane;
-		if (idx < len)
-			load_rec<SIZE>(T + (size_t)idx * SIZE, key[r]);
-		else {
-#pragma unroll
-			for (int w = 0; w < SIZE; ++w)
-				key[r][w] = 0;
-		}
-	}
-	/* bucket starts ("heads") as one scalar mask per row */
-	const u32 bsh = 64 - hbits;
-	auto bucket_of = [&](const u64(&x)[SIZE]) -> u64 { return hbits ? bs_p64<SIZE>(x, key_bits) >> bsh : 0ull; };
-	u64 prev_last = 0; /* bucket of the record in front of the row */
-	if (crel > 0 && crel - 1 < len) {
-		u64 x[SIZE];
-		load_rec<SIZE>(T + (size_t)(crel - 1) * SIZE, x);
-		prev_last = bucket_of(x);
-	}
-	u64 heads[ITEMS];
-	u32 wfirst = NONE, wlast = NONE;
-#pragma unroll
-	for (int r = 0; r < ITEMS; ++r) {
-		const u32 rowrel = crel + r * 64, idx = rowrel + lane;
-		const u64 bk = bucket_of(key[r]);
-		u64 pv = __shfl_up(bk, 1);
-		if (lane == 0)
-			pv = prev_last;
-		const u64 m = __ballot(idx < len && (idx == 0 || pv != bk));
-		heads[r] = m;
-		if (m) {
-			if (wfirst == NONE)
-				wfirst = rowrel + (u32)__ffsll((long long)m) - 1;
-			wlast = rowrel + 63 - (u32)__clzll((long long)m);
-		}
-		prev_last = __shfl(bk, 63); /* lane 63's bucket in every lane */
-	}
-	if (lane == 0) {
-		s_wfirst[wave] = wfirst;
-		s_wlast[wave] = wlast;
-	}
-	__syncthreads();
-	u32 carry_f = 0, carry_b = len; /* start of the bucket open at the wave's first record; first bucket start after the wave's last record */
-#pragma unroll
-	for (int w = 0; w < NW; ++w) {
-		const u32 l = s_wlast[w], f = s_wfirst[NW - 1 - w];
-		if (w < (int)wave && l != NONE)
-			carry_f = l;
-		if (NW - 1 - w > (int)wave && f != NONE)
-			carry_b = f;
-	}
-	carry_f = (u32)__builtin_amdgcn_readfirstlane((int)carry_f);
-	carry_b = (u32)__builtin_amdgcn_readfirstlane((int)carry_b);
-	/* end of every record's bucket (rows backwards), then its start (rows forwards) -> sub-bucket and arrival rank */
-	u32 bend[ITEMS];
-#pragma unroll
-	for (int r = ITEMS - 1; r >= 0; --r) {
-		const u32 rowrel = crel + r * 64;
-		const u64 m = heads[r];
-		const u64 above = m & ~(((2ull << lane) - 1)); /* heads at higher lanes (lane 63: none) */
-		bend[r] = above ? rowrel + (u32)__ffsll((long long)above) - 1 : carry_b;
-		if (m)
-			carry_b = rowrel + (u32)__ffsll((long long)m) - 1;
-	}
-	u32 ir[ITEMS]; /* [15:0] sub-bucket, [31:16] rank */
-#pragma unroll
-	for (int r = 0; r < ITEMS; ++r) {
-		const u32 rowrel = crel + r * 64, idx = rowrel + lane;
-		const u64 m = heads[r];
-		const u64 upto = m & ((2ull << lane) - 1); /* heads at this lane or below */
-		const u32 bstart = upto ? rowrel + 63 - (u32)__clzll((long long)upto) : carry_f;
-		if (m)
-			carry_f = rowrel + 63 - (u32)__clzll((long long)m);
-		ir[r] = 0;
-		if (idx < len) {
-			const u64 p = bs_p64<SIZE>(key[r], key_bits);
-			const u32 rem32 = (u32)((hbits ? (p << hbits) : p) >> 32);
-			u32 id = bstart + __umulhi(rem32, bend[r] - bstart);
-			id = id < len ? id : len - 1; /* in range by construction; the clamp is for records of a corrupt bin (bits above the key, a count that
-			                               * disagrees with the stream: the error word is already set) */
-			const u32 rk = __hip_atomic_fetch_add(&s_cnt[id], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-			ir[r] = id | (rk << 16);
-		}
-	}
-	__syncthreads();
-	/* counts -> first slots: thread t owns counters ITEMS t .. ITEMS t + ITEMS - 1 */
-	{
-		u32 c[ITEMS], sum = 0;
-#pragma unroll
-		for (int q = 0; q < ITEMS; ++q) {
-			c[q] = s_cnt[tid * ITEMS + q];
-			sum += c[q];
-		}
-		u32 total;
-		u32 run = block_excl_sum<NW, u32>(sum, s_tmp, total);
-#pragma unroll
-		for (int q = 0; q < ITEMS; ++q) {
-			s_cnt[tid * ITEMS + q] = run;
-			run += c[q];
-		}
-		if (tid == 0)
-			s_cnt[CAP] = total; /* == len */
-	}
-	__syncthreads();
-#pragma unroll
-	for (int r = 0; r < ITEMS; ++r) {
-		const u32 idx = crel + r * 64 + lane;
-		if (idx < len) {
-			const u32 pos = s_cnt[ir[r] & 0xFFFFu] + (ir[r] >> 16);
-			store_rec<SIZE>(s_rec + (size_t)pos * SIZE, key[r]);
-		}
-	}
-	__syncthreads();
-	/* every sub-bucket is finished by one thread. The common shapes — one or two distinct k-mers, each with all its copies — cost one
-	 * compare per record ("not smaller than the largest so far"). */
-	{
-		u32 moves = 0;
-		for (u32 id = tid; id < len; id += THREADS) {
-			const u32 a = s_cnt[id], b = s_cnt[id + 1];
-			if (b - a < 2)
-				continue;
-			u64 last[SIZE];
-			load_rec<SIZE>(s_rec + (size_t)a * SIZE, last);
-			for (u32 i = a + 1; i < b; ++i) {
-				u64 x[SIZE];
-				load_rec<SIZE>(s_rec + (size_t)i * SIZE, x);
-				if (!kmc_less<SIZE>(x, last)) {
-#pragma unroll
-					for (int w = 0; w < SIZE; ++w)
-						last[w] = x[w];
-					continue;
-				}
-				u32 q = i;
-				while (true) { /* x < record q-1: shift it up */
-					u64 y[SIZE];
-					load_rec<SIZE>(s_rec + (size_t)(q - 1) * SIZE, y);
-					if (!kmc_less<SIZE>(x, y))
-						break;
-					store_rec<SIZE>(s_rec + (size_t)q * SIZE, y);
-					++moves;
-					if (--q == a)
-						break;
-				}
-				store_rec<SIZE>(s_rec + (size_t)q * SIZE, x);
-				if (moves > (u32)BS_MOVE_LIMIT)
-					break; /* between two insertions: the sub-bucket still holds all its records */
-			}
-			if (moves > (u32)BS_MOVE_LIMIT) {
-				*s_fail = 1;
-				break;
-			}
-		}
-	}
-	__syncthreads();
-	if (*s_fail && tid == 0)
-		atomicOr(flag, 1u); /* many distinct keys that the sub-buckets do not separate: LSD passes will sort them (the tile stays a permutation) */
-	for (u32 idx = tid; idx < len; idx += THREADS) {
-		u64 x[SIZE];
-		load_rec<SIZE>(s_rec + (size_t)idx * SIZE, x);
-		store_rec<SIZE>(T + (size_t)idx * SIZE, x);
-	}
-}
-
 /* ------------------------------------------------------------------------------------------------ rank inside the bucket, count in place
- * k_bucket_sort finishes a sub-bucket with ONE thread; at sequencing depth a bucket is the ~30 copies of one k-mer plus a few one-off neighbours
- * (read errors below the bucket bits), those land in the same sub-bucket interleaved, and the thread that owns it walks them serially while 29 of
- * 30 threads have nothing to do. Here every record finds its own place, all at once:
+ * At sequencing depth a bucket is the ~30 copies of one k-mer plus a few one-off neighbours (read errors below the bucket bits). Round 3's first finisher gave
+ * every sub-bucket to ONE thread, which walked those records serially while 29 of 30 threads had nothing to do. Here every record finds its own place, all at once:
  *       place(i) = bucket start + #{ j in the bucket : (rem_j, j) < (rem_i, i) }        rem = the key bits below the bucket bits
  * A step of the count is an LDS read (the lanes of a bucket read the same address: a broadcast), a compare and an add-with-carry; the wave takes as
  * many steps as its largest bucket has records (the bench's bins with the top 30 key bits ordered: 25 on average). Stable (ties go by index), no
- * atomics, no data-dependent failure: the only thing it cannot take is a bucket larger than the tile (flag -> the host's LSD passes, as in
- * k_bucket_sort). Work grows with sum(bucket^2): the host asks for enough HBM passes to keep buckets at a few dozen records (plan_sort).
+ * atomics, no data-dependent failure: the only thing it cannot take is a bucket larger than the tile (k_giant_tiles / the arena). Work grows with sum(bucket^2): the host asks for enough HBM passes to keep buckets at a few dozen records (plan_sort).
  * What is compared, by record width:
  *   one word     (rem, bucket-relative index) in ONE word: 32 bits whenever the tile's largest bucket leaves room for its indices next to rem (always, on
  *                sequencing data with 24 key bits left), else 64 with the index in the low 16 (host: key_bits - hbits <= 48)
@@ -617,7 +385,7 @@ __device__ __forceinline__ void br_tile(const GrpRank &gr, const DevParams &P, c
 			}
 		}
 	}
-	/* Bucket starts ("heads") and, from them, every record's bucket — as in k_bucket_count: a record's bucket is known by its ORDINAL among the tile's
+	/* Bucket starts ("heads") and, from them, every record's bucket: a record's bucket is known by its ORDINAL among the tile's
 	 * buckets (heads at or before the record - 1: a popcount below the lane + the heads of the rows and waves before); the start positions go into a
 	 * table indexed by that ordinal, and a record finds the start and the end of its bucket with two LDS reads. The predecessor's bucket comes through
 	 * a DPP wave shift, not through the LDS crossbar. */
@@ -1502,469 +1270,6 @@ __global__ void __launch_bounds__(GT_THREADS) k_giant_tiles(const GrpRank gr, De
 			atomicAdd(reinterpret_cast<u64 *>(err + 14), (u64)L);
 		}
 	}
-}
-
-/* ================================================================================================ fused: tile -> (k-mer, count) records
- * What stage 2 wants from the sort is not the sorted records but the RUNS of equal k-mers: ascending distinct k-mers with their counts
- * (kb_sorter.h:1128-1281). All copies of a k-mer share their bucket, hence their tile, hence their sub-bucket — so a tile can be counted
- * without ever being sorted:
- *   1  records -> registers and, in arrival order, LDS; bucket boundaries -> sub-bucket id as in k_bucket_sort; count per sub-bucket (LDS
- *      atomics, nothing returned); scan: sub-bucket i owns slots [base[i], base[i+1]) of a tag array — as many slots as it has records
- *   2  every record looks for its k-mer in its sub-bucket's slots, open addressing from a hashed start: an empty slot is claimed with a
- *      compare-and-swap (tag = the claiming record's position, count 1: the record now OWNS its k-mer), a slot whose owner holds the same
- *      k-mer gets its count bumped. This is the run-length counting, parallel over RECORDS: 30x coverage costs one probe and one add per copy.
- *   3  owners apply the cutoffs (kb_sorter.h:1174-1192); a counted k-mer adds one to its sub-bucket's number of counted k-mers, one scan over the
- *      sub-buckets turns those into "counted k-mers before this sub-bucket" = the rank in the tile of a counted k-mer that is alone in its
- *      sub-bucket; the rare one that is not adds the smaller counted k-mers of its sub-bucket (a scan of a few slots). Nothing is sorted.
- *   4  the owner writes its record at that rank into the tile's span of the free record array (counted k-mers are ~4 % of the records at the
- *      default cutoff: byte stores, merged in L2) and counts its LUT prefix in a small LDS histogram (flushed with one global atomic per
- *      prefix); the tile's count goes to status[tile] (two-phase output: k_compact_fold turns the counts into offsets, k_compact_gather moves
- *      the records), tallies are sharded exactly as in k_compact.
- * HBM traffic per record: the 8 SIZE bytes of its one read. The span of a tile starts at the byte offset of its first record in the free
- * array (8 SIZE bytes per record of room), so a tile of any length has room for its output. A tile longer than the LDS capacity is counted in
- * bucket-aligned chunks; only a single BUCKET beyond the capacity (one k-mer repeated thousands of times) sets *flag: the host runs the group
- * again with LSD passes over every byte and k_compact. */
-#ifndef BC_BLOCK_THREADS
-#define BC_BLOCK_THREADS 1024 /* 16 waves x 4 rows of 64 records: 4096-record tiles of one-word records, 64 KB of LDS, two workgroups per CU */
-#endif
-#ifndef BC_WORDS_PER_THREAD
-#define BC_WORDS_PER_THREAD 4
-#endif
-#ifndef BC_MIN_WAVES
-#define BC_MIN_WAVES 8 /* waves per SIMD the register allocator must leave room for: two workgroups of 1024 per CU */
-#endif
-#ifndef BC_HASH_CAP
-#define BC_HASH_CAP 8 /* a k-mer's probe sequence starts in the first BC_HASH_CAP slots of its region: a region has one slot per RECORD (25 copies of
-                       * one k-mer: 25 slots, one of them claimed), and whoever scans a region for its claimed slots (step 4) can stop at the first
-                       * free slot behind those — a slot further back is only ever claimed by a probe that found the slot before it taken */
-#endif
-constexpr int BC_LUT_HIST = 1024; /* LUT prefixes a tile aggregates in LDS; a tile that spans more of them adds to the LUT directly */
-template <int SIZE> struct BcCfg {
-	static constexpr int THREADS = BC_BLOCK_THREADS;
-	static constexpr int ITEMS = (BC_WORDS_PER_THREAD / SIZE) > 2 ? (BC_WORDS_PER_THREAD / SIZE) : 2;
-	static constexpr int CAP = THREADS * ITEMS;
-	static constexpr int STRIDE = CAP / 4 * 3; /* window length: a tile is STRIDE records on average; one that outgrows CAP takes a second chunk */
-	static_assert(CAP < 65535, "positions + 1 are kept in 16 bits");
-};
-template <int SIZE> constexpr size_t bc_lds_bytes()
-{
-	return (size_t)BcCfg<SIZE>::CAP * SIZE * 8 + ((size_t)2 * BcCfg<SIZE>::CAP + 3) * 4 + (size_t)BC_LUT_HIST * 4 +
-	       (6 * (BcCfg<SIZE>::THREADS / 64) + 4) * 4 + 16;
-}
-/* average bucket size the host aims for when it picks the number of HBM passes. What must not happen is ONE bucket beyond CAP (a longer TILE is only a
- * second chunk), and the k-mers of a signature bin are clustered — the longer the k-mer, the more: on the bench's bins the largest of 2^22 buckets holds
- * 100x the average at k = 27, 600-1200x at k = 127 (a 9.4 M k-mer bin: average 2.2, largest 3072 > CAP 2048: nearly every group went back to the host).
- * So: CAP / 256 for one-word records, 1 beyond (k = 55 and k = 127 on 30 Gbp: 4 passes); a group that still comes back raises the number of passes for
- * the groups after it (kmc_hip.hip plan_sort). */
-template <int SIZE> constexpr u64 bc_target_bucket() { return SIZE == 1 ? BcCfg<SIZE>::CAP / 256 : 1; }
-
-#ifdef KMC_TRACE /* tuning builds: thread 0 of every tile adds the time since its previous stamp to phase counter j (tools/trace_bc.py) */
-#define BC_STAMP(j)                                                                                                             \
-	do {                                                                                                                        \
-		if (threadIdx.x == 0) {                                                                                                 \
-			const unsigned long long now__ = wall_clock64();                                                                   \
-			atomicAdd(&g_trace[(3 * (TRACE_SLOTS / 4)) * 8 + (j)], now__ - bc_t_prev);                                           \
-			bc_t_prev = now__;                                                                                                  \
-		}                                                                                                                       \
-	} while (0)
-#else
-#define BC_STAMP(j) do { } while (0)
-#endif
-
-struct GrpBucket {
-	u32 g, win_prefix[GRP_MAX + 1]; /* windows (= tiles) of bin b */
-	const u64 *S[GRP_MAX];          /* the bin's slice of the record array, ordered by the top `hbits` key bits */
-	const u64 *bounds[GRP_MAX];     /* [windows + 1] tile boundaries (k_bucket_bounds) */
-	uint8_t *scratch[GRP_MAX];      /* the bin's slice of the free record array: tile t's records go to scratch + bounds[t] * 8 SIZE */
-	u64 *status[GRP_MAX];           /* tile t's number of counted k-mers */
-	u64 *lut_base[GRP_MAX];
-	u64 *tally[GRP_MAX];            /* [CP_SHARDS][4] */
-};
-
-template <int SIZE>
-__global__ void __launch_bounds__(BcCfg<SIZE>::THREADS, (SIZE <= 2 ? BC_MIN_WAVES : BC_MIN_WAVES / 2)) k_bucket_count(const GrpBucket gb, DevParams P, u32 key_bits, u32 hbits, u32 lut_shards,
-                                                                                                             u64 lut_stride, u32 lut_mask, u32 *flag)
-{
-	constexpr int THREADS = BcCfg<SIZE>::THREADS, ITEMS = BcCfg<SIZE>::ITEMS, CAP = BcCfg<SIZE>::CAP, NW = THREADS / 64;
-	constexpr u64 S = BcCfg<SIZE>::STRIDE;
-	constexpr u32 NONE = 0xFFFFFFFFu;
-	static_assert(CAP == THREADS * ITEMS, "a thread scans ITEMS consecutive counters / slots");
-	KMC_DYN_LDS(unsigned char, s_raw);
-	u64 *s_rec = reinterpret_cast<u64 *>(s_raw);                      /* [CAP * SIZE] records in arrival order */
-	u32 *s_cnt = reinterpret_cast<u32 *>(s_rec + (size_t)CAP * SIZE); /* [CAP + 1] records per sub-bucket -> [15:0] first slot of its region, [31:16] (step 3) counted k-mers in front of it */
-	u32 *s_tag = s_cnt + CAP + 1;                                     /* [CAP + 1] [15:0] owner position + 1 (0 = free), [31:16] count; before that, the table of bucket starts */
-	u32 *s_lut = s_tag + CAP + 1;                                     /* [BC_LUT_HIST] counted k-mers per LUT prefix, relative to the tile's first */
-	u32 *s_tmp = s_lut + BC_LUT_HIST;                                 /* [2 NW] wave totals of the two scans */
-	u32 *s_wfirst = s_tmp + 2 * NW;                                   /* [NW] bucket starts in wave w's rows */
-	u32 *s_wtal = s_wfirst + NW;                                       /* [NW][3] distinct / below min / above max */
-
-	const u32 gtile = blockIdx.x;
-	const u32 bin = (u32)__builtin_amdgcn_readfirstlane((int)grp_find(gb.win_prefix, gb.g, gtile));
-	const u32 tile = gtile - gb.win_prefix[bin];
-	const u64 *__restrict__ bounds = gb.bounds[bin];
-	const u64 b0 = bounds[tile], b1 = bounds[tile + 1];
-	if (b0 >= ((u64)tile + 1) * S || b0 >= b1)
-		return; /* no bucket starts in this window: status[tile] stays 0 */
-	const u32 tid = threadIdx.x, lane = tid & 63;
-	const u32 wave = (u32)__builtin_amdgcn_readfirstlane((int)(tid >> 6));
-	const u32 crel = wave * (ITEMS * 64);
-	const u32 rec_bytes = P.sbytes + P.cbytes;
-	const bool use_lut = P.lut_prefix_len != 0 && !P.kff && !P.without_output;
-	const u32 bsh = 64 - hbits;
-	auto bucket_of = [&](const u64(&x)[SIZE]) -> u32 { return hbits ? (u32)(bs_p64<SIZE>(x, key_bits) >> bsh) : 0u; }; /* hbits <= 32 (kmc_hip.hip plan_sort) */
-	auto counted = [&](u32 w) -> bool { const u32 c = w >> 16; return w != 0 && c >= P.cutoff_min && c <= P.cutoff_max; };
-	uint8_t *const span = gb.scratch[bin] + b0 * (u64)(SIZE * 8); /* this tile's output: room for 8 SIZE bytes per record */
-	u32 nu = 0, nb = 0, na = 0;                                    /* this thread's owners: distinct / below min / above max */
-	u32 counted_done = 0;                                          /* counted k-mers of the chunks before this one */
-	const u32 pshift = 2 * (P.k - P.lut_prefix_len);
-#ifdef KMC_TRACE
-	unsigned long long bc_t_prev = wall_clock64();
-#endif
-
-	for (u64 c0 = b0; c0 < b1;) { /* chunks of whole buckets; nearly always one */
-		const u64 *__restrict__ T = gb.S[bin] + c0 * SIZE;
-		const u32 avail = (b1 - c0) > (u64)CAP ? (u32)CAP : (u32)(b1 - c0);
-#pragma unroll
-		for (int q = 0; q < ITEMS; ++q)
-			s_cnt[q * THREADS + tid] = 0;
-		if (tid == 0)
-			s_cnt[CAP] = 0;
-		for (u32 i = tid; i < (u32)BC_LUT_HIST; i += THREADS)
-			s_lut[i] = 0;
-		u64 key[ITEMS][SIZE];
-#pragma unroll
-		for (int r = 0; r < ITEMS; ++r) {
-			const u32 idx = crel + r * 64 + lane;
-			if (idx < avail) {
-				load_rec<SIZE>(T + (size_t)idx * SIZE, key[r]);
-				store_rec<SIZE>(s_rec + (size_t)idx * SIZE, key[r]);
-			} else {
-#pragma unroll
-				for (int w = 0; w < SIZE; ++w)
-					key[r][w] = 0;
-			}
-		}
-		/* ---- 1: bucket starts ("heads"). A record's bucket is known by its ORDINAL among the chunk's buckets = heads at or before the record - 1:
-		 * a popcount of the row's head mask below the lane (mbcnt) + the heads of the rows and waves before. The start positions go into a table
-		 * indexed by that ordinal (it lives where the tag array will be: nothing probes yet), so a record finds the start and the end of its bucket
-		 * with two LDS reads — no per-lane 64-bit mask arithmetic. */
-		u32 *s_start = s_tag;
-		u32 prev_last = 0;
-		if (crel > 0 && crel - 1 < avail) {
-			u64 x[SIZE];
-			load_rec<SIZE>(T + (size_t)(crel - 1) * SIZE, x);
-			prev_last = bucket_of(x);
-		}
-		u32 headbits = 0, below[ITEMS], wheads = 0; /* bit r: this lane's record of row r starts a bucket; heads of the wave's earlier rows + lower lanes */
-#pragma unroll
-		for (int r = 0; r < ITEMS; ++r) {
-			const u32 idx = crel + r * 64 + lane;
-			const u32 bk = bucket_of(key[r]);
-			const u32 pv = wave_shift_up1(bk, prev_last, lane);
-			const bool head = idx < avail && (idx == 0 || pv != bk);
-			const u64 m = __ballot(head);
-			headbits |= head ? 1u << r : 0u;
-			below[r] = __builtin_amdgcn_mbcnt_hi((u32)(m >> 32), __builtin_amdgcn_mbcnt_lo((u32)m, wheads));
-			wheads += (u32)__popcll(m);
-			prev_last = __shfl(bk, 63);
-		}
-		if (lane == 0)
-			s_wfirst[wave] = wheads;
-		__syncthreads();
-		u32 wave_heads_before, total_heads;
-		{
-			const u32 v = lane < (u32)NW ? s_wfirst[lane] : 0u;
-			const u32 inc = wave_incl_sum_u32(v, lane);
-			total_heads = __shfl(inc, NW - 1);
-			wave_heads_before = __shfl(inc - v, (int)wave);
-		}
-#pragma unroll
-		for (int r = 0; r < ITEMS; ++r)
-			if ((headbits >> r) & 1u)
-				s_start[wave_heads_before + below[r]] = crel + r * 64 + lane; /* ordinal of this head = heads before it */
-		if (tid == 0)
-			s_start[total_heads] = avail;
-		__syncthreads();
-		BC_STAMP(0); /* clear, load, bucket starts */
-		/* the chunk: everything that was loaded, or — when the tile has more — up to the start of the last bucket that began inside it */
-		u32 len = avail;
-		if ((b1 - c0) > (u64)CAP) {
-			len = s_start[total_heads - 1];
-			if (len == 0) { /* one bucket beyond the LDS capacity (uniform over the workgroup) */
-				if (tid == 0)
-					atomicOr(flag, 1u);
-				return;
-			}
-		}
-		u32 sub[ITEMS]; /* the record's sub-bucket */
-#pragma unroll
-		for (int r = 0; r < ITEMS; ++r) {
-			const u32 idx = crel + r * 64 + lane;
-			sub[r] = 0;
-			if (idx < len) {
-				const u32 ord = wave_heads_before + below[r] + ((headbits >> r) & 1u) - 1;
-				const u32 bstart = s_start[ord], bend = s_start[ord + 1];
-				const u64 p = bs_p64<SIZE>(key[r], key_bits);
-				const u32 rem32 = (u32)((hbits ? (p << hbits) : p) >> 32);
-				u32 id = bstart + __umulhi(rem32, bend - bstart);
-				id = id < len ? id : len - 1; /* in range by construction; the clamp is for records of a corrupt bin (the error word is already set) */
-				sub[r] = id;
-				(void)__hip_atomic_fetch_add(&s_cnt[id], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-			}
-		}
-		__syncthreads();
-		BC_STAMP(1); /* sub-buckets, counting */
-		{
-			u32 c[ITEMS], sum = 0;
-#pragma unroll
-			for (int q = 0; q < ITEMS; ++q) {
-				c[q] = s_cnt[tid * ITEMS + q];
-				sum += c[q];
-				s_tag[q * THREADS + tid] = 0; /* the table of bucket starts has been read: the tag array starts empty */
-			}
-			u32 total;
-			u32 run = block_excl_sum_1b<NW>(sum, s_tmp, total);
-#pragma unroll
-			for (int q = 0; q < ITEMS; ++q) {
-				s_cnt[tid * ITEMS + q] = run;
-				run += c[q];
-			}
-			if (tid == 0) {
-				s_cnt[CAP] = total;
-				s_tag[CAP] = 0;
-			}
-		}
-		__syncthreads();
-		BC_STAMP(2); /* region table scan */
-#if defined(BC_STOP_AFTER) && BC_STOP_AFTER <= 1 /* tuning builds only: what does each phase cost? (the output is garbage) */
-		return;
-#endif
-		/* ---- 2: count the copies. Region of sub-bucket i: slots [s_cnt[i], s_cnt[i+1]) — one slot per record, so a free slot always exists. */
-		u32 myslot[ITEMS]; /* the slot this record owns, NONE if it is a copy */
-#pragma unroll
-		for (int r = 0; r < ITEMS; ++r) {
-			const u32 idx = crel + r * 64 + lane;
-			myslot[r] = NONE;
-			if (idx < len) {
-				const u32 a = s_cnt[sub[r]], nreg = s_cnt[sub[r] + 1] - a;
-				u32 h = 0;
-#pragma unroll
-				for (int w = 0; w < SIZE; ++w)
-					h = (h ^ (u32)key[r][w] ^ (u32)(key[r][w] >> 32)) * 0x9E3779B1u;
-				h ^= h >> 15;
-				u32 slot = a + __umulhi(h * 0x85EBCA6Bu, nreg < (u32)BC_HASH_CAP ? nreg : (u32)BC_HASH_CAP);
-				for (u32 probe = 0; probe < nreg; ++probe) {
-					u32 w = __hip_atomic_load(&s_tag[slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-					if (w == 0) {
-						w = atomicCAS(&s_tag[slot], 0u, (1u << 16) | (idx + 1));
-						if (w == 0) {
-							myslot[r] = slot;
-							break;
-						}
-					}
-					u64 o[SIZE];
-					load_rec<SIZE>(s_rec + (size_t)((w & 0xFFFFu) - 1) * SIZE, o);
-					if (kmc_equal<SIZE>(o, key[r])) {
-						(void)__hip_atomic_fetch_add(&s_tag[slot], 1u << 16, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-						break;
-					}
-					slot = slot + 1 == a + nreg ? a : slot + 1;
-				}
-			}
-		}
-		__syncthreads();
-		BC_STAMP(3); /* probing */
-#if defined(BC_STOP_AFTER) && BC_STOP_AFTER <= 2
-		return;
-#endif
-		/* ---- 3: owners apply the cutoffs (kb_sorter.h:1174-1192); every counted k-mer adds one to its sub-bucket's entry of the region table
-		 * (upper half of the word; the first slot stays in the lower half), and a scan of those numbers replaces them by "counted k-mers in the
-		 * sub-buckets before this one" — which is the rank of a counted k-mer that is alone in its sub-bucket (nearly all are) */
-		u32 mycount[ITEMS]; /* a counted owner's count; 0 for everybody else */
-#pragma unroll
-		for (int r = 0; r < ITEMS; ++r) {
-			mycount[r] = 0;
-			if (myslot[r] != NONE) {
-				const u32 c = s_tag[myslot[r]] >> 16;
-				++nu;
-				if (c < P.cutoff_min)
-					++nb;
-				else if (c > P.cutoff_max)
-					++na;
-				else {
-					mycount[r] = c;
-					(void)__hip_atomic_fetch_add(&s_cnt[sub[r]], 1u << 16, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-				}
-			}
-		}
-		__syncthreads();
-		BC_STAMP(4); /* owners classify + count per sub-bucket */
-		u32 chunk_counted;
-		{
-			u32 w[ITEMS], sum = 0;
-#pragma unroll
-			for (int q = 0; q < ITEMS; ++q) {
-				w[q] = s_cnt[tid * ITEMS + q];
-				sum += w[q] >> 16;
-			}
-			u32 run = block_excl_sum_1b<NW>(sum, s_tmp + NW, chunk_counted);
-#pragma unroll
-			for (int q = 0; q < ITEMS; ++q) {
-				s_cnt[tid * ITEMS + q] = (w[q] & 0xFFFFu) | (run << 16);
-				run += w[q] >> 16;
-			}
-			if (tid == 0)
-				s_cnt[CAP] = (s_cnt[CAP] & 0xFFFFu) | (chunk_counted << 16);
-		}
-		__syncthreads();
-		BC_STAMP(5); /* scan of counted per sub-bucket */
-#if defined(BC_STOP_AFTER) && BC_STOP_AFTER <= 3
-		return;
-#endif
-		/* the LUT prefixes this chunk can hold: those of its first bucket's smallest and its last bucket's largest k-mer */
-		u32 pf_lo = 0, pf_span = 0;
-		if (use_lut) {
-			u64 f[SIZE], l[SIZE];
-			load_rec<SIZE>(s_rec, f);
-			load_rec<SIZE>(s_rec + (size_t)(len - 1) * SIZE, l);
-			kmc_mask_low<SIZE>(f, 2 * P.k);
-			kmc_mask_low<SIZE>(l, 2 * P.k);
-			/* below the bucket bits everything is possible: clear them in the first record, set them in the last */
-			const u32 low = key_bits > hbits ? key_bits - hbits : 0; /* key bits below the bucket bits (tag bits above 2k are masked off already) */
-			u64 fl[SIZE], lh[SIZE];
-#pragma unroll
-			for (int w = 0; w < SIZE; ++w) {
-				const u32 lo_bit = 64u * w;
-				const u64 mask = low <= lo_bit ? 0ull : (low - lo_bit >= 64 ? ~0ull : ((1ull << (low - lo_bit)) - 1));
-				fl[w] = f[w] & ~mask;
-				lh[w] = l[w] | mask;
-			}
-			kmc_mask_low<SIZE>(lh, 2 * P.k);
-			pf_lo = (u32)kmc_remove_suffix<SIZE>(fl, pshift) & lut_mask;
-			const u32 pf_hi = (u32)kmc_remove_suffix<SIZE>(lh, pshift) & lut_mask;
-			pf_span = pf_hi >= pf_lo ? pf_hi - pf_lo + 1 : 0xFFFFFFFFu;
-		}
-		u64 *const lut = use_lut ? gb.lut_base[bin] + (size_t)(tile % lut_shards) * lut_stride : nullptr;
-		/* ---- 4: a counted k-mer finds its rank ... */
-		if (!P.without_output && chunk_counted) { /* uniform over the workgroup */
-#pragma unroll
-			for (int r = 0; r < ITEMS; ++r) {
-				if (mycount[r]) {
-					const u32 w0 = s_cnt[sub[r]], w1 = s_cnt[sub[r] + 1];
-					u32 rank = w0 >> 16;
-					if ((w1 >> 16) - rank > 1) { /* several counted k-mers share the sub-bucket: this one goes behind the smaller ones */
-						const u32 a = w0 & 0xFFFFu, e = w1 & 0xFFFFu;
-						for (u32 q = a; q < e; ++q) {
-							const u32 wq = s_tag[q];
-							if (wq == 0 && q >= a + (u32)BC_HASH_CAP)
-								break; /* nothing is claimed behind a free slot out here (BC_HASH_CAP) */
-							if (q != myslot[r] && counted(wq)) {
-								u64 o[SIZE];
-								load_rec<SIZE>(s_rec + (size_t)((wq & 0xFFFFu) - 1) * SIZE, o);
-								rank += kmc_less<SIZE>(o, key[r]) ? 1u : 0u;
-							}
-						}
-					}
-					mycount[r] = (mycount[r] > P.counter_max ? P.counter_max : mycount[r]) | (rank << 16); /* count <= chunk length < 2^16 */
-				}
-			}
-			__syncthreads(); /* ... and, the region scans being over, assembles its record in LDS where the records were */
-			BC_STAMP(6); /* ranks */
-			/* staged: the k-mer (tag bits cleared) where the records were, at its rank; its count where the tags were */
-#pragma unroll
-			for (int r = 0; r < ITEMS; ++r) {
-				if (mycount[r]) {
-					const u32 rank = mycount[r] >> 16;
-					u64 kx[SIZE];
-#pragma unroll
-					for (int w = 0; w < SIZE; ++w)
-						kx[w] = key[r][w];
-					kmc_mask_low<SIZE>(kx, 2 * P.k); /* drops a group tag above the k-mer (KFF records carry the top bytes) */
-					store_rec<SIZE>(s_rec + (size_t)rank * SIZE, kx);
-					s_tag[rank] = mycount[r] & 0xFFFFu;
-					if (use_lut) {
-						const u32 pf = (u32)kmc_remove_suffix<SIZE>(kx, pshift) & lut_mask;
-						if (pf_span <= (u32)BC_LUT_HIST && pf - pf_lo < (u32)BC_LUT_HIST)
-							(void)__hip_atomic_fetch_add(&s_lut[pf - pf_lo], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-						else
-							atomicAdd(&lut[pf], 1ull);
-					}
-				}
-			}
-			__syncthreads();
-			BC_STAMP(7); /* k-mers staged */
-			/* the chunk's bytes, coalesced: byte i of the chunk is byte i % rec_bytes of record i / rec_bytes — suffix bytes high -> low
-			 * (kb_sorter.h:1198-1199), then the counter, little-endian for KMC (:1200-1201), big-endian for KFF (:1210-1211) */
-			const u32 chunk_bytes = chunk_counted * rec_bytes;
-			const u32 inv = rec_bytes > 1 ? (u32)(((1ull << 32) + rec_bytes - 1) / rec_bytes) : 0u; /* x / rec_bytes = umulhi(x, inv), exact for x < 2^29 */
-			auto out_byte = [&](u32 i) -> u32 {
-				const u32 ri = rec_bytes > 1 ? __umulhi(i, inv) : i, q = i - ri * rec_bytes;
-				if (q < P.sbytes) {
-					const u32 pbyte = P.sbytes - 1 - q;
-					return (u32)(s_rec[(size_t)ri * SIZE + (pbyte >> 3)] >> ((pbyte & 7) * 8)) & 0xFFu;
-				}
-				const u32 cq = q - P.sbytes;
-				return (s_tag[ri] >> (8 * (P.kff ? (P.cbytes - 1 - cq) : cq))) & 0xFFu;
-			};
-			uint8_t *dst = span + (u64)counted_done * rec_bytes;
-			if ((counted_done * rec_bytes & 3u) == 0) { /* the span is 8-byte aligned: whole dwords (the bytes behind the last record are the span's own) */
-				u32 *dst32 = reinterpret_cast<u32 *>(dst);
-#pragma clang loop unroll(disable) vectorize(disable)
-				for (u32 wd = tid; wd < (chunk_bytes + 3) / 4; wd += THREADS) {
-					const u32 i0 = wd * 4;
-					u32 word = out_byte(i0);
-					word |= (i0 + 1 < chunk_bytes ? out_byte(i0 + 1) : 0u) << 8;
-					word |= (i0 + 2 < chunk_bytes ? out_byte(i0 + 2) : 0u) << 16;
-					word |= (i0 + 3 < chunk_bytes ? out_byte(i0 + 3) : 0u) << 24;
-					dst32[wd] = word;
-				}
-			} else { /* a later chunk of a long tile */
-#pragma clang loop unroll(disable) vectorize(disable)
-				for (u32 i = tid; i < chunk_bytes; i += THREADS)
-					dst[i] = (uint8_t)out_byte(i);
-			}
-			if (use_lut && pf_span <= (u32)BC_LUT_HIST) {
-				for (u32 i = tid; i < pf_span; i += THREADS) {
-					const u32 v = s_lut[i];
-					if (v)
-						atomicAdd(&lut[pf_lo + i], (u64)v);
-				}
-			}
-		}
-		BC_STAMP(8); /* copy-out, LUT flush */
-		counted_done += chunk_counted;
-		c0 += len;
-		if (c0 < b1)
-			__syncthreads(); /* the next chunk clears what this one still reads */
-	}
-	nu = wave_sum<u32>(nu);
-	nb = wave_sum<u32>(nb);
-	na = wave_sum<u32>(na);
-	if (lane == 0) {
-		s_wtal[wave * 3 + 0] = nu;
-		s_wtal[wave * 3 + 1] = nb;
-		s_wtal[wave * 3 + 2] = na;
-	}
-	__syncthreads();
-	if (tid == 0) {
-		u32 tu = 0, tb = 0, ta = 0;
-#pragma unroll
-		for (int w = 0; w < NW; ++w) {
-			tu += s_wtal[w * 3 + 0];
-			tb += s_wtal[w * 3 + 1];
-			ta += s_wtal[w * 3 + 2];
-		}
-		u64 *sh = gb.tally[bin] + (size_t)(tile % CP_SHARDS) * 4;
-		if (tu)
-			atomicAdd(&sh[0], (u64)tu);
-		if (tb)
-			atomicAdd(&sh[1], (u64)tb);
-		if (ta)
-			atomicAdd(&sh[2], (u64)ta);
-		if (!P.without_output)
-			gb.status[bin][tile] = counted_done;
-	}
-	BC_STAMP(9); /* tallies */
 }
 
 #endif

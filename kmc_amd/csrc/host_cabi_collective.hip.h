@@ -165,7 +165,7 @@ int kmc_hip_order_database_device(kmc_hip_ctx *ctx, int dev, const kmc_hip_bin_p
 int kmc_hip_set_hybrid(int mode)
 {
 	const int before = hybrid_mode();
-	g_hybrid_override.store(mode, std::memory_order_relaxed);
+	g_hybrid_override.store(mode >= 2 ? 1 : mode, std::memory_order_relaxed); /* 2 (round 3's finishers) left the library in round 6 */
 	g_hybrid_groups.store(0);
 	g_redo_groups.store(0);
 	g_extra_top.store(0);

@@ -19,7 +19,7 @@ struct BinPlan {
 
 /* ---- the sort's shape ----------------------------------------------------------------------------------------------
  * key_bytes = ceil(key bits / 8) byte positions; the TOP `top` of them are sorted by 8-bit LSD passes through HBM (k_onesweep), the rest
- * inside LDS by k_bucket_sort on bucket-aligned tiles (bucket_sort.hip.h). top == key_bytes: the plain LSD sort of rounds 1-2. */
+ * inside LDS by k_bucket_rank on bucket-aligned tiles (bucket_sort.hip.h). top == key_bytes: the plain LSD sort of rounds 1-2 (sort-only calls, redo runs, tiny groups). */
 struct SortPlan {
 	u32 key_bytes = 0, top = 0;
 	u32 key_bits = 0; /* significant bits of the key (2k + tag bits; 8 key_bytes when the caller cannot tell) */
@@ -29,7 +29,7 @@ struct SortPlan {
 	bool local() const { return top < key_bytes; }
 	u32 hbits() const { return top ? 8 * top - (8 * key_bytes - key_bits) : 0; } /* top bits of the significant key that the HBM passes order (plan_sort: 8 top > spare bits) */
 };
-std::atomic<u64> g_path[4] = {}; /* groups by the path they took: 0 rank + count in LDS, 1 rank in place + k_compact, 2 k_bucket_count, 3 LSD passes over every byte */
+std::atomic<u64> g_path[4] = {}; /* groups by the path they took: 0 rank + count in LDS, 1 rank in place + k_compact, 2 unused since round 6 (was k_bucket_count), 3 LSD passes over every byte */
 std::atomic<u64> g_indirect_groups{0}; /* ... of path 0: sorted through (key top, record number) pairs */
 std::atomic<u64> g_hybrid_groups{0}, g_redo_groups{0}; /* process-wide: input whose buckets keep overflowing the tiles stops being tried */
 std::atomic<u32> g_extra_top{0}; /* HBM passes added to the plan after a group came back (finer buckets for the groups after it) */
@@ -48,10 +48,11 @@ int hybrid_mode()
 		return o;
 	static const int v = [] {
 		/* 0 = LSD passes over every byte + k_compact (rounds 1-2); 1 = default: the top key bytes through HBM passes, every bucket-aligned tile ranked and
-		 * counted inside LDS by k_bucket_rank (round 4: every record width; KMC_HIP_RANK=0 / KMC_HIP_RANK_FUSE=0 give round 3's k_bucket_count for k >= 33 and
-		 * rank-in-place + k_compact for k <= 32); 2 = k_bucket_count for every record width and the LDS sort for sort-only calls; -h = force `h` top bytes (tuning) */
+		 * counted inside LDS by k_bucket_rank (round 4: every record width; KMC_HIP_RANK_FUSE=0: one-word records ranked in place + k_compact, wider ones LSD);
+		 * -h = force `h` top bytes (tuning). (2 — round 3's k_bucket_count / k_bucket_sort — left the library in round 6 and is taken as 1.) */
 		const char *e = getenv("KMC_HIP_HYBRID");
-		return e ? atoi(e) : 1;
+		const int m = e ? atoi(e) : 1;
+		return m >= 2 ? 1 : m;
 	}();
 	return v;
 }
@@ -72,74 +73,56 @@ bool rank_enabled()
 	return v;
 }
 template <int SIZE>
-SortPlan plan_sort(u64 n, u32 key_bytes, u32 key_bits, bool classic, bool fused = false /* k_bucket_count's tiles, not k_bucket_sort's */,
-                   bool rank = false /* the records of a group: k_bucket_rank */)
+SortPlan plan_sort(u64 n, u32 key_bytes, u32 key_bits, bool classic, bool rank = false /* the records of a group: k_bucket_rank finishes the low bytes inside LDS */)
 {
 	SortPlan sp;
 	sp.key_bytes = sp.top = key_bytes;
 	sp.key_bits = key_bits;
 	const int mode = hybrid_mode();
-	if (classic || mode == 0 || key_bytes < 3 || n < 2)
-		return sp;
-	if (mode == 1 && (SIZE == 1 || !fused) && !rank)
-		return sp;
-	const u32 rem_limit = br_rem_limit<SIZE>(); /* rank: key bits that may stay below the bucket bits */
+	if (classic || mode == 0 || key_bytes < 3 || n < 2 || !rank)
+		return sp; /* LSD passes over every byte: sort-only calls, redo runs, tiny inputs */
+	const u32 rem_limit = br_rem_limit<SIZE>(); /* key bits that may stay below the bucket bits */
 	const u32 spare = 8 * key_bytes - key_bits;
 	if (mode < 0) {
 		const u32 h = (u32)(-mode);
 		if (h + 1 <= key_bytes && 8 * h > spare)
 			sp.top = h;
-		if (!rank && sp.local() && sp.hbits() > 32)
-			sp.top = key_bytes; /* k_bucket_count keeps bucket numbers in 32 bits */
-		if (rank && sp.local() && key_bits - sp.hbits() <= rem_limit && sp.hbits() <= 48)
+		if (sp.local() && key_bits - sp.hbits() <= rem_limit && sp.hbits() <= 48)
 			sp.rank = true;
-		else if (rank)
+		else
 			sp.top = key_bytes;
 		return sp;
 	}
+	if (n <= (u64)BrCfg<SIZE>::THREADS * (8 / SIZE > 2 ? 8 / SIZE : 2))
+		return sp; /* a tiny group (a few thousand records) is bound by launches, not by bytes */
 	const u64 redo = g_redo_groups.load(std::memory_order_relaxed);
 	if (g_extra_top.load(std::memory_order_relaxed) >= 2 && redo > 128 && redo * 8 > g_hybrid_groups.load(std::memory_order_relaxed))
-		return sp; /* this input defeats the bucket tiles even with two passes more */
-	/* the fewest top bytes that leave buckets of bs_target_bucket() records on average, and only if at least two passes are saved */
-	for (u32 h = 0; h + 2 <= key_bytes && h <= (rank ? 6u : 4u); ++h) { /* (k_bucket_count keeps bucket numbers in 32 bits, k_bucket_rank in 64) */
-		bool ok;
-		if (h == 0)
-			ok = !fused && n <= (u64)BsCfg<SIZE>::CAP; /* groups always take one pass at least: the bins' tags must be ordered */
-		else {
-			const u32 eff = 8 * h > spare ? 8 * h - spare : 0;
-			/* rank: the k-mers of a signature bin that BEGIN with one of the bin's minimizers share ~18 key bits, whatever the size of the bin — 1/19 of the
-			 * records in a few hundred prefixes — and the work grows with the square of a bucket: the passes must reach well below those bits (measured:
-			 * 512 bins of 3.2 M k-mers with 22 key bits ordered 17.7 Gk-mers/s, the 7 LSD passes 24.1; 190 M-record groups with 22 bits 7.2, with 30 bits 31.5) */
-			if (rank)
-				ok = eff >= 28 && (eff >= 63 || (n >> eff) <= 2) && key_bits - eff <= rem_limit;
-			else
-				ok = eff > 0 && (eff >= 63 || (n >> eff) <= (fused ? bc_target_bucket<SIZE>() : bs_target_bucket<SIZE>()));
-		}
-		if (ok) {
+		return sp; /* this input defeats the bucket tiles again and again */
+	/* the fewest top bytes that leave the finisher buckets it can rank, and only if at least two passes are saved */
+	for (u32 h = 1; h + 2 <= key_bytes && h <= 6u; ++h) { /* (groups always take one pass at least: the bins' tags must be ordered) */
+		const u32 eff = 8 * h > spare ? 8 * h - spare : 0;
+		/* the k-mers of a signature bin that BEGIN with one of the bin's minimizers share ~18 key bits, whatever the size of the bin — 1/19 of the
+		 * records in a few hundred prefixes — and the work grows with the square of a bucket: the passes must reach well below those bits (measured:
+		 * 512 bins of 3.2 M k-mers with 22 key bits ordered 17.7 Gk-mers/s, the 7 LSD passes 24.1; 190 M-record groups with 22 bits 7.2, with 30 bits 31.5) */
+		if (eff >= 28 && (eff >= 63 || (n >> eff) <= 2) && key_bits - eff <= rem_limit) {
 			sp.top = h;
 			break;
 		}
 	}
-	if (sp.top < key_bytes && sp.top >= 1) { /* finer buckets after a redo, while that still saves passes and the bucket number fits 32 bits */
-		/* (not for the rank path since round 4: a tile with a bucket beyond LDS goes to k_giant_tiles, and what still comes back is ONE k-mer repeated a million
-		 * times — no number of passes splits that; a fifth pass would only cost every later group its time, and records of two words and more their indirect sort) */
-		const u32 extra = rank ? 0u : g_extra_top.load(std::memory_order_relaxed);
-		sp.top = std::min(std::max(sp.top, std::min(sp.top + extra, rank ? 6u : 4u)), key_bytes);
-		if (sp.top + 2 > key_bytes)
-			sp.top = key_bytes;
-	}
-	if (rank) {
-		static const int forced = [] {
-			const char *e = getenv("KMC_HIP_RANK_TOP"); /* tuning: this many top bytes through HBM */
-			return e ? atoi(e) : 0;
-		}();
-		if (forced >= 1 && (u32)forced + 1 <= key_bytes && 8 * (u32)forced > spare)
-			sp.top = (u32)forced;
-		if (sp.local() && sp.top >= 1 && key_bits - sp.hbits() <= rem_limit && sp.hbits() <= 48)
-			sp.rank = true;
-		else
-			sp.top = key_bytes; /* the pair (key bits below the bucket, index) must fit its words */
-	}
+	if (sp.top + 2 > key_bytes)
+		sp.top = key_bytes;
+	/* (no finer buckets after a redo since round 4: a tile with a bucket beyond LDS goes to k_giant_tiles / the arena, and what still comes back is ONE k-mer repeated a
+	 * million times — no number of passes splits that; a fifth pass would only cost every later group its time, and records of two words and more their indirect sort) */
+	static const int forced = [] {
+		const char *e = getenv("KMC_HIP_RANK_TOP"); /* tuning: this many top bytes through HBM */
+		return e ? atoi(e) : 0;
+	}();
+	if (forced >= 1 && (u32)forced + 1 <= key_bytes && 8 * (u32)forced > spare)
+		sp.top = (u32)forced;
+	if (sp.local() && sp.top >= 1 && key_bits - sp.hbits() <= rem_limit && sp.hbits() <= 48)
+		sp.rank = true;
+	else
+		sp.top = key_bytes; /* the pair (key bits below the bucket, index) must fit its words */
 	return sp;
 }
 
@@ -147,7 +130,7 @@ SortPlan plan_sort(u64 n, u32 key_bytes, u32 key_bits, bool classic, bool fused 
  * shards | digit histograms | one scatter status area per onesweep launch over the group's `n_total` records */
 template <int SIZE>
 ZeroPlan plan_group(const Slot &s, std::vector<BinPlan> &bins, u64 n_total, u32 n_pass /* passes through HBM */, bool front, bool sort, bool compact, u64 lut_shard_entries,
-                    u64 cp_tile = CpCfg<SIZE>::TILE /* records per compaction tile: k_compact's, or the window of k_bucket_count / k_bucket_rank */,
+                    u64 cp_tile = CpCfg<SIZE>::TILE /* records per compaction tile: k_compact's, or the window of k_bucket_rank */,
                     u32 cp_words = 1 /* status words per tile (k_bucket_rank: one per chunk, two chunks) */, u64 giant_entries = 0, bool arena = false)
 {
 	ZeroPlan z;
@@ -202,10 +185,10 @@ int apply_plan(Slot &s, const ZeroPlan &z)
 }
 
 /* ---- the sort: histograms of the digits that go through HBM + one onesweep launch per such digit (and portion), then — hybrid — the
- * bucket-aligned LDS sort of the remaining bytes, in place. `d_flag`: where k_bucket_sort reports a tile it could not sort. ---- */
+ * bucket-aligned LDS sort of the remaining bytes, in place (one-word records, k_bucket_rank<1, false>). `d_flag`: where a tile that could not be sorted is reported. ---- */
 template <int SIZE>
 int sort_device_t(Slot &s, const ZeroPlan &z, u64 *d_recs, u64 *d_tmp, u64 n, const SortPlan &sp, u64 **d_result, u32 &counter_idx, bool hist_done, u32 *d_flag,
-                  bool local_by_caller = false /* the caller finishes the low bytes itself (count_group: k_bucket_count) */)
+                  bool local_by_caller = false /* the caller finishes the low bytes itself (rank_group) */)
 {
 	u64 *src = d_recs, *dst = d_tmp;
 	if (n < 2 || sp.key_bytes == 0) {
@@ -262,41 +245,40 @@ int sort_device_t(Slot &s, const ZeroPlan &z, u64 *d_recs, u64 *d_tmp, u64 n, co
 		}
 	} else if (s.timed)
 		HIPCHK(hipEventRecord(s.ev[3], s.stream));
-	if (sp.local() && !local_by_caller) {
-		const u64 S = SIZE == 1 && sp.rank ? (u64)BrCfg<1>::STRIDE : (u64)BsCfg<SIZE>::STRIDE;
-		const u64 n_win = (n + S - 1) / S;
-		if (n_win > 0x7FFFFFF0ull)
-			return fail(KMC_HIP_EINVAL, "bin too large");
-		if (int rc = ensure(s.bounds, (size_t)(n_win + 2) * 8))
-			return rc;
-		u64 *bounds = (u64 *)s.bounds.p;
-		hipEvent_t e0 = nullptr, e1 = nullptr;
-		if (s.timed) {
-			if (int rc = ls_event_pair(s, e0, e1, n))
-				return rc;
-			HIPCHK(hipEventRecord(e0, s.stream));
-		}
-		GrpBounds gbn = {};
-		gbn.g = 1;
-		gbn.item_prefix[1] = (u32)(n_win + 1);
-		gbn.S[0] = src;
-		gbn.n[0] = n;
-		gbn.bounds[0] = bounds;
-		k_bucket_bounds<SIZE><<<dim3((u32)((n_win + 1 + 3) / 4)), dim3(256), 0, s.stream>>>(gbn, (u32)S, sp.key_bits, sp.hbits());
+	if (sp.local() && !local_by_caller) { /* one-word records whose output may outgrow a tile's span: the tiles sorted in place, the caller's k_compact follows */
 		if constexpr (SIZE == 1) {
-			if (sp.rank) { /* the whole array as one "bin": tiles sorted in place (the caller's k_compact follows) */
-				GrpRank gr = {};
-				gr.g = 1;
-				gr.win_prefix[1] = (u32)n_win;
-				gr.S[0] = src;
-				gr.bounds[0] = bounds;
-				k_bucket_rank<1, false><<<dim3((u32)n_win, 2), dim3(BrCfg<1>::THREADS), br_lds_bytes<1>(), s.stream>>>(gr, DevParams{}, sp.key_bits, sp.hbits(), 1u, 0ull, 0u, d_flag);
-			} else
-				k_bucket_sort<SIZE><<<dim3((u32)n_win), dim3(BsCfg<SIZE>::THREADS), bs_lds_bytes<SIZE>(), s.stream>>>(src, sp.key_bits, sp.hbits(), bounds, d_flag);
+			if (!sp.rank)
+				return fail(KMC_HIP_EINTERNAL, "a local sort plan without the rank finisher");
+			const u64 S = (u64)BrCfg<1>::STRIDE;
+			const u64 n_win = (n + S - 1) / S;
+			if (n_win > 0x7FFFFFF0ull)
+				return fail(KMC_HIP_EINVAL, "bin too large");
+			if (int rc = ensure(s.bounds, (size_t)(n_win + 2) * 8))
+				return rc;
+			u64 *bounds = (u64 *)s.bounds.p;
+			hipEvent_t e0 = nullptr, e1 = nullptr;
+			if (s.timed) {
+				if (int rc = ls_event_pair(s, e0, e1, n))
+					return rc;
+				HIPCHK(hipEventRecord(e0, s.stream));
+			}
+			GrpBounds gbn = {};
+			gbn.g = 1;
+			gbn.item_prefix[1] = (u32)(n_win + 1);
+			gbn.S[0] = src;
+			gbn.n[0] = n;
+			gbn.bounds[0] = bounds;
+			k_bucket_bounds<1><<<dim3((u32)((n_win + 1 + 3) / 4)), dim3(256), 0, s.stream>>>(gbn, (u32)S, sp.key_bits, sp.hbits());
+			GrpRank gr = {}; /* the whole array as one "bin" */
+			gr.g = 1;
+			gr.win_prefix[1] = (u32)n_win;
+			gr.S[0] = src;
+			gr.bounds[0] = bounds;
+			k_bucket_rank<1, false><<<dim3((u32)n_win, 2), dim3(BrCfg<1>::THREADS), br_lds_bytes<1>(), s.stream>>>(gr, DevParams{}, sp.key_bits, sp.hbits(), 1u, 0ull, 0u, d_flag);
+			if (s.timed)
+				HIPCHK(hipEventRecord(e1, s.stream));
 		} else
-			k_bucket_sort<SIZE><<<dim3((u32)n_win), dim3(BsCfg<SIZE>::THREADS), bs_lds_bytes<SIZE>(), s.stream>>>(src, sp.key_bits, sp.hbits(), bounds, d_flag);
-		if (s.timed)
-			HIPCHK(hipEventRecord(e1, s.stream));
+			return fail(KMC_HIP_EINTERNAL, "records of two words and more have no in-place local sort");
 	}
 	HIPCHK(hipGetLastError());
 	*d_result = src;
@@ -494,8 +476,8 @@ int compact_group(Slot &s, const std::vector<BinPlan> &bins, const u64 *sorted, 
 	return 0;
 }
 
-/* ---- hybrid groups: the array is ordered by its top bytes only; k_bucket_count turns bucket-aligned tiles straight into (k-mer, count) records in the
- * tiles' spans of the free record array (kernels: bucket_sort.hip.h), then the fold and the gather of the two-phase output as after k_compact. ---- */
+/* ---- may a tile be counted where it lies (k_bucket_rank fused)? A tile's (suffix, counter) records go to the tile's span of the free record array; then the fold and
+ * the gather of the two-phase output as after k_compact. ---- */
 template <int SIZE> bool count_applicable(const DevParams &P)
 {
 	static const bool allow_two_phase = [] {
@@ -507,87 +489,34 @@ template <int SIZE> bool count_applicable(const DevParams &P)
 	const u32 rec_bytes = P.sbytes + P.cbytes;
 	return allow_two_phase && (P.without_output || rec_bytes <= (u32)(SIZE * 8));
 }
-template <int SIZE>
-int count_group(Slot &s, const std::vector<BinPlan> &bins, const u64 *sorted, u64 *scratch, const DevParams &P, u64 lut_entries, const SortPlan &sp, u64 n_total, u32 *d_flag)
-{
-	if (bins.empty())
-		return 0;
-	u32 *err = err_ptr(s);
-	const bool use_lut = lut_entries && !P.without_output && !P.kff;
-	const u32 n_sh = !use_lut ? 1u : lut_shards_for(lut_entries);
-	const u32 rec_bytes = P.sbytes + P.cbytes;
-	constexpr u64 S = BcCfg<SIZE>::STRIDE;
-	GrpBounds gbn = {};
-	GrpBucket gb = {};
-	GrpFold gf = {};
-	GrpGather gg = {};
-	gbn.g = gb.g = gg.g = (u32)bins.size();
-	u64 wins = 0, items = 0;
-	for (const BinPlan &b : bins)
-		items += (b.n_rec + S - 1) / S + 1;
-	if (items > 0x7FFFFFF0ull)
-		return fail(KMC_HIP_EINVAL, "bin too large");
-	if (int rc = ensure(s.bounds, (size_t)(items + 2) * 8))
-		return rc;
-	u64 *bounds = (u64 *)s.bounds.p;
-	items = 0;
-	for (size_t i = 0; i < bins.size(); ++i) {
-		const BinPlan &b = bins[i];
-		const u64 bin_wins = (b.n_rec + S - 1) / S;
-		gbn.item_prefix[i] = (u32)items;
-		gb.win_prefix[i] = gg.tile_prefix[i] = (u32)wins;
-		u64 *lut_base = b.d_lut;
-		if (use_lut && n_sh > 1)
-			lut_base = zero_ptr<u64>(s, b.off_lutsh);
-		else if (lut_entries && !P.kff && b.d_lut) /* also without output: the caller's LUT is zero-filled by the callee (include/kmc_hip.h) */
-			HIPCHK(hipMemsetAsync(b.d_lut, 0, lut_entries * 8, s.stream));
-		gbn.S[i] = gb.S[i] = sorted + b.rec_off * SIZE;
-		gbn.n[i] = gf.n[i] = b.n_rec;
-		gbn.bounds[i] = bounds + items;
-		gb.bounds[i] = bounds + items;
-		gb.scratch[i] = (uint8_t *)(scratch + b.rec_off * SIZE);
-		gb.status[i] = zero_ptr<u64>(s, b.off_cp_status);
-		gb.lut_base[i] = lut_base;
-		gb.tally[i] = zero_ptr<u64>(s, b.off_tally);
-		gf.tally[i] = gb.tally[i];
-		gf.stats[i] = b.d_stats;
-		gf.lut_base[i] = lut_base;
-		gf.lut_out[i] = b.d_lut;
-		gf.status[i] = gb.status[i];
-		gf.n_tiles[i] = (u32)bin_wins;
-		gf.out_bytes[i] = b.d_out_bytes;
-		gf.out_capacity[i] = b.out_capacity;
-		gg.scratch[i] = gb.scratch[i];
-		gg.prefix[i] = gb.status[i];
-		gg.out[i] = b.d_out;
-		gg.out_capacity[i] = b.out_capacity;
-		gg.src_rec[i] = bounds + items;
-		items += bin_wins + 1;
-		wins += bin_wins;
-	}
-	gbn.item_prefix[bins.size()] = (u32)items;
-	gb.win_prefix[bins.size()] = gg.tile_prefix[bins.size()] = (u32)wins;
-	hipEvent_t e0 = nullptr, e1 = nullptr;
-	if (s.timed) {
-		if (int rc = ls_event_pair(s, e0, e1, n_total))
-			return rc;
-		HIPCHK(hipEventRecord(e0, s.stream));
-	}
-	k_bucket_bounds<SIZE><<<dim3((u32)((items + 3) / 4)), dim3(256), 0, s.stream>>>(gbn, (u32)S, sp.key_bits, sp.hbits());
-	k_bucket_count<SIZE><<<dim3((u32)wins), dim3(BcCfg<SIZE>::THREADS), bc_lds_bytes<SIZE>(), s.stream>>>(
-	    gb, P, sp.key_bits, sp.hbits(), n_sh, lut_entries, P.lut_prefix_len ? (u32)((1ull << (2 * P.lut_prefix_len)) - 1) : 0u, d_flag);
-	if (s.timed)
-		HIPCHK(hipEventRecord(e1, s.stream));
-	k_compact_fold<<<dim3((u32)bins.size()), dim3(256), 0, s.stream>>>(gf, use_lut ? n_sh : 1u, lut_entries, 1u, rec_bytes, err);
-	if (!P.without_output)
-		k_compact_gather<<<dim3((u32)((wins + 3) / 4)), dim3(256), 0, s.stream>>>(gg, rec_bytes, (u64)SIZE * 8);
-	HIPCHK(hipGetLastError());
-	return 0;
-}
-
 /* ---- rank groups (default since round 4): the array is ordered by its top bytes only; k_bucket_rank puts every bucket-aligned tile of every bin in order
  * inside LDS and counts it there, straight into the tile's span of the free record array; then the fold and the gather of the two-phase output. A tile has
  * two output slots (one per chunk: a tile that outgrows the capacity is taken by two workgroups). ---- */
+/* $KMC_HIP_CU_SPLIT: everything rank_group enqueues goes to the slot's fin_stream (its own share of the CUs), behind the passes and in front of the slot's next work */
+struct FinScope {
+	Slot &s;
+	hipStream_t main;
+	bool on = false;
+	explicit FinScope(Slot &slot) : s(slot), main(slot.stream) {}
+	int enter()
+	{
+		if (!s.fin_stream)
+			return 0;
+		HIPCHK(hipEventRecord(s.ev_split, main));
+		HIPCHK(hipStreamWaitEvent(s.fin_stream, s.ev_split, 0));
+		s.stream = s.fin_stream;
+		on = true;
+		return 0;
+	}
+	~FinScope()
+	{
+		if (!on)
+			return;
+		(void)hipEventRecord(s.ev_fin, s.fin_stream);
+		s.stream = main;
+		(void)hipStreamWaitEvent(main, s.ev_fin, 0);
+	}
+};
 template <int SIZE>
 int rank_group(Slot &s, const std::vector<BinPlan> &bins, u64 *sorted, u64 *scratch, const DevParams &P, u64 lut_entries, const SortPlan &sp, u64 n_total, u32 *d_flag,
                u32 *d_giant, const u64 *d_recs_indirect = nullptr /* indirect sort: `sorted` is the ordered PAIR array (one word per record), the records are here */,
@@ -595,6 +524,9 @@ int rank_group(Slot &s, const std::vector<BinPlan> &bins, u64 *sorted, u64 *scra
 {
 	if (bins.empty())
 		return 0;
+	FinScope fin(s);
+	if (int rc = fin.enter())
+		return rc;
 	u32 *err = err_ptr(s);
 	const bool use_lut = lut_entries && !P.without_output && !P.kff;
 	const u32 n_sh = !use_lut ? 1u : lut_shards_for(lut_entries);
@@ -988,21 +920,16 @@ int run_group_device_t(Slot &s, const DevParams &P, const kmc_hip_bin_desc *cons
 	if (2 * k + tag_bits > 64u * SIZE)
 		return fail(KMC_HIP_EINVAL, "group too large for the record width");
 	const u32 key_bytes = (2 * k + tag_bits + 7) / 8;
-	/* hybrid: only the top bytes of the key go through HBM passes, the rest is sorted inside LDS (bucket_sort.hip.h) */
-	/* ... and then the tiles are counted where they lie (k_bucket_count): possible whenever a tile's records fit its span of the free array */
-	/* one-word records (k <= 32) of a default run: the top bytes through HBM, every tile put in order inside LDS by k_bucket_rank, then k_compact as ever */
-	/* default run (round 4): the top bytes through HBM, every tile put in order inside LDS by k_bucket_rank and counted there (fused: whenever a tile's
-	 * records fit its span of the free array; else, one-word records only, the tile is sorted in place and k_compact follows) */
+	/* default run (round 4): only the top bytes of the key go through HBM passes, every tile is put in order inside LDS by k_bucket_rank and counted there (fused:
+	 * whenever a tile's records fit its span of the free array; else, one-word records only, the tile is sorted in place and k_compact follows). Where the rank
+	 * plan does not apply (too many key bits left below the buckets, tiny groups, redo runs): LSD passes over every byte + k_compact */
 	static const bool fuse_enabled = [] {
-		const char *e = getenv("KMC_HIP_RANK_FUSE"); /* 0 (A/B runs): round 3's default — one-word records ranked in place + k_compact, wider ones k_bucket_count */
+		const char *e = getenv("KMC_HIP_RANK_FUSE"); /* 0 (A/B runs): one-word records ranked in place + k_compact, wider ones LSD passes over every byte */
 		return !e || atoi(e) != 0;
 	}();
 	const bool can_fuse = count_applicable<SIZE>(P);
 	const bool by_rank = !classic && hybrid_mode() == 1 && rank_enabled() && (SIZE == 1 || (can_fuse && fuse_enabled));
-	SortPlan sp = by_rank ? plan_sort<SIZE>(N, key_bytes, 2 * k + tag_bits, false, false, true)
-	                      : plan_sort<SIZE>(N, key_bytes, 2 * k + tag_bits, classic || !can_fuse, true);
-	if (by_rank && !sp.rank && SIZE > 1 && can_fuse) /* the rank plan did not apply (too many key bits left below the buckets): k_bucket_count as in round 3 */
-		sp = plan_sort<SIZE>(N, key_bytes, 2 * k + tag_bits, false, true);
+	const SortPlan sp = plan_sort<SIZE>(N, key_bytes, 2 * k + tag_bits, !by_rank, by_rank);
 	const bool rank_fused = sp.rank && can_fuse && fuse_enabled;
 	const u32 n_pass = sp.top;
 	if (used_hybrid)
@@ -1032,7 +959,7 @@ int run_group_device_t(Slot &s, const DevParams &P, const kmc_hip_bin_desc *cons
 		for (const BinPlan &b : bins)
 			rank_tiles += (b.n_rec + BrCfg<SIZE>::STRIDE - 1) / BrCfg<SIZE>::STRIDE;
 	const ZeroPlan z = plan_group<SIZE>(s, bins, N, n_pass, true, true, true, n_sh > 1 ? (u64)n_sh * lut_entries : 0,
-	                                    rank_fused ? (u64)BrCfg<SIZE>::STRIDE : (sp.local() && !sp.rank ? (u64)BcCfg<SIZE>::STRIDE : (u64)CpCfg<SIZE>::TILE), rank_fused ? 2u : 1u,
+	                                    rank_fused ? (u64)BrCfg<SIZE>::STRIDE : (u64)CpCfg<SIZE>::TILE, rank_fused ? 2u : 1u,
 	                                    rank_tiles, rank_fused && SIZE == 1 && arena_enabled());
 	if ((rc = apply_plan(s, z))) /* ONE memset per group: small block, bitmaps, look-back words, histograms, LUT and tally shards, scatter status */
 		return rc;
@@ -1088,8 +1015,6 @@ int run_group_device_t(Slot &s, const DevParams &P, const kmc_hip_bin_desc *cons
 	if (rank_fused && sp.local() && N >= 2)
 		rc = rank_group<SIZE>(s, bins, sorted, free_array, P, lut_entries, sp, N, flag, zero_ptr<u32>(s, z.giant), indirect ? (const u64 *)s.recA.p : nullptr,
 		                      z.arena ? zero_ptr<u32>(s, z.arena) : nullptr);
-	else if (sp.local() && !sp.rank && N >= 2)
-		rc = count_group<SIZE>(s, bins, sorted, free_array, P, lut_entries, sp, N, flag);
 	else
 		rc = compact_group<SIZE>(s, bins, sorted, free_array, P, lut_entries, counter_idx);
 	if (rc)

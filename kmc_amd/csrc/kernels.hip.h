@@ -164,7 +164,7 @@ struct GrpGather { /* two-phase output: tile t's records move from scratch + t *
 	const u64 *prefix[GRP_MAX]; /* [n_tiles + 1] */
 	uint8_t *out[GRP_MAX];
 	u64 out_capacity[GRP_MAX];
-	const u64 *src_rec[GRP_MAX]; /* NULL, or (k_bucket_count's tiles) the first record of every tile: tile t's records lie at scratch + src_rec[t] * tile_pitch */
+	const u64 *src_rec[GRP_MAX]; /* NULL, or (k_bucket_rank's tiles) the first record of every tile: tile t's records lie at scratch + src_rec[t] * tile_pitch */
 };
 /* bin of work item `item` (wave-uniform) */
 __device__ __forceinline__ u32 grp_find(const u32 (&prefix)[GRP_MAX + 1], u32 g, u32 item)

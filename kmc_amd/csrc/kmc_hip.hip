@@ -109,7 +109,7 @@ int ensure_pinned(void *&p, size_t &cap, size_t bytes)
 constexpr size_t SM_STATS = 16;      /* u64[4]                           */
 constexpr size_t SM_OUTBYTES = 48;   /* u64                              */
 constexpr size_t SM_ERR = 56;        /* u32: copy of the slot's sticky error word, taken when a host-boundary bin ends */
-constexpr size_t SM_REDO = 60;       /* u32: set by k_bucket_sort when a tile of the hybrid sort did not fit: the host sorts the group again, LSD over all bytes */
+constexpr size_t SM_REDO = 60;       /* u32: set by the LDS finisher when a tile of the hybrid sort did not fit: the host sorts the group again, LSD over all bytes */
 constexpr size_t SM_DBASE_WORK = 256; /* u64[2][256] per-portion digit bases (ping-pong) */
 constexpr size_t SM_COUNTERS = 256 + 2 * 256 * 8; /* u32[N_COUNTERS] ticket counters, one per launch (the tally shards of the compaction are per bin, BinPlan) */
 constexpr size_t N_COUNTERS = 4096;
@@ -156,6 +156,11 @@ struct HbRes {
 
 struct Slot {
 	hipStream_t stream = nullptr;
+	/* $KMC_HIP_CU_SPLIT=B (experiment, round 6): `stream` may use all CUs but the last B, `fin_stream` those B; rank_group runs the finisher of a group on fin_stream
+	 * (ordered behind the group's passes and in front of whatever the slot does next by two events), so that with several slots in flight the VALU-bound finisher of one
+	 * group and the HBM-bound passes of another run side by side on disjoint CUs instead of one after the other */
+	hipStream_t fin_stream = nullptr;
+	hipEvent_t ev_split = nullptr, ev_fin = nullptr;
 	std::mutex mtx; /* serialises enqueueing on this slot (asynchronous device-resident calls may come from several threads) */
 	u64 portion = PORTION_MAX;
 	DBuf in, pack_start;
@@ -176,7 +181,7 @@ struct Slot {
 	hipEvent_t done_ev = nullptr; /* blocking-sync event: _wait must not spin (stage-2 workers outnumber the cores a container may use) */
 	/* one event pair per scatter launch since the last harvest (roofline input) */
 	std::vector<hipEvent_t> sc_ev;
-	std::vector<u64> sc_cnt; /* records of the launch; bit 63: the pair brackets the LDS sort (k_bucket_bounds + k_bucket_sort), not a scatter pass */
+	std::vector<u64> sc_cnt; /* records of the launch; bit 63: the pair brackets the LDS sort (k_bucket_bounds + k_bucket_rank), not a scatter pass */
 	u32 sc_used = 0;
 	double sc_ms_total = 0, ls_ms_total = 0;
 	u64 sc_keys_total = 0, sc_launch_total = 0, ls_keys_total = 0, ls_launch_total = 0;
@@ -256,10 +261,6 @@ template <int SIZE> int set_func_attrs()
 	if (rs_lds_bytes<SIZE>() > 65536)
 		HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_onesweep<SIZE>), hipFuncAttributeMaxDynamicSharedMemorySize,
 		                           (int)rs_lds_bytes<SIZE>()));
-	if (bc_lds_bytes<SIZE>() > 65536)
-		HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_bucket_count<SIZE>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bc_lds_bytes<SIZE>()));
-	if (bs_lds_bytes<SIZE>() > 65536)
-		HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_bucket_sort<SIZE>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bs_lds_bytes<SIZE>()));
 	if (br_lds_bytes<SIZE>() > 65536) {
 		HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_bucket_rank<SIZE, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)br_lds_bytes<SIZE>() + 32 * 1024)); /* + room for $KMC_HIP_RANK_LDS_PAD */
 		if (SIZE == 1) {
@@ -282,7 +283,25 @@ int set_all_func_attrs()
 int slot_init(Slot &s, u64 portion)
 {
 	s.portion = portion;
-	HIPCHK(hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking));
+	static const int cu_split = [] {
+		const char *e = getenv("KMC_HIP_CU_SPLIT");
+		return e ? atoi(e) : 0;
+	}();
+	int n_cu = 0, dev = 0;
+	if (cu_split > 0) {
+		HIPCHK(hipGetDevice(&dev));
+		HIPCHK(hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev));
+	}
+	if (cu_split >= 8 && n_cu >= 16 && cu_split <= n_cu - 8 && n_cu <= 1024) {
+		std::vector<uint32_t> mask_a((size_t)(n_cu + 31) / 32, 0u), mask_b((size_t)(n_cu + 31) / 32, 0u);
+		for (int i = 0; i < n_cu; ++i) /* (bit i of a queue's mask is CU i / n_xcc of XCC i mod n_xcc: both shares lie on every XCD) */
+			(i < n_cu - cu_split ? mask_a : mask_b)[(size_t)i / 32] |= 1u << (i % 32);
+		HIPCHK(hipExtStreamCreateWithCUMask(&s.stream, (uint32_t)mask_a.size(), mask_a.data()));
+		HIPCHK(hipExtStreamCreateWithCUMask(&s.fin_stream, (uint32_t)mask_b.size(), mask_b.data()));
+		HIPCHK(hipEventCreateWithFlags(&s.ev_split, hipEventDisableTiming));
+		HIPCHK(hipEventCreateWithFlags(&s.ev_fin, hipEventDisableTiming));
+	} else
+		HIPCHK(hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking));
 	HIPCHK(hipHostMalloc((void **)&s.h_res, sizeof(HostRes), hipHostMallocDefault));
 	memset(s.h_res, 0, sizeof(HostRes));
 	for (auto &e : s.ev)
@@ -317,6 +336,12 @@ void slot_destroy(Slot &s)
 		(void)hipEventDestroy(e);
 	if (s.done_ev)
 		(void)hipEventDestroy(s.done_ev);
+	if (s.ev_split)
+		(void)hipEventDestroy(s.ev_split);
+	if (s.ev_fin)
+		(void)hipEventDestroy(s.ev_fin);
+	if (s.fin_stream)
+		(void)hipStreamDestroy(s.fin_stream);
 	if (s.stream)
 		(void)hipStreamDestroy(s.stream);
 }

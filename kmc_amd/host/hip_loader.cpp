@@ -10,6 +10,8 @@
  *                    initialise; HIP_VISIBLE_DEVICES narrows the set from outside); worker i uses device i % n_devices
  *   KMC_HIP_EAGER_INIT  "0": load the library at the first stage-2 worker instead of at program start
  *   KMC_HIP_VERBOSE  "1": print where the worker spent its time when the last engine is destroyed
+ *   KMC_HIP_PINNED_POOL_MB  pinned slab for the bin images (host_pool.h; default 4096, 0 = none): ordinary memory on huge pages, registered with the runtime
+ *   KMC_HIP_TUNE_MALLOC  "0": do not re-execute the program with the allocator tunables below (tune_allocator())
  * There is deliberately NO CPU fallback here: if the library or a GPU is missing the engine reports the error and
  * the worker raises it through CCriticalErrorHandler.
  */
@@ -17,6 +19,7 @@
 #include <execinfo.h>
 #include <pthread.h>
 #include <signal.h>
+#include <sys/mman.h>
 #include <unistd.h>
 
 #include <chrono>
@@ -49,6 +52,7 @@ struct Api {
 	int (*sort_into)(kmc_hip_ctx *, int, const void *, void *, uint64_t, uint32_t, uint32_t) = nullptr;
 	int (*host_alloc)(kmc_hip_ctx *, uint64_t, void **) = nullptr; /* optional: pinned buffers for the reader plug-in (KmcHostPool) */
 	int (*host_free)(kmc_hip_ctx *, void *) = nullptr;
+	int (*host_register)(kmc_hip_ctx *, void *, uint64_t) = nullptr;
 	int n_slots = 1;
 	std::mutex slot_mtx[64][16]; /* the C-ABI wants calls on one (device, slot) serialised; workers may outnumber slots */
 	kmc_hip_ctx *ctx = nullptr;
@@ -186,13 +190,29 @@ void load_api_impl()
 	   * that brings the library up during stage 1 — so that stage 2 never waits for the runtime to pin anything */
 		std::string ignore;
 		const size_t want = KmcHostPool::wanted_bytes();
-		if (want && sym(a.so, "kmc_hip_host_alloc", a.host_alloc, ignore) && sym(a.so, "kmc_hip_host_free", a.host_free, ignore)) {
-			void *p = nullptr;
-			if (a.host_alloc(a.ctx, want, &p) == 0 && p)
-				KmcHostPool::inst().adopt(p, want, [](void *q) { (void)g_api.host_free(g_api.ctx, q); });
-			else if (getenv("KMC_HIP_VERBOSE"))
-				fprintf(stderr, "[kmc_hip] no pinned pool (%zu MB refused): bin images go through the arena\n", want >> 20);
+		bool have = false;
+		/* ordinary anonymous memory on huge pages, pinned by registration: registering is an order of magnitude cheaper than hipHostMalloc (profiles/r02/ubench_host.json:
+		 * 126 against 7.7 GB/s) and — measured in round 6 — a hipHostMalloc slab of 8 GB added 2 s to the process's exit. Never unmapped: the kernel takes it back at exit */
+		if (want && sym(a.so, "kmc_hip_host_register", a.host_register, ignore)) {
+			void *p = mmap(nullptr, want, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS | MAP_NORESERVE, -1, 0);
+			if (p != MAP_FAILED) {
+				(void)madvise(p, want, MADV_HUGEPAGE);
+				if (a.host_register(a.ctx, p, want) == 0) {
+					KmcHostPool::inst().adopt(p, want, nullptr);
+					have = true;
+				} else
+					munmap(p, want);
+			}
 		}
+		if (want && !have && sym(a.so, "kmc_hip_host_alloc", a.host_alloc, ignore) && sym(a.so, "kmc_hip_host_free", a.host_free, ignore)) {
+			void *p = nullptr;
+			if (a.host_alloc(a.ctx, want, &p) == 0 && p) {
+				KmcHostPool::inst().adopt(p, want, [](void *q) { (void)g_api.host_free(g_api.ctx, q); });
+				have = true;
+			}
+		}
+		if (want && !have && getenv("KMC_HIP_VERBOSE"))
+			fprintf(stderr, "[kmc_hip] no pinned pool (%zu MB refused): bin images go through the arena\n", want >> 20);
 	}
 	a.n_slots = a.num_slots();
 	if (a.n_slots > 16)
@@ -280,6 +300,44 @@ struct HipEngine : KmcBinEngine {
  * the whole stage 2 of a 2 Gbp input — and nothing in kmc_core runs before stage 2 that the worker could hook. So the
  * library is loaded by a background thread started when the program is loaded, i.e. during stage 1; the first worker only
  * waits for it (call_once). KMC_HIP_EAGER_INIT=0 restores the lazy behaviour (load at the first stage-2 worker). */
+#ifdef __GLIBC__
+/* The allocator under the REFERENCE's RAM-only pipeline (measured in round 6, profiles/r06/e2e_sweep_8gbp.jsonl). Stage 1 keeps every bin as a list of `new uchar[]`
+ * parts (mem_disk_file.cpp:111-126), tens of megabytes each: mmap'ed chunks on 4 KB pages. Stage 2's CMemDiskFile::Read copies a part and deletes it
+ * (mem_disk_file.cpp:84-100): an munmap of ~12 000 pages under the process's mmap lock, from every reader thread — and everything else that needs that lock waits: the
+ * workers' page faults and the runtime's device allocations (16 workers spent 6.6 s in "pack starts + buffers" where 1.8 s suffice). With
+ *   glibc.malloc.mmap_max=0, trim_threshold / top_pad large : large blocks come from the heap and go back to malloc's lists, not to the kernel (reader wall 0.66 -> 0.20 s,
+ *                                                             "2nd stage" 1.26 -> 0.77 s on 8 Gbp; the pages are returned when the process exits instead)
+ *   glibc.malloc.hugetlb=1                                  : the heap on transparent huge pages where the system offers them by madvise (stage 1's storer touches
+ *                                                             512x fewer pages: "1st stage" 7.9 -> 6.3 s, process wall 9.7 -> 8.5 s)
+ * Tunables are read when the process starts, so the program re-executes itself ONCE, before main() and before any thread exists, with $GLIBC_TUNABLES completed
+ * (settings the user gave are kept). KMC_HIP_TUNE_MALLOC=0 switches this off; a failed exec just carries on. */
+__attribute__((constructor(101))) static void tune_allocator(int /*argc*/, char **argv, char ** /*envp*/)
+{
+	const char *sw = getenv("KMC_HIP_TUNE_MALLOC");
+	if ((sw && sw[0] == '0') || getenv("KMC_HIP_TUNED") || !argv || !argv[0])
+		return;
+	const char *cur = getenv("GLIBC_TUNABLES");
+	std::string t = cur ? cur : "";
+	auto add = [&t](const char *name, const char *val) {
+		if (t.find(name) != std::string::npos)
+			return;
+		if (!t.empty())
+			t += ":";
+		t += name;
+		t += "=";
+		t += val;
+	};
+	add("glibc.malloc.hugetlb", "1");
+	add("glibc.malloc.mmap_max", "0");
+	add("glibc.malloc.trim_threshold", "1099511627776");
+	add("glibc.malloc.top_pad", "1073741824");
+	setenv("GLIBC_TUNABLES", t.c_str(), 1);
+	setenv("KMC_HIP_TUNED", "1", 1);
+	execv("/proc/self/exe", argv);
+	unsetenv("KMC_HIP_TUNED"); /* could not: untuned, as before */
+}
+#endif
+
 namespace {
 struct EagerInit {
 	std::thread th;

@@ -623,7 +623,7 @@ def test_eight_logical_devices_run_their_lpt_shards_concurrently_and_reduce_the_
     from kmc_amd import sharding
 
     bins = capi.synth_bins(seed=11, genome_len=3_000_000, n_reads=600_000, k=27, n_bins=64, n_threads=4)
-    p = hp(27, lut_prefix_len=5)
+    p = hp(27, lut_prefix_len=7)
     c1 = capi.Context((0,))
     try:
         want, err = _run_batch(c1, p, bins, 0)
@@ -733,7 +733,7 @@ HOST_GROUP_CASES = [
 
 
 @pytest.mark.parametrize("k,kw,n_bins", HOST_GROUP_CASES, ids=lambda v: str(v) if not isinstance(v, dict) else "-".join(f"{a}{b}" for a, b in v.items()))
-@pytest.mark.parametrize("hybrid", [0, 1, 2], ids=["lsd", "default", "hybrid"])
+@pytest.mark.parametrize("hybrid", [0, 1], ids=["lsd", "default"])
 def test_host_boundary_with_several_bins_per_call_matches_the_oracle_per_bin(ctx, k, kw, n_bins, hybrid):
     """kmc_hip_process_bins_submit/_wait: the bins of one call are uploaded together and sorted together (tags in the spare bits of the top digit), every
     bin gets its own records, LUT and tallies — those of kmc_hip_process_bin. With caller-supplied packs and without, an empty bin among them."""
@@ -851,18 +851,18 @@ def test_host_boundary_storm_sixteen_slots_in_flight(group):
 
 
 def test_host_boundary_group_redo_errors_and_slot_reuse(ctx):
-    before = ctx.set_hybrid(2)
-    try:
-        bins = capi.synth_bins(seed=5, genome_len=300, n_reads=20_000, k=27, n_bins=3, err=0.0)  # one k-mer thousands of times: the hybrid sort hands the group back
-        p = hp(27)
-        r0 = ctx.local_sort_totals()["redo_groups"]
-        got = ctx.process_bins_host(p, [(b[0], b[1], b[2]) for b in bins])
-        for i, b in enumerate(bins):
-            w = O.process_bin(op(p), b[0], b[1])
-            assert all(np.array_equal(x, y) for x, y in zip(got[i], w)), i
-        assert ctx.local_sort_totals()["redo_groups"] > r0
-    finally:
-        ctx.set_hybrid(before)
+    small = capi.backend_kind() != 0  # the emulated host library: GT_MAX_RECORDS is 2048 there
+    # two-word records with one k-mer more often than k_giant_tiles takes (2^20 copies): the bins come back for LSD passes over every byte, inside the same call
+    bins = capi.synth_bins(seed=5, genome_len=190, n_reads=1_300_000 if not small else 2600, k=55, n_bins=2, err=0.0)
+    p55 = hp(55)
+    r0 = ctx.local_sort_totals()["redo_groups"]
+    got = ctx.process_bins_host(p55, [(b[0], b[1], b[2]) for b in bins])
+    for i, b in enumerate(bins):
+        w = O.process_bin(op(p55), b[0], b[1])
+        assert all(np.array_equal(x, y) for x, y in zip(got[i], w)), i
+    assert ctx.local_sort_totals()["redo_groups"] > r0
+    bins = capi.synth_bins(seed=5, genome_len=300, n_reads=20_000 if not small else 1500, k=27, n_bins=3, err=0.0)
+    p = hp(27)
     img, nk, packs = binsynth.random_bin(np.random.default_rng(1), 27, 500, max_extra=20)
     with pytest.raises(capi.KmcHipError) as e:
         ctx.process_bins_host(p, [(bins[0][0], bins[0][1], bins[0][2]), (img, nk + 1, packs)])
@@ -961,76 +961,6 @@ def test_process_bin_multi_over_two_gpus_exchanges_through_rccl():
             assert all(np.array_equal(a, b) for a, b in zip(got, w)), k
     finally:
         c.close()
-
-
-# ------------------------------------------------------------------------------------------------ hybrid sort (bucket_sort.hip.h)
-@pytest.fixture
-def hybrid_everywhere(ctx):
-    """the hybrid path for every record width (by default one-word records take the LSD passes), counters cleared; restored afterwards"""
-    before = ctx.set_hybrid(2)
-    yield ctx
-    ctx.set_hybrid(before)
-
-
-@pytest.mark.parametrize("k,pl,reads,genome,n_bins,kw", [(27, 7, 400_000, 2_000_000, 16, {}), (27, 3, 120_000, 600_000, 5, {"cutoff_min": 1}), (32, 4, 100_000, 500_000, 8, {}),
-                                                         (33, 5, 100_000, 500_000, 8, {}), (55, 7, 200_000, 1_000_000, 8, {}), (127, 3, 60_000, 300_000, 4, {"cutoff_min": 1, "counter_max": 3}),
-                                                         (27, 0, 100_000, 500_000, 8, {"output_type": 1}), (55, 0, 60_000, 300_000, 4, {"output_type": 1}), (27, 3, 100_000, 500_000, 4, {"without_output": 1}),
-                                                         (200, 4, 20_000, 100_000, 3, {"cutoff_min": 1})])
-def test_hybrid_sort_groups_match_the_oracle_per_bin(hybrid_everywhere, k, pl, reads, genome, n_bins, kw):
-    """LSD passes over the TOP key bytes only, then k_bucket_count on bucket-aligned tiles in LDS (no sorted records ever reach HBM): every bin of
-    every group byte for byte against the oracle — suffix records, LUT, tallies — and no group may have been handed back to the host."""
-    ctx = hybrid_everywhere
-    bins = capi.synth_bins(seed=99, genome_len=genome, n_reads=reads, k=k, n_bins=n_bins, read_len=150 if k < 140 else 300)
-    p = hp(k, lut_prefix_len=pl, **kw)
-    got, err = _run_batch(ctx, p, bins, 1)
-    assert err is None, err
-    for i, (img, nrec, packs, _) in enumerate(bins):
-        w_out, w_lut, w_st = O.process_bin(op(p), img, nrec)
-        assert np.array_equal(got[i][2], w_st), (i, got[i][2], w_st)
-        assert np.array_equal(got[i][0], w_out), (i, _first_diff(got[i][0], w_out))
-        assert np.array_equal(got[i][1], w_lut), i
-    t = ctx.local_sort_totals()
-    assert t["hybrid_groups"] >= 1 and t["redo_groups"] == 0, t
-
-
-@pytest.mark.parametrize("k", [27, 55])
-def test_hybrid_sort_hands_a_group_with_a_huge_bucket_back_to_the_lsd_passes(hybrid_everywhere, k):
-    """one k-mer repeated more often than a tile holds records (a 300 bp 'genome' read 20 000 times): k_bucket_count must say so (redo), the host
-    must sort the group again with LSD passes over every byte, and the result must be the oracle's — through the asynchronous device-resident
-    entry and through the host-buffer entry."""
-    ctx = hybrid_everywhere
-    bins = capi.synth_bins(seed=5, genome_len=300, n_reads=20_000, k=k, n_bins=2, read_len=150, err=0.0)
-    p = hp(k, lut_prefix_len=3)
-    got, err = _run_batch(ctx, p, bins, 1)
-    assert err is None, err
-    for i, (img, nrec, packs, _) in enumerate(bins):
-        w = O.process_bin(op(p), img, nrec)
-        assert np.array_equal(got[i][0], w[0]) and np.array_equal(got[i][1], w[1]) and np.array_equal(got[i][2], w[2]), i
-    t = ctx.local_sort_totals()
-    assert t["redo_groups"] >= 1, t
-    img, nrec, packs, _ = max(bins, key=lambda b: b[1])
-    out, lut, st = ctx.process_bin(p, img, nrec, packs)
-    w = O.process_bin(op(p), img, nrec)
-    assert np.array_equal(out, w[0]) and np.array_equal(lut, w[1]) and np.array_equal(st, w[2])
-    assert ctx.local_sort_totals()["redo_groups"] >= 1
-
-
-def test_hybrid_sort_only_calls_match_the_oracle(hybrid_everywhere):
-    """kmc_hip_sort_records under the hybrid mode: k_bucket_sort finishes the low bytes in LDS; skewed input goes back to the LSD passes"""
-    ctx = hybrid_everywhere
-    rng = np.random.default_rng(17)
-    for words, kb, n in ((1, 7, 300_001), (2, 14, 100_003), (4, 32, 50_000)):
-        recs = rng.integers(0, 2**63, size=(n, words), dtype=np.uint64)
-        for w in range(words):
-            lo = 8 * w
-            if kb <= lo:
-                recs[:, w] = 0
-            elif kb - lo < 8:
-                recs[:, w] &= np.uint64((1 << (8 * (kb - lo))) - 1)
-        got = ctx.sort_records(recs, kb)
-        assert np.array_equal(got, O.sort(recs))
-    a = np.where(rng.random(200_000) < 0.5, np.uint64(5), np.uint64(0x0011223344556677))
-    assert np.array_equal(ctx.sort_records(a.reshape(-1, 1), 7)[:, 0], np.sort(a))
 
 
 # ------------------------------------------------------------------------------------------------ globally ordered database (SURVEY 8f rank 4)

@@ -114,7 +114,6 @@ from kmc_amd import capi
 from test_gpu_parity import _run_batch
 
 ctx = capi.Context((0,))
-ctx.set_hybrid(2)  # the hybrid sort for every record width
 for k, pl, kw in ((27, 3, {}), (55, 3, {"cutoff_min": 1}), (27, 0, {"output_type": 1})):
     bins = capi.synth_bins(seed=7, genome_len=6000, n_reads=1200, k=k, n_bins=5, n_threads=1)
     p = capi.make_params(k, lut_prefix_len=pl, **kw)
@@ -126,10 +125,10 @@ for k, pl, kw in ((27, 3, {}), (55, 3, {"cutoff_min": 1}), (27, 0, {"output_type
         assert np.array_equal(got[i][0], w[0]) and np.array_equal(got[i][1], w[1]) and np.array_equal(got[i][2], w[2]), (k, i)
 t = ctx.local_sort_totals()
 assert t["hybrid_groups"] >= 3 and t["redo_groups"] == 0, t
-# one k-mer repeated more often than a tile of the small geometry holds records: the group must come back through the LSD passes
-bins = capi.synth_bins(seed=5, genome_len=300, n_reads=1500, k=27, n_bins=2, err=0.0, n_threads=1)
-p = capi.make_params(27)
-op = O.make_params(27)
+# two-word records with one k-mer more often than k_giant_tiles takes (GT_MAX_RECORDS: 2048 in this build): the bins must come back through the LSD passes
+bins = capi.synth_bins(seed=5, genome_len=190, n_reads=2600, k=55, n_bins=2, err=0.0, n_threads=1)
+p = capi.make_params(55)
+op = O.make_params(55)
 got, err = _run_batch(ctx, p, bins, 1)
 assert err is None, err
 for i, (img, nrec, packs, _) in enumerate(bins):
@@ -147,11 +146,11 @@ for k, pl, kw, nb in ((27, 3, {}, 7), (55, 3, {"cutoff_min": 1}, 5), (27, 0, {"o
     for i, (img, nrec, _) in enumerate(hb):
         w = O.process_bin(op, img, nrec) if nrec else (np.zeros(0, np.uint8), np.zeros(ctx.lut_entries(p), np.uint64), np.zeros(4, np.uint64))
         assert np.array_equal(got[i][0], w[0]) and np.array_equal(got[i][1], w[1]) and np.array_equal(got[i][2], w[2]), (k, i)
-bins = capi.synth_bins(seed=5, genome_len=300, n_reads=1500, k=27, n_bins=3, err=0.0, n_threads=1)  # ... and a group that comes back for LSD passes
+bins = capi.synth_bins(seed=5, genome_len=190, n_reads=2600, k=55, n_bins=3, err=0.0, n_threads=1)  # ... and bins that come back for LSD passes
 before = ctx.local_sort_totals()["redo_groups"]
-got = ctx.process_bins_host(capi.make_params(27), [(b[0], b[1], b[2]) for b in bins])
+got = ctx.process_bins_host(capi.make_params(55), [(b[0], b[1], b[2]) for b in bins])
 for i, b in enumerate(bins):
-    w = O.process_bin(O.make_params(27), b[0], b[1])
+    w = O.process_bin(O.make_params(55), b[0], b[1])
     assert np.array_equal(got[i][0], w[0]) and np.array_equal(got[i][1], w[1]) and np.array_equal(got[i][2], w[2]), i
 assert ctx.local_sort_totals()["redo_groups"] > before
 rng = np.random.default_rng(3)
@@ -241,8 +240,8 @@ def test_rank_path_on_the_emulated_host_library(arena):
 
 
 def test_hybrid_sort_on_the_emulated_host_library():
-    """bucket_sort.hip.h on the CPU: k_bucket_bounds + k_bucket_count (groups of bins, k = 27 / 55, KFF records) and k_bucket_sort (sort-only call)
-    against the oracle, and the redo of a group whose tile does not fit — through the product's host library over the emulated runtime; and the host
+    """bucket_sort.hip.h on the CPU, as a default run takes it: k_bucket_bounds + k_bucket_rank (groups of bins, k = 27 / 55, KFF records), a sort-only call (LSD passes)
+    against the oracle, and the redo of bins with a bucket nothing on the device takes — through the product's host library over the emulated runtime; and the host
     boundary with several bins per call (kmc_hip_process_bins_submit/_wait), hybrid and redo included."""
     lib = emu.build_hostlib("small")
     r = subprocess.run([sys.executable, "-c", _HYBRID_CASE % {"root": ROOT}], env=dict(os.environ, KMC_HIP_LIB=lib), capture_output=True, text=True, timeout=1500, cwd=ROOT)

@@ -158,8 +158,17 @@ def test_oracle_database_equals_reference(flags, ref_bins, tmp_path):
                            ("kmc_oracle", "orc12", ["-t16", "-sr12"])):
         tmp = tmp_path / ("tmp_" + out)
         tmp.mkdir()
-        subprocess.check_call([ref_bins[exe], *flags, *mode, fq, str(tmp_path / out), str(tmp)], stdout=subprocess.DEVNULL,
-                              stderr=subprocess.DEVNULL)
+        cmd = [ref_bins[exe], *flags, *mode, fq, str(tmp_path / out), str(tmp)]
+        # bounded: in strict-memory mode the reference joins its big-bin threads in an order that never returns when one of them ends on an exception (kmc.h:1661-1668;
+        # seen once under memory pressure, with four test processes running beside it: the big-bin sorter gone, writer / merger / completer waiting for it) — a second
+        # attempt then, and a failure that says what happened instead of a suite that hangs
+        for attempt in (0, 1):
+            try:
+                subprocess.run(cmd, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=300, check=True)
+                break
+            except subprocess.TimeoutExpired:
+                if attempt:
+                    raise
     for ext in (".kmc_pre", ".kmc_suf"):
         assert _md5(str(tmp_path / ("ref" + ext))) == _md5(str(tmp_path / ("orc" + ext)))
         assert _md5(str(tmp_path / ("ref" + ext))) == _md5(str(tmp_path / ("orc3" + ext)))

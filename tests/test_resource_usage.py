@@ -20,7 +20,7 @@ BUDGET = {
     # round 6: the arena of the repeat-rich buckets (arena_sort.hip.h). With nothing listed its launches return at once; the pass kernel is k_onesweep<1>'s tile body in a loop
     "k_bucket_detect": (0, 8), "k_arena_plan": (0, 8), "k_arena_gather": (0, 8), "k_arena_finish": (0, 4), "k_onesweep_dyn<1>": (24, 8),
     # off the default path since round 4 (redo / LSD runs; KMC_HIP_RANK=0): known spills, must not grow
-    "k_compact<1>": (124, 8), "k_compact<2>": (60, 4), "k_bucket_count<1>": (56, 8), "k_bucket_count<2>": (16, 8),
+    "k_compact<1>": (124, 8), "k_compact<2>": (60, 4),
 }
 
 
