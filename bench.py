@@ -1197,7 +1197,7 @@ def main():
             s2 = secondary_leg("2gbp-512bins", k, [])
             sec["bins512_2gbp"] = {kk: s2.get(kk) for kk in ("value", "ms_per_step", "config", "roofline", "tallies", "stage2_frac_of_hbm_peak", "error") if kk in s2}
             sec["stage1_groundwork"] = stage1_leg(k)
-            if k == 27:  # configs[4]'s record widths on a quarter of the reads: the hybrid sort; full size: bench.py --k 55 / --k 127
+            if k == 27:  # configs[4]'s record widths on a quarter of the reads: the hybrid sort (docs/history/DESIGN_rounds_1_to_5.md §4b); full size: bench.py --k 55 / --k 127
                 for kk in (55, 127):
                     sk = secondary_leg("quarter", kk, ["--no-digest"])
                     sec["k%d_quarter" % kk] = {x: sk.get(x) for x in ("value", "ms_per_step", "config", "roofline", "sort_path", "local_sort", "tallies", "self_check", "error") if x in sk}

@@ -492,31 +492,6 @@ template <int SIZE> bool count_applicable(const DevParams &P)
 /* ---- rank groups (default since round 4): the array is ordered by its top bytes only; k_bucket_rank puts every bucket-aligned tile of every bin in order
  * inside LDS and counts it there, straight into the tile's span of the free record array; then the fold and the gather of the two-phase output. A tile has
  * two output slots (one per chunk: a tile that outgrows the capacity is taken by two workgroups). ---- */
-/* $KMC_HIP_CU_SPLIT: everything rank_group enqueues goes to the slot's fin_stream (its own share of the CUs), behind the passes and in front of the slot's next work */
-struct FinScope {
-	Slot &s;
-	hipStream_t main;
-	bool on = false;
-	explicit FinScope(Slot &slot) : s(slot), main(slot.stream) {}
-	int enter()
-	{
-		if (!s.fin_stream)
-			return 0;
-		HIPCHK(hipEventRecord(s.ev_split, main));
-		HIPCHK(hipStreamWaitEvent(s.fin_stream, s.ev_split, 0));
-		s.stream = s.fin_stream;
-		on = true;
-		return 0;
-	}
-	~FinScope()
-	{
-		if (!on)
-			return;
-		(void)hipEventRecord(s.ev_fin, s.fin_stream);
-		s.stream = main;
-		(void)hipStreamWaitEvent(main, s.ev_fin, 0);
-	}
-};
 template <int SIZE>
 int rank_group(Slot &s, const std::vector<BinPlan> &bins, u64 *sorted, u64 *scratch, const DevParams &P, u64 lut_entries, const SortPlan &sp, u64 n_total, u32 *d_flag,
                u32 *d_giant, const u64 *d_recs_indirect = nullptr /* indirect sort: `sorted` is the ordered PAIR array (one word per record), the records are here */,
@@ -524,9 +499,6 @@ int rank_group(Slot &s, const std::vector<BinPlan> &bins, u64 *sorted, u64 *scra
 {
 	if (bins.empty())
 		return 0;
-	FinScope fin(s);
-	if (int rc = fin.enter())
-		return rc;
 	u32 *err = err_ptr(s);
 	const bool use_lut = lut_entries && !P.without_output && !P.kff;
 	const u32 n_sh = !use_lut ? 1u : lut_shards_for(lut_entries);

@@ -156,11 +156,6 @@ struct HbRes {
 
 struct Slot {
 	hipStream_t stream = nullptr;
-	/* $KMC_HIP_CU_SPLIT=B (experiment, round 6): `stream` may use all CUs but the last B, `fin_stream` those B; rank_group runs the finisher of a group on fin_stream
-	 * (ordered behind the group's passes and in front of whatever the slot does next by two events), so that with several slots in flight the VALU-bound finisher of one
-	 * group and the HBM-bound passes of another run side by side on disjoint CUs instead of one after the other */
-	hipStream_t fin_stream = nullptr;
-	hipEvent_t ev_split = nullptr, ev_fin = nullptr;
 	std::mutex mtx; /* serialises enqueueing on this slot (asynchronous device-resident calls may come from several threads) */
 	u64 portion = PORTION_MAX;
 	DBuf in, pack_start;
@@ -283,25 +278,7 @@ int set_all_func_attrs()
 int slot_init(Slot &s, u64 portion)
 {
 	s.portion = portion;
-	static const int cu_split = [] {
-		const char *e = getenv("KMC_HIP_CU_SPLIT");
-		return e ? atoi(e) : 0;
-	}();
-	int n_cu = 0, dev = 0;
-	if (cu_split > 0) {
-		HIPCHK(hipGetDevice(&dev));
-		HIPCHK(hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev));
-	}
-	if (cu_split >= 8 && n_cu >= 16 && cu_split <= n_cu - 8 && n_cu <= 1024) {
-		std::vector<uint32_t> mask_a((size_t)(n_cu + 31) / 32, 0u), mask_b((size_t)(n_cu + 31) / 32, 0u);
-		for (int i = 0; i < n_cu; ++i) /* (bit i of a queue's mask is CU i / n_xcc of XCC i mod n_xcc: both shares lie on every XCD) */
-			(i < n_cu - cu_split ? mask_a : mask_b)[(size_t)i / 32] |= 1u << (i % 32);
-		HIPCHK(hipExtStreamCreateWithCUMask(&s.stream, (uint32_t)mask_a.size(), mask_a.data()));
-		HIPCHK(hipExtStreamCreateWithCUMask(&s.fin_stream, (uint32_t)mask_b.size(), mask_b.data()));
-		HIPCHK(hipEventCreateWithFlags(&s.ev_split, hipEventDisableTiming));
-		HIPCHK(hipEventCreateWithFlags(&s.ev_fin, hipEventDisableTiming));
-	} else
-		HIPCHK(hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking));
+	HIPCHK(hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking));
 	HIPCHK(hipHostMalloc((void **)&s.h_res, sizeof(HostRes), hipHostMallocDefault));
 	memset(s.h_res, 0, sizeof(HostRes));
 	for (auto &e : s.ev)
@@ -336,12 +313,6 @@ void slot_destroy(Slot &s)
 		(void)hipEventDestroy(e);
 	if (s.done_ev)
 		(void)hipEventDestroy(s.done_ev);
-	if (s.ev_split)
-		(void)hipEventDestroy(s.ev_split);
-	if (s.ev_fin)
-		(void)hipEventDestroy(s.ev_fin);
-	if (s.fin_stream)
-		(void)hipStreamDestroy(s.fin_stream);
 	if (s.stream)
 		(void)hipStreamDestroy(s.stream);
 }

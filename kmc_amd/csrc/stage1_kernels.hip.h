@@ -1,5 +1,5 @@
 /*
- * kmc_amd/csrc/stage1_kernels.hip.h — the kernels of KMC's STAGE 1 on gfx950: text of a FASTA/FASTQ part ->
+ * kmc_amd/csrc/stage1_kernels.hip.h — the kernels of KMC's STAGE 1 on gfx950 (docs/history/DESIGN_rounds_1_to_5.md §9): text of a FASTA/FASTQ part ->
  * codes -> minimizer signatures -> super-k-mers -> bin records + the collector's sums. Reachable through kmc_hip_split_part (one part, host
  * text -> host records: the engine of the stage-1 worker plug-in), kmc_hip_split_reads_plan/_emit (codes in HBM -> bins in HBM in the layout
  * kmc_hip_process_bins_device takes) and the test hook kmc_hip_debug_split_reads. The signature -> bin map is an input (stage 0 stays the

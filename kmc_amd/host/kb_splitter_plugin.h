@@ -1,6 +1,6 @@
 /*
  * kmc_amd/host/kb_splitter_plugin.h — the stage-1 splitter worker of kmc_core with the splitting done by an engine
- * (DESIGN.md §9): the drop-in boundary of a GPU stage 1.
+ * (docs/history/DESIGN_rounds_1_to_5.md §9): the drop-in boundary of a GPU stage 1.
  *
  * Drop-in for the reference's CWSplitter (splitter.h:100-113, splitter.cpp:814-867): the same class name, constructor, operator()(),
  * GetTotal() and destructor, so CKMC<SIZE>::ProcessStage1_impl (kmc.h:1274-1362) builds against it unchanged. Compiled in with

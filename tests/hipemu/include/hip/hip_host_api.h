@@ -89,16 +89,6 @@ static inline hipError_t hipStreamCreateWithFlags(hipStream_t *s, unsigned)
 	*s = reinterpret_cast<hipStream_t>(new char);
 	return hipSuccess;
 }
-/* $KMC_HIP_CU_SPLIT (kmc_hip.hip slot_init, rank_group): streams with a CU mask are streams; the emulated runtime executes every launch at once, in enqueue order, so an
- * event wait has nothing to wait for */
-enum hipDeviceAttribute_t { hipDeviceAttributeMultiprocessorCount = 16 };
-static inline hipError_t hipDeviceGetAttribute(int *v, hipDeviceAttribute_t, int)
-{
-	*v = 256;
-	return hipSuccess;
-}
-static inline hipError_t hipExtStreamCreateWithCUMask(hipStream_t *s, uint32_t, const uint32_t *) { return hipStreamCreateWithFlags(s, 0); }
-static inline hipError_t hipStreamWaitEvent(hipStream_t, hipEvent_t, unsigned) { return hipSuccess; }
 static inline hipError_t hipStreamDestroy(hipStream_t s)
 {
 	delete reinterpret_cast<char *>(s);

@@ -1,4 +1,4 @@
-"""First timing of the stage-1 groundwork on one MI355X: reads already in HBM as codes -> bins in HBM.
+"""First timing of the stage-1 groundwork (docs/history/DESIGN_rounds_1_to_5.md §9) on one MI355X: reads already in HBM as codes -> bins in HBM.
 Wall-clock of kmc_hip_split_reads_plan and _emit (both synchronise), best of --reps; run it under `rocprofv3 --kernel-trace --stats` for the
 per-kernel durations. Not part of bench.py: stage 1 is not in the drop-in. No torch: numpy + the C-ABI only."""
 import argparse
