@@ -37,7 +37,7 @@ Keys of the N=1 record (each measured after the timed region, none inside it):
   moved_bytes_per_kmer: {"pmc": from the committed rocprofv3 --pmc run of this workload (profiles/r06/pmc_hbm_traffic.json: every kernel of one step), "design": what the path
                         is designed to move}; moved_frac_of_hbm_peak likewise. Neither is a counter of THIS run (counters cannot be read from inside it); roofline.traffic idem.
   self_check.oracle_bins: 16 bins of the timed run, stratified by size, byte for byte against the oracle (one host thread per bin)
-  logical_devices     : the resident bins LPT-sharded over 8 LOGICAL devices of the one GPU (a context naming it 8 times), one enqueueing host thread each: the control flow of
+  logical_devices     : (--logical 8; off by default) the resident bins LPT-sharded over 8 LOGICAL devices of the one GPU (a context naming it 8 times), one enqueueing host thread each: the control flow of
                         --gpus 8 inside one process; value ~ `value` means the scheduling around the kernels costs nothing; enqueue_ms_per_bin = host time per bin. Not a scaling number.
   e2e_large           : ONE FASTQ of --e2e-gbp Gbp (default 8): reference vs drop-in "2nd stage" in RAM-only mode, and the reference's own stage-1 bins (dumped by the drop-in's
                         worker) device-resident, tallies against the reference's statistics
@@ -853,7 +853,7 @@ def main():
     ap.add_argument("--host-probe", action="store_true", help="diagnostics: the host-boundary leg for every sort selection and call style, errors reported per leg")
     ap.add_argument("--no-host-single", action="store_true", help="skip the one-bin-per-call comparison of the host-boundary leg")
     ap.add_argument("--no-secondary", action="store_true")
-    ap.add_argument("--logical", type=int, default=8, help="after the timed region: the same bins over this many LOGICAL devices of the one GPU, one host thread each (0/1 = skip)")
+    ap.add_argument("--logical", type=int, default=0, help="after the timed region: the same bins over this many LOGICAL devices of the one GPU, one host thread each (0/1 = skip; 8 = the control flow of --gpus 8 inside one process)")
     ap.add_argument("--no-full-wide", action="store_true", help="skip the full-size k = 55 / k = 127 legs (configs[4] on one GPU, ~80 s each)")
     ap.add_argument("--no-repeat-baselines", action="store_true", help="skip cpu_baseline_skew / cpu_baseline_spectrum (the reference on the skew legs' reads, ~40 s each)")
     ap.add_argument("--no-two-streams", action="store_true", help="skip the value_two_streams leg (profiling runs: keeps overlapped launches out of the kernel statistics)")

@@ -10,8 +10,9 @@
  *                    initialise; HIP_VISIBLE_DEVICES narrows the set from outside); worker i uses device i % n_devices
  *   KMC_HIP_EAGER_INIT  "0": load the library at the first stage-2 worker instead of at program start
  *   KMC_HIP_VERBOSE  "1": print where the worker spent its time when the last engine is destroyed
- *   KMC_HIP_PINNED_POOL_MB  pinned slab for the bin images (host_pool.h; default 4096, 0 = none): ordinary memory on huge pages, registered with the runtime
- *   KMC_HIP_TUNE_MALLOC  "0": do not re-execute the program with the allocator tunables below (tune_allocator())
+ *   KMC_HIP_PINNED_POOL_MB  pinned slab for the bin images (host_pool.h; default 1024, 0 = none)
+ *   KMC_HIP_POOL_REGISTER  "1" (opt-in, round 6): the slab is ordinary memory on huge pages, registered with the runtime, instead of hipHostMalloc'ed
+ *   KMC_HIP_TUNE_MALLOC  "1" (opt-in, round 6): re-execute the program once with the allocator tunables below (tune_allocator())
  * There is deliberately NO CPU fallback here: if the library or a GPU is missing the engine reports the error and
  * the worker raises it through CCriticalErrorHandler.
  */
@@ -191,9 +192,12 @@ void load_api_impl()
 		std::string ignore;
 		const size_t want = KmcHostPool::wanted_bytes();
 		bool have = false;
-		/* ordinary anonymous memory on huge pages, pinned by registration: registering is an order of magnitude cheaper than hipHostMalloc (profiles/r02/ubench_host.json:
-		 * 126 against 7.7 GB/s) and — measured in round 6 — a hipHostMalloc slab of 8 GB added 2 s to the process's exit. Never unmapped: the kernel takes it back at exit */
-		if (want && sym(a.so, "kmc_hip_host_register", a.host_register, ignore)) {
+		/* opt-in: ordinary anonymous memory on huge pages, pinned by registration — registering is an order of magnitude cheaper than hipHostMalloc (profiles/r02/
+		 * ubench_host.json: 126 against 7.7 GB/s) and, measured in round 6, a hipHostMalloc slab of 8 GB added 2 s to the process's exit. Never unmapped: the kernel takes
+		 * it back at exit. NOT the default: the two sessions that ran the drop-in with this and the allocator tunables as defaults (r06o, r06s) each lost their GPU box
+		 * (host memory, by the look of it) before a result came back; which of the two is at fault was not established */
+		const char *reg = getenv("KMC_HIP_POOL_REGISTER");
+		if (want && reg && reg[0] == '1' && sym(a.so, "kmc_hip_host_register", a.host_register, ignore)) {
 			void *p = mmap(nullptr, want, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS | MAP_NORESERVE, -1, 0);
 			if (p != MAP_FAILED) {
 				(void)madvise(p, want, MADV_HUGEPAGE);
@@ -310,11 +314,13 @@ struct HipEngine : KmcBinEngine {
  *   glibc.malloc.hugetlb=1                                  : the heap on transparent huge pages where the system offers them by madvise (stage 1's storer touches
  *                                                             512x fewer pages: "1st stage" 7.9 -> 6.3 s, process wall 9.7 -> 8.5 s)
  * Tunables are read when the process starts, so the program re-executes itself ONCE, before main() and before any thread exists, with $GLIBC_TUNABLES completed
- * (settings the user gave are kept). KMC_HIP_TUNE_MALLOC=0 switches this off; a failed exec just carries on. */
+ * (settings the user gave are kept); a failed exec just carries on. OPT-IN (KMC_HIP_TUNE_MALLOC=1): each tunable was measured on its own at 8 Gbp (session n), but the two
+ * sessions that ran them together as the default, at 8 and 30 Gbp, lost their GPU boxes — most likely host memory: with -m512 KMC sizes its pools for 512 GB, a pool part that
+ * is touched pins a whole 2 MB page once the heap is on huge pages, and nothing is ever returned to the kernel. Until that is understood the default is the round-5 behaviour. */
 __attribute__((constructor(101))) static void tune_allocator(int /*argc*/, char **argv, char ** /*envp*/)
 {
 	const char *sw = getenv("KMC_HIP_TUNE_MALLOC");
-	if ((sw && sw[0] == '0') || getenv("KMC_HIP_TUNED") || !argv || !argv[0])
+	if (!sw || sw[0] != '1' || getenv("KMC_HIP_TUNED") || !argv || !argv[0])
 		return;
 	const char *cur = getenv("GLIBC_TUNABLES");
 	std::string t = cur ? cur : "";

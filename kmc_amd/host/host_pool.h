@@ -16,7 +16,7 @@
 /* Pinned host buffers for bin images, shared by the reader plug-in (reads a bin file straight into one) and the worker plug-in (hands it to the engine, gives
  * it back): the image then reaches the GPU by DMA from where the reader put it — no page of the arena is touched for it, and the library has nothing to stage
  * (1.7 of the 2.3 GB a 2 Gbp run moves; summed over the workers the staging copies were 1 s of CPU). ONE slab of pinned memory, allocated by the engine's loader
- * when the library comes up — on its background thread, during KMC's stage 1 ($KMC_HIP_PINNED_POOL_MB, default 4096 since round 6 — ordinary memory on huge pages, registered —; allocating pinned buffers one by one while
+ * when the library comes up — on its background thread, during KMC's stage 1 ($KMC_HIP_PINNED_POOL_MB, default 1024; allocating pinned buffers one by one while
  * stage 2 runs serialised the readers behind the runtime: reader wall 0.17 -> 0.42 s) — and cut first-fit. No slab (the oracle engines of the tests), or no room:
  * get() returns NULL and the image goes to the arena as in the reference. */
 struct KmcHostPool {
@@ -34,7 +34,7 @@ struct KmcHostPool {
 	static size_t wanted_bytes()
 	{
 		const char *e = getenv("KMC_HIP_PINNED_POOL_MB");
-		return (size_t)(e ? strtoull(e, nullptr, 10) : 4096) << 20; /* 16 workers x up to 4 waiting bins + the readers' look-ahead: ~1 GB of 13 MB bins (8 Gbp), 1.2+ GB of 50 MB bins (30 Gbp) */
+		return (size_t)(e ? strtoull(e, nullptr, 10) : 1024) << 20; /* (16 workers x up to 4 waiting bins + the readers' look-ahead want ~1 GB of 13 MB bins at 8 Gbp, 1.2+ GB of 50 MB bins at 30 Gbp: with 1 GB some images go through the arena and a staging copy; a larger hipHostMalloc slab costs 0.25 s per GB when the process exits) */
 	}
 	void adopt(void *p, size_t bytes, void (*release)(void *))
 	{

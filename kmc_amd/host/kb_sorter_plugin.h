@@ -287,17 +287,8 @@ public:
 				list<pair<uint64, uint64>> data_packs;
 				if (!bp.without_output && !(max_x && t.n_plus_x_recs == 0))
 					data_packs.emplace_back(0, out_bytes[i]);
-				{
-					const long long t2 = KmcOrderedEmit::now_ns();
-					std::unique_lock<std::mutex> lck(order->emit_mtx);
-					order->cv.wait(lck, [&] { return order->next_emit == t.seq; });
-					const long long t3 = KmcOrderedEmit::now_ns();
-					kq->push(t.bin_id, t.out_buffer, data_packs, t.raw_lut, lut_recs * sizeof(uint64), stats[i][0], stats[i][1], stats[i][2], stats[i][3]);
-					++order->next_emit;
-					order->ns_turn += t3 - t2;
-					order->ns_push += KmcOrderedEmit::now_ns() - t3;
-				}
-				order->cv.notify_all();
+				KmcOrderedEmit::Ready rdy{t.bin_id, t.out_buffer, std::move(data_packs), t.raw_lut, lut_recs * sizeof(uint64), stats[i][0], stats[i][1], stats[i][2], stats[i][3]};
+				order->deposit(kq, t.seq, std::move(rdy)); /* pushed in sequence, by this thread or by the one that deposits the bin in front of it (kmc_order.h) */
 				++order->n_bins;
 				if (t.n_sorting_threads)
 					sorters_manager->ReturnThreads(t.n_sorting_threads, t.bin_id);

@@ -8,12 +8,16 @@
  * under a mutex; bins reach the bin queue in CBinDesc's sorted order, queues.h:499-571, from the reference's reader and
  * from the reader plug-in alike) and is pushed to kq strictly in that sequence, however many workers / GPUs / stream
  * slots finish out of order: the DB equals the reference's -sr1 bytes for ANY -sr.
+ * Since round 6 a worker does not WAIT for its turn: it deposits the finished bin in a reorder buffer and goes for the next one; whoever deposits the bin the
+ * completer is waiting for pushes it and every consecutive bin behind it (16 workers spent a third of their wall time waiting for their turn on 8 Gbp:
+ * 3.3 of 9.6 s summed, profiles/r06/e2e_sweep_8gbp_session_n.jsonl).
  */
 #ifndef KMC_AMD_ORDER_H
 #define KMC_AMD_ORDER_H
 
 #include <atomic>
 #include <chrono>
+#include <list>
 #include <cstdio>
 #include <cstdlib>
 #include <map>
@@ -189,8 +193,30 @@ struct KmcArena {
 
 struct KmcOrderedEmit {
 	std::mutex take_mtx, emit_mtx;
-	CThrowingOnCancelConditionVariable cv; /* cancelled by CCriticalErrorHandler like every other wait in kmc_core */
 	uint64 next_take = 0, next_emit = 0;
+	/* a finished bin, as kq->push wants it (queues.h:826) */
+	struct Ready {
+		int32 bin_id;
+		uchar *out;
+		std::list<std::pair<uint64, uint64>> packs;
+		uchar *lut;
+		uint64 lut_bytes, n_unique, n_cutoff_min, n_cutoff_max, n_total;
+	};
+	std::map<uint64, Ready> ready; /* by sequence number; under emit_mtx */
+	/* hand a finished bin over; pushes it, and whatever is consecutive behind it, if it is the one the completer waits for */
+	template <typename KQ> void deposit(KQ *kq, uint64 seq, Ready &&r)
+	{
+		const long long t0 = now_ns();
+		std::lock_guard<std::mutex> lck(emit_mtx);
+		ready.emplace(seq, std::move(r));
+		while (!ready.empty() && ready.begin()->first == next_emit) {
+			Ready &a = ready.begin()->second;
+			kq->push(a.bin_id, a.out, a.packs, a.lut, a.lut_bytes, a.n_unique, a.n_cutoff_min, a.n_cutoff_max, a.n_total);
+			ready.erase(ready.begin());
+			++next_emit;
+		}
+		ns_push += now_ns() - t0;
+	}
 	/* KMC_HIP_VERBOSE=1: nanoseconds summed over threads */
 	std::atomic<long long> ns_reader_init{0}, ns_reader_read{0}, ns_reader_wall{0}, ns_getnext{0}, ns_engine{0}, ns_turn{0}, ns_push{0},
 	    ns_worker_wall{0};
