@@ -358,6 +358,10 @@ int kmc_hip_split_part(kmc_hip_ctx *ctx, int dev, int slot, const kmc_hip_split_
 	if (p->kmer_len < 1 || p->kmer_len > (uint32_t)S1_MAX_K || p->signature_len < 5 || p->signature_len > 11 || p->signature_len > p->kmer_len || p->n_bins < 1 ||
 	    p->n_bins > (uint32_t)S1_MAX_BINS || p->max_x > 3 || p->file_type > 1 || p->part_kind > 1 || (p->max_x && p->kmer_len < 4))
 		return fail(KMC_HIP_EINVAL, "kmc_hip_split_part: unsupported parameters");
+	/* a configuration limit, not a property of the text: the pieces of an over-long line are cut at workgroup windows (stage1_chain.h) */
+	if (p->line_cap < (uint64_t)p->kmer_len + S1_WG_TILE + 2)
+		return fail(KMC_HIP_EINVAL, "kmc_hip_split_part: line_cap (mem_part_pmm_reads) is too small for the device splitter: it needs kmer_len + " + std::to_string(S1_WG_TILE + 2) +
+		                                " symbols at least");
 	Dev &d = *ctx->devs[dev];
 	if (!d.d_sig_map || d.sig_map_entries != (1u << (2 * p->signature_len)) + 1)
 		return fail(KMC_HIP_EINVAL, "kmc_hip_split_part: kmc_hip_split_set_map was not called for this signature length");

@@ -560,7 +560,10 @@ int rank_group(Slot &s, const std::vector<BinPlan> &bins, u64 *sorted, u64 *scra
 	}
 	gbn.item_prefix[bins.size()] = (u32)items;
 	gr.win_prefix[bins.size()] = (u32)wins;
-	gr.giant = d_giant;
+	/* a giant-list entry keeps the tile's number in GT_CUT_SHIFT bits (bucket_sort.hip.h): a group with more tiles (a single bin beyond ~2.9 G records, as a group of
+	 * one) gets no list — a tile with a bucket beyond LDS then raises its bin's redo flag, as tiles beyond GT_MAX_RECORDS do */
+	const bool giant_list = wins < (1ull << GT_CUT_SHIFT);
+	gr.giant = giant_list ? d_giant : nullptr;
 	gr.rec_base = d_recs_indirect;
 	gg.tile_prefix[bins.size()] = (u32)(2 * wins);
 	/* The arena (one-word records): every bucket beyond BR_MID records is disjoint from every other, a giant one owns a tile — n_total / BR_MID + wins entries can never be
@@ -810,7 +813,7 @@ int rank_group(Slot &s, const std::vector<BinPlan> &bins, u64 *sorted, u64 *scra
 	/* every tile ranked and counted inside LDS (with the arena: its buckets beyond BR_MID records are in order by now and keep their places) */
 	k_bucket_rank<SIZE, true><<<dim3((u32)wins, 2), dim3(BrCfg<SIZE>::THREADS), br_lds_bytes<SIZE>() + lds_pad, s.stream>>>(gr, P, sp.key_bits, sp.hbits(), n_sh, lut_entries, lut_mask, d_flag);
 	/* the tiles with a bucket beyond the LDS capacity (k-mers repeated thousands of times), one workgroup each; nothing listed: a launch that returns */
-	if (!arena_ran)
+	if (!arena_ran && giant_list)
 		k_giant_tiles<SIZE><<<dim3((u32)std::min<u64>(wins, 256 * (1024 / GT_THREADS))), dim3(GT_THREADS), 0, s.stream>>>(gr, P, (u32)S, sp.key_bits, sp.hbits(), n_sh, lut_entries, lut_mask, err);
 	if (s.timed)
 		HIPCHK(hipEventRecord(e1, s.stream));

@@ -108,6 +108,10 @@ struct KmcArena {
 	 * VMA), and the chunk that holds `inside` must have exactly the size CMemoryBins asked for, page-rounded. Anything else: not found, feature off. */
 	static bool find_block(const void *inside, uint64_t bytes, uintptr_t &blo, uintptr_t &bhi)
 	{
+#ifndef __GLIBC__
+		(void)inside, (void)bytes, (void)blo, (void)bhi;
+		return false; /* the chunk-header layout below is glibc's */
+#endif
 		FILE *f = fopen("/proc/self/maps", "r");
 		if (!f)
 			return false;
@@ -119,8 +123,12 @@ struct KmcArena {
 		const uintptr_t p = (uintptr_t)inside;
 		bool past = false;
 		while (fgets(line, sizeof line, f) && !past) {
-			unsigned long long a = 0, b = 0;
-			if (sscanf(line, "%llx-%llx %7s", &a, &b, perms) != 3)
+			unsigned long long a = 0, b = 0, off = 0, ino = 0;
+			char devno[16], path[8];
+			path[0] = 0;
+			if (sscanf(line, "%llx-%llx %7s %llx %15s %llu %7s", &a, &b, perms, &off, devno, &ino, path) < 6)
+				continue;
+			if (ino != 0 || path[0] == '/') /* a file-backed mapping is never the allocator's (and a read past its end would fault: ADVICE r5) */
 				continue;
 			const bool rw = perms[0] == 'r' && perms[1] == 'w' && perms[3] == 'p';
 			if (!rw || (!region.empty() && region.back().second != (uintptr_t)a)) {

@@ -1,6 +1,6 @@
 """CPU suite: the register / scratch budget of the hot kernels of the shipped build (hipcc cross-compiles gfx950 without a GPU). A spilled register in a
 kernel that runs at the HBM roofline is HBM traffic nobody asked for (round 3: k_onesweep<1> 4 VGPRs / 12 B per lane, k_compact<1> 30 / 124 B): the kernels
-of the default path stay at ZERO bytes of scratch, the others may not grow. profiles/r04/resource_usage.txt is the table of the committed tree."""
+of the default path stay at ZERO bytes of scratch, the others may not grow. profiles/r06/resource_usage.txt is the table of the committed tree."""
 import os
 import shutil
 import sys
