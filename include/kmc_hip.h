@@ -247,6 +247,12 @@ int kmc_hip_path_counters(kmc_hip_ctx *ctx, int dev, uint64_t counters[8]);
  * [5] staging copy out (callers whose output buffers are ordinary memory); [6] calls, [7] redo rounds (counts). What the drop-in's worker report prints under
  * $KMC_HIP_VERBOSE; no reference counterpart (the CPU worker has no host link). */
 int kmc_hip_host_boundary_times(double seconds[8]);
+/* Optional, once per (device, slot), before the slot's first bin: ONE device allocation of `bytes` from which the host-boundary entries (kmc_hip_process_bin_submit/_wait,
+ * kmc_hip_process_bins_submit/_wait) carve the slot's grow-only buffers; a buffer that does not fit what is left is allocated on its own, as without a slab. Lets a caller
+ * whose process is busy mapping and unmapping memory while bins arrive (the reference's RAM-only stage 2: mem_disk_file.cpp:84-100) pay for device allocations ahead of time —
+ * the drop-in's loader reserves while KMC's stage 1 runs. What the CPU worker gets from CMemoryBins, reserved by the reader before the worker sees the bin
+ * (queues.h:1288-1340). Refused (KMC_HIP_ECAPACITY, nothing allocated) when it would leave the device with less than half of its memory free. Freed with the context. */
+int kmc_hip_reserve_slot(kmc_hip_ctx *ctx, int dev, int slot, uint64_t bytes);
 /* Device memory helpers so non-HIP callers (ctypes tests, the C++ worker) need not link HIP themselves. */
 int kmc_hip_malloc(kmc_hip_ctx *ctx, int dev, uint64_t bytes, void **d_ptr);
 int kmc_hip_free(kmc_hip_ctx *ctx, int dev, void *d_ptr);

@@ -83,7 +83,7 @@ SYMBOLS = [
     "kmc_hip_sort_records", "kmc_hip_sort_records_into", "kmc_hip_sort_records_device",
     "kmc_hip_process_bin", "kmc_hip_process_bin_multi", "kmc_hip_process_bins_submit", "kmc_hip_process_bins_wait", "kmc_hip_process_bin_submit", "kmc_hip_process_bin_wait", "kmc_hip_process_bin_device",
     "kmc_hip_process_bins_device", "kmc_hip_order_database_device",
-    "kmc_hip_allreduce_stats", "kmc_hip_last_timings", "kmc_hip_scatter_totals", "kmc_hip_local_sort_totals", "kmc_hip_set_hybrid", "kmc_hip_path_counters", "kmc_hip_host_boundary_times",
+    "kmc_hip_allreduce_stats", "kmc_hip_last_timings", "kmc_hip_scatter_totals", "kmc_hip_local_sort_totals", "kmc_hip_set_hybrid", "kmc_hip_path_counters", "kmc_hip_host_boundary_times", "kmc_hip_reserve_slot",
     "kmc_hip_malloc", "kmc_hip_free", "kmc_hip_memcpy_h2d", "kmc_hip_memcpy_d2h",
     "kmc_hip_host_register", "kmc_hip_host_unregister", "kmc_hip_host_alloc", "kmc_hip_host_free", "kmc_hip_synchronize",
     "kmc_hip_debug_expand", "kmc_hip_debug_compact", "kmc_hip_debug_split_reads",

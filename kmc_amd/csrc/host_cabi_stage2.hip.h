@@ -529,6 +529,29 @@ static void hb_report()
 	        g_hb_ns[5].load() * 1e-9);
 }
 
+int kmc_hip_reserve_slot(kmc_hip_ctx *ctx, int dev, int slot, uint64_t bytes)
+{
+	if (int rc = set_dev(ctx, dev))
+		return rc;
+	if (slot < 0 || slot >= N_SLOTS)
+		return fail(KMC_HIP_EINVAL, "slot out of range (see kmc_hip_num_slots)");
+	Slot &s = ctx->devs[dev]->slot[slot];
+	std::lock_guard<std::mutex> lck(s.mtx);
+	if (s.slab.p)
+		return fail(KMC_HIP_EINVAL, "kmc_hip_reserve_slot: the slot has a slab already (buffers may point into it)");
+	if (!bytes)
+		return 0;
+	const size_t want = ((size_t)bytes + 255) & ~(size_t)255;
+	size_t free_b = 0, total_b = 0;
+	HIPCHK(hipMemGetInfo(&free_b, &total_b));
+	if (free_b < want || free_b - want < total_b / 2) /* reservations never take the device below half of its memory (several logical devices or processes on one GPU) */
+		return fail(KMC_HIP_ECAPACITY, "kmc_hip_reserve_slot: refused — the device would be left with less than half of its memory free");
+	HIPCHK(hipMalloc(&s.slab.p, want));
+	s.slab.cap = want;
+	s.slab.used = 0;
+	return 0;
+}
+
 int kmc_hip_host_boundary_times(double seconds[8])
 {
 	if (!seconds)
@@ -602,6 +625,7 @@ int kmc_hip_process_bin_submit(kmc_hip_ctx *ctx, int dev, int slot, const kmc_hi
 		return rc;
 	Slot &s = ctx->devs[dev]->slot[slot];
 	std::lock_guard<std::mutex> lck(s.mtx);
+	SlabScope slab_scope(s.slab);
 	if (s.pending || s.hb_pending)
 		return fail(KMC_HIP_EINVAL, "slot already has a bin in flight");
 	if (size && !superkmers)
@@ -691,6 +715,7 @@ int kmc_hip_process_bin_wait(kmc_hip_ctx *ctx, int dev, int slot, uint64_t *out_
 		return fail(KMC_HIP_EINVAL, "slot out of range (see kmc_hip_num_slots)");
 	Slot &s = ctx->devs[dev]->slot[slot];
 	std::lock_guard<std::mutex> lck(s.mtx);
+	SlabScope slab_scope(s.slab);
 	if (!s.pending)
 		return fail(KMC_HIP_EINVAL, "no bin in flight on this slot");
 	s.pending = false;
@@ -787,6 +812,7 @@ int kmc_hip_process_bins_submit(kmc_hip_ctx *ctx, int dev, int slot, const kmc_h
 		return fail(KMC_HIP_EINVAL, "kmc_hip_process_bins_submit: 1..16 bins per call");
 	Slot &s = ctx->devs[dev]->slot[slot];
 	std::lock_guard<std::mutex> lck(s.mtx);
+	SlabScope slab_scope(s.slab);
 	if (s.pending || s.hb_pending)
 		return fail(KMC_HIP_EINVAL, "slot already has a bin in flight");
 	const u64 lut_entries = P.kff ? 0 : kmc_hip_lut_entries(params);
@@ -902,6 +928,7 @@ int kmc_hip_process_bins_wait(kmc_hip_ctx *ctx, int dev, int slot, uint64_t *out
 		return fail(KMC_HIP_EINVAL, "slot out of range (see kmc_hip_num_slots)");
 	Slot &s = ctx->devs[dev]->slot[slot];
 	std::lock_guard<std::mutex> lck(s.mtx);
+	SlabScope slab_scope(s.slab);
 	if (!s.hb_pending)
 		return fail(KMC_HIP_EINVAL, "no group of bins in flight on this slot");
 	s.hb_pending = false;

@@ -55,18 +55,43 @@ int fail_hip(const char *what, hipError_t e)
 struct DBuf {
 	void *p = nullptr;
 	size_t cap = 0;
+	bool carved = false; /* p lies inside a slot's slab (kmc_hip_reserve_slot): never freed on its own */
+};
+
+/* A slot's slab: ONE device allocation made ahead of time (kmc_hip_reserve_slot: the drop-in's loader calls it while KMC's stage 1 runs) from which the slot's grow-only
+ * buffers are carved. Why: the drop-in's workers allocate ~10 buffers each when stage 2 starts, through a runtime that takes the process's mmap lock — and the reference's
+ * reader holds that lock while it unmaps every bin part it has copied (mem_disk_file.cpp:84-100): 16 workers spent 6.6 of 11.9 engine-seconds in those allocations on an
+ * 8 Gbp input (profiles/r06/e2e_sweep_8gbp_session_n.jsonl). A buffer that does not fit what is left of the slab is allocated on its own, as before. */
+struct Slab {
+	void *p = nullptr;
+	size_t cap = 0, used = 0;
+};
+thread_local Slab *t_slab = nullptr; /* the slab of the slot whose mutex this thread holds (SlabScope), if it has one */
+struct SlabScope {
+	Slab *prev;
+	explicit SlabScope(Slab &sl) : prev(t_slab) { t_slab = sl.p ? &sl : nullptr; }
+	~SlabScope() { t_slab = prev; }
 };
 
 int ensure(DBuf &b, size_t bytes)
 {
 	if (bytes <= b.cap)
 		return 0;
-	if (b.p) {
-		HIPCHK(hipFree(b.p));
-		b.p = nullptr;
-		b.cap = 0;
+	const size_t want = (bytes + 255) & ~(size_t)255;
+	if (t_slab && t_slab->used + want <= t_slab->cap) { /* (what the buffer held before stays where it was: a little of the slab lost when a buffer grows) */
+		if (b.p && !b.carved)
+			HIPCHK(hipFree(b.p));
+		b.p = (char *)t_slab->p + t_slab->used;
+		b.cap = want;
+		b.carved = true;
+		t_slab->used += want;
+		return 0;
 	}
-	size_t want = (bytes + 255) & ~(size_t)255;
+	if (b.p && !b.carved)
+		HIPCHK(hipFree(b.p));
+	b.p = nullptr;
+	b.cap = 0;
+	b.carved = false;
 	HIPCHK(hipMalloc(&b.p, want));
 	b.cap = want;
 	return 0;
@@ -156,6 +181,7 @@ struct HbRes {
 
 struct Slot {
 	hipStream_t stream = nullptr;
+	Slab slab; /* kmc_hip_reserve_slot */
 	std::mutex mtx; /* serialises enqueueing on this slot (asynchronous device-resident calls may come from several threads) */
 	u64 portion = PORTION_MAX;
 	DBuf in, pack_start;
@@ -296,8 +322,10 @@ int slot_init(Slot &s, u64 portion)
 void slot_destroy(Slot &s)
 {
 	for (DBuf *b : {&s.in, &s.pack_start, &s.recA, &s.recB, &s.recC, &s.pairA, &s.pairB, &s.zero, &s.dbase, &s.out, &s.lut, &s.sticky, &s.bounds, &s.arena_work, &s.redo_log, &s.hb_res})
-		if (b->p)
+		if (b->p && !b->carved)
 			(void)hipFree(b->p);
+	if (s.slab.p)
+		(void)hipFree(s.slab.p);
 	if (s.h_res)
 		(void)hipHostFree(s.h_res);
 	if (s.h_hb_res)
