@@ -780,6 +780,9 @@ def e2e_large_leg(ctx, k: int, gbp: float, budget_s: float = 1500.0):
         tl = [ln for ln in verbose if ln.startswith("[kmc_hip timeline]")]
         if tl:
             out["timeline"] = tl[0][:900]
+        hb = [ln for ln in verbose if ln.startswith("[kmc_hip host boundary]")]
+        if hb:  # kmc_hip_host_boundary_times: where the workers' engine seconds went (device buffers, staging copies, enqueue, wait for the kernels, D2H)
+            out["host_boundary_times"] = hb[0][24:400]
         # the same bins, device resident: what is left when reader, host link and completer are taken away
         if time.time() - t_leg < budget_s * 0.6:
             dump = os.path.join(td, "dump")

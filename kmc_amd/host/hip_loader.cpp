@@ -13,7 +13,7 @@
  *   KMC_HIP_PINNED_POOL_MB  pinned slab for the bin images (host_pool.h; default 1024, 0 = none)
  *   KMC_HIP_SLOT_SLAB_MB  device memory reserved per stream slot while stage 1 runs (default 3072, 0 = none): kmc_hip_reserve_slot
  *   KMC_HIP_POOL_REGISTER  "1" (opt-in, round 6): the slab is ordinary memory on huge pages, registered with the runtime, instead of hipHostMalloc'ed
- *   KMC_HIP_TUNE_MALLOC  "1" (opt-in, round 6): re-execute the program once with the allocator tunables below (tune_allocator())
+ *   KMC_HIP_TUNE_MALLOC  "1" (opt-in, round 6): re-execute the program once with the allocator tunables below (tune_allocator()); "2": the same without the huge-page heap
  * There is deliberately NO CPU fallback here: if the library or a GPU is missing the engine reports the error and
  * the worker raises it through CCriticalErrorHandler.
  */
@@ -341,8 +341,9 @@ struct HipEngine : KmcBinEngine {
 __attribute__((constructor(101))) static void tune_allocator(int /*argc*/, char **argv, char ** /*envp*/)
 {
 	const char *sw = getenv("KMC_HIP_TUNE_MALLOC");
-	if (!sw || sw[0] != '1' || getenv("KMC_HIP_TUNED") || !argv || !argv[0])
+	if (!sw || (sw[0] != '1' && sw[0] != '2') || getenv("KMC_HIP_TUNED") || !argv || !argv[0])
 		return;
+	const bool huge_pages = sw[0] == '1'; /* 2: without the huge-page heap — the subset that was measured on its own at 8 Gbp ("2nd stage" 1.26 -> 0.77 s) */
 	const char *cur = getenv("GLIBC_TUNABLES");
 	std::string t = cur ? cur : "";
 	auto add = [&t](const char *name, const char *val) {
@@ -354,7 +355,8 @@ __attribute__((constructor(101))) static void tune_allocator(int /*argc*/, char 
 		t += "=";
 		t += val;
 	};
-	add("glibc.malloc.hugetlb", "1");
+	if (huge_pages)
+		add("glibc.malloc.hugetlb", "1");
 	add("glibc.malloc.mmap_max", "0");
 	add("glibc.malloc.trim_threshold", "1099511627776");
 	add("glibc.malloc.top_pad", "1073741824");
