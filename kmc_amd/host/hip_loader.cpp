@@ -10,8 +10,8 @@
  *                    initialise; HIP_VISIBLE_DEVICES narrows the set from outside); worker i uses device i % n_devices
  *   KMC_HIP_EAGER_INIT  "0": load the library at the first stage-2 worker instead of at program start
  *   KMC_HIP_VERBOSE  "1": print where the worker spent its time when the last engine is destroyed
- *   KMC_HIP_PINNED_POOL_MB  pinned slab for the bin images (host_pool.h; default 1024, 0 = none)
- *   KMC_HIP_SLOT_SLAB_MB  device memory reserved per stream slot while stage 1 runs (default 3072, 0 = none): kmc_hip_reserve_slot
+ *   KMC_HIP_PINNED_POOL_MB  pinned slab for the bin images (host_pool.h; default 2048, 0 = none); KMC_HIP_POOL_WAIT_MS: how long a reader waits for a buffer of it (default 2000)
+ *   KMC_HIP_SLOT_SLAB_MB  device memory reserved per stream slot while stage 1 runs (default 4096, 0 = none): kmc_hip_reserve_slot
  *   KMC_HIP_POOL_REGISTER  "1" (opt-in, round 6): the slab is ordinary memory on huge pages, registered with the runtime, instead of hipHostMalloc'ed
  *   KMC_HIP_TUNE_MALLOC  "1" (opt-in, round 6): re-execute the program once with the allocator tunables below (tune_allocator()); "2": the same without the huge-page heap
  * There is deliberately NO CPU fallback here: if the library or a GPU is missing the engine reports the error and
@@ -226,14 +226,14 @@ void load_api_impl()
 		a.n_slots = 1;
 	{ /* device memory of the stream slots, ahead of time (include/kmc_hip.h kmc_hip_reserve_slot): one allocation per slot now — on this background thread, during stage 1 —
 	   * instead of ~10 per worker at the moment stage 2 starts, when the reference's reader is unmapping bin parts and every allocation of the runtime waits for the
-	   * process's mmap lock. $KMC_HIP_SLOT_SLAB_MB per slot (default 3072: a 48-84 M-k-mer bin of a 30 Gbp run wants 2.8-3.2 GB; what does not fit is allocated on
-	   * demand, as before; 0 = off) */
+	   * process's mmap lock. $KMC_HIP_SLOT_SLAB_MB per slot (default 4096: a 48-84 M-k-mer bin of a 30 Gbp run wants 2.8-3.2 GB, and ONE buffer
+	   * that does not fit and is allocated on demand costs its worker ~1 s at that moment — session w, 3 GB slabs: 17.9 s summed; 0 = off) */
 		const char *e = getenv("KMC_HIP_SLOT_SLAB_MB");
 		int (*backend_kind)(void) = nullptr;
 		std::string ignore;
 		/* a test build of the library (tests/hipemu: "device" memory is host memory, filled on allocation) reserves nothing unless told to */
 		const bool test_build = sym(a.so, "kmc_hip_backend_kind", backend_kind, ignore) && backend_kind() != 0;
-		const uint64_t mb = e ? strtoull(e, nullptr, 10) : (test_build ? 0 : 3072);
+		const uint64_t mb = e ? strtoull(e, nullptr, 10) : (test_build ? 0 : 4096);
 		int (*reserve)(kmc_hip_ctx *, int, int, uint64_t) = nullptr;
 		if (mb && sym(a.so, "kmc_hip_reserve_slot", reserve, ignore)) {
 			int ok = 0;

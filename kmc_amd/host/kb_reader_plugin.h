@@ -160,7 +160,11 @@ template <unsigned SIZE> class CWKmerBinReader {
 			advise_arena_once(data, (uint64)memory_bins->GetTotalSize());
 			/* a pinned buffer of the engine's, if it has any to give: the image never touches the arena (its space there stays reserved, as the protocol
 			 * wants, but no page of it is faulted in); the worker plug-in returns the buffer */
-			pinned = (uchar *)KmcHostPool::inst().get(b.size);
+			static const int pool_wait_ms = [] {
+				const char *e = getenv("KMC_HIP_POOL_WAIT_MS"); /* 0: never wait for a pool buffer (round 5: straight to the arena) */
+				return e ? atoi(e) : 2000;
+			}();
+			pinned = (uchar *)KmcHostPool::inst().get_wait(b.size, pool_wait_ms);
 			if (pinned)
 				data = pinned;
 			const long long t0 = KmcOrderedEmit::now_ns();
