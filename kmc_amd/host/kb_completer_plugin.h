@@ -16,7 +16,7 @@
  * (kb_completer.cpp:207-213: 134 M probes per run).
  * Here the thread that pops kq only does the order-dependent work — file offsets, the running LUT prefix sum
  * (kb_completer.cpp:187-199), signature -> LUT index through a bin -> signatures table built once — and hands the suffix data
- * to $KMC_HIP_WRITERS (default 4) threads that pwrite() it at its final offset and release the bin's mba_suffix slot.
+ * to $KMC_HIP_WRITERS (default 8) threads that pwrite() it at its final offset and release the bin's mba_suffix slot.
  *
  * The files are byte-identical to the reference's (format: kb_completer.cpp:119-127, :141-199, :283-324):
  *   .kmc_suf  "KMCS" | records of every bin in kq order | "KMCS"
@@ -139,7 +139,7 @@ class CWKmerBinCompleter {
 			}
 		}
 
-		int n_writers = 4;
+		int n_writers = 8; /* round 6: with 4, the writers were 0.3-0.6 s behind the last push at 30 Gbp (7 GB of suffix records; profiles/r06/e2e_sweep_30gbp_session_y.jsonl: "2nd stage" 2.96 -> 2.34 s) */
 		if (const char *e = getenv("KMC_HIP_WRITERS"))
 			n_writers = atoi(e);
 		n_writers = n_writers < 1 ? 1 : (n_writers > 32 ? 32 : n_writers);

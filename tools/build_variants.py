@@ -57,10 +57,6 @@ VARIANTS = {
     "bidx2": ["-DCP_TILE_FROM_BLOCKIDX=1", "-DRS_TILE_FROM_BLOCKIDX=1"],
     "cpmw6": ["-DCP_MIN_WAVES_1=6"],  # k_compact<1> with 80 VGPRs (no spills?) instead of 64 + 30 spilled
     "cpmw5": ["-DCP_MIN_WAVES_1=5"],
-    "bc768": ["-DBC_BLOCK_THREADS=768", "-DBC_MIN_WAVES=6"],  # k_bucket_count: 12 waves x 4 rows, 80 VGPRs (nothing spilled), two workgroups per CU
-    "bc512mw6": ["-DBC_BLOCK_THREADS=512", "-DBC_MIN_WAVES=6"],  # 8 waves x 4 rows, 80 VGPRs, three workgroups per CU
-    "bcmw4": ["-DBC_MIN_WAVES=4"],  # k_bucket_count with 128 VGPRs: one workgroup of 1024 per CU, nothing spilled
-    "bc512": ["-DBC_BLOCK_THREADS=512", "-DBC_WORDS_PER_THREAD=8", "-DBC_MIN_WAVES=4"],  # 8 waves x 8 rows, two workgroups per CU at 128 VGPRs
     "br512": ["-DBR_THREADS=512"],  # k_bucket_rank geometry: 8 waves (x 8 / 4 / 2 rows by record width)
     "br1024": ["-DBR_THREADS=1024", "-DBR_MIN_WAVES=4"],
     "brslack6": ["-DBR_SLACK_DIV=6"],  # 768 x 8 with windows of 5120 records (1024 of slack)
@@ -75,9 +71,6 @@ VARIANTS = {
     "br2": ["-DBR_STOP_AFTER=2"],  # 4 + run tails, counts, classes, ranks of the counted k-mers (garbage output): phase costs
     "br3": ["-DBR_STOP_AFTER=3"],
     "br4": ["-DBR_STOP_AFTER=4"],
-    "bc1": ["-DBC_STOP_AFTER=1"],  # k_bucket_count cut after its phase 1 / 2 / 3 (garbage output): phase costs
-    "bc2": ["-DBC_STOP_AFTER=2"],
-    "bc3": ["-DBC_STOP_AFTER=3"],
 }
 
 
