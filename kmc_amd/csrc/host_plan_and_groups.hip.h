@@ -232,7 +232,14 @@ int sort_device_t(Slot &s, const ZeroPlan &z, u64 *d_recs, u64 *d_tmp, u64 n, co
 						return rc;
 					HIPCHK(hipEventRecord(e0, s.stream));
 				}
-				k_onesweep<SIZE><<<dim3((tiles + RS_TPB - 1) / RS_TPB), dim3(RS_BLOCK), rs_lds_bytes<SIZE>(), s.stream>>>(
+				/* experiment (round 6): dynamic LDS beyond what the kernel uses = ONE scatter workgroup per CU instead of two, so that with several groups in
+				 * flight a finisher workgroup (12 waves, 72 KB) of another group fits beside it (16 waves, 59 + 24 KB) */
+				static const size_t scatter_pad = [] {
+					const char *e = getenv("KMC_HIP_SCATTER_LDS_PAD");
+					const size_t v = e ? (size_t)strtoull(e, nullptr, 10) : (size_t)0;
+					return v > 32 * 1024 ? (size_t)32 * 1024 : v;
+				}();
+				k_onesweep<SIZE><<<dim3((tiles + RS_TPB - 1) / RS_TPB), dim3(RS_BLOCK), rs_lds_bytes<SIZE>() + scatter_pad, s.stream>>>(
 				    src + start * SIZE, dst, cnt, pass_lo + pass, base_in, base_out, status, counters + counter_idx, tiles, err);
 				if (s.timed)
 					HIPCHK(hipEventRecord(e1, s.stream));

@@ -279,7 +279,10 @@ int set_dev(kmc_hip_ctx *ctx, int dev)
  * the function): k_onesweep<SIZE> for SIZE >= 6 (k > 160), the histogram-fusing k_expand at 16 passes (k = 61..64). */
 template <int SIZE> int set_func_attrs()
 {
-	if (rs_lds_bytes<SIZE>() > 65536)
+	if (rs_lds_bytes<SIZE>() + 32 * 1024 > 65536 && rs_lds_bytes<SIZE>() + 32 * 1024 <= 160 * 1024) /* + room for $KMC_HIP_SCATTER_LDS_PAD */
+		HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_onesweep<SIZE>), hipFuncAttributeMaxDynamicSharedMemorySize,
+		                           (int)rs_lds_bytes<SIZE>() + 32 * 1024));
+	else if (rs_lds_bytes<SIZE>() > 65536)
 		HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_onesweep<SIZE>), hipFuncAttributeMaxDynamicSharedMemorySize,
 		                           (int)rs_lds_bytes<SIZE>()));
 	if (br_lds_bytes<SIZE>() > 65536) {
