@@ -246,3 +246,29 @@ def test_hybrid_sort_on_the_emulated_host_library():
     lib = emu.build_hostlib("small")
     r = subprocess.run([sys.executable, "-c", _HYBRID_CASE % {"root": ROOT}], env=dict(os.environ, KMC_HIP_LIB=lib), capture_output=True, text=True, timeout=1500, cwd=ROOT)
     assert r.returncode == 0 and "HYBRID-OK" in r.stdout, (r.stdout + r.stderr)[-1500:]
+
+
+def test_dropin_host_side_switches_of_round_6_keep_the_database(tmp_path):
+    """The drop-in (kmc_amd/bin/kmc_hip, RAM-only mode) over the emulated host library under the host-side switches of round 6 — a pinned pool too small for the bins in flight
+    (readers WAIT for a buffer: host_pool.h get_wait; with no wait they spill into the arena as in round 5; no pool at all), stream-slot slabs too small for a bin's buffers
+    (kmc_hip_reserve_slot: carved while there is room, allocated on demand after), the allocator tunables by re-exec (both variants), 2 and 16 completer writers — every
+    one must write the reference's `-sr1` bytes (the reorder buffer of kmc_order.h is on every path)."""
+    if not (os.path.exists(_exe("kmc_hip")) and os.path.exists(_exe("kmc"))):
+        pytest.skip("kmc_amd/bin/kmc_hip or oracle/_ref/kmc not built (needs /root/reference)")
+    lib = emu.build_hostlib("small")
+    fq = str(tmp_path / "in.fq")
+    synth.make_fastq(fq, seed=5, genome_len=40_000, n_reads=3000, read_len=150)
+    flags = ["-k27", "-ci1", "-m2", "-sf1", "-n64", "-sp1", "-r"]
+    want = _run("kmc", flags + ["-sr1"], fq, tmp_path, "ref")
+    for tag, env in (("defaults", {}),
+                     ("pool-wait", {"KMC_HIP_PINNED_POOL_MB": "1", "KMC_HIP_POOL_WAIT_MS": "30"}),
+                     ("pool-spill", {"KMC_HIP_PINNED_POOL_MB": "1", "KMC_HIP_POOL_WAIT_MS": "0"}),
+                     ("no-pool", {"KMC_HIP_PINNED_POOL_MB": "0"}),
+                     ("slab-1MB", {"KMC_HIP_SLOT_SLAB_MB": "1"}),
+                     ("tunables-1", {"KMC_HIP_TUNE_MALLOC": "1"}),
+                     ("tunables-2", {"KMC_HIP_TUNE_MALLOC": "2", "KMC_HIP_WRITERS": "2"}),
+                     ("writers-16", {"KMC_HIP_WRITERS": "16", "KMC_HIP_READERS": "3"})):
+        got = _run("kmc_hip", flags + ["-sr4"], fq, tmp_path, tag, env=dict({"KMC_HIP_LIB": lib, "KMC_HIP_VERBOSE": "1"}, **env))
+        assert got[:2] == want[:2], tag
+        if tag == "slab-1MB":
+            assert "stream slots have a slab of 1 MB" in got[2], got[2][-600:]
