@@ -1024,12 +1024,12 @@ def main():
         rpl = sc_recs / max(n_launch, 1)
         achieved = (2 * SW * sc_recs) / (sc_ms * 1e-3) / 1e9 if n_launch else 0.0
         value = w.total_kmers_all * args.steps / dt / 1e9
-        # which sort ran: LSD passes over every key byte (P of them), or — hybrid — over the top bytes only + k_bucket_count in LDS. The sampled groups carry
+        # which sort ran: LSD passes over every key byte (P of them), or — hybrid — over the top bytes only + the LDS finisher. The sampled groups carry
         # both kinds of event pairs, so passes per record = scatter records / LDS-sorted records.
         hyb = ls["launches"] > 0 and ls["records"] > 0
         hbm_passes = (sc_recs / ls["records"]) if hyb else float(P)
         # which LDS finisher ran (library's own counters): k_bucket_rank fused (tiles ranked and counted in LDS: one read), k_bucket_rank in place + k_compact
-        # (one more read + write), or k_bucket_count (one read)
+        # (one more read + write)
         rank_fused = hyb and pc["rank_count"] > 0 and pc["rank_compact"] == 0 and pc["bucket_count"] == 0
         by_rank = hyb and not rank_fused and pc["rank_compact"] > 0
         moved = W * (1 + 2 * hbm_passes + (2 if by_rank else 0) + 1) + 1.2  # expand write + passes (read + write) [+ rank in place] + one read by the finisher / k_compact + the bin image
@@ -1059,7 +1059,7 @@ def main():
                                    if rank_fused else
                                    "hybrid: 8-bit LSD passes through HBM over the top key bytes only, then every bucket-aligned tile put in order inside LDS (k_bucket_rank: a record's "
                                    "place = the records of its bucket below it, counted pairwise), then k_compact" if by_rank else
-                                   "hybrid: 8-bit LSD passes through HBM over the top key bytes only, the rest counted inside LDS on bucket-aligned tiles (k_bucket_count)" if hyb
+                                   "hybrid: 8-bit LSD passes through HBM over the top key bytes only, the rest inside LDS on bucket-aligned tiles" if hyb
                                    else "8-bit LSD passes through HBM over every key byte, then k_compact"),
                           "groups_by_path": pc, "hbm_passes_per_record": hbm_passes, "hbm_bytes_per_kmer_moved_by_design": moved, "moved_GBs": moved * value, "moved_frac_of_hbm_peak": moved * value / HBM_PEAK_GBS,
                           "hbm_bytes_per_kmer_moved_pmc": moved_pmc, "moved_frac_of_hbm_peak_pmc": (moved_pmc * value / HBM_PEAK_GBS) if moved_pmc else None,
@@ -1079,7 +1079,7 @@ def main():
                                  "top radix digit), so a launch covers that many bins; every 8th group of a stream carries the event pairs (an event costs "
                                  "stream time); big bins run on one stream, so launches do not overlap and the event durations are the kernel's own"},
             "local_sort": {"kernel": ("k_bucket_bounds + k_bucket_rank<%d, fused>" % ((k + 31) // 32) if rank_fused else "k_bucket_bounds + k_bucket_rank<1, in place>" if by_rank
-                                      else "k_bucket_bounds + k_bucket_count<%d>" % ((k + 31) // 32)) +
+                                      else "k_bucket_bounds + LDS finisher<%d>" % ((k + 31) // 32)) +
                                      " (the key bytes below the HBM passes, resolved inside LDS on bucket-aligned tiles)",
                            "launches_timed": ls["launches"], "avg_launch_ms": ls["ms"] / max(ls["launches"], 1), "records_per_launch": ls["records"] / max(ls["launches"], 1),
                            "GBs_read_plus_written": (2 * W * ls["records"]) / (ls["ms"] * 1e-3) / 1e9 if ls["launches"] else 0.0,
