@@ -12,7 +12,6 @@
  *   KMC_HIP_VERBOSE  "1": print where the worker spent its time when the last engine is destroyed
  *   KMC_HIP_PINNED_POOL_MB  pinned slab for the bin images (host_pool.h; default 2048, 0 = none); KMC_HIP_POOL_WAIT_MS: how long a reader waits for a buffer of it (default 2000)
  *   KMC_HIP_SLOT_SLAB_MB  device memory reserved per stream slot while stage 1 runs (default 4096, 0 = none): kmc_hip_reserve_slot
- *   KMC_HIP_DEFER_FREE_MB  blocks of this many MB and more that are freed with delete[] are handed to a background thread (default 1, 0 = off): see operator delete[] below
  *   KMC_HIP_POOL_REGISTER  "1" (opt-in, round 6): the slab is ordinary memory on huge pages, registered with the runtime, instead of hipHostMalloc'ed
  *   KMC_HIP_TUNE_MALLOC  "1" (opt-in, round 6): re-execute the program once with the allocator tunables below (tune_allocator()); "2": the same without the huge-page heap
  * There is deliberately NO CPU fallback here: if the library or a GPU is missing the engine reports the error and
@@ -248,7 +247,6 @@ void load_api_impl()
 }
 
 void start_main_sampler(); /* below: KMC_HIP_SAMPLE_MAIN diagnostics */
-void deferred_free_report(); /* below: operator delete[] */
 
 struct HipEngine : KmcBinEngine {
 	int dev, slot;
@@ -264,8 +262,6 @@ struct HipEngine : KmcBinEngine {
 			fprintf(stderr, "[kmc_hip] init %.3f s; %lld bins (%lld calls with several bins), %.3f s inside the engine (sum over workers), %.1f MB in, %.1f MB out, %lld k-mers\n",
 			        g_ns_init.load() * 1e-9, g_n_bins.load(), g_n_group_calls.load(), g_ns_bins.load() * 1e-9, g_bytes_in.load() / 1e6, g_bytes_out.load() / 1e6,
 			        g_kmers.load());
-		if (getenv("KMC_HIP_VERBOSE") && g_engines == 0)
-			deferred_free_report();
 		int (*hb_times)(double *) = nullptr;
 		std::string ignore;
 		double t[8];
@@ -499,90 +495,3 @@ bool kmc_hip_loader_handles(void *&so, kmc_hip_ctx *&ctx, int &n_dev, int &n_slo
 		err = g_api.err.empty() ? "HIP engine not initialised" : g_api.err;
 	return g_api.ctx != nullptr;
 }
-
-/* ---- large blocks freed with delete[] go back to the allocator on a thread of their own (round 6) -----------------------------------------------------------------------
- * In RAM-only mode the reference keeps every bin as `new uchar[]` parts of tens of MB (mem_disk_file.cpp:111-126: mmap'ed chunks) and its stage-2 reader deletes each part
- * right after copying it (mem_disk_file.cpp:84-100): an munmap of ~12 000 pages under the process's mmap lock, INSIDE the reader's critical path, from every reader thread
- * — 60-70 % of the reader's wall time (session n: 0.66 -> 0.20 s at 8 Gbp once large blocks stopped being unmapped), and the reader is what bounds the drop-in's "2nd
- * stage" (DESIGN.md 8). The replaceable global `operator delete[]` of this executable (it is linked with -rdynamic, so every shared object resolves to it too; `new[]` stays
- * the library's: malloc) hands blocks of $KMC_HIP_DEFER_FREE_MB (default 1) MB and more to ONE background thread that calls free() on them: the same munmaps, one at a
- * time, off everybody's critical path; nothing changes for small blocks, for the allocator's mode or for what memory the process holds at any time except that a block
- * lives until the thread gets to it. Blocks still queued when the process exits go with the process. 0 = off. */
-#ifdef __GLIBC__
-#include <malloc.h>
-#include <condition_variable>
-#include <deque>
-#include <new>
-namespace {
-struct DeferredFree {
-	std::mutex m;
-	std::condition_variable cv;
-	std::deque<void *> q;
-	std::atomic<long long> n{0}, bytes{0}, done{0};
-	DeferredFree()
-	{
-		std::thread([this] {
-			for (;;) {
-				void *p;
-				{
-					std::unique_lock<std::mutex> l(m);
-					cv.wait(l, [this] { return !q.empty(); });
-					p = q.front();
-					q.pop_front();
-				}
-				free(p);
-				++done;
-			}
-		}).detach();
-	}
-	void push(void *p, size_t sz)
-	{
-		{
-			std::lock_guard<std::mutex> l(m);
-			q.push_back(p);
-		}
-		++n;
-		bytes += (long long)sz;
-		cv.notify_one();
-	}
-};
-std::atomic<DeferredFree *> g_deferred{nullptr};
-DeferredFree *deferred()
-{
-	static DeferredFree *d = new DeferredFree; /* never destroyed: blocks may be deleted during static destruction */
-	g_deferred.store(d);
-	return d;
-}
-/* (zero until this translation unit's dynamic initialisers have run: deletes before that are plain frees) */
-const size_t g_defer_min = [] {
-	if (const char *kb = getenv("KMC_HIP_DEFER_FREE_KB")) /* tests: the path with blocks of a few KB */
-		return (size_t)strtoull(kb, nullptr, 10) << 10;
-	const char *e = getenv("KMC_HIP_DEFER_FREE_MB");
-	return (size_t)(e ? strtoull(e, nullptr, 10) : 1) << 20;
-}();
-void deferred_free_report()
-{
-	if (DeferredFree *d = g_deferred.load())
-		fprintf(stderr, "[kmc_hip] delete[] of large blocks: %lld blocks, %.2f GB handed to the background thread, %lld freed so far\n", d->n.load(), d->bytes.load() / 1e9,
-		        d->done.load());
-}
-} // namespace
-void operator delete[](void *p) noexcept
-{
-	if (!p)
-		return;
-	if (g_defer_min) {
-		const size_t sz = malloc_usable_size(p);
-		if (sz >= g_defer_min) {
-			deferred()->push(p, sz);
-			return;
-		}
-	}
-	free(p);
-}
-void operator delete[](void *p, std::size_t) noexcept { operator delete[](p); }
-#else
-namespace {
-void deferred_free_report() {}
-} // namespace
-#endif

@@ -268,13 +268,8 @@ def test_dropin_host_side_switches_of_round_6_keep_the_database(tmp_path):
                      ("slab-1MB", {"KMC_HIP_SLOT_SLAB_MB": "1"}),
                      ("tunables-1", {"KMC_HIP_TUNE_MALLOC": "1"}),
                      ("tunables-2", {"KMC_HIP_TUNE_MALLOC": "2", "KMC_HIP_WRITERS": "2"}),
-                     ("writers-16", {"KMC_HIP_WRITERS": "16", "KMC_HIP_READERS": "3"}),
-                     ("deferred-delete", {"KMC_HIP_DEFER_FREE_KB": "4"}),       # blocks of 4 KB and more freed with delete[] (the bin parts of RAM-only mode) go to the background thread
-                     ("no-deferred-delete", {"KMC_HIP_DEFER_FREE_MB": "0"})):
+                     ("writers-16", {"KMC_HIP_WRITERS": "16", "KMC_HIP_READERS": "3"})):
         got = _run("kmc_hip", flags + ["-sr4"], fq, tmp_path, tag, env=dict({"KMC_HIP_LIB": lib, "KMC_HIP_VERBOSE": "1"}, **env))
         assert got[:2] == want[:2], tag
         if tag == "slab-1MB":
             assert "stream slots have a slab of 1 MB" in got[2], got[2][-600:]
-        if tag == "deferred-delete":
-            m = re.search(r"delete\[\] of large blocks: (\d+) blocks", got[2])
-            assert m and int(m.group(1)) >= 1, got[2][-800:]
