@@ -22,6 +22,7 @@
 #include <stdint.h>
 #include <string.h>
 
+#include <cstdio>
 #include <cstdlib>
 #include <thread>
 #include <type_traits>
@@ -137,6 +138,13 @@ template <class F> void launch(dim3 grid, dim3 block, size_t dyn_bytes, F body)
 	for (auto &x : th)
 		x.join();
 	g_launch = nullptr;
+	/* the 256 bytes behind what the launch asked for are a guard (on the GPU a store past the dynamic LDS is dropped and a load returns 0 — silently): a kernel
+	 * that wrote there laid out more LDS than its launch requests */
+	for (size_t i = 0; i < 256; ++i)
+		if (static_cast<unsigned char *>(dyn)[dyn_bytes + i] != 0xA5) {
+			fprintf(stderr, "hipemu: a kernel stored %zu bytes past its %zu bytes of dynamic LDS\n", i + 1, dyn_bytes);
+			abort();
+		}
 	free(dyn);
 }
 } // namespace hipemu
